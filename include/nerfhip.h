@@ -1,0 +1,243 @@
+/* nerfhip.h -- C ABI of libnerfhip.so: the MI355X (gfx950) NeRF render + training hot path.
+ *
+ * This is the drop-in boundary underneath the Python API of krrish94/nerf-pytorch.  The reference has no
+ * FFI of its own for this path (it is pure PyTorch); every entry point below names the reference
+ * function it replaces (file:line relative to the reference tree).  The binding a maintainer adds on the
+ * reference side is a ctypes stub -- see INTEGRATION.md.
+ *
+ * Conventions (all entry points):
+ *   - plain C types only; every pointer marked "dev" is a device pointer (hipMalloc'ed / a torch CUDA
+ *     tensor's data_ptr()), fp32 row-major contiguous unless a stride argument says otherwise;
+ *   - returns 0 on success, a negative NERFHIP_ERR_* code otherwise; nerfhip_last_error() then returns a
+ *     thread-local message.  Nothing throws across the ABI;
+ *   - the library never allocates or frees caller-visible memory, never creates streams, never
+ *     synchronises the device: work is enqueued on the `stream` argument (a hipStream_t passed as void*;
+ *     NULL = the legacy default stream) and the caller owns all buffers for the duration of that work;
+ *   - `plan` handles are host-only objects (weight packing tables, kernel schedules).
+ *
+ * Random draws: wherever the reference calls torch.rand / torch.randn the caller may pass the draws in
+ * (parity mode: identical results for identical draws) or pass NULL and a (seed, ray_offset) pair, in
+ * which case a counter-based Philox4x32-10 generator is evaluated in-kernel (production mode).  Stream
+ * ids: 0 = stratified t_rand, 1 = coarse sigma noise, 2 = inverse-CDF u, 3 = fine sigma noise.
+ * nerfhip_rng_fill() writes exactly the numbers the kernels would draw.
+ */
+#ifndef NERFHIP_H_
+#define NERFHIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* nerfhip_stream_t;
+
+#define NERFHIP_OK 0
+#define NERFHIP_ERR_ARG (-1)
+#define NERFHIP_ERR_UNSUPPORTED (-2)
+#define NERFHIP_ERR_LAUNCH (-3)
+#define NERFHIP_ERR_WORKSPACE (-4)
+
+#define NERFHIP_RNG_UNIFORM 0
+#define NERFHIP_RNG_NORMAL 1
+
+/* ---- library --------------------------------------------------------------------------------------------------- */
+int nerfhip_version(void);
+const char* nerfhip_last_error(void);
+/* 0 for the product library.  (The CPU wave-emulator build used by the test-suite returns 1.) */
+int nerfhip_is_emulated(void);
+
+/* Writes n draws of the in-kernel generator: element e of `stream_id` under `seed`, e = first .. first+n-1. */
+int nerfhip_rng_fill(int kind, uint64_t seed, uint32_t stream_id, uint64_t first, int64_t n, float* out_dev,
+                     nerfhip_stream_t stream);
+
+/* ---- K1: rays -------------------------------------------------------------------------------------------------- */
+/* get_ray_bundle (nerf/nerf_helpers.py:67-110) incl. meshgrid_xy (:28-40).  c2w: dev, rows >= 3, row stride
+ * c2w_ld floats (columns 0..2 rotation, column 3 translation).  pixels: dev int64 linear ids (row*width+col) of
+ * the n rays wanted, or NULL for the whole image (then n must be height*width; output is (H,W,3) row-major).
+ * ray_origins / ray_directions: dev [n,3].  Directions are NOT normalised (reference behaviour). */
+int nerfhip_ray_bundle(int height, int width, float focal, const float* c2w, int c2w_ld, const int64_t* pixels,
+                       int64_t n, float* ray_origins, float* ray_directions, nerfhip_stream_t stream);
+
+/* ndc_rays (nerf/nerf_helpers.py:170-197).  cw = -1/(W/(2*focal)), ch = -1/(H/(2*focal)), two_near = 2*near,
+ * neg_two_near = -2*near are evaluated by the caller exactly as the reference's Python scalar arithmetic does. */
+int nerfhip_ndc_rays(float near, float cw, float ch, float two_near, float neg_two_near, const float* rays_o,
+                     const float* rays_d, int64_t n, float* out_o, float* out_d, nerfhip_stream_t stream);
+
+/* viewdirs + ray packing of run_one_iter_of_nerf (nerf/train_utils.py:143-168):
+ * rays[n, 8|11] = [o(3) d(3) near far (d/||d||)(3)].  viewdir_src (dev [n,3]) is the PRE-ndc direction the
+ * reference normalises; pass NULL for use_viewdirs = false (row width 8). */
+int nerfhip_pack_rays(const float* rays_o, const float* rays_d, const float* viewdir_src, float near, float far,
+                      int64_t n, float* rays_out, nerfhip_stream_t stream);
+
+/* ---- K3: positional encoding ----------------------------------------------------------------------------------- */
+/* positional_encoding (nerf/nerf_helpers.py:113-157).  x: dev [m,d]; freqs: dev [num_freqs] frequency bands as the
+ * reference builds them; out: dev [m, d*(include_input + 2*num_freqs)] laid out
+ * [x | sin(f0 x) | cos(f0 x) | sin(f1 x) | ...]. */
+int nerfhip_positional_encoding(const float* x, int64_t m, int d, const float* freqs, int num_freqs, int include_input,
+                                float* out, nerfhip_stream_t stream);
+
+/* ---- K2: stratified depth samples ------------------------------------------------------------------------------ */
+/* predict_and_render_radiance lines nerf/train_utils.py:38-65.  rays: dev rows of ray_stride floats with near/far in
+ * columns 6/7; t_vals: dev [nc] = torch.linspace(0,1,nc); t_rand: dev [n,nc] uniform draws or NULL (in-kernel
+ * stream 0).  z_out: dev [n,nc]. */
+int nerfhip_stratified_z(const float* rays, int ray_stride, int64_t n, const float* t_vals, int nc, int lindisp,
+                         int perturb, const float* t_rand, uint64_t seed, uint64_t ray_offset, float* z_out,
+                         nerfhip_stream_t stream);
+
+/* ---- K5: sigma/alpha compositing ------------------------------------------------------------------------------- */
+/* cumprod_exclusive (nerf/nerf_helpers.py:43-64) over the last dimension of x[rows, cols]. */
+int nerfhip_cumprod_exclusive(const float* x, int64_t rows, int cols, float* out, nerfhip_stream_t stream);
+
+/* volume_render_radiance_field (nerf/volume_rendering_utils.py:6-53).  raw: dev [n,s,4]; z: dev [n,s];
+ * rd: dev rows of rd_stride floats whose first 3 entries are the ray direction; noise: dev [n,s] N(0,1) draws or
+ * NULL (in-kernel stream `rng_stream` when noise_std > 0).  Outputs (any may be NULL): rgb [n,3], disp [n],
+ * acc [n], weights [n,s], depth [n]. */
+int nerfhip_volume_render_fwd(const float* raw, const float* z, const float* rd, int rd_stride, int64_t n, int s,
+                              float noise_std, const float* noise, uint64_t seed, uint32_t rng_stream,
+                              uint64_t ray_offset, int white_background, float* rgb, float* disp, float* acc,
+                              float* weights, float* depth, nerfhip_stream_t stream);
+
+/* Closed-form backward of the above (what autograd computes for nerf/volume_rendering_utils.py:26-50).
+ * g_rgb [n,3], g_depth [n], g_acc [n], g_weights [n,s] are the output cotangents (each may be NULL = 0; the
+ * disparity cotangent is folded into g_depth/g_acc by the caller).  g_raw: dev [n,s,4]. */
+int nerfhip_volume_render_bwd(const float* raw, const float* z, const float* rd, int rd_stride, int64_t n, int s,
+                              float noise_std, const float* noise, uint64_t seed, uint32_t rng_stream,
+                              uint64_t ray_offset, int white_background, const float* g_rgb, const float* g_depth,
+                              const float* g_acc, const float* g_weights, float* g_raw, nerfhip_stream_t stream);
+
+/* ---- K6: inverse-CDF importance sampling ----------------------------------------------------------------------- */
+/* sample_pdf_2 (nerf/nerf_helpers.py:260-302) including the torchsearchsorted call (:288, side="right").
+ * bins: dev [n,nbins]; weights: dev [n,nbins-1]; u: dev [n,nf] uniform draws, or NULL with det=1 (then u_det: dev
+ * [nf] = torch.linspace(0,1,nf)) or NULL with det=0 (in-kernel stream 2).  samples: dev [n,nf];
+ * inds (optional): dev int64 [n,nf] searchsorted result; cdf (optional): dev [n,nbins]. */
+int nerfhip_sample_pdf(const float* bins, const float* weights, int64_t n, int nbins, const float* u, int det,
+                       const float* u_det, int nf, uint64_t seed, uint64_t ray_offset, float* samples, int64_t* inds,
+                       float* cdf, nerfhip_stream_t stream);
+
+/* The hierarchical step of predict_and_render_radiance (nerf/train_utils.py:96-105): z_vals_mid, sample_pdf_2 on
+ * weights[...,1:-1], detach, sort(cat(z_coarse, z_samples)).  z_coarse, weights: dev [n,nc]; z_samples (optional):
+ * dev [n,nf]; z_fine: dev [n,nc+nf] ascending. */
+int nerfhip_hierarchical_z(const float* z_coarse, const float* weights, int64_t n, int nc, const float* u, int det,
+                           const float* u_det, int nf, uint64_t seed, uint64_t ray_offset, float* z_samples,
+                           float* z_fine, nerfhip_stream_t stream);
+
+/* ---- K4/K8: the MLP (models.FlexibleNeRFModel, nerf/models.py:185-256) ----------------------------------------- */
+typedef struct nerfhip_model_cfg {
+    int num_layers;         /* models.py:188 */
+    int hidden_size;        /* models.py:189; 128 or 256 */
+    int skip_connect_every; /* models.py:190; cat(h, xyz) before layers_xyz[i] iff i % skip == 0 and i > 0 */
+    int num_encoding_fn_xyz;
+    int num_encoding_fn_dir;
+    int include_input_xyz;
+    int include_input_dir;
+    int log_sampling_xyz;
+    int log_sampling_dir;
+    int use_viewdirs;
+} nerfhip_model_cfg;
+
+typedef struct nerfhip_plan* nerfhip_plan_t;
+
+/* Host-only.  Returns NULL (and sets the error string) for an unsupported geometry. */
+nerfhip_plan_t nerfhip_plan_create(const nerfhip_model_cfg* cfg);
+void nerfhip_plan_destroy(nerfhip_plan_t plan);
+/* Number of fp32 parameters of the model = length of the flat parameter/gradient vector, laid out as the
+ * concatenation of the reference state_dict tensors in registration order (layer1.weight, layer1.bias,
+ * layers_xyz.{i}.weight/.bias, layers_dir.0.weight/.bias, fc_alpha.*, fc_rgb.*, fc_feat.* | fc_out.*). */
+int64_t nerfhip_plan_num_params(nerfhip_plan_t plan);
+int nerfhip_plan_dim_xyz(nerfhip_plan_t plan);
+int nerfhip_plan_dim_dir(nerfhip_plan_t plan);
+/* Number of tensors and, for tensor i, its name, offset into the flat vector and 2-D shape (cols = 0 for a bias). */
+int nerfhip_plan_num_tensors(nerfhip_plan_t plan);
+int nerfhip_plan_tensor_info(nerfhip_plan_t plan, int i, const char** name, int64_t* offset, int* rows, int* cols);
+/* MFMA-packed weight image: number of floats, and the gather table (host int32[packed_floats]: source index into
+ * the flat parameter vector, or -1 for zero padding). */
+int64_t nerfhip_plan_packed_floats(nerfhip_plan_t plan);
+int nerfhip_plan_pack_index(nerfhip_plan_t plan, int32_t* host_table);
+/* packed[i] = table[i] >= 0 ? params[table[i]] : 0   (run once per optimiser step). */
+int nerfhip_pack_weights(const float* params, const int32_t* table, int64_t n, float* packed, nerfhip_stream_t stream);
+/* Bytes of activation stash a training forward over m sample points needs (0-filled is not required). */
+int64_t nerfhip_plan_stash_bytes(nerfhip_plan_t plan, int64_t m);
+/* Bytes of scratch nerfhip_mlp_bwd needs for m sample points. */
+int64_t nerfhip_plan_bwd_scratch_bytes(nerfhip_plan_t plan, int64_t m);
+/* Frequency bands (host float[16] each) exactly as the reference builds them are supplied by the caller. */
+int nerfhip_plan_set_freqs(nerfhip_plan_t plan, const float* freqs_xyz, const float* freqs_dir);
+
+/* FlexibleNeRFModel.forward (nerf/models.py:233-256) on already-encoded rows x: dev [m, dim_xyz+dim_dir] ->
+ * out: dev [m,4] = cat(rgb_raw, sigma_raw).  stash: NULL (inference) or dev buffer of
+ * nerfhip_plan_stash_bytes(plan, m) for a later nerfhip_mlp_bwd. */
+int nerfhip_mlp_fwd(nerfhip_plan_t plan, const float* packed, const float* x, int64_t m, float* out, void* stash,
+                    nerfhip_stream_t stream);
+/* Backward w.r.t. all parameters (what autograd computes for models.py:233-256): g_out: dev [m,4]; g_params: dev
+ * flat gradient vector (overwritten); scratch: dev, nerfhip_plan_bwd_scratch_bytes. */
+int nerfhip_mlp_bwd(nerfhip_plan_t plan, const float* packed, const float* g_out, int64_t m, const void* stash,
+                    void* scratch, int64_t scratch_bytes, float* g_params, nerfhip_stream_t stream);
+
+/* ---- fused render (predict_and_render_radiance, nerf/train_utils.py:28-127, + run_network :8-25) --------------- */
+typedef struct nerfhip_render_cfg {
+    int num_coarse;
+    int num_fine; /* 0 = coarse only */
+    int perturb;
+    int lindisp;
+    int white_background;
+    float noise_std; /* radiance_field_noise_std */
+    int ray_stride;  /* 8 or 11 floats per ray row */
+} nerfhip_render_cfg;
+
+/* Caller-supplied random draws (each may be NULL -> in-kernel generator). */
+typedef struct nerfhip_render_rand {
+    const float* t_rand;       /* [n, num_coarse]            stream 0 */
+    const float* noise_coarse; /* [n, num_coarse]            stream 1 */
+    const float* u;            /* [n, num_fine]              stream 2 */
+    const float* noise_fine;   /* [n, num_coarse + num_fine] stream 3 */
+} nerfhip_render_rand;
+
+/* Outputs; any pointer may be NULL.  *_fine are ignored when num_fine == 0. */
+typedef struct nerfhip_render_out {
+    float* rgb_coarse;   /* [n,3] */
+    float* disp_coarse;  /* [n]   */
+    float* acc_coarse;   /* [n]   */
+    float* depth_coarse; /* [n]   (not returned by the reference) */
+    float* rgb_fine;
+    float* disp_fine;
+    float* acc_fine;
+    float* depth_fine;
+} nerfhip_render_out;
+
+int64_t nerfhip_render_workspace_bytes(nerfhip_plan_t plan_coarse, nerfhip_plan_t plan_fine,
+                                       const nerfhip_render_cfg* cfg, int64_t n_rays, int training);
+
+/* rays: dev [n, ray_stride]; t_vals: dev [num_coarse] linspace(0,1); u_det: dev [num_fine] linspace(0,1) (used
+ * when perturb == 0); workspace: dev, nerfhip_render_workspace_bytes (keeps everything render_bwd needs when
+ * training != 0). */
+int nerfhip_render_fwd(nerfhip_plan_t plan_coarse, nerfhip_plan_t plan_fine, const nerfhip_render_cfg* cfg,
+                       const float* rays, int64_t n_rays, const float* packed_coarse, const float* packed_fine,
+                       const float* t_vals, const float* u_det, const nerfhip_render_rand* rnd, uint64_t seed,
+                       uint64_t ray_offset, const nerfhip_render_out* out, void* workspace, int64_t workspace_bytes,
+                       int training, nerfhip_stream_t stream);
+
+/* Backward of the fused render w.r.t. both nets' parameters.  g_rgb_coarse / g_rgb_fine: dev [n,3] cotangents of
+ * the two colour maps (the only outputs the reference's loss touches, train_nerf.py:244-258).  g_params_*: dev
+ * flat gradient vectors (overwritten).  The workspace must be the one a training nerfhip_render_fwd filled, with
+ * the same rays / packed weights / random arguments. */
+int nerfhip_render_bwd(nerfhip_plan_t plan_coarse, nerfhip_plan_t plan_fine, const nerfhip_render_cfg* cfg,
+                       const float* rays, int64_t n_rays, const float* packed_coarse, const float* packed_fine,
+                       const nerfhip_render_rand* rnd, uint64_t seed, uint64_t ray_offset, const float* g_rgb_coarse,
+                       const float* g_rgb_fine, void* workspace, int64_t workspace_bytes, float* g_params_coarse,
+                       float* g_params_fine, nerfhip_stream_t stream);
+
+/* ---- loss + optimiser (train_nerf.py:244-270) ------------------------------------------------------------------ */
+/* mse_loss(rgb_coarse, target) + mse_loss(rgb_fine, target) and its cotangents; loss_out: dev float[3] =
+ * {coarse_mse, fine_mse, sum}.  target rows have target_stride floats (RGB or RGBA; only [:3] is used). */
+int nerfhip_mse_loss_fwd_bwd(const float* rgb_coarse, const float* rgb_fine, const float* target, int target_stride,
+                             int64_t n, float grad_scale, float* g_rgb_coarse, float* g_rgb_fine, float* loss_out,
+                             nerfhip_stream_t stream);
+/* torch.optim.Adam single-tensor step (no amsgrad, no weight decay) on a flat vector; step counts from 1. */
+int nerfhip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                      float beta1, float beta2, float eps, int64_t step, float grad_scale, nerfhip_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERFHIP_H_ */

@@ -1,0 +1,340 @@
+// elementwise.hip -- the HBM-bound, per-ray / per-sample pieces of the path: ray generation, NDC, ray packing,
+// positional encoding (stand-alone form), stratified depths, exclusive cumprod, RNG fill, weight gather,
+// MSE loss and Adam.  All arithmetic is fp32 with the reference's operation order (-ffp-contract=off).
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "nh_host.h"
+
+// ---- error string ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void nh_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* nerfhip_last_error(void) { return g_err; }
+extern "C" int nerfhip_version(void) { return 100; }
+extern "C" int nerfhip_is_emulated(void) {
+#ifdef NERFHIP_EMU
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+// ---- K1 get_ray_bundle (nerf/nerf_helpers.py:67-110) ----------------------------------------------------------------
+NH_KERNEL void k_ray_bundle(int height, int width, float focal, const float* __restrict__ c2w, int ld,
+                            const int64_t* __restrict__ pixels, int64_t n, float* __restrict__ ro,
+                            float* __restrict__ rd) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    int64_t p = pixels ? pixels[idx] : idx;
+    float ii = (float)(p % width);  // column (x)
+    float jj = (float)(p / width);  // row (y)
+    float dx = (ii - (float)(width * 0.5)) / focal;
+    float dy = -(jj - (float)(height * 0.5)) / focal;
+    float dz = -1.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = dx * c2w[c * ld + 0];
+        v = v + dy * c2w[c * ld + 1];
+        v = v + dz * c2w[c * ld + 2];
+        rd[idx * 3 + c] = v;
+        ro[idx * 3 + c] = c2w[c * ld + 3];
+    }
+}
+
+extern "C" int nerfhip_ray_bundle(int height, int width, float focal, const float* c2w, int c2w_ld,
+                                  const int64_t* pixels, int64_t n, float* ray_origins, float* ray_directions,
+                                  nerfhip_stream_t stream) {
+    NH_REQUIRE(height > 0 && width > 0 && c2w && ray_origins && ray_directions && c2w_ld >= 4,
+               "ray_bundle: bad arguments");
+    NH_REQUIRE(pixels || n == (int64_t)height * width, "ray_bundle: n must be height*width when pixels is NULL");
+    if (n == 0) return NERFHIP_OK;
+    NH_LAUNCH(k_ray_bundle, nh_ceil_div(n, 256), 256, 0, stream, height, width, focal, c2w, c2w_ld, pixels, n,
+              ray_origins, ray_directions);
+    return nh_launch_status("ray_bundle");
+}
+
+// ---- ndc_rays (nerf/nerf_helpers.py:170-197) -------------------------------------------------------------------------
+NH_KERNEL void k_ndc_rays(float near, float cw, float ch, float two_near, float neg_two_near,
+                          const float* __restrict__ ro, const float* __restrict__ rd, int64_t n, float* __restrict__ oo,
+                          float* __restrict__ od) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float ox = ro[i * 3], oy = ro[i * 3 + 1], oz = ro[i * 3 + 2];
+    float dx = rd[i * 3], dy = rd[i * 3 + 1], dz = rd[i * 3 + 2];
+    float t = -(near + oz) / dz;
+    ox = ox + t * dx;
+    oy = oy + t * dy;
+    oz = oz + t * dz;
+    float o0 = cw * ox / oz;
+    float o1 = ch * oy / oz;
+    float o2 = 1.0f + two_near / oz;
+    float d0 = cw * (dx / dz - ox / oz);
+    float d1 = ch * (dy / dz - oy / oz);
+    float d2 = neg_two_near / oz;
+    oo[i * 3] = o0;
+    oo[i * 3 + 1] = o1;
+    oo[i * 3 + 2] = o2;
+    od[i * 3] = d0;
+    od[i * 3 + 1] = d1;
+    od[i * 3 + 2] = d2;
+}
+
+extern "C" int nerfhip_ndc_rays(float near, float cw, float ch, float two_near, float neg_two_near,
+                                const float* rays_o, const float* rays_d, int64_t n, float* out_o, float* out_d,
+                                nerfhip_stream_t stream) {
+    NH_REQUIRE(rays_o && rays_d && out_o && out_d && n >= 0, "ndc_rays: bad arguments");
+    if (n == 0) return NERFHIP_OK;
+    NH_LAUNCH(k_ndc_rays, nh_ceil_div(n, 256), 256, 0, stream, near, cw, ch, two_near, neg_two_near, rays_o, rays_d, n,
+              out_o, out_d);
+    return nh_launch_status("ndc_rays");
+}
+
+// ---- viewdirs + ray packing (nerf/train_utils.py:143-168) ------------------------------------------------------------
+NH_KERNEL void k_pack_rays(const float* __restrict__ ro, const float* __restrict__ rd, const float* __restrict__ vsrc,
+                           float near, float far, int64_t n, float* __restrict__ rays) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int stride = vsrc ? 11 : 8;
+    float* r = rays + i * stride;
+    r[0] = ro[i * 3];
+    r[1] = ro[i * 3 + 1];
+    r[2] = ro[i * 3 + 2];
+    r[3] = rd[i * 3];
+    r[4] = rd[i * 3 + 1];
+    r[5] = rd[i * 3 + 2];
+    r[6] = near;
+    r[7] = far;
+    if (vsrc) {
+        float x = vsrc[i * 3], y = vsrc[i * 3 + 1], z = vsrc[i * 3 + 2];
+        float nrm = sqrtf((x * x + y * y) + z * z);
+        r[8] = x / nrm;
+        r[9] = y / nrm;
+        r[10] = z / nrm;
+    }
+}
+
+extern "C" int nerfhip_pack_rays(const float* rays_o, const float* rays_d, const float* viewdir_src, float near,
+                                 float far, int64_t n, float* rays_out, nerfhip_stream_t stream) {
+    NH_REQUIRE(rays_o && rays_d && rays_out && n >= 0, "pack_rays: bad arguments");
+    if (n == 0) return NERFHIP_OK;
+    NH_LAUNCH(k_pack_rays, nh_ceil_div(n, 256), 256, 0, stream, rays_o, rays_d, viewdir_src, near, far, n, rays_out);
+    return nh_launch_status("pack_rays");
+}
+
+// ---- K3 positional_encoding (nerf/nerf_helpers.py:113-157) -----------------------------------------------------------
+NH_KERNEL void k_posenc(const float* __restrict__ x, int64_t m, int d, const float* __restrict__ freqs, int nf,
+                        int include_input, float* __restrict__ out) {
+    int dout = d * (include_input + 2 * nf);
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= m * dout) return;
+    int64_t row = idx / dout;
+    int e = (int)(idx % dout);
+    int blk = e / d, c = e % d;
+    float v = x[row * d + c];
+    float r;
+    if (include_input && blk == 0) {
+        r = v;
+    } else {
+        int b = blk - include_input;
+        float arg = v * freqs[b >> 1];
+        r = (b & 1) ? cosf(arg) : sinf(arg);
+    }
+    out[idx] = r;
+}
+
+extern "C" int nerfhip_positional_encoding(const float* x, int64_t m, int d, const float* freqs, int num_freqs,
+                                           int include_input, float* out, nerfhip_stream_t stream) {
+    NH_REQUIRE(x && out && m >= 0 && d > 0 && num_freqs >= 0 && (num_freqs == 0 || freqs),
+               "positional_encoding: bad arguments");
+    include_input = include_input ? 1 : 0;
+    int64_t total = m * d * (include_input + 2 * num_freqs);
+    if (total == 0) return NERFHIP_OK;
+    NH_LAUNCH(k_posenc, nh_ceil_div(total, 256), 256, 0, stream, x, m, d, freqs, num_freqs, include_input, out);
+    return nh_launch_status("positional_encoding");
+}
+
+// ---- K2 stratified depths (nerf/train_utils.py:38-65) ----------------------------------------------------------------
+NH_DEVICE float nh_depth_at(float near, float far, float t, int lindisp) {
+    if (!lindisp) return near * (1.0f - t) + far * t;
+    return 1.0f / (1.0f / near * (1.0f - t) + 1.0f / far * t);
+}
+
+NH_KERNEL void k_stratified_z(const float* __restrict__ rays, int stride, int64_t n, const float* __restrict__ t_vals,
+                              int nc, int lindisp, int perturb, const float* __restrict__ t_rand, uint64_t seed,
+                              uint64_t ray_offset, float* __restrict__ z_out) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * nc) return;
+    int64_t r = idx / nc;
+    int s = (int)(idx % nc);
+    float near = rays[r * stride + 6], far = rays[r * stride + 7];
+    float z = nh_depth_at(near, far, t_vals[s], lindisp);
+    if (perturb) {
+        float lower = z, upper = z;
+        if (s > 0) lower = 0.5f * (z + nh_depth_at(near, far, t_vals[s - 1], lindisp));
+        if (s < nc - 1) upper = 0.5f * (nh_depth_at(near, far, t_vals[s + 1], lindisp) + z);
+        float tr = t_rand ? t_rand[idx] : nh_rand_uniform(seed, 0u, (ray_offset + (uint64_t)r) * (uint64_t)nc + s);
+        z = lower + (upper - lower) * tr;
+    }
+    z_out[idx] = z;
+}
+
+extern "C" int nerfhip_stratified_z(const float* rays, int ray_stride, int64_t n, const float* t_vals, int nc,
+                                    int lindisp, int perturb, const float* t_rand, uint64_t seed, uint64_t ray_offset,
+                                    float* z_out, nerfhip_stream_t stream) {
+    NH_REQUIRE(rays && t_vals && z_out && ray_stride >= 8 && nc > 0 && n >= 0, "stratified_z: bad arguments");
+    if (n == 0) return NERFHIP_OK;
+    NH_LAUNCH(k_stratified_z, nh_ceil_div(n * nc, 256), 256, 0, stream, rays, ray_stride, n, t_vals, nc, lindisp,
+              perturb, t_rand, seed, ray_offset, z_out);
+    return nh_launch_status("stratified_z");
+}
+
+// ---- cumprod_exclusive (nerf/nerf_helpers.py:43-64) ------------------------------------------------------------------
+// One wavefront per row.  torch's CPU cumprod accumulates fp32 rows in fp64 and rounds each prefix to fp32; the
+// wave scan below forms the same fp64 prefix products (association differs only in the last fp64 bits).
+NH_KERNEL void k_cumprod_exclusive(const float* __restrict__ x, int64_t rows, int cols, float* __restrict__ out) {
+    int64_t row = blockIdx.x;
+    int lane = nh_lane();
+    double carry = 1.0;
+    for (int base = 0; base < cols; base += 64) {
+        int c = base + lane;
+        double p = (c < cols) ? (double)x[row * cols + c] : 1.0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            double o = nh_shfl_up_d(p, d);
+            if (lane >= d) p *= o;
+        }
+        double excl = nh_shfl_up_d(p, 1);
+        if (lane == 0) excl = 1.0;
+        if (c < cols) out[row * cols + c] = (float)(carry * excl);
+        carry *= nh_shfl_d(p, 63);
+    }
+}
+
+extern "C" int nerfhip_cumprod_exclusive(const float* x, int64_t rows, int cols, float* out, nerfhip_stream_t stream) {
+    NH_REQUIRE(x && out && rows >= 0 && cols > 0, "cumprod_exclusive: bad arguments");
+    if (rows == 0) return NERFHIP_OK;
+    NH_LAUNCH(k_cumprod_exclusive, rows, 64, 0, stream, x, rows, cols, out);
+    return nh_launch_status("cumprod_exclusive");
+}
+
+// ---- RNG fill ----------------------------------------------------------------------------------------------------
+NH_KERNEL void k_rng_fill(int kind, uint64_t seed, uint32_t stream_id, uint64_t first, int64_t n,
+                          float* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t e = first + (uint64_t)i;
+    out[i] = kind == NERFHIP_RNG_NORMAL ? nh_rand_normal(seed, stream_id, e) : nh_rand_uniform(seed, stream_id, e);
+}
+
+extern "C" int nerfhip_rng_fill(int kind, uint64_t seed, uint32_t stream_id, uint64_t first, int64_t n, float* out,
+                                nerfhip_stream_t stream) {
+    NH_REQUIRE(out && n >= 0 && (kind == NERFHIP_RNG_UNIFORM || kind == NERFHIP_RNG_NORMAL), "rng_fill: bad arguments");
+    if (n == 0) return NERFHIP_OK;
+    NH_LAUNCH(k_rng_fill, nh_ceil_div(n, 256), 256, 0, stream, kind, seed, stream_id, first, n, out);
+    return nh_launch_status("rng_fill");
+}
+
+// ---- weight gather ---------------------------------------------------------------------------------------------------
+NH_KERNEL void k_pack_weights(const float* __restrict__ params, const int32_t* __restrict__ table, int64_t n,
+                              float* __restrict__ packed) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t s = table[i];
+    packed[i] = s >= 0 ? params[s] : 0.0f;
+}
+
+extern "C" int nerfhip_pack_weights(const float* params, const int32_t* table, int64_t n, float* packed,
+                                    nerfhip_stream_t stream) {
+    NH_REQUIRE(params && table && packed && n >= 0, "pack_weights: bad arguments");
+    if (n == 0) return NERFHIP_OK;
+    NH_LAUNCH(k_pack_weights, nh_ceil_div(n, 256), 256, 0, stream, params, table, n, packed);
+    return nh_launch_status("pack_weights");
+}
+
+// ---- loss (train_nerf.py:244-258) ------------------------------------------------------------------------------------
+// One workgroup; deterministic fp64 tree.  loss_out = {mse(rgb_c, tgt), mse(rgb_f, tgt), sum}; cotangents are
+// 2 (rgb - tgt) / (3 n) * grad_scale.
+NH_KERNEL void k_mse_loss(const float* __restrict__ rc, const float* __restrict__ rf, const float* __restrict__ tgt,
+                          int tstride, int64_t n, float grad_scale, float* __restrict__ gc, float* __restrict__ gf,
+                          float* __restrict__ loss_out) {
+    NH_SHARED double red[2][16];
+    double sc = 0.0, sf = 0.0;
+    const float k = 2.0f / (float)(3 * n) * grad_scale;
+    for (int64_t i = threadIdx.x; i < n * 3; i += blockDim.x) {
+        int64_t r = i / 3;
+        int c = (int)(i % 3);
+        float t = tgt[r * tstride + c];
+        float dc = rc[i] - t;
+        sc += (double)dc * (double)dc;
+        if (gc) gc[i] = dc * k;
+        if (rf) {
+            float df = rf[i] - t;
+            sf += (double)df * (double)df;
+            if (gf) gf[i] = df * k;
+        }
+    }
+    sc = nh_wave_sum_d(sc);
+    sf = nh_wave_sum_d(sf);
+    int w = nh_wave_in_block();
+    if (nh_lane() == 0) {
+        red[0][w] = sc;
+        red[1][w] = sf;
+    }
+    nh_block_sync();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        int nw = (int)(blockDim.x >> 6);
+        for (int i = 0; i < nw; ++i) {
+            a += red[0][i];
+            b += red[1][i];
+        }
+        float la = (float)(a / (double)(3 * n)), lb = (float)(b / (double)(3 * n));
+        loss_out[0] = la;
+        loss_out[1] = lb;
+        loss_out[2] = la + lb;
+    }
+}
+
+extern "C" int nerfhip_mse_loss_fwd_bwd(const float* rgb_coarse, const float* rgb_fine, const float* target,
+                                        int target_stride, int64_t n, float grad_scale, float* g_rgb_coarse,
+                                        float* g_rgb_fine, float* loss_out, nerfhip_stream_t stream) {
+    NH_REQUIRE(rgb_coarse && target && loss_out && n > 0 && target_stride >= 3, "mse_loss: bad arguments");
+    NH_LAUNCH(k_mse_loss, 1, 1024, 0, stream, rgb_coarse, rgb_fine, target, target_stride, n, grad_scale, g_rgb_coarse,
+              g_rgb_fine, loss_out);
+    return nh_launch_status("mse_loss");
+}
+
+// ---- Adam (torch.optim.Adam single-tensor step; train_nerf.py:141-143,261) -------------------------------------------
+NH_KERNEL void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                      int64_t n, float one_minus_b1, float b2, float one_minus_b2, float step_size, float bc2_sqrt,
+                      float eps, float grad_scale) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float gi = g[i] * grad_scale;
+    float mi = m[i];
+    mi = mi + one_minus_b1 * (gi - mi);  // exp_avg.lerp_(grad, 1 - beta1)
+    float vi = v[i] * b2 + one_minus_b2 * (gi * gi);
+    m[i] = mi;
+    v[i] = vi;
+    float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+}
+
+extern "C" int nerfhip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                 float lr, float beta1, float beta2, float eps, int64_t step, float grad_scale,
+                                 nerfhip_stream_t stream) {
+    NH_REQUIRE(params && grads && exp_avg && exp_avg_sq && n >= 0 && step >= 1, "adam_step: bad arguments");
+    if (n == 0) return NERFHIP_OK;
+    double bc1 = 1.0 - pow((double)beta1, (double)step);
+    double bc2 = 1.0 - pow((double)beta2, (double)step);
+    float step_size = (float)((double)lr / bc1);
+    float bc2_sqrt = (float)sqrt(bc2);
+    NH_LAUNCH(k_adam, nh_ceil_div(n, 256), 256, 0, stream, params, grads, exp_avg, exp_avg_sq, n,
+              (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2), step_size, bc2_sqrt, eps, grad_scale);
+    return nh_launch_status("adam_step");
+}

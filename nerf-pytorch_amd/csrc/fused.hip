@@ -1,0 +1,158 @@
+// fused.hip -- predict_and_render_radiance (nerf/train_utils.py:28-127) as a fixed pipeline of kernels on one stream:
+//   stratified depths -> coarse MLP (encodes in registers) -> compositing -> inverse-CDF + merge -> fine MLP ->
+//   compositing, and the matching backward.  Nothing of size (N*S, 90) or (N*S, 256) is materialised for inference;
+//   a training forward additionally writes the activation stash the weight-gradient GEMM consumes.
+#include "nh_mlp.h"
+
+namespace {
+
+struct Workspace {
+    int64_t z_c, raw_c, w_c, z_f, raw_f, stash_c, stash_f, g_raw, scratch, total;
+    int64_t scratch_bytes;
+};
+
+int64_t align_up(int64_t v) { return (v + 255) & ~(int64_t)255; }
+
+Workspace layout(nerfhip_plan* pc, nerfhip_plan* pf, const nerfhip_render_cfg* cfg, int64_t n, int training) {
+    Workspace w;
+    memset(&w, 0, sizeof(w));
+    const int64_t nc = cfg->num_coarse, nf = cfg->num_fine, sf = nc + nf;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) {
+        int64_t o = off;
+        off = align_up(off + bytes);
+        return o;
+    };
+    w.z_c = take(n * nc * 4);
+    w.raw_c = take(n * nc * 16);
+    w.w_c = take(n * nc * 4);
+    if (nf > 0) {
+        w.z_f = take(n * sf * 4);
+        w.raw_f = take(n * sf * 16);
+    }
+    if (training) {
+        w.stash_c = take(nerfhip_plan_stash_bytes(pc, n * nc));
+        int64_t sb = nh_mlp_bwd_scratch_bytes(pc, n * nc);
+        int64_t graw = n * nc * 16;
+        if (nf > 0) {
+            w.stash_f = take(nerfhip_plan_stash_bytes(pf, n * sf));
+            int64_t sbf = nh_mlp_bwd_scratch_bytes(pf, n * sf);
+            if (sbf > sb) sb = sbf;
+            graw = n * sf * 16;
+        }
+        w.g_raw = take(graw);
+        w.scratch = take(sb);
+        w.scratch_bytes = sb;
+    }
+    w.total = off;
+    return w;
+}
+
+int check_cfg(nerfhip_plan* pc, nerfhip_plan* pf, const nerfhip_render_cfg* cfg) {
+    NH_REQUIRE(pc && cfg, "render: plan/cfg is NULL");
+    NH_REQUIRE(cfg->num_coarse >= 3 || (cfg->num_coarse >= 1 && cfg->num_fine == 0), "render: num_coarse too small");
+    NH_REQUIRE(cfg->num_fine >= 0, "render: num_fine < 0");
+    NH_REQUIRE(cfg->num_fine == 0 || pf, "render: num_fine > 0 needs a fine plan");
+    NH_REQUIRE(cfg->ray_stride >= (pc->view ? 11 : 8), "render: ray_stride too small for use_viewdirs");
+    NH_REQUIRE(!pf || pf->view == pc->view, "render: coarse/fine use_viewdirs mismatch");
+    return NERFHIP_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t nerfhip_render_workspace_bytes(nerfhip_plan_t plan_coarse, nerfhip_plan_t plan_fine,
+                                                  const nerfhip_render_cfg* cfg, int64_t n_rays, int training) {
+    if (check_cfg(plan_coarse, plan_fine, cfg) != NERFHIP_OK || n_rays < 0) return -1;
+    return layout(plan_coarse, plan_fine, cfg, n_rays, training).total;
+}
+
+extern "C" int nerfhip_render_fwd(nerfhip_plan_t pc, nerfhip_plan_t pf, const nerfhip_render_cfg* cfg, const float* rays,
+                                  int64_t n, const float* packed_c, const float* packed_f, const float* t_vals,
+                                  const float* u_det, const nerfhip_render_rand* rnd, uint64_t seed, uint64_t ray_offset,
+                                  const nerfhip_render_out* out, void* workspace, int64_t workspace_bytes, int training,
+                                  nerfhip_stream_t stream) {
+    int rc = check_cfg(pc, pf, cfg);
+    if (rc) return rc;
+    NH_REQUIRE(rays && packed_c && t_vals && out && workspace && n >= 0, "render_fwd: bad arguments");
+    NH_REQUIRE(cfg->num_fine == 0 || packed_f, "render_fwd: packed_fine is NULL");
+    if (n == 0) return NERFHIP_OK;
+    const Workspace w = layout(pc, pf, cfg, n, training);
+    NH_REQUIRE(workspace_bytes >= w.total, "render_fwd: workspace too small (%lld < %lld)", (long long)workspace_bytes,
+               (long long)w.total);
+    char* ws = (char*)workspace;
+    const int nc = cfg->num_coarse, nf = cfg->num_fine, sf = nc + nf, stride = cfg->ray_stride;
+    nerfhip_render_rand none = {nullptr, nullptr, nullptr, nullptr};
+    const nerfhip_render_rand* r = rnd ? rnd : &none;
+    float* z_c = (float*)(ws + w.z_c);
+    float* raw_c = (float*)(ws + w.raw_c);
+    float* w_c = (float*)(ws + w.w_c);
+
+    rc = nerfhip_stratified_z(rays, stride, n, t_vals, nc, cfg->lindisp, cfg->perturb, r->t_rand, seed, ray_offset, z_c,
+                              stream);
+    if (rc) return rc;
+    NhMlpInput in;
+    memset(&in, 0, sizeof(in));
+    in.mode = 1;
+    in.rays = rays;
+    in.ray_stride = stride;
+    in.z = z_c;
+    in.S = nc;
+    rc = nh_mlp_forward(pc, packed_c, in, n * nc, raw_c, training ? (float*)(ws + w.stash_c) : nullptr, stream);
+    if (rc) return rc;
+    rc = nerfhip_volume_render_fwd(raw_c, z_c, rays + 3, stride, n, nc, cfg->noise_std, r->noise_coarse, seed, 1u,
+                                   ray_offset, cfg->white_background, out->rgb_coarse, out->disp_coarse, out->acc_coarse,
+                                   w_c, out->depth_coarse, stream);
+    if (rc) return rc;
+    if (nf > 0) {
+        float* z_f = (float*)(ws + w.z_f);
+        float* raw_f = (float*)(ws + w.raw_f);
+        const int det = cfg->perturb ? 0 : 1;  // det = (perturb == 0.0), nerf/train_utils.py:101
+        NH_REQUIRE(!det || r->u || u_det, "render_fwd: perturb == 0 needs u_det");
+        rc = nerfhip_hierarchical_z(z_c, w_c, n, nc, r->u, det, u_det, nf, seed, ray_offset, nullptr, z_f, stream);
+        if (rc) return rc;
+        in.z = z_f;
+        in.S = sf;
+        rc = nh_mlp_forward(pf, packed_f, in, n * sf, raw_f, training ? (float*)(ws + w.stash_f) : nullptr, stream);
+        if (rc) return rc;
+        rc = nerfhip_volume_render_fwd(raw_f, z_f, rays + 3, stride, n, sf, cfg->noise_std, r->noise_fine, seed, 3u,
+                                       ray_offset, cfg->white_background, out->rgb_fine, out->disp_fine, out->acc_fine,
+                                       nullptr, out->depth_fine, stream);
+        if (rc) return rc;
+    }
+    return NERFHIP_OK;
+}
+
+extern "C" int nerfhip_render_bwd(nerfhip_plan_t pc, nerfhip_plan_t pf, const nerfhip_render_cfg* cfg, const float* rays,
+                                  int64_t n, const float* packed_c, const float* packed_f, const nerfhip_render_rand* rnd,
+                                  uint64_t seed, uint64_t ray_offset, const float* g_rgb_c, const float* g_rgb_f,
+                                  void* workspace, int64_t workspace_bytes, float* g_params_c, float* g_params_f,
+                                  nerfhip_stream_t stream) {
+    int rc = check_cfg(pc, pf, cfg);
+    if (rc) return rc;
+    NH_REQUIRE(rays && packed_c && g_rgb_c && workspace && g_params_c && n > 0, "render_bwd: bad arguments");
+    const Workspace w = layout(pc, pf, cfg, n, 1);
+    NH_REQUIRE(workspace_bytes >= w.total, "render_bwd: workspace too small (%lld < %lld)", (long long)workspace_bytes,
+               (long long)w.total);
+    char* ws = (char*)workspace;
+    const int nc = cfg->num_coarse, nf = cfg->num_fine, sf = nc + nf, stride = cfg->ray_stride;
+    nerfhip_render_rand none = {nullptr, nullptr, nullptr, nullptr};
+    const nerfhip_render_rand* r = rnd ? rnd : &none;
+    float* g_raw = (float*)(ws + w.g_raw);
+    float* scratch = (float*)(ws + w.scratch);
+    if (nf > 0) {
+        NH_REQUIRE(packed_f && g_rgb_f && g_params_f, "render_bwd: fine arguments missing");
+        rc = nerfhip_volume_render_bwd((const float*)(ws + w.raw_f), (const float*)(ws + w.z_f), rays + 3, stride, n, sf,
+                                       cfg->noise_std, r->noise_fine, seed, 3u, ray_offset, cfg->white_background,
+                                       g_rgb_f, nullptr, nullptr, nullptr, g_raw, stream);
+        if (rc) return rc;
+        rc = nh_mlp_backward(pf, packed_f, g_raw, n * sf, (const float*)(ws + w.stash_f), scratch, w.scratch_bytes,
+                             g_params_f, stream);
+        if (rc) return rc;
+    }
+    rc = nerfhip_volume_render_bwd((const float*)(ws + w.raw_c), (const float*)(ws + w.z_c), rays + 3, stride, n, nc,
+                                   cfg->noise_std, r->noise_coarse, seed, 1u, ray_offset, cfg->white_background, g_rgb_c,
+                                   nullptr, nullptr, nullptr, g_raw, stream);
+    if (rc) return rc;
+    return nh_mlp_backward(pc, packed_c, g_raw, n * nc, (const float*)(ws + w.stash_c), scratch, w.scratch_bytes,
+                           g_params_c, stream);
+}

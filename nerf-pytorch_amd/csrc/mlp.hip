@@ -1,0 +1,753 @@
+// mlp.hip -- FlexibleNeRFModel (nerf/models.py:185-256) forward and backward on fp32 MFMA
+// (v_mfma_f32_32x32x2_f32: exact fp32, a k-ordered fmaf chain).
+//
+// Forward / data-gradient kernels: a workgroup is 4 wavefronts (one per SIMD, <= 512 registers each); every
+// wavefront owns 32 sample points for the whole network.  The computation is transposed, out^T = W * h^T: the
+// weights are the MFMA A operand, the activations the B operand.  With that orientation the C/D register layout of
+// one layer IS the B-operand layout of the next one, so activations never leave the register file -- no LDS
+// round-trip, no HBM materialisation of the (N*S, 90) encodings or (N*S, 256) hidden states the reference creates
+// (nerf/train_utils.py:8-25).  Weights stream L2 -> registers -> LDS in 32-output-row chunks (double buffered, one
+// barrier per chunk) and are broadcast to the 4 wavefronts by ds_read_b128.
+//
+// Weight-gradient kernel: a split-K GEMM  dW[out,in] = sum_samples dpre[out][s] * act[in][s]  whose operands are
+// the [tile][row][32 samples] images the other two kernels write; each wavefront keeps up to a 128x128 patch of dW
+// in 256 accumulator registers and walks a contiguous range of sample tiles; a second kernel reduces the split-K
+// partials in a fixed order (bit-reproducible) and scatters them into the reference parameter layout.
+#include "nh_mlp.h"
+
+namespace {
+
+template <int W>
+struct Cfg {
+    static constexpr int KH = W / 2;                       // registers of a hidden activation
+    static constexpr int KRMAX = KH + NH_KRX;              // widest layer (skip layer)
+    static constexpr int LB = KRMAX * 64 + 32;             // floats of one LDS weight buffer
+    static constexpr int N4MAX = (LB / 4 + 255) / 256;     // float4 per thread to stage one chunk
+    static constexpr int LDS_BYTES = 2 * LB * 4;
+};
+
+template <int N4MAX>
+struct Stage {
+    float4 v[N4MAX];
+};
+
+template <int N4MAX>
+NH_DEVICE void stage_load(Stage<N4MAX>& s, const float* __restrict__ chunk, int n4) {
+    const float4* p = (const float4*)chunk;
+    const int tid = (int)threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < N4MAX; ++q) {
+        const int idx = tid + q * 256;
+        if (idx < n4) s.v[q] = p[idx];
+    }
+}
+template <int N4MAX>
+NH_DEVICE void stage_store(const Stage<N4MAX>& s, float* ldsbuf, int n4) {
+    float4* p = (float4*)ldsbuf;
+    const int tid = (int)threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < N4MAX; ++q) {
+        const int idx = tid + q * 256;
+        if (idx < n4) p[idx] = s.v[q];
+    }
+}
+
+NH_DEVICE int n4_of(int kr) { return kr * 16 + 8; }
+
+// One linear layer for the 32 samples of this wavefront:  out[t] (32 rows x 32 samples) = Wchunk_t * in + bias_t.
+// Precondition: chunk 0 of this layer is in lds buffer `buf` and a barrier has been passed.  While tile t is being
+// computed the next chunk (of this layer, or the first chunk of the next layer) travels global -> registers; it is
+// written to the other LDS buffer after the MFMAs and published by the barrier that ends the tile.
+template <int W, int KRA, int KRB, int TILES>
+NH_DEVICE void gemm_layer(const float* inA, const float* inB, const float* __restrict__ wl,
+                          const float* __restrict__ next_chunk, int next_n4, float* lds, int& buf,
+                          Stage<Cfg<W>::N4MAX>& st, f32x16* out, int lane) {
+    constexpr int KR = KRA + KRB;
+    constexpr int CH = KR * 64 + 32;
+    static_assert(KR % 4 == 0, "KR must be a multiple of 4");
+    static_assert(KR <= Cfg<W>::KRMAX, "KR too large for the LDS buffer");
+    const int h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+        const float* nxt = (t + 1 < TILES) ? wl + (size_t)(t + 1) * CH : next_chunk;
+        const int n4 = (t + 1 < TILES) ? CH / 4 : next_n4;
+        if (nxt) stage_load(st, nxt, n4);
+        const float* cur = lds + buf * Cfg<W>::LB;
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 b4 = *(const float4*)(cur + KR * 64 + 8 * g + 4 * h);
+            acc[4 * g + 0] = b4.x;
+            acc[4 * g + 1] = b4.y;
+            acc[4 * g + 2] = b4.z;
+            acc[4 * g + 3] = b4.w;
+        }
+        const float4* w4 = (const float4*)cur + lane;
+        float4 wc = w4[0];
+#pragma unroll
+        for (int g = 0; g < KR / 4; ++g) {
+            float4 wn = wc;
+            if (g + 1 < KR / 4) wn = w4[(g + 1) * 64];
+            const int r = 4 * g;
+            acc = nh_mfma32(wc.x, (r + 0 < KRA) ? inA[r + 0] : inB[r + 0 - KRA], acc);
+            acc = nh_mfma32(wc.y, (r + 1 < KRA) ? inA[r + 1] : inB[r + 1 - KRA], acc);
+            acc = nh_mfma32(wc.z, (r + 2 < KRA) ? inA[r + 2] : inB[r + 2 - KRA], acc);
+            acc = nh_mfma32(wc.w, (r + 3 < KRA) ? inA[r + 3] : inB[r + 3 - KRA], acc);
+            wc = wn;
+        }
+        out[t] = acc;
+        if (nxt) stage_store(st, lds + (buf ^ 1) * Cfg<W>::LB, n4);
+        nh_block_sync();
+        buf ^= 1;
+    }
+}
+
+// ---- stash helpers: region image [tile][row][32 samples] ------------------------------------------------------------
+template <int N>
+NH_DEVICE void store_feat_rows(float* __restrict__ tile_base, const float* v, int j, int h) {
+#pragma unroll
+    for (int r = 0; r < N; ++r) tile_base[(size_t)nh_feat_of(r >> 4, r & 15, h) * 32 + j] = v[r];
+}
+template <int N>
+NH_DEVICE void store_slot_rows(float* __restrict__ tile_base, const float* v, int j, int h) {
+#pragma unroll
+    for (int r = 0; r < N; ++r) tile_base[(size_t)(2 * r + h) * 32 + j] = v[r];
+}
+NH_DEVICE float* region_tile(float* base, const NhRegion& R, int64_t nt, int64_t tile) {
+    return base + (size_t)32 * (size_t)nt * (size_t)R.row_prefix + (size_t)tile * (size_t)R.rows * 32;
+}
+NH_DEVICE const float* region_tile_c(const float* base, const NhRegion& R, int64_t nt, int64_t tile) {
+    return base + (size_t)32 * (size_t)nt * (size_t)R.row_prefix + (size_t)tile * (size_t)R.rows * 32;
+}
+
+struct MlpFwdArgs {
+    const float* packed;
+    NhPackedOffsets off;
+    int L, skip;
+    int64_t M, nt;
+    int mode;
+    const float* x;
+    int dx, dd;
+    const float* rays;
+    int ray_stride;
+    const float* z;
+    int S;
+    short xcol[2][NH_KRX];
+    short dcol[2][NH_KRD];
+    float fx[16], fd[16];
+    int Lx, Ld, P0x, P0d;
+    float* out;
+    float* stash;
+    NhStashLayout sl;
+};
+
+NH_DEVICE float sel3(int a, float x, float y, float z) { return a == 0 ? x : (a == 1 ? y : z); }
+
+// encoding registers of one lane: slot layout documented in nh_plan.h / plan.cpp build_slot_map
+template <int KR>
+NH_DEVICE void encode_slots(float* e, float x, float y, float z, int h, const float* freqs, int Lf, int P0) {
+    e[0] = h ? z : x;
+    e[1] = h ? 0.0f : y;
+#pragma unroll
+    for (int q = 0; 3 + 2 * q < KR; ++q) {
+        const int ph = q + P0;
+        const int fh = ph / 3, ah = ph - 3 * fh;
+        const bool valid = h ? (ph < 3 * Lf) : (q < P0);
+        const float f_lo = freqs[q / 3];
+        const float f_hi = freqs[fh < 16 ? fh : 15];
+        const float c_lo = sel3(q % 3, x, y, z);
+        const float c_hi = sel3(ah, x, y, z);
+        const float arg = (h ? c_hi : c_lo) * (h ? f_hi : f_lo);
+        float s, c;
+        nh_sincos(arg, &s, &c);
+        e[2 + 2 * q] = valid ? s : 0.0f;
+        e[3 + 2 * q] = valid ? c : 0.0f;
+    }
+}
+
+template <int W, bool VIEW>
+NH_KERNEL void NH_LB(256, 1) k_mlp_fwd(MlpFwdArgs a) {
+    using C = Cfg<W>;
+    constexpr int KH = C::KH, TW = W / 32;
+    NH_DYN_LDS(lds_raw);
+    float* lds = (float*)lds_raw;
+    const int lane = nh_lane(), j = lane & 31, h = lane >> 5, wave = nh_wave_in_block();
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t m = tile * 32 + j;
+    const bool valid = m < a.M;
+    const int64_t mc = valid ? m : a.M - 1;
+
+    float ex[NH_KRX];
+    float ed[NH_KRD];
+    if (a.mode == 0) {
+        const float* xr = a.x + (size_t)mc * (size_t)(a.dx + a.dd);
+#pragma unroll
+        for (int r = 0; r < NH_KRX; ++r) {
+            const int c = h ? a.xcol[1][r] : a.xcol[0][r];
+            ex[r] = c >= 0 ? xr[c] : 0.0f;
+        }
+        if (VIEW) {
+#pragma unroll
+            for (int r = 0; r < NH_KRD; ++r) {
+                const int c = h ? a.dcol[1][r] : a.dcol[0][r];
+                ed[r] = c >= 0 ? xr[a.dx + c] : 0.0f;
+            }
+        }
+    } else {
+        const int64_t ray = mc / a.S;
+        const float* rr = a.rays + (size_t)ray * a.ray_stride;
+        const float zz = a.z[mc];
+        // pts = ro + rd * z   (nerf/train_utils.py:67,107)
+        const float px = rr[0] + rr[3] * zz, py = rr[1] + rr[4] * zz, pz = rr[2] + rr[5] * zz;
+        encode_slots<NH_KRX>(ex, px, py, pz, h, a.fx, a.Lx, a.P0x);
+        if (VIEW) encode_slots<NH_KRD>(ed, rr[8], rr[9], rr[10], h, a.fd, a.Ld, a.P0d);
+    }
+    if (!VIEW) {
+#pragma unroll
+        for (int r = 0; r < NH_KRD; ++r) ed[r] = 0.0f;
+    }
+    if (a.stash) {
+        store_slot_rows<NH_KRX>(region_tile(a.stash, a.sl.X, a.nt, tile), ex, j, h);
+        if (VIEW) store_slot_rows<NH_KRD>(region_tile(a.stash, a.sl.D, a.nt, tile), ed, j, h);
+    }
+
+    Stage<C::N4MAX> st;
+    int buf = 0;
+    const float* pk = a.packed;
+    stage_load(st, pk + a.off.f_layer1, n4_of(NH_KRX));
+    stage_store(st, lds, n4_of(NH_KRX));
+    nh_block_sync();
+
+    f32x16 o[TW + 1];
+    float act[KH];
+    {
+        const bool more = a.L > 1;
+        const float* nxt = pk + (more ? a.off.f_xyz[0] : a.off.f_head);
+        const int nn4 = n4_of(KH);  // layers_xyz[0] is never a skip layer (i > 0 is required)
+        gemm_layer<W, NH_KRX, 0, TW>(ex, nullptr, pk + a.off.f_layer1, nxt, nn4, lds, buf, st, o, lane);
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) act[16 * t + c] = o[t][c];  // no activation after layer1 (models.py:238)
+        if (a.stash) store_feat_rows<KH>(region_tile(a.stash, a.sl.H[0], a.nt, tile), act, j, h);
+    }
+    for (int i = 0; i < a.L - 1; ++i) {
+        const bool sk = (i % a.skip == 0) && i > 0;
+        const bool more = i + 1 < a.L - 1;
+        const bool nsk = more && ((i + 1) % a.skip == 0);
+        const float* nxt = pk + (more ? a.off.f_xyz[i + 1] : a.off.f_head);
+        const int nn4 = n4_of(KH + (nsk ? NH_KRX : 0));
+        if (sk)
+            gemm_layer<W, KH, NH_KRX, TW>(act, ex, pk + a.off.f_xyz[i], nxt, nn4, lds, buf, st, o, lane);
+        else
+            gemm_layer<W, KH, 0, TW>(act, nullptr, pk + a.off.f_xyz[i], nxt, nn4, lds, buf, st, o, lane);
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) act[16 * t + c] = fmaxf(o[t][c], 0.0f);
+        if (a.stash) store_feat_rows<KH>(region_tile(a.stash, a.sl.H[i + 1], a.nt, tile), act, j, h);
+    }
+    if (VIEW) {
+        gemm_layer<W, KH, 0, TW + 1>(act, nullptr, pk + a.off.f_head, pk + a.off.f_dir, n4_of(KH + NH_KRD), lds, buf, st,
+                                     o, lane);
+        const float alpha = o[TW][0];  // row 0 of the extra tile = fc_alpha(h) (models.py:249), raw
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) act[16 * t + c] = fmaxf(o[t][c], 0.0f);  // feat = relu(fc_feat(h))
+        if (a.stash) store_feat_rows<KH>(region_tile(a.stash, a.sl.FEAT, a.nt, tile), act, j, h);
+        gemm_layer<W, KH, NH_KRD, TW / 2>(act, ed, pk + a.off.f_dir, pk + a.off.f_rgb, n4_of(KH / 2), lds, buf, st, o,
+                                          lane);
+        float dh[KH / 2];
+#pragma unroll
+        for (int t = 0; t < TW / 2; ++t)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) dh[16 * t + c] = fmaxf(o[t][c], 0.0f);
+        if (a.stash) store_feat_rows<KH / 2>(region_tile(a.stash, a.sl.DIRH, a.nt, tile), dh, j, h);
+        gemm_layer<W, KH / 2, 0, 1>(dh, nullptr, pk + a.off.f_rgb, nullptr, 0, lds, buf, st, o, lane);
+        if (valid && h == 0) {
+            float4 r4;
+            r4.x = o[0][0];
+            r4.y = o[0][1];
+            r4.z = o[0][2];
+            r4.w = alpha;
+            *(float4*)(a.out + (size_t)m * 4) = r4;
+        }
+    } else {
+        gemm_layer<W, KH, 0, 1>(act, nullptr, pk + a.off.f_head, nullptr, 0, lds, buf, st, o, lane);
+        if (valid && h == 0) {
+            float4 r4;
+            r4.x = o[0][0];
+            r4.y = o[0][1];
+            r4.z = o[0][2];
+            r4.w = o[0][3];
+            *(float4*)(a.out + (size_t)m * 4) = r4;
+        }
+    }
+}
+
+// ---- data-gradient chain ---------------------------------------------------------------------------------------------
+struct DgradArgs {
+    const float* packed;
+    NhPackedOffsets off;
+    int L;
+    int64_t M, nt;
+    const float* g_out;
+    const float* stash;
+    NhStashLayout sl;
+    float* grad;
+    NhGradLayout gl;
+};
+
+// v[r] = (stash row feat(r,h) of this sample > 0) ? o[r] : 0, then store the masked value to the grad region
+template <int N>
+NH_DEVICE void mask_and_store(float* v, const f32x16* o, const float* __restrict__ act_tile, float* __restrict__ dst_tile,
+                              int j, int h, bool masked) {
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+        const size_t idx = (size_t)nh_feat_of(r >> 4, r & 15, h) * 32 + j;
+        float g = o[r >> 4][r & 15];
+        if (masked) g = act_tile[idx] > 0.0f ? g : 0.0f;
+        v[r] = g;
+        dst_tile[idx] = g;
+    }
+}
+
+template <int W, bool VIEW>
+NH_KERNEL void NH_LB(256, 1) k_mlp_dgrad(DgradArgs a) {
+    using C = Cfg<W>;
+    constexpr int KH = C::KH, TW = W / 32;
+    NH_DYN_LDS(lds_raw);
+    float* lds = (float*)lds_raw;
+    const int lane = nh_lane(), j = lane & 31, h = lane >> 5, wave = nh_wave_in_block();
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t m = tile * 32 + j;
+    const bool valid = m < a.M;
+    float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) go = *(const float4*)(a.g_out + (size_t)m * 4);
+    {
+        float* po = region_tile(a.grad, a.gl.POUT, a.nt, tile);
+        if (h == 0) {
+            po[0 * 32 + j] = go.x;
+            po[1 * 32 + j] = go.y;
+            po[2 * 32 + j] = go.z;
+            po[3 * 32 + j] = go.w;
+        }
+#pragma unroll
+        for (int c = 0; c < 14; ++c) po[(4 + 2 * c + h) * 32 + j] = 0.0f;
+    }
+    Stage<C::N4MAX> st;
+    int buf = 0;
+    const float* pk = a.packed;
+    f32x16 o[TW];
+    float dp[KH];
+    const int L = a.L;
+    if (VIEW) {
+        float d4[4];
+        d4[0] = h == 0 ? go.x : 0.0f;
+        d4[1] = h == 0 ? go.y : 0.0f;
+        d4[2] = h == 0 ? go.z : 0.0f;
+        d4[3] = 0.0f;
+        stage_load(st, pk + a.off.b_rgb, n4_of(4));
+        stage_store(st, lds, n4_of(4));
+        nh_block_sync();
+        gemm_layer<W, 4, 0, TW / 2>(d4, nullptr, pk + a.off.b_rgb, pk + a.off.b_dir, n4_of(KH / 2), lds, buf, st, o, lane);
+        float dpd[KH / 2];
+        mask_and_store<KH / 2>(dpd, o, region_tile_c(a.stash, a.sl.DIRH, a.nt, tile),
+                               region_tile(a.grad, a.gl.PDIR, a.nt, tile), j, h, true);
+        gemm_layer<W, KH / 2, 0, TW>(dpd, nullptr, pk + a.off.b_dir, pk + a.off.b_head, n4_of(KH + 4), lds, buf, st, o,
+                                     lane);
+        mask_and_store<KH>(dp, o, region_tile_c(a.stash, a.sl.FEAT, a.nt, tile),
+                           region_tile(a.grad, a.gl.PFEAT, a.nt, tile), j, h, true);
+        float da[4];
+        da[0] = h == 0 ? go.w : 0.0f;
+        da[1] = da[2] = da[3] = 0.0f;
+        const float* nxt = L > 1 ? pk + a.off.b_xyz[L - 2] : nullptr;
+        gemm_layer<W, KH, 4, TW>(dp, da, pk + a.off.b_head, nxt, n4_of(KH), lds, buf, st, o, lane);
+    } else {
+        float d4[4];
+        d4[0] = h == 0 ? go.x : 0.0f;
+        d4[1] = h == 0 ? go.y : 0.0f;
+        d4[2] = h == 0 ? go.z : 0.0f;
+        d4[3] = h == 0 ? go.w : 0.0f;
+        stage_load(st, pk + a.off.b_head, n4_of(4));
+        stage_store(st, lds, n4_of(4));
+        nh_block_sync();
+        const float* nxt = L > 1 ? pk + a.off.b_xyz[L - 2] : nullptr;
+        gemm_layer<W, 4, 0, TW>(d4, nullptr, pk + a.off.b_head, nxt, n4_of(KH), lds, buf, st, o, lane);
+    }
+    // o = dL/dH_{L-1}
+    for (int k = L - 1; k >= 1; --k) {
+        mask_and_store<KH>(dp, o, region_tile_c(a.stash, a.sl.H[k], a.nt, tile), region_tile(a.grad, a.gl.P[k], a.nt, tile),
+                           j, h, true);
+        const float* nxt = k >= 2 ? pk + a.off.b_xyz[k - 2] : nullptr;
+        gemm_layer<W, KH, 0, TW>(dp, nullptr, pk + a.off.b_xyz[k - 1], nxt, n4_of(KH), lds, buf, st, o, lane);
+    }
+    mask_and_store<KH>(dp, o, nullptr, region_tile(a.grad, a.gl.P[0], a.nt, tile), j, h, false);
+}
+
+// ---- weight gradients ----------------------------------------------------------------------------------------------
+struct JobDev {
+    int a_rows, a_prefix, a_tiles;
+    int b_rows, b_prefix, b_row0, b_tiles;
+    int wo, wi, po, pi;
+    int r_lo, r_hi;
+    int w_off, w_ld;
+    int col_kind, col_base, col_count;
+    int bias_off;
+    int wg_start;
+};
+constexpr int NH_JOBS_DEV = 32;
+constexpr int NH_PART = 65536 + 512;  // floats of split-K partial per workgroup (4 waves x 256 regs x 64 lanes + bias)
+
+struct WgradArgs {
+    const float* stash;
+    const float* grad;
+    float* partial;
+    float* g_params;
+    int64_t nt;
+    int njobs, total_wgs;
+    JobDev jobs[NH_JOBS_DEV];
+    short xcol[2][NH_KRX];
+    short dcol[2][NH_KRD];
+};
+
+template <int PO, int PI>
+struct WOperands {
+    float4 A[PO][2];
+    float4 B[PI][2];
+};
+
+template <int PO, int PI>
+NH_DEVICE void wgrad_load(WOperands<PO, PI>& op, const float* __restrict__ Ab, const float* __restrict__ Bb, int half,
+                          int k) {
+#pragma unroll
+    for (int a = 0; a < PO; ++a)
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) op.A[a][mm] = *(const float4*)(Ab + a * 1024 + 8 * (2 * half + mm) + 4 * k);
+#pragma unroll
+    for (int b = 0; b < PI; ++b)
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) op.B[b][mm] = *(const float4*)(Bb + b * 1024 + 8 * (2 * half + mm) + 4 * k);
+}
+
+template <int PO, int PI>
+NH_DEVICE void wgrad_compute(const WOperands<PO, PI>& op, f32x16 (&acc)[PO][PI], float (&bsum)[PO]) {
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm) {
+#pragma unroll
+        for (int a = 0; a < PO; ++a) {
+            const float4 av = op.A[a][mm];
+            bsum[a] += (av.x + av.y) + (av.z + av.w);
+#pragma unroll
+            for (int b = 0; b < PI; ++b) {
+                const float4 bv = op.B[b][mm];
+                acc[a][b] = nh_mfma32(av.x, bv.x, acc[a][b]);
+                acc[a][b] = nh_mfma32(av.y, bv.y, acc[a][b]);
+                acc[a][b] = nh_mfma32(av.z, bv.z, acc[a][b]);
+                acc[a][b] = nh_mfma32(av.w, bv.w, acc[a][b]);
+            }
+        }
+    }
+}
+
+template <int PO, int PI>
+NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int64_t t1, int ow, int iw, int wave,
+                          int lane, int64_t wg) {
+    const int i = lane & 31, k = lane >> 5;
+    f32x16 acc[PO][PI];
+    float bsum[PO];
+#pragma unroll
+    for (int x = 0; x < PO; ++x) {
+        bsum[x] = 0.0f;
+#pragma unroll
+        for (int y = 0; y < PI; ++y)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[x][y][c] = 0.0f;
+    }
+    const size_t a_tile_stride = (size_t)jb.a_rows * 32, b_tile_stride = (size_t)jb.b_rows * 32;
+    const float* A0 = a.grad + (size_t)32 * (size_t)a.nt * (size_t)jb.a_prefix + (size_t)(32 * ow * PO + i) * 32;
+    const float* B0 = a.stash + (size_t)32 * (size_t)a.nt * (size_t)jb.b_prefix +
+                      (size_t)(jb.b_row0 + 32 * iw * PI + i) * 32;
+    WOperands<PO, PI> op0, op1;
+    if (t0 < t1) wgrad_load(op0, A0 + t0 * a_tile_stride, B0 + t0 * b_tile_stride, 0, k);
+    for (int64_t t = t0; t < t1; ++t) {
+        wgrad_load(op1, A0 + t * a_tile_stride, B0 + t * b_tile_stride, 1, k);
+        wgrad_compute(op0, acc, bsum);
+        if (t + 1 < t1) wgrad_load(op0, A0 + (t + 1) * a_tile_stride, B0 + (t + 1) * b_tile_stride, 0, k);
+        wgrad_compute(op1, acc, bsum);
+    }
+    float* part = a.partial + (size_t)wg * NH_PART;
+#pragma unroll
+    for (int x = 0; x < PO; ++x)
+#pragma unroll
+        for (int y = 0; y < PI; ++y)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) part[((size_t)(wave * 16 + x * 4 + y) * 16 + c) * 64 + lane] = acc[x][y][c];
+#pragma unroll
+    for (int x = 0; x < PO; ++x) {
+        const float tot = bsum[x] + nh_shfl_xor(bsum[x], 32);
+        if (k == 0) part[65536 + (wave * 4 + x) * 32 + i] = tot;
+    }
+}
+
+NH_KERNEL void NH_LB(256, 1) k_wgrad(WgradArgs a) {
+    const int64_t wg = blockIdx.x;
+    int ji = 0;
+    for (int q = 1; q < a.njobs; ++q)
+        if ((int)wg >= a.jobs[q].wg_start) ji = q;
+    const JobDev jb = a.jobs[ji];
+    const int nks = (ji + 1 < a.njobs ? a.jobs[ji + 1].wg_start : a.total_wgs) - jb.wg_start;
+    const int ks = (int)wg - jb.wg_start;
+    const int64_t t0 = a.nt * ks / nks, t1 = a.nt * (ks + 1) / nks;
+    const int lane = nh_lane(), wave = nh_wave_in_block();
+    const bool active = wave < jb.wo * jb.wi;
+    const int ow = wave / jb.wi, iw = wave % jb.wi;
+    if (!active) return;  // no workgroup-level synchronisation in this kernel
+    const int sel = jb.po * 8 + jb.pi;
+    switch (sel) {
+        case 4 * 8 + 4: wgrad_body<4, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
+        case 4 * 8 + 2: wgrad_body<4, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
+        case 4 * 8 + 1: wgrad_body<4, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
+        case 2 * 8 + 4: wgrad_body<2, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
+        case 2 * 8 + 2: wgrad_body<2, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
+        case 2 * 8 + 1: wgrad_body<2, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
+        case 1 * 8 + 4: wgrad_body<1, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
+        case 1 * 8 + 2: wgrad_body<1, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
+        default: wgrad_body<1, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
+    }
+}
+
+// fixed-order split-K reduction + scatter into the reference parameter layout
+NH_KERNEL void k_wgrad_reduce(WgradArgs a) {
+    const int ji = (int)(blockIdx.x >> 8);
+    const JobDev jb = a.jobs[ji];
+    const int local = (int)((blockIdx.x & 255u) * 256u + threadIdx.x);
+    const int lane = local & 63, c = (local >> 6) & 15, ab = (local >> 10) & 15, wave = local >> 14;
+    const int x = ab >> 2, y = ab & 3;
+    if (wave >= jb.wo * jb.wi || x >= jb.po || y >= jb.pi) return;
+    const int ow = wave / jb.wi, iw = wave % jb.wi;
+    const int a_t = ow * jb.po + x, b_t = iw * jb.pi + y;
+    if (a_t >= jb.a_tiles || b_t >= jb.b_tiles) return;
+    const int nks = (ji + 1 < a.njobs ? a.jobs[ji + 1].wg_start : a.total_wgs) - jb.wg_start;
+    const int out_row = 32 * a_t + (c & 3) + 8 * (c >> 2) + 4 * (lane >> 5);
+    const int in_row = 32 * b_t + (lane & 31);
+    if (out_row >= jb.r_lo && out_row < jb.r_hi) {
+        int col = -1;
+        if (jb.col_kind == 0) {
+            if (in_row < jb.col_count) col = jb.col_base + in_row;
+        } else {
+            const int r = in_row >> 1, hh = in_row & 1;
+            const int cc = jb.col_kind == 1 ? (int)a.xcol[hh][r] : (int)a.dcol[hh][r];
+            if (cc >= 0) col = jb.col_base + cc;
+        }
+        if (col >= 0) {
+            float s = 0.0f;
+            const float* p = a.partial + (size_t)jb.wg_start * NH_PART + ((size_t)(wave * 16 + ab) * 16 + c) * 64 + lane;
+            for (int q = 0; q < nks; ++q) s += p[(size_t)q * NH_PART];
+            a.g_params[(size_t)jb.w_off + (size_t)(out_row - jb.r_lo) * jb.w_ld + col] = s;
+        }
+    }
+    if (jb.bias_off >= 0 && iw == 0 && y == 0 && c == 0 && lane < 32) {
+        const int brow = 32 * a_t + lane;
+        if (brow >= jb.r_lo && brow < jb.r_hi) {
+            float s = 0.0f;
+            const float* p = a.partial + (size_t)jb.wg_start * NH_PART + 65536 + (wave * 4 + x) * 32 + lane;
+            for (int q = 0; q < nks; ++q) s += p[(size_t)q * NH_PART];
+            a.g_params[(size_t)jb.bias_off + (brow - jb.r_lo)] = s;
+        }
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------
+constexpr int NH_WGRAD_TARGET_WGS = 1024;
+
+void wgrad_schedule(const nerfhip_plan* p, int64_t nt, WgradArgs& w) {
+    int64_t total_cost = 0;
+    for (const NhJob& j : p->jobs) total_cost += j.cost;
+    w.njobs = (int)p->jobs.size();
+    int start = 0;
+    for (int q = 0; q < w.njobs; ++q) {
+        const NhJob& j = p->jobs[q];
+        int64_t ks = (NH_WGRAD_TARGET_WGS * (int64_t)j.cost + total_cost / 2) / total_cost;
+        if (ks < 1) ks = 1;
+        if (ks > nt) ks = nt;
+        JobDev& d = w.jobs[q];
+        d.a_rows = j.a_region_rows;
+        d.a_prefix = (int)j.a_row_prefix;
+        d.a_tiles = j.a_tiles;
+        d.b_rows = j.b_region_rows;
+        d.b_prefix = (int)j.b_row_prefix;
+        d.b_row0 = j.b_row0;
+        d.b_tiles = j.b_tiles;
+        d.wo = j.wo;
+        d.wi = j.wi;
+        d.po = j.po;
+        d.pi = j.pi;
+        d.r_lo = j.r_lo;
+        d.r_hi = j.r_hi;
+        d.w_off = (int)j.w_off;
+        d.w_ld = j.w_ld;
+        d.col_kind = j.col_kind;
+        d.col_base = j.col_base;
+        d.col_count = j.col_count;
+        d.bias_off = (int)j.bias_off;
+        d.wg_start = start;
+        start += (int)ks;
+    }
+    w.total_wgs = start;
+    for (int h = 0; h < 2; ++h) {
+        for (int r = 0; r < NH_KRX; ++r) w.xcol[h][r] = (short)p->xyz_col[h][r];
+        for (int r = 0; r < NH_KRD; ++r) w.dcol[h][r] = (short)p->dir_col[h][r];
+    }
+}
+
+template <class K>
+int set_lds_limit(K kern, int bytes) {
+#ifndef NERFHIP_EMU
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        nh_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d): %s", bytes, hipGetErrorString(e));
+        return NERFHIP_ERR_LAUNCH;
+    }
+#else
+    (void)kern;
+    (void)bytes;
+#endif
+    return NERFHIP_OK;
+}
+
+}  // namespace
+
+int64_t nh_mlp_bwd_scratch_bytes(nerfhip_plan* p, int64_t M) {
+    const int64_t nt = nh_ceil_div(M, 128) * 4;
+    WgradArgs w;
+    wgrad_schedule(p, nt > 0 ? nt : 1, w);
+    return (nt * p->grad.total_rows * 32 + (int64_t)w.total_wgs * NH_PART) * (int64_t)sizeof(float);
+}
+
+int nh_mlp_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
+                   nerfhip_stream_t stream) {
+    NH_REQUIRE(p && packed && out && M >= 0, "mlp_fwd: bad arguments");
+    if (M == 0) return NERFHIP_OK;
+    MlpFwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.packed = packed;
+    a.off = p->po;
+    a.L = p->L;
+    a.skip = p->skip;
+    a.M = M;
+    a.nt = nh_ceil_div(M, 128) * 4;
+    a.mode = in.mode;
+    a.x = in.x;
+    a.dx = p->Dx;
+    a.dd = p->Dd;
+    a.rays = in.rays;
+    a.ray_stride = in.ray_stride;
+    a.z = in.z;
+    a.S = in.S;
+    for (int h = 0; h < 2; ++h) {
+        for (int r = 0; r < NH_KRX; ++r) a.xcol[h][r] = (short)p->xyz_col[h][r];
+        for (int r = 0; r < NH_KRD; ++r) a.dcol[h][r] = (short)p->dir_col[h][r];
+    }
+    if (in.mode == 1) {
+        NH_REQUIRE(p->freqs_set, "mlp_fwd: nerfhip_plan_set_freqs has not been called");
+        NH_REQUIRE(in.rays && in.z && in.S > 0 && in.ray_stride >= (p->view ? 11 : 8), "mlp_fwd: bad fused input");
+    } else {
+        NH_REQUIRE(in.x, "mlp_fwd: x is NULL");
+    }
+    for (int k = 0; k < 16; ++k) {
+        a.fx[k] = p->freqs_xyz[k];
+        a.fd[k] = p->freqs_dir[k];
+    }
+    a.Lx = p->cfg.num_encoding_fn_xyz;
+    a.Ld = p->view ? p->cfg.num_encoding_fn_dir : 0;
+    a.P0x = p->P0x;
+    a.P0d = p->P0d;
+    a.out = out;
+    a.stash = stash;
+    a.sl = p->stash;
+    const int64_t grid = nh_ceil_div(M, 128);
+    int rc = NERFHIP_OK;
+#define NH_FWD_CASE(WW, VV)                                                         \
+    {                                                                               \
+        rc = set_lds_limit(k_mlp_fwd<WW, VV>, Cfg<WW>::LDS_BYTES);                  \
+        if (rc) return rc;                                                          \
+        NH_LAUNCH((k_mlp_fwd<WW, VV>), grid, 256, Cfg<WW>::LDS_BYTES, stream, a);   \
+    }
+    if (p->W == 256 && p->view) NH_FWD_CASE(256, true)
+    else if (p->W == 256) NH_FWD_CASE(256, false)
+    else if (p->view) NH_FWD_CASE(128, true)
+    else NH_FWD_CASE(128, false)
+#undef NH_FWD_CASE
+    return nh_launch_status("mlp_fwd");
+}
+
+int nh_mlp_backward(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash,
+                    float* scratch, int64_t scratch_bytes, float* g_params, nerfhip_stream_t stream) {
+    NH_REQUIRE(p && packed && g_out && stash && scratch && g_params && M > 0, "mlp_bwd: bad arguments");
+    NH_REQUIRE(scratch_bytes >= nh_mlp_bwd_scratch_bytes(p, M), "mlp_bwd: scratch too small (%lld < %lld)",
+               (long long)scratch_bytes, (long long)nh_mlp_bwd_scratch_bytes(p, M));
+    const int64_t nt = nh_ceil_div(M, 128) * 4;
+    DgradArgs d;
+    memset(&d, 0, sizeof(d));
+    d.packed = packed;
+    d.off = p->po;
+    d.L = p->L;
+    d.M = M;
+    d.nt = nt;
+    d.g_out = g_out;
+    d.stash = stash;
+    d.sl = p->stash;
+    d.grad = scratch;
+    d.gl = p->grad;
+    const int64_t grid = nh_ceil_div(M, 128);
+    int rc = NERFHIP_OK;
+#define NH_BWD_CASE(WW, VV)                                                           \
+    {                                                                                 \
+        rc = set_lds_limit(k_mlp_dgrad<WW, VV>, Cfg<WW>::LDS_BYTES);                  \
+        if (rc) return rc;                                                            \
+        NH_LAUNCH((k_mlp_dgrad<WW, VV>), grid, 256, Cfg<WW>::LDS_BYTES, stream, d);   \
+    }
+    if (p->W == 256 && p->view) NH_BWD_CASE(256, true)
+    else if (p->W == 256) NH_BWD_CASE(256, false)
+    else if (p->view) NH_BWD_CASE(128, true)
+    else NH_BWD_CASE(128, false)
+#undef NH_BWD_CASE
+    rc = nh_launch_status("mlp_dgrad");
+    if (rc) return rc;
+
+    WgradArgs w;
+    memset(&w, 0, sizeof(w));
+    wgrad_schedule(p, nt, w);
+    w.stash = stash;
+    w.grad = scratch;
+    w.partial = scratch + (size_t)nt * (size_t)p->grad.total_rows * 32;
+    w.g_params = g_params;
+    w.nt = nt;
+    NH_LAUNCH(k_wgrad, w.total_wgs, 256, 0, stream, w);
+    rc = nh_launch_status("wgrad");
+    if (rc) return rc;
+    NH_LAUNCH(k_wgrad_reduce, w.njobs * 256, 256, 0, stream, w);
+    return nh_launch_status("wgrad_reduce");
+}
+
+extern "C" int64_t nerfhip_plan_bwd_scratch_bytes(nerfhip_plan_t plan, int64_t m) {
+    if (!plan || m < 0) return -1;
+    return nh_mlp_bwd_scratch_bytes(plan, m);
+}
+
+extern "C" int nerfhip_mlp_fwd(nerfhip_plan_t plan, const float* packed, const float* x, int64_t m, float* out,
+                               void* stash, nerfhip_stream_t stream) {
+    NhMlpInput in;
+    memset(&in, 0, sizeof(in));
+    in.mode = 0;
+    in.x = x;
+    return nh_mlp_forward(plan, packed, in, m, out, (float*)stash, stream);
+}
+
+extern "C" int nerfhip_mlp_bwd(nerfhip_plan_t plan, const float* packed, const float* g_out, int64_t m,
+                               const void* stash, void* scratch, int64_t scratch_bytes, float* g_params,
+                               nerfhip_stream_t stream) {
+    return nh_mlp_backward(plan, packed, g_out, m, (const float*)stash, (float*)scratch, scratch_bytes, g_params, stream);
+}

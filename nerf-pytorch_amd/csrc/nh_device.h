@@ -1,0 +1,108 @@
+// nh_device.h -- thin device-side vocabulary used by every kernel in this library.
+//
+// The product build is HIP for gfx950 only (hipcc --offload-arch=gfx950).  The same kernel
+// sources can also be compiled as plain C++ against tests/emu/nh_emu.h (-DNERFHIP_EMU): a
+// fibre-based wavefront emulator that exists ONLY so that the CPU test-suite can execute the
+// kernel index algebra without a GPU.  The emulator is test infrastructure; the product library
+// (libnerfhip.so) never contains it and the Python package never loads it.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include <math.h>
+
+#ifdef NERFHIP_EMU
+#include "nh_emu.h"
+#else
+#include <hip/hip_runtime.h>
+
+#define NH_KERNEL __global__
+#define NH_LB(threads, waves_per_simd) __launch_bounds__(threads, waves_per_simd)
+#define NH_DEVICE __device__ __forceinline__
+#define NH_SHARED __shared__
+#define NH_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) char name[]
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+NH_DEVICE int nh_lane() { return (int)(threadIdx.x & 63u); }
+NH_DEVICE int nh_wave_in_block() { return (int)(threadIdx.x >> 6); }
+NH_DEVICE void nh_block_sync() { __syncthreads(); }
+
+NH_DEVICE float nh_shfl(float v, int src) { return __shfl(v, src, 64); }
+NH_DEVICE int nh_shfl_i(int v, int src) { return __shfl(v, src, 64); }
+NH_DEVICE float nh_shfl_up(float v, int d) { return __shfl_up(v, d, 64); }
+NH_DEVICE float nh_shfl_down(float v, int d) { return __shfl_down(v, d, 64); }
+NH_DEVICE float nh_shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
+NH_DEVICE double nh_shfl_d(double v, int src) { return __shfl(v, src, 64); }
+NH_DEVICE double nh_shfl_up_d(double v, int d) { return __shfl_up(v, d, 64); }
+NH_DEVICE double nh_shfl_down_d(double v, int d) { return __shfl_down(v, d, 64); }
+NH_DEVICE double nh_shfl_xor_d(double v, int m) { return __shfl_xor(v, m, 64); }
+
+// D = A(32x2) * B(2x32) + C, exact fp32 (k-ordered fmaf chain).  Lane l supplies A[l&31][l>>5] and
+// B[l>>5][l&31]; D register c of lane l is D[(c&3) + 8*(c>>2) + 4*(l>>5)][l&31].
+NH_DEVICE f32x16 nh_mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+NH_DEVICE void nh_atomic_add(float* p, float v) { atomicAdd(p, v); }
+NH_DEVICE void nh_sincos(float x, float* s, float* c) { sincosf(x, s, c); }
+#endif  // NERFHIP_EMU
+
+// ---- helpers shared by both builds -------------------------------------------------------------------------------
+
+// Row (feature) index held by accumulator register c (0..15) of MFMA tile t for lane-half h.
+NH_DEVICE int nh_feat_of(int t, int c, int h) { return 32 * t + (c & 3) + 8 * (c >> 2) + 4 * h; }
+
+// wave-wide sums (all 64 lanes end with the total)
+NH_DEVICE float nh_wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += nh_shfl_xor(v, m);
+    return v;
+}
+NH_DEVICE double nh_wave_sum_d(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += nh_shfl_xor_d(v, m);
+    return v;
+}
+
+// Philox4x32-10 counter based RNG (Salmon et al.); production-mode random draws (see rng.hip).
+struct nh_u4 {
+    uint32_t x, y, z, w;
+};
+NH_DEVICE void nh_mulhilo(uint32_t a, uint32_t b, uint32_t* hi, uint32_t* lo) {
+    uint64_t p = (uint64_t)a * (uint64_t)b;
+    *hi = (uint32_t)(p >> 32);
+    *lo = (uint32_t)p;
+}
+NH_DEVICE nh_u4 nh_philox(uint64_t seed, uint64_t ctr_lo, uint32_t stream) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    nh_u4 c = {(uint32_t)ctr_lo, (uint32_t)(ctr_lo >> 32), stream, 0x9E3779B9u};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0, lo0, hi1, lo1;
+        nh_mulhilo(0xD2511F53u, c.x, &hi0, &lo0);
+        nh_mulhilo(0xCD9E8D57u, c.z, &hi1, &lo1);
+        nh_u4 n = {hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+        c = n;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+// uniform in [0,1): top 24 bits, exactly like torch's float conversion
+NH_DEVICE float nh_u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+// element e of stream `stream`: uniform
+NH_DEVICE float nh_rand_uniform(uint64_t seed, uint32_t stream, uint64_t e) {
+    nh_u4 r = nh_philox(seed, e, stream);
+    return nh_u01(r.x);
+}
+// element e of stream `stream`: standard normal (Box-Muller on two independent words)
+NH_DEVICE float nh_rand_normal(uint64_t seed, uint32_t stream, uint64_t e) {
+    nh_u4 r = nh_philox(seed, e, stream);
+    float u1 = 1.0f - nh_u01(r.x);  // (0,1]
+    float u2 = nh_u01(r.y);
+    float rad = sqrtf(-2.0f * logf(u1));
+    float s, c;
+    nh_sincos(6.283185307179586f * u2, &s, &c);
+    return rad * c;
+}

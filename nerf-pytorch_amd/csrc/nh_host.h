@@ -1,0 +1,35 @@
+// nh_host.h -- host-side plumbing shared by the C-ABI translation units.
+#pragma once
+#include "../../include/nerfhip.h"
+#include <string.h>
+
+#include "nh_device.h"
+
+void nh_set_error(const char* fmt, ...);
+
+#define NH_REQUIRE(cond, ...)          \
+    do {                               \
+        if (!(cond)) {                 \
+            nh_set_error(__VA_ARGS__); \
+            return NERFHIP_ERR_ARG;    \
+        }                              \
+    } while (0)
+
+#ifdef NERFHIP_EMU
+#define NH_LAUNCH(kern, grid, block, smem, stream, ...) \
+    emu::launch(emu::Dim3((unsigned)(grid)), emu::Dim3((unsigned)(block)), (size_t)(smem), [&]() { kern(__VA_ARGS__); })
+static inline int nh_launch_status(const char*) { return NERFHIP_OK; }
+#else
+#define NH_LAUNCH(kern, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (size_t)(smem), (hipStream_t)(stream), __VA_ARGS__)
+static inline int nh_launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        nh_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return NERFHIP_ERR_LAUNCH;
+    }
+    return NERFHIP_OK;
+}
+#endif
+
+static inline int64_t nh_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

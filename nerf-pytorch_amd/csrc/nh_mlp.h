@@ -1,0 +1,19 @@
+// nh_mlp.h -- internal host entry points of mlp.hip (used by the C ABI in mlp.hip and by fused.hip).
+#pragma once
+#include "nh_host.h"
+#include "nh_plan.h"
+
+struct NhMlpInput {
+    int mode;          // 0: encoded rows x [M, dim_xyz+dim_dir];  1: rays [n, ray_stride] + depths z [n, S] (M = n*S)
+    const float* x;
+    const float* rays;
+    int ray_stride;
+    const float* z;
+    int S;
+};
+
+int nh_mlp_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
+                   nerfhip_stream_t stream);
+int nh_mlp_backward(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash,
+                    float* scratch, int64_t scratch_bytes, float* g_params, nerfhip_stream_t stream);
+int64_t nh_mlp_bwd_scratch_bytes(nerfhip_plan* p, int64_t M);

@@ -1,0 +1,101 @@
+// nh_plan.h -- host-side description of one FlexibleNeRFModel (nerf/models.py:185-256) mapped onto the MFMA kernels:
+// flat parameter layout, packed-weight image, activation stash layout and the weight-gradient job list.
+//
+// Register/tile vocabulary used everywhere (see DESIGN.md "MLP data layout"):
+//   * a wavefront owns 32 sample points; lane l = (j = l & 31: sample, h = l >> 5: k-half);
+//   * an activation vector of F features lives in F/2 registers per lane: register r of lane (j,h) holds feature
+//       feat(r,h) = 32*(r>>4) + (r&3) + 8*((r>>2)&3) + 4*h       of sample j
+//     which is exactly the C/D layout of v_mfma_f32_32x32x2_f32, so a layer's output registers are the next layer's
+//     B operands with no data movement;
+//   * encodings use "slots": register r of lane (j,h) is slot (r,h); the slot -> reference-column map is baked into
+//     the packed weights (xyz: 32 registers = 64 slots, dir: 16 registers = 32 slots).
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/nerfhip.h"
+
+constexpr int NH_KRX = 32;         // registers of the xyz encoding (supports num_encoding_fn_xyz <= 10)
+constexpr int NH_KRD = 16;         // registers of the direction encoding (supports num_encoding_fn_dir <= 4)
+constexpr int NH_MAX_LAYERS = 16;  // num_layers limit
+constexpr int NH_MAX_JOBS = 48;
+
+static inline int nh_feat(int r, int h) { return 32 * (r >> 4) + (r & 3) + 8 * ((r >> 2) & 3) + 4 * h; }
+// floats of one packed weight chunk (one 32-row output tile): kr*64 weights + 32 biases
+static inline int64_t nh_chunk_floats(int kr) { return (int64_t)kr * 64 + 32; }
+
+struct NhTensor {
+    std::string name;
+    int64_t off;
+    int rows, cols;  // cols == 0 for a bias
+};
+
+// Offsets (in floats) of every layer inside the packed image, handed to the kernels by value.
+struct NhPackedOffsets {
+    int64_t f_layer1;
+    int64_t f_xyz[NH_MAX_LAYERS];
+    int64_t f_head;  // fc_feat + fc_alpha rows (viewdirs) or fc_out (no viewdirs)
+    int64_t f_dir;
+    int64_t f_rgb;
+    int64_t b_rgb;   // transposed images for the data-gradient chain
+    int64_t b_dir;
+    int64_t b_head;
+    int64_t b_xyz[NH_MAX_LAYERS];
+};
+
+// Activation stash regions: [tiles][rows][32 samples] each, `row_prefix` rows precede it inside a tile group.
+struct NhRegion {
+    int rows;
+    int64_t row_prefix;  // offset (floats) = 32 * n_tiles * row_prefix
+};
+struct NhStashLayout {
+    NhRegion X, D, H[NH_MAX_LAYERS], FEAT, DIRH;
+    int64_t total_rows;
+};
+struct NhGradLayout {  // d(pre-activation) scratch written by the data-gradient kernel
+    NhRegion P[NH_MAX_LAYERS], PFEAT, PDIR, POUT;
+    int64_t total_rows;
+};
+
+// One weight-gradient job: dW[out_rows, in_rows] = sum_samples A[out_row][sample] * B[in_row][sample].
+struct NhJob {
+    int a_region_rows;    // rows of the A region (tile stride = rows*32 floats)
+    int64_t a_row_prefix; // A region offset = 32*n_tiles*a_row_prefix (in the grad scratch)
+    int a_tiles;          // 32-row tiles of A covered by this job (starting at row 0 of the region)
+    int b_region_rows;
+    int64_t b_row_prefix; // B region offset in the activation stash
+    int b_row0;           // first row of B covered
+    int b_tiles;
+    int wo, wi, po, pi;   // wave grid (wo*wi <= 4) and per-wave patch in tiles (<= 4 x 4)
+    // unpack: out row r is real iff r_lo <= r < r_hi and maps to parameter row (r - r_lo)
+    int r_lo, r_hi;
+    int64_t w_off;        // flat offset of the weight tensor
+    int w_ld;             // its column count
+    int col_kind;         // 0: col = col_base + in_row (valid iff < col_base + col_count); 1: xyz slot map; 2: dir slot map
+    int col_base, col_count;
+    int64_t bias_off;     // flat offset of the bias tensor, or -1 (only one job per layer carries the bias)
+    int cost;             // po*pi
+};
+
+struct nerfhip_plan {
+    nerfhip_model_cfg cfg;
+    int W, L, skip, Dx, Dd, view;
+    int P0x, P0d;  // pairs handled by lane-half 0
+    std::vector<NhTensor> tensors;
+    int64_t nparams;
+    int t_layer1_w, t_layer1_b, t_xyz_w[NH_MAX_LAYERS], t_xyz_b[NH_MAX_LAYERS];
+    int t_dir_w, t_dir_b, t_alpha_w, t_alpha_b, t_rgb_w, t_rgb_b, t_feat_w, t_feat_b, t_out_w, t_out_b;
+    int xyz_col[2][NH_KRX];  // slot (r,h) -> reference column of the xyz encoding, or -1
+    int dir_col[2][NH_KRD];
+    float freqs_xyz[16], freqs_dir[16];
+    bool freqs_set;
+    NhPackedOffsets po;
+    int64_t packed_floats;
+    NhStashLayout stash;
+    NhGradLayout grad;
+    std::vector<NhJob> jobs;
+    bool is_skip(int i) const { return i % skip == 0 && i > 0; }
+    int kr_xyz(int i) const { return W / 2 + (is_skip(i) ? NH_KRX : 0); }
+};

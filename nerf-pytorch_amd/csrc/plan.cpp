@@ -1,0 +1,423 @@
+// plan.cpp -- host-only: builds the plan of nh_plan.h for a FlexibleNeRFModel geometry (nerf/models.py:185-231).
+#include <string.h>
+
+#include <functional>
+
+#include "nh_host.h"
+#include "nh_plan.h"
+
+namespace {
+
+int add_tensor(nerfhip_plan* p, const std::string& name, int rows, int cols) {
+    NhTensor t;
+    t.name = name;
+    t.off = p->nparams;
+    t.rows = rows;
+    t.cols = cols;
+    p->nparams += (int64_t)rows * (cols ? cols : 1);
+    p->tensors.push_back(t);
+    return (int)p->tensors.size() - 1;
+}
+
+// slot (r,h) -> reference column of positional_encoding's output (nerf/nerf_helpers.py:130-157), or -1.
+// Registers 0,1 carry the raw coordinates (h=0: x,y; h=1: z,pad); registers 2+2q / 3+2q carry sin / cos of the q-th
+// (frequency, axis) pair owned by that lane half: half 0 owns pairs [0,P0), half 1 owns [P0, 3L); pair p = 3*f + axis.
+void build_slot_map(int L, int include_input, int kr, int* col_h0, int* col_h1, int* p0_out) {
+    const int P = 3 * L, P0 = (P + 1) / 2, base = include_input ? 3 : 0;
+    *p0_out = P0;
+    for (int r = 0; r < kr; ++r) col_h0[r] = col_h1[r] = -1;
+    if (include_input) {
+        col_h0[0] = 0;
+        col_h0[1] = 1;
+        col_h1[0] = 2;
+    }
+    for (int q = 0; 3 + 2 * q < kr; ++q) {
+        for (int h = 0; h < 2; ++h) {
+            int p = q + h * P0;
+            bool valid = h == 0 ? q < P0 : p < P;
+            if (!valid) continue;
+            int f = p / 3, a = p % 3;
+            int* col = h ? col_h1 : col_h0;
+            col[2 + 2 * q] = base + 6 * f + a;
+            col[3 + 2 * q] = base + 6 * f + 3 + a;
+        }
+    }
+}
+
+struct GemmSpec {
+    int kr = 0, tiles = 0;
+    std::function<int64_t(int, int, int)> w;  // (out_row, r, h) -> flat param index or -1
+    std::function<int64_t(int)> b;            // out_row -> flat param index or -1
+};
+
+int64_t spec_floats(const GemmSpec& s) { return (int64_t)s.tiles * nh_chunk_floats(s.kr); }
+
+void fill_spec(const GemmSpec& s, int64_t off, int32_t* table) {
+    for (int t = 0; t < s.tiles; ++t) {
+        int32_t* ch = table + off + (int64_t)t * nh_chunk_floats(s.kr);
+        for (int r = 0; r < s.kr; ++r)
+            for (int lane = 0; lane < 64; ++lane) {
+                int i = lane & 31, h = lane >> 5;
+                int64_t src = s.w(32 * t + i, r, h);
+                ch[((r >> 2) * 64 + lane) * 4 + (r & 3)] = (int32_t)src;
+            }
+        for (int row = 0; row < 32; ++row) ch[(int64_t)s.kr * 64 + row] = s.b ? (int32_t)s.b(32 * t + row) : -1;
+    }
+}
+
+struct Specs {
+    GemmSpec f_layer1, f_xyz[NH_MAX_LAYERS], f_head, f_dir, f_rgb, b_rgb, b_dir, b_head, b_xyz[NH_MAX_LAYERS];
+};
+
+void build_specs(const nerfhip_plan* p, Specs& S) {
+    const int W = p->W, KH = W / 2, Dx = p->Dx, Dd = p->Dd, L = p->L;
+    auto T = [p](int idx) { return p->tensors[idx]; };
+    {
+        GemmSpec& s = S.f_layer1;
+        s.kr = NH_KRX;
+        s.tiles = W / 32;
+        NhTensor w = T(p->t_layer1_w), b = T(p->t_layer1_b);
+        s.w = [=](int o, int r, int h) -> int64_t {
+            int c = p->xyz_col[h][r];
+            return (o < W && c >= 0) ? w.off + (int64_t)o * Dx + c : -1;
+        };
+        s.b = [=](int o) -> int64_t { return o < W ? b.off + o : -1; };
+    }
+    for (int i = 0; i < L - 1; ++i) {
+        GemmSpec& s = S.f_xyz[i];
+        const bool sk = p->is_skip(i);
+        s.kr = p->kr_xyz(i);
+        s.tiles = W / 32;
+        NhTensor w = T(p->t_xyz_w[i]), b = T(p->t_xyz_b[i]);
+        const int ld = W + (sk ? Dx : 0);
+        s.w = [=](int o, int r, int h) -> int64_t {
+            if (r < KH) return w.off + (int64_t)o * ld + nh_feat(r, h);
+            int c = p->xyz_col[h][r - KH];
+            return c >= 0 ? w.off + (int64_t)o * ld + W + c : -1;
+        };
+        s.b = [=](int o) -> int64_t { return b.off + o; };
+        GemmSpec& bt = S.b_xyz[i];  // dh_in[f] = sum_u W[u][f] dpre[u]   (hidden columns only)
+        bt.kr = KH;
+        bt.tiles = W / 32;
+        bt.w = [=](int f, int r, int h) -> int64_t { return w.off + (int64_t)nh_feat(r, h) * ld + f; };
+    }
+    if (p->view) {
+        NhTensor fw = T(p->t_feat_w), fb = T(p->t_feat_b), aw = T(p->t_alpha_w), ab = T(p->t_alpha_b);
+        NhTensor dw = T(p->t_dir_w), db = T(p->t_dir_b), rw = T(p->t_rgb_w), rb = T(p->t_rgb_b);
+        {
+            GemmSpec& s = S.f_head;  // rows 0..W-1 = fc_feat, row W = fc_alpha
+            s.kr = KH;
+            s.tiles = W / 32 + 1;
+            s.w = [=](int o, int r, int h) -> int64_t {
+                if (o < W) return fw.off + (int64_t)o * W + nh_feat(r, h);
+                if (o == W) return aw.off + nh_feat(r, h);
+                return -1;
+            };
+            s.b = [=](int o) -> int64_t { return o < W ? fb.off + o : (o == W ? ab.off : -1); };
+        }
+        {
+            GemmSpec& s = S.f_dir;
+            s.kr = KH + NH_KRD;
+            s.tiles = W / 64;
+            const int ld = W + Dd;
+            s.w = [=](int o, int r, int h) -> int64_t {
+                if (r < KH) return dw.off + (int64_t)o * ld + nh_feat(r, h);
+                int c = p->dir_col[h][r - KH];
+                return c >= 0 ? dw.off + (int64_t)o * ld + W + c : -1;
+            };
+            s.b = [=](int o) -> int64_t { return db.off + o; };
+        }
+        {
+            GemmSpec& s = S.f_rgb;
+            s.kr = KH / 2;
+            s.tiles = 1;
+            s.w = [=](int o, int r, int h) -> int64_t { return o < 3 ? rw.off + (int64_t)o * (W / 2) + nh_feat(r, h) : -1; };
+            s.b = [=](int o) -> int64_t { return o < 3 ? rb.off + o : -1; };
+        }
+        {
+            GemmSpec& s = S.b_rgb;  // d(dir hidden)[f] = sum_{rho<3} Wrgb[rho][f] d_rgb[rho]
+            s.kr = 4;
+            s.tiles = W / 64;
+            s.w = [=](int f, int r, int h) -> int64_t {
+                int rho = nh_feat(r, h);
+                return rho < 3 ? rw.off + (int64_t)rho * (W / 2) + f : -1;
+            };
+        }
+        {
+            GemmSpec& s = S.b_dir;  // d(feat)[f] = sum_u Wdir[u][f] dpre_dir[u]
+            s.kr = KH / 2;
+            s.tiles = W / 32;
+            const int ld = W + Dd;
+            s.w = [=](int f, int r, int h) -> int64_t { return dw.off + (int64_t)nh_feat(r, h) * ld + f; };
+        }
+        {
+            GemmSpec& s = S.b_head;  // dh[f] = sum_u Wfeat[u][f] dpre_feat[u] + Walpha[0][f] d_alpha
+            s.kr = KH + 4;
+            s.tiles = W / 32;
+            s.w = [=](int f, int r, int h) -> int64_t {
+                if (r < KH) return fw.off + (int64_t)nh_feat(r, h) * W + f;
+                return nh_feat(r - KH, h) == 0 ? aw.off + f : -1;
+            };
+        }
+    } else {
+        NhTensor ow = T(p->t_out_w), ob = T(p->t_out_b);
+        GemmSpec& s = S.f_head;  // fc_out
+        s.kr = KH;
+        s.tiles = 1;
+        s.w = [=](int o, int r, int h) -> int64_t { return o < 4 ? ow.off + (int64_t)o * W + nh_feat(r, h) : -1; };
+        s.b = [=](int o) -> int64_t { return o < 4 ? ob.off + o : -1; };
+        GemmSpec& bt = S.b_head;
+        bt.kr = 4;
+        bt.tiles = W / 32;
+        bt.w = [=](int f, int r, int h) -> int64_t {
+            int rho = nh_feat(r, h);
+            return rho < 4 ? ow.off + (int64_t)rho * W + f : -1;
+        };
+    }
+}
+
+void layout_packed(nerfhip_plan* p) {
+    Specs S;
+    build_specs(p, S);
+    int64_t off = 0;
+    auto place = [&](const GemmSpec& s, int64_t* dst) {
+        *dst = off;
+        off += spec_floats(s);
+    };
+    memset(&p->po, 0, sizeof(p->po));
+    place(S.f_layer1, &p->po.f_layer1);
+    for (int i = 0; i < p->L - 1; ++i) place(S.f_xyz[i], &p->po.f_xyz[i]);
+    place(S.f_head, &p->po.f_head);
+    if (p->view) {
+        place(S.f_dir, &p->po.f_dir);
+        place(S.f_rgb, &p->po.f_rgb);
+        place(S.b_rgb, &p->po.b_rgb);
+        place(S.b_dir, &p->po.b_dir);
+    }
+    place(S.b_head, &p->po.b_head);
+    for (int i = 0; i < p->L - 1; ++i) place(S.b_xyz[i], &p->po.b_xyz[i]);
+    p->packed_floats = off;
+}
+
+NhRegion add_region(int64_t* total, int rows) {
+    NhRegion r;
+    r.rows = rows;
+    r.row_prefix = *total;
+    *total += rows;
+    return r;
+}
+
+void add_job(nerfhip_plan* p, const NhRegion& A, int a_tiles, const NhRegion& B, int b_row0, int b_tiles, int r_lo,
+             int r_hi, int w_tensor, int col_kind, int col_base, int col_count, int bias_tensor) {
+    NhJob j;
+    memset(&j, 0, sizeof(j));
+    j.a_region_rows = A.rows;
+    j.a_row_prefix = A.row_prefix;
+    j.a_tiles = a_tiles;
+    j.b_region_rows = B.rows;
+    j.b_row_prefix = B.row_prefix;
+    j.b_row0 = b_row0;
+    j.b_tiles = b_tiles;
+    // wave grid: give the 4 waves of a workgroup equal patches of at most 4 x 4 tiles
+    int best_wo = 1, best_wi = 1, best_cost = 1 << 30;
+    for (int wo = 1; wo <= 4; wo *= 2)
+        for (int wi = 1; wo * wi <= 4; wi *= 2) {
+            int po = (a_tiles + wo - 1) / wo, pi = (b_tiles + wi - 1) / wi;
+            if (po > 4 || pi > 4 || po == 3 || pi == 3) continue;
+            int cost = po * pi;
+            if (cost < best_cost || (cost == best_cost && wo * wi < best_wo * best_wi)) {
+                best_cost = cost;
+                best_wo = wo;
+                best_wi = wi;
+            }
+        }
+    j.wo = best_wo;
+    j.wi = best_wi;
+    j.po = (a_tiles + j.wo - 1) / j.wo;
+    j.pi = (b_tiles + j.wi - 1) / j.wi;
+    j.cost = j.po * j.pi;
+    j.r_lo = r_lo;
+    j.r_hi = r_hi;
+    j.w_off = p->tensors[w_tensor].off;
+    j.w_ld = p->tensors[w_tensor].cols;
+    j.col_kind = col_kind;
+    j.col_base = col_base;
+    j.col_count = col_count;
+    j.bias_off = bias_tensor >= 0 ? p->tensors[bias_tensor].off : -1;
+    p->jobs.push_back(j);
+}
+
+void build_layouts_and_jobs(nerfhip_plan* p) {
+    const int W = p->W, L = p->L;
+    NhStashLayout& S = p->stash;
+    memset(&S, 0, sizeof(S));
+    S.total_rows = 0;
+    S.X = add_region(&S.total_rows, 2 * NH_KRX);
+    if (p->view) S.D = add_region(&S.total_rows, 2 * NH_KRD);
+    for (int k = 0; k < L; ++k) S.H[k] = add_region(&S.total_rows, W);
+    if (p->view) {
+        S.FEAT = add_region(&S.total_rows, W);
+        S.DIRH = add_region(&S.total_rows, W / 2);
+    }
+    NhGradLayout& G = p->grad;
+    memset(&G, 0, sizeof(G));
+    G.total_rows = 0;
+    for (int k = 0; k < L; ++k) G.P[k] = add_region(&G.total_rows, W);
+    if (p->view) {
+        G.PFEAT = add_region(&G.total_rows, W);
+        G.PDIR = add_region(&G.total_rows, W / 2);
+    }
+    G.POUT = add_region(&G.total_rows, 32);
+
+    p->jobs.clear();
+    const int TW = W / 32;
+    // layer1: dP_0 x X
+    add_job(p, G.P[0], TW, S.X, 0, 2, 0, W, p->t_layer1_w, 1, 0, p->Dx, p->t_layer1_b);
+    for (int i = 0; i < L - 1; ++i) {
+        add_job(p, G.P[i + 1], TW, S.H[i], 0, TW, 0, W, p->t_xyz_w[i], 0, 0, W, p->t_xyz_b[i]);
+        if (p->is_skip(i)) add_job(p, G.P[i + 1], TW, S.X, 0, 2, 0, W, p->t_xyz_w[i], 1, W, p->Dx, -1);
+    }
+    if (p->view) {
+        add_job(p, G.PFEAT, TW, S.H[L - 1], 0, TW, 0, W, p->t_feat_w, 0, 0, W, p->t_feat_b);
+        add_job(p, G.POUT, 1, S.H[L - 1], 0, TW, 3, 4, p->t_alpha_w, 0, 0, W, p->t_alpha_b);
+        add_job(p, G.PDIR, TW / 2, S.FEAT, 0, TW, 0, W / 2, p->t_dir_w, 0, 0, W, p->t_dir_b);
+        add_job(p, G.PDIR, TW / 2, S.D, 0, 1, 0, W / 2, p->t_dir_w, 2, W, p->Dd, -1);
+        add_job(p, G.POUT, 1, S.DIRH, 0, TW / 2, 0, 3, p->t_rgb_w, 0, 0, W / 2, p->t_rgb_b);
+    } else {
+        add_job(p, G.POUT, 1, S.H[L - 1], 0, TW, 0, 4, p->t_out_w, 0, 0, W, p->t_out_b);
+    }
+}
+
+}  // namespace
+
+extern "C" nerfhip_plan_t nerfhip_plan_create(const nerfhip_model_cfg* cfg) {
+    if (!cfg) {
+        nh_set_error("plan_create: cfg is NULL");
+        return nullptr;
+    }
+    if (cfg->hidden_size != 128 && cfg->hidden_size != 256) {
+        nh_set_error("plan_create: hidden_size must be 128 or 256 (got %d)", cfg->hidden_size);
+        return nullptr;
+    }
+    if (cfg->num_layers < 1 || cfg->num_layers > NH_MAX_LAYERS) {
+        nh_set_error("plan_create: num_layers must be in [1,%d] (got %d)", NH_MAX_LAYERS, cfg->num_layers);
+        return nullptr;
+    }
+    if (cfg->skip_connect_every < 1) {
+        nh_set_error("plan_create: skip_connect_every must be >= 1");
+        return nullptr;
+    }
+    if (cfg->num_encoding_fn_xyz < 0 || cfg->num_encoding_fn_xyz > 10 || cfg->num_encoding_fn_dir < 0 ||
+        cfg->num_encoding_fn_dir > 4) {
+        nh_set_error("plan_create: num_encoding_fn_xyz must be <= 10 and num_encoding_fn_dir <= 4 (got %d, %d)",
+                     cfg->num_encoding_fn_xyz, cfg->num_encoding_fn_dir);
+        return nullptr;
+    }
+    nerfhip_plan* p = new nerfhip_plan();
+    p->cfg = *cfg;
+    p->W = cfg->hidden_size;
+    p->L = cfg->num_layers;
+    p->skip = cfg->skip_connect_every;
+    p->view = cfg->use_viewdirs ? 1 : 0;
+    p->Dx = (cfg->include_input_xyz ? 3 : 0) + 6 * cfg->num_encoding_fn_xyz;
+    p->Dd = p->view ? (cfg->include_input_dir ? 3 : 0) + 6 * cfg->num_encoding_fn_dir : 0;
+    if (p->Dx == 0) {
+        nh_set_error("plan_create: empty xyz encoding");
+        delete p;
+        return nullptr;
+    }
+    p->nparams = 0;
+    p->freqs_set = false;
+    const int W = p->W, L = p->L;
+    // registration order of nerf/models.py:205-229
+    p->t_layer1_w = add_tensor(p, "layer1.weight", W, p->Dx);
+    p->t_layer1_b = add_tensor(p, "layer1.bias", W, 0);
+    for (int i = 0; i < L - 1; ++i) {
+        std::string n = "layers_xyz." + std::to_string(i);
+        p->t_xyz_w[i] = add_tensor(p, n + ".weight", W, W + (p->is_skip(i) ? p->Dx : 0));
+        p->t_xyz_b[i] = add_tensor(p, n + ".bias", W, 0);
+    }
+    p->t_dir_w = p->t_dir_b = p->t_alpha_w = p->t_alpha_b = p->t_rgb_w = p->t_rgb_b = p->t_feat_w = p->t_feat_b = -1;
+    p->t_out_w = p->t_out_b = -1;
+    if (p->view) {
+        p->t_dir_w = add_tensor(p, "layers_dir.0.weight", W / 2, W + p->Dd);
+        p->t_dir_b = add_tensor(p, "layers_dir.0.bias", W / 2, 0);
+        p->t_alpha_w = add_tensor(p, "fc_alpha.weight", 1, W);
+        p->t_alpha_b = add_tensor(p, "fc_alpha.bias", 1, 0);
+        p->t_rgb_w = add_tensor(p, "fc_rgb.weight", 3, W / 2);
+        p->t_rgb_b = add_tensor(p, "fc_rgb.bias", 3, 0);
+        p->t_feat_w = add_tensor(p, "fc_feat.weight", W, W);
+        p->t_feat_b = add_tensor(p, "fc_feat.bias", W, 0);
+    } else {
+        p->t_out_w = add_tensor(p, "fc_out.weight", 4, W);
+        p->t_out_b = add_tensor(p, "fc_out.bias", 4, 0);
+    }
+    build_slot_map(cfg->num_encoding_fn_xyz, cfg->include_input_xyz ? 1 : 0, NH_KRX, p->xyz_col[0], p->xyz_col[1],
+                   &p->P0x);
+    build_slot_map(p->view ? cfg->num_encoding_fn_dir : 0, (p->view && cfg->include_input_dir) ? 1 : 0, NH_KRD,
+                   p->dir_col[0], p->dir_col[1], &p->P0d);
+    for (int k = 0; k < 16; ++k) {
+        p->freqs_xyz[k] = 0.f;
+        p->freqs_dir[k] = 0.f;
+    }
+    layout_packed(p);
+    build_layouts_and_jobs(p);
+    if ((int)p->jobs.size() > NH_MAX_JOBS) {
+        nh_set_error("plan_create: too many gradient jobs");
+        delete p;
+        return nullptr;
+    }
+    return p;
+}
+
+extern "C" void nerfhip_plan_destroy(nerfhip_plan_t plan) { delete plan; }
+extern "C" int64_t nerfhip_plan_num_params(nerfhip_plan_t plan) { return plan ? plan->nparams : -1; }
+extern "C" int nerfhip_plan_dim_xyz(nerfhip_plan_t plan) { return plan ? plan->Dx : -1; }
+extern "C" int nerfhip_plan_dim_dir(nerfhip_plan_t plan) { return plan ? plan->Dd : -1; }
+extern "C" int nerfhip_plan_num_tensors(nerfhip_plan_t plan) { return plan ? (int)plan->tensors.size() : -1; }
+extern "C" int nerfhip_plan_tensor_info(nerfhip_plan_t plan, int i, const char** name, int64_t* offset, int* rows,
+                                        int* cols) {
+    NH_REQUIRE(plan && i >= 0 && i < (int)plan->tensors.size(), "plan_tensor_info: bad index");
+    const NhTensor& t = plan->tensors[i];
+    if (name) *name = t.name.c_str();
+    if (offset) *offset = t.off;
+    if (rows) *rows = t.rows;
+    if (cols) *cols = t.cols;
+    return NERFHIP_OK;
+}
+extern "C" int64_t nerfhip_plan_packed_floats(nerfhip_plan_t plan) { return plan ? plan->packed_floats : -1; }
+
+extern "C" int nerfhip_plan_pack_index(nerfhip_plan_t plan, int32_t* host_table) {
+    NH_REQUIRE(plan && host_table, "plan_pack_index: bad arguments");
+    Specs S;
+    build_specs(plan, S);
+    const NhPackedOffsets& o = plan->po;
+    fill_spec(S.f_layer1, o.f_layer1, host_table);
+    for (int i = 0; i < plan->L - 1; ++i) fill_spec(S.f_xyz[i], o.f_xyz[i], host_table);
+    fill_spec(S.f_head, o.f_head, host_table);
+    if (plan->view) {
+        fill_spec(S.f_dir, o.f_dir, host_table);
+        fill_spec(S.f_rgb, o.f_rgb, host_table);
+        fill_spec(S.b_rgb, o.b_rgb, host_table);
+        fill_spec(S.b_dir, o.b_dir, host_table);
+    }
+    fill_spec(S.b_head, o.b_head, host_table);
+    for (int i = 0; i < plan->L - 1; ++i) fill_spec(S.b_xyz[i], o.b_xyz[i], host_table);
+    return NERFHIP_OK;
+}
+
+extern "C" int nerfhip_plan_set_freqs(nerfhip_plan_t plan, const float* freqs_xyz, const float* freqs_dir) {
+    NH_REQUIRE(plan && freqs_xyz, "plan_set_freqs: bad arguments");
+    for (int k = 0; k < 16; ++k) {
+        plan->freqs_xyz[k] = k < plan->cfg.num_encoding_fn_xyz ? freqs_xyz[k] : 0.f;
+        plan->freqs_dir[k] = (freqs_dir && plan->view && k < plan->cfg.num_encoding_fn_dir) ? freqs_dir[k] : 0.f;
+    }
+    plan->freqs_set = true;
+    return NERFHIP_OK;
+}
+
+extern "C" int64_t nerfhip_plan_stash_bytes(nerfhip_plan_t plan, int64_t m) {
+    if (!plan || m < 0) return -1;
+    int64_t tiles = nh_ceil_div(m, 128) * 4;
+    return tiles * plan->stash.total_rows * 32 * (int64_t)sizeof(float);
+}

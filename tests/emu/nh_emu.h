@@ -1,0 +1,128 @@
+// nh_emu.h -- TEST INFRASTRUCTURE ONLY.
+//
+// A minimal wavefront emulator: lets the CPU test-suite execute the library's HIP kernel sources
+// (compiled as plain C++ with -DNERFHIP_EMU) so that index algebra, weight packing, LDS addressing
+// and barrier placement can be checked in a container that has no GPU.  Every thread of a
+// workgroup is a fibre (hand-rolled x86-64 context switch); wave-level operations (shuffles, MFMA)
+// and __syncthreads() are rendezvous points.  Blocks run one after another.  Nothing here is part
+// of the product: libnerfhip.so is built by hipcc for gfx950 and never sees this header.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+#include <math.h>
+#include <functional>
+
+namespace emu {
+struct Dim3 {
+    unsigned x, y, z;
+    Dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
+};
+struct Fiber {
+    void* sp;
+    char* stack;
+    Dim3 tid;
+    int lin, lane, wave;
+    int xphase;
+    bool done;
+};
+struct WaveState {
+    int live, arrived;
+    unsigned gen;
+    uint64_t xa[2][64];
+    uint64_t xb[2][64];
+};
+extern Fiber* cur;
+extern Dim3 g_blockIdx, g_blockDim, g_gridDim;
+extern char* g_dyn_smem;
+WaveState& cur_wave();
+void wave_barrier();
+void block_barrier();
+void launch(Dim3 grid, Dim3 block, size_t smem, const std::function<void()>& body);
+}  // namespace emu
+
+#define threadIdx (emu::cur->tid)
+#define blockIdx (emu::g_blockIdx)
+#define blockDim (emu::g_blockDim)
+#define gridDim (emu::g_gridDim)
+
+#define NH_KERNEL
+#define NH_LB(threads, waves_per_simd)
+#define NH_DEVICE static inline
+#define NH_SHARED static
+#define NH_DYN_LDS(name) char* name = emu::g_dyn_smem
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct float4 {
+    float x, y, z, w;
+};
+struct float2 {
+    float x, y;
+};
+static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
+static inline float2 make_float2(float a, float b) { return float2{a, b}; }
+
+NH_DEVICE int nh_lane() { return emu::cur->lane; }
+NH_DEVICE int nh_wave_in_block() { return emu::cur->wave; }
+NH_DEVICE void nh_block_sync() { emu::block_barrier(); }
+
+template <class T>
+static inline T nh_emu_xchg(T v, int src) {
+    static_assert(sizeof(T) <= 8, "xchg");
+    emu::WaveState& w = emu::cur_wave();
+    int ph = emu::cur->xphase;
+    emu::cur->xphase ^= 1;
+    uint64_t raw = 0;
+    memcpy(&raw, &v, sizeof(T));
+    w.xa[ph][emu::cur->lane] = raw;
+    emu::wave_barrier();
+    T out = v;
+    if (src >= 0 && src < 64) memcpy(&out, &w.xa[ph][src], sizeof(T));
+    return out;
+}
+NH_DEVICE float nh_shfl(float v, int src) { return nh_emu_xchg(v, src & 63); }
+NH_DEVICE int nh_shfl_i(int v, int src) { return nh_emu_xchg(v, src & 63); }
+NH_DEVICE float nh_shfl_up(float v, int d) { return nh_emu_xchg(v, emu::cur->lane - d); }
+NH_DEVICE float nh_shfl_down(float v, int d) { return nh_emu_xchg(v, emu::cur->lane + d); }
+NH_DEVICE float nh_shfl_xor(float v, int m) { return nh_emu_xchg(v, emu::cur->lane ^ m); }
+NH_DEVICE double nh_shfl_d(double v, int src) { return nh_emu_xchg(v, src & 63); }
+NH_DEVICE double nh_shfl_up_d(double v, int d) { return nh_emu_xchg(v, emu::cur->lane - d); }
+NH_DEVICE double nh_shfl_down_d(double v, int d) { return nh_emu_xchg(v, emu::cur->lane + d); }
+NH_DEVICE double nh_shfl_xor_d(double v, int m) { return nh_emu_xchg(v, emu::cur->lane ^ m); }
+
+// v_mfma_f32_32x32x2_f32 semantics as documented for gfx950: lane l supplies A[l&31][l>>5] and
+// B[l>>5][l&31]; result register c of lane l is D[(c&3)+8*(c>>2)+4*(l>>5)][l&31]; the sum over k
+// is a k-ordered fmaf chain.
+NH_DEVICE f32x16 nh_mfma32(float a, float b, f32x16 c) {
+    emu::WaveState& w = emu::cur_wave();
+    int ph = emu::cur->xphase;
+    emu::cur->xphase ^= 1;
+    int lane = emu::cur->lane;
+    uint64_t ra = 0, rb = 0;
+    memcpy(&ra, &a, 4);
+    memcpy(&rb, &b, 4);
+    w.xa[ph][lane] = ra;
+    w.xb[ph][lane] = rb;
+    emu::wave_barrier();
+    int j = lane & 31, h = lane >> 5;
+    f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) {
+            float av, bv;
+            memcpy(&av, &w.xa[ph][i + 32 * k], 4);
+            memcpy(&bv, &w.xb[ph][j + 32 * k], 4);
+            acc = fmaf(av, bv, acc);
+        }
+        d[r] = acc;
+    }
+    return d;
+}
+
+NH_DEVICE void nh_atomic_add(float* p, float v) { *p += v; }
+NH_DEVICE void nh_sincos(float x, float* s, float* c) {
+    *s = sinf(x);
+    *c = cosf(x);
+}

@@ -1,0 +1,216 @@
+#!/usr/bin/env python
+"""bench.py -- NeRF training-iteration throughput on MI355X (BASELINE.json metric: train rays/sec, lego 400x400,
+64 coarse + 128 fine samples, 4096 rays/iter, 8x256 nets).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+One "step" = one full training iteration of the reference's loop body (train_nerf.py:210-270) on synthetic data of the
+configured shape: select 4096 pixels of a 400x400 view -> generate those rays -> coarse+fine render forward (stratified
++ inverse-CDF sampling, positional encoding, two 8x256 MLPs, compositing) -> MSE loss -> backward through both nets ->
+gradient all-reduce over RCCL (N > 1) -> Adam step -> weight re-pack.  fp32 throughout (fp32 MFMA).  Weak scaling:
+every rank renders its own 4096 rays per step.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, from HIP events recorded on the launch stream
+inside the timed region; `cpu_baseline` is the oracle (CPU port of the reference path, oracle/nerf_oracle.py) timed on
+this box's host cores on a bounded sample (N=1 only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import nerf_pytorch_amd as N  # noqa: E402
+
+H = W = 400
+FOCAL = 555.5555
+RAYS_PER_GPU = 4096
+NC, NF = 64, 128
+MODEL = dict(num_layers=8, hidden_size=256, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4)
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md chip table
+
+
+def pose_spherical(theta_deg, phi_deg, radius):
+    """Camera-to-world of a camera on a sphere looking at the origin (the 360-degree poses of the blender scenes)."""
+    th, ph = math.radians(theta_deg), math.radians(phi_deg)
+    t = torch.eye(4)
+    t[2, 3] = radius
+    rp = torch.tensor([[1, 0, 0, 0], [0, math.cos(ph), -math.sin(ph), 0], [0, math.sin(ph), math.cos(ph), 0], [0, 0, 0, 1.0]])
+    rt = torch.tensor([[math.cos(th), 0, -math.sin(th), 0], [0, 1, 0, 0], [math.sin(th), 0, math.cos(th), 0], [0, 0, 0, 1.0]])
+    flip = torch.tensor([[-1.0, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]])
+    return flip @ rt @ rp @ t
+
+
+def macs_per_sample(cfg, dx=63, dd=27):
+    Wd, L, sk = cfg["hidden_size"], cfg["num_layers"], cfg["skip_connect_every"]
+    fwd = dx * Wd
+    dgrad = 0
+    for i in range(L - 1):
+        k = Wd + (dx if (i % sk == 0 and i > 0) else 0)
+        fwd += k * Wd
+        dgrad += Wd * Wd
+    fwd += Wd * Wd + Wd + (Wd + dd) * (Wd // 2) + 3 * (Wd // 2)
+    dgrad += Wd * Wd + Wd + Wd * (Wd // 2) + 3 * (Wd // 2)
+    return fwd, dgrad
+
+
+def cpu_baseline(sample_rays=512, reps=2):
+    """The oracle (CPU port of the reference path) forward+backward on `sample_rays` synthetic rays, 64+128, 8x256."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import nerf_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = dict(MODEL)
+    pc = {k: v.requires_grad_(True) for k, v in O.init_params(cfg, seed=1).items()}
+    pf = {k: v.requires_grad_(True) for k, v in O.init_params(cfg, seed=2).items()}
+    g = torch.Generator().manual_seed(0)
+    n = sample_rays
+    ro = torch.tensor([0.0, 0.0, 4.0]).expand(n, 3)
+    rd = torch.randn(n, 3, generator=g) * 0.3
+    rd[:, 2] = -1.0
+    rays = O.pack_rays(ro, rd, 2.0, 6.0, rd)
+    tgt = torch.rand(n, 3, generator=g)
+    opt = dict(num_coarse=NC, num_fine=NF, perturb=True, lindisp=False, white_background=False, noise_std=0.2)
+    best = float("inf")
+    for it in range(reps + 1):
+        rand = dict(t_rand=torch.rand(n, NC, generator=g), noise_coarse=torch.randn(n, NC, generator=g),
+                    u=torch.rand(n, NF, generator=g), noise_fine=torch.randn(n, NC + NF, generator=g))
+        t0 = time.perf_counter()
+        out = O.render_rays(rays, pc, pf, cfg, cfg, opt, rand, chunksize=131072)
+        loss, _, _, _ = O.loss_and_psnr(out["rgb_coarse"], out["rgb_fine"], tgt)
+        loss.backward()
+        for p in list(pc.values()) + list(pf.values()):
+            p.grad = None
+        dt = time.perf_counter() - t0
+        if it > 0:
+            best = min(best, dt)
+    return dict(value=n / best, unit="rays/s", cores=torch.get_num_threads(), kind="port",
+                sample="%d rays x (64 coarse + 128 fine), 8x256 nets, fwd+bwd (no optimizer), best of %d after 1 warm-up; "
+                       "oracle/nerf_oracle.py (torch %s CPU)" % (n, reps, torch.__version__))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rays", type=int, default=RAYS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hidden", type=int, default=MODEL["hidden_size"])
+    ap.add_argument("--layers", type=int, default=MODEL["num_layers"])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    cfg = dict(MODEL, hidden_size=args.hidden, num_layers=args.layers)
+    torch.manual_seed(42)  # config/lego.yml:8; every rank builds identical weights
+    mc = N.FlexibleNeRFModel(**cfg).to(dev)
+    mf = N.FlexibleNeRFModel(**cfg).to(dev)
+    eng = N.TrainEngine(mc, mf, NC, NF, perturb=True, lindisp=False, white_background=False, noise_std=0.2, lr=5e-3,
+                        seed=1234, world_size=world, rank=rank)
+    n = args.rays
+    opts = N.make_options(NC, NF, num_random_rays=n)
+    g = torch.Generator().manual_seed(1000 + rank)
+    poses = torch.stack([pose_spherical(th, -30.0, 4.0) for th in torch.linspace(-180, 180, 101)[:-1].tolist()]).to(dev)
+    pixel_sets = [torch.randperm(H * W, generator=g)[:n].to(dev) for _ in range(8)]
+    targets = torch.rand(8, n, 3, generator=g).to(dev)
+    lib = N._lib.get_lib()
+
+    def one_step(i):
+        pose = poses[(i * world + rank) % poses.shape[0]]
+        pix = pixel_sets[i % 8]
+        ro, rd = N.get_rays_at_pixels(H, W, FOCAL, pose, pix)      # only the selected rays are generated
+        rays = N.pack_rays(ro, rd, opts)
+        lr = N.TrainEngine.lr_at(i)
+        return eng.step(rays, targets[i % 8], ray_offset=rank * n, lr=lr)
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i)
+    fence()
+    lib.profile_enable(1)
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        loss = one_step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    lib.profile_enable(0)
+    import ctypes
+    buf = ctypes.create_string_buffer(1 << 16)
+    lib.profile_report(buf, len(buf))
+    tmax = torch.tensor([dt], device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax)
+    loss_host = [float(v) for v in loss.cpu()]
+
+    if rank == 0:
+        kern = {}
+        for line in buf.value.decode().splitlines():
+            name, cnt, ms = line.rsplit(" ", 2)
+            kern[name] = (int(cnt), float(ms))
+        fwd_macs, dgrad_macs = macs_per_sample(cfg)
+        m_c, m_f = n * NC, n * (NC + NF)
+        # algorithmic FLOPs per launch of each MLP kernel: 2 * MACs/sample * samples of the launch
+        flops = {"fwd": 2.0 * fwd_macs, "dgrad": 2.0 * dgrad_macs, "wgrad": 2.0 * fwd_macs}
+        table = []
+        for name, (cnt, ms) in kern.items():
+            kind = "fwd" if "k_mlp_fwd" in name else "dgrad" if "k_mlp_dgrad" in name else "wgrad" if name.startswith("k_wgrad") and "reduce" not in name else None
+            table.append((ms, name, cnt, kind))
+        table.sort(reverse=True)
+        dom = next((t for t in table if t[3] is not None), None)
+        roof = None
+        if dom is not None:
+            ms, name, cnt, kind = dom
+            # the kernel is launched once per net per step: coarse (m_c samples) and fine (m_f samples)
+            per_step_flops = flops[kind] * (m_c + m_f)
+            launches_per_step = cnt / args.steps
+            avg_ms = ms / cnt
+            achieved = per_step_flops / launches_per_step / (avg_ms * 1e-3) / 1e12
+            roof = dict(bound="mfma", kernel=name.strip("()"), achieved=round(achieved, 3), peak=FP32_MFMA_PEAK_TFLOPS,
+                        unit="TFLOP/s", frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                        avg_launch_ms=round(avg_ms, 4), launches=cnt,
+                        algorithmic_gflop_per_launch=round(per_step_flops / launches_per_step / 1e9, 2),
+                        kernel_ms_per_step={nm.strip("()"): round(m / args.steps, 4) for m, nm, _, _ in table})
+        total_flops = (2.0 * (2 * fwd_macs + dgrad_macs)) * (m_c + m_f)
+        res = dict(metric="train rays/sec", value=round(world * n * args.steps / dt, 2), unit="rays/s", n_gpus=world,
+                   steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3),
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   config=dict(workload="lego 400x400 synthetic views (BASELINE configs[1]): %d rays/GPU/iter, %d coarse + "
+                                        "%d fine samples, %dx%d coarse+fine nets, perturb, noise 0.2, Adam, full iteration"
+                                        % (n, NC, NF, cfg["num_layers"], cfg["hidden_size"]),
+                               rays_per_gpu=n, global_rays=n * world, parallelism="dp%d" % world),
+                   step_tflops=round(total_flops / (dt / args.steps) / 1e12, 2),
+                   step_frac_of_fp32_mfma_peak=round(total_flops / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                   final_loss=loss_host, roofline=roof)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

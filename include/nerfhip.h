@@ -52,6 +52,11 @@ int nerfhip_is_emulated(void);
 int nerfhip_rng_fill(int kind, uint64_t seed, uint32_t stream_id, uint64_t first, int64_t n, float* out_dev,
                      nerfhip_stream_t stream);
 
+/* Per-kernel timing: while enabled, every kernel launch is bracketed by HIP events recorded on the launch stream.
+ * nerfhip_profile_report waits for them and writes "kernel_name launches total_ms\n" lines into buf, then clears. */
+int nerfhip_profile_enable(int on);
+int nerfhip_profile_report(char* buf, int64_t cap);
+
 /* ---- K1: rays -------------------------------------------------------------------------------------------------- */
 /* get_ray_bundle (nerf/nerf_helpers.py:67-110) incl. meshgrid_xy (:28-40).  c2w: dev, rows >= 3, row stride
  * c2w_ld floats (columns 0..2 rotation, column 3 translation).  pixels: dev int64 linear ids (row*width+col) of

@@ -24,6 +24,74 @@ extern "C" int nerfhip_is_emulated(void) {
 #endif
 }
 
+// ---- per-kernel profiling (HIP events on the launch stream) ---------------------------------------------------------
+#include <map>
+#include <string>
+#include <vector>
+namespace {
+bool g_prof_on = false;
+#ifndef NERFHIP_EMU
+struct ProfRec {
+    std::string name;
+    hipEvent_t a, b;
+};
+std::vector<ProfRec> g_prof;
+#endif
+}  // namespace
+void nh_prof_begin(const char* name, nerfhip_stream_t stream) {
+#ifndef NERFHIP_EMU
+    if (!g_prof_on) return;
+    ProfRec r;
+    r.name = name;
+    (void)hipEventCreate(&r.a);
+    (void)hipEventCreate(&r.b);
+    (void)hipEventRecord(r.a, (hipStream_t)stream);
+    g_prof.push_back(r);
+#else
+    (void)name;
+    (void)stream;
+#endif
+}
+void nh_prof_end(nerfhip_stream_t stream) {
+#ifndef NERFHIP_EMU
+    if (!g_prof_on || g_prof.empty()) return;
+    (void)hipEventRecord(g_prof.back().b, (hipStream_t)stream);
+#else
+    (void)stream;
+#endif
+}
+extern "C" int nerfhip_profile_enable(int on) {
+    g_prof_on = on != 0;
+    return NERFHIP_OK;
+}
+// Waits for the recorded events, writes "kernel_name launches total_ms\n" lines into buf and clears the records.
+extern "C" int nerfhip_profile_report(char* buf, int64_t cap) {
+    NH_REQUIRE(buf && cap > 0, "profile_report: bad arguments");
+    buf[0] = 0;
+#ifndef NERFHIP_EMU
+    std::map<std::string, std::pair<int64_t, double>> acc;
+    for (ProfRec& r : g_prof) {
+        (void)hipEventSynchronize(r.b);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+        auto& e = acc[r.name];
+        e.first += 1;
+        e.second += ms;
+    }
+    g_prof.clear();
+    int64_t used = 0;
+    for (auto& kv : acc) {
+        int w = snprintf(buf + used, (size_t)(cap - used), "%s %lld %.6f\n", kv.first.c_str(), (long long)kv.second.first,
+                         kv.second.second);
+        if (w < 0 || used + w >= cap) break;
+        used += w;
+    }
+#endif
+    return NERFHIP_OK;
+}
+
 // ---- K1 get_ray_bundle (nerf/nerf_helpers.py:67-110) ----------------------------------------------------------------
 NH_KERNEL void k_ray_bundle(int height, int width, float focal, const float* __restrict__ c2w, int ld,
                             const int64_t* __restrict__ pixels, int64_t n, float* __restrict__ ro,
@@ -111,7 +179,7 @@ NH_KERNEL void k_pack_rays(const float* __restrict__ ro, const float* __restrict
     r[7] = far;
     if (vsrc) {
         float x = vsrc[i * 3], y = vsrc[i * 3 + 1], z = vsrc[i * 3 + 2];
-        float nrm = sqrtf((x * x + y * y) + z * z);
+        float nrm = sqrtf(fmaf(z, z, fmaf(y, y, x * x)));  // torch's CPU norm(p=2) is this fma chain (bit-exact)
         r[8] = x / nrm;
         r[9] = y / nrm;
         r[10] = z / nrm;

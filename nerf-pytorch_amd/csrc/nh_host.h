@@ -15,13 +15,22 @@ void nh_set_error(const char* fmt, ...);
         }                              \
     } while (0)
 
+// Optional per-kernel timing with HIP events recorded on the launch stream (nerfhip_profile_enable / _report).
+void nh_prof_begin(const char* name, nerfhip_stream_t stream);
+void nh_prof_end(nerfhip_stream_t stream);
+
 #ifdef NERFHIP_EMU
 #define NH_LAUNCH(kern, grid, block, smem, stream, ...) \
     emu::launch(emu::Dim3((unsigned)(grid)), emu::Dim3((unsigned)(block)), (size_t)(smem), [&]() { kern(__VA_ARGS__); })
 static inline int nh_launch_status(const char*) { return NERFHIP_OK; }
 #else
-#define NH_LAUNCH(kern, grid, block, smem, stream, ...) \
-    hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (size_t)(smem), (hipStream_t)(stream), __VA_ARGS__)
+#define NH_LAUNCH(kern, grid, block, smem, stream, ...)                                                             \
+    do {                                                                                                            \
+        nh_prof_begin(#kern, stream);                                                                               \
+        hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (size_t)(smem), (hipStream_t)(stream), \
+                           __VA_ARGS__);                                                                            \
+        nh_prof_end(stream);                                                                                        \
+    } while (0)
 static inline int nh_launch_status(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -41,7 +41,7 @@ NH_KERNEL void k_volume_render_fwd(const float* __restrict__ raw, const float* _
     const int64_t ray = blockIdx.x;
     const int lane = nh_lane();
     const float dx = rd[ray * rd_stride], dy = rd[ray * rd_stride + 1], dz = rd[ray * rd_stride + 2];
-    const float norm = sqrtf((dx * dx + dy * dy) + dz * dz);
+    const float norm = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));  // == torch CPU norm(p=2), bit-exact
     double carry = 1.0;
     float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
     for (int base = 0; base < s; base += 64) {
@@ -124,7 +124,7 @@ NH_KERNEL void k_volume_render_bwd(const float* __restrict__ raw, const float* _
     const int64_t ray = blockIdx.x;
     const int lane = nh_lane();
     const float dx = rd[ray * rd_stride], dy = rd[ray * rd_stride + 1], dz = rd[ray * rd_stride + 2];
-    const float norm = sqrtf((dx * dx + dy * dy) + dz * dz);
+    const float norm = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));  // == torch CPU norm(p=2), bit-exact
     // pass 1: transmittance
     double carry = 1.0;
     for (int base = 0; base < s; base += 64) {

@@ -1,0 +1,230 @@
+"""Drop-in for ``nerf/train_utils.py``: run_network, predict_and_render_radiance, run_one_iter_of_nerf with the
+reference's signatures, defaults and return layout (nerf/train_utils.py:8-202).
+
+When both networks are this package's FlexibleNeRFModel and the encoders come from this package's
+get_embedding_function, predict_and_render_radiance runs the fused pipeline of libnerfhip.so (one C-ABI call forward,
+one backward; encodings and activations never reach HBM).  Otherwise it composes the unit kernels exactly like the
+reference composes its torch ops, so arbitrary user networks still work.
+
+Random draws: made with torch.rand / torch.randn on the rays' device in the reference's order and shapes
+(t_rand, coarse noise, u, fine noise per ray chunk), then handed to the kernels -- seeding torch reproduces a run.
+
+Reference quirk kept on purpose: run_one_iter_of_nerf does not forward `mode` to predict_and_render_radiance
+(train_utils.py:171-181), so rendering always reads options.nerf.train.* ; only the ray chunk size and the output
+reshape honour `mode`.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from .models import FlexibleNeRFModel
+from .nerf_helpers import EmbeddingFunction, get_minibatches, linspace01, ndc_rays, sample_pdf_2 as sample_pdf
+from .volume_rendering_utils import volume_render_radiance_field
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def run_network(network_fn, pts, ray_batch, chunksize, embed_fn, embeddirs_fn):
+    """nerf/train_utils.py:8-25."""
+    pts_flat = pts.reshape((-1, pts.shape[-1]))
+    embedded = embed_fn(pts_flat)
+    if embeddirs_fn is not None:
+        viewdirs = ray_batch[..., None, -3:]
+        input_dirs = viewdirs.expand(pts.shape)
+        input_dirs_flat = input_dirs.reshape((-1, input_dirs.shape[-1]))
+        embedded_dirs = embeddirs_fn(input_dirs_flat)
+        embedded = torch.cat((embedded, embedded_dirs), dim=-1)
+    batches = get_minibatches(embedded, chunksize=chunksize)
+    preds = [network_fn(batch) for batch in batches]
+    radiance_field = torch.cat(preds, dim=0)
+    return radiance_field.reshape(list(pts.shape[:-1]) + [radiance_field.shape[-1]])
+
+
+# ---- fused path -------------------------------------------------------------------------------------------------------
+def _fusable(model_coarse, model_fine, enc_xyz, enc_dir, num_fine):
+    if not isinstance(model_coarse, FlexibleNeRFModel):
+        return False
+    if num_fine > 0 and not isinstance(model_fine, FlexibleNeRFModel):
+        return False
+    models = [model_coarse] + ([model_fine] if num_fine > 0 else [])
+    for m in models:
+        c = m.cfg
+        if not isinstance(enc_xyz, EmbeddingFunction):
+            return False
+        if (enc_xyz.num_encoding_functions, bool(enc_xyz.include_input), bool(enc_xyz.log_sampling)) != (
+                c["num_encoding_fn_xyz"], c["include_input_xyz"], c["log_sampling_xyz"]):
+            return False
+        if c["use_viewdirs"]:
+            if not isinstance(enc_dir, EmbeddingFunction):
+                return False
+            if (enc_dir.num_encoding_functions, bool(enc_dir.include_input), bool(enc_dir.log_sampling)) != (
+                    c["num_encoding_fn_dir"], c["include_input_dir"], c["log_sampling_dir"]):
+                return False
+        elif enc_dir is not None:
+            return False
+    return True
+
+
+class _FusedRender(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rays, model_c, model_f, cfg_tuple, rand, flat_c, flat_f):
+        lib = L.get_lib()
+        nc, nf, perturb, lindisp, white, noise_std = cfg_tuple
+        n, stride = rays.shape
+        dev = rays.device
+        cfg = L.RenderCfg(nc, nf, int(bool(perturb)), int(bool(lindisp)), int(bool(white)), float(noise_std), stride)
+        training = torch.is_grad_enabled() and (flat_c.requires_grad or (flat_f is not None and flat_f.requires_grad))
+        plan_f = model_f._plan if nf > 0 else None
+        wsb = lib.render_workspace_bytes(model_c._plan, plan_f, C.byref(cfg), n, int(training))
+        if wsb < 0:
+            raise L.NerfHipError(lib.last_error().decode())
+        ws = torch.empty(wsb // 4 + 1, dtype=torch.float32, device=dev)
+        names = ("rgb_coarse", "disp_coarse", "acc_coarse", "depth_coarse", "rgb_fine", "disp_fine", "acc_fine",
+                 "depth_fine")
+        bufs = {k: torch.empty((n, 3) if k.startswith("rgb") else (n,), dtype=torch.float32, device=dev) for k in names}
+        out = L.RenderOut(*[bufs[k].data_ptr() for k in names])
+        rr = L.RenderRand(*[None if r is None else r.data_ptr() for r in rand])
+        packed_c = model_c._packed()
+        packed_f = model_f._packed() if nf > 0 else None
+        lib.render_fwd(model_c._plan, plan_f, C.byref(cfg), rays.data_ptr(), n, packed_c.data_ptr(),
+                       packed_f.data_ptr() if packed_f is not None else None, linspace01(nc, dev).data_ptr(),
+                       linspace01(nf, dev).data_ptr() if nf > 0 else None, C.byref(rr), 0, 0, C.byref(out), ws.data_ptr(),
+                       wsb, int(training), _stream())
+        ctx.keep = (rays, model_c, model_f, cfg, rand, ws, wsb, packed_c, packed_f, training)
+        outs = [bufs[k] for k in names]
+        ctx.mark_non_differentiable(bufs["disp_coarse"], bufs["acc_coarse"], bufs["depth_coarse"], bufs["disp_fine"],
+                                    bufs["acc_fine"], bufs["depth_fine"])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_rgb_c, g_disp_c, g_acc_c, g_depth_c, g_rgb_f, g_disp_f, g_acc_f, g_depth_f):
+        lib = L.get_lib()
+        rays, model_c, model_f, cfg, rand, ws, wsb, packed_c, packed_f, training = ctx.keep
+        if not training:
+            raise RuntimeError("fused render was run without gradient bookkeeping")
+        n = rays.shape[0]
+        dev = rays.device
+        nf = cfg.num_fine
+        gc = (g_rgb_c if g_rgb_c is not None else torch.zeros((n, 3), device=dev)).contiguous().float()
+        gf = None
+        if nf > 0:
+            gf = (g_rgb_f if g_rgb_f is not None else torch.zeros((n, 3), device=dev)).contiguous().float()
+        rr = L.RenderRand(*[None if r is None else r.data_ptr() for r in rand])
+        gpc = torch.empty(model_c.num_flat_params, dtype=torch.float32, device=dev)
+        gpf = torch.empty(model_f.num_flat_params, dtype=torch.float32, device=dev) if nf > 0 else None
+        lib.render_bwd(model_c._plan, model_f._plan if nf > 0 else None, C.byref(cfg), rays.data_ptr(), n,
+                       packed_c.data_ptr(), packed_f.data_ptr() if nf > 0 else None, C.byref(rr), 0, 0, gc.data_ptr(),
+                       gf.data_ptr() if gf is not None else None, ws.data_ptr(), wsb, gpc.data_ptr(),
+                       gpf.data_ptr() if gpf is not None else None, _stream())
+        return None, None, None, None, None, gpc, gpf
+
+
+def _flat_leaf(model):
+    if torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters()):
+        return torch.cat([p.reshape(-1) for p in model._ordered_params()])
+    return model.flat_params
+
+
+def _predict_fused(ray_batch, model_coarse, model_fine, opts):
+    rays = ray_batch.detach().contiguous().float()
+    n = rays.shape[0]
+    dev = rays.device
+    nc, nf = opts.num_coarse, opts.num_fine
+    perturb, noise_std = opts.perturb, opts.radiance_field_noise_std
+    # the reference's draw order per ray chunk (train_utils.py:63, volume_rendering_utils.py:30, nerf_helpers.py:279,
+    # volume_rendering_utils.py:30)
+    t_rand = torch.rand((n, nc), dtype=torch.float32, device=dev) if perturb else None
+    noise_c = torch.randn((n, nc), dtype=torch.float32, device=dev) if noise_std > 0.0 else None
+    u = torch.rand((n, nf), dtype=torch.float32, device=dev) if (nf > 0 and not (perturb == 0.0)) else None
+    noise_f = torch.randn((n, nc + nf), dtype=torch.float32, device=dev) if (nf > 0 and noise_std > 0.0) else None
+    cfg_tuple = (nc, nf, bool(perturb), bool(opts.lindisp), bool(opts.white_background), float(noise_std))
+    flat_c = _flat_leaf(model_coarse)
+    flat_f = _flat_leaf(model_fine) if nf > 0 else None
+    outs = _FusedRender.apply(rays, model_coarse, model_fine if nf > 0 else None, cfg_tuple,
+                              (t_rand, noise_c, u, noise_f), flat_c, flat_f)
+    rgb_c, disp_c, acc_c, _, rgb_f, disp_f, acc_f, _ = outs
+    if nf > 0:
+        return rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f
+    return rgb_c, disp_c, acc_c, None, None, None
+
+
+def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, mode="train", encode_position_fn=None,
+                                encode_direction_fn=None):
+    """nerf/train_utils.py:28-127.  Returns (rgb_coarse, disp_coarse, acc_coarse, rgb_fine, disp_fine, acc_fine)."""
+    if not ray_batch.is_cuda:
+        raise RuntimeError("predict_and_render_radiance needs CUDA (HIP) tensors: nerf_pytorch_amd has no CPU path")
+    opts = getattr(options.nerf, mode)
+    if _fusable(model_coarse, model_fine, encode_position_fn, encode_direction_fn, opts.num_fine):
+        return _predict_fused(ray_batch, model_coarse, model_fine, opts)
+
+    # generic composition (arbitrary networks / encoders), mirroring the reference step by step
+    lib = L.get_lib()
+    num_rays = ray_batch.shape[0]
+    rays = ray_batch.detach().contiguous().float()
+    ro, rd = rays[..., :3], rays[..., 3:6]
+    dev = rays.device
+    nc = opts.num_coarse
+    t_rand = torch.rand((num_rays, nc), dtype=torch.float32, device=dev) if opts.perturb else None
+    z_vals = torch.empty((num_rays, nc), dtype=torch.float32, device=dev)
+    lib.stratified_z(rays.data_ptr(), rays.shape[1], num_rays, linspace01(nc, dev).data_ptr(), nc, int(bool(opts.lindisp)),
+                     int(bool(opts.perturb)), t_rand.data_ptr() if t_rand is not None else None, 0, 0, z_vals.data_ptr(),
+                     _stream())
+    pts = ro[..., None, :] + rd[..., None, :] * z_vals[..., :, None]
+    radiance_field = run_network(model_coarse, pts, ray_batch, opts.chunksize, encode_position_fn, encode_direction_fn)
+    rgb_coarse, disp_coarse, acc_coarse, weights, _ = volume_render_radiance_field(
+        radiance_field, z_vals, rd, radiance_field_noise_std=opts.radiance_field_noise_std,
+        white_background=opts.white_background)
+    rgb_fine, disp_fine, acc_fine = None, None, None
+    if opts.num_fine > 0:
+        z_vals_mid = 0.5 * (z_vals[..., 1:] + z_vals[..., :-1])
+        z_samples = sample_pdf(z_vals_mid, weights[..., 1:-1].detach(), opts.num_fine, det=(opts.perturb == 0.0))
+        z_vals, _ = torch.sort(torch.cat((z_vals, z_samples), dim=-1), dim=-1)
+        pts = ro[..., None, :] + rd[..., None, :] * z_vals[..., :, None]
+        radiance_field = run_network(model_fine, pts, ray_batch, opts.chunksize, encode_position_fn, encode_direction_fn)
+        rgb_fine, disp_fine, acc_fine, _, _ = volume_render_radiance_field(
+            radiance_field, z_vals, rd, radiance_field_noise_std=opts.radiance_field_noise_std,
+            white_background=opts.white_background)
+    return rgb_coarse, disp_coarse, acc_coarse, rgb_fine, disp_fine, acc_fine
+
+
+def pack_rays(ray_origins, ray_directions, options, height=None, width=None, focal_length=None):
+    """The ray packing of run_one_iter_of_nerf (nerf/train_utils.py:143-168): rows [o d near far (d/||d||)]."""
+    lib = L.get_lib()
+    rd_src = ray_directions.detach().reshape(-1, 3).contiguous().float()
+    ro = ray_origins.detach().reshape(-1, 3).contiguous().float()
+    rd = rd_src
+    if options.dataset.no_ndc is False:
+        ro, rd = ndc_rays(height, width, focal_length, 1.0, ro, rd_src)
+    n = rd.shape[0]
+    use_view = bool(options.nerf.use_viewdirs)
+    rays = torch.empty((n, 11 if use_view else 8), dtype=torch.float32, device=rd.device)
+    lib.pack_rays(ro.data_ptr(), rd.data_ptr(), rd_src.data_ptr() if use_view else None, float(options.dataset.near),
+                  float(options.dataset.far), n, rays.data_ptr(), _stream())
+    return rays
+
+
+def run_one_iter_of_nerf(height, width, focal_length, model_coarse, model_fine, ray_origins, ray_directions, options,
+                         mode="train", encode_position_fn=None, encode_direction_fn=None):
+    """nerf/train_utils.py:130-202."""
+    if not ray_directions.is_cuda:
+        raise RuntimeError("run_one_iter_of_nerf needs CUDA (HIP) tensors: nerf_pytorch_amd has no CPU path")
+    restore_shapes = [ray_directions.shape, ray_directions.shape[:-1], ray_directions.shape[:-1]]
+    if model_fine:
+        restore_shapes += restore_shapes
+    rays = pack_rays(ray_origins, ray_directions, options, height, width, focal_length)
+    batches = get_minibatches(rays, chunksize=getattr(options.nerf, mode).chunksize)
+    pred = [predict_and_render_radiance(batch, model_coarse, model_fine, options,
+                                        encode_position_fn=encode_position_fn,
+                                        encode_direction_fn=encode_direction_fn) for batch in batches]
+    synthesized_images = list(zip(*pred))
+    synthesized_images = [torch.cat(image, dim=0) if image[0] is not None else None for image in synthesized_images]
+    if mode == "validation":
+        synthesized_images = [image.view(shape) if image is not None else None
+                              for (image, shape) in zip(synthesized_images, restore_shapes)]
+        if model_fine:
+            return tuple(synthesized_images)
+        return tuple(synthesized_images + [None, None, None])
+    return tuple(synthesized_images)

@@ -1,0 +1,407 @@
+"""Parity cases shared by the emulator suite (CPU, `-m "not gpu"`) and the GPU suite (`-m gpu`).
+
+Each case feeds identical seeded inputs (and identical random draws) to a backend (tests/backends.py) and to the
+oracle (oracle/nerf_oracle.py, pinned against the real reference by tests/test_oracle.py), and compares.
+
+Tolerances (fp32): elementwise geometry is bit-exact or within 1 ulp; anything through sin/cos/exp within 2e-6;
+MLP outputs within 2e-5 (different fp32 summation order than torch's GEMM); rendered rgb/depth within 1e-4 abs (the
+north-star bar, BASELINE.json); inverse-CDF indices exact for a given (cdf, u).
+"""
+import ast
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+import nerf_oracle as O
+from backends import ROOT, model_cfg
+from conftest import gold
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def close(a, b, atol, rtol=0.0, what=""):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert np.array_equal(np.isnan(a), np.isnan(b)), what + ": NaN masks differ"
+    err = np.abs(np.nan_to_num(a) - np.nan_to_num(b))
+    lim = atol + rtol * np.abs(np.nan_to_num(b))
+    assert np.all(err <= lim), "%s: max err %.3e (limit %.3e)" % (what, float(err.max()), float(lim.flat[err.argmax()]))
+
+
+def rng(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# ---- geometry ----------------------------------------------------------------------------------------------------------
+def case_rays(b):
+    g = gold("helpers.npz")
+    ro, rd = b.ray_bundle(5, 7, 3.3, g["rb_c2w"])
+    close(rd.reshape(5, 7, 3), g["rb_rd"], 1e-6, what="ray_bundle rd")
+    close(ro.reshape(5, 7, 3), g["rb_ro"], 0, what="ray_bundle ro")
+    pix = np.array([0, 3, 319, 160, 7], np.int64)
+    ro2, rd2 = b.ray_bundle(20, 16, 555.5555 / 20, g["rb2_c2w"], pix)
+    close(rd2, g["rb2_rd"].reshape(-1, 3)[pix], 1e-6, what="ray_bundle pixels")
+    no, nd = b.ndc_rays(378, 504, 407.5, 1.0, g["ndc_o"], g["ndc_d"])
+    close(no, g["ndc_out_o"], 1e-6, 1e-6, what="ndc o")
+    close(nd, g["ndc_out_d"], 1e-6, 1e-6, what="ndc d")
+    rays = b.pack_rays(g["ndc_o"], g["ndc_d"], 2.0, 6.0, g["ndc_d"])
+    want = O.pack_rays(T(g["ndc_o"]), T(g["ndc_d"]), 2.0, 6.0, T(g["ndc_d"])).numpy()
+    close(rays, want, 1e-7, what="pack_rays")
+    rays8 = b.pack_rays(g["ndc_o"], g["ndc_d"], 0.0, 1.0, None)
+    close(rays8, O.pack_rays(T(g["ndc_o"]), T(g["ndc_d"]), 0.0, 1.0, None).numpy(), 0, what="pack_rays (no viewdirs)")
+
+
+def case_posenc(b):
+    g = gold("helpers.npz")
+    x = g["pe_x"]
+    close(b.positional_encoding(x, O.frequency_bands(10).numpy(), True), g["pe_L10"], 2e-6, what="posenc L10")
+    close(b.positional_encoding(x, O.frequency_bands(4).numpy(), True), g["pe_L4"], 2e-6, what="posenc L4")
+    close(b.positional_encoding(x, O.frequency_bands(6).numpy(), False), g["pe_L6_noinput"], 2e-6, what="posenc noinput")
+    close(b.positional_encoding(x, O.frequency_bands(3, False).numpy(), True), g["pe_L3_linear"], 2e-6, what="posenc lin")
+    close(b.positional_encoding(x, np.zeros(0, np.float32), True), g["pe_L0"], 0, what="posenc L0")
+
+
+def case_stratified(b):
+    gen = rng(3)
+    n, nc = 7, 64
+    rays = torch.zeros(n, 11)
+    rays[:, 6] = 2.0 + torch.rand(n, generator=gen)
+    rays[:, 7] = 6.0 + torch.rand(n, generator=gen)
+    tr = torch.rand(n, nc, generator=gen)
+    tv = torch.linspace(0, 1, nc).numpy()
+    for lindisp in (False, True):
+        for perturb in (False, True):
+            want = O.stratified_z(rays[:, 6:7], rays[:, 7:8], nc, lindisp, perturb, tr).numpy()
+            got = b.stratified_z(rays.numpy(), tv, lindisp, perturb, tr.numpy() if perturb else None)
+            close(got, want, 0, what="stratified lindisp=%s perturb=%s" % (lindisp, perturb))
+    # production RNG: the kernel's own draws are the ones rng_fill reports (stream 0, element = ray*nc + s)
+    draws = b.rng_fill(0, 99, 0, 5 * nc, n * nc).reshape(n, nc)
+    assert draws.min() >= 0.0 and draws.max() < 1.0
+    got = b.stratified_z(rays.numpy(), tv, False, True, None, seed=99, ray_offset=5)
+    want = O.stratified_z(rays[:, 6:7], rays[:, 7:8], nc, False, True, T(draws)).numpy()
+    close(got, want, 0, what="stratified internal rng")
+
+
+def case_cumprod(b):
+    g = gold("helpers.npz")
+    close(b.cumprod_exclusive(g["cp_x"]), g["cp_y"], 0, 2e-7, what="cumprod_exclusive")
+    close(b.cumprod_exclusive(np.array([[1, 2, 3, 4]], np.float32)), [[1, 1, 2, 6]], 0, what="KAT1")
+    x = (torch.rand(3, 200, generator=rng(5)) * 0.2 + 0.9).numpy()
+    close(b.cumprod_exclusive(x), O.cumprod_exclusive(T(x)).numpy(), 0, 2e-7, what="cumprod 200")
+
+
+# ---- compositing -------------------------------------------------------------------------------------------------------
+def case_volume_render(b):
+    g = gold("helpers.npz")
+    names = ("rgb", "disp", "acc", "weights", "depth")
+    r1 = b.volume_render_fwd(g["vr_raw"], g["vr_z"], g["vr_rd"], 0.7, g["vr_noise"], True)
+    r2 = b.volume_render_fwd(g["vr_raw"], g["vr_z"], g["vr_rd"], 0.0, None, False)
+    for i, n in enumerate(names):
+        close(r1[i], g["vr1_" + n], 2e-6, 2e-6, what="render1 " + n)
+        close(r2[i], g["vr2_" + n], 2e-6, 2e-6, what="render2 " + n)
+    r3 = b.volume_render_fwd(g["vr3_raw"], g["vr_z"], g["vr_rd"])
+    close(r3[1], g["vr3_disp"], 2e-6, 2e-6, what="NaN disparity")  # NaN mask must match
+    raw = np.array([[[0., 0, 0, 1], [1, -1, 2, .5], [0, 0, 0, -1], [3, 3, 3, 2]]], np.float32)
+    k = b.volume_render_fwd(raw, np.array([[2., 3, 4, 6]], np.float32), np.array([[0., 0, -2]], np.float32), white=True)
+    close(k[3], [[0.8646647, 0.0855482, 0, 0.0497871]], 1e-6, what="KAT4 weights")
+    close(k[0], [[0.5422990, 0.5027657, 0.5551088]], 1e-6, what="KAT4 rgb")
+    close(k[4], [2.2846966], 1e-6, what="KAT4 depth")
+    close(k[1], [0.4376949], 1e-6, what="KAT4 disp")
+    # 192 samples (3 chunks of 64) incl. ray stride 11 as the fused path passes it
+    gen = rng(8)
+    n, s = 5, 192
+    raw = (torch.randn(n, s, 4, generator=gen) * 1.5)
+    z = torch.sort(torch.rand(n, s, generator=gen) * 4 + 2, -1)[0]
+    rays = torch.randn(n, 11, generator=gen)
+    nz = torch.randn(n, s, generator=gen)
+    want = O.volume_render(raw, z, rays[:, 3:6], 0.2, nz, False)
+    got = b.volume_render_fwd(raw.numpy(), z.numpy(), rays.numpy()[:, 3:], 0.2, nz.numpy(), False)
+    for i, nme in enumerate(names):
+        close(got[i], want[i].numpy(), 2e-6, 2e-6, what="render192 " + nme)
+
+
+def case_volume_render_bwd(b):
+    gen = rng(9)
+    for (n, s, white, std) in ((4, 64, False, 0.0), (3, 192, True, 0.5), (2, 40, True, 0.0)):
+        raw = (torch.randn(n, s, 4, generator=gen) * 1.5).requires_grad_(True)
+        z = torch.sort(torch.rand(n, s, generator=gen) * 4 + 2, -1)[0]
+        rd = torch.randn(n, 3, generator=gen)
+        nz = torch.randn(n, s, generator=gen)
+        g_rgb, g_depth, g_acc = torch.randn(n, 3, generator=gen), torch.randn(n, generator=gen), torch.randn(n, generator=gen)
+        g_w = torch.randn(n, s, generator=gen)
+        rgb, disp, acc, w, depth = O.volume_render(raw, z, rd, std, nz, white)
+        ((rgb * g_rgb).sum() + (depth * g_depth).sum() + (acc * g_acc).sum() + (w * g_w).sum()).backward()
+        got = b.volume_render_bwd(raw.detach().numpy(), z.numpy(), rd.numpy(), g_rgb.numpy(), g_depth.numpy(),
+                                  g_acc.numpy(), g_w.numpy(), std, nz.numpy(), white)
+        close(got, raw.grad.numpy(), 2e-6, 2e-4, what="render bwd n=%d s=%d" % (n, s))
+        raw.grad = None
+        rgb = O.volume_render(raw, z, rd, std, nz, white)[0]
+        (rgb * g_rgb).sum().backward()
+        got = b.volume_render_bwd(raw.detach().numpy(), z.numpy(), rd.numpy(), g_rgb.numpy(), None, None, None, std,
+                                  nz.numpy(), white)
+        close(got, raw.grad.numpy(), 2e-6, 2e-4, what="render bwd (rgb only)")
+
+
+# ---- sampling ----------------------------------------------------------------------------------------------------------
+_C_ORACLE = None
+
+
+def c_oracle():
+    global _C_ORACLE
+    if _C_ORACLE is None:
+        out = os.path.join(ROOT, "oracle", "_build")
+        os.makedirs(out, exist_ok=True)
+        so = os.path.join(out, "libcdf_oracle.so")
+        src = os.path.join(ROOT, "oracle", "cdf_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", so, src], check=True)
+        _C_ORACLE = C.CDLL(so)
+    return _C_ORACLE
+
+
+def run_c_oracle(bins, w, u):
+    n, nb = bins.shape
+    nf = u.shape[1]
+    s, i, c = np.empty((n, nf), np.float32), np.empty((n, nf), np.int64), np.empty((n, nb), np.float32)
+    bins, w, u = (np.ascontiguousarray(a, np.float32) for a in (bins, w, u))
+    c_oracle().oracle_sample_pdf(C.c_void_p(bins.ctypes.data), C.c_void_p(w.ctypes.data), C.c_int64(n), C.c_int(nb),
+                                 C.c_void_p(u.ctypes.data), C.c_int(nf), C.c_void_p(s.ctypes.data),
+                                 C.c_void_p(i.ctypes.data), C.c_void_p(c.ctypes.data))
+    return s, i, c
+
+
+def case_sample_pdf(b):
+    g = gold("helpers.npz")
+    bins, w, u = g["sp_bins"], g["sp_w"], g["sp_u"]
+    s, inds, cdf = b.sample_pdf(bins, w, 128, u=u)
+    # (1) the declared-order contract: kernel == C restatement, bit for bit
+    cs, ci, cc = run_c_oracle(bins, w, u)
+    assert np.array_equal(cdf, cc), "cdf differs from the C restatement"
+    assert np.array_equal(inds, ci), "searchsorted indices differ from the C restatement"
+    assert np.array_equal(s, cs), "samples differ from the C restatement"
+    # (2) indices are exactly torch.searchsorted(right=True) of the kernel's own cdf
+    ti = torch.searchsorted(T(cdf), T(u), right=True).numpy()
+    assert np.array_equal(inds, ti)
+    # (3) vs the reference: identical except where a 1-ulp cdf difference flips an index
+    _, oi, oc = O.sample_pdf(T(bins), T(w), 128, u=T(u), return_aux=True)
+    close(cdf, oc.numpy(), 2.5e-7, what="cdf vs torch")
+    flips = float((inds != oi.numpy()).mean())
+    assert flips < 2e-3, flips
+    same = inds == oi.numpy()
+    close(s[same], g["sp_rand"][same], 1e-5, what="samples vs reference")
+    sd, _, _ = b.sample_pdf(bins, w, 128, det=True)
+    close(sd, g["sp_det"], 1e-5, what="det samples vs reference")
+    k, ki, _ = b.sample_pdf(np.array([[1, 2, 3, 4]], np.float32), np.array([[1, 0, 3]], np.float32), 5, det=True)
+    close(k, [[1.0, 1.9999975, 3.3333306, 3.6666653, 4.0]], 1e-6, what="KAT5")
+    assert ki[0, -1] == 4  # u = 1.0 lands past the last cdf entry
+    # KAT8 tie behaviour through the kernel: cdf [0,.2,.2,.7,1] <- weights chosen so that pdf reproduces it
+    gen = rng(21)
+    z = torch.sort(torch.rand(6, 64, generator=gen) * 4 + 2, -1)[0]
+    wf = torch.rand(6, 64, generator=gen) ** 3
+    uu = torch.rand(6, 128, generator=gen)
+    zs_want, zf_want = O.hierarchical_z(z, wf, 128, det=False, u=uu)
+    zs, zf = b.hierarchical_z(z.numpy(), wf.numpy(), 128, u=uu.numpy())
+    assert np.all(np.diff(zf, axis=-1) >= 0), "z_fine not sorted"
+    close(zs, zs_want.numpy(), 1e-5, what="hierarchical samples")
+    close(zf, zf_want.numpy(), 1e-5, what="hierarchical merged")
+    zs2, zf2 = b.hierarchical_z(z.numpy(), wf.numpy(), 64, det=True)
+    zs_w2, zf_w2 = O.hierarchical_z(z, wf, 64, det=True)
+    close(zf2, zf_w2.numpy(), 1e-5, what="hierarchical det")
+
+
+# ---- MLP ---------------------------------------------------------------------------------------------------------------
+def mlp_setup(b, cfg, seed):
+    plan = b.make_plan(cfg)
+    params = O.init_params(cfg, seed=seed)
+    flat = b.flatten_params(plan, {k: v.numpy() for k, v in params.items()})
+    packed = b.pack(plan, flat)
+    return plan, params, flat, packed
+
+
+MLP_GEOMETRIES = {
+    "default4x128": model_cfg(4, 128, 4, 10, 4),
+    "deep8x128_skip4": model_cfg(8, 128, 4, 10, 4),
+    "fern8x128_skip3_L6": model_cfg(8, 128, 3, 6, 4),
+    "novw4x128": model_cfg(4, 128, 4, 10, 4, use_viewdirs=False),
+    "two_layer_L4_L2": model_cfg(2, 128, 4, 4, 2),
+    "noinput_linear": model_cfg(3, 128, 2, 5, 3, include_input_xyz=False, include_input_dir=False,
+                                log_sampling_xyz=False),
+    "northstar8x256": model_cfg(8, 256, 4, 10, 4),
+}
+
+
+def case_mlp_forward(b, names=None, m=70):
+    for name in names or MLP_GEOMETRIES:
+        cfg = MLP_GEOMETRIES[name]
+        plan, params, flat, packed = mlp_setup(b, cfg, seed=31)
+        dx, dd = O.model_dims(cfg)
+        x = torch.randn(m, dx + dd, generator=rng(32))
+        want = O.mlp_forward(params, x, cfg).numpy()
+        got, _ = b.mlp_fwd(plan, packed, x.numpy())
+        close(got, want, 2e-5, 2e-5, what="mlp fwd " + name)
+        b.lib.plan_destroy(plan)
+
+
+def case_mlp_golden(b):
+    g = gold("mlp_forward.npz")
+    geo = {"a": (8, 128, 4, 10, 4, True), "b": (8, 128, 3, 6, 4, True), "c": (6, 128, 2, 10, 4, True),
+           "d": (4, 128, 4, 10, 4, False), "e": (2, 128, 4, 4, 2, True)}
+    for tag, (L, W, sk, lx, ld, view) in geo.items():
+        cfg = model_cfg(L, W, sk, lx, ld, use_viewdirs=view)
+        plan, params, flat, packed = mlp_setup(b, cfg, seed=100 + ord(tag))
+        got, _ = b.mlp_fwd(plan, packed, g["x_" + tag])
+        close(got, g["y_" + tag], 2e-5, 2e-5, what="mlp golden " + tag)
+        b.lib.plan_destroy(plan)
+
+
+def case_mlp_backward(b, names=None, m=150):
+    for name in names or ("default4x128", "deep8x128_skip4", "fern8x128_skip3_L6", "novw4x128"):
+        cfg = MLP_GEOMETRIES[name]
+        plan, params, flat, packed = mlp_setup(b, cfg, seed=41)
+        dx, dd = O.model_dims(cfg)
+        gen = rng(42)
+        x = torch.randn(m, dx + dd, generator=gen)
+        go = torch.randn(m, 4, generator=gen)
+        p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        (O.mlp_forward(p, x, cfg) * go).sum().backward()
+        got_y, stash = b.mlp_fwd(plan, packed, x.numpy(), want_stash=True)
+        gflat = b.mlp_bwd(plan, packed, go.numpy(), stash)
+        grads = b.unflatten(plan, gflat)
+        for k, v in p.items():
+            ref = v.grad.numpy()
+            scale = float(np.abs(ref).max()) + 1e-12
+            close(grads[k], ref, 2e-5 * scale + 1e-7, 2e-4, what="mlp bwd %s %s" % (name, k))
+        b.lib.plan_destroy(plan)
+
+
+# ---- the whole path ----------------------------------------------------------------------------------------------------
+def e2e_inputs(name):
+    g = gold(name)
+    meta = ast.literal_eval(str(g["meta"]))
+    cfg_c = model_cfg(**{k: v for k, v in meta["cfg_c"].items()})
+    cfg_f = model_cfg(**{k: v for k, v in meta["cfg_f"].items()})
+    ro, rd = T(g["ro"]), T(g["rd"])
+    vsrc = rd if cfg_c["use_viewdirs"] else None
+    if meta["ndc"]:
+        ro, rd = O.ndc_rays(int(g["H"]), int(g["W"]), float(g["focal"]), 1.0, ro, rd)
+    rays = O.pack_rays(ro, rd, float(g["near"]), float(g["far"]), vsrc).numpy()
+    rand = {k: g[k] for k in ("t_rand", "noise_coarse", "u", "noise_fine") if k in g.files}
+    opt = dict(num_coarse=meta["nc"], num_fine=meta["nf"], perturb=meta["perturb"], lindisp=meta["lindisp"],
+               white_background=meta["white"], noise_std=meta["noise"])
+    return g, meta, cfg_c, cfg_f, rays, rand, opt
+
+
+def case_e2e_golden(b, name, with_grads=True):
+    """Fused render (+ backward) against outputs and gradients recorded from the REAL reference."""
+    g, meta, cfg_c, cfg_f, rays, rand, opt = e2e_inputs(name)
+    pc, _, flat_c, packed_c = mlp_setup(b, cfg_c, seed=meta["seed"] * 2 + 1)
+    pf, _, flat_f, packed_f = mlp_setup(b, cfg_f, seed=meta["seed"] * 2 + 2)
+    n = rays.shape[0]
+    out = b.render(pc, pf, packed_c, packed_f, rays, opt, rand, training=with_grads)
+    for k in ("rgb_coarse", "acc_coarse", "rgb_fine", "acc_fine"):
+        close(out[k], g[k], 1e-4, what="%s %s" % (name, k))
+    for k in ("disp_coarse", "disp_fine"):
+        close(out[k], g[k], 1e-4, 1e-4, what="%s %s" % (name, k))
+    if with_grads:
+        tgt = g["target"]
+        loss, gc, gf = b.mse_loss(out["rgb_coarse"], out["rgb_fine"], tgt)
+        assert abs(float(loss[2]) - float(g["loss"])) < 1e-5
+        out = b.render(pc, pf, packed_c, packed_f, rays, opt, rand, training=True, g_rgb=(gc, gf))
+        for tag, plan, key in (("gc_", pc, "g_params_coarse"), ("gf_", pf, "g_params_fine")):
+            grads = b.unflatten(plan, out[key])
+            for k, v in grads.items():
+                ref = g[tag + k]
+                scale = float(np.abs(ref).max()) + 1e-12
+                close(v, ref, 5e-5 * scale + 1e-9, 5e-4, what="%s grad %s%s" % (name, tag, k))
+    b.lib.plan_destroy(pc)
+    b.lib.plan_destroy(pf)
+
+
+def case_render_vs_oracle(b, cfg, n, nc, nf, seed=5, white=False, noise=0.3, with_grads=False, tol=1e-4):
+    """Fused render against the oracle on random-init nets of an arbitrary geometry (e.g. the 8x256 north star)."""
+    gen = rng(seed)
+    pc, par_c, _, packed_c = mlp_setup(b, cfg, seed=seed + 1)
+    pf, par_f, _, packed_f = mlp_setup(b, cfg, seed=seed + 2)
+    ro = torch.tensor([0.2, -0.1, 4.0]).expand(n, 3) + 0.05 * torch.randn(n, 3, generator=gen)
+    rd = torch.randn(n, 3, generator=gen) * 0.3
+    rd[:, 2] = -1.0
+    rays = O.pack_rays(ro, rd, 2.0, 6.0, rd if cfg["use_viewdirs"] else None)
+    rand = dict(t_rand=torch.rand(n, nc, generator=gen), noise_coarse=torch.randn(n, nc, generator=gen),
+                u=torch.rand(n, nf, generator=gen), noise_fine=torch.randn(n, nc + nf, generator=gen))
+    opt = dict(num_coarse=nc, num_fine=nf, perturb=True, lindisp=False, white_background=white, noise_std=noise)
+    tgt = torch.rand(n, 3, generator=gen)
+    if with_grads:
+        par_c = {k: v.requires_grad_(True) for k, v in par_c.items()}
+        par_f = {k: v.requires_grad_(True) for k, v in par_f.items()}
+    want = O.render_rays(rays, par_c, par_f, cfg, cfg, opt, rand)
+    rnp = {k: v.numpy() for k, v in rand.items()}
+    out = b.render(pc, pf, packed_c, packed_f, rays.numpy(), opt, rnp, training=with_grads)
+    for k in ("rgb_coarse", "acc_coarse", "depth_coarse", "rgb_fine", "acc_fine", "depth_fine"):
+        close(out[k], want[k].detach().numpy(), tol, what="render %s" % k)
+    if with_grads:
+        loss, _, _, _ = O.loss_and_psnr(want["rgb_coarse"], want["rgb_fine"], tgt)
+        loss.backward()
+        l3, gc, gf = b.mse_loss(out["rgb_coarse"], out["rgb_fine"], tgt.numpy())
+        assert abs(float(l3[2]) - float(loss)) < 1e-5
+        out = b.render(pc, pf, packed_c, packed_f, rays.numpy(), opt, rnp, training=True, g_rgb=(gc, gf))
+        for plan, par, key in ((pc, par_c, "g_params_coarse"), (pf, par_f, "g_params_fine")):
+            grads = b.unflatten(plan, out[key])
+            for k, v in grads.items():
+                ref = par[k].grad.numpy()
+                scale = float(np.abs(ref).max()) + 1e-12
+                close(v, ref, 5e-5 * scale + 1e-9, 5e-4, what="grad %s %s" % (key, k))
+    b.lib.plan_destroy(pc)
+    b.lib.plan_destroy(pf)
+
+
+def case_internal_rng(b):
+    """Production mode (in-kernel Philox) == parity mode fed with nerfhip_rng_fill's numbers."""
+    cfg = MLP_GEOMETRIES["default4x128"]
+    n, nc, nf, seed, off = 6, 32, 32, 1234, 17
+    pc, _, _, packed_c = mlp_setup(b, cfg, seed=7)
+    pf, _, _, packed_f = mlp_setup(b, cfg, seed=8)
+    gen = rng(2)
+    ro = torch.tensor([0., 0., 4.0]).expand(n, 3) + 0.05 * torch.randn(n, 3, generator=gen)
+    rd = torch.randn(n, 3, generator=gen) * 0.3
+    rd[:, 2] = -1.0
+    rays = O.pack_rays(ro, rd, 2.0, 6.0, rd).numpy()
+    opt = dict(num_coarse=nc, num_fine=nf, perturb=True, lindisp=False, white_background=False, noise_std=0.5)
+    a = b.render(pc, pf, packed_c, packed_f, rays, opt, None, seed=seed, ray_offset=off)
+    rand = dict(t_rand=b.rng_fill(0, seed, 0, off * nc, n * nc).reshape(n, nc),
+                noise_coarse=b.rng_fill(1, seed, 1, off * nc, n * nc).reshape(n, nc),
+                u=b.rng_fill(0, seed, 2, off * nf, n * nf).reshape(n, nf),
+                noise_fine=b.rng_fill(1, seed, 3, off * (nc + nf), n * (nc + nf)).reshape(n, nc + nf))
+    c = b.render(pc, pf, packed_c, packed_f, rays, opt, rand)
+    for k in ("rgb_coarse", "rgb_fine", "depth_fine", "acc_fine"):
+        assert np.array_equal(a[k], c[k], equal_nan=True), k
+    nrm = b.rng_fill(1, 5, 1, 0, 20000)
+    assert abs(float(nrm.mean())) < 0.03 and abs(float(nrm.std()) - 1.0) < 0.03
+    b.lib.plan_destroy(pc)
+    b.lib.plan_destroy(pf)
+
+
+def case_loss_adam(b):
+    gen = rng(77)
+    n = 333
+    rc, rf, tg = torch.rand(n, 3, generator=gen), torch.rand(n, 3, generator=gen), torch.rand(n, 4, generator=gen)
+    rc.requires_grad_(True)
+    rf.requires_grad_(True)
+    loss, lc, lf, _ = O.loss_and_psnr(rc, rf, tg)
+    loss.backward()
+    l3, gc, gf = b.mse_loss(rc.detach().numpy(), rf.detach().numpy(), tg.numpy())
+    close(l3, [float(lc), float(lf), float(loss)], 1e-7, 1e-6, what="loss")
+    close(gc, rc.grad.numpy(), 1e-9, 1e-6, what="g_rgb_coarse")
+    close(gf, rf.grad.numpy(), 1e-9, 1e-6, what="g_rgb_fine")
+    p = torch.randn(5000, generator=gen)
+    m, v = torch.zeros(5000), torch.zeros(5000)
+    pp, mm, vv = p.numpy().copy(), m.numpy().copy(), v.numpy().copy()
+    for step in (1, 2, 3):
+        gr = torch.randn(5000, generator=gen)
+        O.adam_step(p, gr, m, v, step, 5e-3)
+        pp, mm, vv = b.adam_step(pp, gr.numpy(), mm, vv, 5e-3, step)
+        close(pp, p.numpy(), 1e-7, 1e-6, what="adam step %d" % step)

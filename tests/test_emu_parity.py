@@ -1,0 +1,66 @@
+"""CPU suite: the HIP kernel sources executed by the wave emulator (tests/emu) against the oracle / reference goldens.
+
+This checks kernel index algebra, weight packing, LDS addressing and barrier placement without a GPU.  It says nothing
+about the hardware; `tests/test_gpu_parity.py` (-m gpu) runs the same cases through the product library on an MI355X.
+"""
+import parity_cases as P
+
+
+def test_rays(emu):
+    P.case_rays(emu)
+
+
+def test_posenc(emu):
+    P.case_posenc(emu)
+
+
+def test_stratified(emu):
+    P.case_stratified(emu)
+
+
+def test_cumprod(emu):
+    P.case_cumprod(emu)
+
+
+def test_volume_render(emu):
+    P.case_volume_render(emu)
+
+
+def test_volume_render_bwd(emu):
+    P.case_volume_render_bwd(emu)
+
+
+def test_sample_pdf(emu):
+    P.case_sample_pdf(emu)
+
+
+def test_loss_adam(emu):
+    P.case_loss_adam(emu)
+
+
+def test_mlp_forward(emu):
+    P.case_mlp_forward(emu, names=("default4x128", "fern8x128_skip3_L6", "novw4x128", "noinput_linear"), m=40)
+
+
+def test_mlp_forward_northstar(emu):
+    P.case_mlp_forward(emu, names=("northstar8x256",), m=33)
+
+
+def test_mlp_golden(emu):
+    P.case_mlp_golden(emu)
+
+
+def test_mlp_backward(emu):
+    P.case_mlp_backward(emu, names=("default4x128", "fern8x128_skip3_L6", "novw4x128"), m=70)
+
+
+def test_e2e_golden_a(emu):
+    P.case_e2e_golden(emu, "e2e_a.npz")
+
+
+def test_e2e_golden_d_noviewdirs(emu):
+    P.case_e2e_golden(emu, "e2e_d.npz")
+
+
+def test_internal_rng(emu):
+    P.case_internal_rng(emu)

@@ -1,0 +1,249 @@
+"""GPU suite (-m gpu): the product library libnerfhip.so on a real MI355X against the oracle / reference goldens,
+through the C ABI (tests/backends.py GpuBackend) and through the Python drop-in API."""
+import ast
+
+import numpy as np
+import pytest
+import torch
+
+import nerf_oracle as O
+import parity_cases as P
+from backends import model_cfg
+from conftest import gold
+
+pytestmark = pytest.mark.gpu
+
+
+def test_native_library_is_the_one_loaded(gpu):
+    assert gpu.lib.is_emulated() == 0
+    assert gpu.lib.path.endswith("nerf-pytorch_amd/libnerfhip.so")
+
+
+def test_rays(gpu):
+    P.case_rays(gpu)
+
+
+def test_posenc(gpu):
+    P.case_posenc(gpu)
+
+
+def test_stratified(gpu):
+    P.case_stratified(gpu)
+
+
+def test_cumprod(gpu):
+    P.case_cumprod(gpu)
+
+
+def test_volume_render(gpu):
+    P.case_volume_render(gpu)
+
+
+def test_volume_render_bwd(gpu):
+    P.case_volume_render_bwd(gpu)
+
+
+def test_sample_pdf_indices_bit_exact(gpu):
+    P.case_sample_pdf(gpu)
+
+
+def test_loss_adam(gpu):
+    P.case_loss_adam(gpu)
+
+
+def test_mlp_forward_all_geometries(gpu):
+    P.case_mlp_forward(gpu, m=1000)
+
+
+def test_mlp_forward_reference_goldens(gpu):
+    P.case_mlp_golden(gpu)
+
+
+def test_mlp_backward(gpu):
+    P.case_mlp_backward(gpu, names=("default4x128", "deep8x128_skip4", "fern8x128_skip3_L6", "novw4x128",
+                                    "northstar8x256"), m=1500)
+
+
+@pytest.mark.parametrize("name", ["e2e_a.npz", "e2e_b.npz", "e2e_c.npz", "e2e_d.npz"])
+def test_e2e_reference_goldens(gpu, name):
+    P.case_e2e_golden(gpu, name)
+
+
+def test_northstar_render_and_gradients_vs_oracle(gpu):
+    P.case_render_vs_oracle(gpu, P.MLP_GEOMETRIES["northstar8x256"], n=48, nc=64, nf=128, with_grads=True)
+
+
+def test_default_model_render_white_background(gpu):
+    P.case_render_vs_oracle(gpu, P.MLP_GEOMETRIES["default4x128"], n=200, nc=64, nf=64, white=True, noise=1.0,
+                            with_grads=True)
+
+
+def test_internal_rng_equals_external_draws(gpu):
+    P.case_internal_rng(gpu)
+
+
+# ---- full size (BASELINE configs[1]: 4096 rays, 64+128, 8x256): size-independent properties ----------------------------
+def _full_setup(gpu, n=4096):
+    cfg = P.MLP_GEOMETRIES["northstar8x256"]
+    pc, _, _, packed_c = P.mlp_setup(gpu, cfg, seed=11)
+    pf, _, _, packed_f = P.mlp_setup(gpu, cfg, seed=12)
+    g = torch.Generator().manual_seed(3)
+    ro = torch.tensor([0.0, 0.0, 4.0]).expand(n, 3) + 0.02 * torch.randn(n, 3, generator=g)
+    rd = torch.randn(n, 3, generator=g) * 0.35
+    rd[:, 2] = -1.0
+    rays = O.pack_rays(ro, rd, 2.0, 6.0, rd).numpy()
+    opt = dict(num_coarse=64, num_fine=128, perturb=True, lindisp=False, white_background=False, noise_std=0.2)
+    return cfg, pc, pf, packed_c, packed_f, rays, opt, torch.rand(n, 3, generator=g).numpy()
+
+
+def test_full_size_chunk_invariance_and_reproducibility(gpu):
+    """Rendering 4096 rays at once == rendering them in two halves with the matching ray_offset (chunking is
+    semantically transparent), bit for bit; and a repeat run is bit-identical."""
+    cfg, pc, pf, packed_c, packed_f, rays, opt, tgt = _full_setup(gpu)
+    a = gpu.render(pc, pf, packed_c, packed_f, rays, opt, None, seed=77, ray_offset=0)
+    b = gpu.render(pc, pf, packed_c, packed_f, rays, opt, None, seed=77, ray_offset=0)
+    h1 = gpu.render(pc, pf, packed_c, packed_f, rays[:2048], opt, None, seed=77, ray_offset=0)
+    h2 = gpu.render(pc, pf, packed_c, packed_f, rays[2048:], opt, None, seed=77, ray_offset=2048)
+    for k in ("rgb_coarse", "rgb_fine", "acc_fine", "depth_fine", "disp_fine"):
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+        assert np.array_equal(a[k], np.concatenate([h1[k], h2[k]]), equal_nan=True), k
+    assert np.isfinite(a["rgb_fine"]).all() and (a["acc_fine"] >= 0).all() and (a["acc_fine"] <= 1.0 + 1e-4).all()
+
+
+def test_full_size_gradient_linearity(gpu):
+    """grad(all 4096 rays) == grad(first half) + grad(second half) for the same cotangents (the weight gradient is a
+    sum over samples): checks the split-K reduction at full size."""
+    cfg, pc, pf, packed_c, packed_f, rays, opt, tgt = _full_setup(gpu)
+    n = rays.shape[0]
+    full = gpu.render(pc, pf, packed_c, packed_f, rays, opt, None, seed=5, training=True)
+    _, gc, gf = gpu.mse_loss(full["rgb_coarse"], full["rgb_fine"], tgt)
+    full = gpu.render(pc, pf, packed_c, packed_f, rays, opt, None, seed=5, training=True, g_rgb=(gc, gf))
+    h = n // 2
+    p1 = gpu.render(pc, pf, packed_c, packed_f, rays[:h], opt, None, seed=5, ray_offset=0, training=True,
+                    g_rgb=(gc[:h], gf[:h]))
+    p2 = gpu.render(pc, pf, packed_c, packed_f, rays[h:], opt, None, seed=5, ray_offset=h, training=True,
+                    g_rgb=(gc[h:], gf[h:]))
+    for key in ("g_params_coarse", "g_params_fine"):
+        s = p1[key] + p2[key]
+        scale = float(np.abs(full[key]).max())
+        assert scale > 0
+        assert float(np.abs(full[key] - s).max()) <= 2e-4 * scale, key
+
+
+# ---- the Python drop-in API --------------------------------------------------------------------------------------------
+def _inject(draws, dev):
+    q = [torch.as_tensor(d).to(dev) for d in draws]
+    return q
+
+
+def test_python_api_run_one_iter_matches_reference_golden():
+    import nerf_pytorch_amd as N
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    dev = torch.device("cuda", 0)
+    g = gold("e2e_b.npz")
+    meta = ast.literal_eval(str(g["meta"]))
+    cfg = meta["cfg_c"]
+    mc, mf = N.FlexibleNeRFModel(**cfg), N.FlexibleNeRFModel(**cfg)
+    mc.load_state_dict(O.init_params(cfg, seed=meta["seed"] * 2 + 1))
+    mf.load_state_dict(O.init_params(cfg, seed=meta["seed"] * 2 + 2))
+    mc, mf = mc.to(dev), mf.to(dev)
+    opts = N.make_options(meta["nc"], meta["nf"], perturb=meta["perturb"], lindisp=meta["lindisp"],
+                          white_background=meta["white"], radiance_field_noise_std=meta["noise"])
+    ex = N.get_embedding_function(cfg["num_encoding_fn_xyz"], True, True)
+    ed = N.get_embedding_function(cfg["num_encoding_fn_dir"], True, True)
+    q = _inject([g["t_rand"], g["noise_coarse"], g["u"], g["noise_fine"]], dev)
+    real = torch.rand, torch.randn
+    torch.rand = lambda *a, **k: q.pop(0)
+    torch.randn = lambda *a, **k: q.pop(0)
+    try:
+        out = N.run_one_iter_of_nerf(int(g["H"]), int(g["W"]), float(g["focal"]), mc, mf, torch.from_numpy(g["ro"]).to(dev),
+                                     torch.from_numpy(g["rd"]).to(dev), opts, mode="train", encode_position_fn=ex,
+                                     encode_direction_fn=ed)
+    finally:
+        torch.rand, torch.randn = real
+    tgt = torch.from_numpy(g["target"]).to(dev)
+    loss = N.img2mse(out[0], tgt) + N.img2mse(out[3], tgt)
+    loss.backward()
+    for i, k in enumerate(("rgb_coarse", "disp_coarse", "acc_coarse", "rgb_fine", "disp_fine", "acc_fine")):
+        P.close(out[i].detach().cpu().numpy(), g[k], 1e-4, 1e-4, what="api " + k)
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    for tag, m in (("gc_", mc), ("gf_", mf)):
+        for k, p in m.named_parameters():
+            ref = g[tag + k]
+            scale = float(np.abs(ref).max()) + 1e-12
+            P.close(p.grad.cpu().numpy(), ref, 5e-5 * scale + 1e-9, 5e-4, what="api grad " + tag + k)
+
+
+def test_python_api_unfused_composition_and_model_autograd():
+    """A user network_fn that is NOT a FlexibleNeRFModel takes the generic composition path; FlexibleNeRFModel.forward
+    with autograd (the unit API) matches the oracle."""
+    import nerf_pytorch_amd as N
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    dev = torch.device("cuda", 0)
+    cfg = dict(num_layers=4, hidden_size=128, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4)
+    m = N.FlexibleNeRFModel(**cfg)
+    par = O.init_params(cfg, seed=9)
+    m.load_state_dict(par)
+    m = m.to(dev)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(300, 90, generator=g)
+    go = torch.randn(300, 4, generator=g)
+    y = m(x.to(dev))
+    (y * go.to(dev)).sum().backward()
+    p = {k: v.clone().requires_grad_(True) for k, v in par.items()}
+    yw = O.mlp_forward(p, x, cfg)
+    (yw * go).sum().backward()
+    P.close(y.detach().cpu().numpy(), yw.detach().numpy(), 2e-5, 2e-5, what="model forward")
+    for k, v in m.named_parameters():
+        ref = p[k].grad.numpy()
+        scale = float(np.abs(ref).max()) + 1e-12
+        P.close(v.grad.cpu().numpy(), ref, 2e-5 * scale + 1e-7, 2e-4, what="model grad " + k)
+    # generic path: wrap the model in a plain callable so that the fused path is not taken
+    opts = N.make_options(16, 16, perturb=False, radiance_field_noise_std=0.0)
+    ex, ed = N.get_embedding_function(10, True, True), N.get_embedding_function(4, True, True)
+    ro = torch.tensor([0.0, 0.0, 4.0]).expand(10, 3).contiguous()
+    rd = torch.randn(10, 3, generator=g) * 0.3
+    rd[:, 2] = -1.0
+    wrapped = lambda t: m(t)  # noqa: E731
+    with torch.no_grad():
+        a = N.run_one_iter_of_nerf(10, 10, 10.0, wrapped, wrapped, ro.to(dev), rd.to(dev), opts, encode_position_fn=ex,
+                                   encode_direction_fn=ed)
+        b = N.run_one_iter_of_nerf(10, 10, 10.0, m, m, ro.to(dev), rd.to(dev), opts, encode_position_fn=ex,
+                                   encode_direction_fn=ed)
+    for u, v in zip(a, b):
+        P.close(u.cpu().numpy(), v.cpu().numpy(), 2e-5, 2e-5, what="generic vs fused")
+
+
+def test_pretrained_lego_checkpoint_renders_like_the_reference():
+    """Reference-format state_dict (pretrained/lego-lowres, 4x128 nets) loads unchanged and the 64+64 deterministic
+    render of pose_spherical(30,-30,4) matches the reference's image rows (trained nets: SURVEY 0.11 noise floor)."""
+    import nerf_pytorch_amd as N
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    dev = torch.device("cuda", 0)
+    w, r = gold("lego_lowres_weights.npz"), gold("lego_lowres_render.npz")
+    cfg = dict(num_layers=4, hidden_size=128, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4)
+    mc, mf = N.FlexibleNeRFModel(**cfg), N.FlexibleNeRFModel(**cfg)
+    mc.load_state_dict({k[2:]: torch.from_numpy(w[k]) for k in w.files if k.startswith("c_")})
+    mf.load_state_dict({k[2:]: torch.from_numpy(w[k]) for k in w.files if k.startswith("f_")})
+    mc, mf = mc.to(dev), mf.to(dev)
+    H, W, focal = int(r["H"]), int(r["W"]), float(r["focal"])
+    opts = N.make_options(64, 64, perturb=False, white_background=True, radiance_field_noise_std=0.0)
+    ex, ed = N.get_embedding_function(10, True, True), N.get_embedding_function(4, True, True)
+    ro, rd = N.get_ray_bundle(H, W, focal, torch.from_numpy(r["pose"])[:3, :4].to(dev))
+    with torch.no_grad():
+        out = N.run_one_iter_of_nerf(H, W, focal, mc, mf, ro, rd, opts, mode="validation", encode_position_fn=ex,
+                                     encode_direction_fn=ed)
+    rows = torch.from_numpy(r["rows"]).to(dev)
+    rgb = out[3][rows].cpu().numpy()
+    acc = out[5][rows].cpu().numpy()
+    err = np.abs(rgb - r["rgb_fine"])
+    # trained nets: the inverse CDF is ill-conditioned on flat plateaus; the reference itself moves by up to 6e-4
+    # between fp32 and fp64.  Require the bulk within 1e-4 and the tail within 2e-3.
+    assert float(np.quantile(err, 0.999)) < 2e-4, float(np.quantile(err, 0.999))
+    assert float(err.max()) < 2e-3, float(err.max())
+    assert float(np.abs(acc - r["acc_fine"]).max()) < 2e-3
+    full_mean = float(out[3].mean())
+    assert abs(full_mean - float(r["rgb_fine_mean"])) < 1e-4

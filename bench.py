@@ -65,7 +65,9 @@ def cpu_baseline(sample_rays=512, reps=2):
     """The oracle (CPU port of the reference path) forward+backward on `sample_rays` synthetic rays, 64+128, 8x256."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import nerf_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    # 16 threads is the fastest setting on the 256-thread EPYC host of the GPU box (measured: 8 -> 520, 16 -> 709,
+    # 32 -> 576, 64 -> 253, 128 -> 49 rays/s; profiles/r01_cpu_threads.txt): more threads only add fork/join overhead
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     cfg = dict(MODEL)
     pc = {k: v.requires_grad_(True) for k, v in O.init_params(cfg, seed=1).items()}
     pf = {k: v.requires_grad_(True) for k, v in O.init_params(cfg, seed=2).items()}
@@ -93,6 +95,42 @@ def cpu_baseline(sample_rays=512, reps=2):
     return dict(value=n / best, unit="rays/s", cores=torch.get_num_threads(), kind="port",
                 sample="%d rays x (64 coarse + 128 fine), 8x256 nets, fwd+bwd (no optimizer), best of %d after 1 warm-up; "
                        "oracle/nerf_oracle.py (torch %s CPU)" % (n, reps, torch.__version__))
+
+
+def pytorch_rocm_reference(dev, n=RAYS_PER_GPU, reps=3):
+    """The reference's own PyTorch path (the oracle's torch ops, op for op) on THIS GPU: forward+backward on n rays --
+    the denominator of the north star's "x the reference single-GPU PyTorch-ROCm rays/sec"."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import nerf_oracle as O
+    cfg = dict(MODEL)
+    pc = {k: v.to(dev).requires_grad_(True) for k, v in O.init_params(cfg, 1).items()}
+    pf = {k: v.to(dev).requires_grad_(True) for k, v in O.init_params(cfg, 2).items()}
+    g = torch.Generator().manual_seed(0)
+    ro = torch.tensor([0.0, 0.0, 4.0]).expand(n, 3)
+    rd = torch.randn(n, 3, generator=g) * 0.3
+    rd[:, 2] = -1.0
+    rays = O.pack_rays(ro, rd, 2.0, 6.0, rd).to(dev)
+    tgt = torch.rand(n, 3, generator=g).to(dev)
+    opt = dict(num_coarse=NC, num_fine=NF, perturb=True, lindisp=False, white_background=False, noise_std=0.2)
+    best = float("inf")
+    for it in range(reps + 1):
+        rand = dict(t_rand=torch.rand(n, NC, device=dev), noise_coarse=torch.randn(n, NC, device=dev),
+                    u=torch.rand(n, NF, device=dev), noise_fine=torch.randn(n, NC + NF, device=dev))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = O.render_rays(rays, pc, pf, cfg, cfg, opt, rand, chunksize=131072)
+        loss = torch.nn.functional.mse_loss(out["rgb_coarse"], tgt) + torch.nn.functional.mse_loss(out["rgb_fine"], tgt)
+        loss.backward()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        for p in list(pc.values()) + list(pf.values()):
+            p.grad = None
+        if it > 0:
+            best = min(best, dt)
+    del pc, pf, out, loss
+    torch.cuda.empty_cache()
+    return dict(value=n / best, unit="rays/s", what="oracle torch ops on cuda (== reference PyTorch-ROCm path), "
+                "fwd+bwd, no optimizer, %d rays, best of %d" % (n, reps))
 
 
 def main():
@@ -205,6 +243,11 @@ def main():
                    final_loss=loss_host, roofline=roof)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
+            try:
+                res["pytorch_rocm_reference"] = pytorch_rocm_reference(dev)
+                res["speedup_vs_pytorch_rocm_fwd_bwd"] = round(res["value"] / res["pytorch_rocm_reference"]["value"], 3)
+            except Exception as e:  # the torch arm needs ~13 GB and must never take the bench line down
+                res["pytorch_rocm_reference"] = dict(error=repr(e)[:200])
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res))

@@ -6,23 +6,27 @@
 // weights are the MFMA A operand, the activations the B operand.  With that orientation the C/D register layout of
 // one layer IS the B-operand layout of the next one, so activations never leave the register file -- no LDS
 // round-trip, no HBM materialisation of the (N*S, 90) encodings or (N*S, 256) hidden states the reference creates
-// (nerf/train_utils.py:8-25).  Weights stream L2 -> registers -> LDS in 32-output-row chunks (double buffered, one
-// barrier per chunk) and are broadcast to the 4 wavefronts by ds_read_b128.
+// (nerf/train_utils.py:8-25).  Weights stream L2 -> LDS in 32-output-row chunks by LDS-DMA (global_load_lds, issued
+// when the previous chunk starts computing; double buffered, one barrier per chunk) and are broadcast to the 4
+// wavefronts by ds_read_b128, prefetched two groups ahead of the MFMAs that consume them.
 //
 // Weight-gradient kernel: a split-K GEMM  dW[out,in] = sum_samples dpre[out][s] * act[in][s]  whose operands are
-// the [tile][row][32 samples] images the other two kernels write; each wavefront keeps up to a 128x128 patch of dW
-// in 256 accumulator registers and walks a contiguous range of sample tiles; a second kernel reduces the split-K
-// partials in a fixed order (bit-reproducible) and scatters them into the reference parameter layout.
+// the sample-major [tile][32 samples][rows] images the other two kernels write (one coalesced dword load = 32
+// consecutive rows of one sample = one MFMA operand); each wavefront keeps up to a 128x128 patch of dW in 256
+// accumulator registers and walks a contiguous range of sample tiles; a second kernel reduces the split-K partials
+// in a fixed order (bit-reproducible) and scatters them into the reference parameter layout.
+#include <stdlib.h>
+
 #include "nh_mlp.h"
 
 namespace {
 
 template <int W>
 struct Cfg {
-    static constexpr int KH = W / 2;                       // registers of a hidden activation
-    static constexpr int KRMAX = KH + NH_KRX;              // widest layer (skip layer)
-    static constexpr int LB = KRMAX * 64 + 32;             // floats of one LDS weight buffer
-    static constexpr int N4MAX = (LB / 4 + 255) / 256;     // float4 per thread to stage one chunk
+    static constexpr int KH = W / 2;                    // registers of a hidden activation
+    static constexpr int KRMAX = KH + NH_KRX;           // widest layer (skip layer)
+    static constexpr int LB = KRMAX * 64 + 256;         // floats of one LDS weight buffer
+    static constexpr int N4MAX = (LB / 4 + 255) / 256;  // float4 per thread to stage one chunk (register path)
     static constexpr int LDS_BYTES = 2 * LB * 4;
 };
 
@@ -51,19 +55,25 @@ NH_DEVICE void stage_store(const Stage<N4MAX>& s, float* ldsbuf, int n4) {
         if (idx < n4) p[idx] = s.v[q];
     }
 }
+// LDS-DMA of one chunk: n4/64 pieces of 1 KiB, piece p by wave (p & 3)
+NH_DEVICE void dma_issue(const float* __restrict__ chunk, int n4, float* ldsbuf, int wave, int lane) {
+    const int pieces = n4 >> 6;
+    for (int p = wave; p < pieces; p += 4) nh_glds16(chunk + p * 256 + lane * 4, ldsbuf + p * 256);
+}
 
-NH_DEVICE int n4_of(int kr) { return kr * 16 + 8; }
+NH_DEVICE int n4_of(int kr) { return kr * 16 + 64; }
 
 // One linear layer for the 32 samples of this wavefront:  out[t] (32 rows x 32 samples) = Wchunk_t * in + bias_t.
 // Precondition: chunk 0 of this layer is in lds buffer `buf` and a barrier has been passed.  While tile t is being
-// computed the next chunk (of this layer, or the first chunk of the next layer) travels global -> registers; it is
-// written to the other LDS buffer after the MFMAs and published by the barrier that ends the tile.
-template <int W, int KRA, int KRB, int TILES>
+// computed the next chunk (of this layer, or the first chunk of the next layer) travels to the other LDS buffer; it
+// is published by the barrier that ends the tile.
+template <int W, bool DMA, int KRA, int KRB, int TILES>
 NH_DEVICE void gemm_layer(const float* inA, const float* inB, const float* __restrict__ wl,
                           const float* __restrict__ next_chunk, int next_n4, float* lds, int& buf,
-                          Stage<Cfg<W>::N4MAX>& st, f32x16* out, int lane) {
+                          Stage<Cfg<W>::N4MAX>& st, f32x16* out, int lane, int wave) {
     constexpr int KR = KRA + KRB;
-    constexpr int CH = KR * 64 + 32;
+    constexpr int CH = KR * 64 + 256;
+    constexpr int NG = KR / 4;
     static_assert(KR % 4 == 0, "KR must be a multiple of 4");
     static_assert(KR <= Cfg<W>::KRMAX, "KR too large for the LDS buffer");
     const int h = lane >> 5;
@@ -71,7 +81,13 @@ NH_DEVICE void gemm_layer(const float* inA, const float* inB, const float* __res
     for (int t = 0; t < TILES; ++t) {
         const float* nxt = (t + 1 < TILES) ? wl + (size_t)(t + 1) * CH : next_chunk;
         const int n4 = (t + 1 < TILES) ? CH / 4 : next_n4;
-        if (nxt) stage_load(st, nxt, n4);
+        float* other = lds + (buf ^ 1) * Cfg<W>::LB;
+        if (nxt) {
+            if (DMA)
+                dma_issue(nxt, n4, other, wave, lane);
+            else
+                stage_load(st, nxt, n4);
+        }
         const float* cur = lds + buf * Cfg<W>::LB;
         f32x16 acc;
 #pragma unroll
@@ -83,41 +99,92 @@ NH_DEVICE void gemm_layer(const float* inA, const float* inB, const float* __res
             acc[4 * g + 3] = b4.w;
         }
         const float4* w4 = (const float4*)cur + lane;
-        float4 wc = w4[0];
+        float4 w0 = w4[0];
+        float4 w1 = w4[(NG > 1 ? 1 : 0) * 64];
 #pragma unroll
-        for (int g = 0; g < KR / 4; ++g) {
-            float4 wn = wc;
-            if (g + 1 < KR / 4) wn = w4[(g + 1) * 64];
+        for (int g = 0; g < NG; ++g) {
+            float4 w2 = w1;
+            if (g + 2 < NG) w2 = w4[(g + 2) * 64];
+            nh_sched_fence();  // the prefetch above is issued before these MFMAs; its data is used two groups later
             const int r = 4 * g;
-            acc = nh_mfma32(wc.x, (r + 0 < KRA) ? inA[r + 0] : inB[r + 0 - KRA], acc);
-            acc = nh_mfma32(wc.y, (r + 1 < KRA) ? inA[r + 1] : inB[r + 1 - KRA], acc);
-            acc = nh_mfma32(wc.z, (r + 2 < KRA) ? inA[r + 2] : inB[r + 2 - KRA], acc);
-            acc = nh_mfma32(wc.w, (r + 3 < KRA) ? inA[r + 3] : inB[r + 3 - KRA], acc);
-            wc = wn;
+            acc = nh_mfma32(w0.x, (r + 0 < KRA) ? inA[r + 0] : inB[r + 0 - KRA], acc);
+            acc = nh_mfma32(w0.y, (r + 1 < KRA) ? inA[r + 1] : inB[r + 1 - KRA], acc);
+            acc = nh_mfma32(w0.z, (r + 2 < KRA) ? inA[r + 2] : inB[r + 2 - KRA], acc);
+            acc = nh_mfma32(w0.w, (r + 3 < KRA) ? inA[r + 3] : inB[r + 3 - KRA], acc);
+            w0 = w1;
+            w1 = w2;
         }
         out[t] = acc;
-        if (nxt) stage_store(st, lds + (buf ^ 1) * Cfg<W>::LB, n4);
+        if (nxt) {
+            if (DMA)
+                nh_wait_vmem();
+            else
+                stage_store(st, other, n4);
+        }
         nh_block_sync();
         buf ^= 1;
     }
 }
 
-// ---- stash helpers: region image [tile][row][32 samples] ------------------------------------------------------------
-template <int N>
-NH_DEVICE void store_feat_rows(float* __restrict__ tile_base, const float* v, int j, int h) {
-#pragma unroll
-    for (int r = 0; r < N; ++r) tile_base[(size_t)nh_feat_of(r >> 4, r & 15, h) * 32 + j] = v[r];
+template <int W, bool DMA>
+NH_DEVICE void first_chunk(const float* __restrict__ chunk, int n4, float* lds, Stage<Cfg<W>::N4MAX>& st, int wave,
+                           int lane) {
+    if (DMA) {
+        dma_issue(chunk, n4, lds, wave, lane);
+        nh_wait_vmem();
+    } else {
+        stage_load(st, chunk, n4);
+        stage_store(st, lds, n4);
+    }
+    nh_block_sync();
 }
-template <int N>
-NH_DEVICE void store_slot_rows(float* __restrict__ tile_base, const float* v, int j, int h) {
-#pragma unroll
-    for (int r = 0; r < N; ++r) tile_base[(size_t)(2 * r + h) * 32 + j] = v[r];
-}
+
+// ---- sample-major region images: element (tile, sample j, row) at base + ((tile*32 + j)*rows + row) -------------------
 NH_DEVICE float* region_tile(float* base, const NhRegion& R, int64_t nt, int64_t tile) {
     return base + (size_t)32 * (size_t)nt * (size_t)R.row_prefix + (size_t)tile * (size_t)R.rows * 32;
 }
 NH_DEVICE const float* region_tile_c(const float* base, const NhRegion& R, int64_t nt, int64_t tile) {
     return base + (size_t)32 * (size_t)nt * (size_t)R.row_prefix + (size_t)tile * (size_t)R.rows * 32;
+}
+// hidden activations: registers 4q..4q+3 of lane (j,h) are rows feat(4q,h)..+3 of sample j
+template <int N>
+NH_DEVICE void store_feat_rows(float* __restrict__ tile_base, int rows, const float* v, int j, int h) {
+    float* row = tile_base + (size_t)j * rows;
+#pragma unroll
+    for (int q = 0; q < N / 4; ++q) {
+        float4 x;
+        x.x = v[4 * q + 0];
+        x.y = v[4 * q + 1];
+        x.z = v[4 * q + 2];
+        x.w = v[4 * q + 3];
+        *(float4*)(row + nh_feat_of(q >> 2, 4 * (q & 3), h)) = x;
+    }
+}
+template <int N>
+NH_DEVICE void load_feat_rows(float* v, const float* __restrict__ tile_base, int rows, int j, int h) {
+    const float* row = tile_base + (size_t)j * rows;
+#pragma unroll
+    for (int q = 0; q < N / 4; ++q) {
+        const float4 x = *(const float4*)(row + nh_feat_of(q >> 2, 4 * (q & 3), h));
+        v[4 * q + 0] = x.x;
+        v[4 * q + 1] = x.y;
+        v[4 * q + 2] = x.z;
+        v[4 * q + 3] = x.w;
+    }
+}
+// encoding slots: register r of lane (j,h) is row h*N + r
+template <int N>
+NH_DEVICE void store_slot_rows(float* __restrict__ tile_base, int rows, const float* v, int j, int h) {
+    float* row = tile_base + (size_t)j * rows + h * N;
+#pragma unroll
+    for (int q = 0; q < N / 4; ++q) {
+        float4 x;
+        x.x = v[4 * q + 0];
+        x.y = v[4 * q + 1];
+        x.z = v[4 * q + 2];
+        x.w = v[4 * q + 3];
+        *(float4*)(row + 4 * q) = x;
+    }
 }
 
 struct MlpFwdArgs {
@@ -165,7 +232,7 @@ NH_DEVICE void encode_slots(float* e, float x, float y, float z, int h, const fl
     }
 }
 
-template <int W, bool VIEW>
+template <int W, bool VIEW, bool DMA>
 NH_KERNEL void NH_LB(256, 1) k_mlp_fwd(MlpFwdArgs a) {
     using C = Cfg<W>;
     constexpr int KH = C::KH, TW = W / 32;
@@ -207,16 +274,14 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_fwd(MlpFwdArgs a) {
         for (int r = 0; r < NH_KRD; ++r) ed[r] = 0.0f;
     }
     if (a.stash) {
-        store_slot_rows<NH_KRX>(region_tile(a.stash, a.sl.X, a.nt, tile), ex, j, h);
-        if (VIEW) store_slot_rows<NH_KRD>(region_tile(a.stash, a.sl.D, a.nt, tile), ed, j, h);
+        store_slot_rows<NH_KRX>(region_tile(a.stash, a.sl.X, a.nt, tile), a.sl.X.rows, ex, j, h);
+        if (VIEW) store_slot_rows<NH_KRD>(region_tile(a.stash, a.sl.D, a.nt, tile), a.sl.D.rows, ed, j, h);
     }
 
     Stage<C::N4MAX> st;
     int buf = 0;
     const float* pk = a.packed;
-    stage_load(st, pk + a.off.f_layer1, n4_of(NH_KRX));
-    stage_store(st, lds, n4_of(NH_KRX));
-    nh_block_sync();
+    first_chunk<W, DMA>(pk + a.off.f_layer1, n4_of(NH_KRX), lds, st, wave, lane);
 
     f32x16 o[TW + 1];
     float act[KH];
@@ -224,12 +289,12 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_fwd(MlpFwdArgs a) {
         const bool more = a.L > 1;
         const float* nxt = pk + (more ? a.off.f_xyz[0] : a.off.f_head);
         const int nn4 = n4_of(KH);  // layers_xyz[0] is never a skip layer (i > 0 is required)
-        gemm_layer<W, NH_KRX, 0, TW>(ex, nullptr, pk + a.off.f_layer1, nxt, nn4, lds, buf, st, o, lane);
+        gemm_layer<W, DMA, NH_KRX, 0, TW>(ex, nullptr, pk + a.off.f_layer1, nxt, nn4, lds, buf, st, o, lane, wave);
 #pragma unroll
         for (int t = 0; t < TW; ++t)
 #pragma unroll
             for (int c = 0; c < 16; ++c) act[16 * t + c] = o[t][c];  // no activation after layer1 (models.py:238)
-        if (a.stash) store_feat_rows<KH>(region_tile(a.stash, a.sl.H[0], a.nt, tile), act, j, h);
+        if (a.stash) store_feat_rows<KH>(region_tile(a.stash, a.sl.H[0], a.nt, tile), W, act, j, h);
     }
     for (int i = 0; i < a.L - 1; ++i) {
         const bool sk = (i % a.skip == 0) && i > 0;
@@ -238,33 +303,33 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_fwd(MlpFwdArgs a) {
         const float* nxt = pk + (more ? a.off.f_xyz[i + 1] : a.off.f_head);
         const int nn4 = n4_of(KH + (nsk ? NH_KRX : 0));
         if (sk)
-            gemm_layer<W, KH, NH_KRX, TW>(act, ex, pk + a.off.f_xyz[i], nxt, nn4, lds, buf, st, o, lane);
+            gemm_layer<W, DMA, KH, NH_KRX, TW>(act, ex, pk + a.off.f_xyz[i], nxt, nn4, lds, buf, st, o, lane, wave);
         else
-            gemm_layer<W, KH, 0, TW>(act, nullptr, pk + a.off.f_xyz[i], nxt, nn4, lds, buf, st, o, lane);
+            gemm_layer<W, DMA, KH, 0, TW>(act, nullptr, pk + a.off.f_xyz[i], nxt, nn4, lds, buf, st, o, lane, wave);
 #pragma unroll
         for (int t = 0; t < TW; ++t)
 #pragma unroll
             for (int c = 0; c < 16; ++c) act[16 * t + c] = fmaxf(o[t][c], 0.0f);
-        if (a.stash) store_feat_rows<KH>(region_tile(a.stash, a.sl.H[i + 1], a.nt, tile), act, j, h);
+        if (a.stash) store_feat_rows<KH>(region_tile(a.stash, a.sl.H[i + 1], a.nt, tile), W, act, j, h);
     }
     if (VIEW) {
-        gemm_layer<W, KH, 0, TW + 1>(act, nullptr, pk + a.off.f_head, pk + a.off.f_dir, n4_of(KH + NH_KRD), lds, buf, st,
-                                     o, lane);
+        gemm_layer<W, DMA, KH, 0, TW + 1>(act, nullptr, pk + a.off.f_head, pk + a.off.f_dir, n4_of(KH + NH_KRD), lds, buf,
+                                          st, o, lane, wave);
         const float alpha = o[TW][0];  // row 0 of the extra tile = fc_alpha(h) (models.py:249), raw
 #pragma unroll
         for (int t = 0; t < TW; ++t)
 #pragma unroll
             for (int c = 0; c < 16; ++c) act[16 * t + c] = fmaxf(o[t][c], 0.0f);  // feat = relu(fc_feat(h))
-        if (a.stash) store_feat_rows<KH>(region_tile(a.stash, a.sl.FEAT, a.nt, tile), act, j, h);
-        gemm_layer<W, KH, NH_KRD, TW / 2>(act, ed, pk + a.off.f_dir, pk + a.off.f_rgb, n4_of(KH / 2), lds, buf, st, o,
-                                          lane);
+        if (a.stash) store_feat_rows<KH>(region_tile(a.stash, a.sl.FEAT, a.nt, tile), W, act, j, h);
+        gemm_layer<W, DMA, KH, NH_KRD, TW / 2>(act, ed, pk + a.off.f_dir, pk + a.off.f_rgb, n4_of(KH / 2), lds, buf, st, o,
+                                               lane, wave);
         float dh[KH / 2];
 #pragma unroll
         for (int t = 0; t < TW / 2; ++t)
 #pragma unroll
             for (int c = 0; c < 16; ++c) dh[16 * t + c] = fmaxf(o[t][c], 0.0f);
-        if (a.stash) store_feat_rows<KH / 2>(region_tile(a.stash, a.sl.DIRH, a.nt, tile), dh, j, h);
-        gemm_layer<W, KH / 2, 0, 1>(dh, nullptr, pk + a.off.f_rgb, nullptr, 0, lds, buf, st, o, lane);
+        if (a.stash) store_feat_rows<KH / 2>(region_tile(a.stash, a.sl.DIRH, a.nt, tile), W / 2, dh, j, h);
+        gemm_layer<W, DMA, KH / 2, 0, 1>(dh, nullptr, pk + a.off.f_rgb, nullptr, 0, lds, buf, st, o, lane, wave);
         if (valid && h == 0) {
             float4 r4;
             r4.x = o[0][0];
@@ -274,7 +339,7 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_fwd(MlpFwdArgs a) {
             *(float4*)(a.out + (size_t)m * 4) = r4;
         }
     } else {
-        gemm_layer<W, KH, 0, 1>(act, nullptr, pk + a.off.f_head, nullptr, 0, lds, buf, st, o, lane);
+        gemm_layer<W, DMA, KH, 0, 1>(act, nullptr, pk + a.off.f_head, nullptr, 0, lds, buf, st, o, lane, wave);
         if (valid && h == 0) {
             float4 r4;
             r4.x = o[0][0];
@@ -299,21 +364,17 @@ struct DgradArgs {
     NhGradLayout gl;
 };
 
-// v[r] = (stash row feat(r,h) of this sample > 0) ? o[r] : 0, then store the masked value to the grad region
+// v[r] = (mk[r] > 0) ? o[r] : 0   (mk = the stashed post-ReLU activation, prefetched before the GEMM)
 template <int N>
-NH_DEVICE void mask_and_store(float* v, const f32x16* o, const float* __restrict__ act_tile, float* __restrict__ dst_tile,
-                              int j, int h, bool masked) {
+NH_DEVICE void apply_mask(float* v, const f32x16* o, const float* mk, bool masked) {
 #pragma unroll
     for (int r = 0; r < N; ++r) {
-        const size_t idx = (size_t)nh_feat_of(r >> 4, r & 15, h) * 32 + j;
-        float g = o[r >> 4][r & 15];
-        if (masked) g = act_tile[idx] > 0.0f ? g : 0.0f;
-        v[r] = g;
-        dst_tile[idx] = g;
+        const float g = o[r >> 4][r & 15];
+        v[r] = (!masked || mk[r] > 0.0f) ? g : 0.0f;
     }
 }
 
-template <int W, bool VIEW>
+template <int W, bool VIEW, bool DMA>
 NH_KERNEL void NH_LB(256, 1) k_mlp_dgrad(DgradArgs a) {
     using C = Cfg<W>;
     constexpr int KH = C::KH, TW = W / 32;
@@ -326,21 +387,20 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_dgrad(DgradArgs a) {
     float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
     if (valid) go = *(const float4*)(a.g_out + (size_t)m * 4);
     {
-        float* po = region_tile(a.grad, a.gl.POUT, a.nt, tile);
-        if (h == 0) {
-            po[0 * 32 + j] = go.x;
-            po[1 * 32 + j] = go.y;
-            po[2 * 32 + j] = go.z;
-            po[3 * 32 + j] = go.w;
-        }
-#pragma unroll
-        for (int c = 0; c < 14; ++c) po[(4 + 2 * c + h) * 32 + j] = 0.0f;
+        // POUT: rows 0..2 d(rgb raw), row 3 d(sigma raw), rows 4..31 zero
+        float* po = region_tile(a.grad, a.gl.POUT, a.nt, tile) + (size_t)j * 32 + h * 16;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        *(float4*)(po + 0) = h == 0 ? go : z4;
+        *(float4*)(po + 4) = z4;
+        *(float4*)(po + 8) = z4;
+        *(float4*)(po + 12) = z4;
     }
     Stage<C::N4MAX> st;
     int buf = 0;
     const float* pk = a.packed;
     f32x16 o[TW];
     float dp[KH];
+    float mk[KH];
     const int L = a.L;
     if (VIEW) {
         float d4[4];
@@ -348,42 +408,50 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_dgrad(DgradArgs a) {
         d4[1] = h == 0 ? go.y : 0.0f;
         d4[2] = h == 0 ? go.z : 0.0f;
         d4[3] = 0.0f;
-        stage_load(st, pk + a.off.b_rgb, n4_of(4));
-        stage_store(st, lds, n4_of(4));
-        nh_block_sync();
-        gemm_layer<W, 4, 0, TW / 2>(d4, nullptr, pk + a.off.b_rgb, pk + a.off.b_dir, n4_of(KH / 2), lds, buf, st, o, lane);
+        load_feat_rows<KH / 2>(mk, region_tile_c(a.stash, a.sl.DIRH, a.nt, tile), W / 2, j, h);
+        nh_sched_fence();
+        first_chunk<W, DMA>(pk + a.off.b_rgb, n4_of(4), lds, st, wave, lane);
+        gemm_layer<W, DMA, 4, 0, TW / 2>(d4, nullptr, pk + a.off.b_rgb, pk + a.off.b_dir, n4_of(KH / 2), lds, buf, st, o,
+                                         lane, wave);
         float dpd[KH / 2];
-        mask_and_store<KH / 2>(dpd, o, region_tile_c(a.stash, a.sl.DIRH, a.nt, tile),
-                               region_tile(a.grad, a.gl.PDIR, a.nt, tile), j, h, true);
-        gemm_layer<W, KH / 2, 0, TW>(dpd, nullptr, pk + a.off.b_dir, pk + a.off.b_head, n4_of(KH + 4), lds, buf, st, o,
-                                     lane);
-        mask_and_store<KH>(dp, o, region_tile_c(a.stash, a.sl.FEAT, a.nt, tile),
-                           region_tile(a.grad, a.gl.PFEAT, a.nt, tile), j, h, true);
+        apply_mask<KH / 2>(dpd, o, mk, true);
+        store_feat_rows<KH / 2>(region_tile(a.grad, a.gl.PDIR, a.nt, tile), W / 2, dpd, j, h);
+        load_feat_rows<KH>(mk, region_tile_c(a.stash, a.sl.FEAT, a.nt, tile), W, j, h);
+        nh_sched_fence();
+        gemm_layer<W, DMA, KH / 2, 0, TW>(dpd, nullptr, pk + a.off.b_dir, pk + a.off.b_head, n4_of(KH + 4), lds, buf, st, o,
+                                          lane, wave);
+        apply_mask<KH>(dp, o, mk, true);
+        store_feat_rows<KH>(region_tile(a.grad, a.gl.PFEAT, a.nt, tile), W, dp, j, h);
+        if (L > 1) load_feat_rows<KH>(mk, region_tile_c(a.stash, a.sl.H[L - 1], a.nt, tile), W, j, h);
+        nh_sched_fence();
         float da[4];
         da[0] = h == 0 ? go.w : 0.0f;
         da[1] = da[2] = da[3] = 0.0f;
         const float* nxt = L > 1 ? pk + a.off.b_xyz[L - 2] : nullptr;
-        gemm_layer<W, KH, 4, TW>(dp, da, pk + a.off.b_head, nxt, n4_of(KH), lds, buf, st, o, lane);
+        gemm_layer<W, DMA, KH, 4, TW>(dp, da, pk + a.off.b_head, nxt, n4_of(KH), lds, buf, st, o, lane, wave);
     } else {
         float d4[4];
         d4[0] = h == 0 ? go.x : 0.0f;
         d4[1] = h == 0 ? go.y : 0.0f;
         d4[2] = h == 0 ? go.z : 0.0f;
         d4[3] = h == 0 ? go.w : 0.0f;
-        stage_load(st, pk + a.off.b_head, n4_of(4));
-        stage_store(st, lds, n4_of(4));
-        nh_block_sync();
+        if (L > 1) load_feat_rows<KH>(mk, region_tile_c(a.stash, a.sl.H[L - 1], a.nt, tile), W, j, h);
+        nh_sched_fence();
+        first_chunk<W, DMA>(pk + a.off.b_head, n4_of(4), lds, st, wave, lane);
         const float* nxt = L > 1 ? pk + a.off.b_xyz[L - 2] : nullptr;
-        gemm_layer<W, 4, 0, TW>(d4, nullptr, pk + a.off.b_head, nxt, n4_of(KH), lds, buf, st, o, lane);
+        gemm_layer<W, DMA, 4, 0, TW>(d4, nullptr, pk + a.off.b_head, nxt, n4_of(KH), lds, buf, st, o, lane, wave);
     }
-    // o = dL/dH_{L-1}
+    // o = dL/dH_{L-1};  mk = H_{L-1}
     for (int k = L - 1; k >= 1; --k) {
-        mask_and_store<KH>(dp, o, region_tile_c(a.stash, a.sl.H[k], a.nt, tile), region_tile(a.grad, a.gl.P[k], a.nt, tile),
-                           j, h, true);
+        apply_mask<KH>(dp, o, mk, true);
+        store_feat_rows<KH>(region_tile(a.grad, a.gl.P[k], a.nt, tile), W, dp, j, h);
+        if (k - 1 >= 1) load_feat_rows<KH>(mk, region_tile_c(a.stash, a.sl.H[k - 1], a.nt, tile), W, j, h);
+        nh_sched_fence();
         const float* nxt = k >= 2 ? pk + a.off.b_xyz[k - 2] : nullptr;
-        gemm_layer<W, KH, 0, TW>(dp, nullptr, pk + a.off.b_xyz[k - 1], nxt, n4_of(KH), lds, buf, st, o, lane);
+        gemm_layer<W, DMA, KH, 0, TW>(dp, nullptr, pk + a.off.b_xyz[k - 1], nxt, n4_of(KH), lds, buf, st, o, lane, wave);
     }
-    mask_and_store<KH>(dp, o, nullptr, region_tile(a.grad, a.gl.P[0], a.nt, tile), j, h, false);
+    apply_mask<KH>(dp, o, mk, false);  // layer1 has no activation
+    store_feat_rows<KH>(region_tile(a.grad, a.gl.P[0], a.nt, tile), W, dp, j, h);
 }
 
 // ---- weight gradients ----------------------------------------------------------------------------------------------
@@ -412,41 +480,35 @@ struct WgradArgs {
     short dcol[2][NH_KRD];
 };
 
+// MFMA operands of one half tile (16 samples): k-step e uses sample 16*half + 2e + k of the tile (k = lane >> 5)
 template <int PO, int PI>
 struct WOperands {
-    float4 A[PO][2];
-    float4 B[PI][2];
+    float A[PO][8];
+    float B[PI][8];
 };
 
 template <int PO, int PI>
-NH_DEVICE void wgrad_load(WOperands<PO, PI>& op, const float* __restrict__ Ab, const float* __restrict__ Bb, int half,
-                          int k) {
+NH_DEVICE void wgrad_load(WOperands<PO, PI>& op, const float* __restrict__ Ab, const float* __restrict__ Bb, size_t a_rows,
+                          size_t b_rows, int half, int k) {
 #pragma unroll
-    for (int a = 0; a < PO; ++a)
+    for (int e = 0; e < 8; ++e) {
+        const size_t s = (size_t)(16 * half + 2 * e + k);
 #pragma unroll
-        for (int mm = 0; mm < 2; ++mm) op.A[a][mm] = *(const float4*)(Ab + a * 1024 + 8 * (2 * half + mm) + 4 * k);
+        for (int x = 0; x < PO; ++x) op.A[x][e] = Ab[s * a_rows + 32 * x];
 #pragma unroll
-    for (int b = 0; b < PI; ++b)
-#pragma unroll
-        for (int mm = 0; mm < 2; ++mm) op.B[b][mm] = *(const float4*)(Bb + b * 1024 + 8 * (2 * half + mm) + 4 * k);
+        for (int y = 0; y < PI; ++y) op.B[y][e] = Bb[s * b_rows + 32 * y];
+    }
 }
 
 template <int PO, int PI>
 NH_DEVICE void wgrad_compute(const WOperands<PO, PI>& op, f32x16 (&acc)[PO][PI], float (&bsum)[PO]) {
 #pragma unroll
-    for (int mm = 0; mm < 2; ++mm) {
+    for (int e = 0; e < 8; ++e) {
 #pragma unroll
-        for (int a = 0; a < PO; ++a) {
-            const float4 av = op.A[a][mm];
-            bsum[a] += (av.x + av.y) + (av.z + av.w);
+        for (int x = 0; x < PO; ++x) {
+            bsum[x] += op.A[x][e];
 #pragma unroll
-            for (int b = 0; b < PI; ++b) {
-                const float4 bv = op.B[b][mm];
-                acc[a][b] = nh_mfma32(av.x, bv.x, acc[a][b]);
-                acc[a][b] = nh_mfma32(av.y, bv.y, acc[a][b]);
-                acc[a][b] = nh_mfma32(av.z, bv.z, acc[a][b]);
-                acc[a][b] = nh_mfma32(av.w, bv.w, acc[a][b]);
-            }
+            for (int y = 0; y < PI; ++y) acc[x][y] = nh_mfma32(op.A[x][e], op.B[y][e], acc[x][y]);
         }
     }
 }
@@ -465,16 +527,18 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
 #pragma unroll
             for (int c = 0; c < 16; ++c) acc[x][y][c] = 0.0f;
     }
-    const size_t a_tile_stride = (size_t)jb.a_rows * 32, b_tile_stride = (size_t)jb.b_rows * 32;
-    const float* A0 = a.grad + (size_t)32 * (size_t)a.nt * (size_t)jb.a_prefix + (size_t)(32 * ow * PO + i) * 32;
-    const float* B0 = a.stash + (size_t)32 * (size_t)a.nt * (size_t)jb.b_prefix +
-                      (size_t)(jb.b_row0 + 32 * iw * PI + i) * 32;
+    const size_t ar = (size_t)jb.a_rows, br = (size_t)jb.b_rows;
+    const size_t a_tile_stride = ar * 32, b_tile_stride = br * 32;
+    const float* A0 = a.grad + (size_t)32 * (size_t)a.nt * (size_t)jb.a_prefix + (size_t)(32 * ow * PO + i);
+    const float* B0 = a.stash + (size_t)32 * (size_t)a.nt * (size_t)jb.b_prefix + (size_t)(jb.b_row0 + 32 * iw * PI + i);
     WOperands<PO, PI> op0, op1;
-    if (t0 < t1) wgrad_load(op0, A0 + t0 * a_tile_stride, B0 + t0 * b_tile_stride, 0, k);
+    if (t0 < t1) wgrad_load(op0, A0 + t0 * a_tile_stride, B0 + t0 * b_tile_stride, ar, br, 0, k);
     for (int64_t t = t0; t < t1; ++t) {
-        wgrad_load(op1, A0 + t * a_tile_stride, B0 + t * b_tile_stride, 1, k);
+        wgrad_load(op1, A0 + t * a_tile_stride, B0 + t * b_tile_stride, ar, br, 1, k);
+        nh_sched_fence();
         wgrad_compute(op0, acc, bsum);
-        if (t + 1 < t1) wgrad_load(op0, A0 + (t + 1) * a_tile_stride, B0 + (t + 1) * b_tile_stride, 0, k);
+        if (t + 1 < t1) wgrad_load(op0, A0 + (t + 1) * a_tile_stride, B0 + (t + 1) * b_tile_stride, ar, br, 0, k);
+        nh_sched_fence();
         wgrad_compute(op1, acc, bsum);
     }
     float* part = a.partial + (size_t)wg * NH_PART;
@@ -537,7 +601,8 @@ NH_KERNEL void k_wgrad_reduce(WgradArgs a) {
         if (jb.col_kind == 0) {
             if (in_row < jb.col_count) col = jb.col_base + in_row;
         } else {
-            const int r = in_row >> 1, hh = in_row & 1;
+            const int kr = jb.col_kind == 1 ? NH_KRX : NH_KRD;  // slot rows are numbered h*KR + r
+            const int hh = in_row / kr, r = in_row % kr;
             const int cc = jb.col_kind == 1 ? (int)a.xcol[hh][r] : (int)a.dcol[hh][r];
             if (cc >= 0) col = jb.col_base + cc;
         }
@@ -617,6 +682,16 @@ int set_lds_limit(K kern, int bytes) {
     return NERFHIP_OK;
 }
 
+// NERFHIP_STAGE=reg selects the register-staged weight path (global -> VGPR -> ds_write) instead of LDS-DMA.
+bool use_dma() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("NERFHIP_STAGE");
+        v = (e && e[0] == 'r') ? 0 : 1;
+    }
+    return v == 1;
+}
+
 }  // namespace
 
 int64_t nh_mlp_bwd_scratch_bytes(nerfhip_plan* p, int64_t M) {
@@ -669,16 +744,21 @@ int nh_mlp_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, i
     a.sl = p->stash;
     const int64_t grid = nh_ceil_div(M, 128);
     int rc = NERFHIP_OK;
-#define NH_FWD_CASE(WW, VV)                                                         \
-    {                                                                               \
-        rc = set_lds_limit(k_mlp_fwd<WW, VV>, Cfg<WW>::LDS_BYTES);                  \
-        if (rc) return rc;                                                          \
-        NH_LAUNCH((k_mlp_fwd<WW, VV>), grid, 256, Cfg<WW>::LDS_BYTES, stream, a);   \
+#define NH_FWD_CASE(WW, VV, DD)                                                         \
+    {                                                                                   \
+        rc = set_lds_limit(k_mlp_fwd<WW, VV, DD>, Cfg<WW>::LDS_BYTES);                  \
+        if (rc) return rc;                                                              \
+        NH_LAUNCH((k_mlp_fwd<WW, VV, DD>), grid, 256, Cfg<WW>::LDS_BYTES, stream, a);   \
     }
-    if (p->W == 256 && p->view) NH_FWD_CASE(256, true)
-    else if (p->W == 256) NH_FWD_CASE(256, false)
-    else if (p->view) NH_FWD_CASE(128, true)
-    else NH_FWD_CASE(128, false)
+    const bool dma = use_dma();
+    if (p->W == 256 && p->view && dma) NH_FWD_CASE(256, true, true)
+    else if (p->W == 256 && p->view) NH_FWD_CASE(256, true, false)
+    else if (p->W == 256 && dma) NH_FWD_CASE(256, false, true)
+    else if (p->W == 256) NH_FWD_CASE(256, false, false)
+    else if (p->view && dma) NH_FWD_CASE(128, true, true)
+    else if (p->view) NH_FWD_CASE(128, true, false)
+    else if (dma) NH_FWD_CASE(128, false, true)
+    else NH_FWD_CASE(128, false, false)
 #undef NH_FWD_CASE
     return nh_launch_status("mlp_fwd");
 }
@@ -703,16 +783,21 @@ int nh_mlp_backward(nerfhip_plan* p, const float* packed, const float* g_out, in
     d.gl = p->grad;
     const int64_t grid = nh_ceil_div(M, 128);
     int rc = NERFHIP_OK;
-#define NH_BWD_CASE(WW, VV)                                                           \
-    {                                                                                 \
-        rc = set_lds_limit(k_mlp_dgrad<WW, VV>, Cfg<WW>::LDS_BYTES);                  \
-        if (rc) return rc;                                                            \
-        NH_LAUNCH((k_mlp_dgrad<WW, VV>), grid, 256, Cfg<WW>::LDS_BYTES, stream, d);   \
+#define NH_BWD_CASE(WW, VV, DD)                                                           \
+    {                                                                                     \
+        rc = set_lds_limit(k_mlp_dgrad<WW, VV, DD>, Cfg<WW>::LDS_BYTES);                  \
+        if (rc) return rc;                                                                \
+        NH_LAUNCH((k_mlp_dgrad<WW, VV, DD>), grid, 256, Cfg<WW>::LDS_BYTES, stream, d);   \
     }
-    if (p->W == 256 && p->view) NH_BWD_CASE(256, true)
-    else if (p->W == 256) NH_BWD_CASE(256, false)
-    else if (p->view) NH_BWD_CASE(128, true)
-    else NH_BWD_CASE(128, false)
+    const bool dma = use_dma();
+    if (p->W == 256 && p->view && dma) NH_BWD_CASE(256, true, true)
+    else if (p->W == 256 && p->view) NH_BWD_CASE(256, true, false)
+    else if (p->W == 256 && dma) NH_BWD_CASE(256, false, true)
+    else if (p->W == 256) NH_BWD_CASE(256, false, false)
+    else if (p->view && dma) NH_BWD_CASE(128, true, true)
+    else if (p->view) NH_BWD_CASE(128, true, false)
+    else if (dma) NH_BWD_CASE(128, false, true)
+    else NH_BWD_CASE(128, false, false)
 #undef NH_BWD_CASE
     rc = nh_launch_status("mlp_dgrad");
     if (rc) return rc;

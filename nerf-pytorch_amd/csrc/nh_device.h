@@ -25,7 +25,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 NH_DEVICE int nh_lane() { return (int)(threadIdx.x & 63u); }
-NH_DEVICE int nh_wave_in_block() { return (int)(threadIdx.x >> 6); }
+// wave index inside the workgroup, as a provably wave-uniform (SGPR) value
+NH_DEVICE int nh_wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 NH_DEVICE void nh_block_sync() { __syncthreads(); }
 
 NH_DEVICE float nh_shfl(float v, int src) { return __shfl(v, src, 64); }
@@ -45,6 +46,15 @@ NH_DEVICE f32x16 nh_mfma32(float a, float b, f32x16 c) {
 }
 
 NH_DEVICE void nh_atomic_add(float* p, float v) { atomicAdd(p, v); }
+// Asynchronous global -> LDS copy of 16 bytes per lane (global_load_lds_dwordx4): lane l's 16 bytes at `g` land at
+// lds_wave_base + 16*l (the LDS destination is wave-uniform base + lane*16).  Completion: nh_wait_vmem() + barrier.
+NH_DEVICE void nh_glds16(const float* g, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+NH_DEVICE void nh_wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// nothing is scheduled across this point (pins "issue the prefetch BEFORE the MFMAs")
+NH_DEVICE void nh_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 NH_DEVICE void nh_sincos(float x, float* s, float* c) { sincosf(x, s, c); }
 #endif  // NERFHIP_EMU
 

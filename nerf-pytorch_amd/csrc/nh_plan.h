@@ -9,6 +9,9 @@
 //     B operands with no data movement;
 //   * encodings use "slots": register r of lane (j,h) is slot (r,h); the slot -> reference-column map is baked into
 //     the packed weights (xyz: 32 registers = 64 slots, dir: 16 registers = 32 slots).
+//   * stash / gradient regions are sample-major images [tile][32 samples][rows]: a lane's 4 consecutive registers
+//     are 4 consecutive rows (one 16-byte store), and the weight-gradient GEMM reads 32 consecutive rows of one
+//     sample with one fully coalesced dword load.  Slot rows are numbered h*KR + r.
 #pragma once
 #include <stdint.h>
 
@@ -23,8 +26,9 @@ constexpr int NH_MAX_LAYERS = 16;  // num_layers limit
 constexpr int NH_MAX_JOBS = 48;
 
 static inline int nh_feat(int r, int h) { return 32 * (r >> 4) + (r & 3) + 8 * ((r >> 2) & 3) + 4 * h; }
-// floats of one packed weight chunk (one 32-row output tile): kr*64 weights + 32 biases
-static inline int64_t nh_chunk_floats(int kr) { return (int64_t)kr * 64 + 32; }
+// floats of one packed weight chunk (one 32-row output tile): kr*64 weights + 32 biases padded to 256, so that a
+// chunk is a whole number of 1-KiB pieces (one LDS-DMA wave-instruction each)
+static inline int64_t nh_chunk_floats(int kr) { return (int64_t)kr * 64 + 256; }
 
 struct NhTensor {
     std::string name;

@@ -61,7 +61,8 @@ void fill_spec(const GemmSpec& s, int64_t off, int32_t* table) {
                 int64_t src = s.w(32 * t + i, r, h);
                 ch[((r >> 2) * 64 + lane) * 4 + (r & 3)] = (int32_t)src;
             }
-        for (int row = 0; row < 32; ++row) ch[(int64_t)s.kr * 64 + row] = s.b ? (int32_t)s.b(32 * t + row) : -1;
+        for (int row = 0; row < 256; ++row)
+            ch[(int64_t)s.kr * 64 + row] = (row < 32 && s.b) ? (int32_t)s.b(32 * t + row) : -1;
     }
 }
 

@@ -28,7 +28,7 @@ class _MlpFunction(torch.autograd.Function):
         lib = L.get_lib()
         m = x.shape[0]
         out = torch.empty((m, 4), dtype=torch.float32, device=x.device)
-        need = torch.is_grad_enabled() and flat.requires_grad
+        need = bool(ctx.needs_input_grad[2])  # (grad mode is off inside Function.forward: ask autograd instead)
         packed = model._packed()
         stash = None
         if need:

@@ -76,7 +76,8 @@ class _FusedRender(torch.autograd.Function):
         n, stride = rays.shape
         dev = rays.device
         cfg = L.RenderCfg(nc, nf, int(bool(perturb)), int(bool(lindisp)), int(bool(white)), float(noise_std), stride)
-        training = torch.is_grad_enabled() and (flat_c.requires_grad or (flat_f is not None and flat_f.requires_grad))
+        # grad mode is off inside Function.forward: ask autograd whether a parameter gradient will be wanted
+        training = bool(ctx.needs_input_grad[5] or ctx.needs_input_grad[6])
         plan_f = model_f._plan if nf > 0 else None
         wsb = lib.render_workspace_bytes(model_c._plan, plan_f, C.byref(cfg), n, int(training))
         if wsb < 0:

@@ -23,8 +23,8 @@ import torch.nn.functional as F
 # ---------------------------------------------------------------------------------------------------------------
 def get_ray_bundle(height, width, focal, c2w):
     """nerf/nerf_helpers.py:67-110 (+ meshgrid_xy :28-40).  Returns (ray_origins, ray_directions), each (H, W, 3)."""
-    cols = torch.arange(width, dtype=c2w.dtype)
-    rows = torch.arange(height, dtype=c2w.dtype)
+    cols = torch.arange(width, dtype=c2w.dtype, device=c2w.device)
+    rows = torch.arange(height, dtype=c2w.dtype, device=c2w.device)
     ii = cols[None, :].expand(height, width)  # x pixel coordinate varies along the last axis
     jj = rows[:, None].expand(height, width)
     d_cam = torch.stack([(ii - width * 0.5) / focal, -(jj - height * 0.5) / focal, -torch.ones_like(ii)], dim=-1)
@@ -72,7 +72,7 @@ def frequency_bands(num_freqs, log_sampling=True, dtype=torch.float32):
 def positional_encoding(x, num_freqs=6, include_input=True, log_sampling=True):
     """nerf/nerf_helpers.py:113-157: [x | sin(f0 x) | cos(f0 x) | sin(f1 x) | ...] (blocks of the full last dim)."""
     parts = [x] if include_input else []
-    for f in frequency_bands(num_freqs, log_sampling, x.dtype):
+    for f in frequency_bands(num_freqs, log_sampling, x.dtype).to(x.device):
         parts.append(torch.sin(x * f))
         parts.append(torch.cos(x * f))
     return parts[0] if len(parts) == 1 else torch.cat(parts, dim=-1)
@@ -83,7 +83,7 @@ def positional_encoding(x, num_freqs=6, include_input=True, log_sampling=True):
 # ---------------------------------------------------------------------------------------------------------------
 def stratified_z(near, far, num_coarse, lindisp=False, perturb=True, t_rand=None):
     """nerf/train_utils.py:38-65.  near/far: (N,1).  t_rand: (N, num_coarse) uniform draws (needed iff perturb)."""
-    t = torch.linspace(0.0, 1.0, num_coarse, dtype=near.dtype)
+    t = torch.linspace(0.0, 1.0, num_coarse, dtype=near.dtype).to(near.device)
     if not lindisp:
         z = near * (1.0 - t) + far * t
     else:
@@ -111,7 +111,7 @@ def cumprod_exclusive(x):
 def volume_render(raw, z, rd, noise_std=0.0, noise=None, white_background=False):
     """nerf/volume_rendering_utils.py:6-53.  `noise`: N(0,1) draws shaped like z (used iff noise_std > 0).
     Returns (rgb_map, disp_map, acc_map, weights, depth_map)."""
-    far_gap = torch.tensor([1e10], dtype=rd.dtype).expand(z[..., :1].shape)
+    far_gap = torch.tensor([1e10], dtype=rd.dtype, device=rd.device).expand(z[..., :1].shape)
     dists = torch.cat((z[..., 1:] - z[..., :-1], far_gap), dim=-1)
     dists = dists * rd[..., None, :].norm(p=2, dim=-1)
     rgb = torch.sigmoid(raw[..., :3])
@@ -142,7 +142,7 @@ def sample_pdf(bins, weights, num_samples, det=False, u=None, return_aux=False):
     cdf = torch.cumsum(pdf, dim=-1)
     cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], dim=-1)
     if det:
-        u = torch.linspace(0.0, 1.0, steps=num_samples, dtype=w.dtype).expand(list(cdf.shape[:-1]) + [num_samples])
+        u = torch.linspace(0.0, 1.0, steps=num_samples, dtype=w.dtype).to(w.device).expand(list(cdf.shape[:-1]) + [num_samples])
     u = u.contiguous()
     cdf = cdf.contiguous()
     inds = torch.searchsorted(cdf, u, right=True)

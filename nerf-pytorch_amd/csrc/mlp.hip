@@ -63,14 +63,20 @@ NH_DEVICE void dma_issue(const float* __restrict__ chunk, int n4, float* ldsbuf,
 
 NH_DEVICE int n4_of(int kr) { return kr * 16 + 64; }
 
-// One linear layer for the 32 samples of this wavefront:  out[t] (32 rows x 32 samples) = Wchunk_t * in + bias_t.
+// One linear layer for the 32 samples of this wavefront:  tile t (32 rows x 32 samples) = Wchunk_t * in + bias_t.
 // Precondition: chunk 0 of this layer is in lds buffer `buf` and a barrier has been passed.  While tile t is being
 // computed the next chunk (of this layer, or the first chunk of the next layer) travels to the other LDS buffer; it
 // is published by the barrier that ends the tile.
-template <int W, bool DMA, int KRA, int KRB, int TILES>
+// Epilogue of the first EPI tiles: v = acc, zeroed where mk <= 0 if `masked`, ReLU'd if `relu`; v becomes
+// res[16t + c] (the next layer's B operand) and, if st_row != NULL, rows 32t.. of this lane's sample in a
+// sample-major image -- four 16-byte stores issued as soon as the tile is done, so that they drain under the next
+// tile's MFMAs instead of piling up in front of the next barrier's vmcnt(0) (CDNA4's vmcnt counts stores too).
+// Tiles >= EPI are returned raw in out[t - EPI].
+template <int W, bool DMA, int KRA, int KRB, int TILES, int EPI>
 NH_DEVICE void gemm_layer(const float* inA, const float* inB, const float* __restrict__ wl,
                           const float* __restrict__ next_chunk, int next_n4, float* lds, int& buf,
-                          Stage<Cfg<W>::N4MAX>& st, f32x16* out, int lane, int wave) {
+                          Stage<Cfg<W>::N4MAX>& st, f32x16* out, int lane, int wave, float* res, bool relu,
+                          const float* mk, bool masked, float* __restrict__ st_row) {
     constexpr int KR = KRA + KRB;
     constexpr int CH = KR * 64 + 256;
     constexpr int NG = KR / 4;
@@ -114,7 +120,30 @@ NH_DEVICE void gemm_layer(const float* inA, const float* inB, const float* __res
             w0 = w1;
             w1 = w2;
         }
-        out[t] = acc;
+        if (t < EPI) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float e[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float v = acc[4 * g + c];
+                    if (masked) v = mk[16 * t + 4 * g + c] > 0.0f ? v : 0.0f;
+                    if (relu) v = fmaxf(v, 0.0f);
+                    e[c] = v;
+                    res[16 * t + 4 * g + c] = v;
+                }
+                if (st_row) {
+                    float4 x;
+                    x.x = e[0];
+                    x.y = e[1];
+                    x.z = e[2];
+                    x.w = e[3];
+                    *(float4*)(st_row + 32 * t + 8 * g + 4 * h) = x;
+                }
+            }
+        } else {
+            out[t - EPI] = acc;
+        }
         if (nxt) {
             if (DMA)
                 nh_wait_vmem();
@@ -283,18 +312,20 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_fwd(MlpFwdArgs a) {
     const float* pk = a.packed;
     first_chunk<W, DMA>(pk + a.off.f_layer1, n4_of(NH_KRX), lds, st, wave, lane);
 
-    f32x16 o[TW + 1];
+    f32x16 o[1];  // raw tiles only: fc_alpha's tile / the rgb tile / fc_out
     float act[KH];
+    float res[KH];
+    auto strow = [&](const NhRegion& R) -> float* {
+        return a.stash ? region_tile(a.stash, R, a.nt, tile) + (size_t)j * R.rows : nullptr;
+    };
     {
         const bool more = a.L > 1;
         const float* nxt = pk + (more ? a.off.f_xyz[0] : a.off.f_head);
         const int nn4 = n4_of(KH);  // layers_xyz[0] is never a skip layer (i > 0 is required)
-        gemm_layer<W, DMA, NH_KRX, 0, TW>(ex, nullptr, pk + a.off.f_layer1, nxt, nn4, lds, buf, st, o, lane, wave);
+        // no activation after layer1 (models.py:238)
+        gemm_layer<W, DMA, NH_KRX, 0, TW, TW>(ex, nullptr, pk + a.off.f_layer1, nxt, nn4, lds, buf, st, o, lane, wave, res, false, res, false, strow(a.sl.H[0]));
 #pragma unroll
-        for (int t = 0; t < TW; ++t)
-#pragma unroll
-            for (int c = 0; c < 16; ++c) act[16 * t + c] = o[t][c];  // no activation after layer1 (models.py:238)
-        if (a.stash) store_feat_rows<KH>(region_tile(a.stash, a.sl.H[0], a.nt, tile), W, act, j, h);
+        for (int r = 0; r < KH; ++r) act[r] = res[r];
     }
     for (int i = 0; i < a.L - 1; ++i) {
         const bool sk = (i % a.skip == 0) && i > 0;
@@ -302,34 +333,24 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_fwd(MlpFwdArgs a) {
         const bool nsk = more && ((i + 1) % a.skip == 0);
         const float* nxt = pk + (more ? a.off.f_xyz[i + 1] : a.off.f_head);
         const int nn4 = n4_of(KH + (nsk ? NH_KRX : 0));
+        float* sr = strow(a.sl.H[i + 1]);
         if (sk)
-            gemm_layer<W, DMA, KH, NH_KRX, TW>(act, ex, pk + a.off.f_xyz[i], nxt, nn4, lds, buf, st, o, lane, wave);
+            gemm_layer<W, DMA, KH, NH_KRX, TW, TW>(act, ex, pk + a.off.f_xyz[i], nxt, nn4, lds, buf, st, o, lane, wave, res, true, res, false, sr);
         else
-            gemm_layer<W, DMA, KH, 0, TW>(act, nullptr, pk + a.off.f_xyz[i], nxt, nn4, lds, buf, st, o, lane, wave);
+            gemm_layer<W, DMA, KH, 0, TW, TW>(act, nullptr, pk + a.off.f_xyz[i], nxt, nn4, lds, buf, st, o, lane, wave, res, true, res, false, sr);
 #pragma unroll
-        for (int t = 0; t < TW; ++t)
-#pragma unroll
-            for (int c = 0; c < 16; ++c) act[16 * t + c] = fmaxf(o[t][c], 0.0f);
-        if (a.stash) store_feat_rows<KH>(region_tile(a.stash, a.sl.H[i + 1], a.nt, tile), W, act, j, h);
+        for (int r = 0; r < KH; ++r) act[r] = res[r];
     }
     if (VIEW) {
-        gemm_layer<W, DMA, KH, 0, TW + 1>(act, nullptr, pk + a.off.f_head, pk + a.off.f_dir, n4_of(KH + NH_KRD), lds, buf,
-                                          st, o, lane, wave);
-        const float alpha = o[TW][0];  // row 0 of the extra tile = fc_alpha(h) (models.py:249), raw
-#pragma unroll
-        for (int t = 0; t < TW; ++t)
-#pragma unroll
-            for (int c = 0; c < 16; ++c) act[16 * t + c] = fmaxf(o[t][c], 0.0f);  // feat = relu(fc_feat(h))
-        if (a.stash) store_feat_rows<KH>(region_tile(a.stash, a.sl.FEAT, a.nt, tile), W, act, j, h);
-        gemm_layer<W, DMA, KH, NH_KRD, TW / 2>(act, ed, pk + a.off.f_dir, pk + a.off.f_rgb, n4_of(KH / 2), lds, buf, st, o,
-                                               lane, wave);
+        // tiles 0..TW-1: feat = relu(fc_feat(h)); tile TW row 0: fc_alpha(h), raw (models.py:248-249)
+        gemm_layer<W, DMA, KH, 0, TW + 1, TW>(act, nullptr, pk + a.off.f_head, pk + a.off.f_dir, n4_of(KH + NH_KRD), lds, buf,
+                                          st, o, lane, wave, res, true, res, false, strow(a.sl.FEAT));
+        const float alpha = o[0][0];
         float dh[KH / 2];
-#pragma unroll
-        for (int t = 0; t < TW / 2; ++t)
-#pragma unroll
-            for (int c = 0; c < 16; ++c) dh[16 * t + c] = fmaxf(o[t][c], 0.0f);
-        if (a.stash) store_feat_rows<KH / 2>(region_tile(a.stash, a.sl.DIRH, a.nt, tile), W / 2, dh, j, h);
-        gemm_layer<W, DMA, KH / 2, 0, 1>(dh, nullptr, pk + a.off.f_rgb, nullptr, 0, lds, buf, st, o, lane, wave);
+        gemm_layer<W, DMA, KH, NH_KRD, TW / 2, TW / 2>(res, ed, pk + a.off.f_dir, pk + a.off.f_rgb, n4_of(KH / 2), lds, buf, st, o,
+                                               lane, wave, dh, true, dh, false, strow(a.sl.DIRH));
+        gemm_layer<W, DMA, KH / 2, 0, 1, 0>(dh, nullptr, pk + a.off.f_rgb, nullptr, 0, lds, buf, st, o, lane, wave, dh, false,
+                                         dh, false, nullptr);
         if (valid && h == 0) {
             float4 r4;
             r4.x = o[0][0];
@@ -339,7 +360,8 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_fwd(MlpFwdArgs a) {
             *(float4*)(a.out + (size_t)m * 4) = r4;
         }
     } else {
-        gemm_layer<W, DMA, KH, 0, 1>(act, nullptr, pk + a.off.f_head, nullptr, 0, lds, buf, st, o, lane, wave);
+        gemm_layer<W, DMA, KH, 0, 1, 0>(act, nullptr, pk + a.off.f_head, nullptr, 0, lds, buf, st, o, lane, wave, res, false,
+                                     res, false, nullptr);
         if (valid && h == 0) {
             float4 r4;
             r4.x = o[0][0];
@@ -364,16 +386,6 @@ struct DgradArgs {
     NhGradLayout gl;
 };
 
-// v[r] = (mk[r] > 0) ? o[r] : 0   (mk = the stashed post-ReLU activation, prefetched before the GEMM)
-template <int N>
-NH_DEVICE void apply_mask(float* v, const f32x16* o, const float* mk, bool masked) {
-#pragma unroll
-    for (int r = 0; r < N; ++r) {
-        const float g = o[r >> 4][r & 15];
-        v[r] = (!masked || mk[r] > 0.0f) ? g : 0.0f;
-    }
-}
-
 template <int W, bool VIEW, bool DMA>
 NH_KERNEL void NH_LB(256, 1) k_mlp_dgrad(DgradArgs a) {
     using C = Cfg<W>;
@@ -395,12 +407,14 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_dgrad(DgradArgs a) {
         *(float4*)(po + 8) = z4;
         *(float4*)(po + 12) = z4;
     }
+    auto grow = [&](const NhRegion& R) -> float* { return region_tile(a.grad, R, a.nt, tile) + (size_t)j * R.rows; };
     Stage<C::N4MAX> st;
     int buf = 0;
     const float* pk = a.packed;
-    f32x16 o[TW];
-    float dp[KH];
-    float mk[KH];
+    f32x16 o[1];
+    float dp[KH];   // d(pre-activation) of the layer just finished = B operand of the next transposed GEMM
+    float res[KH];
+    float mk[KH];   // stashed post-ReLU activation of the layer being produced (prefetched before its GEMM)
     const int L = a.L;
     if (VIEW) {
         float d4[4];
@@ -411,24 +425,23 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_dgrad(DgradArgs a) {
         load_feat_rows<KH / 2>(mk, region_tile_c(a.stash, a.sl.DIRH, a.nt, tile), W / 2, j, h);
         nh_sched_fence();
         first_chunk<W, DMA>(pk + a.off.b_rgb, n4_of(4), lds, st, wave, lane);
-        gemm_layer<W, DMA, 4, 0, TW / 2>(d4, nullptr, pk + a.off.b_rgb, pk + a.off.b_dir, n4_of(KH / 2), lds, buf, st, o,
-                                         lane, wave);
         float dpd[KH / 2];
-        apply_mask<KH / 2>(dpd, o, mk, true);
-        store_feat_rows<KH / 2>(region_tile(a.grad, a.gl.PDIR, a.nt, tile), W / 2, dpd, j, h);
+        gemm_layer<W, DMA, 4, 0, TW / 2, TW / 2>(d4, nullptr, pk + a.off.b_rgb, pk + a.off.b_dir, n4_of(KH / 2), lds, buf, st, o,
+                                         lane, wave, dpd, false, mk, true, grow(a.gl.PDIR));
         load_feat_rows<KH>(mk, region_tile_c(a.stash, a.sl.FEAT, a.nt, tile), W, j, h);
         nh_sched_fence();
-        gemm_layer<W, DMA, KH / 2, 0, TW>(dpd, nullptr, pk + a.off.b_dir, pk + a.off.b_head, n4_of(KH + 4), lds, buf, st, o,
-                                          lane, wave);
-        apply_mask<KH>(dp, o, mk, true);
-        store_feat_rows<KH>(region_tile(a.grad, a.gl.PFEAT, a.nt, tile), W, dp, j, h);
+        gemm_layer<W, DMA, KH / 2, 0, TW, TW>(dpd, nullptr, pk + a.off.b_dir, pk + a.off.b_head, n4_of(KH + 4), lds, buf, st, o,
+                                          lane, wave, dp, false, mk, true, grow(a.gl.PFEAT));
         if (L > 1) load_feat_rows<KH>(mk, region_tile_c(a.stash, a.sl.H[L - 1], a.nt, tile), W, j, h);
         nh_sched_fence();
         float da[4];
         da[0] = h == 0 ? go.w : 0.0f;
         da[1] = da[2] = da[3] = 0.0f;
         const float* nxt = L > 1 ? pk + a.off.b_xyz[L - 2] : nullptr;
-        gemm_layer<W, DMA, KH, 4, TW>(dp, da, pk + a.off.b_head, nxt, n4_of(KH), lds, buf, st, o, lane, wave);
+        gemm_layer<W, DMA, KH, 4, TW, TW>(dp, da, pk + a.off.b_head, nxt, n4_of(KH), lds, buf, st, o, lane, wave, res, false,
+                                      mk, L > 1, grow(a.gl.P[L - 1]));
+#pragma unroll
+        for (int r = 0; r < KH; ++r) dp[r] = res[r];
     } else {
         float d4[4];
         d4[0] = h == 0 ? go.x : 0.0f;
@@ -439,19 +452,19 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_dgrad(DgradArgs a) {
         nh_sched_fence();
         first_chunk<W, DMA>(pk + a.off.b_head, n4_of(4), lds, st, wave, lane);
         const float* nxt = L > 1 ? pk + a.off.b_xyz[L - 2] : nullptr;
-        gemm_layer<W, DMA, 4, 0, TW>(d4, nullptr, pk + a.off.b_head, nxt, n4_of(KH), lds, buf, st, o, lane, wave);
+        gemm_layer<W, DMA, 4, 0, TW, TW>(d4, nullptr, pk + a.off.b_head, nxt, n4_of(KH), lds, buf, st, o, lane, wave, dp, false, mk, L > 1, grow(a.gl.P[L - 1]));
     }
-    // o = dL/dH_{L-1};  mk = H_{L-1}
+    // dp = d(pre-activation of H_{L-1}), already stored.  Walk down: dpre_{k-1} = relu'(H_{k-1}) * (W_{k-1}^T dpre_k);
+    // H_0 = layer1 output has no activation (models.py:238).
     for (int k = L - 1; k >= 1; --k) {
-        apply_mask<KH>(dp, o, mk, true);
-        store_feat_rows<KH>(region_tile(a.grad, a.gl.P[k], a.nt, tile), W, dp, j, h);
-        if (k - 1 >= 1) load_feat_rows<KH>(mk, region_tile_c(a.stash, a.sl.H[k - 1], a.nt, tile), W, j, h);
+        const bool masked = k - 1 >= 1;
+        if (masked) load_feat_rows<KH>(mk, region_tile_c(a.stash, a.sl.H[k - 1], a.nt, tile), W, j, h);
         nh_sched_fence();
         const float* nxt = k >= 2 ? pk + a.off.b_xyz[k - 2] : nullptr;
-        gemm_layer<W, DMA, KH, 0, TW>(dp, nullptr, pk + a.off.b_xyz[k - 1], nxt, n4_of(KH), lds, buf, st, o, lane, wave);
+        gemm_layer<W, DMA, KH, 0, TW, TW>(dp, nullptr, pk + a.off.b_xyz[k - 1], nxt, n4_of(KH), lds, buf, st, o, lane, wave, res, false, mk, masked, grow(a.gl.P[k - 1]));
+#pragma unroll
+        for (int r = 0; r < KH; ++r) dp[r] = res[r];
     }
-    apply_mask<KH>(dp, o, mk, false);  // layer1 has no activation
-    store_feat_rows<KH>(region_tile(a.grad, a.gl.P[0], a.nt, tile), W, dp, j, h);
 }
 
 // ---- weight gradients ----------------------------------------------------------------------------------------------
@@ -627,16 +640,45 @@ NH_KERNEL void k_wgrad_reduce(WgradArgs a) {
 // ---- host side -------------------------------------------------------------------------------------------------------
 constexpr int NH_WGRAD_TARGET_WGS = 1024;
 
+// Split-K allocation: job j gets ks_j workgroups with ks_j proportional to its per-tile cost (every workgroup then
+// runs for about the same time), and sum ks_j == NH_WGRAD_TARGET_WGS exactly (largest-remainder rounding) -- the grid
+// is a whole number of rounds over the 256 CUs (one 4-wave workgroup per CU), with no straggler round.
 void wgrad_schedule(const nerfhip_plan* p, int64_t nt, WgradArgs& w) {
     int64_t total_cost = 0;
     for (const NhJob& j : p->jobs) total_cost += j.cost;
     w.njobs = (int)p->jobs.size();
+    int64_t ks[NH_JOBS_DEV], rem[NH_JOBS_DEV];
+    int64_t used = 0;
+    for (int q = 0; q < w.njobs; ++q) {
+        const int64_t num = (int64_t)NH_WGRAD_TARGET_WGS * p->jobs[q].cost;
+        ks[q] = num / total_cost;
+        rem[q] = num % total_cost;
+        if (ks[q] < 1) {
+            ks[q] = 1;
+            rem[q] = 0;
+        }
+        used += ks[q];
+    }
+    while (used < NH_WGRAD_TARGET_WGS) {  // hand out the remaining workgroups by largest remainder
+        int best = 0;
+        for (int q = 1; q < w.njobs; ++q)
+            if (rem[q] > rem[best]) best = q;
+        ks[best] += 1;
+        rem[best] = -1;
+        used += 1;
+    }
+    while (used > NH_WGRAD_TARGET_WGS) {  // (only if many jobs were lifted to 1) take from the largest
+        int best = 0;
+        for (int q = 1; q < w.njobs; ++q)
+            if (ks[q] > ks[best]) best = q;
+        if (ks[best] <= 1) break;
+        ks[best] -= 1;
+        used -= 1;
+    }
     int start = 0;
     for (int q = 0; q < w.njobs; ++q) {
         const NhJob& j = p->jobs[q];
-        int64_t ks = (NH_WGRAD_TARGET_WGS * (int64_t)j.cost + total_cost / 2) / total_cost;
-        if (ks < 1) ks = 1;
-        if (ks > nt) ks = nt;
+        if (ks[q] > nt) ks[q] = nt;
         JobDev& d = w.jobs[q];
         d.a_rows = j.a_region_rows;
         d.a_prefix = (int)j.a_row_prefix;
@@ -658,7 +700,7 @@ void wgrad_schedule(const nerfhip_plan* p, int64_t nt, WgradArgs& w) {
         d.col_count = j.col_count;
         d.bias_off = (int)j.bias_off;
         d.wg_start = start;
-        start += (int)ks;
+        start += (int)ks[q];
     }
     w.total_wgs = start;
     for (int h = 0; h < 2; ++h) {

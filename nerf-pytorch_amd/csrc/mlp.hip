@@ -63,14 +63,27 @@ NH_DEVICE void dma_issue(const float* __restrict__ chunk, int n4, float* ldsbuf,
 
 NH_DEVICE int n4_of(int kr) { return kr * 16 + 64; }
 
+// rows 32t .. 32t+31 of this lane's sample (its 16 registers res[16t..]) as four 16-byte stores
+NH_DEVICE void store_tile_rows(float* __restrict__ st_row, const float* res, int t, int h) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float4 x;
+        x.x = res[16 * t + 4 * g + 0];
+        x.y = res[16 * t + 4 * g + 1];
+        x.z = res[16 * t + 4 * g + 2];
+        x.w = res[16 * t + 4 * g + 3];
+        *(float4*)(st_row + 32 * t + 8 * g + 4 * h) = x;
+    }
+}
+
 // One linear layer for the 32 samples of this wavefront:  tile t (32 rows x 32 samples) = Wchunk_t * in + bias_t.
 // Precondition: chunk 0 of this layer is in lds buffer `buf` and a barrier has been passed.  While tile t is being
 // computed the next chunk (of this layer, or the first chunk of the next layer) travels to the other LDS buffer; it
 // is published by the barrier that ends the tile.
 // Epilogue of the first EPI tiles: v = acc, zeroed where mk <= 0 if `masked`, ReLU'd if `relu`; v becomes
 // res[16t + c] (the next layer's B operand) and, if st_row != NULL, rows 32t.. of this lane's sample in a
-// sample-major image -- four 16-byte stores issued as soon as the tile is done, so that they drain under the next
-// tile's MFMAs instead of piling up in front of the next barrier's vmcnt(0) (CDNA4's vmcnt counts stores too).
+// sample-major image -- four 16-byte stores issued right AFTER the barrier that ends the tile, so that they drain
+// under the next tile's MFMAs instead of sitting in front of a vmcnt(0) (CDNA4's vmcnt counts stores too).
 // Tiles >= EPI are returned raw in out[t - EPI].
 template <int W, bool DMA, int KRA, int KRB, int TILES, int EPI>
 NH_DEVICE void gemm_layer(const float* inA, const float* inB, const float* __restrict__ wl,
@@ -94,6 +107,8 @@ NH_DEVICE void gemm_layer(const float* inA, const float* inB, const float* __res
             else
                 stage_load(st, nxt, n4);
         }
+        // rows of the PREVIOUS tile go out now: they have this whole tile's MFMAs to drain before the next vmcnt(0)
+        if (st_row && t >= 1 && t - 1 < EPI) store_tile_rows(st_row, res, t - 1, h);
         const float* cur = lds + buf * Cfg<W>::LB;
         f32x16 acc;
 #pragma unroll
@@ -122,24 +137,11 @@ NH_DEVICE void gemm_layer(const float* inA, const float* inB, const float* __res
         }
         if (t < EPI) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float e[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float v = acc[4 * g + c];
-                    if (masked) v = mk[16 * t + 4 * g + c] > 0.0f ? v : 0.0f;
-                    if (relu) v = fmaxf(v, 0.0f);
-                    e[c] = v;
-                    res[16 * t + 4 * g + c] = v;
-                }
-                if (st_row) {
-                    float4 x;
-                    x.x = e[0];
-                    x.y = e[1];
-                    x.z = e[2];
-                    x.w = e[3];
-                    *(float4*)(st_row + 32 * t + 8 * g + 4 * h) = x;
-                }
+            for (int c = 0; c < 16; ++c) {
+                float v = acc[c];
+                if (masked) v = mk[16 * t + c] > 0.0f ? v : 0.0f;
+                if (relu) v = fmaxf(v, 0.0f);
+                res[16 * t + c] = v;
             }
         } else {
             out[t - EPI] = acc;
@@ -153,6 +155,8 @@ NH_DEVICE void gemm_layer(const float* inA, const float* inB, const float* __res
         nh_block_sync();
         buf ^= 1;
     }
+    // the last epilogue tile: when raw tiles follow (EPI < TILES) it was stored at the start of tile EPI above
+    if (st_row && EPI >= 1 && EPI == TILES) store_tile_rows(st_row, res, TILES - 1, h);
 }
 
 template <int W, bool DMA>
@@ -526,7 +530,9 @@ NH_DEVICE void wgrad_compute(const WOperands<PO, PI>& op, f32x16 (&acc)[PO][PI],
     }
 }
 
-template <int PO, int PI>
+// Half-tile steps are software pipelined through a ring of DEPTH operand sets: small patches do few MFMAs per step, so
+// they need more loads in flight to cover HBM latency (a 1x1 patch computes 512 cycles per step, a 4x4 patch 8192).
+template <int PO, int PI, int DEPTH>
 NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int64_t t1, int ow, int iw, int wave,
                           int lane, int64_t wg) {
     const int i = lane & 31, k = lane >> 5;
@@ -544,15 +550,25 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
     const size_t a_tile_stride = ar * 32, b_tile_stride = br * 32;
     const float* A0 = a.grad + (size_t)32 * (size_t)a.nt * (size_t)jb.a_prefix + (size_t)(32 * ow * PO + i);
     const float* B0 = a.stash + (size_t)32 * (size_t)a.nt * (size_t)jb.b_prefix + (size_t)(jb.b_row0 + 32 * iw * PI + i);
-    WOperands<PO, PI> op0, op1;
-    if (t0 < t1) wgrad_load(op0, A0 + t0 * a_tile_stride, B0 + t0 * b_tile_stride, ar, br, 0, k);
-    for (int64_t t = t0; t < t1; ++t) {
-        wgrad_load(op1, A0 + t * a_tile_stride, B0 + t * b_tile_stride, ar, br, 1, k);
-        nh_sched_fence();
-        wgrad_compute(op0, acc, bsum);
-        if (t + 1 < t1) wgrad_load(op0, A0 + (t + 1) * a_tile_stride, B0 + (t + 1) * b_tile_stride, ar, br, 0, k);
-        nh_sched_fence();
-        wgrad_compute(op1, acc, bsum);
+    WOperands<PO, PI> ring[DEPTH];
+    const int64_t s0 = 2 * t0, s1 = 2 * t1;  // half-tile steps: step s = (tile s >> 1, half s & 1)
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+        const int64_t s = s0 + d;
+        if (s < s1) wgrad_load(ring[d], A0 + (s >> 1) * a_tile_stride, B0 + (s >> 1) * b_tile_stride, ar, br, (int)(s & 1), k);
+    }
+    for (int64_t sb = s0; sb < s1; sb += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int64_t s = sb + d;
+            if (s < s1) {
+                nh_sched_fence();
+                wgrad_compute(ring[d], acc, bsum);
+                const int64_t sn = s + DEPTH;
+                if (sn < s1)
+                    wgrad_load(ring[d], A0 + (sn >> 1) * a_tile_stride, B0 + (sn >> 1) * b_tile_stride, ar, br, (int)(sn & 1), k);
+            }
+        }
     }
     float* part = a.partial + (size_t)wg * NH_PART;
 #pragma unroll
@@ -583,15 +599,15 @@ NH_KERNEL void NH_LB(256, 1) k_wgrad(WgradArgs a) {
     if (!active) return;  // no workgroup-level synchronisation in this kernel
     const int sel = jb.po * 8 + jb.pi;
     switch (sel) {
-        case 4 * 8 + 4: wgrad_body<4, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
-        case 4 * 8 + 2: wgrad_body<4, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
-        case 4 * 8 + 1: wgrad_body<4, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
-        case 2 * 8 + 4: wgrad_body<2, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
-        case 2 * 8 + 2: wgrad_body<2, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
-        case 2 * 8 + 1: wgrad_body<2, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
-        case 1 * 8 + 4: wgrad_body<1, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
-        case 1 * 8 + 2: wgrad_body<1, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
-        default: wgrad_body<1, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
+        case 4 * 8 + 4: wgrad_body<4, 4, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
+        case 4 * 8 + 2: wgrad_body<4, 2, 3>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
+        case 4 * 8 + 1: wgrad_body<4, 1, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
+        case 2 * 8 + 4: wgrad_body<2, 4, 3>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
+        case 2 * 8 + 2: wgrad_body<2, 2, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
+        case 2 * 8 + 1: wgrad_body<2, 1, 6>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
+        case 1 * 8 + 4: wgrad_body<1, 4, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
+        case 1 * 8 + 2: wgrad_body<1, 2, 6>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
+        default: wgrad_body<1, 1, 8>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
     }
 }
 

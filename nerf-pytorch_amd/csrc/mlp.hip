@@ -550,6 +550,19 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
     const size_t a_tile_stride = ar * 32, b_tile_stride = br * 32;
     const float* A0 = a.grad + (size_t)32 * (size_t)a.nt * (size_t)jb.a_prefix + (size_t)(32 * ow * PO + i);
     const float* B0 = a.stash + (size_t)32 * (size_t)a.nt * (size_t)jb.b_prefix + (size_t)(jb.b_row0 + 32 * iw * PI + i);
+    if constexpr (DEPTH == 2) {
+        // large patch: plain double buffering at half-tile granularity (8192 MFMA cycles per step cover HBM latency)
+        WOperands<PO, PI> op0, op1;
+        if (t0 < t1) wgrad_load(op0, A0 + t0 * a_tile_stride, B0 + t0 * b_tile_stride, ar, br, 0, k);
+        for (int64_t t = t0; t < t1; ++t) {
+            wgrad_load(op1, A0 + t * a_tile_stride, B0 + t * b_tile_stride, ar, br, 1, k);
+            nh_sched_fence();
+            wgrad_compute(op0, acc, bsum);
+            if (t + 1 < t1) wgrad_load(op0, A0 + (t + 1) * a_tile_stride, B0 + (t + 1) * b_tile_stride, ar, br, 0, k);
+            nh_sched_fence();
+            wgrad_compute(op1, acc, bsum);
+        }
+    } else {
     WOperands<PO, PI> ring[DEPTH];
     const int64_t s0 = 2 * t0, s1 = 2 * t1;  // half-tile steps: step s = (tile s >> 1, half s & 1)
 #pragma unroll
@@ -564,11 +577,13 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
             if (s < s1) {
                 nh_sched_fence();
                 wgrad_compute(ring[d], acc, bsum);
+                nh_sched_fence();  // refill this slot only after its MFMAs are issued (no renaming into fresh registers)
                 const int64_t sn = s + DEPTH;
                 if (sn < s1)
                     wgrad_load(ring[d], A0 + (sn >> 1) * a_tile_stride, B0 + (sn >> 1) * b_tile_stride, ar, br, (int)(sn & 1), k);
             }
         }
+    }
     }
     float* part = a.partial + (size_t)wg * NH_PART;
 #pragma unroll

@@ -483,7 +483,8 @@ struct JobDev {
     int wg_start;
 };
 constexpr int NH_JOBS_DEV = 32;
-constexpr int NH_PART = 65536 + 512;  // floats of split-K partial per workgroup (4 waves x 256 regs x 64 lanes + bias)
+// floats of split-K partial per workgroup: 4 waves x 256 regs x 64 lanes, + 512 bias partials, + 64 for the timeline
+constexpr int NH_PART = 65536 + 512 + 64;
 
 struct WgradArgs {
     const float* stash;
@@ -600,6 +601,7 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
 }
 
 NH_KERNEL void NH_LB(256, 1) k_wgrad(WgradArgs a) {
+    const unsigned long long t_begin = nh_wall_clock();
     const int64_t wg = blockIdx.x;
     int ji = 0;
     for (int q = 1; q < a.njobs; ++q)
@@ -623,6 +625,13 @@ NH_KERNEL void NH_LB(256, 1) k_wgrad(WgradArgs a) {
         case 1 * 8 + 4: wgrad_body<1, 4, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
         case 1 * 8 + 2: wgrad_body<1, 2, 6>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
         default: wgrad_body<1, 1, 8>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
+    }
+    if (lane == 0) {  // timeline slot (last 64 floats of this workgroup's partial block): begin, end, job, K-slice
+        unsigned long long* dbg = (unsigned long long*)(a.partial + (size_t)wg * NH_PART + 65536 + 512) + wave * 4;
+        dbg[0] = t_begin;
+        dbg[1] = nh_wall_clock();
+        dbg[2] = (unsigned long long)ji;
+        dbg[3] = (unsigned long long)ks;
     }
 }
 

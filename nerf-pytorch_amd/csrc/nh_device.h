@@ -56,6 +56,7 @@ NH_DEVICE void nh_wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 // nothing is scheduled across this point (pins "issue the prefetch BEFORE the MFMAs")
 NH_DEVICE void nh_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 NH_DEVICE void nh_sincos(float x, float* s, float* c) { sincosf(x, s, c); }
+NH_DEVICE unsigned long long nh_wall_clock() { return wall_clock64(); }  // constant 100 MHz
 #endif  // NERFHIP_EMU
 
 // ---- helpers shared by both builds -------------------------------------------------------------------------------

@@ -236,7 +236,10 @@ void add_job(nerfhip_plan* p, const NhRegion& A, int a_tiles, const NhRegion& B,
     j.wi = best_wi;
     j.po = (a_tiles + j.wo - 1) / j.wo;
     j.pi = (b_tiles + j.wi - 1) / j.wi;
-    j.cost = j.po * j.pi;
+    // Relative time one workgroup spends per sample tile, measured on MI355X with per-workgroup timestamps
+    // (profiles/r01_wgrad_timeline.txt): t ~= 1.1 us + 0.45 us * po*pi  -- the MFMA work plus a fixed per-tile cost
+    // (address arithmetic, load issue, exposed latency) that dominates the small patches.
+    j.cost = 2 * j.po * j.pi + 5;
     j.r_lo = r_lo;
     j.r_hi = r_hi;
     j.w_off = p->tensors[w_tensor].off;

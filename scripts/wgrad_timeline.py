@@ -1,0 +1,46 @@
+"""GPU-box diagnostic: per-workgroup timeline of k_wgrad for one fine-pass-sized launch (M = 786432 samples)."""
+import ctypes as C, os, sys, json
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import nerf_pytorch_amd as N
+dev = torch.device("cuda", 0)
+lib = N._lib.get_lib()
+m = N.FlexibleNeRFModel(8, 256, 4, 10, 4).to(dev)
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 786432
+x = torch.randn(M, 90, device=dev)
+out = torch.empty(M, 4, device=dev)
+stash = torch.empty(lib.plan_stash_bytes(m._plan, M) // 4, device=dev)
+st = torch.cuda.current_stream().cuda_stream
+packed = m._packed()
+lib.mlp_fwd(m._plan, packed.data_ptr(), x.data_ptr(), M, out.data_ptr(), stash.data_ptr(), st)
+g = torch.randn(M, 4, device=dev)
+sb = lib.plan_bwd_scratch_bytes(m._plan, M)
+scratch = torch.zeros(sb // 4 + 1, device=dev)
+gp = torch.empty(m.num_flat_params, device=dev)
+for _ in range(2):
+    lib.mlp_bwd(m._plan, packed.data_ptr(), g.data_ptr(), M, stash.data_ptr(), scratch.data_ptr(), sb, gp.data_ptr(), st)
+torch.cuda.synchronize()
+nt = 4 * ((M + 127) // 128)
+rows = 8 * 256 + 256 + 128 + 32
+PART = 65536 + 512 + 64
+part = scratch[nt * rows * 32:]
+nwg = part.numel() // PART
+part = part[:nwg * PART].view(nwg, PART)[:, 65536 + 512:65536 + 512 + 32].contiguous().cpu().numpy().view(np.uint64).reshape(nwg, 4, 4)
+t0 = part[:, :, 0][part[:, :, 0] > 0].min()
+jobs = {}
+for w in range(nwg):
+    act = part[w, :, 1] > 0
+    if not act.any():
+        continue
+    b = (part[w, act, 0].min() - t0) / 100.0   # us (100 MHz)
+    e = (part[w, act, 1].max() - t0) / 100.0
+    per_wave = (part[w, act, 1] - part[w, act, 0]) / 100.0
+    j = int(part[w, act, 2][0])
+    jobs.setdefault(j, []).append((b, e, per_wave.mean(), int(act.sum())))
+end = max(e for v in jobs.values() for (_, e, _, _) in v)
+print(json.dumps(dict(nwg=nwg, makespan_us=end)))
+for j in sorted(jobs):
+    v = np.array(jobs[j])
+    print("job %2d  wgs %4d  waves/wg %d  start %8.1f..%8.1f us  end %8.1f..%8.1f us  dur mean %8.1f max %8.1f us" % (
+        j, len(v), int(v[0, 3]), v[:, 0].min(), v[:, 0].max(), v[:, 1].min(), v[:, 1].max(), (v[:, 1] - v[:, 0]).mean(), (v[:, 1] - v[:, 0]).max()))

@@ -125,6 +125,7 @@ NH_DEVICE void nh_atomic_add(float* p, float v) { *p += v; }
 NH_DEVICE void nh_glds16(const float* g, float* lds_wave_base) { memcpy(lds_wave_base + 4 * emu::cur->lane, g, 16); }
 NH_DEVICE void nh_wait_vmem() {}
 NH_DEVICE void nh_sched_fence() {}
+NH_DEVICE unsigned long long nh_wall_clock() { return 0ull; }
 NH_DEVICE void nh_sincos(float x, float* s, float* c) {
     *s = sinf(x);
     *c = cosf(x);

@@ -33,7 +33,41 @@ struct Cfg {
 template <int N4MAX>
 struct Stage {
     float4 v[N4MAX];
+#ifdef NH_PHASE_TIMING
+    unsigned long long ph[6], last;  // debug build only: cycles per tile phase, accumulated per wave
+#endif
 };
+#ifdef NH_PHASE_TIMING
+__device__ unsigned long long g_phase[32];
+#define NH_PH(i)                                   \
+    do {                                           \
+        const unsigned long long _t = clock64();   \
+        st.ph[i] += _t - st.last;                  \
+        st.last = _t;                              \
+    } while (0)
+#define NH_PH_INIT()                               \
+    do {                                           \
+        for (int _i = 0; _i < 6; ++_i) st.ph[_i] = 0; \
+        st.last = clock64();                       \
+    } while (0)
+#define NH_PH_FLUSH(base)                                                                         \
+    do {                                                                                          \
+        if (lane == 0)                                                                            \
+            for (int _i = 0; _i < 6; ++_i) atomicAdd(&g_phase[(base) + _i], st.ph[_i]);           \
+    } while (0)
+extern "C" int nerfhip_debug_phases(unsigned long long* host32, int reset) {
+    (void)hipMemcpyFromSymbol(host32, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 32);
+    if (reset) {
+        unsigned long long z[32] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z));
+    }
+    return 0;
+}
+#else
+#define NH_PH(i)
+#define NH_PH_INIT()
+#define NH_PH_FLUSH(base)
+#endif
 
 template <int N4MAX>
 NH_DEVICE void stage_load(Stage<N4MAX>& s, const float* __restrict__ chunk, int n4) {
@@ -85,14 +119,22 @@ NH_DEVICE void store_tile_rows(float* __restrict__ st_row, const float* res, int
 // sample-major image -- four 16-byte stores issued right AFTER the barrier that ends the tile, so that they drain
 // under the next tile's MFMAs instead of sitting in front of a vmcnt(0) (CDNA4's vmcnt counts stores too).
 // Tiles >= EPI are returned raw in out[t - EPI].
+// VMEM work of a tile -- the LDS-DMA pieces of the next chunk and the previous tile's four row stores -- is issued
+// BETWEEN the MFMA groups: a VMEM instruction placed in front of an MFMA issues while the previous MFMA is still
+// executing, so it costs no matrix-pipe time (issuing it all up front cost 17 % / 29 % of fwd / dgrad wave time --
+// profiles/r01_phase_timing.txt).
+// ReLU masks travel as bits: bit (r & 31) of word r >> 5 belongs to register r of the lane.  `bits_out` (forward)
+// collects [v > 0] of the values this layer produces; `mbits` (data-gradient) gates them.
 template <int W, bool DMA, int KRA, int KRB, int TILES, int EPI>
 NH_DEVICE void gemm_layer(const float* inA, const float* inB, const float* __restrict__ wl,
                           const float* __restrict__ next_chunk, int next_n4, float* lds, int& buf,
                           Stage<Cfg<W>::N4MAX>& st, f32x16* out, int lane, int wave, float* res, bool relu,
-                          const float* mk, bool masked, float* __restrict__ st_row) {
+                          unsigned* bits_out, bool want_bits, const unsigned* mbits, bool masked,
+                          float* __restrict__ st_row) {
     constexpr int KR = KRA + KRB;
     constexpr int CH = KR * 64 + 256;
     constexpr int NG = KR / 4;
+    constexpr int QMAX = (Cfg<W>::LB / 256 + 3) / 4;  // most 1-KiB pieces one wave ever issues for a chunk
     static_assert(KR % 4 == 0, "KR must be a multiple of 4");
     static_assert(KR <= Cfg<W>::KRMAX, "KR too large for the LDS buffer");
     const int h = lane >> 5;
@@ -101,14 +143,10 @@ NH_DEVICE void gemm_layer(const float* inA, const float* inB, const float* __res
         const float* nxt = (t + 1 < TILES) ? wl + (size_t)(t + 1) * CH : next_chunk;
         const int n4 = (t + 1 < TILES) ? CH / 4 : next_n4;
         float* other = lds + (buf ^ 1) * Cfg<W>::LB;
-        if (nxt) {
-            if (DMA)
-                dma_issue(nxt, n4, other, wave, lane);
-            else
-                stage_load(st, nxt, n4);
-        }
-        // rows of the PREVIOUS tile go out now: they have this whole tile's MFMAs to drain before the next vmcnt(0)
-        if (st_row && t >= 1 && t - 1 < EPI) store_tile_rows(st_row, res, t - 1, h);
+        if (nxt && !DMA) stage_load(st, nxt, n4);
+        const int qn = (nxt && DMA) ? (((n4 >> 6) - wave + 3) >> 2) : 0;  // pieces wave + 4q, q < qn, are this wave's
+        const bool st_prev = st_row && t >= 1 && t - 1 < EPI;            // rows of the previous tile still to store
+        NH_PH(0);  // [0] between tiles / layers
         const float* cur = lds + buf * Cfg<W>::LB;
         f32x16 acc;
 #pragma unroll
@@ -127,6 +165,20 @@ NH_DEVICE void gemm_layer(const float* inA, const float* inB, const float* __res
             float4 w2 = w1;
             if (g + 2 < NG) w2 = w4[(g + 2) * 64];
             nh_sched_fence();  // the prefetch above is issued before these MFMAs; its data is used two groups later
+            // this group's share of the tile's VMEM instructions
+#pragma unroll
+            for (int q = (g * QMAX) / NG; q < ((g + 1) * QMAX) / NG; ++q)
+                if (q < qn) nh_glds16(nxt + (wave + 4 * q) * 256 + lane * 4, other + (wave + 4 * q) * 256);
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4)
+                if (st_prev && g == (NG >= 8 ? 1 + k4 * (NG / 4) : 0)) {
+                    float4 x;
+                    x.x = res[16 * (t - 1) + 4 * k4 + 0];
+                    x.y = res[16 * (t - 1) + 4 * k4 + 1];
+                    x.z = res[16 * (t - 1) + 4 * k4 + 2];
+                    x.w = res[16 * (t - 1) + 4 * k4 + 3];
+                    *(float4*)(st_row + 32 * (t - 1) + 8 * k4 + 4 * h) = x;
+                }
             const int r = 4 * g;
             acc = nh_mfma32(w0.x, (r + 0 < KRA) ? inA[r + 0] : inB[r + 0 - KRA], acc);
             acc = nh_mfma32(w0.y, (r + 1 < KRA) ? inA[r + 1] : inB[r + 1 - KRA], acc);
@@ -135,24 +187,30 @@ NH_DEVICE void gemm_layer(const float* inA, const float* inB, const float* __res
             w0 = w1;
             w1 = w2;
         }
+        NH_PH(1);  // [1] bias + operand reads + MFMA issue (+ interleaved VMEM issue)
         if (t < EPI) {
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
+                const int r = 16 * t + c;
                 float v = acc[c];
-                if (masked) v = mk[16 * t + c] > 0.0f ? v : 0.0f;
+                if (masked) v = ((mbits[r >> 5] >> (r & 31)) & 1u) ? v : 0.0f;
                 if (relu) v = fmaxf(v, 0.0f);
-                res[16 * t + c] = v;
+                if (want_bits) bits_out[r >> 5] |= (v > 0.0f ? 1u : 0u) << (r & 31);
+                res[r] = v;
             }
         } else {
             out[t - EPI] = acc;
         }
+        NH_PH(2);  // [2] epilogue (waits for the last MFMA)
         if (nxt) {
             if (DMA)
                 nh_wait_vmem();
             else
                 stage_store(st, other, n4);
         }
+        NH_PH(3);  // [3] vmcnt(0): DMA + stores + mask loads
         nh_block_sync();
+        NH_PH(4);  // [4] barrier
         buf ^= 1;
     }
     // the last epilogue tile: when raw tiles follow (EPI < TILES) it was stored at the start of tile EPI above
@@ -312,6 +370,7 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_fwd(MlpFwdArgs a) {
     }
 
     Stage<C::N4MAX> st;
+    NH_PH_INIT();
     int buf = 0;
     const float* pk = a.packed;
     first_chunk<W, DMA>(pk + a.off.f_layer1, n4_of(NH_KRX), lds, st, wave, lane);
@@ -319,15 +378,28 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_fwd(MlpFwdArgs a) {
     f32x16 o[1];  // raw tiles only: fc_alpha's tile / the rgb tile / fc_out
     float act[KH];
     float res[KH];
+    unsigned bits[4];
+    const bool tr = a.stash != nullptr;
     auto strow = [&](const NhRegion& R) -> float* {
-        return a.stash ? region_tile(a.stash, R, a.nt, tile) + (size_t)j * R.rows : nullptr;
+        return tr ? region_tile(a.stash, R, a.nt, tile) + (size_t)j * R.rows : nullptr;
+    };
+    // ReLU masks for the data-gradient kernel: 128 bits per lane per layer, one coalesced 1-KiB record per wave
+    auto put_mask = [&](int idx) {
+        if (!tr) return;
+        unsigned* p = (unsigned*)(a.stash + (size_t)32 * (size_t)a.nt * (size_t)a.sl.total_rows) +
+                      ((size_t)(tile * a.sl.n_masks + idx) * 64 + lane) * 4;
+        p[0] = bits[0];
+        p[1] = bits[1];
+        p[2] = bits[2];
+        p[3] = bits[3];
     };
     {
         const bool more = a.L > 1;
         const float* nxt = pk + (more ? a.off.f_xyz[0] : a.off.f_head);
         const int nn4 = n4_of(KH);  // layers_xyz[0] is never a skip layer (i > 0 is required)
         // no activation after layer1 (models.py:238)
-        gemm_layer<W, DMA, NH_KRX, 0, TW, TW>(ex, nullptr, pk + a.off.f_layer1, nxt, nn4, lds, buf, st, o, lane, wave, res, false, res, false, strow(a.sl.H[0]));
+        gemm_layer<W, DMA, NH_KRX, 0, TW, TW>(ex, nullptr, pk + a.off.f_layer1, nxt, nn4, lds, buf, st, o, lane, wave, res,
+                                              false, bits, false, bits, false, strow(a.sl.H[0]));
 #pragma unroll
         for (int r = 0; r < KH; ++r) act[r] = res[r];
     }
@@ -338,23 +410,31 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_fwd(MlpFwdArgs a) {
         const float* nxt = pk + (more ? a.off.f_xyz[i + 1] : a.off.f_head);
         const int nn4 = n4_of(KH + (nsk ? NH_KRX : 0));
         float* sr = strow(a.sl.H[i + 1]);
+        bits[0] = bits[1] = bits[2] = bits[3] = 0u;
         if (sk)
-            gemm_layer<W, DMA, KH, NH_KRX, TW, TW>(act, ex, pk + a.off.f_xyz[i], nxt, nn4, lds, buf, st, o, lane, wave, res, true, res, false, sr);
+            gemm_layer<W, DMA, KH, NH_KRX, TW, TW>(act, ex, pk + a.off.f_xyz[i], nxt, nn4, lds, buf, st, o, lane, wave, res,
+                                                   true, bits, tr, bits, false, sr);
         else
-            gemm_layer<W, DMA, KH, 0, TW, TW>(act, nullptr, pk + a.off.f_xyz[i], nxt, nn4, lds, buf, st, o, lane, wave, res, true, res, false, sr);
+            gemm_layer<W, DMA, KH, 0, TW, TW>(act, nullptr, pk + a.off.f_xyz[i], nxt, nn4, lds, buf, st, o, lane, wave, res,
+                                              true, bits, tr, bits, false, sr);
+        put_mask(i);  // H_{i+1}
 #pragma unroll
         for (int r = 0; r < KH; ++r) act[r] = res[r];
     }
     if (VIEW) {
         // tiles 0..TW-1: feat = relu(fc_feat(h)); tile TW row 0: fc_alpha(h), raw (models.py:248-249)
+        bits[0] = bits[1] = bits[2] = bits[3] = 0u;
         gemm_layer<W, DMA, KH, 0, TW + 1, TW>(act, nullptr, pk + a.off.f_head, pk + a.off.f_dir, n4_of(KH + NH_KRD), lds, buf,
-                                          st, o, lane, wave, res, true, res, false, strow(a.sl.FEAT));
+                                              st, o, lane, wave, res, true, bits, tr, bits, false, strow(a.sl.FEAT));
+        put_mask(a.L - 1);
         const float alpha = o[0][0];
         float dh[KH / 2];
-        gemm_layer<W, DMA, KH, NH_KRD, TW / 2, TW / 2>(res, ed, pk + a.off.f_dir, pk + a.off.f_rgb, n4_of(KH / 2), lds, buf, st, o,
-                                               lane, wave, dh, true, dh, false, strow(a.sl.DIRH));
+        bits[0] = bits[1] = bits[2] = bits[3] = 0u;
+        gemm_layer<W, DMA, KH, NH_KRD, TW / 2, TW / 2>(res, ed, pk + a.off.f_dir, pk + a.off.f_rgb, n4_of(KH / 2), lds, buf, st,
+                                                       o, lane, wave, dh, true, bits, tr, bits, false, strow(a.sl.DIRH));
+        put_mask(a.L);
         gemm_layer<W, DMA, KH / 2, 0, 1, 0>(dh, nullptr, pk + a.off.f_rgb, nullptr, 0, lds, buf, st, o, lane, wave, dh, false,
-                                         dh, false, nullptr);
+                                            bits, false, bits, false, nullptr);
         if (valid && h == 0) {
             float4 r4;
             r4.x = o[0][0];
@@ -363,9 +443,11 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_fwd(MlpFwdArgs a) {
             r4.w = alpha;
             *(float4*)(a.out + (size_t)m * 4) = r4;
         }
+        NH_PH(5);
+        NH_PH_FLUSH(0);
     } else {
         gemm_layer<W, DMA, KH, 0, 1, 0>(act, nullptr, pk + a.off.f_head, nullptr, 0, lds, buf, st, o, lane, wave, res, false,
-                                     res, false, nullptr);
+                                        bits, false, bits, false, nullptr);
         if (valid && h == 0) {
             float4 r4;
             r4.x = o[0][0];
@@ -413,12 +495,22 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_dgrad(DgradArgs a) {
     }
     auto grow = [&](const NhRegion& R) -> float* { return region_tile(a.grad, R, a.nt, tile) + (size_t)j * R.rows; };
     Stage<C::N4MAX> st;
+    NH_PH_INIT();
     int buf = 0;
     const float* pk = a.packed;
     f32x16 o[1];
-    float dp[KH];   // d(pre-activation) of the layer just finished = B operand of the next transposed GEMM
+    float dp[KH];  // d(pre-activation) of the layer just finished = B operand of the next transposed GEMM
     float res[KH];
-    float mk[KH];   // stashed post-ReLU activation of the layer being produced (prefetched before its GEMM)
+    unsigned mb[4];  // ReLU mask bits (written by the forward kernel) of the layer being produced
+    auto get_mask = [&](int idx) {
+        const unsigned* p = (const unsigned*)(a.stash + (size_t)32 * (size_t)a.nt * (size_t)a.sl.total_rows) +
+                            ((size_t)(tile * a.sl.n_masks + idx) * 64 + lane) * 4;
+        mb[0] = p[0];
+        mb[1] = p[1];
+        mb[2] = p[2];
+        mb[3] = p[3];
+    };
+    mb[0] = mb[1] = mb[2] = mb[3] = 0u;
     const int L = a.L;
     if (VIEW) {
         float d4[4];
@@ -426,24 +518,21 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_dgrad(DgradArgs a) {
         d4[1] = h == 0 ? go.y : 0.0f;
         d4[2] = h == 0 ? go.z : 0.0f;
         d4[3] = 0.0f;
-        load_feat_rows<KH / 2>(mk, region_tile_c(a.stash, a.sl.DIRH, a.nt, tile), W / 2, j, h);
-        nh_sched_fence();
+        get_mask(L);  // DIRH
         first_chunk<W, DMA>(pk + a.off.b_rgb, n4_of(4), lds, st, wave, lane);
         float dpd[KH / 2];
         gemm_layer<W, DMA, 4, 0, TW / 2, TW / 2>(d4, nullptr, pk + a.off.b_rgb, pk + a.off.b_dir, n4_of(KH / 2), lds, buf, st, o,
-                                         lane, wave, dpd, false, mk, true, grow(a.gl.PDIR));
-        load_feat_rows<KH>(mk, region_tile_c(a.stash, a.sl.FEAT, a.nt, tile), W, j, h);
-        nh_sched_fence();
+                                                 lane, wave, dpd, false, mb, false, mb, true, grow(a.gl.PDIR));
+        get_mask(L - 1);  // FEAT
         gemm_layer<W, DMA, KH / 2, 0, TW, TW>(dpd, nullptr, pk + a.off.b_dir, pk + a.off.b_head, n4_of(KH + 4), lds, buf, st, o,
-                                          lane, wave, dp, false, mk, true, grow(a.gl.PFEAT));
-        if (L > 1) load_feat_rows<KH>(mk, region_tile_c(a.stash, a.sl.H[L - 1], a.nt, tile), W, j, h);
-        nh_sched_fence();
+                                              lane, wave, dp, false, mb, false, mb, true, grow(a.gl.PFEAT));
+        if (L > 1) get_mask(L - 2);  // H_{L-1}
         float da[4];
         da[0] = h == 0 ? go.w : 0.0f;
         da[1] = da[2] = da[3] = 0.0f;
         const float* nxt = L > 1 ? pk + a.off.b_xyz[L - 2] : nullptr;
         gemm_layer<W, DMA, KH, 4, TW, TW>(dp, da, pk + a.off.b_head, nxt, n4_of(KH), lds, buf, st, o, lane, wave, res, false,
-                                      mk, L > 1, grow(a.gl.P[L - 1]));
+                                          mb, false, mb, L > 1, grow(a.gl.P[L - 1]));
 #pragma unroll
         for (int r = 0; r < KH; ++r) dp[r] = res[r];
     } else {
@@ -452,23 +541,25 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_dgrad(DgradArgs a) {
         d4[1] = h == 0 ? go.y : 0.0f;
         d4[2] = h == 0 ? go.z : 0.0f;
         d4[3] = h == 0 ? go.w : 0.0f;
-        if (L > 1) load_feat_rows<KH>(mk, region_tile_c(a.stash, a.sl.H[L - 1], a.nt, tile), W, j, h);
-        nh_sched_fence();
+        if (L > 1) get_mask(L - 2);  // H_{L-1}
         first_chunk<W, DMA>(pk + a.off.b_head, n4_of(4), lds, st, wave, lane);
         const float* nxt = L > 1 ? pk + a.off.b_xyz[L - 2] : nullptr;
-        gemm_layer<W, DMA, 4, 0, TW, TW>(d4, nullptr, pk + a.off.b_head, nxt, n4_of(KH), lds, buf, st, o, lane, wave, dp, false, mk, L > 1, grow(a.gl.P[L - 1]));
+        gemm_layer<W, DMA, 4, 0, TW, TW>(d4, nullptr, pk + a.off.b_head, nxt, n4_of(KH), lds, buf, st, o, lane, wave, dp, false,
+                                         mb, false, mb, L > 1, grow(a.gl.P[L - 1]));
     }
     // dp = d(pre-activation of H_{L-1}), already stored.  Walk down: dpre_{k-1} = relu'(H_{k-1}) * (W_{k-1}^T dpre_k);
     // H_0 = layer1 output has no activation (models.py:238).
     for (int k = L - 1; k >= 1; --k) {
         const bool masked = k - 1 >= 1;
-        if (masked) load_feat_rows<KH>(mk, region_tile_c(a.stash, a.sl.H[k - 1], a.nt, tile), W, j, h);
-        nh_sched_fence();
+        if (masked) get_mask(k - 2);  // H_{k-1}
         const float* nxt = k >= 2 ? pk + a.off.b_xyz[k - 2] : nullptr;
-        gemm_layer<W, DMA, KH, 0, TW, TW>(dp, nullptr, pk + a.off.b_xyz[k - 1], nxt, n4_of(KH), lds, buf, st, o, lane, wave, res, false, mk, masked, grow(a.gl.P[k - 1]));
+        gemm_layer<W, DMA, KH, 0, TW, TW>(dp, nullptr, pk + a.off.b_xyz[k - 1], nxt, n4_of(KH), lds, buf, st, o, lane, wave, res,
+                                          false, mb, false, mb, masked, grow(a.gl.P[k - 1]));
 #pragma unroll
         for (int r = 0; r < KH; ++r) dp[r] = res[r];
     }
+    NH_PH(5);
+    NH_PH_FLUSH(8);
 }
 
 // ---- weight gradients ----------------------------------------------------------------------------------------------

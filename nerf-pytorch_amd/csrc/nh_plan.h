@@ -57,6 +57,9 @@ struct NhRegion {
 struct NhStashLayout {
     NhRegion X, D, H[NH_MAX_LAYERS], FEAT, DIRH;
     int64_t total_rows;
+    // After the row regions: ReLU bit masks, [tile][n_masks][64 lanes][4 words]; mask index k-1 = H_k (k >= 1),
+    // L-1 = FEAT, L = DIRH.
+    int n_masks;
 };
 struct NhGradLayout {  // d(pre-activation) scratch written by the data-gradient kernel
     NhRegion P[NH_MAX_LAYERS], PFEAT, PDIR, POUT;

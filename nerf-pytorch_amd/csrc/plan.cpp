@@ -263,6 +263,7 @@ void build_layouts_and_jobs(nerfhip_plan* p) {
         S.FEAT = add_region(&S.total_rows, W);
         S.DIRH = add_region(&S.total_rows, W / 2);
     }
+    S.n_masks = p->view ? L + 1 : (L > 1 ? L - 1 : 1);
     NhGradLayout& G = p->grad;
     memset(&G, 0, sizeof(G));
     G.total_rows = 0;
@@ -423,5 +424,5 @@ extern "C" int nerfhip_plan_set_freqs(nerfhip_plan_t plan, const float* freqs_xy
 extern "C" int64_t nerfhip_plan_stash_bytes(nerfhip_plan_t plan, int64_t m) {
     if (!plan || m < 0) return -1;
     int64_t tiles = nh_ceil_div(m, 128) * 4;
-    return tiles * plan->stash.total_rows * 32 * (int64_t)sizeof(float);
+    return tiles * (plan->stash.total_rows * 32 + (int64_t)plan->stash.n_masks * 256) * (int64_t)sizeof(float);
 }

@@ -125,7 +125,7 @@ NH_DEVICE void store_tile_rows(float* __restrict__ st_row, const float* res, int
 // profiles/r01_phase_timing.txt).
 // ReLU masks travel as bits: bit (r & 31) of word r >> 5 belongs to register r of the lane.  `bits_out` (forward)
 // collects [v > 0] of the values this layer produces; `mbits` (data-gradient) gates them.
-template <int W, bool DMA, int KRA, int KRB, int TILES, int EPI>
+template <int W, int DMA, int KRA, int KRB, int TILES, int EPI>
 NH_DEVICE void gemm_layer(const float* inA, const float* inB, const float* __restrict__ wl,
                           const float* __restrict__ next_chunk, int next_n4, float* lds, int& buf,
                           Stage<Cfg<W>::N4MAX>& st, f32x16* out, int lane, int wave, float* res, bool relu,
@@ -143,9 +143,14 @@ NH_DEVICE void gemm_layer(const float* inA, const float* inB, const float* __res
         const float* nxt = (t + 1 < TILES) ? wl + (size_t)(t + 1) * CH : next_chunk;
         const int n4 = (t + 1 < TILES) ? CH / 4 : next_n4;
         float* other = lds + (buf ^ 1) * Cfg<W>::LB;
-        if (nxt && !DMA) stage_load(st, nxt, n4);
-        const int qn = (nxt && DMA) ? (((n4 >> 6) - wave + 3) >> 2) : 0;  // pieces wave + 4q, q < qn, are this wave's
-        const bool st_prev = st_row && t >= 1 && t - 1 < EPI;            // rows of the previous tile still to store
+        // DMA: 0 = register staging, 1 = LDS-DMA + previous tile's stores issued here (before the MFMAs),
+        //      2 = the same VMEM instructions spread between the MFMA groups
+        if (nxt && DMA == 0) stage_load(st, nxt, n4);
+        if (nxt && DMA == 1) dma_issue(nxt, n4, other, wave, lane);
+        const bool st_prev = st_row && t >= 1 && t - 1 < EPI;  // rows of the previous tile still to store
+        if (st_prev && DMA != 2) store_tile_rows(st_row, res, t - 1, h);
+        const int qn = (nxt && DMA == 2) ? (((n4 >> 6) - wave + 3) >> 2) : 0;  // pieces wave + 4q, q < qn: this wave's
+        const bool st_mix = st_prev && DMA == 2;
         NH_PH(0);  // [0] between tiles / layers
         const float* cur = lds + buf * Cfg<W>::LB;
         f32x16 acc;
@@ -171,7 +176,7 @@ NH_DEVICE void gemm_layer(const float* inA, const float* inB, const float* __res
                 if (q < qn) nh_glds16(nxt + (wave + 4 * q) * 256 + lane * 4, other + (wave + 4 * q) * 256);
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4)
-                if (st_prev && g == (NG >= 8 ? 1 + k4 * (NG / 4) : 0)) {
+                if (st_mix && g == (NG >= 8 ? 1 + k4 * (NG / 4) : 0)) {
                     float4 x;
                     x.x = res[16 * (t - 1) + 4 * k4 + 0];
                     x.y = res[16 * (t - 1) + 4 * k4 + 1];
@@ -217,7 +222,7 @@ NH_DEVICE void gemm_layer(const float* inA, const float* inB, const float* __res
     if (st_row && EPI >= 1 && EPI == TILES) store_tile_rows(st_row, res, TILES - 1, h);
 }
 
-template <int W, bool DMA>
+template <int W, int DMA>
 NH_DEVICE void first_chunk(const float* __restrict__ chunk, int n4, float* lds, Stage<Cfg<W>::N4MAX>& st, int wave,
                            int lane) {
     if (DMA) {
@@ -323,7 +328,7 @@ NH_DEVICE void encode_slots(float* e, float x, float y, float z, int h, const fl
     }
 }
 
-template <int W, bool VIEW, bool DMA>
+template <int W, bool VIEW, int DMA>
 NH_KERNEL void NH_LB(256, 1) k_mlp_fwd(MlpFwdArgs a) {
     using C = Cfg<W>;
     constexpr int KH = C::KH, TW = W / 32;
@@ -472,7 +477,7 @@ struct DgradArgs {
     NhGradLayout gl;
 };
 
-template <int W, bool VIEW, bool DMA>
+template <int W, bool VIEW, int DMA>
 NH_KERNEL void NH_LB(256, 1) k_mlp_dgrad(DgradArgs a) {
     using C = Cfg<W>;
     constexpr int KH = C::KH, TW = W / 32;
@@ -855,14 +860,15 @@ int set_lds_limit(K kern, int bytes) {
     return NERFHIP_OK;
 }
 
-// NERFHIP_STAGE=reg selects the register-staged weight path (global -> VGPR -> ds_write) instead of LDS-DMA.
-bool use_dma() {
+// NERFHIP_STAGE selects how weight chunks reach LDS: reg (global -> VGPR -> ds_write), front (LDS-DMA issued at the
+// start of a tile), mix (LDS-DMA pieces and row stores spread between the MFMA groups; default).
+int use_dma() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("NERFHIP_STAGE");
-        v = (e && e[0] == 'r') ? 0 : 1;
+        v = !e ? 2 : (e[0] == 'r' ? 0 : (e[0] == 'f' ? 1 : 2));  // reg | front | mix (default: measured fastest)
     }
-    return v == 1;
+    return v;
 }
 
 }  // namespace
@@ -923,15 +929,14 @@ int nh_mlp_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, i
         if (rc) return rc;                                                              \
         NH_LAUNCH((k_mlp_fwd<WW, VV, DD>), grid, 256, Cfg<WW>::LDS_BYTES, stream, a);   \
     }
-    const bool dma = use_dma();
-    if (p->W == 256 && p->view && dma) NH_FWD_CASE(256, true, true)
-    else if (p->W == 256 && p->view) NH_FWD_CASE(256, true, false)
-    else if (p->W == 256 && dma) NH_FWD_CASE(256, false, true)
-    else if (p->W == 256) NH_FWD_CASE(256, false, false)
-    else if (p->view && dma) NH_FWD_CASE(128, true, true)
-    else if (p->view) NH_FWD_CASE(128, true, false)
-    else if (dma) NH_FWD_CASE(128, false, true)
-    else NH_FWD_CASE(128, false, false)
+    const int dma = use_dma();
+#define NH_FWD_GEO(DD)                                      \
+    if (p->W == 256 && p->view) NH_FWD_CASE(256, true, DD)  \
+    else if (p->W == 256) NH_FWD_CASE(256, false, DD)       \
+    else if (p->view) NH_FWD_CASE(128, true, DD)            \
+    else NH_FWD_CASE(128, false, DD)
+    if (dma == 0) { NH_FWD_GEO(0) } else if (dma == 2) { NH_FWD_GEO(2) } else { NH_FWD_GEO(1) }
+#undef NH_FWD_GEO
 #undef NH_FWD_CASE
     return nh_launch_status("mlp_fwd");
 }
@@ -962,15 +967,14 @@ int nh_mlp_backward(nerfhip_plan* p, const float* packed, const float* g_out, in
         if (rc) return rc;                                                                \
         NH_LAUNCH((k_mlp_dgrad<WW, VV, DD>), grid, 256, Cfg<WW>::LDS_BYTES, stream, d);   \
     }
-    const bool dma = use_dma();
-    if (p->W == 256 && p->view && dma) NH_BWD_CASE(256, true, true)
-    else if (p->W == 256 && p->view) NH_BWD_CASE(256, true, false)
-    else if (p->W == 256 && dma) NH_BWD_CASE(256, false, true)
-    else if (p->W == 256) NH_BWD_CASE(256, false, false)
-    else if (p->view && dma) NH_BWD_CASE(128, true, true)
-    else if (p->view) NH_BWD_CASE(128, true, false)
-    else if (dma) NH_BWD_CASE(128, false, true)
-    else NH_BWD_CASE(128, false, false)
+    const int dma = use_dma();
+#define NH_BWD_GEO(DD)                                      \
+    if (p->W == 256 && p->view) NH_BWD_CASE(256, true, DD)  \
+    else if (p->W == 256) NH_BWD_CASE(256, false, DD)       \
+    else if (p->view) NH_BWD_CASE(128, true, DD)            \
+    else NH_BWD_CASE(128, false, DD)
+    if (dma == 0) { NH_BWD_GEO(0) } else if (dma == 2) { NH_BWD_GEO(2) } else { NH_BWD_GEO(1) }
+#undef NH_BWD_GEO
 #undef NH_BWD_CASE
     rc = nh_launch_status("mlp_dgrad");
     if (rc) return rc;

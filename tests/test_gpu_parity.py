@@ -247,3 +247,38 @@ def test_pretrained_lego_checkpoint_renders_like_the_reference():
     assert float(np.abs(acc - r["acc_fine"]).max()) < 2e-3
     full_mean = float(out[3].mean())
     assert abs(full_mean - float(r["rgb_fine_mean"])) < 1e-4
+
+
+def test_validation_mode_image_shapes_and_coarse_only():
+    """mode="validation" reshapes to the image (train_utils.py:187-200); num_fine == 0 returns None for the fine
+    outputs (train_utils.py:92-95,127); chunking over rays is transparent (A.9)."""
+    import nerf_pytorch_amd as N
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    dev = torch.device("cuda", 0)
+    cfg = dict(num_layers=4, hidden_size=128, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4)
+    par = O.init_params(cfg, seed=3)
+    m = N.FlexibleNeRFModel(**cfg)
+    m.load_state_dict(par)
+    m = m.to(dev)
+    H, W, focal = 12, 20, 15.0
+    pose = torch.eye(4)
+    pose[2, 3] = 4.0
+    ex, ed = N.get_embedding_function(10, True, True), N.get_embedding_function(4, True, True)
+    ro, rd = N.get_ray_bundle(H, W, focal, pose.to(dev))
+    opts = N.make_options(32, 0, perturb=False, radiance_field_noise_std=0.0, chunksize=64)
+    with torch.no_grad():
+        out = N.run_one_iter_of_nerf(H, W, focal, m, None, ro, rd, opts, mode="validation", encode_position_fn=ex,
+                                     encode_direction_fn=ed)
+    assert len(out) == 6 and out[3] is None and out[4] is None and out[5] is None
+    assert tuple(out[0].shape) == (H, W, 3) and tuple(out[1].shape) == (H, W) and tuple(out[2].shape) == (H, W)
+    oro, ord_ = O.get_ray_bundle(H, W, focal, pose)
+    rays = O.pack_rays(oro, ord_, 2.0, 6.0, ord_)
+    want = O.render_rays(rays, par, None, cfg, None, dict(num_coarse=32, num_fine=0, perturb=False, noise_std=0.0))
+    P.close(out[0].cpu().numpy().reshape(-1, 3), want["rgb_coarse"].numpy(), 1e-5, what="coarse-only rgb")
+    P.close(out[2].cpu().numpy().reshape(-1), want["acc_coarse"].numpy(), 1e-5, what="coarse-only acc")
+    opts2 = N.make_options(32, 0, perturb=False, radiance_field_noise_std=0.0, chunksize=1 << 17)
+    with torch.no_grad():
+        out2 = N.run_one_iter_of_nerf(H, W, focal, m, None, ro, rd, opts2, mode="validation", encode_position_fn=ex,
+                                      encode_direction_fn=ed)
+    assert torch.equal(out[0], out2[0]) and torch.equal(out[2], out2[2])

@@ -25,14 +25,17 @@ template <int W>
 struct Cfg {
     static constexpr int KH = W / 2;                    // registers of a hidden activation
     static constexpr int KRMAX = KH + NH_KRX;           // widest layer (skip layer)
-    static constexpr int LB = KRMAX * 64 + 256;         // floats of one LDS weight buffer
+    // floats of one LDS weight buffer: the widest chunk (KRMAX/4 + 1 pieces of 1 KiB) rounded up to 4 pieces per wave
+    static constexpr int LB = ((KRMAX / 4 + 1 + 3) / 4) * 4 * 256;
     static constexpr int N4MAX = (LB / 4 + 255) / 256;  // float4 per thread to stage one chunk (register path)
     static constexpr int LDS_BYTES = 2 * LB * 4;
 };
 
 template <int N4MAX>
 struct Stage {
-    float4 v[N4MAX];
+    float4 v[N4MAX];   // register-staging path only
+    NhDmaSrc dma;      // buffer descriptor over the whole packed-weight image
+    const float* base; // its base pointer
 #ifdef NH_PHASE_TIMING
     unsigned long long ph[6], last;  // debug build only: cycles per tile phase, accumulated per wave
 #endif
@@ -90,9 +93,12 @@ NH_DEVICE void stage_store(const Stage<N4MAX>& s, float* ldsbuf, int n4) {
     }
 }
 // LDS-DMA of one chunk: n4/64 pieces of 1 KiB, piece p by wave (p & 3)
-NH_DEVICE void dma_issue(const float* __restrict__ chunk, int n4, float* ldsbuf, int wave, int lane) {
-    const int pieces = n4 >> 6;
-    for (int p = wave; p < pieces; p += 4) nh_glds16(chunk + p * 256 + lane * 4, ldsbuf + p * 256);
+// (every wave issues the same number of pieces; pieces past the end of the image are dropped by the descriptor)
+template <int N4MAX>
+NH_DEVICE void dma_issue(const Stage<N4MAX>& st, const float* __restrict__ chunk, int n4, float* ldsbuf, int wave, int lane) {
+    const int qn = ((n4 >> 6) + 3) >> 2;
+    const int soff = (int)(chunk - st.base) * 4;
+    for (int q = 0; q < qn; ++q) nh_dma16(st.dma, lane * 16, soff + (wave + 4 * q) * 1024, ldsbuf + (wave + 4 * q) * 256);
 }
 
 NH_DEVICE int n4_of(int kr) { return kr * 16 + 64; }
@@ -129,7 +135,7 @@ template <int W, int DMA, int KRA, int KRB, int TILES, int EPI>
 NH_DEVICE void gemm_layer(const float* inA, const float* inB, const float* __restrict__ wl,
                           const float* __restrict__ next_chunk, int next_n4, float* lds, int& buf,
                           Stage<Cfg<W>::N4MAX>& st, f32x16* out, int lane, int wave, float* res, bool relu,
-                          unsigned* bits_out, bool want_bits, const unsigned* mbits, bool masked,
+                          unsigned* bits_out, bool want_bits, const unsigned* mbits, bool masked, bool do_store,
                           float* __restrict__ st_row) {
     constexpr int KR = KRA + KRB;
     constexpr int CH = KR * 64 + 256;
@@ -146,10 +152,11 @@ NH_DEVICE void gemm_layer(const float* inA, const float* inB, const float* __res
         // DMA: 0 = register staging, 1 = LDS-DMA + previous tile's stores issued here (before the MFMAs),
         //      2 = the same VMEM instructions spread between the MFMA groups
         if (nxt && DMA == 0) stage_load(st, nxt, n4);
-        if (nxt && DMA == 1) dma_issue(nxt, n4, other, wave, lane);
-        const bool st_prev = st_row && t >= 1 && t - 1 < EPI;  // rows of the previous tile still to store
+        if (nxt && DMA == 1) dma_issue(st, nxt, n4, other, wave, lane);
+        const bool st_prev = do_store && t >= 1 && t - 1 < EPI;  // rows of the previous tile still to store
         if (st_prev && DMA != 2) store_tile_rows(st_row, res, t - 1, h);
-        const int qn = (nxt && DMA == 2) ? (((n4 >> 6) - wave + 3) >> 2) : 0;  // pieces wave + 4q, q < qn: this wave's
+        const int qn = (nxt && DMA == 2) ? (((n4 >> 6) + 3) >> 2) : 0;  // pieces wave + 4q, q < qn (same for every wave)
+        const int soff = nxt ? (int)(nxt - st.base) * 4 : 0;
         const bool st_mix = st_prev && DMA == 2;
         NH_PH(0);  // [0] between tiles / layers
         const float* cur = lds + buf * Cfg<W>::LB;
@@ -173,7 +180,7 @@ NH_DEVICE void gemm_layer(const float* inA, const float* inB, const float* __res
             // this group's share of the tile's VMEM instructions
 #pragma unroll
             for (int q = (g * QMAX) / NG; q < ((g + 1) * QMAX) / NG; ++q)
-                if (q < qn) nh_glds16(nxt + (wave + 4 * q) * 256 + lane * 4, other + (wave + 4 * q) * 256);
+                if (q < qn) nh_dma16(st.dma, lane * 16, soff + (wave + 4 * q) * 1024, other + (wave + 4 * q) * 256);
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4)
                 if (st_mix && g == (NG >= 8 ? 1 + k4 * (NG / 4) : 0)) {
@@ -219,14 +226,14 @@ NH_DEVICE void gemm_layer(const float* inA, const float* inB, const float* __res
         buf ^= 1;
     }
     // the last epilogue tile: when raw tiles follow (EPI < TILES) it was stored at the start of tile EPI above
-    if (st_row && EPI >= 1 && EPI == TILES) store_tile_rows(st_row, res, TILES - 1, h);
+    if (do_store && EPI >= 1 && EPI == TILES) store_tile_rows(st_row, res, TILES - 1, h);
 }
 
 template <int W, int DMA>
 NH_DEVICE void first_chunk(const float* __restrict__ chunk, int n4, float* lds, Stage<Cfg<W>::N4MAX>& st, int wave,
                            int lane) {
     if (DMA) {
-        dma_issue(chunk, n4, lds, wave, lane);
+        dma_issue(st, chunk, n4, lds, wave, lane);
         nh_wait_vmem();
     } else {
         stage_load(st, chunk, n4);
@@ -285,6 +292,7 @@ NH_DEVICE void store_slot_rows(float* __restrict__ tile_base, int rows, const fl
 
 struct MlpFwdArgs {
     const float* packed;
+    unsigned packed_bytes;
     NhPackedOffsets off;
     int L, skip;
     int64_t M, nt;
@@ -340,6 +348,13 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_fwd(MlpFwdArgs a) {
     const bool valid = m < a.M;
     const int64_t mc = valid ? m : a.M - 1;
 
+    Stage<C::N4MAX> st;
+    st.base = a.packed;
+    st.dma = nh_dma_src(a.packed, a.packed_bytes);
+    NH_PH_INIT();
+    // the first weight chunk travels to LDS while the encodings are computed
+    if (DMA) dma_issue(st, a.packed + a.off.f_layer1, n4_of(NH_KRX), lds, wave, lane);
+
     float ex[NH_KRX];
     float ed[NH_KRD];
     if (a.mode == 0) {
@@ -374,11 +389,14 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_fwd(MlpFwdArgs a) {
         if (VIEW) store_slot_rows<NH_KRD>(region_tile(a.stash, a.sl.D, a.nt, tile), a.sl.D.rows, ed, j, h);
     }
 
-    Stage<C::N4MAX> st;
-    NH_PH_INIT();
     int buf = 0;
     const float* pk = a.packed;
-    first_chunk<W, DMA>(pk + a.off.f_layer1, n4_of(NH_KRX), lds, st, wave, lane);
+    if (DMA) {
+        nh_wait_vmem();
+        nh_block_sync();
+    } else {
+        first_chunk<W, DMA>(pk + a.off.f_layer1, n4_of(NH_KRX), lds, st, wave, lane);
+    }
 
     f32x16 o[1];  // raw tiles only: fc_alpha's tile / the rgb tile / fc_out
     float act[KH];
@@ -404,7 +422,7 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_fwd(MlpFwdArgs a) {
         const int nn4 = n4_of(KH);  // layers_xyz[0] is never a skip layer (i > 0 is required)
         // no activation after layer1 (models.py:238)
         gemm_layer<W, DMA, NH_KRX, 0, TW, TW>(ex, nullptr, pk + a.off.f_layer1, nxt, nn4, lds, buf, st, o, lane, wave, res,
-                                              false, bits, false, bits, false, strow(a.sl.H[0]));
+                                              false, bits, false, bits, false, tr, strow(a.sl.H[0]));
 #pragma unroll
         for (int r = 0; r < KH; ++r) act[r] = res[r];
     }
@@ -418,10 +436,10 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_fwd(MlpFwdArgs a) {
         bits[0] = bits[1] = bits[2] = bits[3] = 0u;
         if (sk)
             gemm_layer<W, DMA, KH, NH_KRX, TW, TW>(act, ex, pk + a.off.f_xyz[i], nxt, nn4, lds, buf, st, o, lane, wave, res,
-                                                   true, bits, tr, bits, false, sr);
+                                                   true, bits, tr, bits, false, tr, sr);
         else
             gemm_layer<W, DMA, KH, 0, TW, TW>(act, nullptr, pk + a.off.f_xyz[i], nxt, nn4, lds, buf, st, o, lane, wave, res,
-                                              true, bits, tr, bits, false, sr);
+                                              true, bits, tr, bits, false, tr, sr);
         put_mask(i);  // H_{i+1}
 #pragma unroll
         for (int r = 0; r < KH; ++r) act[r] = res[r];
@@ -430,16 +448,16 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_fwd(MlpFwdArgs a) {
         // tiles 0..TW-1: feat = relu(fc_feat(h)); tile TW row 0: fc_alpha(h), raw (models.py:248-249)
         bits[0] = bits[1] = bits[2] = bits[3] = 0u;
         gemm_layer<W, DMA, KH, 0, TW + 1, TW>(act, nullptr, pk + a.off.f_head, pk + a.off.f_dir, n4_of(KH + NH_KRD), lds, buf,
-                                              st, o, lane, wave, res, true, bits, tr, bits, false, strow(a.sl.FEAT));
+                                              st, o, lane, wave, res, true, bits, tr, bits, false, tr, strow(a.sl.FEAT));
         put_mask(a.L - 1);
         const float alpha = o[0][0];
         float dh[KH / 2];
         bits[0] = bits[1] = bits[2] = bits[3] = 0u;
         gemm_layer<W, DMA, KH, NH_KRD, TW / 2, TW / 2>(res, ed, pk + a.off.f_dir, pk + a.off.f_rgb, n4_of(KH / 2), lds, buf, st,
-                                                       o, lane, wave, dh, true, bits, tr, bits, false, strow(a.sl.DIRH));
+                                                       o, lane, wave, dh, true, bits, tr, bits, false, tr, strow(a.sl.DIRH));
         put_mask(a.L);
         gemm_layer<W, DMA, KH / 2, 0, 1, 0>(dh, nullptr, pk + a.off.f_rgb, nullptr, 0, lds, buf, st, o, lane, wave, dh, false,
-                                            bits, false, bits, false, nullptr);
+                                            bits, false, bits, false, false, nullptr);
         if (valid && h == 0) {
             float4 r4;
             r4.x = o[0][0];
@@ -452,7 +470,7 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_fwd(MlpFwdArgs a) {
         NH_PH_FLUSH(0);
     } else {
         gemm_layer<W, DMA, KH, 0, 1, 0>(act, nullptr, pk + a.off.f_head, nullptr, 0, lds, buf, st, o, lane, wave, res, false,
-                                        bits, false, bits, false, nullptr);
+                                        bits, false, bits, false, false, nullptr);
         if (valid && h == 0) {
             float4 r4;
             r4.x = o[0][0];
@@ -467,6 +485,7 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_fwd(MlpFwdArgs a) {
 // ---- data-gradient chain ---------------------------------------------------------------------------------------------
 struct DgradArgs {
     const float* packed;
+    unsigned packed_bytes;
     NhPackedOffsets off;
     int L;
     int64_t M, nt;
@@ -500,6 +519,8 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_dgrad(DgradArgs a) {
     }
     auto grow = [&](const NhRegion& R) -> float* { return region_tile(a.grad, R, a.nt, tile) + (size_t)j * R.rows; };
     Stage<C::N4MAX> st;
+    st.base = a.packed;
+    st.dma = nh_dma_src(a.packed, a.packed_bytes);
     NH_PH_INIT();
     int buf = 0;
     const float* pk = a.packed;
@@ -527,17 +548,17 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_dgrad(DgradArgs a) {
         first_chunk<W, DMA>(pk + a.off.b_rgb, n4_of(4), lds, st, wave, lane);
         float dpd[KH / 2];
         gemm_layer<W, DMA, 4, 0, TW / 2, TW / 2>(d4, nullptr, pk + a.off.b_rgb, pk + a.off.b_dir, n4_of(KH / 2), lds, buf, st, o,
-                                                 lane, wave, dpd, false, mb, false, mb, true, grow(a.gl.PDIR));
+                                                 lane, wave, dpd, false, mb, false, mb, true, true, grow(a.gl.PDIR));
         get_mask(L - 1);  // FEAT
         gemm_layer<W, DMA, KH / 2, 0, TW, TW>(dpd, nullptr, pk + a.off.b_dir, pk + a.off.b_head, n4_of(KH + 4), lds, buf, st, o,
-                                              lane, wave, dp, false, mb, false, mb, true, grow(a.gl.PFEAT));
+                                              lane, wave, dp, false, mb, false, mb, true, true, grow(a.gl.PFEAT));
         if (L > 1) get_mask(L - 2);  // H_{L-1}
         float da[4];
         da[0] = h == 0 ? go.w : 0.0f;
         da[1] = da[2] = da[3] = 0.0f;
         const float* nxt = L > 1 ? pk + a.off.b_xyz[L - 2] : nullptr;
         gemm_layer<W, DMA, KH, 4, TW, TW>(dp, da, pk + a.off.b_head, nxt, n4_of(KH), lds, buf, st, o, lane, wave, res, false,
-                                          mb, false, mb, L > 1, grow(a.gl.P[L - 1]));
+                                          mb, false, mb, L > 1, true, grow(a.gl.P[L - 1]));
 #pragma unroll
         for (int r = 0; r < KH; ++r) dp[r] = res[r];
     } else {
@@ -550,7 +571,7 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_dgrad(DgradArgs a) {
         first_chunk<W, DMA>(pk + a.off.b_head, n4_of(4), lds, st, wave, lane);
         const float* nxt = L > 1 ? pk + a.off.b_xyz[L - 2] : nullptr;
         gemm_layer<W, DMA, 4, 0, TW, TW>(d4, nullptr, pk + a.off.b_head, nxt, n4_of(KH), lds, buf, st, o, lane, wave, dp, false,
-                                         mb, false, mb, L > 1, grow(a.gl.P[L - 1]));
+                                         mb, false, mb, L > 1, true, grow(a.gl.P[L - 1]));
     }
     // dp = d(pre-activation of H_{L-1}), already stored.  Walk down: dpre_{k-1} = relu'(H_{k-1}) * (W_{k-1}^T dpre_k);
     // H_0 = layer1 output has no activation (models.py:238).
@@ -559,7 +580,7 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_dgrad(DgradArgs a) {
         if (masked) get_mask(k - 2);  // H_{k-1}
         const float* nxt = k >= 2 ? pk + a.off.b_xyz[k - 2] : nullptr;
         gemm_layer<W, DMA, KH, 0, TW, TW>(dp, nullptr, pk + a.off.b_xyz[k - 1], nxt, n4_of(KH), lds, buf, st, o, lane, wave, res,
-                                          false, mb, false, mb, masked, grow(a.gl.P[k - 1]));
+                                          false, mb, false, mb, masked, true, grow(a.gl.P[k - 1]));
 #pragma unroll
         for (int r = 0; r < KH; ++r) dp[r] = res[r];
     }
@@ -887,6 +908,7 @@ int nh_mlp_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, i
     MlpFwdArgs a;
     memset(&a, 0, sizeof(a));
     a.packed = packed;
+    a.packed_bytes = (unsigned)(p->packed_floats * 4);
     a.off = p->po;
     a.L = p->L;
     a.skip = p->skip;
@@ -950,6 +972,7 @@ int nh_mlp_backward(nerfhip_plan* p, const float* packed, const float* g_out, in
     DgradArgs d;
     memset(&d, 0, sizeof(d));
     d.packed = packed;
+    d.packed_bytes = (unsigned)(p->packed_floats * 4);
     d.off = p->po;
     d.L = p->L;
     d.M = M;

@@ -52,6 +52,21 @@ NH_DEVICE void nh_glds16(const float* g, float* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// The same copy through a buffer descriptor: source = desc.base + soff (wave-uniform, SGPR) + voff (per lane), all in
+// bytes.  One piece costs two scalar adds + buffer_load_dwordx4 ... offen lds -- no VALU address arithmetic -- and
+// bytes beyond `bytes` are bounds-checked away by the descriptor instead of faulting.
+struct NhDmaSrc {
+    __amdgpu_buffer_rsrc_t r;
+};
+NH_DEVICE NhDmaSrc nh_dma_src(const float* base, unsigned bytes) {
+    NhDmaSrc s;
+    s.r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+    return s;
+}
+NH_DEVICE void nh_dma16(const NhDmaSrc& s, int voff, int soff, float* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(s.r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0,
+                                             0);
+}
 NH_DEVICE void nh_wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // nothing is scheduled across this point (pins "issue the prefetch BEFORE the MFMAs")
 NH_DEVICE void nh_sched_fence() { __builtin_amdgcn_sched_barrier(0); }

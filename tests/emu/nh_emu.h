@@ -123,6 +123,16 @@ NH_DEVICE f32x16 nh_mfma32(float a, float b, f32x16 c) {
 
 NH_DEVICE void nh_atomic_add(float* p, float v) { *p += v; }
 NH_DEVICE void nh_glds16(const float* g, float* lds_wave_base) { memcpy(lds_wave_base + 4 * emu::cur->lane, g, 16); }
+struct NhDmaSrc {
+    const char* base;
+    unsigned bytes;
+};
+NH_DEVICE NhDmaSrc nh_dma_src(const float* base, unsigned bytes) { return NhDmaSrc{(const char*)base, bytes}; }
+NH_DEVICE void nh_dma16(const NhDmaSrc& s, int voff, int soff, float* lds_wave_base) {
+    const unsigned off = (unsigned)(voff + soff);
+    if (off + 16 <= s.bytes)  // out-of-range lanes: the descriptor's bounds check (nothing is read)
+        memcpy(lds_wave_base + 4 * emu::cur->lane, s.base + off, 16);
+}
 NH_DEVICE void nh_wait_vmem() {}
 NH_DEVICE void nh_sched_fence() {}
 NH_DEVICE unsigned long long nh_wall_clock() { return 0ull; }

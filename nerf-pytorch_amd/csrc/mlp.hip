@@ -625,64 +625,31 @@ struct WOperands {
 template <int PO, int PI>
 NH_DEVICE void wgrad_load(WOperands<PO, PI>& op, const float* __restrict__ Ab, const float* __restrict__ Bb, size_t a_rows,
                           size_t b_rows, int half, int k) {
-    const float* pa = Ab + (size_t)(16 * half + k) * a_rows;
-    const float* pb = Bb + (size_t)(16 * half + k) * b_rows;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
+        const size_t s = (size_t)(16 * half + 2 * e + k);
 #pragma unroll
-        for (int x = 0; x < PO; ++x) op.A[x][e] = pa[32 * x];
+        for (int x = 0; x < PO; ++x) op.A[x][e] = Ab[s * a_rows + 32 * x];
 #pragma unroll
-        for (int y = 0; y < PI; ++y) op.B[y][e] = pb[32 * y];
-        pa += 2 * a_rows;
-        pb += 2 * b_rows;
+        for (int y = 0; y < PI; ++y) op.B[y][e] = Bb[s * b_rows + 32 * y];
     }
 }
 
-// Consume one half-tile operand set (8 k-steps) and, if `refill`, reload the SAME slot in place with the operands of
-// a later step: the loads of element e-1 are issued between the MFMAs of element e (an MFMA reads its operands when it
-// issues, so the slot is free again), one or two loads behind each MFMA.  Issuing all loads of a step up front costs
-// about 20 cycles each with the matrix pipe idle -- the 1.1 us per tile measured in profiles/r01_wgrad_timeline.txt.
 template <int PO, int PI>
-NH_DEVICE void wgrad_step(WOperands<PO, PI>& op, bool refill, const float* __restrict__ Ab, const float* __restrict__ Bb,
-                          size_t a_rows, size_t b_rows, int half, int k, f32x16 (&acc)[PO][PI], float (&bsum)[PO]) {
-    constexpr int NLOAD = PO + PI;
-    constexpr int NL = (NLOAD + PO * PI - 1) / (PO * PI);  // loads issued behind each MFMA
-    // running row pointers of the refill step: element e' is sample 16*half + 2e' + k; tile-block l is +32*l floats
-    const float* pa = Ab + (size_t)(16 * half + k) * a_rows;
-    const float* pb = Bb + (size_t)(16 * half + k) * b_rows;
+NH_DEVICE void wgrad_compute(const WOperands<PO, PI>& op, f32x16 (&acc)[PO][PI], float (&bsum)[PO]) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
 #pragma unroll
         for (int x = 0; x < PO; ++x) {
             bsum[x] += op.A[x][e];
 #pragma unroll
-            for (int y = 0; y < PI; ++y) {
-                acc[x][y] = nh_mfma32(op.A[x][e], op.B[y][e], acc[x][y]);
-                if (e >= 1 && refill) {
-#pragma unroll
-                    for (int l = (x * PI + y) * NL; l < (x * PI + y + 1) * NL; ++l) {
-                        if (l < PO) op.A[l][e - 1] = pa[32 * l];
-                        else if (l < NLOAD) op.B[l - PO][e - 1] = pb[32 * (l - PO)];
-                    }
-                }
-                nh_sched_fence();
-            }
+            for (int y = 0; y < PI; ++y) acc[x][y] = nh_mfma32(op.A[x][e], op.B[y][e], acc[x][y]);
         }
-        if (e >= 1) {  // advance to the rows of element e
-            pa += 2 * a_rows;
-            pb += 2 * b_rows;
-        }
-    }
-    if (refill) {
-#pragma unroll
-        for (int x = 0; x < PO; ++x) op.A[x][7] = pa[32 * x];
-#pragma unroll
-        for (int y = 0; y < PI; ++y) op.B[y][7] = pb[32 * y];
     }
 }
 
 // Half-tile steps are software pipelined through a ring of DEPTH operand sets: small patches do few MFMAs per step, so
-// they need more steps in flight to cover HBM latency (a 1x1 patch computes 512 cycles per step, a 4x4 patch 8192).
+// they need more loads in flight to cover HBM latency (a 1x1 patch computes 512 cycles per step, a 4x4 patch 8192).
 template <int PO, int PI, int DEPTH>
 NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int64_t t1, int ow, int iw, int wave,
                           int lane, int64_t wg) {
@@ -702,18 +669,16 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
     const float* A0 = a.grad + (size_t)32 * (size_t)a.nt * (size_t)jb.a_prefix + (size_t)(32 * ow * PO + i);
     const float* B0 = a.stash + (size_t)32 * (size_t)a.nt * (size_t)jb.b_prefix + (size_t)(jb.b_row0 + 32 * iw * PI + i);
     if constexpr (DEPTH == 2) {
-        // large patch: two named slots = the two halves of a tile, each refilled in place for the next tile
-        // (the in-place interleaved refill of wgrad_step makes hipcc spill ~140 registers for this 384-register
-        // variant, so the 4x4 patch keeps whole-step loads: issue the next half's loads, then compute the current half)
+        // large patch: plain double buffering at half-tile granularity (8192 MFMA cycles per step cover HBM latency)
         WOperands<PO, PI> op0, op1;
         if (t0 < t1) wgrad_load(op0, A0 + t0 * a_tile_stride, B0 + t0 * b_tile_stride, ar, br, 0, k);
         for (int64_t t = t0; t < t1; ++t) {
             wgrad_load(op1, A0 + t * a_tile_stride, B0 + t * b_tile_stride, ar, br, 1, k);
             nh_sched_fence();
-            wgrad_step(op0, false, A0, B0, ar, br, 0, k, acc, bsum);
+            wgrad_compute(op0, acc, bsum);
             if (t + 1 < t1) wgrad_load(op0, A0 + (t + 1) * a_tile_stride, B0 + (t + 1) * b_tile_stride, ar, br, 0, k);
             nh_sched_fence();
-            wgrad_step(op1, false, A0, B0, ar, br, 1, k, acc, bsum);
+            wgrad_compute(op1, acc, bsum);
         }
     } else {
     WOperands<PO, PI> ring[DEPTH];
@@ -728,10 +693,12 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
         for (int d = 0; d < DEPTH; ++d) {
             const int64_t s = sb + d;
             if (s < s1) {
+                nh_sched_fence();
+                wgrad_compute(ring[d], acc, bsum);
+                nh_sched_fence();  // refill this slot only after its MFMAs are issued (no renaming into fresh registers)
                 const int64_t sn = s + DEPTH;
-                const int64_t tn = sn < s1 ? (sn >> 1) : (s >> 1);  // (clamped: the pointers are unused when !refill)
-                wgrad_step(ring[d], sn < s1, A0 + tn * a_tile_stride, B0 + tn * b_tile_stride, ar, br, (int)(sn & 1), k, acc,
-                           bsum);
+                if (sn < s1)
+                    wgrad_load(ring[d], A0 + (sn >> 1) * a_tile_stride, B0 + (sn >> 1) * b_tile_stride, ar, br, (int)(sn & 1), k);
             }
         }
     }

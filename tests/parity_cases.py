@@ -415,3 +415,64 @@ def case_loss_adam(b):
         O.adam_step(p, gr, m, v, step, 5e-3)
         pp, mm, vv = b.adam_step(pp, gr.numpy(), mm, vv, 5e-3, step)
         close(pp, p.numpy(), 1e-7, 1e-6, what="adam step %d" % step)
+
+
+# ---- edge cases -----------------------------------------------------------------------------------------------------------
+def case_edges(b):
+    """Empty and ragged inputs, single samples, minimal bin counts, ties exactly at CDF values."""
+    z0 = np.zeros((0, 3), np.float32)
+    # empty inputs: every entry point accepts n == 0 / m == 0 and launches nothing
+    assert b.cumprod_exclusive(np.zeros((0, 5), np.float32)).shape == (0, 5)
+    assert b.pack_rays(z0, z0, 2.0, 6.0, z0).shape == (0, 11)
+    assert b.positional_encoding(z0, O.frequency_bands(4).numpy(), True).shape == (0, 27)
+    assert b.stratified_z(np.zeros((0, 11), np.float32), torch.linspace(0, 1, 8).numpy(), False, False).shape == (0, 8)
+    r = b.volume_render_fwd(np.zeros((0, 4, 4), np.float32), np.zeros((0, 4), np.float32), z0)
+    assert r[0].shape == (0, 3) and r[3].shape == (0, 4)
+    s, i, c = b.sample_pdf(np.zeros((0, 5), np.float32), np.zeros((0, 4), np.float32), 3, det=True)
+    assert s.shape == (0, 3)
+    # one sample per ray: the only interval is the 1e10 tail
+    raw = np.array([[[0.3, -0.2, 1.0, 0.7]], [[0.1, 0.1, 0.1, -0.5]]], np.float32)
+    z = np.array([[3.0], [4.0]], np.float32)
+    rd = np.array([[0, 0, -1.0], [0.5, 0, -1.0]], np.float32)
+    got = b.volume_render_fwd(raw, z, rd)
+    want = O.volume_render(T(raw), T(z), T(rd))
+    for g_, w_ in zip(got, want):
+        close(g_, w_.numpy(), 2e-6, 2e-6, what="single-sample render")
+    close(b.cumprod_exclusive(np.array([[5.0], [7.0]], np.float32)), [[1.0], [1.0]], 0, what="cumprod cols=1")
+    # one coarse sample (linspace(0,1,1) == [0]) with and without perturbation
+    rays = np.zeros((3, 11), np.float32)
+    rays[:, 6], rays[:, 7] = 2.0, 6.0
+    tr = torch.rand(3, 1, generator=rng(1))
+    t1 = torch.linspace(0, 1, 1).numpy()
+    close(b.stratified_z(rays, t1, False, True, tr.numpy()), O.stratified_z(T(rays[:, 6:7]), T(rays[:, 7:8]), 1, False, True, tr).numpy(), 0,
+          what="stratified nc=1")
+    # minimal pdf: two bins / one weight; flat pdf (all-zero weights); u exactly on CDF entries (ties -> side="right")
+    bins = np.array([[1.0, 2.0]], np.float32)
+    s, i, c = b.sample_pdf(bins, np.array([[0.0]], np.float32), 4, u=np.array([[0.0, 0.5, 1.0, 0.999]], np.float32))
+    ws, wi, wc = O.sample_pdf(T(bins), torch.zeros(1, 1), 4, u=torch.tensor([[0.0, 0.5, 1.0, 0.999]]), return_aux=True)
+    assert np.array_equal(i, wi.numpy()) and np.array_equal(c, wc.numpy())
+    close(s, ws.numpy(), 1e-6, what="two-bin samples")
+    bins = torch.sort(torch.rand(4, 9, generator=rng(2)) * 3 + 1, -1)[0].numpy()
+    w = np.zeros((4, 8), np.float32)
+    s, i, c = b.sample_pdf(bins, w, 16, det=True)
+    ws, wi, wc = O.sample_pdf(T(bins), T(w), 16, det=True, return_aux=True)
+    close(c, wc.numpy(), 2.5e-7, what="flat cdf")
+    close(s, ws.numpy(), 1e-5, what="flat pdf samples")
+    w = (torch.rand(4, 8, generator=rng(3)) ** 2).numpy()
+    _, _, cdf = b.sample_pdf(bins, w, 9, u=np.zeros((4, 9), np.float32))
+    _, inds, _ = b.sample_pdf(bins, w, 9, u=cdf.copy())       # every u sits exactly on a CDF entry
+    assert np.array_equal(inds, torch.searchsorted(T(cdf), T(cdf), right=True).numpy())
+    # minimal hierarchical step: 3 coarse samples (one interior weight), 1 fine sample
+    zc = np.array([[2.0, 3.0, 5.0]], np.float32)
+    wf = np.array([[0.2, 0.5, 0.3]], np.float32)
+    zs, zf = b.hierarchical_z(zc, wf, 1, u=np.array([[0.4]], np.float32))
+    wzs, wzf = O.hierarchical_z(T(zc), T(wf), 1, u=torch.tensor([[0.4]]))
+    close(zf, wzf.numpy(), 1e-6, what="minimal hierarchical")
+    # ragged MLP row counts: 1 row, and one more than a workgroup tile
+    cfg = MLP_GEOMETRIES["default4x128"]
+    plan, params, flat, packed = mlp_setup(b, cfg, seed=5)
+    for m in (1, 129):
+        x = torch.randn(m, 90, generator=rng(m))
+        got, _ = b.mlp_fwd(plan, packed, x.numpy())
+        close(got, O.mlp_forward(params, x, cfg).numpy(), 2e-5, 2e-5, what="mlp m=%d" % m)
+    b.lib.plan_destroy(plan)

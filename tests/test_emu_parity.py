@@ -64,3 +64,7 @@ def test_e2e_golden_d_noviewdirs(emu):
 
 def test_internal_rng(emu):
     P.case_internal_rng(emu)
+
+
+def test_edge_cases(emu):
+    P.case_edges(emu)

@@ -282,3 +282,7 @@ def test_validation_mode_image_shapes_and_coarse_only():
         out2 = N.run_one_iter_of_nerf(H, W, focal, m, None, ro, rd, opts2, mode="validation", encode_position_fn=ex,
                                       encode_direction_fn=ed)
     assert torch.equal(out[0], out2[0]) and torch.equal(out[2], out2[2])
+
+
+def test_edge_cases(gpu):
+    P.case_edges(gpu)

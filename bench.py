@@ -164,19 +164,16 @@ def main():
                         seed=1234, world_size=world, rank=rank)
     n = args.rays
     opts = N.make_options(NC, NF, num_random_rays=n)
-    g = torch.Generator().manual_seed(1000 + rank)
     poses = torch.stack([pose_spherical(th, -30.0, 4.0) for th in torch.linspace(-180, 180, 101)[:-1].tolist()]).to(dev)
-    pixel_sets = [torch.randperm(H * W, generator=g)[:n].to(dev) for _ in range(8)]
-    targets = torch.rand(8, n, 3, generator=g).to(dev)
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    images = torch.rand(8, H, W, 3, generator=g, device=dev)        # synthetic training views, resident in HBM
     lib = N._lib.get_lib()
 
     def one_step(i):
-        pose = poses[(i * world + rank) % poses.shape[0]]
-        pix = pixel_sets[i % 8]
-        ro, rd = N.get_rays_at_pixels(H, W, FOCAL, pose, pix)      # only the selected rays are generated
-        rays = N.pack_rays(ro, rd, opts)
-        lr = N.TrainEngine.lr_at(i)
-        return eng.step(rays, targets[i % 8], ray_offset=rank * n, lr=lr)
+        # the reference's loop body, train_nerf.py:210-270: pick a view, draw 4096 distinct pixels, their rays and
+        # targets (one launch, on the device), forward, loss, backward, [all-reduce], Adam with the decayed lr
+        k = i * world + rank
+        return eng.step_on_image(images[k % 8], poses[k % poses.shape[0]], H, W, FOCAL, opts, n, lr=N.TrainEngine.lr_at(i))
 
     def fence():
         if world > 1:

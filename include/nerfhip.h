@@ -242,6 +242,51 @@ int nerfhip_mse_loss_fwd_bwd(const float* rgb_coarse, const float* rgb_fine, con
 int nerfhip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                       float beta1, float beta2, float eps, int64_t step, float grad_scale, nerfhip_stream_t stream);
 
+/* ---- next to the path: training-ray selection and the 8-bit output stage -------- */
+/* Distinct sample positions: out[i] = P(first + i), P = a keyed pseudo-random permutation of [0, population)
+ * (6-round Feistel network, cycle-walking; round keys = Philox4x32-10(seed, step)).  Replaces
+ * np.random.choice(population, n, replace=False) of train_nerf.py:185-189 and :219-221: distinct, uniformly
+ * spread, reproducible, O(1) per index; ranks of a data-parallel job take disjoint [first, first+n) ranges of the
+ * same permutation.  population <= 2^32, first + n <= population. */
+int nerfhip_select_indices(uint64_t seed, uint64_t step, int64_t population, int64_t first, int64_t n, int64_t* out,
+                           nerfhip_stream_t stream);
+
+typedef struct nerfhip_select_cfg {
+    int32_t height, width; /* select index k addresses pixel (row k % height, col k / height): the reference goes
+                              through coords = stack(meshgrid_xy(arange(H), arange(W)), -1).reshape(-1, 2)
+                              (train_nerf.py:214-225) */
+    float focal;
+    float near, far;       /* options.dataset.near / far (train_utils.py:164-165) */
+    int32_t use_viewdirs;  /* rows of 11 floats (else 8) */
+    int32_t ndc;           /* options.dataset.no_ndc is False: ndc_rays(H, W, focal, 1.0, ...) (train_utils.py:156-160) */
+    float ndc_near, ndc_cw, ndc_ch, ndc_two_near, ndc_neg_two_near; /* as for nerfhip_ndc_rays */
+    int32_t channels;      /* floats per target pixel (3 or 4); the loss reads [:3] */
+    uint64_t seed, step;   /* permutation key, used when select_inds == NULL */
+    int64_t first;         /* first permutation position of this rank */
+} nerfhip_select_cfg;
+
+/* Image branch of the training loop (train_nerf.py:210-227) fused with run_one_iter_of_nerf's ray packing
+ * (train_utils.py:143-168): for n selected pixels generate ONLY their rays from the pose (c2w: dev, row-major,
+ * row stride c2w_ld >= 4), write packed rows rays[n, 8|11] and gather target[n, channels] from image[H, W, channels]
+ * (image/target may be NULL).  select_inds: dev int64 [n] flat select indices as the reference draws them, or NULL
+ * to draw them here (nerfhip_select_indices with population H*W); inds_out (optional) receives the indices used. */
+int nerfhip_select_rays(const nerfhip_select_cfg* cfg, const float* c2w, int c2w_ld, const float* image,
+                        const int64_t* select_inds, int64_t n, float* rays, float* target, int64_t* inds_out,
+                        nerfhip_stream_t stream);
+/* Cached branch (train_nerf.py:175-194): rows of a stored ray bundle (ray_origins / ray_directions: dev
+ * [population, 3]) and of targets[population, channels]. */
+int nerfhip_select_cached_rays(const nerfhip_select_cfg* cfg, const float* ray_origins, const float* ray_directions,
+                               const float* targets, int64_t population, const int64_t* select_inds, int64_t n,
+                               float* rays, float* target, int64_t* inds_out, nerfhip_stream_t stream);
+
+/* cast_to_image (eval_nerf.py:23-29): ToPILImage of a float image = mul(255) then byte conversion (truncation).
+ * rgb: dev [pixels, in_channels >= 3] (first three used); out: dev uint8 [pixels, 3] (H, W, 3 byte order). */
+int nerfhip_cast_to_image(const float* rgb, int in_channels, int64_t pixels, uint8_t* out, nerfhip_stream_t stream);
+/* cast_to_disparity_image (eval_nerf.py:32-35): min-max normalise, clamp(0,1)*255, truncate.  NaN pixels make
+ * min()/max() NaN in the reference, which zeroes the whole image -- reproduced.  scratch3: dev float[3]. */
+int nerfhip_cast_to_disparity_image(const float* disparity, int64_t pixels, float* scratch3, uint8_t* out,
+                                    nerfhip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

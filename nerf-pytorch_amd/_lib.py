@@ -38,6 +38,14 @@ class RenderOut(C.Structure):
                                    "acc_fine", "depth_fine")]
 
 
+class SelectCfg(C.Structure):
+    _fields_ = [("height", C.c_int32), ("width", C.c_int32), ("focal", C.c_float), ("near", C.c_float),
+                ("far", C.c_float), ("use_viewdirs", C.c_int32), ("ndc", C.c_int32), ("ndc_near", C.c_float),
+                ("ndc_cw", C.c_float), ("ndc_ch", C.c_float), ("ndc_two_near", C.c_float),
+                ("ndc_neg_two_near", C.c_float), ("channels", C.c_int32), ("seed", c_u64), ("step", c_u64),
+                ("first", c_i64)]
+
+
 _PROTOS = {
     "nerfhip_version": (C.c_int, []),
     "nerfhip_last_error": (C.c_char_p, []),
@@ -85,6 +93,12 @@ _PROTOS = {
     "nerfhip_mse_loss_fwd_bwd": (C.c_int, [c_f, c_f, c_f, C.c_int, c_i64, C.c_float, c_f, c_f, c_f, c_f]),
     "nerfhip_adam_step": (C.c_int, [c_f, c_f, c_f, c_f, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, c_i64,
                                      C.c_float, c_f]),
+    "nerfhip_select_indices": (C.c_int, [c_u64, c_u64, c_i64, c_i64, c_i64, c_f, c_f]),
+    "nerfhip_select_rays": (C.c_int, [C.POINTER(SelectCfg), c_f, C.c_int, c_f, c_f, c_i64, c_f, c_f, c_f, c_f]),
+    "nerfhip_select_cached_rays": (C.c_int, [C.POINTER(SelectCfg), c_f, c_f, c_f, c_i64, c_f, c_i64, c_f, c_f, c_f,
+                                             c_f]),
+    "nerfhip_cast_to_image": (C.c_int, [c_f, C.c_int, c_i64, c_f, c_f]),
+    "nerfhip_cast_to_disparity_image": (C.c_int, [c_f, c_i64, c_f, c_f, c_f]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_PROTOS))

@@ -5,6 +5,7 @@
 #include <stdio.h>
 
 #include "nh_host.h"
+#include "nh_rays.h"
 
 // ---- error string ------------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -99,18 +100,12 @@ NH_KERNEL void k_ray_bundle(int height, int width, float focal, const float* __r
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     int64_t p = pixels ? pixels[idx] : idx;
-    float ii = (float)(p % width);  // column (x)
-    float jj = (float)(p / width);  // row (y)
-    float dx = (ii - (float)(width * 0.5)) / focal;
-    float dy = -(jj - (float)(height * 0.5)) / focal;
-    float dz = -1.0f;
+    float o[3], d[3];
+    nh_pinhole_ray(height, width, focal, c2w, ld, p / width, p % width, o, d);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        float v = dx * c2w[c * ld + 0];
-        v = v + dy * c2w[c * ld + 1];
-        v = v + dz * c2w[c * ld + 2];
-        rd[idx * 3 + c] = v;
-        ro[idx * 3 + c] = c2w[c * ld + 3];
+        rd[idx * 3 + c] = d[c];
+        ro[idx * 3 + c] = o[c];
     }
 }
 
@@ -127,29 +122,18 @@ extern "C" int nerfhip_ray_bundle(int height, int width, float focal, const floa
 }
 
 // ---- ndc_rays (nerf/nerf_helpers.py:170-197) -------------------------------------------------------------------------
-NH_KERNEL void k_ndc_rays(float near, float cw, float ch, float two_near, float neg_two_near,
-                          const float* __restrict__ ro, const float* __restrict__ rd, int64_t n, float* __restrict__ oo,
-                          float* __restrict__ od) {
+NH_KERNEL void k_ndc_rays(NhNdc k, const float* __restrict__ ro, const float* __restrict__ rd, int64_t n,
+                          float* __restrict__ oo, float* __restrict__ od) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float ox = ro[i * 3], oy = ro[i * 3 + 1], oz = ro[i * 3 + 2];
-    float dx = rd[i * 3], dy = rd[i * 3 + 1], dz = rd[i * 3 + 2];
-    float t = -(near + oz) / dz;
-    ox = ox + t * dx;
-    oy = oy + t * dy;
-    oz = oz + t * dz;
-    float o0 = cw * ox / oz;
-    float o1 = ch * oy / oz;
-    float o2 = 1.0f + two_near / oz;
-    float d0 = cw * (dx / dz - ox / oz);
-    float d1 = ch * (dy / dz - oy / oz);
-    float d2 = neg_two_near / oz;
-    oo[i * 3] = o0;
-    oo[i * 3 + 1] = o1;
-    oo[i * 3 + 2] = o2;
-    od[i * 3] = d0;
-    od[i * 3 + 1] = d1;
-    od[i * 3 + 2] = d2;
+    float o[3] = {ro[i * 3], ro[i * 3 + 1], ro[i * 3 + 2]};
+    float d[3] = {rd[i * 3], rd[i * 3 + 1], rd[i * 3 + 2]};
+    nh_ndc_ray(k, o, d);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        oo[i * 3 + c] = o[c];
+        od[i * 3 + c] = d[c];
+    }
 }
 
 extern "C" int nerfhip_ndc_rays(float near, float cw, float ch, float two_near, float neg_two_near,
@@ -157,8 +141,8 @@ extern "C" int nerfhip_ndc_rays(float near, float cw, float ch, float two_near, 
                                 nerfhip_stream_t stream) {
     NH_REQUIRE(rays_o && rays_d && out_o && out_d && n >= 0, "ndc_rays: bad arguments");
     if (n == 0) return NERFHIP_OK;
-    NH_LAUNCH(k_ndc_rays, nh_ceil_div(n, 256), 256, 0, stream, near, cw, ch, two_near, neg_two_near, rays_o, rays_d, n,
-              out_o, out_d);
+    NhNdc k = {near, cw, ch, two_near, neg_two_near};
+    NH_LAUNCH(k_ndc_rays, nh_ceil_div(n, 256), 256, 0, stream, k, rays_o, rays_d, n, out_o, out_d);
     return nh_launch_status("ndc_rays");
 }
 
@@ -167,23 +151,15 @@ NH_KERNEL void k_pack_rays(const float* __restrict__ ro, const float* __restrict
                            float near, float far, int64_t n, float* __restrict__ rays) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    int stride = vsrc ? 11 : 8;
-    float* r = rays + i * stride;
-    r[0] = ro[i * 3];
-    r[1] = ro[i * 3 + 1];
-    r[2] = ro[i * 3 + 2];
-    r[3] = rd[i * 3];
-    r[4] = rd[i * 3 + 1];
-    r[5] = rd[i * 3 + 2];
-    r[6] = near;
-    r[7] = far;
+    float o[3] = {ro[i * 3], ro[i * 3 + 1], ro[i * 3 + 2]};
+    float d[3] = {rd[i * 3], rd[i * 3 + 1], rd[i * 3 + 2]};
+    float v[3];
     if (vsrc) {
-        float x = vsrc[i * 3], y = vsrc[i * 3 + 1], z = vsrc[i * 3 + 2];
-        float nrm = sqrtf(fmaf(z, z, fmaf(y, y, x * x)));  // torch's CPU norm(p=2) is this fma chain (bit-exact)
-        r[8] = x / nrm;
-        r[9] = y / nrm;
-        r[10] = z / nrm;
+        v[0] = vsrc[i * 3];
+        v[1] = vsrc[i * 3 + 1];
+        v[2] = vsrc[i * 3 + 2];
     }
+    nh_write_ray_row(rays + i * (vsrc ? 11 : 8), o, d, near, far, vsrc ? v : nullptr);
 }
 
 extern "C" int nerfhip_pack_rays(const float* rays_o, const float* rays_d, const float* viewdir_src, float near,

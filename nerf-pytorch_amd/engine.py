@@ -130,6 +130,16 @@ class TrainEngine:
         self.optimizer_step(lr)
         return self.loss
 
+    def step_on_image(self, image, pose, height, width, focal_length, options, num_random_rays, lr=None):
+        """One whole iteration of the reference's loop body (train_nerf.py:210-270) on a resident training image:
+        on-device selection of this rank's `num_random_rays` distinct pixels (ranks take disjoint slices of one
+        permutation keyed by (seed, iteration)), their rays and targets, then `step`.  No host work besides launches."""
+        from .train_utils import select_training_rays
+        n = int(num_random_rays)
+        rays, target, _ = select_training_rays(height, width, focal_length, pose, image, n, options, seed=self.seed,
+                                               step=self.step_count, first=self.rank * n)
+        return self.step(rays, target, ray_offset=self.rank * n, lr=lr)
+
     @staticmethod
     def lr_at(iteration, lr0=5e-3, lr_decay=250, lr_decay_factor=0.1):
         """train_nerf.py:264-270: lr0 * factor ** (i / (lr_decay * 1000))."""

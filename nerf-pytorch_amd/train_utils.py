@@ -207,6 +207,65 @@ def pack_rays(ray_origins, ray_directions, options, height=None, width=None, foc
     return rays
 
 
+def _select_cfg(height, width, focal_length, options, channels, seed, step, first):
+    f = float(focal_length)
+    f32 = lambda v: torch.tensor(v, dtype=torch.float32).item()  # noqa: E731
+    return L.SelectCfg(height=int(height), width=int(width), focal=f, near=float(options.dataset.near),
+                       far=float(options.dataset.far), use_viewdirs=int(bool(options.nerf.use_viewdirs)),
+                       ndc=int(options.dataset.no_ndc is False), ndc_near=1.0, ndc_cw=f32(-1.0 / (width / (2.0 * f))),
+                       ndc_ch=f32(-1.0 / (height / (2.0 * f))), ndc_two_near=2.0, ndc_neg_two_near=-2.0,
+                       channels=int(channels), seed=int(seed) & 0xFFFFFFFFFFFFFFFF, step=int(step), first=int(first))
+
+
+def select_training_rays(height, width, focal_length, pose, image, num_random_rays, options, select_inds=None, seed=0,
+                         step=0, first=0):
+    """The image branch of the training loop (train_nerf.py:210-227) fused with run_one_iter_of_nerf's ray packing
+    (train_utils.py:143-168), in ONE launch: draws `num_random_rays` distinct pixels on the device (or takes the
+    reference's `select_inds`, the flat indices it draws with np.random.choice), generates only those rays from `pose`
+    (>= 3x4, device), and gathers their targets from `image` (H, W, 3|4).  Returns (rays (N, 8|11) -- feed them to
+    predict_and_render_radiance or TrainEngine.step --, target (N, C), select_inds (N,))."""
+    lib = L.get_lib()
+    pose = pose.detach().float()
+    if pose.stride(-1) != 1:
+        pose = pose.contiguous()
+    dev = pose.device
+    n = int(num_random_rays)
+    channels = 3 if image is None else image.shape[-1]
+    cfg = _select_cfg(height, width, focal_length, options, channels, seed, step, first)
+    if image is not None:
+        image = image.detach().float().contiguous()
+    if select_inds is not None:
+        select_inds = torch.as_tensor(select_inds, dtype=torch.int64, device=dev).contiguous()
+    rays = torch.empty((n, 11 if cfg.use_viewdirs else 8), dtype=torch.float32, device=dev)
+    target = torch.empty((n, channels), dtype=torch.float32, device=dev) if image is not None else None
+    used = torch.empty((n,), dtype=torch.int64, device=dev)
+    lib.select_rays(C.byref(cfg), pose.data_ptr(), pose.stride(-2), image.data_ptr() if image is not None else None,
+                    select_inds.data_ptr() if select_inds is not None else None, n, rays.data_ptr(),
+                    target.data_ptr() if target is not None else None, used.data_ptr(), _stream())
+    return rays, target, used
+
+
+def select_cached_training_rays(cache_dict, num_random_rays, options, select_inds=None, seed=0, step=0, first=0):
+    """The cached branch (train_nerf.py:175-194): rows of cache_dict["ray_bundle"] (2, ., 3) and of
+    cache_dict["target"][..., :3], both already on the device."""
+    lib = L.get_lib()
+    bundle = cache_dict["ray_bundle"]
+    ro = bundle[0].reshape((-1, 3)).float().contiguous()
+    rd = bundle[1].reshape((-1, 3)).float().contiguous()
+    tgt = cache_dict["target"][..., :3].reshape((-1, 3)).float().contiguous()
+    dev, n = ro.device, int(num_random_rays)
+    cfg = _select_cfg(cache_dict["height"], cache_dict["width"], cache_dict["focal_length"], options, 3, seed, step, first)
+    if select_inds is not None:
+        select_inds = torch.as_tensor(select_inds, dtype=torch.int64, device=dev).contiguous()
+    rays = torch.empty((n, 11 if cfg.use_viewdirs else 8), dtype=torch.float32, device=dev)
+    target = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    used = torch.empty((n,), dtype=torch.int64, device=dev)
+    lib.select_cached_rays(C.byref(cfg), ro.data_ptr(), rd.data_ptr(), tgt.data_ptr(), ro.shape[0],
+                           select_inds.data_ptr() if select_inds is not None else None, n, rays.data_ptr(),
+                           target.data_ptr(), used.data_ptr(), _stream())
+    return rays, target, used
+
+
 def run_one_iter_of_nerf(height, width, focal_length, model_coarse, model_fine, ray_origins, ray_directions, options,
                          mode="train", encode_position_fn=None, encode_direction_fn=None):
     """nerf/train_utils.py:130-202."""

@@ -212,10 +212,70 @@ def pretrained_lego(nerf):
     npz("lego_lowres_render.npz", **d)
 
 
+def reference_script_function(script, name, namespace):
+    """Execute ONE function definition of a reference script (the scripts themselves cannot be imported here:
+    torchvision / tensorboard / imageio are absent) and return it."""
+    import ast
+    path = os.path.join(R.REFERENCE_ROOT, script)
+    tree = ast.parse(open(path).read(), path)
+    node = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name][0]
+    exec(compile(ast.Module([node], []), path, "exec"), namespace)
+    return namespace[name]
+
+
+def dataio(nerf):
+    """Rows either side of the path: the training loop's ray selection (train_nerf.py:210-227; those statements sit in
+    the script's main() and are restated here literally around the reference's own get_ray_bundle / meshgrid_xy) and
+    eval_nerf.py's 8-bit casts (executed from the reference source)."""
+    g = torch.Generator().manual_seed(21)
+    out = {}
+    for tag, (H, W, C, n) in {"a": (5, 7, 4, 12), "b": (20, 16, 3, 64)}.items():
+        focal = 0.9 * W
+        pose = pose_like(g)
+        img = torch.rand(H, W, C, generator=g)
+        select_inds = np.random.RandomState(5).choice(H * W, size=(n), replace=False)
+        ray_origins, ray_directions = nerf.get_ray_bundle(H, W, focal, pose[:3, :4])
+        coords = torch.stack(nerf.meshgrid_xy(torch.arange(H), torch.arange(W)), dim=-1)
+        coords = coords.reshape((-1, 2))
+        sel = coords[select_inds]
+        out.update({"sel_%s_hwfc" % tag: np.array([H, W, focal, C], np.float64), "sel_%s_pose" % tag: pose,
+                    "sel_%s_img" % tag: img, "sel_%s_inds" % tag: select_inds.astype(np.int64),
+                    "sel_%s_ro" % tag: ray_origins[sel[:, 0], sel[:, 1], :],
+                    "sel_%s_rd" % tag: ray_directions[sel[:, 0], sel[:, 1], :],
+                    "sel_%s_target" % tag: img[sel[:, 0], sel[:, 1], :]})
+    ns = {"np": np, "torch": torch}
+    disp_fn = reference_script_function("eval_nerf.py", "cast_to_disparity_image", ns)
+    d0 = torch.rand(9, 11, generator=g) * 3 + 0.1
+    d1 = d0.clone()
+    d1[2, 3] = float("nan")
+    d2 = torch.full((4, 4), 0.7)
+    d3 = d0.clone()
+    d3[0, 0] = float("inf")
+    with np.errstate(invalid="ignore"):
+        for i, d in enumerate((d0, d1, d2, d3)):
+            out["disp%d_in" % i] = d
+            out["disp%d_out" % i] = disp_fn(d)
+    # cast_to_image needs torchvision (absent): ToPILImage is stubbed with torchvision's published conversion for float
+    # tensors (functional.to_pil_image: pic.mul(255).byte(), CHW -> HWC) -- "parity unpinned" for that dependency.
+    import types
+    from PIL import Image
+    tv = types.SimpleNamespace(transforms=types.SimpleNamespace(ToPILImage=lambda: (
+        lambda pic: Image.fromarray(np.transpose(pic.mul(255).byte().numpy(), (1, 2, 0)), mode="RGB"))))
+    img_fn = reference_script_function("eval_nerf.py", "cast_to_image", dict(ns, torchvision=tv))
+    rgb = torch.rand(6, 5, 3, generator=g)
+    rgb[0, 0] = torch.tensor([0.0, 1.0, 1.0000001])
+    rgb[0, 1] = torch.tensor([254.999 / 255, 0.5, 1 / 255])
+    out["img_in"] = rgb
+    out["img_out"] = img_fn(rgb, "blender")
+    npz("dataio.npz", **out)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
     nerf = R.import_reference()
+    if sys.argv[1:] == ["dataio"]:
+        return dataio(nerf)
     helpers(nerf)
     mlp_case(nerf)
     base = dict(num_layers=4, hidden_size=128, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4)
@@ -228,6 +288,7 @@ def main():
     e2e_case(nerf, "e2e_c.npz", fern, fern, 4, 32, 32, False, False, False, 0.0, seed=3, ndc=True)
     e2e_case(nerf, "e2e_d.npz", novw, novw, 5, 8, 8, True, True, True, 1.0, seed=4)
     pretrained_lego(nerf)
+    dataio(nerf)
 
 
 if __name__ == "__main__":

@@ -305,3 +305,37 @@ def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
     bc2 = 1 - beta2 ** step
     denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
     p.addcdiv_(m, denom, value=-(lr / bc1))
+
+
+# ---- next to the path: training-ray selection (train_nerf.py:210-227, :175-194) and the 8-bit output stage ----------
+def select_training_rays(height, width, focal, c2w, image, select_inds):
+    """train_nerf.py:213-227: rays of the whole image, then rows picked through coords[select_inds]."""
+    ro, rd = get_ray_bundle(height, width, focal, c2w)
+    ii, jj = torch.meshgrid(torch.arange(height), torch.arange(width), indexing="ij")
+    coords = torch.stack([ii.transpose(-1, -2), jj.transpose(-1, -2)], dim=-1).reshape((-1, 2))  # meshgrid_xy
+    sel = coords[torch.as_tensor(select_inds, dtype=torch.int64)]
+    tgt = None if image is None else image[sel[:, 0], sel[:, 1], :]
+    return ro[sel[:, 0], sel[:, 1], :], rd[sel[:, 0], sel[:, 1], :], tgt
+
+
+def select_cached_rays(ray_bundle, target, select_inds):
+    """train_nerf.py:175-194: rows of a cached bundle (2, ., 3) and of its targets (first three channels)."""
+    idx = torch.as_tensor(select_inds, dtype=torch.int64)
+    ro, rd = ray_bundle[0].reshape((-1, 3)), ray_bundle[1].reshape((-1, 3))
+    return ro[idx], rd[idx], target[..., :3].reshape((-1, 3))[idx]
+
+
+def cast_to_image(rgb):
+    """eval_nerf.py:23-29.  torchvision (absent here; ToPILImage of a float tensor is pic.mul(255).byte(), functional
+    to_pil_image) followed by np.array -> (H, W, 3) uint8."""
+    return rgb[..., :3].permute(2, 0, 1).mul(255).byte().permute(1, 2, 0).contiguous().numpy()
+
+
+def cast_to_disparity_image(t):
+    """eval_nerf.py:32-35."""
+    import numpy as np
+    img = (t - t.min()) / (t.max() - t.min())
+    img = img.clamp(0, 1) * 255
+    a = img.detach().cpu().numpy()
+    # astype(uint8) of NaN is platform-defined; the reference run on x86-64 (tests/golden/dataio.npz) yields 0
+    return np.where(np.isnan(a), 0, a).astype(np.uint8)

@@ -62,6 +62,53 @@ class Backend:
     def devopt(self, a, dtype=np.float32):
         return None if a is None else self.dev(np.ascontiguousarray(a, dtype=dtype))
 
+    # -- rows either side of the path: ray selection, 8-bit output ---------------------------------------------------
+    def select_indices(self, seed, step, population, first, n):
+        out = self.empty((n,), np.int64)
+        self.lib.select_indices(seed, step, population, first, n, self.ptr(out), self.stream())
+        return self.host(out)
+
+    def _select_cfg(self, H, W, focal, near, far, use_viewdirs, ndc, channels, seed, step, first):
+        f32 = np.float32
+        return L.SelectCfg(height=H, width=W, focal=float(focal), near=float(near), far=float(far),
+                           use_viewdirs=int(use_viewdirs), ndc=int(ndc), ndc_near=1.0,
+                           ndc_cw=float(f32(-1.0 / (W / (2.0 * focal)))), ndc_ch=float(f32(-1.0 / (H / (2.0 * focal)))),
+                           ndc_two_near=2.0, ndc_neg_two_near=-2.0, channels=channels, seed=seed, step=step, first=first)
+
+    def select_rays(self, H, W, focal, c2w, image, n, near, far, inds=None, use_viewdirs=True, ndc=False, seed=0, step=0,
+                    first=0):
+        c2w = np.ascontiguousarray(c2w, np.float32)
+        ch = 3 if image is None else image.shape[-1]
+        cfg = self._select_cfg(H, W, focal, near, far, use_viewdirs, ndc, ch, seed, step, first)
+        dc, di, dn = self.dev(c2w), self.devopt(image), self.devopt(inds, np.int64)
+        rays, tgt, used = self.empty((n, 11 if use_viewdirs else 8)), self.empty((n, ch)), self.empty((n,), np.int64)
+        self.lib.select_rays(C.byref(cfg), self.ptr(dc), c2w.shape[1], self.p(di), self.p(dn), n, self.ptr(rays),
+                             self.ptr(tgt) if image is not None else None, self.ptr(used), self.stream())
+        return self.host(rays), (self.host(tgt) if image is not None else None), self.host(used)
+
+    def select_cached_rays(self, H, W, focal, ro, rd, targets, n, near, far, inds=None, use_viewdirs=True, ndc=False,
+                           seed=0, step=0, first=0):
+        ch = targets.shape[-1]
+        cfg = self._select_cfg(H, W, focal, near, far, use_viewdirs, ndc, ch, seed, step, first)
+        do, dd, dt, dn = self.dev(ro), self.dev(rd), self.dev(targets), self.devopt(inds, np.int64)
+        rays, tgt, used = self.empty((n, 11 if use_viewdirs else 8)), self.empty((n, ch)), self.empty((n,), np.int64)
+        self.lib.select_cached_rays(C.byref(cfg), self.ptr(do), self.ptr(dd), self.ptr(dt), ro.shape[0], self.p(dn), n,
+                                    self.ptr(rays), self.ptr(tgt), self.ptr(used), self.stream())
+        return self.host(rays), self.host(tgt), self.host(used)
+
+    def cast_to_image(self, rgb):
+        h, w, c = rgb.shape
+        d = self.dev(np.ascontiguousarray(rgb, np.float32))
+        out = self.empty((h, w, 3), np.uint8)
+        self.lib.cast_to_image(self.ptr(d), c, h * w, self.ptr(out), self.stream())
+        return self.host(out)
+
+    def cast_to_disparity_image(self, disp):
+        d = self.dev(np.ascontiguousarray(disp, np.float32))
+        out, scratch = self.empty(disp.shape, np.uint8), self.empty((3,))
+        self.lib.cast_to_disparity_image(self.ptr(d), disp.size, self.ptr(scratch), self.ptr(out), self.stream())
+        return self.host(out)
+
     # -- unit ops ---------------------------------------------------------------------------------------------------
     def rng_fill(self, kind, seed, stream_id, first, n):
         out = self.empty((n,))
@@ -315,7 +362,8 @@ class GpuBackend(Backend):
         return self.torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
     def empty(self, shape, dtype=np.float32):
-        td = {np.float32: self.torch.float32, np.int64: self.torch.int64, np.int32: self.torch.int32}[dtype]
+        td = {np.float32: self.torch.float32, np.int64: self.torch.int64, np.int32: self.torch.int32,
+              np.uint8: self.torch.uint8}[dtype]
         t = self.torch.empty(shape, dtype=td, device="cuda")
         if dtype == np.float32:
             t.fill_(float("nan"))

@@ -476,3 +476,91 @@ def case_edges(b):
         got, _ = b.mlp_fwd(plan, packed, x.numpy())
         close(got, O.mlp_forward(params, x, cfg).numpy(), 2e-5, 2e-5, what="mlp m=%d" % m)
     b.lib.plan_destroy(plan)
+
+
+# ---- rows either side of the path ----------------------------------------------------------------
+def case_select(b):
+    """Training-ray selection: given the reference's select indices the fused kernel must equal the reference's
+    gathers (golden, recorded from its get_ray_bundle / meshgrid_xy) followed by its ray packing; with its own draw
+    the indices must equal the restated permutation and be distinct."""
+    import select_oracle as S
+    g = gold("dataio.npz")
+    for tag in "ab":
+        H, W, focal, C_ = g["sel_%s_hwfc" % tag]
+        H, W = int(H), int(W)
+        pose, img, inds = g["sel_%s_pose" % tag], g["sel_%s_img" % tag], g["sel_%s_inds" % tag]
+        ro, rd, tgt = T(g["sel_%s_ro" % tag]), T(g["sel_%s_rd" % tag]), g["sel_%s_target" % tag]
+        for use_viewdirs in (True, False):
+            rays, t, used = b.select_rays(H, W, focal, pose, img, len(inds), 2.0, 6.0, inds=inds, use_viewdirs=use_viewdirs)
+            want = O.pack_rays(ro, rd, 2.0, 6.0, rd if use_viewdirs else None).numpy()
+            close(rays, want, 1e-6, what="select rays " + tag)
+            assert np.array_equal(t, tgt) and np.array_equal(used, inds)
+        # NDC variant: viewdirs from the pre-NDC directions, ndc_rays(H, W, focal, 1.0, ...) (train_utils.py:143-168)
+        rays, _, _ = b.select_rays(H, W, focal, pose, None, len(inds), 0.0, 1.0, inds=inds, ndc=True)
+        no, nd = O.ndc_rays(H, W, focal, 1.0, ro, rd)
+        close(rays, O.pack_rays(no, nd, 0.0, 1.0, rd).numpy(), 1e-5, 1e-5, what="select rays ndc " + tag)
+        # same bits as the unit kernels (ray_bundle at those pixels -> pack_rays)
+        pix = (inds % H) * W + inds // H
+        uro, urd = b.ray_bundle(H, W, focal, pose, pix)
+        rays, _, _ = b.select_rays(H, W, focal, pose, None, len(inds), 2.0, 6.0, inds=inds)
+        close(rays, b.pack_rays(uro, urd, 2.0, 6.0, urd), 0, what="select == unit kernels")
+        # the oracle restatement of the selection agrees with the golden as well
+        oro, ord_, otg = O.select_training_rays(H, W, focal, T(pose)[:3, :4], T(img), inds)
+        assert torch.equal(oro, ro) and torch.equal(ord_, rd) and np.array_equal(otg.numpy(), tgt)
+        # cached branch: rows of the stored bundle
+        full_o, full_d = O.get_ray_bundle(H, W, focal, T(pose)[:3, :4])
+        bundle = torch.stack([full_o, full_d], 0)
+        cro, crd, ctg = O.select_cached_rays(bundle, T(img), inds)
+        rays, t, _ = b.select_cached_rays(H, W, focal, full_o.reshape(-1, 3).numpy(), full_d.reshape(-1, 3).numpy(),
+                                          np.ascontiguousarray(img.reshape(-1, img.shape[-1])), len(inds), 2.0, 6.0, inds=inds)
+        close(rays, O.pack_rays(cro, crd, 2.0, 6.0, crd).numpy(), 1e-6, what="cached rays " + tag)
+        assert np.array_equal(t[:, :3], ctg.numpy())
+    # own draw: bit-exact against the restated permutation; a bijection over the whole population
+    for (seed, step, pop) in ((1, 0, 35), (7, 123456789012, 1000), (2 ** 63 + 5, 3, 1), (3, 9, 2), (4, 4, 4096)):
+        got = b.select_indices(seed, step, pop, 0, pop)
+        assert np.array_equal(got, S.select_indices(seed, step, pop, 0, pop)), (seed, step, pop)
+        assert np.array_equal(np.sort(got), np.arange(pop))
+    part = b.select_indices(7, 5, 160000, 4096, 512)
+    assert np.array_equal(part, S.select_indices(7, 5, 160000, 4096, 512))
+    rays, t, used = b.select_rays(20, 16, 14.4, g["sel_b_pose"], g["sel_b_img"], 64, 2.0, 6.0, seed=11, step=3, first=64)
+    assert np.array_equal(used, S.select_indices(11, 3, 320, 64, 64))
+    assert np.array_equal(t, g["sel_b_img"][used % 20, used // 20])
+    # Philox stream of nerfhip_rng_fill against the restated generator (itself pinned on the Random123 vectors)
+    assert np.array_equal(b.rng_fill(0, 0xDEADBEEFCAFE, 2, 2 ** 33 + 1, 64), S.uniform(0xDEADBEEFCAFE, 2, 2 ** 33 + 1, 64))
+
+
+def case_select_uniformity(b):
+    """Statistical sanity of the draw at the headline size: 4096 of 160000 pixels, many steps -> every pixel's hit
+    count is Binomial(steps, 4096/160000); chi-square over 400 coarse cells within 5 sigma; no repeats in a batch."""
+    pop, n, steps = 160000, 4096, 48
+    counts = np.zeros(400)
+    for s in range(steps):
+        idx = b.select_indices(42, s, pop, 0, n)
+        assert len(np.unique(idx)) == n and idx.min() >= 0 and idx.max() < pop
+        counts += np.bincount(idx // 400, minlength=400)
+    expected = steps * n / 400.0
+    chi2 = float(((counts - expected) ** 2 / expected).sum())
+    assert abs(chi2 - 399) < 5 * np.sqrt(2 * 399), chi2
+    # consecutive steps are unrelated: overlap of two batches ~ n*n/pop = 105 +- 5 sigma
+    a, c = b.select_indices(42, 0, pop, 0, n), b.select_indices(42, 1, pop, 0, n)
+    ov = len(np.intersect1d(a, c))
+    assert abs(ov - n * n / pop) < 5 * np.sqrt(n * n / pop), ov
+
+
+def case_image_output(b):
+    g = gold("dataio.npz")
+    assert np.array_equal(b.cast_to_image(g["img_in"]), g["img_out"])
+    assert np.array_equal(O.cast_to_image(T(g["img_in"])), g["img_out"])
+    rgba = np.concatenate([g["img_in"], np.ones_like(g["img_in"][..., :1])], -1)
+    assert np.array_equal(b.cast_to_image(rgba), g["img_out"])
+    for i in range(4):
+        assert np.array_equal(b.cast_to_disparity_image(g["disp%d_in" % i]), g["disp%d_out" % i]), i
+        assert np.array_equal(O.cast_to_disparity_image(T(g["disp%d_in" % i])), g["disp%d_out" % i]), i
+    big = (torch.rand(300, 217, generator=rng(4)) * 5).numpy()      # more than one pass of the 1024-thread reduction
+    assert np.array_equal(b.cast_to_disparity_image(big), O.cast_to_disparity_image(T(big)))
+    x = (torch.rand(64, 50, 3, generator=rng(6)) * 1.003).numpy()        # whole defined range of the byte conversion
+    assert np.array_equal(b.cast_to_image(x), O.cast_to_image(T(x)))
+    # outside [0, 256) the host conversion is undefined behaviour; the library defines it as x86-64 does (truncate to
+    # int32, keep the low byte; NaN -> 0)
+    odd = np.array([[[-1.0, 2.0, np.nan], [1e20, -0.001, 256.5 / 255]]], np.float32)
+    assert np.array_equal(b.cast_to_image(odd), np.array([[[1, 254, 0], [0, 0, 0]]], np.uint8))

@@ -68,3 +68,15 @@ def test_internal_rng(emu):
 
 def test_edge_cases(emu):
     P.case_edges(emu)
+
+
+def test_select_rays(emu):
+    P.case_select(emu)
+
+
+def test_select_uniformity(emu):
+    P.case_select_uniformity(emu)
+
+
+def test_image_output(emu):
+    P.case_image_output(emu)

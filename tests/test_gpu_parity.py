@@ -286,3 +286,86 @@ def test_validation_mode_image_shapes_and_coarse_only():
 
 def test_edge_cases(gpu):
     P.case_edges(gpu)
+
+
+def test_select_rays(gpu):
+    P.case_select(gpu)
+
+
+def test_select_uniformity(gpu):
+    P.case_select_uniformity(gpu)
+
+
+def test_image_output(gpu):
+    P.case_image_output(gpu)
+
+
+def test_python_api_select_step_resume_and_writer(tmp_path):
+    """The rows next to the path through their Python surface: select_training_rays == the reference's gathers
+    (golden), TrainEngine.step_on_image trains, a checkpoint written in the reference's format resumes bit-exactly,
+    and ImageWriter's PNGs hold the reference's 8-bit casts."""
+    import zlib
+    import nerf_pytorch_amd as N
+    from nerf_pytorch_amd import io_utils as IO
+    from nerf_pytorch_amd.engine import TrainEngine
+    from nerf_pytorch_amd.eval_utils import ImageWriter, cast_to_disparity_image, cast_to_image
+    from nerf_pytorch_amd.train_utils import select_cached_training_rays, select_training_rays
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    dev = torch.device("cuda", 0)
+    g = gold("dataio.npz")
+    H, W, focal = 20, 16, float(g["sel_b_hwfc"][2])
+    pose, img, inds = torch.from_numpy(g["sel_b_pose"]).to(dev), torch.from_numpy(g["sel_b_img"]).to(dev), g["sel_b_inds"]
+    opts = N.make_options(16, 16)
+    rays, tgt, used = select_training_rays(H, W, focal, pose, img, len(inds), opts, select_inds=inds)
+    want = O.pack_rays(torch.from_numpy(g["sel_b_ro"]), torch.from_numpy(g["sel_b_rd"]), 2.0, 6.0, torch.from_numpy(g["sel_b_rd"]))
+    P.close(rays.cpu().numpy(), want.numpy(), 1e-6, what="select_training_rays")
+    assert np.array_equal(tgt.cpu().numpy(), g["sel_b_target"]) and np.array_equal(used.cpu().numpy(), inds)
+    ro, rd = N.get_ray_bundle(H, W, focal, pose[:3, :4])
+    cache = {"height": H, "width": W, "focal_length": focal, "ray_bundle": torch.stack([ro, rd], 0), "target": img}
+    rays_c, tgt_c, _ = select_cached_training_rays(cache, 32, opts, seed=5, step=2)
+    rays_i, tgt_i, used_i = select_training_rays(H, W, focal, pose, img, 32, opts, seed=5, step=2)
+    # cached rows are row-major (k = row*W + col) while the image branch reads k as (k % H, k // H): same draw, the
+    # rays differ but each is the ray of its own target pixel
+    flat = (ro.reshape(-1, 3), img.reshape(-1, 3))
+    assert torch.equal(rays_c[:, :3], flat[0][used_i]) and torch.equal(tgt_c, flat[1][used_i])
+    assert torch.equal(tgt_i, img[used_i % H, used_i // H])
+
+    cfg = dict(num_layers=4, hidden_size=128, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4)
+
+    def make():
+        mc, mf = N.FlexibleNeRFModel(**cfg), N.FlexibleNeRFModel(**cfg)
+        mc.load_state_dict(O.init_params(cfg, seed=1))
+        mf.load_state_dict(O.init_params(cfg, seed=2))
+        mc, mf = mc.to(dev), mf.to(dev)
+        return mc, mf, TrainEngine(mc, mf, 16, 16, perturb=True, noise_std=0.2, lr=5e-3, seed=9, world_size=1, rank=0)
+
+    mc, mf, eng = make()
+    losses = [float(eng.step_on_image(img, pose, H, W, focal, opts, 64)[2]) for _ in range(6)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    # uninterrupted run of 4 more steps vs save -> fresh engine -> load -> 4 steps
+    path = str(tmp_path / "checkpoint00005.ckpt")
+    IO.save_checkpoint(path, 5, mc, mf, IO.engine_optimizer_state_dict(eng), eng.loss[2].clone(), 0.0)
+    tail = [float(eng.step_on_image(img, pose, H, W, focal, opts, 64)[2]) for _ in range(4)]
+    mc2, mf2, eng2 = make()
+    ck = IO.load_checkpoint(path, mc2, mf2, engine=eng2)
+    assert ck["iter"] == 5 and eng2.step_count == 6
+    tail2 = [float(eng2.step_on_image(img, pose, H, W, focal, opts, 64)[2]) for _ in range(4)]
+    assert tail == tail2, (tail, tail2)
+    assert torch.equal(mc.flat_params, mc2.flat_params) and torch.equal(mf.flat_params, mf2.flat_params)
+    # a torch.optim.Adam built the reference's way accepts the saved optimizer state (train_nerf.py:138-143,161)
+    opt = torch.optim.Adam(list(mc2.parameters()) + list(mf2.parameters()), lr=5e-3)
+    opt.load_state_dict(torch.load(path, weights_only=False)["optimizer_state_dict"])
+
+    rgb, disp = torch.from_numpy(g["img_in"]).to(dev), torch.from_numpy(g["disp0_in"]).to(dev)
+    assert np.array_equal(cast_to_image(rgb, "blender"), g["img_out"])
+    assert np.array_equal(cast_to_disparity_image(disp), g["disp0_out"])
+    wr = ImageWriter(workers=2)
+    wr.submit(str(tmp_path / "out" / "0000.png"), rgb)
+    wr.submit(str(tmp_path / "out" / "disparity" / "0000.png"), disp, disparity=True)
+    paths = wr.close()
+    for pth, want8 in zip(paths, (g["img_out"], g["disp0_out"])):
+        data = open(pth, "rb").read()
+        n = int.from_bytes(data[33:37], "big")
+        raw = np.frombuffer(zlib.decompress(data[41:41 + n]), np.uint8).reshape(want8.shape[0], -1)
+        assert np.array_equal(raw[:, 1:].reshape(want8.shape), want8)

@@ -598,8 +598,13 @@ struct JobDev {
     int col_kind, col_base, col_count;
     int bias_off;
     int wg_start;
+    int g;  // LDS-staged variant: 32-sample tiles per stage
 };
 constexpr int NH_JOBS_DEV = 32;
+// LDS-staged weight-gradient kernel: two stages of at most NH_WG_STAGE_FLOATS floats (+ slack for the operand prefetch
+// that runs one k-step past the end of a stage)
+constexpr int NH_WG_STAGE_FLOATS = 16384;
+constexpr int NH_WG_LDS_BYTES = 2 * NH_WG_STAGE_FLOATS * 4 + 4096;
 // floats of split-K partial per workgroup: 4 waves x 256 regs x 64 lanes, + 512 bias partials, + 64 for the timeline
 constexpr int NH_PART = 65536 + 512 + 64;
 
@@ -752,6 +757,148 @@ NH_KERNEL void NH_LB(256, 1) k_wgrad(WgradArgs a) {
     }
 }
 
+// ---- LDS-staged variant ------------------------------------------------------------------------------------------------
+// A workgroup's operands for a run of G sample tiles are two CONTIGUOUS blocks of HBM ([G*32 samples][a_rows] of the
+// gradient scratch, [G*32 samples][b_rows] of the stash: every job covers whole regions).  They are copied once per
+// workgroup by LDS-DMA (1 KiB per instruction, no VGPRs, 16 instructions per wave for a 256x256 job instead of 128
+// per-lane dword loads), double buffered: stage n+1 streams in while stage n is multiplied.  Lane (i, k) then reads
+// its MFMA operands A[i][k] = lds[(2e + k) * rows + 32 * tile + i] with ds_read_b32, one k-step ahead of the MFMAs.
+template <int PO, int PI>
+struct WStep {
+    float A[PO], B[PI];
+};
+template <int PO, int PI>
+NH_DEVICE void wstep_load(WStep<PO, PI>& o, const float* pa, const float* pb) {
+#pragma unroll
+    for (int x = 0; x < PO; ++x) o.A[x] = pa[32 * x];
+#pragma unroll
+    for (int y = 0; y < PI; ++y) o.B[y] = pb[32 * y];
+}
+template <int PO, int PI>
+NH_DEVICE void wstep_mfma(const WStep<PO, PI>& o, f32x16 (&acc)[PO][PI], float (&bsum)[PO]) {
+#pragma unroll
+    for (int x = 0; x < PO; ++x) {
+        bsum[x] += o.A[x];
+#pragma unroll
+        for (int y = 0; y < PI; ++y) acc[x][y] = nh_mfma32(o.A[x], o.B[y], acc[x][y]);
+    }
+}
+
+NH_DEVICE void wgrad_stage_dma(const float* ga, const float* gb, int a_fl, int b_fl, int ntile, int g, float* buf, int wave,
+                               int lane) {
+    // block A: ntile * a_fl floats -> buf[0 ..); block B: ntile * b_fl floats -> buf[g * a_fl ..)
+    const NhDmaSrc sa = nh_dma_src(ga, (unsigned)(ntile * a_fl * 4));
+    const NhDmaSrc sb = nh_dma_src(gb, (unsigned)(ntile * b_fl * 4));
+    const int pa = ntile * a_fl / 256, pb = ntile * b_fl / 256;
+    for (int q = wave; q < pa; q += 4) nh_dma16(sa, lane * 16, q * 1024, buf + q * 256);
+    float* bb = buf + g * a_fl;
+    for (int q = wave; q < pb; q += 4) nh_dma16(sb, lane * 16, q * 1024, bb + q * 256);
+}
+
+template <int PO, int PI>
+NH_DEVICE void wgrad_body_lds(const WgradArgs& a, const JobDev& jb, int64_t t0, int64_t t1, int ow, int iw, int wave,
+                              int lane, int64_t wg, bool active, float* lds) {
+    const int i = lane & 31, k = lane >> 5;
+    f32x16 acc[PO][PI];
+    float bsum[PO];
+#pragma unroll
+    for (int x = 0; x < PO; ++x) {
+        bsum[x] = 0.0f;
+#pragma unroll
+        for (int y = 0; y < PI; ++y)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[x][y][c] = 0.0f;
+    }
+    const int ar = jb.a_rows, br = jb.b_rows, g = jb.g;
+    const int a_fl = 32 * ar, b_fl = 32 * br;
+    const float* A0 = a.grad + (size_t)32 * (size_t)a.nt * (size_t)jb.a_prefix;
+    const float* B0 = a.stash + (size_t)32 * (size_t)a.nt * (size_t)jb.b_prefix;
+    const int64_t nstage = (t1 - t0 + g - 1) / g;
+    if (nstage > 0) {
+        const int nt0 = (int)(t1 - t0 < g ? t1 - t0 : g);
+        wgrad_stage_dma(A0 + (size_t)t0 * a_fl, B0 + (size_t)t0 * b_fl, a_fl, b_fl, nt0, g, lds, wave, lane);
+    }
+    for (int64_t n = 0; n < nstage; ++n) {
+        const int64_t t = t0 + n * g;
+        const int ntile = (int)(t1 - t < g ? t1 - t : g);
+        nh_wait_vmem();
+        nh_block_sync();  // stage n has landed for every wave; everybody is done reading the other buffer
+        if (n + 1 < nstage) {
+            const int64_t tn = t + g;
+            const int ntn = (int)(t1 - tn < g ? t1 - tn : g);
+            wgrad_stage_dma(A0 + (size_t)tn * a_fl, B0 + (size_t)tn * b_fl, a_fl, b_fl, ntn, g,
+                            lds + ((n + 1) & 1) * NH_WG_STAGE_FLOATS, wave, lane);
+        }
+        if (active) {
+            const float* buf = lds + (n & 1) * NH_WG_STAGE_FLOATS;
+            const float* pa = buf + k * ar + 32 * ow * PO + i;
+            const float* pb = buf + g * a_fl + k * br + 32 * iw * PI + i;
+            const int steps = 16 * ntile;  // k-steps of two samples each
+            WStep<PO, PI> c0, c1;
+            wstep_load(c0, pa, pb);
+            for (int s = 0; s < steps; s += 2) {
+                pa += 2 * ar, pb += 2 * br;
+                wstep_load(c1, pa, pb);
+                nh_sched_fence();
+                wstep_mfma(c0, acc, bsum);
+                pa += 2 * ar, pb += 2 * br;
+                wstep_load(c0, pa, pb);  // the last one reads one k-step past the stage (slack / other block): unused
+                nh_sched_fence();
+                wstep_mfma(c1, acc, bsum);
+            }
+        }
+    }
+    if (!active) return;
+    float* part = a.partial + (size_t)wg * NH_PART;
+#pragma unroll
+    for (int x = 0; x < PO; ++x)
+#pragma unroll
+        for (int y = 0; y < PI; ++y)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) part[((size_t)(wave * 16 + x * 4 + y) * 16 + c) * 64 + lane] = acc[x][y][c];
+#pragma unroll
+    for (int x = 0; x < PO; ++x) {
+        const float tot = bsum[x] + nh_shfl_xor(bsum[x], 32);
+        if (k == 0) part[65536 + (wave * 4 + x) * 32 + i] = tot;
+    }
+}
+
+NH_KERNEL void NH_LB(256, 1) k_wgrad_lds(WgradArgs a) {
+    NH_DYN_LDS(smem);
+    float* lds = (float*)smem;
+    const unsigned long long t_begin = nh_wall_clock();
+    const int64_t wg = blockIdx.x;
+    int ji = 0;
+    for (int q = 1; q < a.njobs; ++q)
+        if ((int)wg >= a.jobs[q].wg_start) ji = q;
+    const JobDev jb = a.jobs[ji];
+    const int nks = (ji + 1 < a.njobs ? a.jobs[ji + 1].wg_start : a.total_wgs) - jb.wg_start;
+    const int ks = (int)wg - jb.wg_start;
+    const int64_t t0 = a.nt * ks / nks, t1 = a.nt * (ks + 1) / nks;
+    const int lane = nh_lane(), wave = nh_wave_in_block();
+    const bool active = wave < jb.wo * jb.wi;  // idle waves still copy and synchronise
+    const int ow = wave / jb.wi, iw = wave % jb.wi;
+    const int sel = jb.po * 8 + jb.pi;
+    switch (sel) {
+        case 4 * 8 + 4: wgrad_body_lds<4, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 4 * 8 + 2: wgrad_body_lds<4, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 4 * 8 + 1: wgrad_body_lds<4, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 2 * 8 + 4: wgrad_body_lds<2, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 2 * 8 + 2: wgrad_body_lds<2, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 2 * 8 + 1: wgrad_body_lds<2, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 1 * 8 + 4: wgrad_body_lds<1, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 1 * 8 + 2: wgrad_body_lds<1, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        default: wgrad_body_lds<1, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+    }
+    if (lane == 0 && active) {
+        unsigned long long* dbg = (unsigned long long*)(a.partial + (size_t)wg * NH_PART + 65536 + 512) + wave * 4;
+        dbg[0] = t_begin;
+        dbg[1] = nh_wall_clock();
+        dbg[2] = (unsigned long long)ji;
+        dbg[3] = (unsigned long long)ks;
+    }
+}
+
 // fixed-order split-K reduction + scatter into the reference parameter layout
 NH_KERNEL void k_wgrad_reduce(WgradArgs a) {
     const int ji = (int)(blockIdx.x >> 8);
@@ -795,19 +942,39 @@ NH_KERNEL void k_wgrad_reduce(WgradArgs a) {
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
+// NERFHIP_WGRAD selects the weight-gradient kernel: lds (operands staged through LDS by DMA; default) or reg (per-lane
+// global loads into registers).
+int use_lds_wgrad() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("NERFHIP_WGRAD");
+        v = !e ? 1 : (e[0] == 'r' ? 0 : 1);
+    }
+    return v;
+}
+
 constexpr int NH_WGRAD_TARGET_WGS = 1024;
 
 // Split-K allocation: job j gets ks_j workgroups with ks_j proportional to its per-tile cost (every workgroup then
 // runs for about the same time), and sum ks_j == NH_WGRAD_TARGET_WGS exactly (largest-remainder rounding) -- the grid
 // is a whole number of rounds over the 256 CUs (one 4-wave workgroup per CU), with no straggler round.
 void wgrad_schedule(const nerfhip_plan* p, int64_t nt, WgradArgs& w) {
-    int64_t total_cost = 0;
-    for (const NhJob& j : p->jobs) total_cost += j.cost;
     w.njobs = (int)p->jobs.size();
+    int64_t cost[NH_JOBS_DEV];
+    for (int q = 0; q < w.njobs; ++q) cost[q] = use_lds_wgrad() ? p->jobs[q].cost_lds : p->jobs[q].cost;
+    if (const char* e = getenv("NERFHIP_WGRAD_COSTS")) {  // tuning aid: per-job costs measured by scripts/wgrad_timeline.py
+        for (int q = 0; q < w.njobs && *e; ++q) {
+            const long v = strtol(e, (char**)&e, 10);
+            if (v > 0) cost[q] = v;
+            if (*e == ',') ++e;
+        }
+    }
+    int64_t total_cost = 0;
+    for (int q = 0; q < w.njobs; ++q) total_cost += cost[q];
     int64_t ks[NH_JOBS_DEV], rem[NH_JOBS_DEV];
     int64_t used = 0;
     for (int q = 0; q < w.njobs; ++q) {
-        const int64_t num = (int64_t)NH_WGRAD_TARGET_WGS * p->jobs[q].cost;
+        const int64_t num = (int64_t)NH_WGRAD_TARGET_WGS * cost[q];
         ks[q] = num / total_cost;
         rem[q] = num % total_cost;
         if (ks[q] < 1) {
@@ -857,6 +1024,8 @@ void wgrad_schedule(const nerfhip_plan* p, int64_t nt, WgradArgs& w) {
         d.col_count = j.col_count;
         d.bias_off = (int)j.bias_off;
         d.wg_start = start;
+        d.g = NH_WG_STAGE_FLOATS / (32 * (j.a_region_rows + j.b_region_rows));
+        if (d.g < 1) d.g = 1;
         start += (int)ks[q];
     }
     w.total_wgs = start;
@@ -1010,7 +1179,19 @@ int nh_mlp_backward(nerfhip_plan* p, const float* packed, const float* g_out, in
     w.partial = scratch + (size_t)nt * (size_t)p->grad.total_rows * 32;
     w.g_params = g_params;
     w.nt = nt;
-    NH_LAUNCH(k_wgrad, w.total_wgs, 256, 0, stream, w);
+    if (use_lds_wgrad()) {
+        for (int q = 0; q < w.njobs; ++q) {
+            const NhJob& j = p->jobs[q];
+            NH_REQUIRE(j.b_row0 == 0 && 32 * j.a_tiles == j.a_region_rows && 32 * j.b_tiles == j.b_region_rows &&
+                           32 * (j.a_region_rows + j.b_region_rows) <= NH_WG_STAGE_FLOATS,
+                       "wgrad: job %d does not cover whole regions", q);
+        }
+        rc = set_lds_limit(k_wgrad_lds, NH_WG_LDS_BYTES);
+        if (rc) return rc;
+        NH_LAUNCH(k_wgrad_lds, w.total_wgs, 256, NH_WG_LDS_BYTES, stream, w);
+    } else {
+        NH_LAUNCH(k_wgrad, w.total_wgs, 256, 0, stream, w);
+    }
     rc = nh_launch_status("wgrad");
     if (rc) return rc;
     NH_LAUNCH(k_wgrad_reduce, w.njobs * 256, 256, 0, stream, w);

@@ -83,7 +83,8 @@ struct NhJob {
     int col_kind;         // 0: col = col_base + in_row (valid iff < col_base + col_count); 1: xyz slot map; 2: dir slot map
     int col_base, col_count;
     int64_t bias_off;     // flat offset of the bias tensor, or -1 (only one job per layer carries the bias)
-    int cost;             // po*pi
+    int cost;             // relative time per sample tile of one workgroup, register-operand kernel (2*po*pi + 5)
+    int cost_lds;         // the same for the LDS-staged kernel
 };
 
 struct nerfhip_plan {

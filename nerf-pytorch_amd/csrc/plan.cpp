@@ -240,6 +240,13 @@ void add_job(nerfhip_plan* p, const NhRegion& A, int a_tiles, const NhRegion& B,
     // (profiles/r01_wgrad_timeline.txt): t ~= 1.1 us + 0.45 us * po*pi  -- the MFMA work plus a fixed per-tile cost
     // (address arithmetic, load issue, exposed latency) that dominates the small patches.
     j.cost = 2 * j.po * j.pi + 5;
+    // LDS-staged kernel: the MFMA work (0.43 us per tile pair) or the stage copy (128 B per operand row), whichever is
+    // longer, plus a fixed per-tile cost -- provisional until fitted to a timeline
+    {
+        const int rows = A.rows + B.rows;
+        const int mfma = 43 * j.po * j.pi, dma = 9 * rows / 10;
+        j.cost_lds = (mfma > dma ? mfma : dma) + 30;
+    }
     j.r_lo = r_lo;
     j.r_hi = r_hi;
     j.w_off = p->tensors[w_tensor].off;

@@ -6,8 +6,11 @@ sys.path.insert(0, ROOT)
 import nerf_pytorch_amd as N
 dev = torch.device("cuda", 0)
 lib = N._lib.get_lib()
-m = N.FlexibleNeRFModel(8, 256, 4, 10, 4).to(dev)
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 786432
+HID = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+LAY = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+COSTS_OUT = sys.argv[4] if len(sys.argv) > 4 else None
+m = N.FlexibleNeRFModel(LAY, HID, 4, 10, 4).to(dev)
 x = torch.randn(M, 90, device=dev)
 out = torch.empty(M, 4, device=dev)
 stash = torch.empty(lib.plan_stash_bytes(m._plan, M) // 4, device=dev)
@@ -22,7 +25,7 @@ for _ in range(2):
     lib.mlp_bwd(m._plan, packed.data_ptr(), g.data_ptr(), M, stash.data_ptr(), scratch.data_ptr(), sb, gp.data_ptr(), st)
 torch.cuda.synchronize()
 nt = 4 * ((M + 127) // 128)
-rows = 8 * 256 + 256 + 128 + 32
+rows = LAY * HID + HID + HID // 2 + 32
 PART = 65536 + 512 + 64
 part = scratch[nt * rows * 32:]
 nwg = part.numel() // PART
@@ -44,3 +47,14 @@ for j in sorted(jobs):
     v = np.array(jobs[j])
     print("job %2d  wgs %4d  waves/wg %d  start %8.1f..%8.1f us  end %8.1f..%8.1f us  dur mean %8.1f max %8.1f us" % (
         j, len(v), int(v[0, 3]), v[:, 0].min(), v[:, 0].max(), v[:, 1].min(), v[:, 1].max(), (v[:, 1] - v[:, 0]).mean(), (v[:, 1] - v[:, 0]).max()))
+# per-job time per sample tile of one workgroup -> the split-K costs that would equalise workgroup durations
+tau = {}
+for j in sorted(jobs):
+    v = np.array(jobs[j])
+    tau[j] = float((v[:, 1] - v[:, 0]).mean()) * len(v) / nt
+scale = 1000.0 / max(tau.values())
+costs = [max(1, int(round(tau[j] * scale))) for j in sorted(tau)]
+print("us per sample tile per workgroup:", " ".join("%d:%.3f" % (j, tau[j]) for j in sorted(tau)))
+print("fitted costs:", ",".join(str(c) for c in costs))
+if COSTS_OUT:
+    open(COSTS_OUT, "w").write(",".join(str(c) for c in costs))

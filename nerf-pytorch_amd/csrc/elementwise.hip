@@ -139,8 +139,8 @@ NH_KERNEL void k_ndc_rays(NhNdc k, const float* __restrict__ ro, const float* __
 extern "C" int nerfhip_ndc_rays(float near, float cw, float ch, float two_near, float neg_two_near,
                                 const float* rays_o, const float* rays_d, int64_t n, float* out_o, float* out_d,
                                 nerfhip_stream_t stream) {
+    if (n == 0) return NERFHIP_OK;  // empty input: nothing to launch, pointers may be NULL
     NH_REQUIRE(rays_o && rays_d && out_o && out_d && n >= 0, "ndc_rays: bad arguments");
-    if (n == 0) return NERFHIP_OK;
     NhNdc k = {near, cw, ch, two_near, neg_two_near};
     NH_LAUNCH(k_ndc_rays, nh_ceil_div(n, 256), 256, 0, stream, k, rays_o, rays_d, n, out_o, out_d);
     return nh_launch_status("ndc_rays");
@@ -164,8 +164,8 @@ NH_KERNEL void k_pack_rays(const float* __restrict__ ro, const float* __restrict
 
 extern "C" int nerfhip_pack_rays(const float* rays_o, const float* rays_d, const float* viewdir_src, float near,
                                  float far, int64_t n, float* rays_out, nerfhip_stream_t stream) {
+    if (n == 0) return NERFHIP_OK;  // empty input: nothing to launch, pointers may be NULL
     NH_REQUIRE(rays_o && rays_d && rays_out && n >= 0, "pack_rays: bad arguments");
-    if (n == 0) return NERFHIP_OK;
     NH_LAUNCH(k_pack_rays, nh_ceil_div(n, 256), 256, 0, stream, rays_o, rays_d, viewdir_src, near, far, n, rays_out);
     return nh_launch_status("pack_rays");
 }
@@ -193,6 +193,7 @@ NH_KERNEL void k_posenc(const float* __restrict__ x, int64_t m, int d, const flo
 
 extern "C" int nerfhip_positional_encoding(const float* x, int64_t m, int d, const float* freqs, int num_freqs,
                                            int include_input, float* out, nerfhip_stream_t stream) {
+    if (m == 0) return NERFHIP_OK;  // empty input: nothing to launch, pointers may be NULL
     NH_REQUIRE(x && out && m >= 0 && d > 0 && num_freqs >= 0 && (num_freqs == 0 || freqs),
                "positional_encoding: bad arguments");
     include_input = include_input ? 1 : 0;
@@ -230,8 +231,8 @@ NH_KERNEL void k_stratified_z(const float* __restrict__ rays, int stride, int64_
 extern "C" int nerfhip_stratified_z(const float* rays, int ray_stride, int64_t n, const float* t_vals, int nc,
                                     int lindisp, int perturb, const float* t_rand, uint64_t seed, uint64_t ray_offset,
                                     float* z_out, nerfhip_stream_t stream) {
+    if (n == 0) return NERFHIP_OK;  // empty input: nothing to launch, pointers may be NULL
     NH_REQUIRE(rays && t_vals && z_out && ray_stride >= 8 && nc > 0 && n >= 0, "stratified_z: bad arguments");
-    if (n == 0) return NERFHIP_OK;
     NH_LAUNCH(k_stratified_z, nh_ceil_div(n * nc, 256), 256, 0, stream, rays, ray_stride, n, t_vals, nc, lindisp,
               perturb, t_rand, seed, ray_offset, z_out);
     return nh_launch_status("stratified_z");
@@ -260,8 +261,8 @@ NH_KERNEL void k_cumprod_exclusive(const float* __restrict__ x, int64_t rows, in
 }
 
 extern "C" int nerfhip_cumprod_exclusive(const float* x, int64_t rows, int cols, float* out, nerfhip_stream_t stream) {
+    if (rows == 0) return NERFHIP_OK;  // empty input: nothing to launch, pointers may be NULL
     NH_REQUIRE(x && out && rows >= 0 && cols > 0, "cumprod_exclusive: bad arguments");
-    if (rows == 0) return NERFHIP_OK;
     NH_LAUNCH(k_cumprod_exclusive, rows, 64, 0, stream, x, rows, cols, out);
     return nh_launch_status("cumprod_exclusive");
 }
@@ -277,8 +278,8 @@ NH_KERNEL void k_rng_fill(int kind, uint64_t seed, uint32_t stream_id, uint64_t 
 
 extern "C" int nerfhip_rng_fill(int kind, uint64_t seed, uint32_t stream_id, uint64_t first, int64_t n, float* out,
                                 nerfhip_stream_t stream) {
+    if (n == 0) return NERFHIP_OK;  // empty input: nothing to launch, pointers may be NULL
     NH_REQUIRE(out && n >= 0 && (kind == NERFHIP_RNG_UNIFORM || kind == NERFHIP_RNG_NORMAL), "rng_fill: bad arguments");
-    if (n == 0) return NERFHIP_OK;
     NH_LAUNCH(k_rng_fill, nh_ceil_div(n, 256), 256, 0, stream, kind, seed, stream_id, first, n, out);
     return nh_launch_status("rng_fill");
 }
@@ -294,8 +295,8 @@ NH_KERNEL void k_pack_weights(const float* __restrict__ params, const int32_t* _
 
 extern "C" int nerfhip_pack_weights(const float* params, const int32_t* table, int64_t n, float* packed,
                                     nerfhip_stream_t stream) {
+    if (n == 0) return NERFHIP_OK;  // empty input: nothing to launch, pointers may be NULL
     NH_REQUIRE(params && table && packed && n >= 0, "pack_weights: bad arguments");
-    if (n == 0) return NERFHIP_OK;
     NH_LAUNCH(k_pack_weights, nh_ceil_div(n, 256), 256, 0, stream, params, table, n, packed);
     return nh_launch_status("pack_weights");
 }
@@ -372,8 +373,8 @@ NH_KERNEL void k_adam(float* __restrict__ p, const float* __restrict__ g, float*
 extern "C" int nerfhip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                                  float lr, float beta1, float beta2, float eps, int64_t step, float grad_scale,
                                  nerfhip_stream_t stream) {
+    if (n == 0) return NERFHIP_OK;  // empty input: nothing to launch, pointers may be NULL
     NH_REQUIRE(params && grads && exp_avg && exp_avg_sq && n >= 0 && step >= 1, "adam_step: bad arguments");
-    if (n == 0) return NERFHIP_OK;
     double bc1 = 1.0 - pow((double)beta1, (double)step);
     double bc2 = 1.0 - pow((double)beta2, (double)step);
     float step_size = (float)((double)lr / bc1);

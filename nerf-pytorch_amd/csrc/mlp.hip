@@ -724,6 +724,7 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
 
 NH_KERNEL void NH_LB(256, 1) k_wgrad(WgradArgs a) {
     const unsigned long long t_begin = nh_wall_clock();
+    const unsigned long long c_begin = nh_core_clock();
     const int64_t wg = blockIdx.x;
     int ji = 0;
     for (int q = 1; q < a.njobs; ++q)
@@ -749,11 +750,13 @@ NH_KERNEL void NH_LB(256, 1) k_wgrad(WgradArgs a) {
         default: wgrad_body<1, 1, 8>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
     }
     if (lane == 0) {  // timeline slot (last 64 floats of this workgroup's partial block): begin, end, job, K-slice
-        unsigned long long* dbg = (unsigned long long*)(a.partial + (size_t)wg * NH_PART + 65536 + 512) + wave * 4;
+        unsigned long long* dbg = (unsigned long long*)(a.partial + (size_t)wg * NH_PART + 65536 + 512) + wave * 8;
         dbg[0] = t_begin;
         dbg[1] = nh_wall_clock();
         dbg[2] = (unsigned long long)ji;
         dbg[3] = (unsigned long long)ks;
+        dbg[4] = c_begin;
+        dbg[5] = nh_core_clock();
     }
 }
 
@@ -784,16 +787,32 @@ NH_DEVICE void wstep_mfma(const WStep<PO, PI>& o, f32x16 (&acc)[PO][PI], float (
     }
 }
 
-NH_DEVICE void wgrad_stage_dma(const float* ga, const float* gb, int a_fl, int b_fl, int ntile, int g, float* buf, int wave,
-                               int lane) {
-    // block A: ntile * a_fl floats -> buf[0 ..); block B: ntile * b_fl floats -> buf[g * a_fl ..)
-    const NhDmaSrc sa = nh_dma_src(ga, (unsigned)(ntile * a_fl * 4));
-    const NhDmaSrc sb = nh_dma_src(gb, (unsigned)(ntile * b_fl * 4));
-    const int pa = ntile * a_fl / 256, pb = ntile * b_fl / 256;
-    for (int q = wave; q < pa; q += 4) nh_dma16(sa, lane * 16, q * 1024, buf + q * 256);
-    float* bb = buf + g * a_fl;
-    for (int q = wave; q < pb; q += 4) nh_dma16(sb, lane * 16, q * 1024, bb + q * 256);
-}
+// One stage copy, cut into 1-KiB pieces (one DMA instruction each): block A (ntile * a_fl floats) -> buf[0 ..), block B
+// (ntile * b_fl floats) -> buf[g * a_fl ..).  Wave w issues pieces w, w+4, ...; `issue(n)` emits the next n of them, so
+// that the copy of stage n+1 can be spread over the MFMA groups of stage n instead of stalling the matrix pipe.
+struct WStageDma {
+    NhDmaSrc sa, sb;
+    float* buf;
+    int pa, ptot, boff, q, lane16;
+    NH_MEMBER void init(const float* ga, const float* gb, int a_fl, int b_fl, int ntile, int g, float* dst, int wave, int lane) {
+        sa = nh_dma_src(ga, (unsigned)(ntile * a_fl * 4));
+        sb = nh_dma_src(gb, (unsigned)(ntile * b_fl * 4));
+        buf = dst;
+        pa = ntile * a_fl / 256;
+        ptot = pa + ntile * b_fl / 256;
+        boff = g * a_fl - pa * 256;  // piece q >= pa lands at buf + g*a_fl + (q - pa)*256
+        q = wave;
+        lane16 = lane * 16;
+    }
+    NH_MEMBER void issue(int n) {
+        for (int c = 0; c < n && q < ptot; ++c, q += 4) {
+            if (q < pa)
+                nh_dma16(sa, lane16, q * 1024, buf + q * 256);
+            else
+                nh_dma16(sb, lane16, (q - pa) * 1024, buf + boff + q * 256);
+        }
+    }
+};
 
 template <int PO, int PI>
 NH_DEVICE void wgrad_body_lds(const WgradArgs& a, const JobDev& jb, int64_t t0, int64_t t1, int ow, int iw, int wave,
@@ -813,32 +832,38 @@ NH_DEVICE void wgrad_body_lds(const WgradArgs& a, const JobDev& jb, int64_t t0, 
     const int a_fl = 32 * ar, b_fl = 32 * br;
     const float* A0 = a.grad + (size_t)32 * (size_t)a.nt * (size_t)jb.a_prefix;
     const float* B0 = a.stash + (size_t)32 * (size_t)a.nt * (size_t)jb.b_prefix;
-    const int64_t nstage = (t1 - t0 + g - 1) / g;
+    const int nstage = (int)((t1 - t0 + g - 1) / g);
+    const float* ga = A0 + (size_t)t0 * a_fl;  // stage n+1's blocks (running pointers: one 64-bit add per stage)
+    const float* gb = B0 + (size_t)t0 * b_fl;
+    int left = (int)(t1 - t0);                 // tiles not yet requested
+    WStageDma dma;
+    dma.ptot = 0;
     if (nstage > 0) {
-        const int nt0 = (int)(t1 - t0 < g ? t1 - t0 : g);
-        wgrad_stage_dma(A0 + (size_t)t0 * a_fl, B0 + (size_t)t0 * b_fl, a_fl, b_fl, nt0, g, lds, wave, lane);
+        const int nt0 = left < g ? left : g;
+        dma.init(ga, gb, a_fl, b_fl, nt0, g, lds, wave, lane);
+        dma.issue(1 << 20);
+        ga += (size_t)nt0 * a_fl, gb += (size_t)nt0 * b_fl, left -= nt0;
     }
-    for (int64_t n = 0; n < nstage; ++n) {
-        const int64_t t = t0 + n * g;
-        const int ntile = (int)(t1 - t < g ? t1 - t : g);
+    int ntile = (int)(t1 - t0) < g ? (int)(t1 - t0) : g;  // tiles of the stage being multiplied
+    for (int n = 0; n < nstage; ++n) {
+        const float* buf = lds + (n & 1) * NH_WG_STAGE_FLOATS;
+        const float* pa = buf + k * ar + 32 * ow * PO + i;
+        const float* pb = buf + g * a_fl + k * br + 32 * iw * PI + i;
         nh_wait_vmem();
         nh_block_sync();  // stage n has landed for every wave; everybody is done reading the other buffer
-        if (n + 1 < nstage) {
-            const int64_t tn = t + g;
-            const int ntn = (int)(t1 - tn < g ? t1 - tn : g);
-            wgrad_stage_dma(A0 + (size_t)tn * a_fl, B0 + (size_t)tn * b_fl, a_fl, b_fl, ntn, g,
-                            lds + ((n + 1) & 1) * NH_WG_STAGE_FLOATS, wave, lane);
-        }
+        WStep<PO, PI> c0, c1;
+        if (active) wstep_load(c0, pa, pb);
+        nh_sched_fence();  // first operand reads leave before the scalar set-up of the next copy
+        const int ntn = left < g ? left : g;
+        dma.ptot = 0;
+        if (ntn > 0) dma.init(ga, gb, a_fl, b_fl, ntn, g, lds + ((n + 1) & 1) * NH_WG_STAGE_FLOATS, wave, lane);
+        ga += (size_t)ntn * a_fl, gb += (size_t)ntn * b_fl, left -= ntn;
         if (active) {
-            const float* buf = lds + (n & 1) * NH_WG_STAGE_FLOATS;
-            const float* pa = buf + k * ar + 32 * ow * PO + i;
-            const float* pb = buf + g * a_fl + k * br + 32 * iw * PI + i;
             const int steps = 16 * ntile;  // k-steps of two samples each
-            WStep<PO, PI> c0, c1;
-            wstep_load(c0, pa, pb);
             for (int s = 0; s < steps; s += 2) {
                 pa += 2 * ar, pb += 2 * br;
                 wstep_load(c1, pa, pb);
+                dma.issue(2);  // the next stage streams in underneath the MFMAs (at most 16 pieces per wave and stage)
                 nh_sched_fence();
                 wstep_mfma(c0, acc, bsum);
                 pa += 2 * ar, pb += 2 * br;
@@ -847,6 +872,8 @@ NH_DEVICE void wgrad_body_lds(const WgradArgs& a, const JobDev& jb, int64_t t0, 
                 wstep_mfma(c1, acc, bsum);
             }
         }
+        dma.issue(1 << 20);  // idle waves, and whatever a short stage left over
+        ntile = ntn;
     }
     if (!active) return;
     float* part = a.partial + (size_t)wg * NH_PART;
@@ -867,6 +894,7 @@ NH_KERNEL void NH_LB(256, 1) k_wgrad_lds(WgradArgs a) {
     NH_DYN_LDS(smem);
     float* lds = (float*)smem;
     const unsigned long long t_begin = nh_wall_clock();
+    const unsigned long long c_begin = nh_core_clock();
     const int64_t wg = blockIdx.x;
     int ji = 0;
     for (int q = 1; q < a.njobs; ++q)
@@ -890,12 +918,14 @@ NH_KERNEL void NH_LB(256, 1) k_wgrad_lds(WgradArgs a) {
         case 1 * 8 + 2: wgrad_body_lds<1, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
         default: wgrad_body_lds<1, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
     }
-    if (lane == 0 && active) {
-        unsigned long long* dbg = (unsigned long long*)(a.partial + (size_t)wg * NH_PART + 65536 + 512) + wave * 4;
+    if (lane == 0 && active) {  // timeline record (8 x u64 per wave): wall begin/end, job, K-slice, core-clock begin/end
+        unsigned long long* dbg = (unsigned long long*)(a.partial + (size_t)wg * NH_PART + 65536 + 512) + wave * 8;
         dbg[0] = t_begin;
         dbg[1] = nh_wall_clock();
         dbg[2] = (unsigned long long)ji;
         dbg[3] = (unsigned long long)ks;
+        dbg[4] = c_begin;
+        dbg[5] = nh_core_clock();
     }
 }
 

@@ -18,6 +18,7 @@
 #define NH_KERNEL __global__
 #define NH_LB(threads, waves_per_simd) __launch_bounds__(threads, waves_per_simd)
 #define NH_DEVICE __device__ __forceinline__
+#define NH_MEMBER __device__ __forceinline__
 #define NH_SHARED __shared__
 #define NH_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) char name[]
 
@@ -72,6 +73,7 @@ NH_DEVICE void nh_wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 NH_DEVICE void nh_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 NH_DEVICE void nh_sincos(float x, float* s, float* c) { sincosf(x, s, c); }
 NH_DEVICE unsigned long long nh_wall_clock() { return wall_clock64(); }  // constant 100 MHz
+NH_DEVICE unsigned long long nh_core_clock() { return (unsigned long long)clock64(); }  // shader-clock cycles (s_memtime)
 #endif  // NERFHIP_EMU
 
 // ---- helpers shared by both builds -------------------------------------------------------------------------------

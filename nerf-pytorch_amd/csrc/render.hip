@@ -103,8 +103,8 @@ extern "C" int nerfhip_volume_render_fwd(const float* raw, const float* z, const
                                          int s, float noise_std, const float* noise, uint64_t seed, uint32_t rng_stream,
                                          uint64_t ray_offset, int white_background, float* rgb, float* disp, float* acc,
                                          float* weights, float* depth, nerfhip_stream_t stream) {
+    if (n == 0) return NERFHIP_OK;  // empty input: nothing to launch, pointers may be NULL
     NH_REQUIRE(raw && z && rd && rd_stride >= 3 && n >= 0 && s > 0, "volume_render_fwd: bad arguments");
-    if (n == 0) return NERFHIP_OK;
     NH_LAUNCH(k_volume_render_fwd, n, 64, 0, stream, raw, z, rd, rd_stride, n, s, noise_std, noise, seed, rng_stream,
               ray_offset, white_background, rgb, disp, acc, weights, depth);
     return nh_launch_status("volume_render_fwd");
@@ -201,9 +201,9 @@ extern "C" int nerfhip_volume_render_bwd(const float* raw, const float* z, const
                                          uint64_t ray_offset, int white_background, const float* g_rgb,
                                          const float* g_depth, const float* g_acc, const float* g_weights, float* g_raw,
                                          nerfhip_stream_t stream) {
+    if (n == 0) return NERFHIP_OK;  // empty input: nothing to launch, pointers may be NULL
     NH_REQUIRE(raw && z && rd && g_raw && rd_stride >= 3 && n >= 0 && s > 0, "volume_render_bwd: bad arguments");
     NH_REQUIRE(s <= 8192, "volume_render_bwd: at most 8192 samples per ray");
-    if (n == 0) return NERFHIP_OK;
     NH_LAUNCH(k_volume_render_bwd, n, 64, (size_t)s * sizeof(float), stream, raw, z, rd, rd_stride, n, s, noise_std,
               noise, seed, rng_stream, ray_offset, white_background, g_rgb, g_depth, g_acc, g_weights, g_raw);
     return nh_launch_status("volume_render_bwd");

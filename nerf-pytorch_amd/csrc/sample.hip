@@ -112,10 +112,10 @@ NH_KERNEL void k_sample_pdf(int mode, const float* __restrict__ bins_in, const f
 extern "C" int nerfhip_sample_pdf(const float* bins, const float* weights, int64_t n, int nbins, const float* u, int det,
                                   const float* u_det, int nf, uint64_t seed, uint64_t ray_offset, float* samples,
                                   int64_t* inds, float* cdf, nerfhip_stream_t stream) {
+    if (n == 0) return NERFHIP_OK;  // empty input: nothing to launch, pointers may be NULL
     NH_REQUIRE(bins && weights && n >= 0 && nbins >= 2 && nf > 0, "sample_pdf: bad arguments");
     NH_REQUIRE(nbins <= 4096, "sample_pdf: at most 4096 bins");
     NH_REQUIRE(u || !det || u_det, "sample_pdf: det=1 needs u_det (linspace(0,1,nf))");
-    if (n == 0) return NERFHIP_OK;
     size_t lds = (size_t)2 * nbins * sizeof(float);
     NH_LAUNCH(k_sample_pdf, n, 64, lds, stream, 0, bins, weights, n, nbins, u, det, u_det, nf, seed, ray_offset, samples,
               inds, cdf, (float*)nullptr, 0);
@@ -125,10 +125,10 @@ extern "C" int nerfhip_sample_pdf(const float* bins, const float* weights, int64
 extern "C" int nerfhip_hierarchical_z(const float* z_coarse, const float* weights, int64_t n, int nc, const float* u,
                                       int det, const float* u_det, int nf, uint64_t seed, uint64_t ray_offset,
                                       float* z_samples, float* z_fine, nerfhip_stream_t stream) {
+    if (n == 0) return NERFHIP_OK;  // empty input: nothing to launch, pointers may be NULL
     NH_REQUIRE(z_coarse && weights && z_fine && n >= 0 && nc >= 3 && nf > 0, "hierarchical_z: bad arguments");
     NH_REQUIRE(nc + nf <= 8192, "hierarchical_z: at most 8192 samples per ray");
     NH_REQUIRE(u || !det || u_det, "hierarchical_z: det=1 needs u_det (linspace(0,1,nf))");
-    if (n == 0) return NERFHIP_OK;
     int sortp = 1;
     while (sortp < nc + nf) sortp <<= 1;
     size_t lds = (size_t)(2 * (nc - 1) + sortp) * sizeof(float);

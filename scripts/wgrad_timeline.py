@@ -29,7 +29,7 @@ rows = LAY * HID + HID + HID // 2 + 32
 PART = 65536 + 512 + 64
 part = scratch[nt * rows * 32:]
 nwg = part.numel() // PART
-part = part[:nwg * PART].view(nwg, PART)[:, 65536 + 512:65536 + 512 + 32].contiguous().cpu().numpy().view(np.uint64).reshape(nwg, 4, 4)
+part = part[:nwg * PART].view(nwg, PART)[:, 65536 + 512:65536 + 512 + 64].contiguous().cpu().numpy().view(np.uint64).reshape(nwg, 4, 8)
 t0 = part[:, :, 0][part[:, :, 0] > 0].min()
 jobs = {}
 for w in range(nwg):
@@ -42,7 +42,10 @@ for w in range(nwg):
     j = int(part[w, act, 2][0])
     jobs.setdefault(j, []).append((b, e, per_wave.mean(), int(act.sum())))
 end = max(e for v in jobs.values() for (_, e, _, _) in v)
-print(json.dumps(dict(nwg=nwg, makespan_us=end)))
+ok = part[:, :, 1] > part[:, :, 0]
+ghz = ((part[:, :, 5] - part[:, :, 4])[ok] / ((part[:, :, 1] - part[:, :, 0])[ok] * 10.0))   # core cycles per ns
+print(json.dumps(dict(nwg=nwg, makespan_us=end, core_clock_ghz_mean=float(ghz.mean()), core_clock_ghz_min=float(ghz.min()),
+                      core_clock_ghz_max=float(ghz.max()))))
 for j in sorted(jobs):
     v = np.array(jobs[j])
     print("job %2d  wgs %4d  waves/wg %d  start %8.1f..%8.1f us  end %8.1f..%8.1f us  dur mean %8.1f max %8.1f us" % (

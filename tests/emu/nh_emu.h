@@ -49,6 +49,7 @@ void launch(Dim3 grid, Dim3 block, size_t smem, const std::function<void()>& bod
 #define NH_KERNEL
 #define NH_LB(threads, waves_per_simd)
 #define NH_DEVICE static inline
+#define NH_MEMBER inline
 #define NH_SHARED static
 #define NH_DYN_LDS(name) char* name = emu::g_dyn_smem
 
@@ -136,6 +137,7 @@ NH_DEVICE void nh_dma16(const NhDmaSrc& s, int voff, int soff, float* lds_wave_b
 NH_DEVICE void nh_wait_vmem() {}
 NH_DEVICE void nh_sched_fence() {}
 NH_DEVICE unsigned long long nh_wall_clock() { return 0ull; }
+NH_DEVICE unsigned long long nh_core_clock() { return 0ull; }
 NH_DEVICE void nh_sincos(float x, float* s, float* c) {
     *s = sinf(x);
     *c = cosf(x);

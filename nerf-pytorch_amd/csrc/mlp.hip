@@ -598,15 +598,17 @@ struct JobDev {
     int col_kind, col_base, col_count;
     int bias_off;
     int wg_start;
-    int g;  // LDS-staged variant: 32-sample tiles per stage
+    int g;  // 32-sample tiles per LDS stage
 };
 constexpr int NH_JOBS_DEV = 32;
-// LDS-staged weight-gradient kernel: two stages of at most NH_WG_STAGE_FLOATS floats (+ slack for the operand prefetch
-// that runs one k-step past the end of a stage)
+// weight-gradient kernel: 8 waves per workgroup (two per SIMD); two LDS stages of at most NH_WG_STAGE_FLOATS floats
+// (+ slack for the operand prefetch that runs one k-step past the end of a stage)
+constexpr int NH_WG_WAVES = 8;
 constexpr int NH_WG_STAGE_FLOATS = 16384;
 constexpr int NH_WG_LDS_BYTES = 2 * NH_WG_STAGE_FLOATS * 4 + 4096;
-// floats of split-K partial per workgroup: 4 waves x 256 regs x 64 lanes, + 512 bias partials, + 64 for the timeline
-constexpr int NH_PART = 65536 + 512 + 64;
+// floats of split-K partial per workgroup: 64 output tiles x 16 regs x 64 lanes, + 512 bias partials, + 128 for the
+// timeline records of the 8 waves
+constexpr int NH_PART = 65536 + 512 + 128;
 
 struct WgradArgs {
     const float* stash;
@@ -620,152 +622,20 @@ struct WgradArgs {
     short dcol[2][NH_KRD];
 };
 
-// MFMA operands of one half tile (16 samples): k-step e uses sample 16*half + 2e + k of the tile (k = lane >> 5)
-template <int PO, int PI>
-struct WOperands {
-    float A[PO][8];
-    float B[PI][8];
-};
-
-template <int PO, int PI>
-NH_DEVICE void wgrad_load(WOperands<PO, PI>& op, const float* __restrict__ Ab, const float* __restrict__ Bb, size_t a_rows,
-                          size_t b_rows, int half, int k) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const size_t s = (size_t)(16 * half + 2 * e + k);
-#pragma unroll
-        for (int x = 0; x < PO; ++x) op.A[x][e] = Ab[s * a_rows + 32 * x];
-#pragma unroll
-        for (int y = 0; y < PI; ++y) op.B[y][e] = Bb[s * b_rows + 32 * y];
-    }
-}
-
-template <int PO, int PI>
-NH_DEVICE void wgrad_compute(const WOperands<PO, PI>& op, f32x16 (&acc)[PO][PI], float (&bsum)[PO]) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-#pragma unroll
-        for (int x = 0; x < PO; ++x) {
-            bsum[x] += op.A[x][e];
-#pragma unroll
-            for (int y = 0; y < PI; ++y) acc[x][y] = nh_mfma32(op.A[x][e], op.B[y][e], acc[x][y]);
-        }
-    }
-}
-
-// Half-tile steps are software pipelined through a ring of DEPTH operand sets: small patches do few MFMAs per step, so
-// they need more loads in flight to cover HBM latency (a 1x1 patch computes 512 cycles per step, a 4x4 patch 8192).
-template <int PO, int PI, int DEPTH>
-NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int64_t t1, int ow, int iw, int wave,
-                          int lane, int64_t wg) {
-    const int i = lane & 31, k = lane >> 5;
-    f32x16 acc[PO][PI];
-    float bsum[PO];
-#pragma unroll
-    for (int x = 0; x < PO; ++x) {
-        bsum[x] = 0.0f;
-#pragma unroll
-        for (int y = 0; y < PI; ++y)
-#pragma unroll
-            for (int c = 0; c < 16; ++c) acc[x][y][c] = 0.0f;
-    }
-    const size_t ar = (size_t)jb.a_rows, br = (size_t)jb.b_rows;
-    const size_t a_tile_stride = ar * 32, b_tile_stride = br * 32;
-    const float* A0 = a.grad + (size_t)32 * (size_t)a.nt * (size_t)jb.a_prefix + (size_t)(32 * ow * PO + i);
-    const float* B0 = a.stash + (size_t)32 * (size_t)a.nt * (size_t)jb.b_prefix + (size_t)(jb.b_row0 + 32 * iw * PI + i);
-    if constexpr (DEPTH == 2) {
-        // large patch: plain double buffering at half-tile granularity (8192 MFMA cycles per step cover HBM latency)
-        WOperands<PO, PI> op0, op1;
-        if (t0 < t1) wgrad_load(op0, A0 + t0 * a_tile_stride, B0 + t0 * b_tile_stride, ar, br, 0, k);
-        for (int64_t t = t0; t < t1; ++t) {
-            wgrad_load(op1, A0 + t * a_tile_stride, B0 + t * b_tile_stride, ar, br, 1, k);
-            nh_sched_fence();
-            wgrad_compute(op0, acc, bsum);
-            if (t + 1 < t1) wgrad_load(op0, A0 + (t + 1) * a_tile_stride, B0 + (t + 1) * b_tile_stride, ar, br, 0, k);
-            nh_sched_fence();
-            wgrad_compute(op1, acc, bsum);
-        }
-    } else {
-    WOperands<PO, PI> ring[DEPTH];
-    const int64_t s0 = 2 * t0, s1 = 2 * t1;  // half-tile steps: step s = (tile s >> 1, half s & 1)
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
-        const int64_t s = s0 + d;
-        if (s < s1) wgrad_load(ring[d], A0 + (s >> 1) * a_tile_stride, B0 + (s >> 1) * b_tile_stride, ar, br, (int)(s & 1), k);
-    }
-    for (int64_t sb = s0; sb < s1; sb += DEPTH) {
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-            const int64_t s = sb + d;
-            if (s < s1) {
-                nh_sched_fence();
-                wgrad_compute(ring[d], acc, bsum);
-                nh_sched_fence();  // refill this slot only after its MFMAs are issued (no renaming into fresh registers)
-                const int64_t sn = s + DEPTH;
-                if (sn < s1)
-                    wgrad_load(ring[d], A0 + (sn >> 1) * a_tile_stride, B0 + (sn >> 1) * b_tile_stride, ar, br, (int)(sn & 1), k);
-            }
-        }
-    }
-    }
-    float* part = a.partial + (size_t)wg * NH_PART;
-#pragma unroll
-    for (int x = 0; x < PO; ++x)
-#pragma unroll
-        for (int y = 0; y < PI; ++y)
-#pragma unroll
-            for (int c = 0; c < 16; ++c) part[((size_t)(wave * 16 + x * 4 + y) * 16 + c) * 64 + lane] = acc[x][y][c];
-#pragma unroll
-    for (int x = 0; x < PO; ++x) {
-        const float tot = bsum[x] + nh_shfl_xor(bsum[x], 32);
-        if (k == 0) part[65536 + (wave * 4 + x) * 32 + i] = tot;
-    }
-}
-
-NH_KERNEL void NH_LB(256, 1) k_wgrad(WgradArgs a) {
-    const unsigned long long t_begin = nh_wall_clock();
-    const unsigned long long c_begin = nh_core_clock();
-    const int64_t wg = blockIdx.x;
-    int ji = 0;
-    for (int q = 1; q < a.njobs; ++q)
-        if ((int)wg >= a.jobs[q].wg_start) ji = q;
-    const JobDev jb = a.jobs[ji];
-    const int nks = (ji + 1 < a.njobs ? a.jobs[ji + 1].wg_start : a.total_wgs) - jb.wg_start;
-    const int ks = (int)wg - jb.wg_start;
-    const int64_t t0 = a.nt * ks / nks, t1 = a.nt * (ks + 1) / nks;
-    const int lane = nh_lane(), wave = nh_wave_in_block();
-    const bool active = wave < jb.wo * jb.wi;
-    const int ow = wave / jb.wi, iw = wave % jb.wi;
-    if (!active) return;  // no workgroup-level synchronisation in this kernel
-    const int sel = jb.po * 8 + jb.pi;
-    switch (sel) {
-        case 4 * 8 + 4: wgrad_body<4, 4, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
-        case 4 * 8 + 2: wgrad_body<4, 2, 3>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
-        case 4 * 8 + 1: wgrad_body<4, 1, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
-        case 2 * 8 + 4: wgrad_body<2, 4, 3>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
-        case 2 * 8 + 2: wgrad_body<2, 2, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
-        case 2 * 8 + 1: wgrad_body<2, 1, 6>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
-        case 1 * 8 + 4: wgrad_body<1, 4, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
-        case 1 * 8 + 2: wgrad_body<1, 2, 6>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
-        default: wgrad_body<1, 1, 8>(a, jb, t0, t1, ow, iw, wave, lane, wg); break;
-    }
-    if (lane == 0) {  // timeline slot (last 64 floats of this workgroup's partial block): begin, end, job, K-slice
-        unsigned long long* dbg = (unsigned long long*)(a.partial + (size_t)wg * NH_PART + 65536 + 512) + wave * 8;
-        dbg[0] = t_begin;
-        dbg[1] = nh_wall_clock();
-        dbg[2] = (unsigned long long)ji;
-        dbg[3] = (unsigned long long)ks;
-        dbg[4] = c_begin;
-        dbg[5] = nh_core_clock();
-    }
-}
-
-// ---- LDS-staged variant ------------------------------------------------------------------------------------------------
+// The weight-gradient GEMMs, dW[out, in] = sum over samples of dP[out][sample] * act[in][sample], as a split-K MFMA
+// kernel over the sample-major images the forward / data-gradient kernels wrote.
+//
+// Measured on MI355X (scripts/mfma_rate.hip, profiles/r01_mfma_issue_cost.txt): with ONE wave per SIMD every
+// instruction of the wave serialises with its MFMAs (v_add 4 cycles, ds_read ~12 per dword, an LDS-DMA ~14, a 64-cycle
+// MFMA is not overlapped by anything of the same wave), which capped the previous 4-wave kernel at 82 % of the matrix
+// pipe.  Here a workgroup is 8 waves = TWO per SIMD, each owning a patch of at most 8 accumulator tiles (128 AGPRs),
+// so one wave's operand reads, bias sums and copy instructions issue underneath the other wave's MFMAs.
+//
 // A workgroup's operands for a run of G sample tiles are two CONTIGUOUS blocks of HBM ([G*32 samples][a_rows] of the
 // gradient scratch, [G*32 samples][b_rows] of the stash: every job covers whole regions).  They are copied once per
-// workgroup by LDS-DMA (1 KiB per instruction, no VGPRs, 16 instructions per wave for a 256x256 job instead of 128
-// per-lane dword loads), double buffered: stage n+1 streams in while stage n is multiplied.  Lane (i, k) then reads
-// its MFMA operands A[i][k] = lds[(2e + k) * rows + 32 * tile + i] with ds_read_b32, one k-step ahead of the MFMAs.
+// workgroup by LDS-DMA (1 KiB per instruction, no VGPRs), double buffered: stage n+1 streams in while stage n is
+// multiplied.  Lane (i, k) reads its MFMA operands A[i][k] = lds[(2e + k) * rows + 32 * tile + i] with ds_read_b32,
+// one k-step ahead of the MFMAs.
 template <int PO, int PI>
 struct WStep {
     float A[PO], B[PI];
@@ -788,8 +658,8 @@ NH_DEVICE void wstep_mfma(const WStep<PO, PI>& o, f32x16 (&acc)[PO][PI], float (
 }
 
 // One stage copy, cut into 1-KiB pieces (one DMA instruction each): block A (ntile * a_fl floats) -> buf[0 ..), block B
-// (ntile * b_fl floats) -> buf[g * a_fl ..).  Wave w issues pieces w, w+4, ...; `issue(n)` emits the next n of them, so
-// that the copy of stage n+1 can be spread over the MFMA groups of stage n instead of stalling the matrix pipe.
+// (ntile * b_fl floats) -> buf[g * a_fl ..).  Wave w issues pieces w, w+8, ...; `issue(n)` emits the next n of them, so
+// that the copy of stage n+1 is spread over the MFMA groups of stage n.
 struct WStageDma {
     NhDmaSrc sa, sb;
     float* buf;
@@ -805,7 +675,7 @@ struct WStageDma {
         lane16 = lane * 16;
     }
     NH_MEMBER void issue(int n) {
-        for (int c = 0; c < n && q < ptot; ++c, q += 4) {
+        for (int c = 0; c < n && q < ptot; ++c, q += NH_WG_WAVES) {
             if (q < pa)
                 nh_dma16(sa, lane16, q * 1024, buf + q * 256);
             else
@@ -815,8 +685,8 @@ struct WStageDma {
 };
 
 template <int PO, int PI>
-NH_DEVICE void wgrad_body_lds(const WgradArgs& a, const JobDev& jb, int64_t t0, int64_t t1, int ow, int iw, int wave,
-                              int lane, int64_t wg, bool active, float* lds) {
+NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int64_t t1, int ow, int iw, int wave, int lane,
+                          int64_t wg, bool active, float* lds) {
     const int i = lane & 31, k = lane >> 5;
     f32x16 acc[PO][PI];
     float bsum[PO];
@@ -863,7 +733,7 @@ NH_DEVICE void wgrad_body_lds(const WgradArgs& a, const JobDev& jb, int64_t t0, 
             for (int s = 0; s < steps; s += 2) {
                 pa += 2 * ar, pb += 2 * br;
                 wstep_load(c1, pa, pb);
-                dma.issue(2);  // the next stage streams in underneath the MFMAs (at most 16 pieces per wave and stage)
+                dma.issue(1);  // the next stage streams in underneath the MFMAs (at most 8 pieces per wave and stage)
                 nh_sched_fence();
                 wstep_mfma(c0, acc, bsum);
                 pa += 2 * ar, pb += 2 * br;
@@ -876,21 +746,28 @@ NH_DEVICE void wgrad_body_lds(const WgradArgs& a, const JobDev& jb, int64_t t0, 
         ntile = ntn;
     }
     if (!active) return;
+    // split-K partial of this workgroup: output tile (a_t, b_t) of the job at [(a_t * b_tiles + b_t)][16 regs][64 lanes]
     float* part = a.partial + (size_t)wg * NH_PART;
 #pragma unroll
-    for (int x = 0; x < PO; ++x)
-#pragma unroll
-        for (int y = 0; y < PI; ++y)
-#pragma unroll
-            for (int c = 0; c < 16; ++c) part[((size_t)(wave * 16 + x * 4 + y) * 16 + c) * 64 + lane] = acc[x][y][c];
-#pragma unroll
     for (int x = 0; x < PO; ++x) {
-        const float tot = bsum[x] + nh_shfl_xor(bsum[x], 32);
-        if (k == 0) part[65536 + (wave * 4 + x) * 32 + i] = tot;
+        const int a_t = ow * PO + x;
+        if (a_t >= jb.a_tiles) continue;
+#pragma unroll
+        for (int y = 0; y < PI; ++y) {
+            const int b_t = iw * PI + y;
+            if (b_t >= jb.b_tiles) continue;
+            float* dst = part + (size_t)(a_t * jb.b_tiles + b_t) * 1024 + lane;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) dst[c * 64] = acc[x][y][c];
+        }
+        if (iw == 0) {  // bias gradient = row sums of A over this workgroup's samples
+            const float tot = bsum[x] + nh_shfl_xor(bsum[x], 32);
+            if (k == 0) part[65536 + a_t * 32 + i] = tot;
+        }
     }
 }
 
-NH_KERNEL void NH_LB(256, 1) k_wgrad_lds(WgradArgs a) {
+NH_KERNEL void NH_LB(64 * NH_WG_WAVES, 2) k_wgrad(WgradArgs a) {
     NH_DYN_LDS(smem);
     float* lds = (float*)smem;
     const unsigned long long t_begin = nh_wall_clock();
@@ -908,15 +785,14 @@ NH_KERNEL void NH_LB(256, 1) k_wgrad_lds(WgradArgs a) {
     const int ow = wave / jb.wi, iw = wave % jb.wi;
     const int sel = jb.po * 8 + jb.pi;
     switch (sel) {
-        case 4 * 8 + 4: wgrad_body_lds<4, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
-        case 4 * 8 + 2: wgrad_body_lds<4, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
-        case 4 * 8 + 1: wgrad_body_lds<4, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
-        case 2 * 8 + 4: wgrad_body_lds<2, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
-        case 2 * 8 + 2: wgrad_body_lds<2, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
-        case 2 * 8 + 1: wgrad_body_lds<2, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
-        case 1 * 8 + 4: wgrad_body_lds<1, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
-        case 1 * 8 + 2: wgrad_body_lds<1, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
-        default: wgrad_body_lds<1, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 4 * 8 + 2: wgrad_body<4, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 2 * 8 + 4: wgrad_body<2, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 4 * 8 + 1: wgrad_body<4, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 1 * 8 + 4: wgrad_body<1, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 2 * 8 + 2: wgrad_body<2, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 2 * 8 + 1: wgrad_body<2, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 1 * 8 + 2: wgrad_body<1, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        default: wgrad_body<1, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
     }
     if (lane == 0 && active) {  // timeline record (8 x u64 per wave): wall begin/end, job, K-slice, core-clock begin/end
         unsigned long long* dbg = (unsigned long long*)(a.partial + (size_t)wg * NH_PART + 65536 + 512) + wave * 8;
@@ -934,12 +810,9 @@ NH_KERNEL void k_wgrad_reduce(WgradArgs a) {
     const int ji = (int)(blockIdx.x >> 8);
     const JobDev jb = a.jobs[ji];
     const int local = (int)((blockIdx.x & 255u) * 256u + threadIdx.x);
-    const int lane = local & 63, c = (local >> 6) & 15, ab = (local >> 10) & 15, wave = local >> 14;
-    const int x = ab >> 2, y = ab & 3;
-    if (wave >= jb.wo * jb.wi || x >= jb.po || y >= jb.pi) return;
-    const int ow = wave / jb.wi, iw = wave % jb.wi;
-    const int a_t = ow * jb.po + x, b_t = iw * jb.pi + y;
-    if (a_t >= jb.a_tiles || b_t >= jb.b_tiles) return;
+    const int lane = local & 63, c = (local >> 6) & 15, tile = local >> 10;  // output tile (a_t, b_t) = a_t * b_tiles + b_t
+    const int a_t = tile / jb.b_tiles, b_t = tile % jb.b_tiles;
+    if (a_t >= jb.a_tiles) return;
     const int nks = (ji + 1 < a.njobs ? a.jobs[ji + 1].wg_start : a.total_wgs) - jb.wg_start;
     const int out_row = 32 * a_t + (c & 3) + 8 * (c >> 2) + 4 * (lane >> 5);
     const int in_row = 32 * b_t + (lane & 31);
@@ -955,16 +828,16 @@ NH_KERNEL void k_wgrad_reduce(WgradArgs a) {
         }
         if (col >= 0) {
             float s = 0.0f;
-            const float* p = a.partial + (size_t)jb.wg_start * NH_PART + ((size_t)(wave * 16 + ab) * 16 + c) * 64 + lane;
+            const float* p = a.partial + (size_t)jb.wg_start * NH_PART + ((size_t)tile * 16 + c) * 64 + lane;
             for (int q = 0; q < nks; ++q) s += p[(size_t)q * NH_PART];
             a.g_params[(size_t)jb.w_off + (size_t)(out_row - jb.r_lo) * jb.w_ld + col] = s;
         }
     }
-    if (jb.bias_off >= 0 && iw == 0 && y == 0 && c == 0 && lane < 32) {
+    if (jb.bias_off >= 0 && b_t == 0 && c == 0 && lane < 32) {
         const int brow = 32 * a_t + lane;
         if (brow >= jb.r_lo && brow < jb.r_hi) {
             float s = 0.0f;
-            const float* p = a.partial + (size_t)jb.wg_start * NH_PART + 65536 + (wave * 4 + x) * 32 + lane;
+            const float* p = a.partial + (size_t)jb.wg_start * NH_PART + 65536 + a_t * 32 + lane;
             for (int q = 0; q < nks; ++q) s += p[(size_t)q * NH_PART];
             a.g_params[(size_t)jb.bias_off + (brow - jb.r_lo)] = s;
         }
@@ -972,17 +845,6 @@ NH_KERNEL void k_wgrad_reduce(WgradArgs a) {
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
-// NERFHIP_WGRAD selects the weight-gradient kernel: lds (operands staged through LDS by DMA; default) or reg (per-lane
-// global loads into registers).
-int use_lds_wgrad() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("NERFHIP_WGRAD");
-        v = !e ? 1 : (e[0] == 'r' ? 0 : 1);
-    }
-    return v;
-}
-
 constexpr int NH_WGRAD_TARGET_WGS = 1024;
 
 // Split-K allocation: job j gets ks_j workgroups with ks_j proportional to its per-tile cost (every workgroup then
@@ -991,7 +853,7 @@ constexpr int NH_WGRAD_TARGET_WGS = 1024;
 void wgrad_schedule(const nerfhip_plan* p, int64_t nt, WgradArgs& w) {
     w.njobs = (int)p->jobs.size();
     int64_t cost[NH_JOBS_DEV];
-    for (int q = 0; q < w.njobs; ++q) cost[q] = use_lds_wgrad() ? p->jobs[q].cost_lds : p->jobs[q].cost;
+    for (int q = 0; q < w.njobs; ++q) cost[q] = p->jobs[q].cost;
     if (const char* e = getenv("NERFHIP_WGRAD_COSTS")) {  // tuning aid: per-job costs measured by scripts/wgrad_timeline.py
         for (int q = 0; q < w.njobs && *e; ++q) {
             const long v = strtol(e, (char**)&e, 10);
@@ -1209,19 +1071,15 @@ int nh_mlp_backward(nerfhip_plan* p, const float* packed, const float* g_out, in
     w.partial = scratch + (size_t)nt * (size_t)p->grad.total_rows * 32;
     w.g_params = g_params;
     w.nt = nt;
-    if (use_lds_wgrad()) {
-        for (int q = 0; q < w.njobs; ++q) {
-            const NhJob& j = p->jobs[q];
-            NH_REQUIRE(j.b_row0 == 0 && 32 * j.a_tiles == j.a_region_rows && 32 * j.b_tiles == j.b_region_rows &&
-                           32 * (j.a_region_rows + j.b_region_rows) <= NH_WG_STAGE_FLOATS,
-                       "wgrad: job %d does not cover whole regions", q);
-        }
-        rc = set_lds_limit(k_wgrad_lds, NH_WG_LDS_BYTES);
-        if (rc) return rc;
-        NH_LAUNCH(k_wgrad_lds, w.total_wgs, 256, NH_WG_LDS_BYTES, stream, w);
-    } else {
-        NH_LAUNCH(k_wgrad, w.total_wgs, 256, 0, stream, w);
+    for (int q = 0; q < w.njobs; ++q) {
+        const NhJob& j = p->jobs[q];
+        NH_REQUIRE(j.b_row0 == 0 && 32 * j.a_tiles == j.a_region_rows && 32 * j.b_tiles == j.b_region_rows &&
+                       32 * (j.a_region_rows + j.b_region_rows) <= NH_WG_STAGE_FLOATS && j.a_tiles * j.b_tiles <= 64,
+                   "wgrad: job %d does not cover whole regions", q);
     }
+    rc = set_lds_limit(k_wgrad, NH_WG_LDS_BYTES);
+    if (rc) return rc;
+    NH_LAUNCH(k_wgrad, w.total_wgs, 64 * NH_WG_WAVES, NH_WG_LDS_BYTES, stream, w);
     rc = nh_launch_status("wgrad");
     if (rc) return rc;
     NH_LAUNCH(k_wgrad_reduce, w.njobs * 256, 256, 0, stream, w);

@@ -75,7 +75,7 @@ struct NhJob {
     int64_t b_row_prefix; // B region offset in the activation stash
     int b_row0;           // first row of B covered
     int b_tiles;
-    int wo, wi, po, pi;   // wave grid (wo*wi <= 4) and per-wave patch in tiles (<= 4 x 4)
+    int wo, wi, po, pi;   // wave grid (wo*wi <= 8) and per-wave patch in tiles (po*pi <= 8)
     // unpack: out row r is real iff r_lo <= r < r_hi and maps to parameter row (r - r_lo)
     int r_lo, r_hi;
     int64_t w_off;        // flat offset of the weight tensor
@@ -83,8 +83,7 @@ struct NhJob {
     int col_kind;         // 0: col = col_base + in_row (valid iff < col_base + col_count); 1: xyz slot map; 2: dir slot map
     int col_base, col_count;
     int64_t bias_off;     // flat offset of the bias tensor, or -1 (only one job per layer carries the bias)
-    int cost;             // relative time per sample tile of one workgroup, register-operand kernel (2*po*pi + 5)
-    int cost_lds;         // the same for the LDS-staged kernel
+    int cost;             // relative time one workgroup spends per sample tile (split-K allocation)
 };
 
 struct nerfhip_plan {

@@ -219,14 +219,16 @@ void add_job(nerfhip_plan* p, const NhRegion& A, int a_tiles, const NhRegion& B,
     j.b_row_prefix = B.row_prefix;
     j.b_row0 = b_row0;
     j.b_tiles = b_tiles;
-    // wave grid: give the 4 waves of a workgroup equal patches of at most 4 x 4 tiles
+    // wave grid: the 8 waves of a workgroup (two per SIMD) take equal patches of at most 8 accumulator tiles each
     int best_wo = 1, best_wi = 1, best_cost = 1 << 30;
-    for (int wo = 1; wo <= 4; wo *= 2)
-        for (int wi = 1; wo * wi <= 4; wi *= 2) {
+    for (int wo = 1; wo <= 8; wo *= 2)
+        for (int wi = 1; wo * wi <= 8; wi *= 2) {
             int po = (a_tiles + wo - 1) / wo, pi = (b_tiles + wi - 1) / wi;
-            if (po > 4 || pi > 4 || po == 3 || pi == 3) continue;
-            int cost = po * pi;
-            if (cost < best_cost || (cost == best_cost && wo * wi < best_wo * best_wi)) {
+            if (po > 4 || pi > 4 || po * pi > 8 || po == 3 || pi == 3) continue;
+            // SIMD time per sample tile ~ (waves per SIMD) * patch; ties: fewer operand reads per MFMA, then fewer waves
+            const int per_simd = (wo * wi + 3) / 4;
+            int cost = (per_simd * po * pi) * 64 + (po + pi) * 4 + wo * wi;
+            if (cost < best_cost) {
                 best_cost = cost;
                 best_wo = wo;
                 best_wi = wi;
@@ -236,17 +238,10 @@ void add_job(nerfhip_plan* p, const NhRegion& A, int a_tiles, const NhRegion& B,
     j.wi = best_wi;
     j.po = (a_tiles + j.wo - 1) / j.wo;
     j.pi = (b_tiles + j.wi - 1) / j.wi;
-    // Relative time one workgroup spends per sample tile, measured on MI355X with per-workgroup timestamps
-    // (profiles/r01_wgrad_timeline.txt): t ~= 1.1 us + 0.45 us * po*pi  -- the MFMA work plus a fixed per-tile cost
-    // (address arithmetic, load issue, exposed latency) that dominates the small patches.
-    j.cost = 2 * j.po * j.pi + 5;
-    // LDS-staged kernel: the MFMA work (0.43 us per tile pair) or the stage copy (128 B per operand row), whichever is
-    // longer, plus a fixed per-tile cost -- provisional until fitted to a timeline
-    {
-        const int rows = A.rows + B.rows;
-        const int mfma = 43 * j.po * j.pi, dma = 9 * rows / 10;
-        j.cost_lds = (mfma > dma ? mfma : dma) + 30;
-    }
+    // Relative time one workgroup spends per sample tile (split-K allocation), fitted to per-workgroup timestamps on
+    // MI355X for the 8x256 and 4x128 nets (profiles/r01_wgrad_timeline.txt): t = 0.45 us * (tile pairs of the busiest
+    // SIMD) + 0.79 us fixed per tile (stage hand-over, copy issue), within 9 % for every job.
+    j.cost = 45 * ((j.wo * j.wi + 3) / 4) * j.po * j.pi + 79;
     j.r_lo = r_lo;
     j.r_hi = r_hi;
     j.w_off = p->tensors[w_tensor].off;

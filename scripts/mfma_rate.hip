@@ -1,0 +1,308 @@
+// mfma_rate.hip -- GPU-box microbenchmark: sustained issue rate of the fp32 MFMA shapes, one wave per SIMD (the
+// occupancy of the MLP kernels), as a function of how many accumulators rotate and of what else shares the loop.
+// Build (here, cross-compiling):  hipcc --offload-arch=gfx950 -O3 scripts/mfma_rate.hip -o scripts/mfma_rate
+// Output: shader-clock cycles per MFMA (s_memtime) -- ideal 64 for 32x32x2, 32 for 16x16x4 (= 157.3 TFLOP/s).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+
+template <int NACC, int VALU, int LDS>
+__global__ __launch_bounds__(256, 1) void k32(float* out, unsigned long long* cyc, int iters, float a0, float b0) {
+    __shared__ float lds[4096];
+    f32x16 acc[NACC];
+    for (int i = 0; i < NACC; ++i)
+        for (int c = 0; c < 16; ++c) acc[i][c] = 0.f;
+    float a[4] = {a0, a0 + 1, a0 + 2, a0 + 3}, b[4] = {b0, b0 + 1, b0 + 2, b0 + 3};
+    float s[4] = {0, 0, 0, 0};
+    for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = (float)i;
+    __syncthreads();
+    const float* lp = lds + (threadIdx.x & 63);
+    unsigned long long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+        if (LDS) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                a[q] = lp[64 * q + ((it & 7) << 8)];
+                b[q] = lp[64 * q + 2048 + ((it & 7) << 8)];
+            }
+            FENCE();
+        }
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            acc[m % NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m >> 2], b[m & 3], acc[m % NACC], 0, 0, 0);
+            if (VALU && (m & 3) == 0) s[m >> 2] += a[m >> 2];
+        }
+        FENCE();
+    }
+    unsigned long long t1 = clock64();
+    float r = s[0] + s[1] + s[2] + s[3];
+    for (int i = 0; i < NACC; ++i)
+        for (int c = 0; c < 16; ++c) r += acc[i][c];
+    out[blockIdx.x * 256 + threadIdx.x] = r;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+template <int NACC>
+__global__ __launch_bounds__(256, 1) void k16(float* out, unsigned long long* cyc, int iters, float a0, float b0) {
+    f32x4 acc[NACC];
+    for (int i = 0; i < NACC; ++i)
+        for (int c = 0; c < 4; ++c) acc[i][c] = 0.f;
+    float a[8], b[8];
+    for (int q = 0; q < 8; ++q) a[q] = a0 + q, b[q] = b0 + q;
+    unsigned long long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 64; ++m)
+            acc[m % NACC] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m >> 3], b[m & 7], acc[m % NACC], 0, 0, 0);
+        FENCE();
+    }
+    unsigned long long t1 = clock64();
+    float r = 0;
+    for (int i = 0; i < NACC; ++i)
+        for (int c = 0; c < 4; ++c) r += acc[i][c];
+    out[blockIdx.x * 256 + threadIdx.x] = r;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+
+// cost of ONE extra instruction of a given kind issued between MFMAs (single wave per SIMD): N of them per 16 MFMAs
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int KIND, int N>
+__global__ __launch_bounds__(256, 1) void kx(float* out, unsigned long long* cyc, int iters, float a0, float b0) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    f32x16 acc[16];
+    for (int i = 0; i < 16; ++i)
+        for (int c = 0; c < 16; ++c) acc[i][c] = 0.f;
+    float a[4] = {a0, a0 + 1, a0 + 2, a0 + 3}, b[4] = {b0, b0 + 1, b0 + 2, b0 + 3};
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    f32x2 p2[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    for (int i = threadIdx.x; i < 8192; i += 256) lds[i] = (float)(i & 15);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    float* gp = out + (size_t)blockIdx.x * 4096 + threadIdx.x * 4;
+    int soff = 0;
+    float nx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    f32x4 nx4[4] = {};
+    f32x2 nx2[4] = {};
+    unsigned long long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+        const int ro = (it & 7) << 8;
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+            if (KIND == 1) s[q & 7] += a[q & 3];
+            if (KIND == 2) nx[q & 7] = lds[lane + 64 * q + ro];                                   // ds_read_b32
+            if (KIND == 3) nx4[q & 3] = *(const f32x4*)(lds + 4 * lane + 256 * q + ro);          // ds_read_b128
+            if (KIND == 4) nx2[q & 3] = *(const f32x2*)(lds + 2 * lane + 128 * q + ro);          // ds_read_b64
+            if (KIND == 5) nx[q & 7] = gp[q * 1024 + (it & 1)];                                   // global_load_dword
+            if (KIND == 10) {                                                                      // ds_read2_b32
+                nx[(2 * q) & 7] = lds[lane + 128 * q + ro];
+                nx[(2 * q + 1) & 7] = lds[lane + 128 * q + 32 + ro];
+            }
+            if (KIND == 6) *(f32x4*)(gp + q * 1024) = f32x4{a[0], a[1], a[2], a[3]};            // global_store_dwordx4
+            if (KIND == 7) p2[q & 3] += f32x2{a[q & 3], b[q & 3]};                               // v_pk_add_f32
+            if (KIND == 8) soff = __builtin_amdgcn_readfirstlane(soff + q + it);                 // v_readfirstlane + salu
+            if (KIND == 9)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + q * 1024),
+                                                 (__attribute__((address_space(3))) void*)(lds + 256 * q), 16, 0, 0);
+        }
+        FENCE();
+#pragma unroll
+        for (int m = 0; m < 16; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m >> 2], b[m & 3], acc[m], 0, 0, 0);
+        FENCE();
+        // loaded values are consumed AFTER the MFMAs (the prefetch pattern of the real kernels): one v_add per register
+        if (KIND == 2 || KIND == 5 || KIND == 10)
+            for (int q = 0; q < (KIND == 10 ? 2 * N : N) && q < 8; ++q) s[q] += nx[q];
+        if (KIND == 3)
+            for (int q = 0; q < N && q < 4; ++q) s[q] += nx4[q][0] + nx4[q][3];
+        if (KIND == 4)
+            for (int q = 0; q < N && q < 4; ++q) s[q] += nx2[q][0] + nx2[q][1];
+        FENCE();
+    }
+    unsigned long long t1 = clock64();
+    float r = (float)soff;
+    for (int i = 0; i < 8; ++i) r += s[i];
+    for (int i = 0; i < 4; ++i) r += p2[i][0] + p2[i][1];
+    for (int i = 0; i < 16; ++i)
+        for (int c = 0; c < 16; ++c) r += acc[i][c];
+    if (r == 12345.f) out[blockIdx.x * 256 + threadIdx.x] = r;
+    if (lane == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+template <int KIND, int N>
+static void runx(const char* name) {
+    const int grid = 256, iters = 20000;
+    float* out;
+    unsigned long long* cyc;
+    hipMalloc(&out, (size_t)grid * 4096 * 4 + (1 << 20));
+    hipMemset(out, 0, (size_t)grid * 4096 * 4 + (1 << 20));
+    hipMalloc(&cyc, (size_t)grid * 4 * 8);
+    hipFuncSetAttribute((const void*)kx<KIND, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipLaunchKernelGGL((kx<KIND, N>), dim3(grid), dim3(256), 65536, 0, out, cyc, iters, 1.0f, 2.0f);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h((size_t)grid * 4);
+    hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
+    double sum = 0;
+    for (auto v : h) sum += (double)v;
+    const double per_iter = sum / h.size() / iters;
+    printf("%-44s x%-2d per 16 MFMAs: %8.1f cycles / 16 MFMAs  -> %6.2f cycles per extra instruction\n", name, N, per_iter,
+           N ? (per_iter - 1024.0) / N : 0.0);
+    hipFree(out);
+    hipFree(cyc);
+}
+
+// the same probes for (a) the 16x16x4 shape (half the accumulator traffic per FLOP) and (b) two waves per SIMD with
+// 8 accumulator tiles each (what the 8-wave weight-gradient kernel does)
+template <int KIND, int N, int THREADS>
+__global__ __launch_bounds__(THREADS, THREADS / 256) void ky(float* out, unsigned long long* cyc, int iters, float a0, float b0) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr bool SMALL = KIND >= 100;          // 16x16x4
+    constexpr int K = SMALL ? KIND - 100 : KIND;
+    constexpr int NT = THREADS == 512 ? 8 : 16;  // 32x32 accumulator tiles per wave
+    f32x16 acc[NT];
+    for (int i = 0; i < NT; ++i)
+        for (int c = 0; c < 16; ++c) acc[i][c] = 0.f;
+    float a[4] = {a0, a0 + 1, a0 + 2, a0 + 3}, b[4] = {b0, b0 + 1, b0 + 2, b0 + 3};
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < 8192; i += THREADS) lds[i] = (float)(i & 15);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    unsigned long long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+        const int ro = (it & 7) << 8;
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+            if (K == 1) s[q & 7] += a[q & 3];
+            if (K == 2) nx[q & 7] = lds[lane + 64 * q + ro];
+        }
+        FENCE();
+        if (SMALL) {
+#pragma unroll
+            for (int m = 0; m < 4 * NT; ++m) {
+                f32x4 t = {acc[m >> 2][4 * (m & 3)], acc[m >> 2][4 * (m & 3) + 1], acc[m >> 2][4 * (m & 3) + 2], acc[m >> 2][4 * (m & 3) + 3]};
+                t = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m & 3], b[(m >> 2) & 3], t, 0, 0, 0);
+                acc[m >> 2][4 * (m & 3)] = t[0], acc[m >> 2][4 * (m & 3) + 1] = t[1], acc[m >> 2][4 * (m & 3) + 2] = t[2],
+                               acc[m >> 2][4 * (m & 3) + 3] = t[3];
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < NT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m >> 2], b[m & 3], acc[m], 0, 0, 0);
+        }
+        FENCE();
+        if (K == 2)
+            for (int q = 0; q < N && q < 8; ++q) s[q] += nx[q];
+        FENCE();
+    }
+    unsigned long long t1 = clock64();
+    float r = 0;
+    for (int i = 0; i < 8; ++i) r += s[i];
+    for (int i = 0; i < NT; ++i)
+        for (int c = 0; c < 16; ++c) r += acc[i][c];
+    if (r == 12345.f) out[blockIdx.x * THREADS + threadIdx.x] = r;
+    if (lane == 0) cyc[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+template <int KIND, int N, int THREADS>
+static void runy(const char* name) {
+    const int grid = 256, iters = 20000, waves = THREADS / 64;
+    float* out;
+    unsigned long long* cyc;
+    hipMalloc(&out, (size_t)grid * 4096 * 4);
+    hipMalloc(&cyc, (size_t)grid * 8 * 8);
+    hipMemset(cyc, 0, (size_t)grid * 8 * 8);
+    hipFuncSetAttribute((const void*)ky<KIND, N, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipLaunchKernelGGL((ky<KIND, N, THREADS>), dim3(grid), dim3(THREADS), 65536, 0, out, cyc, iters, 1.0f, 2.0f);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h((size_t)grid * 8);
+    hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
+    double sum = 0;
+    int cnt = 0;
+    for (int g = 0; g < grid; ++g)
+        for (int w = 0; w < waves; ++w) sum += (double)h[(size_t)g * 8 + w], ++cnt;
+    const double per_iter = sum / cnt / iters;  // per wave; the SIMD's MFMA work per iteration is 1024 cycles in every configuration
+    printf("%-52s x%-2d: %8.1f cycles per 1024 MFMA-cycles -> %6.2f cycles per extra instruction\n", name, N, per_iter,
+           N ? (per_iter - 1024.0) / (N * (waves / 4)) : 0.0);
+    hipFree(out);
+    hipFree(cyc);
+}
+
+template <class K>
+static void run(const char* name, K kern, int grid, int iters, int mfma_per_iter, double flop_per_mfma) {
+    float* out;
+    unsigned long long* cyc;
+    hipMalloc(&out, (size_t)grid * 256 * 4);
+    hipMalloc(&cyc, (size_t)grid * 4 * 8);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, out, cyc, iters / 8, 1.0f, 2.0f);
+    hipDeviceSynchronize();
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, out, cyc, iters, 1.0f, 2.0f);
+    hipEventRecord(e1, 0);
+    hipDeviceSynchronize();
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h((size_t)grid * 4);
+    hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
+    double sum = 0, mx = 0;
+    for (auto v : h) {
+        sum += (double)v;
+        if ((double)v > mx) mx = (double)v;
+    }
+    const double n = (double)iters * mfma_per_iter;
+    const double tf = (double)grid * 4 * n * flop_per_mfma / (ms * 1e-3) / 1e12;
+    printf("%-34s grid %5d  cycles/MFMA mean %7.2f max %7.2f   kernel %8.3f ms  %7.1f TFLOP/s  clock %.2f GHz\n", name, grid,
+           sum / h.size() / n, mx / n, ms, tf, (sum / h.size()) / (ms * 1e6) * ((grid + 255) / 256 > 1 ? (grid / 256.0) : 1.0));
+    hipFree(out);
+    hipFree(cyc);
+}
+
+int main() {
+    const int it = 20000;
+    for (int grid : {256, 1024}) {
+        run("32x32x2 16 accumulators", k32<16, 0, 0>, grid, it, 16, 4096.0);
+        run("32x32x2  8 accumulators", k32<8, 0, 0>, grid, it, 16, 4096.0);
+        run("32x32x2  4 accumulators", k32<4, 0, 0>, grid, it, 16, 4096.0);
+        run("32x32x2  2 accumulators", k32<2, 0, 0>, grid, it, 16, 4096.0);
+        run("32x32x2  1 accumulator (chain)", k32<1, 0, 0>, grid, it, 16, 4096.0);
+        run("32x32x2 16 acc + 4 v_add / 16", k32<16, 1, 0>, grid, it, 16, 4096.0);
+        run("32x32x2 16 acc + 8 ds_read / 16", k32<16, 0, 1>, grid, it, 16, 4096.0);
+        run("32x32x2 16 acc + v_add + ds_read", k32<16, 1, 1>, grid, it, 16, 4096.0);
+        run("16x16x4 64 accumulators", k16<64>, grid, it / 4, 64, 2048.0);
+        run("16x16x4 16 accumulators", k16<16>, grid, it / 4, 64, 2048.0);
+        run("16x16x4  4 accumulators", k16<4>, grid, it / 4, 64, 2048.0);
+        run("16x16x4  1 accumulator (chain)", k16<1>, grid, it / 4, 64, 2048.0);
+    }
+    runx<0, 0>("(nothing)");
+    runx<1, 4>("v_add_f32");
+    runx<1, 8>("v_add_f32");
+    runx<7, 4>("v_pk_add_f32");
+    runx<2, 8>("ds_read_b32 (prefetched) + 8 v_add");
+    runx<10, 4>("ds_read2_b32 (prefetched) + 8 v_add");
+    runx<4, 4>("ds_read_b64 (prefetched) + 8 v_add");
+    runx<3, 2>("ds_read_b128 (prefetched) + 4 v_add");
+    runx<3, 4>("ds_read_b128 (prefetched) + 8 v_add");
+    runx<5, 4>("global_load_dword (prefetched) + 4 v_add");
+    runx<6, 2>("global_store_dwordx4");
+    runx<9, 2>("global_load_lds_dwordx4");
+    runx<9, 4>("global_load_lds_dwordx4");
+    runx<8, 8>("v_readfirstlane + s_add");
+    runy<0, 0, 256>("1 wave/SIMD 32x32x2 (nothing)");
+    runy<100, 0, 256>("1 wave/SIMD 16x16x4 (nothing)");
+    runy<101, 8, 256>("1 wave/SIMD 16x16x4 + v_add_f32");
+    runy<102, 8, 256>("1 wave/SIMD 16x16x4 + ds_read_b32 (prefetched) + v_add");
+    runy<0, 0, 512>("2 waves/SIMD 32x32x2 (nothing)");
+    runy<1, 4, 512>("2 waves/SIMD 32x32x2 + v_add_f32 (per wave)");
+    runy<1, 8, 512>("2 waves/SIMD 32x32x2 + v_add_f32 (per wave)");
+    runy<2, 4, 512>("2 waves/SIMD 32x32x2 + ds_read_b32 + v_add (per wave)");
+    runy<2, 8, 512>("2 waves/SIMD 32x32x2 + ds_read_b32 + v_add (per wave)");
+    runy<100, 0, 512>("2 waves/SIMD 16x16x4 (nothing)");
+    runy<102, 8, 512>("2 waves/SIMD 16x16x4 + ds_read_b32 + v_add (per wave)");
+    return 0;
+}

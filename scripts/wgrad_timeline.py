@@ -26,10 +26,10 @@ for _ in range(2):
 torch.cuda.synchronize()
 nt = 4 * ((M + 127) // 128)
 rows = LAY * HID + HID + HID // 2 + 32
-PART = 65536 + 512 + 64
+PART = 65536 + 512 + 128
 part = scratch[nt * rows * 32:]
 nwg = part.numel() // PART
-part = part[:nwg * PART].view(nwg, PART)[:, 65536 + 512:65536 + 512 + 64].contiguous().cpu().numpy().view(np.uint64).reshape(nwg, 4, 8)
+part = part[:nwg * PART].view(nwg, PART)[:, 65536 + 512:65536 + 512 + 128].contiguous().cpu().numpy().view(np.uint64).reshape(nwg, 8, 8)
 t0 = part[:, :, 0][part[:, :, 0] > 0].min()
 jobs = {}
 for w in range(nwg):

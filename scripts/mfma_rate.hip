@@ -87,6 +87,11 @@ __global__ __launch_bounds__(256, 1) void kx(float* out, unsigned long long* cyc
     const int lane = threadIdx.x & 63;
     float* gp = out + (size_t)blockIdx.x * 4096 + threadIdx.x * 4;
     int soff = 0;
+    if (KIND >= 20) {  // stagger the four waves of the workgroup so that their LDS reads do not collide
+        const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        for (int q = 0; q < w; ++q) __builtin_amdgcn_s_sleep(1);  // 64 cycles each
+    }
+    constexpr int KK = KIND >= 20 ? KIND - 20 : KIND;
     float nx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     f32x4 nx4[4] = {};
     f32x2 nx2[4] = {};
@@ -95,19 +100,19 @@ __global__ __launch_bounds__(256, 1) void kx(float* out, unsigned long long* cyc
         const int ro = (it & 7) << 8;
 #pragma unroll
         for (int q = 0; q < N; ++q) {
-            if (KIND == 1) s[q & 7] += a[q & 3];
-            if (KIND == 2) nx[q & 7] = lds[lane + 64 * q + ro];                                   // ds_read_b32
-            if (KIND == 3) nx4[q & 3] = *(const f32x4*)(lds + 4 * lane + 256 * q + ro);          // ds_read_b128
-            if (KIND == 4) nx2[q & 3] = *(const f32x2*)(lds + 2 * lane + 128 * q + ro);          // ds_read_b64
-            if (KIND == 5) nx[q & 7] = gp[q * 1024 + (it & 1)];                                   // global_load_dword
-            if (KIND == 10) {                                                                      // ds_read2_b32
+            if (KK == 1) s[q & 7] += a[q & 3];
+            if (KK == 2) nx[q & 7] = lds[lane + 64 * q + ro];                                   // ds_read_b32
+            if (KK == 3) nx4[q & 3] = *(const f32x4*)(lds + 4 * lane + 256 * q + ro);          // ds_read_b128
+            if (KK == 4) nx2[q & 3] = *(const f32x2*)(lds + 2 * lane + 128 * q + ro);          // ds_read_b64
+            if (KK == 5) nx[q & 7] = gp[q * 1024 + (it & 1)];                                   // global_load_dword
+            if (KK == 10) {                                                                      // ds_read2_b32
                 nx[(2 * q) & 7] = lds[lane + 128 * q + ro];
                 nx[(2 * q + 1) & 7] = lds[lane + 128 * q + 32 + ro];
             }
-            if (KIND == 6) *(f32x4*)(gp + q * 1024) = f32x4{a[0], a[1], a[2], a[3]};            // global_store_dwordx4
-            if (KIND == 7) p2[q & 3] += f32x2{a[q & 3], b[q & 3]};                               // v_pk_add_f32
-            if (KIND == 8) soff = __builtin_amdgcn_readfirstlane(soff + q + it);                 // v_readfirstlane + salu
-            if (KIND == 9)
+            if (KK == 6) *(f32x4*)(gp + q * 1024) = f32x4{a[0], a[1], a[2], a[3]};            // global_store_dwordx4
+            if (KK == 7) p2[q & 3] += f32x2{a[q & 3], b[q & 3]};                               // v_pk_add_f32
+            if (KK == 8) soff = __builtin_amdgcn_readfirstlane(soff + q + it);                 // v_readfirstlane + salu
+            if (KK == 9)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + q * 1024),
                                                  (__attribute__((address_space(3))) void*)(lds + 256 * q), 16, 0, 0);
         }
@@ -116,11 +121,11 @@ __global__ __launch_bounds__(256, 1) void kx(float* out, unsigned long long* cyc
         for (int m = 0; m < 16; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m >> 2], b[m & 3], acc[m], 0, 0, 0);
         FENCE();
         // loaded values are consumed AFTER the MFMAs (the prefetch pattern of the real kernels): one v_add per register
-        if (KIND == 2 || KIND == 5 || KIND == 10)
-            for (int q = 0; q < (KIND == 10 ? 2 * N : N) && q < 8; ++q) s[q] += nx[q];
-        if (KIND == 3)
+        if (KK == 2 || KK == 5 || KK == 10)
+            for (int q = 0; q < (KK == 10 ? 2 * N : N) && q < 8; ++q) s[q] += nx[q];
+        if (KK == 3)
             for (int q = 0; q < N && q < 4; ++q) s[q] += nx4[q][0] + nx4[q][3];
-        if (KIND == 4)
+        if (KK == 4)
             for (int q = 0; q < N && q < 4; ++q) s[q] += nx2[q][0] + nx2[q][1];
         FENCE();
     }
@@ -293,6 +298,10 @@ int main() {
     runx<9, 2>("global_load_lds_dwordx4");
     runx<9, 4>("global_load_lds_dwordx4");
     runx<8, 8>("v_readfirstlane + s_add");
+    runx<23, 4>("STAGGERED ds_read_b128 (prefetched) + 8 v_add");
+    runx<23, 2>("STAGGERED ds_read_b128 (prefetched) + 4 v_add");
+    runx<22, 8>("STAGGERED ds_read_b32 (prefetched) + 8 v_add");
+    runx<21, 8>("STAGGERED v_add_f32");
     runy<0, 0, 256>("1 wave/SIMD 32x32x2 (nothing)");
     runy<100, 0, 256>("1 wave/SIMD 16x16x4 (nothing)");
     runy<101, 8, 256>("1 wave/SIMD 16x16x4 + v_add_f32");

@@ -618,8 +618,8 @@ struct WgradArgs {
     int64_t nt;
     int njobs, total_wgs;
     JobDev jobs[NH_JOBS_DEV];
-    short xcol[2][NH_KRX];
-    short dcol[2][NH_KRD];
+    short xslot[64];  // stash slot row -> reference column of the encoding, or -1
+    short dslot[32];
 };
 
 // The weight-gradient GEMMs, dW[out, in] = sum over samples of dP[out][sample] * act[in][sample], as a split-K MFMA
@@ -821,9 +821,7 @@ NH_KERNEL void k_wgrad_reduce(WgradArgs a) {
         if (jb.col_kind == 0) {
             if (in_row < jb.col_count) col = jb.col_base + in_row;
         } else {
-            const int kr = jb.col_kind == 1 ? NH_KRX : NH_KRD;  // slot rows are numbered h*KR + r
-            const int hh = in_row / kr, r = in_row % kr;
-            const int cc = jb.col_kind == 1 ? (int)a.xcol[hh][r] : (int)a.dcol[hh][r];
+            const int cc = jb.col_kind == 1 ? (int)a.xslot[in_row] : (int)a.dslot[in_row];  // stash slot row -> column
             if (cc >= 0) col = jb.col_base + cc;
         }
         if (col >= 0) {
@@ -921,10 +919,8 @@ void wgrad_schedule(const nerfhip_plan* p, int64_t nt, WgradArgs& w) {
         start += (int)ks[q];
     }
     w.total_wgs = start;
-    for (int h = 0; h < 2; ++h) {
-        for (int r = 0; r < NH_KRX; ++r) w.xcol[h][r] = (short)p->xyz_col[h][r];
-        for (int r = 0; r < NH_KRD; ++r) w.dcol[h][r] = (short)p->dir_col[h][r];
-    }
+    for (int r = 0; r < 64; ++r) w.xslot[r] = (short)p->xyz_slot_col[r];
+    for (int r = 0; r < 32; ++r) w.dslot[r] = (short)p->dir_slot_col[r];
 }
 
 template <class K>
@@ -966,6 +962,13 @@ int nh_mlp_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, i
                    nerfhip_stream_t stream) {
     NH_REQUIRE(p && packed && out && M >= 0, "mlp_fwd: bad arguments");
     if (M == 0) return NERFHIP_OK;
+    if (in.mode == 1) {
+        NH_REQUIRE(p->freqs_set, "mlp_fwd: nerfhip_plan_set_freqs has not been called");
+        NH_REQUIRE(in.rays && in.z && in.S > 0 && in.ray_stride >= (p->view ? 11 : 8), "mlp_fwd: bad fused input");
+    } else {
+        NH_REQUIRE(in.x, "mlp_fwd: x is NULL");
+    }
+    if (p->v16) return nh_mlp16_forward(p, packed, in, M, out, stash, stream);
     MlpFwdArgs a;
     memset(&a, 0, sizeof(a));
     a.packed = packed;
@@ -986,12 +989,6 @@ int nh_mlp_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, i
     for (int h = 0; h < 2; ++h) {
         for (int r = 0; r < NH_KRX; ++r) a.xcol[h][r] = (short)p->xyz_col[h][r];
         for (int r = 0; r < NH_KRD; ++r) a.dcol[h][r] = (short)p->dir_col[h][r];
-    }
-    if (in.mode == 1) {
-        NH_REQUIRE(p->freqs_set, "mlp_fwd: nerfhip_plan_set_freqs has not been called");
-        NH_REQUIRE(in.rays && in.z && in.S > 0 && in.ray_stride >= (p->view ? 11 : 8), "mlp_fwd: bad fused input");
-    } else {
-        NH_REQUIRE(in.x, "mlp_fwd: x is NULL");
     }
     for (int k = 0; k < 16; ++k) {
         a.fx[k] = p->freqs_xyz[k];
@@ -1030,6 +1027,11 @@ int nh_mlp_backward(nerfhip_plan* p, const float* packed, const float* g_out, in
     NH_REQUIRE(scratch_bytes >= nh_mlp_bwd_scratch_bytes(p, M), "mlp_bwd: scratch too small (%lld < %lld)",
                (long long)scratch_bytes, (long long)nh_mlp_bwd_scratch_bytes(p, M));
     const int64_t nt = nh_ceil_div(M, 128) * 4;
+    int rc = NERFHIP_OK;
+    if (p->v16) {
+        rc = nh_mlp16_dgrad(p, packed, g_out, M, stash, scratch, stream);
+        if (rc) return rc;
+    } else {
     DgradArgs d;
     memset(&d, 0, sizeof(d));
     d.packed = packed;
@@ -1044,7 +1046,6 @@ int nh_mlp_backward(nerfhip_plan* p, const float* packed, const float* g_out, in
     d.grad = scratch;
     d.gl = p->grad;
     const int64_t grid = nh_ceil_div(M, 128);
-    int rc = NERFHIP_OK;
 #define NH_BWD_CASE(WW, VV, DD)                                                           \
     {                                                                                     \
         rc = set_lds_limit(k_mlp_dgrad<WW, VV, DD>, Cfg<WW>::LDS_BYTES);                  \
@@ -1062,6 +1063,7 @@ int nh_mlp_backward(nerfhip_plan* p, const float* packed, const float* g_out, in
 #undef NH_BWD_CASE
     rc = nh_launch_status("mlp_dgrad");
     if (rc) return rc;
+    }
 
     WgradArgs w;
     memset(&w, 0, sizeof(w));

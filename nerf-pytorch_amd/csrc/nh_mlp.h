@@ -17,3 +17,9 @@ int nh_mlp_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, i
 int nh_mlp_backward(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash,
                     float* scratch, int64_t scratch_bytes, float* g_params, nerfhip_stream_t stream);
 int64_t nh_mlp_bwd_scratch_bytes(nerfhip_plan* p, int64_t M);
+
+// mlp16.hip: the same forward / data-gradient chain on v_mfma_f32_16x16x4_f32 with two waves per SIMD (plans with v16)
+int nh_mlp16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
+                     nerfhip_stream_t stream);
+int nh_mlp16_dgrad(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
+                   nerfhip_stream_t stream);

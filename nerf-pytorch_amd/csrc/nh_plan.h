@@ -26,6 +26,24 @@ constexpr int NH_MAX_LAYERS = 16;  // num_layers limit
 constexpr int NH_MAX_JOBS = 48;
 
 static inline int nh_feat(int r, int h) { return 32 * (r >> 4) + (r & 3) + 8 * ((r >> 2) & 3) + 4 * h; }
+
+// ---- "v16" layout: forward / data-gradient kernels on v_mfma_f32_16x16x4_f32 (mlp16.hip) -----------------------------
+//   * a wavefront owns 16 sample points; lane l = (j = l & 15: sample, g = l >> 4: k-group); a workgroup is 8 waves
+//     (two per SIMD) = 128 samples = four 32-sample stash tiles (wave w: tile w >> 1, samples 16*(w & 1) ..);
+//   * an activation of F features lives in F/4 registers per lane: register r of lane (j,g) holds feature
+//       feat16(r,g) = 16*(r>>2) + 4*g + (r&3)
+//     = the C/D layout of the instruction (tile r>>2, register r&3), and k-step r of the next layer consumes exactly
+//     register r as its B operand (B[k=g][j]);
+//   * encodings: xyz 16 registers = 64 slots, dir 8 registers = 32 slots; slot rows are numbered g*KR + r;
+//   * a layer image is [bias: 512 floats][chunks]: a chunk covers KC consecutive k-steps for ALL output tiles,
+//     [k-step][quad of 4 tiles][64 lanes][4 floats], so one ds_read_b128 yields the A operands of 4 tiles.
+constexpr int NH16_KRX = 16;
+constexpr int NH16_KRD = 8;
+static inline int nh_feat16(int r, int g) { return 16 * (r >> 2) + 4 * g + (r & 3); }
+static inline int nh16_tq(int tiles) { return (tiles + 3) / 4; }
+static inline int nh16_kc(int tiles) { return nh16_tq(tiles) <= 1 ? 32 : (nh16_tq(tiles) == 2 ? 16 : 8); }
+constexpr int NH16_BIAS_FLOATS = 512;
+static inline int64_t nh16_image_floats(int kr, int tiles) { return NH16_BIAS_FLOATS + (int64_t)kr * nh16_tq(tiles) * 256; }
 // floats of one packed weight chunk (one 32-row output tile): kr*64 weights + 32 biases padded to 256, so that a
 // chunk is a whole number of 1-KiB pieces (one LDS-DMA wave-instruction each)
 static inline int64_t nh_chunk_floats(int kr) { return (int64_t)kr * 64 + 256; }
@@ -96,6 +114,11 @@ struct nerfhip_plan {
     int t_dir_w, t_dir_b, t_alpha_w, t_alpha_b, t_rgb_w, t_rgb_b, t_feat_w, t_feat_b, t_out_w, t_out_b;
     int xyz_col[2][NH_KRX];  // slot (r,h) -> reference column of the xyz encoding, or -1
     int dir_col[2][NH_KRD];
+    bool v16;                // forward / data-gradient kernels and packed image in the 16x16x4 layout (mlp16.hip)
+    int xyz_col16[4][NH16_KRX];
+    int dir_col16[4][NH16_KRD];
+    int xyz_slot_col[64];    // stash slot row -> reference column (either layout), used by the weight-gradient scatter
+    int dir_slot_col[32];
     float freqs_xyz[16], freqs_dir[16];
     bool freqs_set;
     NhPackedOffsets po;

@@ -1,4 +1,5 @@
 // plan.cpp -- host-only: builds the plan of nh_plan.h for a FlexibleNeRFModel geometry (nerf/models.py:185-231).
+#include <stdlib.h>
 #include <string.h>
 
 #include <functional>
@@ -177,15 +178,188 @@ void build_specs(const nerfhip_plan* p, Specs& S) {
     }
 }
 
+// ---- v16 layout (mlp16.hip) ------------------------------------------------------------------------------------------
+// slot (r,g) -> reference column.  Group g < 3 owns the (frequency, axis) pairs [g*C, (g+1)*C), C = KR/2; group 3 owns
+// [3C, 3C + (KR-3)/2) and carries the raw coordinates in its last three registers.  Pair p = 3*f + axis sits in
+// registers 2q (sin), 2q+1 (cos), q = p - g*C.
+bool build_slot_map16(int L, int include_input, int kr, int* col_flat) {
+    auto col = [&](int g) { return col_flat + g * kr; };
+    const int P = 3 * L, C = kr / 2, C3 = (kr - 3) / 2, base = include_input ? 3 : 0;
+    if (P > 3 * C + C3) return false;
+    for (int g = 0; g < 4; ++g)
+        for (int r = 0; r < kr; ++r) col(g)[r] = -1;
+    for (int g = 0; g < 4; ++g)
+        for (int q = 0; q < (g < 3 ? C : C3); ++q) {
+            const int pr = g * C + q;
+            if (pr >= P) continue;
+            const int f = pr / 3, a = pr % 3;
+            col(g)[2 * q] = base + 6 * f + a;
+            col(g)[2 * q + 1] = base + 6 * f + 3 + a;
+        }
+    if (include_input)
+        for (int a = 0; a < 3; ++a) col(3)[kr - 3 + a] = a;
+    return true;
+}
+
+struct GemmSpec16 {
+    int kr = 0, tiles = 0;                    // k-steps (B registers), 16-row output tiles
+    std::function<int64_t(int, int, int)> w;  // (out_row, r, g) -> flat param index or -1
+    std::function<int64_t(int)> b;            // out_row -> flat param index or -1
+};
+
+void fill_spec16(const GemmSpec16& s, int64_t off, int32_t* table) {
+    const int tq = nh16_tq(s.tiles);
+    for (int i = 0; i < NH16_BIAS_FLOATS; ++i) table[off + i] = (i < 16 * s.tiles && s.b) ? (int32_t)s.b(i) : -1;
+    int32_t* img = table + off + NH16_BIAS_FLOATS;
+    for (int r = 0; r < s.kr; ++r)
+        for (int q = 0; q < tq; ++q)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 4; ++e) {
+                    const int t = 4 * q + e;
+                    const int64_t src = t < s.tiles ? s.w(16 * t + (lane & 15), r, lane >> 4) : -1;
+                    img[(((int64_t)r * tq + q) * 64 + lane) * 4 + e] = (int32_t)src;
+                }
+}
+
+struct Specs16 {
+    GemmSpec16 f_layer1, f_xyz[NH_MAX_LAYERS], f_head, f_dir, f_rgb, b_rgb, b_dir, b_head, b_xyz[NH_MAX_LAYERS];
+};
+
+void build_specs16(const nerfhip_plan* p, Specs16& S) {
+    const int W = p->W, KH = W / 4, Dx = p->Dx, Dd = p->Dd, L = p->L, TW = W / 16;
+    auto T = [p](int idx) { return p->tensors[idx]; };
+    {
+        GemmSpec16& s = S.f_layer1;
+        s.kr = NH16_KRX;
+        s.tiles = TW;
+        NhTensor w = T(p->t_layer1_w), b = T(p->t_layer1_b);
+        s.w = [=](int o, int r, int g) -> int64_t {
+            int c = p->xyz_col16[g][r];
+            return (o < W && c >= 0) ? w.off + (int64_t)o * Dx + c : -1;
+        };
+        s.b = [=](int o) -> int64_t { return o < W ? b.off + o : -1; };
+    }
+    for (int i = 0; i < L - 1; ++i) {
+        GemmSpec16& s = S.f_xyz[i];
+        const bool sk = p->is_skip(i);
+        s.kr = KH + (sk ? NH16_KRX : 0);
+        s.tiles = TW;
+        NhTensor w = T(p->t_xyz_w[i]), b = T(p->t_xyz_b[i]);
+        const int ld = W + (sk ? Dx : 0);
+        s.w = [=](int o, int r, int g) -> int64_t {
+            if (r < KH) return w.off + (int64_t)o * ld + nh_feat16(r, g);
+            int c = p->xyz_col16[g][r - KH];
+            return c >= 0 ? w.off + (int64_t)o * ld + W + c : -1;
+        };
+        s.b = [=](int o) -> int64_t { return b.off + o; };
+        GemmSpec16& bt = S.b_xyz[i];  // dh_in[f] = sum_u W[u][f] dpre[u]   (hidden columns only)
+        bt.kr = KH;
+        bt.tiles = TW;
+        bt.w = [=](int f, int r, int g) -> int64_t { return w.off + (int64_t)nh_feat16(r, g) * ld + f; };
+    }
+    if (p->view) {
+        NhTensor fw = T(p->t_feat_w), fb = T(p->t_feat_b), aw = T(p->t_alpha_w), ab = T(p->t_alpha_b);
+        NhTensor dw = T(p->t_dir_w), db = T(p->t_dir_b), rw = T(p->t_rgb_w), rb = T(p->t_rgb_b);
+        {
+            GemmSpec16& s = S.f_head;  // rows 0..W-1 = fc_feat, row W = fc_alpha
+            s.kr = KH;
+            s.tiles = TW + 1;
+            s.w = [=](int o, int r, int g) -> int64_t {
+                if (o < W) return fw.off + (int64_t)o * W + nh_feat16(r, g);
+                if (o == W) return aw.off + nh_feat16(r, g);
+                return -1;
+            };
+            s.b = [=](int o) -> int64_t { return o < W ? fb.off + o : (o == W ? ab.off : -1); };
+        }
+        {
+            GemmSpec16& s = S.f_dir;
+            s.kr = KH + NH16_KRD;
+            s.tiles = TW / 2;
+            const int ld = W + Dd;
+            s.w = [=](int o, int r, int g) -> int64_t {
+                if (r < KH) return dw.off + (int64_t)o * ld + nh_feat16(r, g);
+                int c = p->dir_col16[g][r - KH];
+                return c >= 0 ? dw.off + (int64_t)o * ld + W + c : -1;
+            };
+            s.b = [=](int o) -> int64_t { return db.off + o; };
+        }
+        {
+            GemmSpec16& s = S.f_rgb;
+            s.kr = KH / 2;
+            s.tiles = 1;
+            s.w = [=](int o, int r, int g) -> int64_t { return o < 3 ? rw.off + (int64_t)o * (W / 2) + nh_feat16(r, g) : -1; };
+            s.b = [=](int o) -> int64_t { return o < 3 ? rb.off + o : -1; };
+        }
+        {
+            GemmSpec16& s = S.b_rgb;  // d(dir hidden)[f] = sum_{rho<3} Wrgb[rho][f] d_rgb[rho]; ONE k-step: group g carries rho = g
+            s.kr = 1;
+            s.tiles = TW / 2;
+            s.w = [=](int f, int r, int g) -> int64_t { return (r == 0 && g < 3) ? rw.off + (int64_t)g * (W / 2) + f : -1; };
+        }
+        {
+            GemmSpec16& s = S.b_dir;  // d(feat)[f] = sum_u Wdir[u][f] dpre_dir[u]
+            s.kr = KH / 2;
+            s.tiles = TW;
+            const int ld = W + Dd;
+            s.w = [=](int f, int r, int g) -> int64_t { return dw.off + (int64_t)nh_feat16(r, g) * ld + f; };
+        }
+        {
+            GemmSpec16& s = S.b_head;  // dh[f] = sum_u Wfeat[u][f] dpre_feat[u] + Walpha[0][f] d_alpha (k-step KH, group 0)
+            s.kr = KH + 1;
+            s.tiles = TW;
+            s.w = [=](int f, int r, int g) -> int64_t {
+                if (r < KH) return fw.off + (int64_t)nh_feat16(r, g) * W + f;
+                return g == 0 ? aw.off + f : -1;
+            };
+        }
+    } else {
+        NhTensor ow = T(p->t_out_w), ob = T(p->t_out_b);
+        GemmSpec16& s = S.f_head;  // fc_out
+        s.kr = KH;
+        s.tiles = 1;
+        s.w = [=](int o, int r, int g) -> int64_t { return o < 4 ? ow.off + (int64_t)o * W + nh_feat16(r, g) : -1; };
+        s.b = [=](int o) -> int64_t { return o < 4 ? ob.off + o : -1; };
+        GemmSpec16& bt = S.b_head;  // ONE k-step: group g carries d(out row g)
+        bt.kr = 1;
+        bt.tiles = TW;
+        bt.w = [=](int f, int r, int g) -> int64_t { return r == 0 ? ow.off + (int64_t)g * W + f : -1; };
+    }
+}
+
+template <class SpecsT, class Fn>
+void for_each_spec(const nerfhip_plan* p, SpecsT& S, NhPackedOffsets& o, Fn fn) {
+    fn(S.f_layer1, &o.f_layer1);
+    for (int i = 0; i < p->L - 1; ++i) fn(S.f_xyz[i], &o.f_xyz[i]);
+    fn(S.f_head, &o.f_head);
+    if (p->view) {
+        fn(S.f_dir, &o.f_dir);
+        fn(S.f_rgb, &o.f_rgb);
+        fn(S.b_rgb, &o.b_rgb);
+        fn(S.b_dir, &o.b_dir);
+    }
+    fn(S.b_head, &o.b_head);
+    for (int i = 0; i < p->L - 1; ++i) fn(S.b_xyz[i], &o.b_xyz[i]);
+}
+
 void layout_packed(nerfhip_plan* p) {
+    int64_t off = 0;
+    memset(&p->po, 0, sizeof(p->po));
+    if (p->v16) {
+        Specs16 S;
+        build_specs16(p, S);
+        for_each_spec(p, S, p->po, [&](const GemmSpec16& s, int64_t* dst) {
+            *dst = off;
+            off += nh16_image_floats(s.kr, s.tiles);
+        });
+        p->packed_floats = off;
+        return;
+    }
     Specs S;
     build_specs(p, S);
-    int64_t off = 0;
     auto place = [&](const GemmSpec& s, int64_t* dst) {
         *dst = off;
         off += spec_floats(s);
     };
-    memset(&p->po, 0, sizeof(p->po));
     place(S.f_layer1, &p->po.f_layer1);
     for (int i = 0; i < p->L - 1; ++i) place(S.f_xyz[i], &p->po.f_xyz[i]);
     place(S.f_head, &p->po.f_head);
@@ -363,6 +537,23 @@ extern "C" nerfhip_plan_t nerfhip_plan_create(const nerfhip_model_cfg* cfg) {
                    &p->P0x);
     build_slot_map(p->view ? cfg->num_encoding_fn_dir : 0, (p->view && cfg->include_input_dir) ? 1 : 0, NH_KRD,
                    p->dir_col[0], p->dir_col[1], &p->P0d);
+    {
+        // NERFHIP_MLP=16 selects the 16x16x4 kernels (mlp16.hip) and their packed image for this plan
+        const char* e = getenv("NERFHIP_MLP");
+        p->v16 = e && e[0] == '1' && e[1] == '6';
+        const bool okx = build_slot_map16(cfg->num_encoding_fn_xyz, cfg->include_input_xyz ? 1 : 0, NH16_KRX, &p->xyz_col16[0][0]);
+        const bool okd = build_slot_map16(p->view ? cfg->num_encoding_fn_dir : 0, (p->view && cfg->include_input_dir) ? 1 : 0,
+                                          NH16_KRD, &p->dir_col16[0][0]);
+        if (p->v16 && !(okx && okd)) {
+            nh_set_error("plan_create: encoding does not fit the slot registers");
+            delete p;
+            return nullptr;
+        }
+        for (int row = 0; row < 64; ++row)
+            p->xyz_slot_col[row] = p->v16 ? p->xyz_col16[row / NH16_KRX][row % NH16_KRX] : p->xyz_col[row / NH_KRX][row % NH_KRX];
+        for (int row = 0; row < 32; ++row)
+            p->dir_slot_col[row] = p->v16 ? p->dir_col16[row / NH16_KRD][row % NH16_KRD] : p->dir_col[row / NH_KRD][row % NH_KRD];
+    }
     for (int k = 0; k < 16; ++k) {
         p->freqs_xyz[k] = 0.f;
         p->freqs_dir[k] = 0.f;
@@ -396,6 +587,13 @@ extern "C" int64_t nerfhip_plan_packed_floats(nerfhip_plan_t plan) { return plan
 
 extern "C" int nerfhip_plan_pack_index(nerfhip_plan_t plan, int32_t* host_table) {
     NH_REQUIRE(plan && host_table, "plan_pack_index: bad arguments");
+    if (plan->v16) {
+        Specs16 S16;
+        build_specs16(plan, S16);
+        NhPackedOffsets o = plan->po;
+        for_each_spec(plan, S16, o, [&](const GemmSpec16& s, int64_t* dst) { fill_spec16(s, *dst, host_table); });
+        return NERFHIP_OK;
+    }
     Specs S;
     build_specs(plan, S);
     const NhPackedOffsets& o = plan->po;

@@ -236,6 +236,79 @@ static void runy(const char* name) {
     hipFree(cyc);
 }
 
+// Mock of a 16x16x4-based MLP layer loop: each wave owns 16 samples, per k-step it reads 16 A-operand dwords from LDS
+// (4 x ds_read_b128, prefetched one k-step ahead) and issues 16 MFMAs (one per 16-row output tile).  WAVES per workgroup
+// = 4, 8 or 12 (1, 2, 3 per SIMD).  Ideal: 16 x 32 = 512 cycles per k-step and wave.
+template <int WAVES, int SHAPE32>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void kmock(float* out, unsigned long long* cyc, int iters, float b0) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    for (int i = threadIdx.x; i < 16384; i += 64 * WAVES) lds[i] = (float)(i & 7);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const f32x4* lp = (const f32x4*)lds + lane;
+    f32x4 acc[16];
+    f32x16 acc32[4];
+    for (int i = 0; i < 16; ++i) acc[i] = f32x4{0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i)
+        for (int c = 0; c < 16; ++c) acc32[i][c] = 0.f;
+    float b = b0;
+    f32x4 c0[4], c1[4];
+    for (int q = 0; q < 4; ++q) c0[q] = lp[64 * q];
+    unsigned long long t0 = clock64();
+    for (int it = 0; it < iters; it += 2) {
+        const int ro = ((it & 6) + 1) << 8;
+        for (int q = 0; q < (SHAPE32 ? 1 : 4); ++q) c1[q] = lp[64 * q + ro];
+        FENCE();
+        if (SHAPE32) {  // today's shape: 4 MFMAs 32x32x2 (256 cycles) per ds_read_b128
+            for (int m = 0; m < 4; ++m) acc32[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0[0][m], b, acc32[m], 0, 0, 0);
+        } else {
+            for (int m = 0; m < 16; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0[m >> 2][m & 3], b, acc[m], 0, 0, 0);
+        }
+        FENCE();
+        for (int q = 0; q < (SHAPE32 ? 1 : 4); ++q) c0[q] = lp[64 * q + ro + 256];
+        FENCE();
+        if (SHAPE32) {
+            for (int m = 0; m < 4; ++m) acc32[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1[0][m], b, acc32[m], 0, 0, 0);
+        } else {
+            for (int m = 0; m < 16; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1[m >> 2][m & 3], b, acc[m], 0, 0, 0);
+        }
+        FENCE();
+    }
+    unsigned long long t1 = clock64();
+    float r = 0;
+    for (int i = 0; i < 16; ++i) r += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    for (int i = 0; i < 4; ++i)
+        for (int c = 0; c < 16; ++c) r += acc32[i][c];
+    if (r == 12345.f) out[threadIdx.x] = r;
+    if (lane == 0) cyc[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+template <int WAVES, int SHAPE32>
+static void runmock(const char* name) {
+    const int grid = 256, iters = 40000;
+    float* out;
+    unsigned long long* cyc;
+    hipMalloc(&out, 1 << 20);
+    hipMalloc(&cyc, (size_t)grid * 16 * 8);
+    hipFuncSetAttribute((const void*)kmock<WAVES, SHAPE32>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL((kmock<WAVES, SHAPE32>), dim3(grid), dim3(64 * WAVES), 65536, 0, out, cyc, iters / 8, 2.0f);
+    hipDeviceSynchronize();
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((kmock<WAVES, SHAPE32>), dim3(grid), dim3(64 * WAVES), 65536, 0, out, cyc, iters, 2.0f);
+    hipEventRecord(e1, 0);
+    hipDeviceSynchronize();
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double mfma_flop = SHAPE32 ? 4.0 * 4096.0 : 16.0 * 2048.0;
+    const double tf = (double)grid * WAVES * iters * mfma_flop / (ms * 1e-3) / 1e12;
+    printf("%-64s %8.3f ms  %7.1f TFLOP/s = %5.1f %% of 157.3\n", name, ms, tf, tf / 1.573);
+    hipFree(out);
+    hipFree(cyc);
+}
+
 template <class K>
 static void run(const char* name, K kern, int grid, int iters, int mfma_per_iter, double flop_per_mfma) {
     float* out;
@@ -298,6 +371,11 @@ int main() {
     runx<9, 2>("global_load_lds_dwordx4");
     runx<9, 4>("global_load_lds_dwordx4");
     runx<8, 8>("v_readfirstlane + s_add");
+    runmock<4, 1>("mock layer loop: 32x32x2, 1 wave/SIMD, 1 ds_read_b128 / 4 MFMA (today)");
+    runmock<8, 1>("mock layer loop: 32x32x2, 2 waves/SIMD (if registers allowed)");
+    runmock<4, 0>("mock layer loop: 16x16x4, 1 wave/SIMD, 4 ds_read_b128 / 16 MFMA");
+    runmock<8, 0>("mock layer loop: 16x16x4, 2 waves/SIMD");
+    runmock<12, 0>("mock layer loop: 16x16x4, 3 waves/SIMD");
     runx<23, 4>("STAGGERED ds_read_b128 (prefetched) + 8 v_add");
     runx<23, 2>("STAGGERED ds_read_b128 (prefetched) + 4 v_add");
     runx<22, 8>("STAGGERED ds_read_b32 (prefetched) + 8 v_add");

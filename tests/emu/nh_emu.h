@@ -122,6 +122,35 @@ NH_DEVICE f32x16 nh_mfma32(float a, float b, f32x16 c) {
     return d;
 }
 
+// v_mfma_f32_16x16x4_f32: lane l supplies A[l&15][l>>4] and B[l>>4][l&15]; result register c of lane l is
+// D[4*(l>>4)+c][l&15]; the sum over k is a k-ordered fmaf chain.
+NH_DEVICE f32x4 nh_mfma16(float a, float b, f32x4 c) {
+    emu::WaveState& w = emu::cur_wave();
+    int ph = emu::cur->xphase;
+    emu::cur->xphase ^= 1;
+    int lane = emu::cur->lane;
+    uint64_t ra = 0, rb = 0;
+    memcpy(&ra, &a, 4);
+    memcpy(&rb, &b, 4);
+    w.xa[ph][lane] = ra;
+    w.xb[ph][lane] = rb;
+    emu::wave_barrier();
+    int j = lane & 15, g = lane >> 4;
+    f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        int i = 4 * g + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) {
+            float av, bv;
+            memcpy(&av, &w.xa[ph][i + 16 * k], 4);
+            memcpy(&bv, &w.xb[ph][j + 16 * k], 4);
+            acc = fmaf(av, bv, acc);
+        }
+        d[r] = acc;
+    }
+    return d;
+}
+
 NH_DEVICE void nh_atomic_add(float* p, float v) { *p += v; }
 NH_DEVICE void nh_glds16(const float* g, float* lds_wave_base) { memcpy(lds_wave_base + 4 * emu::cur->lane, g, 16); }
 struct NhDmaSrc {

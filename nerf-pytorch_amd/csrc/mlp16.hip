@@ -9,8 +9,7 @@
 //
 // Layout (nh_plan.h, "v16"): lane l = (sample j = l & 15, k-group g = l >> 4); register r of an activation holds feature
 // feat16(r,g) = 16*(r>>2) + 4*g + (r&3) -- the C/D layout of the instruction -- and k-step r of the next layer takes
-// register r as its B operand, so activations never leave the register file (as in mlp.hip).  A workgroup is 8 waves =
-// 128 samples.  Weights stream L2 -> LDS by LDS-DMA in K-chunks that cover all output tiles ([k-step][quad][lane][4]:
+// register r as its B operand, so activations never leave the register file (as in mlp.hip).  Weights stream L2 -> LDS by LDS-DMA in K-chunks that cover all output tiles ([k-step][quad][lane][4]:
 // one ds_read_b128 = the A operands of four 16-row tiles), double buffered, one barrier per chunk.
 // The stash / gradient images keep the [32-sample tile][sample][rows] format of mlp.hip (two waves fill one tile), so
 // the weight-gradient kernel is shared.
@@ -20,19 +19,38 @@
 
 namespace {
 
-constexpr int NW = 8;                                          // waves per workgroup
-constexpr int CHUNK_MAX = 8 * 5 * 256;                         // floats of the largest chunk (8 k-steps x 5 quads)
+// A workgroup is 4 waves (one per SIMD) = 64 samples, and TWO workgroups share a CU (<= 256 registers per wave, 68 KB of
+// LDS each): the two waves of a SIMD then belong to different workgroups with their own barriers, so they drift out of
+// phase and one's layer epilogues, stores and barrier waits overlap the other's MFMAs (8-wave workgroups ran in lock
+// step: measured 6 % slower).
+constexpr int NW = 4;                                          // waves per workgroup
+constexpr int CHUNK_MAX = 8192;                                // floats of the largest chunk (32 KB)
 constexpr int LDS_FLOATS = 2 * CHUNK_MAX + 2 * NH16_BIAS_FLOATS;
-constexpr int LDS_BYTES = LDS_FLOATS * 4;                      // 84 KB
+constexpr int LDS_BYTES = LDS_FLOATS * 4;                      // 68 KB
+
+#ifdef NH_PHASE_TIMING
+__device__ unsigned long long g_phase16[16];
+#define NH16_PH(i)                                \
+    do {                                          \
+        const unsigned long long _t = clock64();  \
+        cx.ph[i] += _t - cx.last;                 \
+        cx.last = _t;                             \
+    } while (0)
+#else
+#define NH16_PH(i)
+#endif
 
 struct Ctx {
+#ifdef NH_PHASE_TIMING
+    unsigned long long ph[5], last;  // debug build: cycles per phase, accumulated per wave
+#endif
     float* lds;
     NhDmaSrc dma;  // descriptor over the whole packed image
     int buf, bbuf;  // chunk / bias buffer of the unit being consumed
     int wave, lane, g;
     NH_MEMBER float* chunk(int b) const { return lds + b * CHUNK_MAX; }
     NH_MEMBER float* bias(int b) const { return lds + 2 * CHUNK_MAX + b * NH16_BIAS_FLOATS; }
-    // LDS-DMA of nfloats (a multiple of 256) from float offset `off` of the packed image; piece q by wave q % 8
+    // LDS-DMA of nfloats (a multiple of 256) from float offset `off` of the packed image; piece q by wave q % NW
     NH_MEMBER void copy(int64_t off, int nfloats, float* dst) const {
         const int np = nfloats >> 8;
         const int soff = (int)off * 4;
@@ -48,7 +66,7 @@ struct Ctx {
 template <int KR, int T>
 struct Geo {
     static constexpr int TQ = (T + 3) / 4;
-    static constexpr int KC = TQ <= 1 ? 32 : (TQ == 2 ? 16 : 8);
+    static constexpr int KC = TQ <= 1 ? 32 : (TQ == 2 ? 16 : (TQ <= 4 ? 8 : 4));
     static constexpr int NCH = (KR + KC - 1) / KC;
     static constexpr int FIRST = (KR < KC ? KR : KC) * TQ * 256;  // floats of chunk 0
     static_assert(KC * TQ * 256 <= CHUNK_MAX, "chunk too large for the LDS buffer");
@@ -57,9 +75,10 @@ struct Geo {
 // One linear layer for the 16 samples of this wavefront: acc[t] (16 rows x 16 samples) = W_t * in + bias_t, t < T.
 // Precondition: the layer's first unit has been requested into chunk(buf) / bias(bbuf).  While chunk c is multiplied,
 // chunk c+1 -- or the first unit of the next layer (next_first > 0) -- travels to the other buffer.
-// `post` holds the global stores of the PREVIOUS layer's results (stash rows, masks): it runs right after this
-// layer's first barrier, so the stores drain under the MFMAs instead of sitting in front of a vmcnt(0) (CDNA4's vmcnt
-// counts stores too; the values stored are this layer's input registers, still live).
+// `post(c, NCH)` holds the global stores of the PREVIOUS layer's results (stash rows, masks), cut into NCH shares: share
+// c is issued right after the barrier that starts chunk c, so the stores are spread over the whole layer and drain
+// under the MFMAs instead of sitting in front of a vmcnt(0) (CDNA4's vmcnt counts stores too; the values stored are
+// this layer's input registers, still live).
 template <int KRA, int KRB, int T, class Post>
 NH_DEVICE void gemm16(Ctx& cx, const float* inA, const float* inB, int64_t img_off, int64_t next_off, int next_first,
                       f32x4* acc, Post&& post) {
@@ -71,16 +90,19 @@ NH_DEVICE void gemm16(Ctx& cx, const float* inA, const float* inB, int64_t img_o
         constexpr int dummy = 0;
         (void)dummy;
         const int kc = (KR - c * KC) < KC ? (KR - c * KC) : KC;
+        NH16_PH(4);  // [4] between gemms / chunks: epilogue, stores, loop control
         nh_wait_vmem();
+        NH16_PH(2);  // [2] s_waitcnt vmcnt(0)
         nh_block_sync();  // chunk c has landed for every wave; everybody is done with the other buffer
+        NH16_PH(3);  // [3] s_barrier
         if (c + 1 < NCH) {
             const int kn = (KR - (c + 1) * KC) < KC ? (KR - (c + 1) * KC) : KC;
             cx.copy(img_off + NH16_BIAS_FLOATS + (int64_t)(c + 1) * KC * TQ * 256, kn * TQ * 256, cx.chunk(cx.buf ^ 1));
         } else if (next_first > 0) {
             cx.copy_first(next_off, next_first, cx.buf ^ 1, cx.bbuf ^ 1);
         }
+        post(c, NCH);
         if (c == 0) {
-            post();
             const float* bp = cx.bias(cx.bbuf) + 4 * cx.g;
 #pragma unroll
             for (int t = 0; t < T; ++t) {
@@ -91,7 +113,9 @@ NH_DEVICE void gemm16(Ctx& cx, const float* inA, const float* inB, int64_t img_o
                 acc[t][3] = b4.w;
             }
         }
+        NH16_PH(0);  // [0] copy issue + previous layer's stores + bias
         const float4* wp = (const float4*)cx.chunk(cx.buf) + cx.lane;
+        // A operands run one k-step ahead of the MFMAs (two k-steps ahead measured no better and costs 16 registers)
         float4 a[2][TQ];
 #pragma unroll
         for (int q = 0; q < TQ; ++q) a[0][q] = wp[q * 64];
@@ -113,6 +137,7 @@ NH_DEVICE void gemm16(Ctx& cx, const float* inA, const float* inB, int64_t img_o
                 }
             }
         }
+        NH16_PH(1);  // [1] operand reads + MFMAs
         cx.buf ^= 1;
     }
     cx.bbuf ^= 1;
@@ -133,12 +158,13 @@ NH_DEVICE void finish(const f32x4* acc, float* act, bool relu, unsigned* bits_ou
     }
 }
 
-// rows feat16(4t.., g) = 16t + 4g .. +3 of this lane's sample: one 16-byte store per tile
+// rows feat16(4t.., g) = 16t + 4g .. +3 of this lane's sample: one 16-byte store per tile; share c of nch (all: 0 of 1)
 template <int T>
-NH_DEVICE void store_rows(float* __restrict__ row, const float* act, int g) {
+NH_DEVICE void store_rows(float* __restrict__ row, const float* act, int g, int c = 0, int nch = 1) {
     if (!row) return;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
+        if (t * nch / T != c) continue;
         float4 x;
         x.x = act[4 * t + 0];
         x.y = act[4 * t + 1];
@@ -149,8 +175,8 @@ NH_DEVICE void store_rows(float* __restrict__ row, const float* act, int g) {
 }
 // encoding slots: register r of lane (j,g) is row g*KR + r
 template <int KR>
-NH_DEVICE void store_slots(float* __restrict__ row, const float* e, int g) {
-    if (!row) return;
+NH_DEVICE void store_slots(float* __restrict__ row, const float* e, int g, int c = 0) {
+    if (!row || c != 0) return;
 #pragma unroll
     for (int q = 0; q < KR / 4; ++q) {
         float4 x;
@@ -223,8 +249,12 @@ NH_KERNEL void NH_LB(64 * NW, 2) k_mlp_fwd16(Fwd16Args a) {
     cx.lane = nh_lane();
     cx.wave = nh_wave_in_block();
     cx.g = cx.lane >> 4;
+#ifdef NH_PHASE_TIMING
+    for (int q = 0; q < 5; ++q) cx.ph[q] = 0;
+    cx.last = clock64();
+#endif
     const int lane = cx.lane, g = cx.g, j = lane & 15, wave = cx.wave;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + (wave >> 1);  // 32-sample stash tile
+    const int64_t tile = (int64_t)blockIdx.x * (NW / 2) + (wave >> 1);  // 32-sample stash tile
     const int js = 16 * (wave & 1) + j;                         // this lane's sample inside it
     const int64_t m = tile * 32 + js;
     const bool valid = m < a.M;
@@ -281,9 +311,9 @@ NH_KERNEL void NH_LB(64 * NW, 2) k_mlp_fwd16(Fwd16Args a) {
         const bool more = a.L > 1;
         // layers_xyz[0] is never a skip layer (i > 0 is required); no activation after layer1 (models.py:238)
         gemm16<KX, 0, TW>(cx, ex, nullptr, po.f_layer1, more ? po.f_xyz[0] : po.f_head,
-                          more ? Geo<KH, TW>::FIRST : (VIEW ? Geo<KH, TW + 1>::FIRST : Geo<KH, 1>::FIRST), acc, [&] {
-                              store_slots<KX>(srow(a.sl.X), ex, g);
-                              if (VIEW) store_slots<KD>(srow(a.sl.D), ed, g);
+                          more ? Geo<KH, TW>::FIRST : (VIEW ? Geo<KH, TW + 1>::FIRST : Geo<KH, 1>::FIRST), acc, [&](int c, int) {
+                              store_slots<KX>(srow(a.sl.X), ex, g, c);
+                              if (VIEW) store_slots<KD>(srow(a.sl.D), ed, g, c);
                           });
         finish<TW>(acc, act, false, bits, false, bits, false);
     }
@@ -295,9 +325,9 @@ NH_KERNEL void NH_LB(64 * NW, 2) k_mlp_fwd16(Fwd16Args a) {
         const int64_t nxt = more ? po.f_xyz[i + 1] : po.f_head;
         const int nfirst = more ? (nsk ? Geo<KH + KX, TW>::FIRST : Geo<KH, TW>::FIRST)
                                 : (VIEW ? Geo<KH, TW + 1>::FIRST : Geo<KH, 1>::FIRST);
-        auto post = [&] {
-            put_mask(i - 1);  // H_i (none for H_0)
-            store_rows<TW>(srow(a.sl.H[i]), act, g);
+        auto post = [&](int c, int nch) {
+            if (c == 0) put_mask(i - 1);  // H_i (none for H_0)
+            store_rows<TW>(srow(a.sl.H[i]), act, g, c, nch);
         };
         if (sk)
             gemm16<KH, KX, TW>(cx, act, ex, po.f_xyz[i], nxt, nfirst, acc, post);
@@ -306,9 +336,9 @@ NH_KERNEL void NH_LB(64 * NW, 2) k_mlp_fwd16(Fwd16Args a) {
         bits[0] = bits[1] = 0u;
         finish<TW>(acc, act, true, bits, tr, bits, false);
     }
-    auto post_last_hidden = [&] {
-        put_mask(a.L - 2);  // H_{L-1}
-        store_rows<TW>(srow(a.sl.H[a.L - 1]), act, g);
+    auto post_last_hidden = [&](int c, int nch) {
+        if (c == 0) put_mask(a.L - 2);  // H_{L-1}
+        store_rows<TW>(srow(a.sl.H[a.L - 1]), act, g, c, nch);
     };
     if (VIEW) {
         // tiles 0..TW-1: feat = relu(fc_feat(h)); tile TW row 0: fc_alpha(h), raw (models.py:248-249)
@@ -317,15 +347,15 @@ NH_KERNEL void NH_LB(64 * NW, 2) k_mlp_fwd16(Fwd16Args a) {
         bits[0] = bits[1] = 0u;
         finish<TW>(acc, act, true, bits, tr, bits, false);
         float dh[KH / 2];
-        gemm16<KH, KD, TW / 2>(cx, act, ed, po.f_dir, po.f_rgb, Geo<KH / 2, 1>::FIRST, acc, [&] {
-            put_mask(a.L - 1);
-            store_rows<TW>(srow(a.sl.FEAT), act, g);
+        gemm16<KH, KD, TW / 2>(cx, act, ed, po.f_dir, po.f_rgb, Geo<KH / 2, 1>::FIRST, acc, [&](int c, int nch) {
+            if (c == 0) put_mask(a.L - 1);
+            store_rows<TW>(srow(a.sl.FEAT), act, g, c, nch);
         });
         bits[0] = bits[1] = 0u;
         finish<TW / 2>(acc, dh, true, bits, tr, bits, false);
-        gemm16<KH / 2, 0, 1>(cx, dh, nullptr, po.f_rgb, 0, 0, acc, [&] {
-            put_mask(a.L);
-            store_rows<TW / 2>(srow(a.sl.DIRH), dh, g);
+        gemm16<KH / 2, 0, 1>(cx, dh, nullptr, po.f_rgb, 0, 0, acc, [&](int c, int nch) {
+            if (c == 0) put_mask(a.L);
+            store_rows<TW / 2>(srow(a.sl.DIRH), dh, g, c, nch);
         });
         if (valid && g == 0) {
             float4 r4;
@@ -346,6 +376,11 @@ NH_KERNEL void NH_LB(64 * NW, 2) k_mlp_fwd16(Fwd16Args a) {
             *(float4*)(a.out + (size_t)m * 4) = r4;
         }
     }
+#ifdef NH_PHASE_TIMING
+    NH16_PH(4);
+    if (lane == 0)
+        for (int q = 0; q < 5; ++q) atomicAdd(&g_phase16[q], cx.ph[q]);
+#endif
 }
 
 // ---- data-gradient chain ---------------------------------------------------------------------------------------------
@@ -373,8 +408,12 @@ NH_KERNEL void NH_LB(64 * NW, 2) k_mlp_dgrad16(Dgrad16Args a) {
     cx.lane = nh_lane();
     cx.wave = nh_wave_in_block();
     cx.g = cx.lane >> 4;
+#ifdef NH_PHASE_TIMING
+    for (int q = 0; q < 5; ++q) cx.ph[q] = 0;
+    cx.last = clock64();
+#endif
     const int lane = cx.lane, g = cx.g, j = lane & 15, wave = cx.wave;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + (wave >> 1);
+    const int64_t tile = (int64_t)blockIdx.x * (NW / 2) + (wave >> 1);
     const int js = 16 * (wave & 1) + j;
     const int64_t m = tile * 32 + js;
     const bool valid = m < a.M;
@@ -389,7 +428,8 @@ NH_KERNEL void NH_LB(64 * NW, 2) k_mlp_dgrad16(Dgrad16Args a) {
     float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
     if (valid) go = *(const float4*)(a.g_out + (size_t)m * 4);
     auto grow = [&](const NhRegion& R) -> float* { return region_row(a.grad, R, a.nt, tile, js); };
-    auto store_pout = [&] {
+    auto store_pout = [&](int c, int) {
+        if (c != 0) return;
         // POUT (32 rows): rows 0..2 d(rgb raw), row 3 d(sigma raw), rows 4..31 zero; group g writes rows 8g..8g+7
         float* po_row = grow(a.gl.POUT) + 8 * g;
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -418,13 +458,13 @@ NH_KERNEL void NH_LB(64 * NW, 2) k_mlp_dgrad16(Dgrad16Args a) {
         finish<TW / 2>(acc, dpd, false, nobits, false, mb, true);
         get_mask(L - 1);  // FEAT
         gemm16<KH / 2, 0, TW>(cx, dpd, nullptr, po.b_dir, po.b_head, Geo<KH + 1, TW>::FIRST, acc,
-                              [&] { store_rows<TW / 2>(grow(a.gl.PDIR), dpd, g); });
+                              [&](int c, int nch) { store_rows<TW / 2>(grow(a.gl.PDIR), dpd, g, c, nch); });
         finish<TW>(acc, dp, false, nobits, false, mb, true);
         if (L > 1) get_mask(L - 2);  // H_{L-1}
         float da[1];
         da[0] = g == 0 ? go.w : 0.0f;  // d(sigma raw) enters through fc_alpha's row (k-step KH, group 0)
         gemm16<KH, 1, TW>(cx, dp, da, po.b_head, L > 1 ? po.b_xyz[L - 2] : 0, L > 1 ? Geo<KH, TW>::FIRST : 0, acc,
-                          [&] { store_rows<TW>(grow(a.gl.PFEAT), dp, g); });
+                          [&](int c, int nch) { store_rows<TW>(grow(a.gl.PFEAT), dp, g, c, nch); });
         finish<TW>(acc, dp, false, nobits, false, mb, L > 1);
     } else {
         float d1[1];
@@ -440,10 +480,15 @@ NH_KERNEL void NH_LB(64 * NW, 2) k_mlp_dgrad16(Dgrad16Args a) {
         const bool masked = k - 1 >= 1;
         if (masked) get_mask(k - 2);  // H_{k-1}
         gemm16<KH, 0, TW>(cx, dp, nullptr, po.b_xyz[k - 1], k >= 2 ? po.b_xyz[k - 2] : 0, k >= 2 ? Geo<KH, TW>::FIRST : 0, acc,
-                          [&] { store_rows<TW>(grow(a.gl.P[k]), dp, g); });
+                          [&](int c, int nch) { store_rows<TW>(grow(a.gl.P[k]), dp, g, c, nch); });
         finish<TW>(acc, dp, false, nobits, false, mb, masked);
     }
     store_rows<TW>(grow(a.gl.P[0]), dp, g);
+#ifdef NH_PHASE_TIMING
+    NH16_PH(4);
+    if (lane == 0)
+        for (int q = 0; q < 5; ++q) atomicAdd(&g_phase16[8 + q], cx.ph[q]);
+#endif
 }
 
 template <class K>
@@ -461,6 +506,17 @@ int lds_limit(K kern) {
 }
 
 }  // namespace
+
+#ifdef NH_PHASE_TIMING
+extern "C" int nerfhip_debug_phases16(unsigned long long* host16, int reset) {
+    (void)hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_phase16), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase16), z, sizeof(z));
+    }
+    return 0;
+}
+#endif
 
 int nh_mlp16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
                      nerfhip_stream_t stream) {
@@ -494,7 +550,7 @@ int nh_mlp16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in,
     a.out = out;
     a.stash = stash;
     a.sl = p->stash;
-    const int64_t grid = nh_ceil_div(M, 128);
+    const int64_t grid = nh_ceil_div(M, 128) * (128 / (16 * NW));  // whole 128-sample groups: every stash tile is written
     int rc = NERFHIP_OK;
 #define NH_FWD16(WW, VV)                                                              \
     {                                                                                 \
@@ -525,7 +581,7 @@ int nh_mlp16_dgrad(nerfhip_plan* p, const float* packed, const float* g_out, int
     d.sl = p->stash;
     d.grad = scratch;
     d.gl = p->grad;
-    const int64_t grid = nh_ceil_div(M, 128);
+    const int64_t grid = nh_ceil_div(M, 128) * (128 / (16 * NW));  // whole 128-sample groups: every stash tile is written
     int rc = NERFHIP_OK;
 #define NH_BWD16(WW, VV)                                                              \
     {                                                                                 \

@@ -60,17 +60,33 @@ NH_DEVICE void nh_glds16(const float* g, float* lds_wave_base) {
 // The same copy through a buffer descriptor: source = desc.base + soff (wave-uniform, SGPR) + voff (per lane), all in
 // bytes.  One piece costs two scalar adds + buffer_load_dwordx4 ... offen lds -- no VALU address arithmetic -- and
 // bytes beyond `bytes` are bounds-checked away by the descriptor instead of faulting.
+// The copy is issued through inline assembly ON PURPOSE: when the compiler sees an LDS-DMA it cannot prove that later
+// ds_reads of the same LDS array do not alias its destination, and inserts s_waitcnt vmcnt(0) in front of the first
+// ds_read that follows -- which exposes the whole copy latency in every chunk of a double-buffered pipeline (seen in
+// the ISA of the 16x16x4 kernels).  The kernels order DMA completion themselves: nh_wait_vmem() + barrier before any
+// wave reads the buffer.  (Untracked VMEM operations only make the compiler's own vmcnt waits more conservative.)
+typedef int nh_i32x4 __attribute__((ext_vector_type(4)));
 struct NhDmaSrc {
-    __amdgpu_buffer_rsrc_t r;
+    nh_i32x4 r;  // raw buffer descriptor: base, stride 0, num_records = bytes, flags
 };
 NH_DEVICE NhDmaSrc nh_dma_src(const float* base, unsigned bytes) {
     NhDmaSrc s;
-    s.r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+    const unsigned long long b = (unsigned long long)base;
+    s.r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    s.r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((b >> 32) & 0xFFFFu));
+    s.r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    s.r[3] = 0x00020000;
     return s;
 }
 NH_DEVICE void nh_dma16(const NhDmaSrc& s, int voff, int soff, float* lds_wave_base) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(s.r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0,
-                                             0);
+    const unsigned m0v = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_wave_base;
+    asm volatile(
+        "s_mov_b32 m0, %0\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen lds"
+        :
+        : "s"(__builtin_amdgcn_readfirstlane((int)m0v)), "v"(voff), "s"(s.r), "s"(__builtin_amdgcn_readfirstlane(soff))
+        : "memory");  // M0 is a reserved register: the compiler never keeps a live value in it across statements
 }
 NH_DEVICE void nh_wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // nothing is scheduled across this point (pins "issue the prefetch BEFORE the MFMAs")

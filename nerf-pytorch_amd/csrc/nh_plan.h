@@ -28,20 +28,19 @@ constexpr int NH_MAX_JOBS = 48;
 static inline int nh_feat(int r, int h) { return 32 * (r >> 4) + (r & 3) + 8 * ((r >> 2) & 3) + 4 * h; }
 
 // ---- "v16" layout: forward / data-gradient kernels on v_mfma_f32_16x16x4_f32 (mlp16.hip) -----------------------------
-//   * a wavefront owns 16 sample points; lane l = (j = l & 15: sample, g = l >> 4: k-group); a workgroup is 8 waves
-//     (two per SIMD) = 128 samples = four 32-sample stash tiles (wave w: tile w >> 1, samples 16*(w & 1) ..);
+//   * a wavefront owns 16 sample points; lane l = (j = l & 15: sample, g = l >> 4: k-group); a workgroup is 4 waves
+//     = 64 samples = two 32-sample stash tiles (wave w: tile w >> 1, samples 16*(w & 1) ..), two workgroups per CU;
 //   * an activation of F features lives in F/4 registers per lane: register r of lane (j,g) holds feature
 //       feat16(r,g) = 16*(r>>2) + 4*g + (r&3)
 //     = the C/D layout of the instruction (tile r>>2, register r&3), and k-step r of the next layer consumes exactly
 //     register r as its B operand (B[k=g][j]);
 //   * encodings: xyz 16 registers = 64 slots, dir 8 registers = 32 slots; slot rows are numbered g*KR + r;
-//   * a layer image is [bias: 512 floats][chunks]: a chunk covers KC consecutive k-steps for ALL output tiles,
-//     [k-step][quad of 4 tiles][64 lanes][4 floats], so one ds_read_b128 yields the A operands of 4 tiles.
+//   * a layer image is [bias: 512 floats][k-step][quad of 4 output tiles][64 lanes][4 floats]: one ds_read_b128 yields
+//     the A operands of 4 tiles; the kernel streams it in chunks of a few k-steps covering ALL output tiles.
 constexpr int NH16_KRX = 16;
 constexpr int NH16_KRD = 8;
 static inline int nh_feat16(int r, int g) { return 16 * (r >> 2) + 4 * g + (r & 3); }
 static inline int nh16_tq(int tiles) { return (tiles + 3) / 4; }
-static inline int nh16_kc(int tiles) { return nh16_tq(tiles) <= 1 ? 32 : (nh16_tq(tiles) == 2 ? 16 : 8); }
 constexpr int NH16_BIAS_FLOATS = 512;
 static inline int64_t nh16_image_floats(int kr, int tiles) { return NH16_BIAS_FLOATS + (int64_t)kr * nh16_tq(tiles) * 256; }
 // floats of one packed weight chunk (one 32-row output tile): kr*64 weights + 32 biases padded to 256, so that a

@@ -309,6 +309,61 @@ static void runmock(const char* name) {
     hipFree(cyc);
 }
 
+// the same mock with the A operands prefetched TWO k-steps ahead (3-deep register ring)
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void kmock3(float* out, unsigned long long* cyc, int iters, float b0) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    for (int i = threadIdx.x; i < 16384; i += 64 * WAVES) lds[i] = (float)(i & 7);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const f32x4* lp = (const f32x4*)lds + lane;
+    f32x4 acc[16];
+    for (int i = 0; i < 16; ++i) acc[i] = f32x4{0, 0, 0, 0};
+    float b = b0;
+    f32x4 c[3][4];
+    for (int q = 0; q < 4; ++q) c[0][q] = lp[64 * q], c[1][q] = lp[64 * q + 256];
+    unsigned long long t0 = clock64();
+    for (int it = 0; it < iters; it += 3) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int ro = (((it + u) & 7) + 2) << 8;
+            for (int q = 0; q < 4; ++q) c[(u + 2) % 3][q] = lp[64 * q + ro];
+            FENCE();
+            for (int m = 0; m < 16; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(c[u][m >> 2][m & 3], b, acc[m], 0, 0, 0);
+            FENCE();
+        }
+    }
+    unsigned long long t1 = clock64();
+    float r = 0;
+    for (int i = 0; i < 16; ++i) r += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (r == 12345.f) out[threadIdx.x] = r;
+    if (lane == 0) cyc[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;
+}
+template <int WAVES>
+static void runmock3(const char* name) {
+    const int grid = 256, iters = 39999;
+    float* out;
+    unsigned long long* cyc;
+    hipMalloc(&out, 1 << 20);
+    hipMalloc(&cyc, (size_t)grid * 16 * 8);
+    hipFuncSetAttribute((const void*)kmock3<WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL((kmock3<WAVES>), dim3(grid), dim3(64 * WAVES), 65536, 0, out, cyc, iters / 9, 2.0f);
+    hipDeviceSynchronize();
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((kmock3<WAVES>), dim3(grid), dim3(64 * WAVES), 65536, 0, out, cyc, iters, 2.0f);
+    hipEventRecord(e1, 0);
+    hipDeviceSynchronize();
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double tf = (double)grid * WAVES * iters * 16.0 * 2048.0 / (ms * 1e-3) / 1e12;
+    printf("%-64s %8.3f ms  %7.1f TFLOP/s = %5.1f %% of 157.3\n", name, ms, tf, tf / 1.573);
+    hipFree(out);
+    hipFree(cyc);
+}
+
 template <class K>
 static void run(const char* name, K kern, int grid, int iters, int mfma_per_iter, double flop_per_mfma) {
     float* out;
@@ -376,6 +431,8 @@ int main() {
     runmock<4, 0>("mock layer loop: 16x16x4, 1 wave/SIMD, 4 ds_read_b128 / 16 MFMA");
     runmock<8, 0>("mock layer loop: 16x16x4, 2 waves/SIMD");
     runmock<12, 0>("mock layer loop: 16x16x4, 3 waves/SIMD");
+    runmock3<4>("mock layer loop: 16x16x4, 1 wave/SIMD, operands 2 k-steps ahead");
+    runmock3<8>("mock layer loop: 16x16x4, 2 waves/SIMD, operands 2 k-steps ahead");
     runx<23, 4>("STAGGERED ds_read_b128 (prefetched) + 8 v_add");
     runx<23, 2>("STAGGERED ds_read_b128 (prefetched) + 4 v_add");
     runx<22, 8>("STAGGERED ds_read_b32 (prefetched) + 8 v_add");

@@ -35,6 +35,20 @@ for _ in range(3):
     eng.step(rays, tgt)
 torch.cuda.synchronize()
 dbg(buf, 0)
+if os.environ.get("NERFHIP_MLP") == "16":
+    dbg16 = lib._dll.nerfhip_debug_phases16
+    dbg16.argtypes = [C.c_void_p, C.c_int]
+    b16 = (C.c_ulonglong * 16)()
+    dbg16(b16, 0)
+    n16 = ["0 copy issue + stores + bias", "1 operand reads + MFMAs", "2 s_waitcnt vmcnt(0)", "3 s_barrier", "4 between gemms (epilogue, encodings)"]
+    # MFMA cycles one wave issues per launch pair (coarse+fine), to compare with phase 1
+    for base, k in ((0, "k_mlp_fwd16"), (8, "k_mlp_dgrad16")):
+        v = [b16[base + i] for i in range(5)]
+        tot = float(sum(v))
+        print(k, "total wave-cycles %.3e (5 steps incl. warm-up)" % tot)
+        for i in range(5):
+            print("   %-44s %6.2f %%" % (n16[i], 100.0 * v[i] / tot))
+    sys.exit(0)
 names = ["0 dma-issue+prev-stores+inter-layer", "1 bias/operand reads + MFMA issue", "2 epilogue (drains last MFMA)",
          "3 s_waitcnt vmcnt(0)", "4 s_barrier", "5 kernel tail"]
 for base, k in ((0, "k_mlp_fwd"), (8, "k_mlp_dgrad")):

@@ -369,3 +369,16 @@ def test_python_api_select_step_resume_and_writer(tmp_path):
         n = int.from_bytes(data[33:37], "big")
         raw = np.frombuffer(zlib.decompress(data[41:41 + n]), np.uint8).reshape(want8.shape[0], -1)
         assert np.array_equal(raw[:, 1:].reshape(want8.shape), want8)
+
+
+# ---- the 16x16x4 kernel family (mlp16.hip; plans created with NERFHIP_MLP=16) -------------------------------------------
+def test_v16_mlp_and_render_parity(gpu, monkeypatch):
+    monkeypatch.setenv("NERFHIP_MLP", "16")
+    P.case_mlp_forward(gpu)
+    P.case_mlp_golden(gpu)
+    P.case_mlp_backward(gpu, names=("default4x128", "deep8x128_skip4", "fern8x128_skip3_L6", "novw4x128", "northstar8x256"),
+                        m=1500)
+    for name in ("e2e_a.npz", "e2e_b.npz", "e2e_c.npz", "e2e_d.npz"):
+        P.case_e2e_golden(gpu, name)
+    P.case_render_vs_oracle(gpu, P.MLP_GEOMETRIES["northstar8x256"], n=48, nc=64, nf=128, with_grads=True)
+    P.case_internal_rng(gpu)

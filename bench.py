@@ -147,13 +147,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook (scripts/gpu_dp2_smoke.sh): exercise the N > 1 code path on a ONE-GPU box -- every rank on cuda:0 and a
+    # gloo process group (RCCL refuses two ranks on one device).  Never set by the driver.
+    one_device = os.environ.get("NERFHIP_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        if one_device:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=dev)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     cfg = dict(MODEL, hidden_size=args.hidden, num_layers=args.layers)

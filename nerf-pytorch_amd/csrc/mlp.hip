@@ -649,44 +649,48 @@ NH_DEVICE void wstep_load(WStep<PO, PI>& o, const float* pa, const float* pb) {
 #pragma unroll
     for (int y = 0; y < PI; ++y) o.B[y] = pb[32 * y];
 }
-template <int PO, int PI>
+template <int PO, int PI, bool BIAS>
 NH_DEVICE void wstep_mfma(const WStep<PO, PI>& o, f32x16 (&acc)[PO][PI], float (&bsum)[PO]) {
 #pragma unroll
     for (int x = 0; x < PO; ++x) {
-        bsum[x] += o.A[x];
+        if (BIAS) bsum[x] += o.A[x];
 #pragma unroll
         for (int y = 0; y < PI; ++y) acc[x][y] = nh_mfma32(o.A[x], o.B[y], acc[x][y]);
     }
 }
 
-// One stage copy, cut into 1-KiB pieces (one DMA instruction each): block A (ntile * a_fl floats) -> buf[0 ..), block B
-// (ntile * b_fl floats) -> buf[g * a_fl ..).  Wave w issues pieces w, w+8, ...; `issue(n)` emits the next n of them, so
-// that the copy of stage n+1 is spread over the MFMA groups of stage n.
+// One stage copy, cut into 1-KiB pieces (one DMA instruction each): block A (ntile * a_fl floats) -> stage[0 ..), block
+// B (ntile * b_fl floats) -> stage[g * a_fl ..).  Wave w issues pieces w, w+8, ...; `issue(n)` emits the next n of
+// them, so that the copy of stage n+1 is spread over the MFMA groups of stage n.  LDS destinations are byte addresses.
 struct WStageDma {
     NhDmaSrc sa, sb;
-    float* buf;
+    unsigned dst;  // LDS byte address of the stage
     int pa, ptot, boff, q, lane16;
-    NH_MEMBER void init(const float* ga, const float* gb, int a_fl, int b_fl, int ntile, int g, float* dst, int wave, int lane) {
+    NH_MEMBER void init(const float* ga, const float* gb, int a_fl, int b_fl, int ntile, int g, unsigned stage_addr, int wave,
+                        int lane) {
         sa = nh_dma_src(ga, (unsigned)(ntile * a_fl * 4));
         sb = nh_dma_src(gb, (unsigned)(ntile * b_fl * 4));
-        buf = dst;
+        dst = stage_addr;
         pa = ntile * a_fl / 256;
         ptot = pa + ntile * b_fl / 256;
-        boff = g * a_fl - pa * 256;  // piece q >= pa lands at buf + g*a_fl + (q - pa)*256
+        boff = (g * a_fl - pa * 256) * 4;  // piece q >= pa lands at stage + (g*a_fl + (q - pa)*256) floats
         q = wave;
         lane16 = lane * 16;
     }
     NH_MEMBER void issue(int n) {
         for (int c = 0; c < n && q < ptot; ++c, q += NH_WG_WAVES) {
             if (q < pa)
-                nh_dma16(sa, lane16, q * 1024, buf + q * 256);
+                nh_dma16a(sa, lane16, q * 1024, dst + q * 1024);
             else
-                nh_dma16(sb, lane16, (q - pa) * 1024, buf + boff + q * 256);
+                nh_dma16a(sb, lane16, (q - pa) * 1024, dst + boff + q * 1024);
         }
     }
 };
 
-template <int PO, int PI>
+// AR / BR: rows of the A / B region when known at compile time (0: read from the job) -- with constant strides the
+// operand addresses of a whole stage are immediates of ONE base register.  BIAS: this wave also forms the bias
+// gradient (row sums of A); only the waves of column iw == 0 do, the others skip the VALU adds.
+template <int PO, int PI, int AR, int BR, bool BIAS>
 NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int64_t t1, int ow, int iw, int wave, int lane,
                           int64_t wg, bool active, float* lds) {
     const int i = lane & 31, k = lane >> 5;
@@ -700,7 +704,8 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
 #pragma unroll
             for (int c = 0; c < 16; ++c) acc[x][y][c] = 0.0f;
     }
-    const int ar = jb.a_rows, br = jb.b_rows, g = jb.g;
+    const int ar = AR ? AR : jb.a_rows, br = BR ? BR : jb.b_rows;
+    const int g = (AR && BR) ? NH_WG_STAGE_FLOATS / (32 * (AR + BR)) : jb.g;
     const int a_fl = 32 * ar, b_fl = 32 * br;
     const float* A0 = a.grad + (size_t)32 * (size_t)a.nt * (size_t)jb.a_prefix;
     const float* B0 = a.stash + (size_t)32 * (size_t)a.nt * (size_t)jb.b_prefix;
@@ -708,11 +713,12 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
     const float* ga = A0 + (size_t)t0 * a_fl;  // stage n+1's blocks (running pointers: one 64-bit add per stage)
     const float* gb = B0 + (size_t)t0 * b_fl;
     int left = (int)(t1 - t0);                 // tiles not yet requested
+    const unsigned lds_addr = nh_lds_addr(lds);
     WStageDma dma;
     dma.ptot = 0;
     if (nstage > 0) {
         const int nt0 = left < g ? left : g;
-        dma.init(ga, gb, a_fl, b_fl, nt0, g, lds, wave, lane);
+        dma.init(ga, gb, a_fl, b_fl, nt0, g, lds_addr, wave, lane);
         dma.issue(1 << 20);
         ga += (size_t)nt0 * a_fl, gb += (size_t)nt0 * b_fl, left -= nt0;
     }
@@ -728,20 +734,35 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
         nh_sched_fence();  // first operand reads leave before the scalar set-up of the next copy
         const int ntn = left < g ? left : g;
         dma.ptot = 0;
-        if (ntn > 0) dma.init(ga, gb, a_fl, b_fl, ntn, g, lds + ((n + 1) & 1) * NH_WG_STAGE_FLOATS, wave, lane);
+        if (ntn > 0)
+            dma.init(ga, gb, a_fl, b_fl, ntn, g, lds_addr + (unsigned)(((n + 1) & 1) * NH_WG_STAGE_FLOATS * 4), wave, lane);
         ga += (size_t)ntn * a_fl, gb += (size_t)ntn * b_fl, left -= ntn;
         if (active) {
-            const int steps = 16 * ntile;  // k-steps of two samples each
-            for (int s = 0; s < steps; s += 2) {
-                pa += 2 * ar, pb += 2 * br;
-                wstep_load(c1, pa, pb);
-                dma.issue(1);  // the next stage streams in underneath the MFMAs (at most 8 pieces per wave and stage)
-                nh_sched_fence();
-                wstep_mfma(c0, acc, bsum);
-                pa += 2 * ar, pb += 2 * br;
-                wstep_load(c0, pa, pb);  // the last one reads one k-step past the stage (slack / other block): unused
-                nh_sched_fence();
-                wstep_mfma(c1, acc, bsum);
+            if (AR && BR && NH_WG_STAGE_FLOATS / (32 * (AR + BR)) == 1) {
+                // one tile per stage, constant strides: 16 k-steps fully unrolled, every operand address an immediate
+#pragma unroll
+                for (int s = 0; s < 16; s += 2) {
+                    wstep_load(c1, pa + (s + 1) * 2 * AR, pb + (s + 1) * 2 * BR);
+                    dma.issue(1);
+                    nh_sched_fence();
+                    wstep_mfma<PO, PI, BIAS>(c0, acc, bsum);
+                    wstep_load(c0, pa + (s + 2) * 2 * AR, pb + (s + 2) * 2 * BR);  // (last: one k-step past the stage, unused)
+                    nh_sched_fence();
+                    wstep_mfma<PO, PI, BIAS>(c1, acc, bsum);
+                }
+            } else {
+                const int steps = 16 * ntile;  // k-steps of two samples each
+                for (int s = 0; s < steps; s += 2) {
+                    pa += 2 * ar, pb += 2 * br;
+                    wstep_load(c1, pa, pb);
+                    dma.issue(1);  // the next stage streams in underneath the MFMAs (at most 8 pieces per wave and stage)
+                    nh_sched_fence();
+                    wstep_mfma<PO, PI, BIAS>(c0, acc, bsum);
+                    pa += 2 * ar, pb += 2 * br;
+                    wstep_load(c0, pa, pb);  // the last one reads one k-step past the stage (slack / other block): unused
+                    nh_sched_fence();
+                    wstep_mfma<PO, PI, BIAS>(c1, acc, bsum);
+                }
             }
         }
         dma.issue(1 << 20);  // idle waves, and whatever a short stage left over
@@ -762,10 +783,26 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
 #pragma unroll
             for (int c = 0; c < 16; ++c) dst[c * 64] = acc[x][y][c];
         }
-        if (iw == 0) {  // bias gradient = row sums of A over this workgroup's samples
+        if (BIAS) {  // bias gradient = row sums of A over this workgroup's samples
             const float tot = bsum[x] + nh_shfl_xor(bsum[x], 32);
             if (k == 0) part[65536 + a_t * 32 + i] = tot;
         }
+    }
+}
+
+template <int PO, int PI>
+NH_DEVICE void wgrad_dispatch(const WgradArgs& a, const JobDev& jb, int64_t t0, int64_t t1, int ow, int iw, int wave, int lane,
+                              int64_t wg, bool active, float* lds) {
+    const bool bias = iw == 0;  // (computed even when the job carries no bias tensor: the reduce kernel ignores it)
+    if (PO == 4 && PI == 2 && jb.a_rows == 256 && jb.b_rows == 256) {  // the 256x256 jobs: 91 % of the 8x256 FLOPs
+        if (bias)
+            wgrad_body<PO, PI, 256, 256, true>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
+        else
+            wgrad_body<PO, PI, 256, 256, false>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
+    } else if (bias) {
+        wgrad_body<PO, PI, 0, 0, true>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
+    } else {
+        wgrad_body<PO, PI, 0, 0, false>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
     }
 }
 
@@ -784,17 +821,19 @@ NH_KERNEL void NH_LB(64 * NH_WG_WAVES, 2) k_wgrad(WgradArgs a) {
     const int64_t t0 = a.nt * ks / nks, t1 = a.nt * (ks + 1) / nks;
     const int lane = nh_lane(), wave = nh_wave_in_block();
     const bool active = wave < jb.wo * jb.wi;  // idle waves still copy and synchronise
-    const int ow = wave / jb.wi, iw = wave % jb.wi;
+    // wave -> patch (ow, iw); the column index is rotated by the row so that the bias-summing waves (iw == 0) of
+    // different rows sit on different SIMDs (wave w runs on SIMD w % 4)
+    const int ow = wave / jb.wi, iw = (wave % jb.wi + ow) % jb.wi;
     const int sel = jb.po * 8 + jb.pi;
     switch (sel) {
-        case 4 * 8 + 2: wgrad_body<4, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
-        case 2 * 8 + 4: wgrad_body<2, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
-        case 4 * 8 + 1: wgrad_body<4, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
-        case 1 * 8 + 4: wgrad_body<1, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
-        case 2 * 8 + 2: wgrad_body<2, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
-        case 2 * 8 + 1: wgrad_body<2, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
-        case 1 * 8 + 2: wgrad_body<1, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
-        default: wgrad_body<1, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 4 * 8 + 2: wgrad_dispatch<4, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 2 * 8 + 4: wgrad_dispatch<2, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 4 * 8 + 1: wgrad_dispatch<4, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 1 * 8 + 4: wgrad_dispatch<1, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 2 * 8 + 2: wgrad_dispatch<2, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 2 * 8 + 1: wgrad_dispatch<2, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 1 * 8 + 2: wgrad_dispatch<1, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        default: wgrad_dispatch<1, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
     }
     if (lane == 0 && active) {  // timeline record (8 x u64 per wave): wall begin/end, job, K-slice, core-clock begin/end
         unsigned long long* dbg = (unsigned long long*)(a.partial + (size_t)wg * NH_PART + 65536 + 512) + wave * 8;

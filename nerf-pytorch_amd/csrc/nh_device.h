@@ -88,6 +88,20 @@ NH_DEVICE void nh_dma16(const NhDmaSrc& s, int voff, int soff, float* lds_wave_b
         : "s"(__builtin_amdgcn_readfirstlane((int)m0v)), "v"(voff), "s"(s.r), "s"(__builtin_amdgcn_readfirstlane(soff))
         : "memory");  // M0 is a reserved register: the compiler never keeps a live value in it across statements
 }
+// the same copy with the LDS destination given as a byte address (nh_lds_addr, computed once per kernel): no
+// generic -> LDS pointer cast (and its null check) per piece
+NH_DEVICE unsigned nh_lds_addr(const float* lds_ptr) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_ptr;
+}
+NH_DEVICE void nh_dma16a(const NhDmaSrc& s, int voff, int soff, unsigned lds_wave_addr) {
+    asm volatile(
+        "s_mov_b32 m0, %0\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen lds"
+        :
+        : "s"(__builtin_amdgcn_readfirstlane((int)lds_wave_addr)), "v"(voff), "s"(s.r), "s"(__builtin_amdgcn_readfirstlane(soff))
+        : "memory");
+}
 NH_DEVICE void nh_wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // nothing is scheduled across this point (pins "issue the prefetch BEFORE the MFMAs")
 NH_DEVICE void nh_sched_fence() { __builtin_amdgcn_sched_barrier(0); }

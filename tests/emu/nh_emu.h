@@ -163,6 +163,10 @@ NH_DEVICE void nh_dma16(const NhDmaSrc& s, int voff, int soff, float* lds_wave_b
     if (off + 16 <= s.bytes)  // out-of-range lanes: the descriptor's bounds check (nothing is read)
         memcpy(lds_wave_base + 4 * emu::cur->lane, s.base + off, 16);
 }
+NH_DEVICE unsigned nh_lds_addr(const float* lds_ptr) { return (unsigned)((const char*)lds_ptr - emu::g_dyn_smem); }
+NH_DEVICE void nh_dma16a(const NhDmaSrc& s, int voff, int soff, unsigned lds_wave_addr) {
+    nh_dma16(s, voff, soff, (float*)(emu::g_dyn_smem + lds_wave_addr));
+}
 NH_DEVICE void nh_wait_vmem() {}
 NH_DEVICE void nh_sched_fence() {}
 NH_DEVICE unsigned long long nh_wall_clock() { return 0ull; }

@@ -399,9 +399,9 @@ void add_job(nerfhip_plan* p, const NhRegion& A, int a_tiles, const NhRegion& B,
         for (int wi = 1; wo * wi <= 8; wi *= 2) {
             int po = (a_tiles + wo - 1) / wo, pi = (b_tiles + wi - 1) / wi;
             if (po > 4 || pi > 4 || po * pi > 8 || po == 3 || pi == 3) continue;
-            // SIMD time per sample tile ~ (waves per SIMD) * patch; ties: fewer operand reads per MFMA, then fewer waves
+            // SIMD time per sample tile ~ (waves per SIMD) * patch
             const int per_simd = (wo * wi + 3) / 4;
-            int cost = (per_simd * po * pi) * 64 + (po + pi) * 4 + wo * wi;
+            int cost = (per_simd * po * pi) * 64 + (8 - wo * wi) * 4 + (po + pi);  // ties: more waves (two per SIMD overlap), then fewer operand reads
             if (cost < best_cost) {
                 best_cost = cost;
                 best_wo = wo;

@@ -36,6 +36,8 @@ struct Stage {
     float4 v[N4MAX];   // register-staging path only
     NhDmaSrc dma;      // buffer descriptor over the whole packed-weight image
     const float* base; // its base pointer
+    unsigned lds_addr; // LDS byte address of the weight buffers (DMA destinations are addresses, not pointers)
+    const float* lds0; // the same as a pointer
 #ifdef NH_PHASE_TIMING
     unsigned long long ph[6], last;  // debug build only: cycles per tile phase, accumulated per wave
 #endif
@@ -98,7 +100,8 @@ template <int N4MAX>
 NH_DEVICE void dma_issue(const Stage<N4MAX>& st, const float* __restrict__ chunk, int n4, float* ldsbuf, int wave, int lane) {
     const int qn = ((n4 >> 6) + 3) >> 2;
     const int soff = (int)(chunk - st.base) * 4;
-    for (int q = 0; q < qn; ++q) nh_dma16(st.dma, lane * 16, soff + (wave + 4 * q) * 1024, ldsbuf + (wave + 4 * q) * 256);
+    const unsigned dst = st.lds_addr + (unsigned)((ldsbuf - st.lds0) * 4);
+    for (int q = 0; q < qn; ++q) nh_dma16a(st.dma, lane * 16, soff + (wave + 4 * q) * 1024, dst + (wave + 4 * q) * 1024);
 }
 
 NH_DEVICE int n4_of(int kr) { return kr * 16 + 64; }
@@ -182,7 +185,9 @@ NH_DEVICE void gemm_layer(const float* inA, const float* inB, const float* __res
             // (256-wide nets: all pieces within the first half of the tile, so that the copy has half a tile to land
             //  before the vmcnt(0) -- measured +1 %; 128-wide nets: spread over the whole tile -- front-loading cost 14 %)
             for (int q = ((W >= 256 ? 2 : 1) * g * QMAX) / NG; q < ((W >= 256 ? 2 : 1) * (g + 1) * QMAX) / NG; ++q)
-                if (q < qn && q < QMAX) nh_dma16(st.dma, lane * 16, soff + (wave + 4 * q) * 1024, other + (wave + 4 * q) * 256);
+                if (q < qn && q < QMAX)
+                    nh_dma16a(st.dma, lane * 16, soff + (wave + 4 * q) * 1024,
+                              st.lds_addr + (unsigned)(((buf ^ 1) * Cfg<W>::LB + (wave + 4 * q) * 256) * 4));
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4)
                 if (st_mix && g == (NG >= 8 ? 1 + k4 * (NG / 4) : 0)) {
@@ -207,9 +212,9 @@ NH_DEVICE void gemm_layer(const float* inA, const float* inB, const float* __res
             for (int c = 0; c < 16; ++c) {
                 const int r = 16 * t + c;
                 float v = acc[c];
-                if (masked) v = ((mbits[r >> 5] >> (r & 31)) & 1u) ? v : 0.0f;
-                if (relu) v = fmaxf(v, 0.0f);
-                if (want_bits) bits_out[r >> 5] |= (v > 0.0f ? 1u : 0u) << (r & 31);
+                if (masked) v = nh_gate(v, mbits[r >> 5], r & 31);
+                if (relu) v = nh_relu(v);
+                if (want_bits) bits_out[r >> 5] |= nh_pos_bit(v) << (r & 31);  // (v >= 0 here: masks are only taken after a ReLU)
                 res[r] = v;
             }
         } else {
@@ -353,6 +358,8 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_fwd(MlpFwdArgs a) {
     Stage<C::N4MAX> st;
     st.base = a.packed;
     st.dma = nh_dma_src(a.packed, a.packed_bytes);
+    st.lds0 = lds;
+    st.lds_addr = nh_lds_addr(lds);
     NH_PH_INIT();
     // the first weight chunk travels to LDS while the encodings are computed
     if (DMA) dma_issue(st, a.packed + a.off.f_layer1, n4_of(NH_KRX), lds, wave, lane);
@@ -523,6 +530,8 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_dgrad(DgradArgs a) {
     Stage<C::N4MAX> st;
     st.base = a.packed;
     st.dma = nh_dma_src(a.packed, a.packed_bytes);
+    st.lds0 = lds;
+    st.lds_addr = nh_lds_addr(lds);
     NH_PH_INIT();
     int buf = 0;
     const float* pk = a.packed;

@@ -45,6 +45,7 @@ struct Ctx {
     unsigned long long ph[5], last;  // debug build: cycles per phase, accumulated per wave
 #endif
     float* lds;
+    unsigned lds_addr;  // its LDS byte address
     NhDmaSrc dma;  // descriptor over the whole packed image
     int buf, bbuf;  // chunk / bias buffer of the unit being consumed
     int wave, lane, g;
@@ -54,7 +55,8 @@ struct Ctx {
     NH_MEMBER void copy(int64_t off, int nfloats, float* dst) const {
         const int np = nfloats >> 8;
         const int soff = (int)off * 4;
-        for (int q = wave; q < np; q += NW) nh_dma16(dma, lane * 16, soff + q * 1024, dst + q * 256);
+        const unsigned d = lds_addr + (unsigned)((dst - lds) * 4);
+        for (int q = wave; q < np; q += NW) nh_dma16a(dma, lane * 16, soff + q * 1024, d + q * 1024);
     }
     // a layer's first unit: its bias block and chunk 0
     NH_MEMBER void copy_first(int64_t img_off, int first_floats, int b, int bb) const {
@@ -151,9 +153,9 @@ NH_DEVICE void finish(const f32x4* acc, float* act, bool relu, unsigned* bits_ou
 #pragma unroll
     for (int r = 0; r < 4 * T; ++r) {
         float v = acc[r >> 2][r & 3];
-        if (masked) v = ((mbits[r >> 5] >> (r & 31)) & 1u) ? v : 0.0f;
-        if (relu) v = fmaxf(v, 0.0f);
-        if (want_bits) bits_out[r >> 5] |= (v > 0.0f ? 1u : 0u) << (r & 31);
+        if (masked) v = nh_gate(v, mbits[r >> 5], r & 31);
+        if (relu) v = nh_relu(v);
+        if (want_bits) bits_out[r >> 5] |= nh_pos_bit(v) << (r & 31);  // (v >= 0 here: masks are only taken after a ReLU)
         act[r] = v;
     }
 }
@@ -244,6 +246,7 @@ NH_KERNEL void NH_LB(64 * NW, 2) k_mlp_fwd16(Fwd16Args a) {
     NH_DYN_LDS(lds_raw);
     Ctx cx;
     cx.lds = (float*)lds_raw;
+    cx.lds_addr = nh_lds_addr(cx.lds);
     cx.dma = nh_dma_src(a.packed, a.packed_bytes);
     cx.buf = cx.bbuf = 0;
     cx.lane = nh_lane();
@@ -403,6 +406,7 @@ NH_KERNEL void NH_LB(64 * NW, 2) k_mlp_dgrad16(Dgrad16Args a) {
     NH_DYN_LDS(lds_raw);
     Ctx cx;
     cx.lds = (float*)lds_raw;
+    cx.lds_addr = nh_lds_addr(cx.lds);
     cx.dma = nh_dma_src(a.packed, a.packed_bytes);
     cx.buf = cx.bbuf = 0;
     cx.lane = nh_lane();

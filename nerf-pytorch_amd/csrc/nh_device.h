@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <math.h>
+#include <string.h>
 
 #ifdef NERFHIP_EMU
 #include "nh_emu.h"
@@ -111,6 +112,32 @@ NH_DEVICE unsigned long long nh_core_clock() { return (unsigned long long)clock6
 #endif  // NERFHIP_EMU
 
 // ---- helpers shared by both builds -------------------------------------------------------------------------------
+
+// ReLU / mask helpers shaped to cost one or two VALU instructions each (every VALU instruction of a one-wave-per-SIMD
+// kernel is taken from the matrix pipe, profiles/r01_mfma_issue_cost.txt):
+//   nh_relu: v_max_i32 on the bit pattern (negative floats and -0 have the sign bit set -> +0; no NaN canonicalisation);
+//   nh_pos_bit: 1 iff v > 0 for v >= 0 (v_min_u32 of the bit pattern with 1);
+//   nh_gate: v if bit k of `word` is set, else +0 (v_bfe_i32 -> 0 / -1, v_and).
+NH_DEVICE float nh_relu(float v) {
+    int i;
+    memcpy(&i, &v, 4);
+    i = i > 0 ? i : 0;
+    memcpy(&v, &i, 4);
+    return v;
+}
+NH_DEVICE unsigned nh_pos_bit(float v) {
+    unsigned u;
+    memcpy(&u, &v, 4);
+    return u < 1u ? u : 1u;
+}
+NH_DEVICE float nh_gate(float v, unsigned word, int k) {
+    const int m = ((int)(word << (31 - k))) >> 31;
+    int i;
+    memcpy(&i, &v, 4);
+    i &= m;
+    memcpy(&v, &i, 4);
+    return v;
+}
 
 // Row (feature) index held by accumulator register c (0..15) of MFMA tile t for lane-half h.
 NH_DEVICE int nh_feat_of(int t, int c, int h) { return 32 * t + (c & 3) + 8 * (c >> 2) + 4 * h; }

@@ -130,6 +130,38 @@ def test_full_size_gradient_linearity(gpu):
         assert float(np.abs(full[key] - s).max()) <= 2e-4 * scale, key
 
 
+def test_full_size_fern_config_ndc_chunk_invariance_and_oracle_rows(gpu):
+    """BASELINE config 4 shape (fern: NDC rays with near 0 / far 1, 6 xyz frequencies -> Dx = 39, 64 + 64 samples,
+    noise std 1.0, 4096 rays, the 8x128 skip-3 nets of the e2e_c golden): chunk-invariant and reproducible at full size,
+    and the first 24 rays equal the oracle fed with the kernels' own random draws."""
+    cfg = P.MLP_GEOMETRIES["fern8x128_skip3_L6"]
+    pc, par_c, _, packed_c = P.mlp_setup(gpu, cfg, seed=21)
+    pf, par_f, _, packed_f = P.mlp_setup(gpu, cfg, seed=22)
+    n, H, W, focal = 4096, 378, 504, 407.5
+    g = torch.Generator().manual_seed(8)
+    ro = torch.tensor([0.0, 0.0, 0.3]).expand(n, 3) + 0.05 * torch.randn(n, 3, generator=g)
+    rd = torch.randn(n, 3, generator=g) * 0.3
+    rd[:, 2] = -1.0
+    no, nd = O.ndc_rays(H, W, focal, 1.0, ro, rd)
+    rays = O.pack_rays(no, nd, 0.0, 1.0, rd).numpy()          # viewdirs from the pre-NDC directions (train_utils.py:143-168)
+    opt = dict(num_coarse=64, num_fine=64, perturb=True, lindisp=False, white_background=False, noise_std=1.0)
+    a = gpu.render(pc, pf, packed_c, packed_f, rays, opt, None, seed=31, ray_offset=0)
+    h1 = gpu.render(pc, pf, packed_c, packed_f, rays[:1000], opt, None, seed=31, ray_offset=0)
+    h2 = gpu.render(pc, pf, packed_c, packed_f, rays[1000:], opt, None, seed=31, ray_offset=1000)
+    for k in ("rgb_coarse", "rgb_fine", "acc_fine", "depth_fine"):
+        assert np.array_equal(a[k], np.concatenate([h1[k], h2[k]]), equal_nan=True), k
+    assert np.isfinite(a["rgb_fine"]).all()
+    m = 24
+    nc, nf = 64, 64
+    rand = dict(t_rand=torch.from_numpy(gpu.rng_fill(0, 31, 0, 0, m * nc).reshape(m, nc)),
+                noise_coarse=torch.from_numpy(gpu.rng_fill(1, 31, 1, 0, m * nc).reshape(m, nc)),
+                u=torch.from_numpy(gpu.rng_fill(0, 31, 2, 0, m * nf).reshape(m, nf)),
+                noise_fine=torch.from_numpy(gpu.rng_fill(1, 31, 3, 0, m * (nc + nf)).reshape(m, nc + nf)))
+    want = O.render_rays(torch.from_numpy(rays[:m]), par_c, par_f, cfg, cfg, opt, rand)
+    P.close(a["rgb_coarse"][:m], want["rgb_coarse"].numpy(), 1e-5, what="fern rgb_coarse")
+    P.close(a["rgb_fine"][:m], want["rgb_fine"].numpy(), 2e-4, what="fern rgb_fine")
+
+
 # ---- the Python drop-in API --------------------------------------------------------------------------------------------
 def _inject(draws, dev):
     q = [torch.as_tensor(d).to(dev) for d in draws]

@@ -163,6 +163,19 @@ mine /= w
 full = flat_grad(0, n)
 err = float((mine - full).abs().max() / full.abs().max())
 assert w == world and err < 1e-5, err
+# eval sharding (BASELINE config 5): ranks render disjoint, possibly ragged, row blocks; gather restores the image
+from nerf_pytorch_amd.parallel import broadcast_parameters, gather_image_rows
+H, W = 7, 5
+img = torch.arange(H * W * 3, dtype=torch.float32).reshape(H, W, 3)
+lo, hi = shard_bounds(H, rank, world)          # 4 + 3 rows
+got = gather_image_rows(img[lo:hi].contiguous())
+assert torch.equal(got, img), got.shape
+lo, hi = shard_bounds(8, rank, world)          # equal shards take the single all_gather path
+img8 = torch.arange(8 * W * 3, dtype=torch.float32).reshape(8, W, 3)
+assert torch.equal(gather_image_rows(img8[lo:hi].contiguous()), img8)
+flat = torch.full((11,), float(rank + 1))
+broadcast_parameters(flat, src=0)
+assert float(flat.sum()) == 11.0
 dist.destroy_process_group()
 print("rank", rank, "ok", err)
 """

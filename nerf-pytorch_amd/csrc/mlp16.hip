@@ -24,9 +24,13 @@ namespace {
 // phase and one's layer epilogues, stores and barrier waits overlap the other's MFMAs (8-wave workgroups ran in lock
 // step: measured 6 % slower).
 constexpr int NW = 4;                                          // waves per workgroup
-constexpr int CHUNK_MAX = 8192;                                // floats of the largest chunk (32 KB)
-constexpr int LDS_FLOATS = 2 * CHUNK_MAX + 2 * NH16_BIAS_FLOATS;
-constexpr int LDS_BYTES = LDS_FLOATS * 4;                      // 68 KB
+// floats of the largest chunk: 256-wide nets 8192 (8 k-steps x 4 quads; 68 KB of LDS per workgroup -> 2 per CU),
+// 128-wide nets 6144 (8 k-steps x 3 quads; 52 KB -> 3 per CU, their 130-register waves fit three to a SIMD)
+template <int W>
+struct Lds {
+    static constexpr int CHUNK_MAX = W >= 256 ? 8192 : 6144;
+    static constexpr int BYTES = (2 * CHUNK_MAX + 2 * NH16_BIAS_FLOATS) * 4;
+};
 
 #ifdef NH_PHASE_TIMING
 __device__ unsigned long long g_phase16[16];
@@ -45,12 +49,13 @@ struct Ctx {
     unsigned long long ph[5], last;  // debug build: cycles per phase, accumulated per wave
 #endif
     float* lds;
-    unsigned lds_addr;  // its LDS byte address
+    int cmax;           // floats per chunk buffer (Lds<W>::CHUNK_MAX)
+    unsigned lds_addr;  // LDS byte address of `lds`
     NhDmaSrc dma;  // descriptor over the whole packed image
     int buf, bbuf;  // chunk / bias buffer of the unit being consumed
     int wave, lane, g;
-    NH_MEMBER float* chunk(int b) const { return lds + b * CHUNK_MAX; }
-    NH_MEMBER float* bias(int b) const { return lds + 2 * CHUNK_MAX + b * NH16_BIAS_FLOATS; }
+    NH_MEMBER float* chunk(int b) const { return lds + b * cmax; }
+    NH_MEMBER float* bias(int b) const { return lds + 2 * cmax + b * NH16_BIAS_FLOATS; }
     // LDS-DMA of nfloats (a multiple of 256) from float offset `off` of the packed image; piece q by wave q % NW
     NH_MEMBER void copy(int64_t off, int nfloats, float* dst) const {
         const int np = nfloats >> 8;
@@ -68,10 +73,10 @@ struct Ctx {
 template <int KR, int T>
 struct Geo {
     static constexpr int TQ = (T + 3) / 4;
-    static constexpr int KC = TQ <= 1 ? 32 : (TQ == 2 ? 16 : (TQ <= 4 ? 8 : 4));
+    static constexpr int KC = TQ <= 1 ? 16 : (TQ <= 4 ? 8 : 4);
     static constexpr int NCH = (KR + KC - 1) / KC;
     static constexpr int FIRST = (KR < KC ? KR : KC) * TQ * 256;  // floats of chunk 0
-    static_assert(KC * TQ * 256 <= CHUNK_MAX, "chunk too large for the LDS buffer");
+    static constexpr int CHUNK = KC * TQ * 256;  // floats; the kernels check it against Lds<W>::CHUNK_MAX
 };
 
 // One linear layer for the 16 samples of this wavefront: acc[t] (16 rows x 16 samples) = W_t * in + bias_t, t < T.
@@ -243,9 +248,13 @@ struct Fwd16Args {
 template <int W, bool VIEW>
 NH_KERNEL void NH_LB(64 * NW, 2) k_mlp_fwd16(Fwd16Args a) {
     constexpr int KH = W / 4, TW = W / 16, KX = NH16_KRX, KD = NH16_KRD;
+    static_assert(Geo<KH, TW + 1>::CHUNK <= Lds<W>::CHUNK_MAX && Geo<KH, TW>::CHUNK <= Lds<W>::CHUNK_MAX &&
+                      Geo<KH, TW / 2>::CHUNK <= Lds<W>::CHUNK_MAX && Geo<KH, 1>::CHUNK <= Lds<W>::CHUNK_MAX,
+                  "chunk too large for the LDS buffer");
     NH_DYN_LDS(lds_raw);
     Ctx cx;
     cx.lds = (float*)lds_raw;
+    cx.cmax = Lds<W>::CHUNK_MAX;
     cx.lds_addr = nh_lds_addr(cx.lds);
     cx.dma = nh_dma_src(a.packed, a.packed_bytes);
     cx.buf = cx.bbuf = 0;
@@ -406,6 +415,7 @@ NH_KERNEL void NH_LB(64 * NW, 2) k_mlp_dgrad16(Dgrad16Args a) {
     NH_DYN_LDS(lds_raw);
     Ctx cx;
     cx.lds = (float*)lds_raw;
+    cx.cmax = Lds<W>::CHUNK_MAX;
     cx.lds_addr = nh_lds_addr(cx.lds);
     cx.dma = nh_dma_src(a.packed, a.packed_bytes);
     cx.buf = cx.bbuf = 0;
@@ -496,15 +506,16 @@ NH_KERNEL void NH_LB(64 * NW, 2) k_mlp_dgrad16(Dgrad16Args a) {
 }
 
 template <class K>
-int lds_limit(K kern) {
+int lds_limit(K kern, int bytes) {
 #ifndef NERFHIP_EMU
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) {
-        nh_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d): %s", LDS_BYTES, hipGetErrorString(e));
+        nh_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d): %s", bytes, hipGetErrorString(e));
         return NERFHIP_ERR_LAUNCH;
     }
 #else
     (void)kern;
+    (void)bytes;
 #endif
     return NERFHIP_OK;
 }
@@ -558,9 +569,9 @@ int nh_mlp16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in,
     int rc = NERFHIP_OK;
 #define NH_FWD16(WW, VV)                                                              \
     {                                                                                 \
-        rc = lds_limit(k_mlp_fwd16<WW, VV>);                                          \
+        rc = lds_limit(k_mlp_fwd16<WW, VV>, Lds<WW>::BYTES);                          \
         if (rc) return rc;                                                            \
-        NH_LAUNCH((k_mlp_fwd16<WW, VV>), grid, 64 * NW, LDS_BYTES, stream, a);        \
+        NH_LAUNCH((k_mlp_fwd16<WW, VV>), grid, 64 * NW, Lds<WW>::BYTES, stream, a);   \
     }
     if (p->W == 256 && p->view) NH_FWD16(256, true)
     else if (p->W == 256) NH_FWD16(256, false)
@@ -589,9 +600,9 @@ int nh_mlp16_dgrad(nerfhip_plan* p, const float* packed, const float* g_out, int
     int rc = NERFHIP_OK;
 #define NH_BWD16(WW, VV)                                                              \
     {                                                                                 \
-        rc = lds_limit(k_mlp_dgrad16<WW, VV>);                                        \
+        rc = lds_limit(k_mlp_dgrad16<WW, VV>, Lds<WW>::BYTES);                        \
         if (rc) return rc;                                                            \
-        NH_LAUNCH((k_mlp_dgrad16<WW, VV>), grid, 64 * NW, LDS_BYTES, stream, d);      \
+        NH_LAUNCH((k_mlp_dgrad16<WW, VV>), grid, 64 * NW, Lds<WW>::BYTES, stream, d); \
     }
     if (p->W == 256 && p->view) NH_BWD16(256, true)
     else if (p->W == 256) NH_BWD16(256, false)

@@ -19,11 +19,14 @@
 
 namespace {
 
-// A workgroup is 4 waves (one per SIMD) = 64 samples, and TWO workgroups share a CU (<= 256 registers per wave, 68 KB of
-// LDS each): the two waves of a SIMD then belong to different workgroups with their own barriers, so they drift out of
-// phase and one's layer epilogues, stores and barrier waits overlap the other's MFMAs (8-wave workgroups ran in lock
-// step: measured 6 % slower).
-constexpr int NW = 4;                                          // waves per workgroup
+// Workgroup shape (measured, profiles/r01_mlp16_ab.txt): 256-wide nets -- ONE 8-wave workgroup per CU (two waves per
+// SIMD; the weight stream is paid once per 128 samples: the LDS-DMA traffic of two independent workgroups cost more,
+// 8 % of the pipe in scripts/mfma_rate.hip's pipeline mock, than their desynchronised epilogues won); 128-wide nets
+// (134 registers per wave, 52 KB of LDS) -- 4-wave workgroups, three per CU.
+template <int W>
+struct Shape {
+    static constexpr int NW = W >= 256 ? 8 : 4;  // waves per workgroup
+};
 // floats of the largest chunk: 256-wide nets 8192 (8 k-steps x 4 quads; 68 KB of LDS per workgroup -> 2 per CU),
 // 128-wide nets 6144 (8 k-steps x 3 quads; 52 KB -> 3 per CU, their 130-register waves fit three to a SIMD)
 template <int W>
@@ -50,6 +53,7 @@ struct Ctx {
 #endif
     float* lds;
     int cmax;           // floats per chunk buffer (Lds<W>::CHUNK_MAX)
+    int nw;             // waves per workgroup
     unsigned lds_addr;  // LDS byte address of `lds`
     NhDmaSrc dma;  // descriptor over the whole packed image
     int buf, bbuf;  // chunk / bias buffer of the unit being consumed
@@ -61,7 +65,7 @@ struct Ctx {
         const int np = nfloats >> 8;
         const int soff = (int)off * 4;
         const unsigned d = lds_addr + (unsigned)((dst - lds) * 4);
-        for (int q = wave; q < np; q += NW) nh_dma16a(dma, lane * 16, soff + q * 1024, d + q * 1024);
+        for (int q = wave; q < np; q += nw) nh_dma16a(dma, lane * 16, soff + q * 1024, d + q * 1024);
     }
     // a layer's first unit: its bias block and chunk 0
     NH_MEMBER void copy_first(int64_t img_off, int first_floats, int b, int bb) const {
@@ -246,8 +250,8 @@ struct Fwd16Args {
 };
 
 template <int W, bool VIEW>
-NH_KERNEL void NH_LB(64 * NW, 2) k_mlp_fwd16(Fwd16Args a) {
-    constexpr int KH = W / 4, TW = W / 16, KX = NH16_KRX, KD = NH16_KRD;
+NH_KERNEL void NH_LB(64 * Shape<W>::NW, 2) k_mlp_fwd16(Fwd16Args a) {
+    constexpr int KH = W / 4, TW = W / 16, KX = NH16_KRX, KD = NH16_KRD, NW = Shape<W>::NW;
     static_assert(Geo<KH, TW + 1>::CHUNK <= Lds<W>::CHUNK_MAX && Geo<KH, TW>::CHUNK <= Lds<W>::CHUNK_MAX &&
                       Geo<KH, TW / 2>::CHUNK <= Lds<W>::CHUNK_MAX && Geo<KH, 1>::CHUNK <= Lds<W>::CHUNK_MAX,
                   "chunk too large for the LDS buffer");
@@ -255,6 +259,7 @@ NH_KERNEL void NH_LB(64 * NW, 2) k_mlp_fwd16(Fwd16Args a) {
     Ctx cx;
     cx.lds = (float*)lds_raw;
     cx.cmax = Lds<W>::CHUNK_MAX;
+    cx.nw = Shape<W>::NW;
     cx.lds_addr = nh_lds_addr(cx.lds);
     cx.dma = nh_dma_src(a.packed, a.packed_bytes);
     cx.buf = cx.bbuf = 0;
@@ -410,12 +415,13 @@ struct Dgrad16Args {
 };
 
 template <int W, bool VIEW>
-NH_KERNEL void NH_LB(64 * NW, 2) k_mlp_dgrad16(Dgrad16Args a) {
-    constexpr int KH = W / 4, TW = W / 16;
+NH_KERNEL void NH_LB(64 * Shape<W>::NW, 2) k_mlp_dgrad16(Dgrad16Args a) {
+    constexpr int KH = W / 4, TW = W / 16, NW = Shape<W>::NW;
     NH_DYN_LDS(lds_raw);
     Ctx cx;
     cx.lds = (float*)lds_raw;
     cx.cmax = Lds<W>::CHUNK_MAX;
+    cx.nw = Shape<W>::NW;
     cx.lds_addr = nh_lds_addr(cx.lds);
     cx.dma = nh_dma_src(a.packed, a.packed_bytes);
     cx.buf = cx.bbuf = 0;
@@ -565,13 +571,13 @@ int nh_mlp16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in,
     a.out = out;
     a.stash = stash;
     a.sl = p->stash;
-    const int64_t grid = nh_ceil_div(M, 128) * (128 / (16 * NW));  // whole 128-sample groups: every stash tile is written
+    const int64_t groups = nh_ceil_div(M, 128);  // whole 128-sample groups: every stash tile is written
     int rc = NERFHIP_OK;
 #define NH_FWD16(WW, VV)                                                              \
     {                                                                                 \
         rc = lds_limit(k_mlp_fwd16<WW, VV>, Lds<WW>::BYTES);                          \
         if (rc) return rc;                                                            \
-        NH_LAUNCH((k_mlp_fwd16<WW, VV>), grid, 64 * NW, Lds<WW>::BYTES, stream, a);   \
+        NH_LAUNCH((k_mlp_fwd16<WW, VV>), groups * (8 / Shape<WW>::NW), 64 * Shape<WW>::NW, Lds<WW>::BYTES, stream, a); \
     }
     if (p->W == 256 && p->view) NH_FWD16(256, true)
     else if (p->W == 256) NH_FWD16(256, false)
@@ -596,13 +602,13 @@ int nh_mlp16_dgrad(nerfhip_plan* p, const float* packed, const float* g_out, int
     d.sl = p->stash;
     d.grad = scratch;
     d.gl = p->grad;
-    const int64_t grid = nh_ceil_div(M, 128) * (128 / (16 * NW));  // whole 128-sample groups: every stash tile is written
+    const int64_t groups = nh_ceil_div(M, 128);
     int rc = NERFHIP_OK;
 #define NH_BWD16(WW, VV)                                                              \
     {                                                                                 \
         rc = lds_limit(k_mlp_dgrad16<WW, VV>, Lds<WW>::BYTES);                        \
         if (rc) return rc;                                                            \
-        NH_LAUNCH((k_mlp_dgrad16<WW, VV>), grid, 64 * NW, Lds<WW>::BYTES, stream, d); \
+        NH_LAUNCH((k_mlp_dgrad16<WW, VV>), groups * (8 / Shape<WW>::NW), 64 * Shape<WW>::NW, Lds<WW>::BYTES, stream, d); \
     }
     if (p->W == 256 && p->view) NH_BWD16(256, true)
     else if (p->W == 256) NH_BWD16(256, false)

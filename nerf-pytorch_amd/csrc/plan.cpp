@@ -538,9 +538,10 @@ extern "C" nerfhip_plan_t nerfhip_plan_create(const nerfhip_model_cfg* cfg) {
     build_slot_map(p->view ? cfg->num_encoding_fn_dir : 0, (p->view && cfg->include_input_dir) ? 1 : 0, NH_KRD,
                    p->dir_col[0], p->dir_col[1], &p->P0d);
     {
-        // NERFHIP_MLP=16 selects the 16x16x4 kernels (mlp16.hip) and their packed image for this plan
+        // Forward / data-gradient kernel family of this plan: the 16x16x4 kernels (mlp16.hip) by default -- measured
+        // 1-2 % ahead (profiles/r01_mlp16_ab.txt); NERFHIP_MLP=32 selects the 32x32x2 family (mlp.hip) instead.
         const char* e = getenv("NERFHIP_MLP");
-        p->v16 = e && e[0] == '1' && e[1] == '6';
+        p->v16 = !(e && e[0] == '3' && e[1] == '2');
         const bool okx = build_slot_map16(cfg->num_encoding_fn_xyz, cfg->include_input_xyz ? 1 : 0, NH16_KRX, &p->xyz_col16[0][0]);
         const bool okd = build_slot_map16(p->view ? cfg->num_encoding_fn_dir : 0, (p->view && cfg->include_input_dir) ? 1 : 0,
                                           NH16_KRD, &p->dir_col16[0][0]);

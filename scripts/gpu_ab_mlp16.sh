@@ -1,14 +1,14 @@
 #!/bin/bash
 # gpurun --timeout 600 -- "bash scripts/gpu_ab_mlp16.sh"
-# A/B inside one box: 32x32x2 kernels (mlp.hip) vs 16x16x4 two-waves-per-SIMD kernels (mlp16.hip, NERFHIP_MLP=16).
+# A/B inside one box: 32x32x2 kernels (mlp.hip, NERFHIP_MLP=32) vs 16x16x4 two-waves-per-SIMD kernels (mlp16.hip, default).
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT/gpurun_out
 NERFHIP_MLP=16 timeout 400 python -m pytest tests -m gpu -q --timeout 200 -p no:cacheprovider > $R/pytest_mlp16.log 2>&1; echo "pytest rc=$?" >> $R/pytest_mlp16.log
-timeout 400 python -m pytest tests -m gpu -q --timeout 200 -p no:cacheprovider > $R/pytest_mlp32.log 2>&1; echo "pytest rc=$?" >> $R/pytest_mlp32.log
+NERFHIP_MLP=32 timeout 400 python -m pytest tests -m gpu -q --timeout 200 -p no:cacheprovider > $R/pytest_mlp32.log 2>&1; echo "pytest rc=$?" >> $R/pytest_mlp32.log
 B="python bench.py --no-cpu-baseline --steps 20 --warmup 5"
-timeout 120 $B > $R/ab32.log 2>&1
+NERFHIP_MLP=32 timeout 120 $B > $R/ab32.log 2>&1
 NERFHIP_MLP=16 timeout 120 $B > $R/ab16.log 2>&1
-timeout 100 $B --hidden 128 --layers 4 > $R/ab32_128.log 2>&1
+NERFHIP_MLP=32 timeout 100 $B --hidden 128 --layers 4 > $R/ab32_128.log 2>&1
 NERFHIP_MLP=16 timeout 100 $B --hidden 128 --layers 4 > $R/ab16_128.log 2>&1
 NERFHIP_MLP=16 timeout 200 python scripts/eval_bench.py > $R/eval16.log 2>&1
 grep -E "passed|failed" $R/pytest_mlp16.log $R/pytest_mlp32.log | tail -4

@@ -364,6 +364,211 @@ static void runmock3(const char* name) {
     hipFree(cyc);
 }
 
+// Mock of the mlp16 layer pipeline, adding the real kernel's ingredients one at a time (FLAGS bits):
+//   1: s_barrier + s_waitcnt vmcnt(0) every 8 k-steps (workgroups of 4 waves, two workgroups per CU)
+//   2: 8 LDS-DMA pieces (1 KiB each) per wave and chunk, issued right after the barrier
+//   4: layer epilogue every 64 k-steps: 64 x (v_max_i32 + v_min_u32 + v_lshl_or) VALU
+//   8: 16 global_store_dwordx4 per layer, two per chunk
+template <int FLAGS>
+__global__ __launch_bounds__(256, 2) void kpipe(float* out, const float* src, unsigned long long* cyc, int chunks, float b0) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    for (int i = threadIdx.x; i < 16384; i += 256) lds[i] = (float)(i & 7);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const f32x4* lp = (const f32x4*)lds + lane;
+    f32x4 acc[16];
+    for (int i = 0; i < 16; ++i) acc[i] = f32x4{0, 0, 0, 0};
+    float act[64];
+    for (int i = 0; i < 64; ++i) act[i] = b0 + i;
+    unsigned bits[2] = {0, 0};
+    float* gout = out + ((size_t)blockIdx.x * 256 + threadIdx.x) * 64;
+    const unsigned ldsb = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 rs;
+    {
+        const unsigned long long bb = (unsigned long long)src;
+        rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)bb);
+        rs[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((bb >> 32) & 0xFFFFu));
+        rs[2] = 1 << 22;
+        rs[3] = 0x00020000;
+    }
+    unsigned long long t0 = clock64();
+    for (int c = 0; c < chunks; ++c) {
+        if (FLAGS & 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if (FLAGS & 2) {
+            for (int q = 0; q < 8; ++q)
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(
+                                 __builtin_amdgcn_readfirstlane((int)(ldsb + 32768 + ((c & 1) << 15) + (wave * 8 + q) * 1024))),
+                             "v"(lane * 16), "s"(rs), "s"(__builtin_amdgcn_readfirstlane(((c & 63) * 32 + wave * 8 + q) * 1024))
+                             : "memory");
+        }
+        if (FLAGS & 8) {
+            *(f32x4*)(gout + (c & 7) * 8) = f32x4{act[(c & 7) * 8], act[(c & 7) * 8 + 1], act[(c & 7) * 8 + 2], act[(c & 7) * 8 + 3]};
+            *(f32x4*)(gout + (c & 7) * 8 + 4) = f32x4{act[(c & 7) * 8 + 4], act[(c & 7) * 8 + 5], act[(c & 7) * 8 + 6], act[(c & 7) * 8 + 7]};
+        }
+        f32x4 a[2][4];
+        for (int q = 0; q < 4; ++q) a[0][q] = lp[64 * q];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            if (ks + 1 < 8)
+                for (int q = 0; q < 4; ++q) a[(ks + 1) & 1][q] = lp[64 * q + ((ks + 1) << 8)];
+            FENCE();
+            const float b = act[(ks * 8) & 63];
+            for (int m = 0; m < 16; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks & 1][m >> 2][m & 3], b, acc[m], 0, 0, 0);
+            FENCE();
+        }
+        if ((FLAGS & 4) && (c & 7) == 7) {
+            bits[0] = bits[1] = 0;
+#pragma unroll
+            for (int r = 0; r < 64; ++r) {
+                int iv = __float_as_int(acc[r >> 2][r & 3]);
+                iv = iv > 0 ? iv : 0;
+                const unsigned u = (unsigned)iv;
+                bits[r >> 5] |= (u < 1u ? u : 1u) << (r & 31);
+                act[r] = __int_as_float(iv) + 1.0f;
+                acc[r >> 2][r & 3] = 0.0f;
+            }
+        }
+    }
+    unsigned long long t1 = clock64();
+    float r = (float)(bits[0] + bits[1]);
+    for (int i = 0; i < 16; ++i) r += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    for (int i = 0; i < 64; ++i) r += act[i];
+    if (r == 12345.f) out[threadIdx.x] = r;
+    if (lane == 0) cyc[blockIdx.x * 4 + wave] = t1 - t0;
+}
+template <int FLAGS>
+static void runpipe(const char* name) {
+    const int grid = 512 * 4, chunks = 75 * 8;  // 2 resident workgroups per CU x 4 rounds; 75 "layers" of 8 chunks
+    float *out, *src;
+    unsigned long long* cyc;
+    hipMalloc(&out, (size_t)grid * 256 * 64 * 4);
+    hipMalloc(&src, 8 << 20);
+    hipMemset(src, 0, 8 << 20);
+    hipMalloc(&cyc, (size_t)grid * 4 * 8);
+    hipFuncSetAttribute((const void*)kpipe<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, 69632);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL((kpipe<FLAGS>), dim3(grid), dim3(256), 69632, 0, out, src, cyc, chunks / 10, 2.0f);
+    hipDeviceSynchronize();
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((kpipe<FLAGS>), dim3(grid), dim3(256), 69632, 0, out, src, cyc, chunks, 2.0f);
+    hipEventRecord(e1, 0);
+    hipDeviceSynchronize();
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double tf = (double)grid * 4 * chunks * 8 * 16 * 2048.0 / (ms * 1e-3) / 1e12;
+    printf("%-72s %8.3f ms  %7.1f TFLOP/s = %5.1f %% of 157.3\n", name, ms, tf, tf / 1.573);
+    hipFree(out);
+    hipFree(src);
+    hipFree(cyc);
+}
+
+// The same pipeline as ONE 8-wave workgroup per CU whose two halves (waves 0-3 / 4-7) run half a chunk out of phase:
+// every wave meets a barrier each half chunk (4 k-steps); the copy of a chunk (4 pieces per wave: half the DMA traffic
+// of two independent workgroups) is issued after every odd barrier into a 3-deep ring of LDS buffers.
+template <int FLAGS>
+__global__ __launch_bounds__(512, 2) void kpipe8(float* out, const float* src, unsigned long long* cyc, int chunks, float b0) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    for (int i = threadIdx.x; i < 24576; i += 512) lds[i] = (float)(i & 7);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, phase = wave >> 2;
+    f32x4 acc[16];
+    for (int i = 0; i < 16; ++i) acc[i] = f32x4{0, 0, 0, 0};
+    float act[64];
+    for (int i = 0; i < 64; ++i) act[i] = b0 + i;
+    unsigned bits[2] = {0, 0};
+    const unsigned ldsb = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 rs;
+    {
+        const unsigned long long bb = (unsigned long long)src;
+        rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)bb);
+        rs[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((bb >> 32) & 0xFFFFu));
+        rs[2] = 1 << 22;
+        rs[3] = 0x00020000;
+    }
+    unsigned long long t0 = clock64();
+    const int nslots = 2 * chunks + 1;
+    for (int n = 0; n < nslots; ++n) {
+        if (FLAGS & 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if ((FLAGS & 2) && (n & 1)) {
+            const int cn = (n + 3) >> 1;
+            for (int q = 0; q < 4; ++q)
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(
+                                 __builtin_amdgcn_readfirstlane((int)(ldsb + (cn % 3) * 32768 + (wave * 4 + q) * 1024))),
+                             "v"(lane * 16), "s"(rs), "s"(__builtin_amdgcn_readfirstlane(((cn & 63) * 32 + wave * 4 + q) * 1024))
+                             : "memory");
+        }
+        const int hc = n - phase;  // this wave's half chunk
+        if (hc < 0 || hc >= 2 * chunks) continue;
+        const f32x4* lp = (const f32x4*)(lds + ((hc >> 1) % 3) * 8192 + (hc & 1) * 4096) + lane;
+        f32x4 a[2][4];
+        for (int q = 0; q < 4; ++q) a[0][q] = lp[64 * q];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks + 1 < 4)
+                for (int q = 0; q < 4; ++q) a[(ks + 1) & 1][q] = lp[64 * q + ((ks + 1) << 8)];
+            FENCE();
+            const float b = act[(ks * 8 + (hc & 1) * 32) & 63];
+            for (int m = 0; m < 16; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks & 1][m >> 2][m & 3], b, acc[m], 0, 0, 0);
+            FENCE();
+        }
+        if ((FLAGS & 4) && (hc & 15) == 15) {
+            bits[0] = bits[1] = 0;
+#pragma unroll
+            for (int r = 0; r < 64; ++r) {
+                int iv = __float_as_int(acc[r >> 2][r & 3]);
+                iv = iv > 0 ? iv : 0;
+                const unsigned u = (unsigned)iv;
+                bits[r >> 5] |= (u < 1u ? u : 1u) << (r & 31);
+                act[r] = __int_as_float(iv) + 1.0f;
+                acc[r >> 2][r & 3] = 0.0f;
+            }
+        }
+    }
+    unsigned long long t1 = clock64();
+    float r = (float)(bits[0] + bits[1]);
+    for (int i = 0; i < 16; ++i) r += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    for (int i = 0; i < 64; ++i) r += act[i];
+    if (r == 12345.f) out[threadIdx.x] = r;
+    if (lane == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
+}
+template <int FLAGS>
+static void runpipe8(const char* name) {
+    const int grid = 256 * 4, chunks = 75 * 8;
+    float *out, *src;
+    unsigned long long* cyc;
+    hipMalloc(&out, 1 << 20);
+    hipMalloc(&src, 8 << 20);
+    hipMemset(src, 0, 8 << 20);
+    hipMalloc(&cyc, (size_t)grid * 8 * 8);
+    hipFuncSetAttribute((const void*)kpipe8<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL((kpipe8<FLAGS>), dim3(grid), dim3(512), 98304, 0, out, src, cyc, chunks / 10, 2.0f);
+    hipDeviceSynchronize();
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((kpipe8<FLAGS>), dim3(grid), dim3(512), 98304, 0, out, src, cyc, chunks, 2.0f);
+    hipEventRecord(e1, 0);
+    hipDeviceSynchronize();
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double tf = (double)grid * 8 * chunks * 8 * 16 * 2048.0 / (ms * 1e-3) / 1e12;
+    printf("%-72s %8.3f ms  %7.1f TFLOP/s = %5.1f %% of 157.3\n", name, ms, tf, tf / 1.573);
+    hipFree(out);
+    hipFree(src);
+    hipFree(cyc);
+}
+
 template <class K>
 static void run(const char* name, K kern, int grid, int iters, int mfma_per_iter, double flop_per_mfma) {
     float* out;
@@ -433,6 +638,16 @@ int main() {
     runmock<12, 0>("mock layer loop: 16x16x4, 3 waves/SIMD");
     runmock3<4>("mock layer loop: 16x16x4, 1 wave/SIMD, operands 2 k-steps ahead");
     runmock3<8>("mock layer loop: 16x16x4, 2 waves/SIMD, operands 2 k-steps ahead");
+    runpipe<0>("mlp16 pipeline mock: MFMA + operand reads only (2 WGs of 4 waves per CU)");
+    runpipe<1>("  + barrier and vmcnt(0) per chunk");
+    runpipe<3>("  + barrier + 8 LDS-DMA pieces per wave and chunk");
+    runpipe<7>("  + barrier + DMA + layer epilogue VALU");
+    runpipe<15>("  + barrier + DMA + epilogue + stash stores (= training forward)");
+    runpipe<11>("  + barrier + DMA + stash stores, no epilogue");
+    runpipe8<0>("8-wave WG, halves half a chunk out of phase: MFMA + operand reads only");
+    runpipe8<1>("  + barrier per half chunk");
+    runpipe8<3>("  + barrier + 4 LDS-DMA pieces per wave and chunk (3-deep ring)");
+    runpipe8<7>("  + barrier + DMA + layer epilogue VALU (= inference forward)");
     runx<23, 4>("STAGGERED ds_read_b128 (prefetched) + 8 v_add");
     runx<23, 2>("STAGGERED ds_read_b128 (prefetched) + 4 v_add");
     runx<22, 8>("STAGGERED ds_read_b32 (prefetched) + 8 v_add");

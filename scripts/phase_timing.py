@@ -35,7 +35,7 @@ for _ in range(3):
     eng.step(rays, tgt)
 torch.cuda.synchronize()
 dbg(buf, 0)
-if os.environ.get("NERFHIP_MLP") == "16":
+if os.environ.get("NERFHIP_MLP") != "32":
     dbg16 = lib._dll.nerfhip_debug_phases16
     dbg16.argtypes = [C.c_void_p, C.c_int]
     b16 = (C.c_ulonglong * 16)()

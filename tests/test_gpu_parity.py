@@ -403,9 +403,9 @@ def test_python_api_select_step_resume_and_writer(tmp_path):
         assert np.array_equal(raw[:, 1:].reshape(want8.shape), want8)
 
 
-# ---- the 16x16x4 kernel family (mlp16.hip; plans created with NERFHIP_MLP=16) -------------------------------------------
-def test_v16_mlp_and_render_parity(gpu, monkeypatch):
-    monkeypatch.setenv("NERFHIP_MLP", "16")
+# ---- the 32x32x2 kernel family (mlp.hip; plans created with NERFHIP_MLP=32; the default family is mlp16.hip) -----------
+def test_v32_mlp_and_render_parity(gpu, monkeypatch):
+    monkeypatch.setenv("NERFHIP_MLP", "32")
     P.case_mlp_forward(gpu)
     P.case_mlp_golden(gpu)
     P.case_mlp_backward(gpu, names=("default4x128", "deep8x128_skip4", "fern8x128_skip3_L6", "novw4x128", "northstar8x256"),

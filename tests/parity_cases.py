@@ -229,6 +229,10 @@ MLP_GEOMETRIES = {
     "fern8x128_skip3_L6": model_cfg(8, 128, 3, 6, 4),
     "novw4x128": model_cfg(4, 128, 4, 10, 4, use_viewdirs=False),
     "two_layer_L4_L2": model_cfg(2, 128, 4, 4, 2),
+    "one_layer": model_cfg(1, 128, 4, 10, 4),
+    "one_layer_novw_256": model_cfg(1, 256, 4, 3, 0, use_viewdirs=False),
+    "sixteen_layers_skip5": model_cfg(16, 128, 5, 10, 4),
+    "skip_every_layer_256": model_cfg(3, 256, 1, 2, 1),
     "noinput_linear": model_cfg(3, 128, 2, 5, 3, include_input_xyz=False, include_input_dir=False,
                                 log_sampling_xyz=False),
     "northstar8x256": model_cfg(8, 256, 4, 10, 4),

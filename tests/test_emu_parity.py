@@ -46,6 +46,13 @@ def test_mlp_forward_northstar(emu):
     P.case_mlp_forward(emu, names=("northstar8x256",), m=33)
 
 
+def test_mlp_extreme_geometries(emu):
+    """num_layers 1 and 16, a skip connection at every layer, no view directions with a 256-wide net."""
+    names = ("one_layer", "one_layer_novw_256", "sixteen_layers_skip5", "skip_every_layer_256")
+    P.case_mlp_forward(emu, names=names, m=37)
+    P.case_mlp_backward(emu, names=names, m=45)
+
+
 def test_mlp_golden(emu):
     P.case_mlp_golden(emu)
 

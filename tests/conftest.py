@@ -32,4 +32,8 @@ def gpu():
     if not torch.cuda.is_available():
         pytest.skip("no GPU visible")
     import backends
+    import nerf_pytorch_amd._lib as L
+    if not os.path.exists(L.LIB_PATH):  # test convenience only: the product never builds or falls back by itself
+        import subprocess
+        subprocess.run(["make", "-C", backends.CSRC, "lib", "-j8"], check=True)
     return backends.GpuBackend()

@@ -875,10 +875,17 @@ NH_KERNEL void k_wgrad_reduce(WgradArgs a) {
             if (cc >= 0) col = jb.col_base + cc;
         }
         if (col >= 0) {
-            float s = 0.0f;
+            // eight interleaved running sums (a fixed order: bit-reproducible) keep eight loads in flight per lane
+            float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             const float* p = a.partial + (size_t)jb.wg_start * NH_PART + ((size_t)tile * 16 + c) * 64 + lane;
-            for (int q = 0; q < nks; ++q) s += p[(size_t)q * NH_PART];
-            a.g_params[(size_t)jb.w_off + (size_t)(out_row - jb.r_lo) * jb.w_ld + col] = s;
+            int q = 0;
+            for (; q + 8 <= nks; q += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sum[u] += p[(size_t)(q + u) * NH_PART];
+            }
+            for (; q < nks; ++q) sum[0] += p[(size_t)q * NH_PART];
+            a.g_params[(size_t)jb.w_off + (size_t)(out_row - jb.r_lo) * jb.w_ld + col] =
+                ((sum[0] + sum[1]) + (sum[2] + sum[3])) + ((sum[4] + sum[5]) + (sum[6] + sum[7]));
         }
     }
     if (jb.bias_off >= 0 && b_t == 0 && c == 0 && lane < 32) {

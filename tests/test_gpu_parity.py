@@ -246,6 +246,10 @@ def test_python_api_unfused_composition_and_model_autograd():
                                    encode_direction_fn=ed)
     for u, v in zip(a, b):
         P.close(u.cpu().numpy(), v.cpu().numpy(), 2e-5, 2e-5, what="generic vs fused")
+    # gradients w.r.t. the encoded inputs are not computed by the kernels: asking for them fails loudly
+    xin = torch.randn(8, m.dim_xyz + m.dim_dir, device=dev, requires_grad=True)
+    with pytest.raises(RuntimeError, match="encoded input are not supported"):
+        m(xin)
 
 
 def test_pretrained_lego_checkpoint_renders_like_the_reference():

@@ -160,6 +160,49 @@ def e2e_case(nerf, name, cfg_c, cfg_f, n_rays, nc, nf, perturb, lindisp, white, 
     npz(name, **d)
 
 
+def e2e_sampled(nerf, name, cfg, n_rays, nc, nf, seed):
+    """The HEADLINE geometry (8x256, 64 + 128 samples) against the real reference.  Full gradients would be 4.8 MB, so the
+    fixture keeps the outputs, every parameter tensor's gradient sum and absolute sum, and 96 sampled gradient entries
+    per tensor (positions recorded in the file).  Weights are oracle init_params(seed), as in e2e_case."""
+    g = torch.Generator().manual_seed(seed)
+    mc, mf = R.make_reference_model(nerf, cfg), R.make_reference_model(nerf, cfg)
+    mc.load_state_dict(O.init_params(cfg, seed=seed * 2 + 1))
+    mf.load_state_dict(O.init_params(cfg, seed=seed * 2 + 2))
+    ex = nerf.get_embedding_function(cfg["num_encoding_fn_xyz"], True, True)
+    ed = nerf.get_embedding_function(cfg["num_encoding_fn_dir"], True, True)
+    H, W, focal = 40, 50, 45.0
+    c2w = pose_like(g)
+    c2w[:3, 3] = torch.tensor([0.3, -0.2, 4.0])
+    ro_img, rd_img = nerf.get_ray_bundle(H, W, focal, c2w)
+    pix = torch.randperm(H * W, generator=g)[:n_rays]
+    ro, rd = ro_img.reshape(-1, 3)[pix].contiguous(), rd_img.reshape(-1, 3)[pix].contiguous()
+    tgt = torch.rand(n_rays, 3, generator=g)
+    opts = make_opts(nerf, nc, nf, True, False, False, 0.2)
+    rec = dict(t_rand=torch.rand(n_rays, nc, generator=g), noise_coarse=torch.randn(n_rays, nc, generator=g),
+               u=torch.rand(n_rays, nf, generator=g), noise_fine=torch.randn(n_rays, nc + nf, generator=g))
+    with R.injected_randoms([rec["t_rand"], rec["noise_coarse"], rec["u"], rec["noise_fine"]]):
+        out = nerf.run_one_iter_of_nerf(H, W, focal, mc, mf, ro, rd, opts, mode="train", encode_position_fn=ex,
+                                        encode_direction_fn=ed)
+    loss = torch.nn.functional.mse_loss(out[0], tgt) + torch.nn.functional.mse_loss(out[3], tgt)
+    loss.backward()
+    d = dict(H=H, W=W, focal=focal, c2w=c2w, pix=pix, ro=ro, rd=rd, target=tgt, near=2.0, far=6.0, loss=loss)
+    d.update(rec)
+    for i, n in enumerate(("rgb_coarse", "disp_coarse", "acc_coarse", "rgb_fine", "disp_fine", "acc_fine")):
+        d[n] = out[i]
+    pick = np.random.RandomState(seed)
+    for tag, m in (("gc_", mc), ("gf_", mf)):
+        for k, prm in m.named_parameters():
+            gr = prm.grad.reshape(-1)
+            idx = pick.randint(0, gr.numel(), size=96).astype(np.int64)
+            d["i" + tag + k] = idx
+            d["v" + tag + k] = gr[torch.from_numpy(idx)]
+            d["s" + tag + k] = torch.stack([gr.sum(), gr.abs().sum(), gr.abs().max()])
+    meta = dict(cfg_c=cfg, cfg_f=cfg, n_rays=n_rays, nc=nc, nf=nf, perturb=True, lindisp=False, white=False, noise=0.2,
+                seed=seed, ndc=False)
+    d["meta"] = np.array(repr(meta))
+    npz(name, **d)
+
+
 def mlp_case(nerf):
     """FlexibleNeRFModel.forward on random encoded rows, incl. the skip geometries of SURVEY 0.3."""
     d = {}
@@ -276,6 +319,9 @@ def main():
     nerf = R.import_reference()
     if sys.argv[1:] == ["dataio"]:
         return dataio(nerf)
+    north = dict(num_layers=8, hidden_size=256, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4)
+    if sys.argv[1:] == ["northstar"]:
+        return e2e_sampled(nerf, "e2e_northstar.npz", north, 5, 64, 128, seed=6)
     helpers(nerf)
     mlp_case(nerf)
     base = dict(num_layers=4, hidden_size=128, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4)
@@ -289,6 +335,7 @@ def main():
     e2e_case(nerf, "e2e_d.npz", novw, novw, 5, 8, 8, True, True, True, 1.0, seed=4)
     pretrained_lego(nerf)
     dataio(nerf)
+    e2e_sampled(nerf, "e2e_northstar.npz", north, 5, 64, 128, seed=6)
 
 
 if __name__ == "__main__":

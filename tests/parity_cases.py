@@ -326,6 +326,32 @@ def case_e2e_golden(b, name, with_grads=True):
     b.lib.plan_destroy(pf)
 
 
+def case_e2e_northstar_golden(b):
+    """The headline geometry (8x256, 64 + 128) against the REAL reference (oracle/gen_golden.py e2e_sampled): outputs,
+    loss, and for every parameter tensor the gradient's sum, absolute sum and 96 sampled entries."""
+    name = "e2e_northstar.npz"
+    g, meta, cfg_c, cfg_f, rays, rand, opt = e2e_inputs(name)
+    pc, _, _, packed_c = mlp_setup(b, cfg_c, seed=meta["seed"] * 2 + 1)
+    pf, _, _, packed_f = mlp_setup(b, cfg_f, seed=meta["seed"] * 2 + 2)
+    out = b.render(pc, pf, packed_c, packed_f, rays, opt, rand, training=True)
+    for k in ("rgb_coarse", "acc_coarse", "rgb_fine", "acc_fine"):
+        close(out[k], g[k], 1e-4, what="%s %s" % (name, k))
+    loss, gc, gf = b.mse_loss(out["rgb_coarse"], out["rgb_fine"], g["target"])
+    assert abs(float(loss[2]) - float(g["loss"])) < 1e-5
+    out = b.render(pc, pf, packed_c, packed_f, rays, opt, rand, training=True, g_rgb=(gc, gf))
+    for tag, plan, key, gt in (("gc_", pc, "g_params_coarse", 1e-4), ("gf_", pf, "g_params_fine", 3e-2)):
+        for k, v in b.unflatten(plan, out[key]).items():
+            sums, idx, val = g["s" + tag + k], g["i" + tag + k], g["v" + tag + k]
+            scale = float(sums[2]) + 1e-12                      # max |grad| of the tensor in the reference
+            flat = np.asarray(v).reshape(-1)
+            close(flat[idx], val, gt * scale + 1e-9, 5e-4, what="%s sampled grad %s%s" % (name, tag, k))
+            # sums over the tensor: errors average out, so a tighter relative bound on the absolute sum
+            assert abs(float(np.abs(flat).sum()) - float(sums[1])) <= (gt * 0.5) * float(sums[1]) + 1e-9, (tag, k)
+            assert abs(float(flat.sum()) - float(sums[0])) <= gt * float(sums[1]) + 1e-9, (tag, k)
+    b.lib.plan_destroy(pc)
+    b.lib.plan_destroy(pf)
+
+
 def case_render_vs_oracle(b, cfg, n, nc, nf, seed=5, white=False, noise=0.3, with_grads=False, tol=1e-4):
     """Fused render against the oracle on random-init nets of an arbitrary geometry (e.g. the 8x256 north star)."""
     gen = rng(seed)

@@ -107,3 +107,7 @@ def test_v32_e2e_goldens(emu, monkeypatch):
     P.case_e2e_golden(emu, "e2e_a.npz")
     P.case_e2e_golden(emu, "e2e_d.npz")
     P.case_internal_rng(emu)
+
+
+def test_e2e_northstar_reference_golden(emu):
+    P.case_e2e_northstar_golden(emu)

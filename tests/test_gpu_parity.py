@@ -417,4 +417,9 @@ def test_v32_mlp_and_render_parity(gpu, monkeypatch):
     for name in ("e2e_a.npz", "e2e_b.npz", "e2e_c.npz", "e2e_d.npz"):
         P.case_e2e_golden(gpu, name)
     P.case_render_vs_oracle(gpu, P.MLP_GEOMETRIES["northstar8x256"], n=48, nc=64, nf=128, with_grads=True)
+    P.case_e2e_northstar_golden(gpu)
     P.case_internal_rng(gpu)
+
+
+def test_e2e_northstar_reference_golden(gpu):
+    P.case_e2e_northstar_golden(gpu)

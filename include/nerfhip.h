@@ -95,6 +95,11 @@ int nerfhip_stratified_z(const float* rays, int ray_stride, int64_t n, const flo
 /* cumprod_exclusive (nerf/nerf_helpers.py:43-64) over the last dimension of x[rows, cols]. */
 int nerfhip_cumprod_exclusive(const float* x, int64_t rows, int cols, float* out, nerfhip_stream_t stream);
 
+/* Its backward (autograd of nerf/nerf_helpers.py:43-64, as tiny_nerf.py:100-101 needs it): y = the forward result,
+ * g_y = cotangent of y, g_x (out) = cotangent of x; all dev [rows, cols].  Division-free: exact for rows with zeros. */
+int nerfhip_cumprod_exclusive_bwd(const float* x, const float* y, const float* g_y, int64_t rows, int cols, float* g_x,
+                                  nerfhip_stream_t stream);
+
 /* volume_render_radiance_field (nerf/volume_rendering_utils.py:6-53).  raw: dev [n,s,4]; z: dev [n,s];
  * rd: dev rows of rd_stride floats whose first 3 entries are the ray direction; noise: dev [n,s] N(0,1) draws or
  * NULL (in-kernel stream `rng_stream` when noise_std > 0).  Outputs (any may be NULL): rgb [n,3], disp [n],
@@ -237,6 +242,34 @@ int nerfhip_render_bwd(nerfhip_plan_t plan_coarse, nerfhip_plan_t plan_fine, con
                        const nerfhip_render_rand* rnd, uint64_t seed, uint64_t ray_offset, const float* g_rgb_coarse,
                        const float* g_rgb_fine, void* workspace, int64_t workspace_bytes, float* g_params_coarse,
                        float* g_params_fine, nerfhip_stream_t stream);
+
+/* The same two calls cut at the coarse / fine seam (`parts`: NERFHIP_PART_COARSE, NERFHIP_PART_FINE or both).  The
+ * reference runs coarse forward -> fine forward -> one backward sequentially (nerf/train_utils.py:68-117,
+ * train_nerf.py:244-259); the coarse net's backward only needs the coarse colour map, so a caller may enqueue it on a
+ * second stream while the fine forward still runs, and launch the fine net's gradient all-reduce while the coarse
+ * backward is in flight (TrainEngine does both).  The fine part reads what the coarse part left in the workspace
+ * (depths, weights); each net's backward uses its own scratch region of the workspace.  Cotangents of the depth and
+ * accumulation maps are optional (NULL = 0): losses that only touch the colour maps pass g_rgb_* alone. */
+#define NERFHIP_PART_COARSE 1
+#define NERFHIP_PART_FINE 2
+typedef struct nerfhip_render_cotangents {
+    const float* g_rgb_coarse;   /* [n,3] */
+    const float* g_acc_coarse;   /* [n]   */
+    const float* g_depth_coarse; /* [n]   */
+    const float* g_rgb_fine;
+    const float* g_acc_fine;
+    const float* g_depth_fine;
+} nerfhip_render_cotangents;
+int nerfhip_render_fwd_parts(nerfhip_plan_t plan_coarse, nerfhip_plan_t plan_fine, const nerfhip_render_cfg* cfg,
+                             const float* rays, int64_t n_rays, const float* packed_coarse, const float* packed_fine,
+                             const float* t_vals, const float* u_det, const nerfhip_render_rand* rnd, uint64_t seed,
+                             uint64_t ray_offset, const nerfhip_render_out* out, void* workspace,
+                             int64_t workspace_bytes, int training, int parts, nerfhip_stream_t stream);
+int nerfhip_render_bwd_parts(nerfhip_plan_t plan_coarse, nerfhip_plan_t plan_fine, const nerfhip_render_cfg* cfg,
+                             const float* rays, int64_t n_rays, const float* packed_coarse, const float* packed_fine,
+                             const nerfhip_render_rand* rnd, uint64_t seed, uint64_t ray_offset,
+                             const nerfhip_render_cotangents* g, void* workspace, int64_t workspace_bytes,
+                             float* g_params_coarse, float* g_params_fine, int parts, nerfhip_stream_t stream);
 
 /* ---- loss + optimiser (train_nerf.py:244-270) ------------------------------------------------------------------ */
 /* mse_loss(rgb_coarse, target) + mse_loss(rgb_fine, target) and its cotangents; loss_out: dev float[3] =

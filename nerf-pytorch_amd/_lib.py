@@ -38,6 +38,14 @@ class RenderOut(C.Structure):
                                    "acc_fine", "depth_fine")]
 
 
+class RenderCotangents(C.Structure):
+    _fields_ = [(n, c_f) for n in ("g_rgb_coarse", "g_acc_coarse", "g_depth_coarse", "g_rgb_fine", "g_acc_fine",
+                                   "g_depth_fine")]
+
+
+PART_COARSE, PART_FINE = 1, 2
+
+
 class SelectCfg(C.Structure):
     _fields_ = [("height", C.c_int32), ("width", C.c_int32), ("focal", C.c_float), ("near", C.c_float),
                 ("far", C.c_float), ("use_viewdirs", C.c_int32), ("ndc", C.c_int32), ("ndc_near", C.c_float),
@@ -60,6 +68,7 @@ _PROTOS = {
     "nerfhip_stratified_z": (C.c_int, [c_f, C.c_int, c_i64, c_f, C.c_int, C.c_int, C.c_int, c_f, c_u64, c_u64, c_f,
                                         c_f]),
     "nerfhip_cumprod_exclusive": (C.c_int, [c_f, c_i64, C.c_int, c_f, c_f]),
+    "nerfhip_cumprod_exclusive_bwd": (C.c_int, [c_f, c_f, c_f, c_i64, C.c_int, c_f, c_f]),
     "nerfhip_volume_render_fwd": (C.c_int, [c_f, c_f, c_f, C.c_int, c_i64, C.c_int, C.c_float, c_f, c_u64, c_u32, c_u64,
                                              C.c_int, c_f, c_f, c_f, c_f, c_f, c_f]),
     "nerfhip_volume_render_bwd": (C.c_int, [c_f, c_f, c_f, C.c_int, c_i64, C.c_int, C.c_float, c_f, c_u64, c_u32, c_u64,
@@ -90,6 +99,12 @@ _PROTOS = {
                                       c_f]),
     "nerfhip_render_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(RenderCfg), c_f, c_i64, c_f, c_f,
                                       C.POINTER(RenderRand), c_u64, c_u64, c_f, c_f, c_f, c_i64, c_f, c_f, c_f]),
+    "nerfhip_render_fwd_parts": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(RenderCfg), c_f, c_i64, c_f, c_f, c_f, c_f,
+                                            C.POINTER(RenderRand), c_u64, c_u64, C.POINTER(RenderOut), c_f, c_i64,
+                                            C.c_int, C.c_int, c_f]),
+    "nerfhip_render_bwd_parts": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(RenderCfg), c_f, c_i64, c_f, c_f,
+                                            C.POINTER(RenderRand), c_u64, c_u64, C.POINTER(RenderCotangents), c_f, c_i64,
+                                            c_f, c_f, C.c_int, c_f]),
     "nerfhip_mse_loss_fwd_bwd": (C.c_int, [c_f, c_f, c_f, C.c_int, c_i64, C.c_float, c_f, c_f, c_f, c_f]),
     "nerfhip_adam_step": (C.c_int, [c_f, c_f, c_f, c_f, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, c_i64,
                                      C.c_float, c_f]),
@@ -141,6 +156,37 @@ class NerfHipLib:
 
 def bind(path):
     return NerfHipLib(path)
+
+
+class launch_on:
+    """``with launch_on(t0, t1, ...) as stream:`` -- the tensors handed to a C-ABI call must all live on ONE CUDA (HIP)
+    device; that device is made current for the duration of the launch and `stream` is ITS current stream (not the
+    current stream of whatever device happens to be current in a process that drives several GPUs)."""
+
+    def __init__(self, *tensors):
+        import torch
+        dev = None
+        for t in tensors:
+            if t is None:
+                continue
+            if not t.is_cuda:
+                raise RuntimeError("nerf_pytorch_amd has no CPU path: got a %s tensor" % t.device)
+            if dev is None:
+                dev = t.device
+            elif t.device != dev:
+                raise RuntimeError("tensors of one call live on different devices (%s and %s)" % (dev, t.device))
+        if dev is None:
+            raise RuntimeError("launch_on needs at least one tensor")
+        self.dev = dev
+        self._guard = torch.cuda.device(dev)
+        self._stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def __enter__(self):
+        self._guard.__enter__()
+        return self._stream
+
+    def __exit__(self, *exc):
+        return self._guard.__exit__(*exc)
 
 
 _LIB = None

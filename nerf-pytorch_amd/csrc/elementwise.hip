@@ -267,6 +267,33 @@ extern "C" int nerfhip_cumprod_exclusive(const float* x, int64_t rows, int cols,
     return nh_launch_status("cumprod_exclusive");
 }
 
+// Backward of the exclusive cumulative product (what autograd computes for nerf/nerf_helpers.py:43-64: cumprod, roll,
+// overwrite column 0): with y_i = prod_{k<i} x_k,  dL/dx_j = sum_{i>j} g_i * prod_{k<i, k != j} x_k -- formed without a
+// division, so rows containing zeros are exact.  One wavefront per row, lane = column j (strided), fp64 running product.
+NH_KERNEL void k_cumprod_exclusive_bwd(const float* __restrict__ x, const float* __restrict__ y,
+                                       const float* __restrict__ g, int64_t rows, int cols, float* __restrict__ gx) {
+    const int64_t row = blockIdx.x;
+    const float* xr = x + row * cols;
+    const float* gr = g + row * cols;
+    for (int j = nh_lane(); j < cols; j += 64) {
+        double t = (double)y[row * cols + j];  // prod_{k<j} x_k
+        double acc = 0.0;
+        for (int i = j + 1; i < cols; ++i) {
+            acc += (double)gr[i] * t;
+            t *= (double)xr[i];
+        }
+        gx[row * cols + j] = (float)acc;
+    }
+}
+
+extern "C" int nerfhip_cumprod_exclusive_bwd(const float* x, const float* y, const float* g_y, int64_t rows, int cols,
+                                             float* g_x, nerfhip_stream_t stream) {
+    if (rows == 0) return NERFHIP_OK;
+    NH_REQUIRE(x && y && g_y && g_x && rows >= 0 && cols > 0, "cumprod_exclusive_bwd: bad arguments");
+    NH_LAUNCH(k_cumprod_exclusive_bwd, rows, 64, 0, stream, x, y, g_y, rows, cols, g_x);
+    return nh_launch_status("cumprod_exclusive_bwd");
+}
+
 // ---- RNG fill ----------------------------------------------------------------------------------------------------
 NH_KERNEL void k_rng_fill(int kind, uint64_t seed, uint32_t stream_id, uint64_t first, int64_t n,
                           float* __restrict__ out) {

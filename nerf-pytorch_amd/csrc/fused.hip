@@ -7,8 +7,10 @@
 namespace {
 
 struct Workspace {
-    int64_t z_c, raw_c, w_c, z_f, raw_f, stash_c, stash_f, g_raw, scratch, total;
-    int64_t scratch_bytes;
+    int64_t z_c, raw_c, w_c, z_f, raw_f, stash_c, stash_f, total;
+    // backward buffers, one set per net: the coarse and the fine backward chains are independent and may run on
+    // different streams (nerfhip_render_bwd_parts)
+    int64_t g_raw_c, scratch_c, scratch_c_bytes, g_raw_f, scratch_f, scratch_f_bytes;
 };
 
 int64_t align_up(int64_t v) { return (v + 255) & ~(int64_t)255; }
@@ -32,17 +34,15 @@ Workspace layout(nerfhip_plan* pc, nerfhip_plan* pf, const nerfhip_render_cfg* c
     }
     if (training) {
         w.stash_c = take(nerfhip_plan_stash_bytes(pc, n * nc));
-        int64_t sb = nh_mlp_bwd_scratch_bytes(pc, n * nc);
-        int64_t graw = n * nc * 16;
+        w.g_raw_c = take(n * nc * 16);
+        w.scratch_c_bytes = nh_mlp_bwd_scratch_bytes(pc, n * nc);
+        w.scratch_c = take(w.scratch_c_bytes);
         if (nf > 0) {
             w.stash_f = take(nerfhip_plan_stash_bytes(pf, n * sf));
-            int64_t sbf = nh_mlp_bwd_scratch_bytes(pf, n * sf);
-            if (sbf > sb) sb = sbf;
-            graw = n * sf * 16;
+            w.g_raw_f = take(n * sf * 16);
+            w.scratch_f_bytes = nh_mlp_bwd_scratch_bytes(pf, n * sf);
+            w.scratch_f = take(w.scratch_f_bytes);
         }
-        w.g_raw = take(graw);
-        w.scratch = take(sb);
-        w.scratch_bytes = sb;
     }
     w.total = off;
     return w;
@@ -66,14 +66,15 @@ extern "C" int64_t nerfhip_render_workspace_bytes(nerfhip_plan_t plan_coarse, ne
     return layout(plan_coarse, plan_fine, cfg, n_rays, training).total;
 }
 
-extern "C" int nerfhip_render_fwd(nerfhip_plan_t pc, nerfhip_plan_t pf, const nerfhip_render_cfg* cfg, const float* rays,
-                                  int64_t n, const float* packed_c, const float* packed_f, const float* t_vals,
-                                  const float* u_det, const nerfhip_render_rand* rnd, uint64_t seed, uint64_t ray_offset,
-                                  const nerfhip_render_out* out, void* workspace, int64_t workspace_bytes, int training,
-                                  nerfhip_stream_t stream) {
+extern "C" int nerfhip_render_fwd_parts(nerfhip_plan_t pc, nerfhip_plan_t pf, const nerfhip_render_cfg* cfg,
+                                        const float* rays, int64_t n, const float* packed_c, const float* packed_f,
+                                        const float* t_vals, const float* u_det, const nerfhip_render_rand* rnd,
+                                        uint64_t seed, uint64_t ray_offset, const nerfhip_render_out* out, void* workspace,
+                                        int64_t workspace_bytes, int training, int parts, nerfhip_stream_t stream) {
     int rc = check_cfg(pc, pf, cfg);
     if (rc) return rc;
     NH_REQUIRE(rays && packed_c && t_vals && out && workspace && n >= 0, "render_fwd: bad arguments");
+    NH_REQUIRE(parts >= 1 && parts <= 3, "render_fwd: parts must be a combination of NERFHIP_PART_COARSE | NERFHIP_PART_FINE");
     NH_REQUIRE(cfg->num_fine == 0 || packed_f, "render_fwd: packed_fine is NULL");
     if (n == 0) return NERFHIP_OK;
     const Workspace w = layout(pc, pf, cfg, n, training);
@@ -87,23 +88,25 @@ extern "C" int nerfhip_render_fwd(nerfhip_plan_t pc, nerfhip_plan_t pf, const ne
     float* raw_c = (float*)(ws + w.raw_c);
     float* w_c = (float*)(ws + w.w_c);
 
-    rc = nerfhip_stratified_z(rays, stride, n, t_vals, nc, cfg->lindisp, cfg->perturb, r->t_rand, seed, ray_offset, z_c,
-                              stream);
-    if (rc) return rc;
     NhMlpInput in;
     memset(&in, 0, sizeof(in));
     in.mode = 1;
     in.rays = rays;
     in.ray_stride = stride;
-    in.z = z_c;
-    in.S = nc;
-    rc = nh_mlp_forward(pc, packed_c, in, n * nc, raw_c, training ? (float*)(ws + w.stash_c) : nullptr, stream);
-    if (rc) return rc;
-    rc = nerfhip_volume_render_fwd(raw_c, z_c, rays + 3, stride, n, nc, cfg->noise_std, r->noise_coarse, seed, 1u,
-                                   ray_offset, cfg->white_background, out->rgb_coarse, out->disp_coarse, out->acc_coarse,
-                                   w_c, out->depth_coarse, stream);
-    if (rc) return rc;
-    if (nf > 0) {
+    if (parts & NERFHIP_PART_COARSE) {
+        rc = nerfhip_stratified_z(rays, stride, n, t_vals, nc, cfg->lindisp, cfg->perturb, r->t_rand, seed, ray_offset, z_c,
+                                  stream);
+        if (rc) return rc;
+        in.z = z_c;
+        in.S = nc;
+        rc = nh_mlp_forward(pc, packed_c, in, n * nc, raw_c, training ? (float*)(ws + w.stash_c) : nullptr, stream);
+        if (rc) return rc;
+        rc = nerfhip_volume_render_fwd(raw_c, z_c, rays + 3, stride, n, nc, cfg->noise_std, r->noise_coarse, seed, 1u,
+                                       ray_offset, cfg->white_background, out->rgb_coarse, out->disp_coarse,
+                                       out->acc_coarse, w_c, out->depth_coarse, stream);
+        if (rc) return rc;
+    }
+    if (nf > 0 && (parts & NERFHIP_PART_FINE)) {
         float* z_f = (float*)(ws + w.z_f);
         float* raw_f = (float*)(ws + w.raw_f);
         const int det = cfg->perturb ? 0 : 1;  // det = (perturb == 0.0), nerf/train_utils.py:101
@@ -122,14 +125,24 @@ extern "C" int nerfhip_render_fwd(nerfhip_plan_t pc, nerfhip_plan_t pf, const ne
     return NERFHIP_OK;
 }
 
-extern "C" int nerfhip_render_bwd(nerfhip_plan_t pc, nerfhip_plan_t pf, const nerfhip_render_cfg* cfg, const float* rays,
-                                  int64_t n, const float* packed_c, const float* packed_f, const nerfhip_render_rand* rnd,
-                                  uint64_t seed, uint64_t ray_offset, const float* g_rgb_c, const float* g_rgb_f,
-                                  void* workspace, int64_t workspace_bytes, float* g_params_c, float* g_params_f,
+extern "C" int nerfhip_render_fwd(nerfhip_plan_t pc, nerfhip_plan_t pf, const nerfhip_render_cfg* cfg, const float* rays,
+                                  int64_t n, const float* packed_c, const float* packed_f, const float* t_vals,
+                                  const float* u_det, const nerfhip_render_rand* rnd, uint64_t seed, uint64_t ray_offset,
+                                  const nerfhip_render_out* out, void* workspace, int64_t workspace_bytes, int training,
                                   nerfhip_stream_t stream) {
+    return nerfhip_render_fwd_parts(pc, pf, cfg, rays, n, packed_c, packed_f, t_vals, u_det, rnd, seed, ray_offset, out,
+                                    workspace, workspace_bytes, training, NERFHIP_PART_COARSE | NERFHIP_PART_FINE, stream);
+}
+
+extern "C" int nerfhip_render_bwd_parts(nerfhip_plan_t pc, nerfhip_plan_t pf, const nerfhip_render_cfg* cfg,
+                                        const float* rays, int64_t n, const float* packed_c, const float* packed_f,
+                                        const nerfhip_render_rand* rnd, uint64_t seed, uint64_t ray_offset,
+                                        const nerfhip_render_cotangents* g, void* workspace, int64_t workspace_bytes,
+                                        float* g_params_c, float* g_params_f, int parts, nerfhip_stream_t stream) {
     int rc = check_cfg(pc, pf, cfg);
     if (rc) return rc;
-    NH_REQUIRE(rays && packed_c && g_rgb_c && workspace && g_params_c && n > 0, "render_bwd: bad arguments");
+    NH_REQUIRE(rays && packed_c && g && workspace && n > 0, "render_bwd: bad arguments");
+    NH_REQUIRE(parts >= 1 && parts <= 3, "render_bwd: parts must be a combination of NERFHIP_PART_COARSE | NERFHIP_PART_FINE");
     const Workspace w = layout(pc, pf, cfg, n, 1);
     NH_REQUIRE(workspace_bytes >= w.total, "render_bwd: workspace too small (%lld < %lld)", (long long)workspace_bytes,
                (long long)w.total);
@@ -137,22 +150,40 @@ extern "C" int nerfhip_render_bwd(nerfhip_plan_t pc, nerfhip_plan_t pf, const ne
     const int nc = cfg->num_coarse, nf = cfg->num_fine, sf = nc + nf, stride = cfg->ray_stride;
     nerfhip_render_rand none = {nullptr, nullptr, nullptr, nullptr};
     const nerfhip_render_rand* r = rnd ? rnd : &none;
-    float* g_raw = (float*)(ws + w.g_raw);
-    float* scratch = (float*)(ws + w.scratch);
-    if (nf > 0) {
-        NH_REQUIRE(packed_f && g_rgb_f && g_params_f, "render_bwd: fine arguments missing");
+    if (nf > 0 && (parts & NERFHIP_PART_FINE)) {
+        NH_REQUIRE(packed_f && g_params_f && (g->g_rgb_fine || g->g_acc_fine || g->g_depth_fine),
+                   "render_bwd: fine arguments missing");
+        float* g_raw = (float*)(ws + w.g_raw_f);
         rc = nerfhip_volume_render_bwd((const float*)(ws + w.raw_f), (const float*)(ws + w.z_f), rays + 3, stride, n, sf,
                                        cfg->noise_std, r->noise_fine, seed, 3u, ray_offset, cfg->white_background,
-                                       g_rgb_f, nullptr, nullptr, nullptr, g_raw, stream);
+                                       g->g_rgb_fine, g->g_depth_fine, g->g_acc_fine, nullptr, g_raw, stream);
         if (rc) return rc;
-        rc = nh_mlp_backward(pf, packed_f, g_raw, n * sf, (const float*)(ws + w.stash_f), scratch, w.scratch_bytes,
-                             g_params_f, stream);
+        rc = nh_mlp_backward(pf, packed_f, g_raw, n * sf, (const float*)(ws + w.stash_f), (float*)(ws + w.scratch_f),
+                             w.scratch_f_bytes, g_params_f, stream);
         if (rc) return rc;
     }
-    rc = nerfhip_volume_render_bwd((const float*)(ws + w.raw_c), (const float*)(ws + w.z_c), rays + 3, stride, n, nc,
-                                   cfg->noise_std, r->noise_coarse, seed, 1u, ray_offset, cfg->white_background, g_rgb_c,
-                                   nullptr, nullptr, nullptr, g_raw, stream);
-    if (rc) return rc;
-    return nh_mlp_backward(pc, packed_c, g_raw, n * nc, (const float*)(ws + w.stash_c), scratch, w.scratch_bytes,
-                           g_params_c, stream);
+    if (parts & NERFHIP_PART_COARSE) {
+        NH_REQUIRE(g_params_c && (g->g_rgb_coarse || g->g_acc_coarse || g->g_depth_coarse),
+                   "render_bwd: coarse arguments missing");
+        float* g_raw = (float*)(ws + w.g_raw_c);
+        rc = nerfhip_volume_render_bwd((const float*)(ws + w.raw_c), (const float*)(ws + w.z_c), rays + 3, stride, n, nc,
+                                       cfg->noise_std, r->noise_coarse, seed, 1u, ray_offset, cfg->white_background,
+                                       g->g_rgb_coarse, g->g_depth_coarse, g->g_acc_coarse, nullptr, g_raw, stream);
+        if (rc) return rc;
+        rc = nh_mlp_backward(pc, packed_c, g_raw, n * nc, (const float*)(ws + w.stash_c), (float*)(ws + w.scratch_c),
+                             w.scratch_c_bytes, g_params_c, stream);
+        if (rc) return rc;
+    }
+    return NERFHIP_OK;
+}
+
+extern "C" int nerfhip_render_bwd(nerfhip_plan_t pc, nerfhip_plan_t pf, const nerfhip_render_cfg* cfg, const float* rays,
+                                  int64_t n, const float* packed_c, const float* packed_f, const nerfhip_render_rand* rnd,
+                                  uint64_t seed, uint64_t ray_offset, const float* g_rgb_c, const float* g_rgb_f,
+                                  void* workspace, int64_t workspace_bytes, float* g_params_c, float* g_params_f,
+                                  nerfhip_stream_t stream) {
+    NH_REQUIRE(g_rgb_c && g_params_c, "render_bwd: bad arguments");
+    nerfhip_render_cotangents g = {g_rgb_c, nullptr, nullptr, g_rgb_f, nullptr, nullptr};
+    return nerfhip_render_bwd_parts(pc, pf, cfg, rays, n, packed_c, packed_f, rnd, seed, ray_offset, &g, workspace,
+                                    workspace_bytes, g_params_c, g_params_f, NERFHIP_PART_COARSE | NERFHIP_PART_FINE, stream);
 }

@@ -1,13 +1,20 @@
-"""TrainEngine: one NeRF training iteration (train_nerf.py:229-270) as a fixed sequence of C-ABI calls on one HIP
-stream, with no host synchronisation inside the step:
+"""TrainEngine: one NeRF training iteration (train_nerf.py:229-270) as a fixed graph of C-ABI calls on two HIP
+streams, with no host synchronisation inside the step.  The reference runs everything sequentially
+(nerf/train_utils.py:68-117 coarse then fine, train_nerf.py:244-261 loss, backward, optimiser); here
 
-    render_fwd (coarse + fine, in-kernel Philox draws) -> mse loss + cotangents -> render_bwd (both nets)
-    -> [RCCL all-reduce of the flat gradient, one collective for both nets] -> fused Adam on the flat parameters
-    -> re-pack the MFMA weight images.
+    main stream:  coarse forward --E1--> hierarchical sampling + fine forward -> fine loss -> fine backward
+                  -> [all-reduce of the fine net's gradient, async] ------------------------------+
+    side stream:           E1 -> coarse loss -> coarse backward --E2-->                           |
+    main stream:                                            wait E2 -> [all-reduce coarse] -> wait both -> Adam -> re-pack
+
+the coarse net's backward needs nothing from the fine pass, so it runs next to the fine forward/backward (fills the
+tails of those launches), and with G > 1 ranks the fine net's gradient all-reduce (RCCL) is in flight while the coarse
+backward still computes.  `overlap=False` gives the single-stream order (coarse+fine forward, loss, fine backward,
+coarse backward) with the same collectives.
 
 Data parallelism (BASELINE config 3): one process per GPU, weights replicated, each rank renders its own N/G rays;
-the only exchange is the all-reduce (sum) of the 2 x 595,844-float gradient, scaled by 1/G inside the Adam kernel.
-Every rank applies the identical update, so no parameter broadcast is needed after step 0.
+the only exchange is the all-reduce (sum) of the 2 x 595,844-float gradient (one collective per net), scaled by 1/G
+inside the Adam kernel.  Every rank applies the identical update, so no parameter broadcast is needed after step 0.
 """
 import ctypes as C
 import math
@@ -19,14 +26,10 @@ from .nerf_helpers import linspace01
 from .parallel import allreduce_gradients
 
 
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
-
-
 class TrainEngine:
     def __init__(self, model_coarse, model_fine, num_coarse, num_fine, perturb=True, lindisp=False, white_background=False,
                  noise_std=0.0, lr=5e-3, betas=(0.9, 0.999), eps=1e-8, seed=0, process_group=None, world_size=None,
-                 rank=None):
+                 rank=None, overlap=True):
         self.lib = L.get_lib()
         self.mc, self.mf = model_coarse, model_fine if num_fine > 0 else None
         self.dev = model_coarse.flat_params.device
@@ -53,6 +56,12 @@ class TrainEngine:
         self.exp_avg = torch.zeros_like(self.grad)
         self.exp_avg_sq = torch.zeros_like(self.grad)
         self.loss = torch.zeros(3, dtype=torch.float32, device=self.dev)
+        self._loss_c = torch.zeros(3, dtype=torch.float32, device=self.dev)
+        self._loss_f = torch.zeros(3, dtype=torch.float32, device=self.dev)
+        self.overlap = bool(overlap)
+        self._side = None       # second HIP stream of this device (created on first use)
+        self._ev = None
+        self._pending = []      # in-flight gradient all-reduces of the current step
         self._ws = None
         self._ws_n = -1
         self._bufs = None
@@ -82,10 +91,38 @@ class TrainEngine:
     def workspace_bytes(self):
         return 0 if self._ws is None else self._wsb
 
-    def forward_backward(self, rays, target, ray_offset=0):
-        """rays: (n, 8|11) packed rows on the device; target: (n, >=3).  Leaves the summed-over-this-rank gradient in
-        self.grad and {coarse_mse, fine_mse, sum} in self.loss (device)."""
+    def _check_inputs(self, rays, target):
+        for name, t in (("rays", rays), ("target", target)):
+            if not isinstance(t, torch.Tensor) or not t.is_cuda or t.device != self.dev:
+                raise RuntimeError("TrainEngine: %s must be a tensor on %s (nerf_pytorch_amd has no CPU path)" % (name, self.dev))
+            if t.dtype != torch.float32:
+                raise RuntimeError("TrainEngine: %s must be float32 (got %s)" % (name, t.dtype))
+            if t.dim() != 2:
+                raise RuntimeError("TrainEngine: %s must be 2-D (got shape %s)" % (name, tuple(t.shape)))
+        if rays.shape[1] != self.stride or not rays.is_contiguous():
+            raise RuntimeError("TrainEngine: rays must be contiguous rows of %d floats (got shape %s, strides %s)"
+                               % (self.stride, tuple(rays.shape), rays.stride()))
+        if target.shape[0] != rays.shape[0] or target.shape[1] < 3 or target.stride(1) != 1:
+            # e.g. target_s[..., :3] of an RGBA image is fine (row stride 4 is passed on), a transposed view is not
+            raise RuntimeError("TrainEngine: target must hold one row of >= 3 unit-stride floats per ray (got shape %s, "
+                               "strides %s)" % (tuple(target.shape), target.stride()))
+
+    def _streams(self):
+        main = torch.cuda.current_stream(self.dev)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+            self._ev = (torch.cuda.Event(), torch.cuda.Event())
+        return main, self._side
+
+    def forward_backward(self, rays, target, ray_offset=0, global_rays=None):
+        """rays: (n, 8|11) packed rows on the device; target: (n, >=3), row stride free (an RGBA image's [..., :3] view
+        works).  Leaves the summed-over-this-rank gradient in self.grad and {coarse_mse, fine_mse, sum} in self.loss
+        (device); with world > 1 the gradient all-reduces are in flight when this returns (optimizer_step waits).
+        global_rays: total rays of the step over all ranks when the shards are NOT equal -- this rank's cotangents are
+        then weighted n * world / global_rays, so that the 1/world-scaled sum is the gradient of the global-batch mean."""
+        self._check_inputs(rays, target)
         lib, n = self.lib, rays.shape[0]
+        gscale = 1.0 if global_rays is None else float(n) * self.world / float(global_rays)
         self._prepare(n)
         b = self._bufs
         nf = self.cfg.num_fine
@@ -94,39 +131,81 @@ class TrainEngine:
                           b["rgb_f"].data_ptr() if nf > 0 else None, b["disp_f"].data_ptr() if nf > 0 else None,
                           b["acc_f"].data_ptr() if nf > 0 else None, None)
         seed = self.seed + self.step_count * 0x9E3779B97F4A7C15 & 0xFFFFFFFFFFFFFFFF
-        st = _stream()
         pf = self.packed_f.data_ptr() if nf > 0 else None
-        lib.render_fwd(self.mc._plan, plan_f, C.byref(self.cfg), rays.data_ptr(), n, self.packed_c.data_ptr(), pf,
-                       self.t_vals.data_ptr(), self.u_det.data_ptr() if nf > 0 else None, None, seed, ray_offset,
-                       C.byref(out), self._ws.data_ptr(), self._wsb, 1, st)
-        lib.mse_loss_fwd_bwd(b["rgb_c"].data_ptr(), b["rgb_f"].data_ptr() if nf > 0 else None, target.data_ptr(),
-                             target.shape[1], n, 1.0, b["g_c"].data_ptr(), b["g_f"].data_ptr() if nf > 0 else None,
-                             self.loss.data_ptr(), st)
         gc = self.grad[:self.nc_params]
         gf = self.grad[self.nc_params:] if nf > 0 else None
-        lib.render_bwd(self.mc._plan, plan_f, C.byref(self.cfg), rays.data_ptr(), n, self.packed_c.data_ptr(), pf, None,
-                       seed, ray_offset, b["g_c"].data_ptr(), b["g_f"].data_ptr() if nf > 0 else None,
-                       self._ws.data_ptr(), self._wsb, gc.data_ptr(), gf.data_ptr() if gf is not None else None, st)
+        tstride = target.stride(0)
+        cot_c = L.RenderCotangents(b["g_c"].data_ptr(), None, None, None, None, None)
+        cot_f = L.RenderCotangents(None, None, None, b["g_f"].data_ptr() if nf > 0 else None, None, None)
+        fwd_args = (self.mc._plan, plan_f, C.byref(self.cfg), rays.data_ptr(), n, self.packed_c.data_ptr(), pf,
+                    self.t_vals.data_ptr(), self.u_det.data_ptr() if nf > 0 else None, None, seed, ray_offset,
+                    C.byref(out), self._ws.data_ptr(), self._wsb, 1)
+        bwd_head = (self.mc._plan, plan_f, C.byref(self.cfg), rays.data_ptr(), n, self.packed_c.data_ptr(), pf, None, seed,
+                    ray_offset)
+        bwd_tail = (self._ws.data_ptr(), self._wsb, gc.data_ptr(), gf.data_ptr() if gf is not None else None)
+        self._pending = []
+        with torch.cuda.device(self.dev):
+            main, side = self._streams()
+            st = main.cuda_stream
+            two = self.overlap and nf > 0
+            lib.render_fwd_parts(*fwd_args, L.PART_COARSE, st)
+
+            def coarse_backward(stream_handle):
+                lib.mse_loss_fwd_bwd(b["rgb_c"].data_ptr(), None, target.data_ptr(), tstride, n, gscale, b["g_c"].data_ptr(),
+                                     None, self._loss_c.data_ptr(), stream_handle)
+                lib.render_bwd_parts(*bwd_head, C.byref(cot_c), *bwd_tail, L.PART_COARSE, stream_handle)
+
+            if two:
+                e1, e2 = self._ev
+                e1.record(main)
+                side.wait_event(e1)
+                coarse_backward(side.cuda_stream)
+                e2.record(side)
+            if nf > 0:
+                lib.render_fwd_parts(*fwd_args, L.PART_FINE, st)
+                lib.mse_loss_fwd_bwd(b["rgb_f"].data_ptr(), None, target.data_ptr(), tstride, n, gscale, b["g_f"].data_ptr(),
+                                     None, self._loss_f.data_ptr(), st)
+                lib.render_bwd_parts(*bwd_head, C.byref(cot_f), *bwd_tail, L.PART_FINE, st)
+                if self.world > 1:  # in flight while the coarse backward computes
+                    self._pending.append(allreduce_gradients(gf, self.pg, async_op=True))
+            if two:
+                main.wait_event(e2)
+            else:
+                coarse_backward(st)
+            if self.world > 1:
+                self._pending.append(allreduce_gradients(gc, self.pg, async_op=True))
+            if nf > 0:
+                torch.stack((self._loss_c[0], self._loss_f[0], self._loss_c[0] + self._loss_f[0]), out=self.loss)
+            else:
+                self.loss.copy_(self._loss_c)
+
+    def wait_gradients(self):
+        """Makes the current stream wait for the step's gradient all-reduces (no-op for one rank)."""
+        for w in self._pending:
+            if w is not None:
+                w.wait()
+        self._pending = []
 
     def optimizer_step(self, lr=None):
-        lib, st = self.lib, _stream()
+        lib = self.lib
+        self.wait_gradients()
         self.step_count += 1
         lr = self.lr if lr is None else lr
         scale = 1.0 / self.world
         b1, b2 = self.betas
         n0 = self.nc_params
-        lib.adam_step(self.mc.flat_params.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(),
-                      self.exp_avg_sq.data_ptr(), n0, lr, b1, b2, self.eps, self.step_count, scale, st)
-        if self.mf is not None:
-            lib.adam_step(self.mf.flat_params.data_ptr(), self.grad[n0:].data_ptr(), self.exp_avg[n0:].data_ptr(),
-                          self.exp_avg_sq[n0:].data_ptr(), self.nf_params, lr, b1, b2, self.eps, self.step_count, scale, st)
+        with L.launch_on(self.grad, self.mc.flat_params) as st:
+            lib.adam_step(self.mc.flat_params.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(),
+                          self.exp_avg_sq.data_ptr(), n0, lr, b1, b2, self.eps, self.step_count, scale, st)
+            if self.mf is not None:
+                lib.adam_step(self.mf.flat_params.data_ptr(), self.grad[n0:].data_ptr(), self.exp_avg[n0:].data_ptr(),
+                              self.exp_avg_sq[n0:].data_ptr(), self.nf_params, lr, b1, b2, self.eps, self.step_count, scale,
+                              st)
         self.repack()
 
-    def step(self, rays, target, ray_offset=0, lr=None):
+    def step(self, rays, target, ray_offset=0, lr=None, global_rays=None):
         """One full training iteration.  Returns the device tensor {coarse_mse, fine_mse, sum} (no host sync)."""
-        self.forward_backward(rays, target, ray_offset)
-        if self.world > 1:
-            allreduce_gradients(self.grad, self.pg)
+        self.forward_backward(rays, target, ray_offset, global_rays)
         self.optimizer_step(lr)
         return self.loss
 

@@ -20,17 +20,14 @@ import torch
 from . import _lib as L
 
 
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
-
-
 def _cast_to_image_device(tensor):
     if not tensor.is_cuda:
         raise RuntimeError("cast_to_image needs a CUDA (HIP) tensor: nerf_pytorch_amd has no CPU path")
     t = tensor.detach().float().contiguous()
     h, w, c = t.shape
     out = torch.empty((h, w, 3), dtype=torch.uint8, device=t.device)
-    L.get_lib().cast_to_image(t.data_ptr(), c, h * w, out.data_ptr(), _stream())
+    with L.launch_on(t, out) as st:
+        L.get_lib().cast_to_image(t.data_ptr(), c, h * w, out.data_ptr(), st)
     return out
 
 
@@ -40,7 +37,8 @@ def _cast_to_disparity_device(tensor):
     t = tensor.detach().float().contiguous()
     out = torch.empty(t.shape, dtype=torch.uint8, device=t.device)
     scratch = torch.empty(3, dtype=torch.float32, device=t.device)
-    L.get_lib().cast_to_disparity_image(t.data_ptr(), t.numel(), scratch.data_ptr(), out.data_ptr(), _stream())
+    with L.launch_on(t, out, scratch) as st:
+        L.get_lib().cast_to_disparity_image(t.data_ptr(), t.numel(), scratch.data_ptr(), out.data_ptr(), st)
     return out
 
 

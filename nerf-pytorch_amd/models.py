@@ -16,25 +16,62 @@ from . import _lib as L
 from .nerf_helpers import frequency_bands_cpu
 
 
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
+class _PlanHandle:
+    """Owner of one native ``nerfhip_plan`` (host-only object: packing tables, kernel schedules).  The handle is never
+    duplicated: copying or unpickling an owner builds a NEW plan from the model configuration, so ``copy.deepcopy(model)``
+    (EMA / best-model snapshots) and ``torch.save(model)`` cannot double-free or revive a stale address."""
+
+    def __init__(self, cfg):
+        self.cfg = dict(cfg)
+        lib = L.get_lib()
+        mc = L.ModelCfg(**{k: int(v) for k, v in self.cfg.items()})
+        self.ptr = lib.plan_create(C.byref(mc))
+        if not self.ptr:
+            raise L.NerfHipError("unsupported FlexibleNeRFModel geometry: " + lib.last_error().decode())
+        fx = torch.zeros(16)
+        fd = torch.zeros(16)
+        nx, nd = self.cfg["num_encoding_fn_xyz"], self.cfg["num_encoding_fn_dir"]
+        fx[:nx] = frequency_bands_cpu(nx, self.cfg["log_sampling_xyz"])
+        if self.cfg["use_viewdirs"]:
+            fd[:nd] = frequency_bands_cpu(nd, self.cfg["log_sampling_dir"])
+        lib.plan_set_freqs(self.ptr, fx.contiguous().data_ptr(), fd.contiguous().data_ptr())
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None):
+                L.get_lib().plan_destroy(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+    def __deepcopy__(self, memo):
+        return _PlanHandle(self.cfg)
+
+    def __copy__(self):
+        return _PlanHandle(self.cfg)
+
+    def __reduce__(self):
+        return (_PlanHandle, (self.cfg,))
 
 
 class _MlpFunction(torch.autograd.Function):
-    """y = FlexibleNeRFModel(x).  Gradients flow to the parameters only (x is an encoding: no gradient in the hot path)."""
+    """y = FlexibleNeRFModel(x).  Gradients flow to the parameters only (x is an encoding: no gradient in the hot path).
+    The parameters are passed as individual autograd inputs (they alias the model's flat buffer, which is what the
+    kernels read); backward hands each one its slice of the flat gradient -- no concatenation in either direction."""
 
     @staticmethod
-    def forward(ctx, model, x, flat):
+    def forward(ctx, model, x, *params):
         lib = L.get_lib()
         m = x.shape[0]
         out = torch.empty((m, 4), dtype=torch.float32, device=x.device)
-        need = bool(ctx.needs_input_grad[2])  # (grad mode is off inside Function.forward: ask autograd instead)
+        need = any(ctx.needs_input_grad[2:])  # (grad mode is off inside Function.forward: ask autograd instead)
         packed = model._packed()
         stash = None
         if need:
             stash = torch.empty(max(lib.plan_stash_bytes(model._plan, m), 4) // 4, dtype=torch.float32, device=x.device)
-        lib.mlp_fwd(model._plan, packed.data_ptr(), x.data_ptr(), m, out.data_ptr(),
-                    stash.data_ptr() if stash is not None else None, _stream())
+        with L.launch_on(x, out, packed, stash) as st:
+            lib.mlp_fwd(model._plan, packed.data_ptr(), x.data_ptr(), m, out.data_ptr(),
+                        stash.data_ptr() if stash is not None else None, st)
         ctx.model, ctx.m, ctx.stash, ctx.packed = model, m, stash, packed
         return out
 
@@ -46,9 +83,10 @@ class _MlpFunction(torch.autograd.Function):
         sb = lib.plan_bwd_scratch_bytes(model._plan, m)
         scratch = torch.empty(sb // 4 + 1, dtype=torch.float32, device=g.device)
         gflat = torch.empty(model.num_flat_params, dtype=torch.float32, device=g.device)
-        lib.mlp_bwd(model._plan, ctx.packed.data_ptr(), g.data_ptr(), m, ctx.stash.data_ptr(), scratch.data_ptr(), sb,
-                    gflat.data_ptr(), _stream())
-        return None, None, gflat
+        with L.launch_on(g, scratch, gflat, ctx.packed, ctx.stash) as st:
+            lib.mlp_bwd(model._plan, ctx.packed.data_ptr(), g.data_ptr(), m, ctx.stash.data_ptr(), scratch.data_ptr(), sb,
+                        gflat.data_ptr(), st)
+        return (None, None) + model._split_flat(gflat)
 
 
 class FlexibleNeRFModel(torch.nn.Module):
@@ -86,19 +124,13 @@ class FlexibleNeRFModel(torch.nn.Module):
         else:
             self.fc_out = torch.nn.Linear(hidden_size, 4)
         self.relu = torch.nn.functional.relu
+        self._native_init()
 
+    # ---- the native plan and the flat parameter storage ---------------------------------------------------------------
+    def _native_init(self):
+        """(Re)creates everything that refers to native memory: the plan, the tensor layout, the flat buffer."""
         lib = L.get_lib()
-        mc = L.ModelCfg(**{k: int(v) for k, v in self.cfg.items()})
-        self._plan = lib.plan_create(C.byref(mc))
-        if not self._plan:
-            raise L.NerfHipError("unsupported FlexibleNeRFModel geometry: " + lib.last_error().decode())
-        fx = torch.zeros(16)
-        fd = torch.zeros(16)
-        fx[:num_encoding_fn_xyz] = frequency_bands_cpu(num_encoding_fn_xyz, log_sampling_xyz)
-        if use_viewdirs:
-            fd[:num_encoding_fn_dir] = frequency_bands_cpu(num_encoding_fn_dir, log_sampling_dir)
-        self._freq_keep = (fx.contiguous(), fd.contiguous())
-        lib.plan_set_freqs(self._plan, fx.data_ptr(), fd.data_ptr())
+        self._plan_owner = _PlanHandle(self.cfg)
         self.num_flat_params = int(lib.plan_num_params(self._plan))
         self._layout = []
         for i in range(lib.plan_num_tensors(self._plan)):
@@ -109,18 +141,24 @@ class FlexibleNeRFModel(torch.nn.Module):
         self._flat_grad = None
         self._pack_table = None
         self._packed_buf = None
-        self._packed_version = None
         self._flatten()
 
-    def __del__(self):
-        try:
-            if getattr(self, "_plan", None):
-                L.get_lib().plan_destroy(self._plan)
-                self._plan = None
-        except Exception:
-            pass
+    @property
+    def _plan(self):
+        return self._plan_owner.ptr
 
-    # ---- flat parameter storage -------------------------------------------------------------------------------------
+    def __getstate__(self):
+        # copy.deepcopy / pickle: the native handle and every cache derived from it stay behind; the parameters travel
+        # as ordinary tensors and are re-homed into a fresh flat buffer by __setstate__
+        state = self.__dict__.copy()
+        for k in ("_plan_owner", "_flat", "_flat_grad", "_pack_table", "_packed_buf"):
+            state[k] = None
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._native_init()
+
     def _named(self):
         return dict(self.named_parameters())
 
@@ -176,8 +214,18 @@ class FlexibleNeRFModel(torch.nn.Module):
             self._packed_buf = torch.empty(n, dtype=torch.float32, device=dev)
             force = True
         if force:
-            lib.pack_weights(self._flat.data_ptr(), self._pack_table.data_ptr(), n, self._packed_buf.data_ptr(), _stream())
+            with L.launch_on(self._flat, self._pack_table, self._packed_buf) as st:
+                lib.pack_weights(self._flat.data_ptr(), self._pack_table.data_ptr(), n, self._packed_buf.data_ptr(), st)
         return self._packed_buf
+
+    def _ordered_params(self):
+        named = self._named()
+        return [named[name] for name, _, _, _ in self._layout]
+
+    def _split_flat(self, gflat):
+        """Slices of a flat gradient vector shaped like the parameters, in _ordered_params() order."""
+        return tuple(gflat[off:off + rows * max(cols, 1)].view((rows, cols) if cols else (rows,))
+                     for _, off, rows, cols in self._layout)
 
     # ---- reference forward contract -----------------------------------------------------------------------------------
     def forward(self, x):
@@ -189,12 +237,5 @@ class FlexibleNeRFModel(torch.nn.Module):
         x2 = x.reshape(-1, x.shape[-1]).contiguous().float()
         if x2.shape[-1] != self.dim_xyz + self.dim_dir:
             raise RuntimeError("expected %d input columns, got %d" % (self.dim_xyz + self.dim_dir, x2.shape[-1]))
-        # route the gradient to the parameters through the flat view: grads of views accumulate into each .grad
-        flat_leaf = torch.cat([p.reshape(-1) for p in self._ordered_params()]) if torch.is_grad_enabled() and any(
-            p.requires_grad for p in self.parameters()) else self._flat
-        y = _MlpFunction.apply(self, x2, flat_leaf)
+        y = _MlpFunction.apply(self, x2, *self._ordered_params())
         return y.reshape(list(lead) + [4])
-
-    def _ordered_params(self):
-        named = self._named()
-        return [named[name] for name, _, _, _ in self._layout]

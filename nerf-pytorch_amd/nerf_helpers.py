@@ -11,11 +11,7 @@ from typing import Optional
 
 import torch
 
-from ._lib import get_lib
-
-
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
+from ._lib import get_lib, launch_on
 
 
 def _dev32(t, what):
@@ -75,14 +71,39 @@ def meshgrid_xy(tensor1: torch.Tensor, tensor2: torch.Tensor):
     return ii.transpose(-1, -2), jj.transpose(-1, -2)
 
 
+class _CumprodExclusive(torch.autograd.Function):
+    """Exclusive cumulative product along the last dimension with the gradient autograd derives for the reference's
+    cumprod / roll / overwrite composition (nerf/nerf_helpers.py:43-64) -- tiny_nerf.py:100-101 backpropagates through it."""
+
+    @staticmethod
+    def forward(ctx, x):
+        cols = x.shape[-1]
+        rows = x.numel() // max(cols, 1)
+        out = torch.empty_like(x)
+        with launch_on(x, out) as st:
+            get_lib().cumprod_exclusive(x.data_ptr(), rows, cols, out.data_ptr(), st)
+        ctx.save_for_backward(x, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        cols = x.shape[-1]
+        rows = x.numel() // max(cols, 1)
+        g = g.contiguous().float()
+        gx = torch.empty_like(x)
+        with launch_on(x, y, g, gx) as st:
+            get_lib().cumprod_exclusive_bwd(x.data_ptr(), y.data_ptr(), g.data_ptr(), rows, cols, gx.data_ptr(), st)
+        return gx
+
+
 def cumprod_exclusive(tensor: torch.Tensor) -> torch.Tensor:
-    """nerf/nerf_helpers.py:43-64 -- exclusive cumulative product along the last dimension."""
-    x = _dev32(tensor, "tensor")
-    cols = x.shape[-1]
-    rows = x.numel() // max(cols, 1)
-    out = torch.empty_like(x)
-    get_lib().cumprod_exclusive(x.data_ptr(), rows, cols, out.data_ptr(), _stream())
-    return out
+    """nerf/nerf_helpers.py:43-64 -- exclusive cumulative product along the last dimension (differentiable)."""
+    if not isinstance(tensor, torch.Tensor) or not tensor.is_cuda:
+        raise RuntimeError("tensor must be a CUDA (HIP) tensor: nerf_pytorch_amd has no CPU path")
+    if tensor.dtype != torch.float32:
+        raise RuntimeError("tensor must be float32 (got %s)" % tensor.dtype)
+    return _CumprodExclusive.apply(tensor.contiguous())
 
 
 def get_ray_bundle(height: int, width: int, focal_length, tform_cam2world: torch.Tensor):
@@ -95,8 +116,8 @@ def get_ray_bundle(height: int, width: int, focal_length, tform_cam2world: torch
     n = height * width
     ro = torch.empty((height, width, 3), dtype=torch.float32, device=c2w.device)
     rd = torch.empty_like(ro)
-    get_lib().ray_bundle(height, width, focal, c2w.data_ptr(), c2w.stride(0), None, n, ro.data_ptr(), rd.data_ptr(),
-                         _stream())
+    with launch_on(c2w, ro, rd) as st:
+        get_lib().ray_bundle(height, width, focal, c2w.data_ptr(), c2w.stride(0), None, n, ro.data_ptr(), rd.data_ptr(), st)
     return ro, rd
 
 
@@ -108,8 +129,9 @@ def get_rays_at_pixels(height: int, width: int, focal_length, tform_cam2world: t
     n = pix.numel()
     ro = torch.empty((n, 3), dtype=torch.float32, device=c2w.device)
     rd = torch.empty_like(ro)
-    get_lib().ray_bundle(height, width, float(focal_length), c2w.data_ptr(), c2w.stride(0), pix.data_ptr(), n,
-                         ro.data_ptr(), rd.data_ptr(), _stream())
+    with launch_on(c2w, pix, ro, rd) as st:
+        get_lib().ray_bundle(height, width, float(focal_length), c2w.data_ptr(), c2w.stride(0), pix.data_ptr(), n,
+                             ro.data_ptr(), rd.data_ptr(), st)
     return ro, rd
 
 
@@ -123,8 +145,9 @@ def positional_encoding(tensor, num_encoding_functions=6, include_input=True, lo
     out = torch.empty(list(x.shape[:-1]) + [d * (int(bool(include_input)) + 2 * num_encoding_functions)],
                       dtype=torch.float32, device=x.device)
     fr = _freqs(num_encoding_functions, log_sampling, x.device)
-    get_lib().positional_encoding(x.data_ptr(), m, d, fr.data_ptr(), num_encoding_functions, int(bool(include_input)),
-                                  out.data_ptr(), _stream())
+    with launch_on(x, fr, out) as st:
+        get_lib().positional_encoding(x.data_ptr(), m, d, fr.data_ptr(), num_encoding_functions, int(bool(include_input)),
+                                      out.data_ptr(), st)
     return out
 
 
@@ -159,8 +182,9 @@ def ndc_rays(H, W, focal, near, rays_o, rays_d):
         ch = -1.0 / (H / (2.0 * focal))
     n = o.numel() // 3
     oo, od = torch.empty_like(o), torch.empty_like(d)
-    get_lib().ndc_rays(float(near), cw, ch, 2.0 * near, -2.0 * near, o.data_ptr(), d.data_ptr(), n, oo.data_ptr(),
-                       od.data_ptr(), _stream())
+    with launch_on(o, d, oo, od) as st:
+        get_lib().ndc_rays(float(near), cw, ch, 2.0 * near, -2.0 * near, o.data_ptr(), d.data_ptr(), n, oo.data_ptr(),
+                           od.data_ptr(), st)
     return oo, od
 
 
@@ -177,9 +201,9 @@ def sample_pdf_2(bins, weights, num_samples, det=False):
     if not det:
         u = torch.rand(list(w.shape[:-1]) + [num_samples], dtype=torch.float32, device=w.device).contiguous()
     out = torch.empty(list(b.shape[:-1]) + [num_samples], dtype=torch.float32, device=b.device)
-    get_lib().sample_pdf(b.data_ptr(), w.data_ptr(), n, nb, u.data_ptr() if u is not None else None, int(bool(det)),
-                         linspace01(num_samples, b.device).data_ptr(), num_samples, 0, 0, out.data_ptr(), None, None,
-                         _stream())
+    with launch_on(b, w, u, out) as st:
+        get_lib().sample_pdf(b.data_ptr(), w.data_ptr(), n, nb, u.data_ptr() if u is not None else None, int(bool(det)),
+                             linspace01(num_samples, b.device).data_ptr(), num_samples, 0, 0, out.data_ptr(), None, None, st)
     return out
 
 
@@ -200,6 +224,7 @@ def sample_pdf_with_indices(bins, weights, u):
     out = torch.empty_like(uu)
     inds = torch.empty(uu.shape, dtype=torch.int64, device=uu.device)
     cdf = torch.empty_like(b)
-    get_lib().sample_pdf(b.data_ptr(), w.data_ptr(), n, nb, uu.data_ptr(), 0, None, nf, 0, 0, out.data_ptr(),
-                         inds.data_ptr(), cdf.data_ptr(), _stream())
+    with launch_on(b, w, uu, out, inds, cdf) as st:
+        get_lib().sample_pdf(b.data_ptr(), w.data_ptr(), n, nb, uu.data_ptr(), 0, None, nf, 0, 0, out.data_ptr(),
+                             inds.data_ptr(), cdf.data_ptr(), st)
     return out, inds, cdf

@@ -1,8 +1,8 @@
 """Data parallelism for the NeRF step: one process per GPU, replicated weights, rays sharded.
 
 The path shards embarrassingly: every rank renders its own contiguous slice of the step's rays; the only exchange is
-ONE all-reduce (sum) per step of the flat fp32 gradient of both nets (2 x 595,844 floats = 4.77 MB for 8x256) over
-RCCL/xGMI.  Each rank's loss is a mean over its own rays, so for equal shards the global gradient is the rank
+the all-reduce (sum) of the flat fp32 gradient (2 x 595,844 floats = 4.77 MB for 8x256) over RCCL/xGMI, issued as one
+collective per net so that the fine net's half travels while the coarse net's backward still computes (engine.py).  Each rank's loss is a mean over its own rays, so for equal shards the global gradient is the rank
 average: the 1/G factor is folded into the Adam kernel (engine.py).  Inference (eval) needs no collective at all.
 """
 import torch
@@ -16,15 +16,20 @@ def shard_bounds(n_global, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def allreduce_gradients(flat_grad, group=None):
-    """In-place sum of the flat gradient across ranks (backend nccl == RCCL on ROCm; gloo in the CPU tests).
-    Returns the world size; the caller scales by 1/world (equal shards) when applying the update."""
+def allreduce_gradients(flat_grad, group=None, async_op=False):
+    """In-place sum of a flat gradient (slice) across ranks (backend nccl == RCCL on ROCm; gloo in the CPU tests).
+    The caller scales by 1/world (equal shards) when applying the update.
+    async_op=False: returns the world size after the collective has been enqueued / completed.
+    async_op=True: returns the work handle (None for one rank); `handle.wait()` orders the CURRENT stream behind the
+    collective, so kernels launched in between (the coarse net's backward) overlap with it."""
     if not dist.is_available() or not dist.is_initialized():
-        return 1
+        return None if async_op else 1
     world = dist.get_world_size(group)
     if world > 1:
-        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
-    return world
+        work = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        if async_op:
+            return work
+    return None if async_op else world
 
 
 def broadcast_parameters(flat_params, src=0, group=None):
@@ -41,9 +46,10 @@ def gather_image_rows(local_rows, group=None):
     world = dist.get_world_size(group)
     sizes = [torch.zeros(1, dtype=torch.int64, device=local_rows.device) for _ in range(world)]
     dist.all_gather(sizes, torch.tensor([local_rows.shape[0]], dtype=torch.int64, device=local_rows.device), group=group)
-    out = [torch.empty((int(s), *local_rows.shape[1:]), dtype=local_rows.dtype, device=local_rows.device) for s in sizes]
-    dist.all_gather(out, local_rows.contiguous(), group=group) if len({int(s) for s in sizes}) == 1 else None
-    if len({int(s) for s in sizes}) != 1:
+    if len({int(s) for s in sizes}) == 1:
+        out = [torch.empty_like(local_rows, memory_format=torch.contiguous_format) for _ in sizes]
+        dist.all_gather(out, local_rows.contiguous(), group=group)
+    else:
         # ragged shards: pad to the largest, gather, trim
         mx = max(int(s) for s in sizes)
         pad = torch.zeros((mx, *local_rows.shape[1:]), dtype=local_rows.dtype, device=local_rows.device)

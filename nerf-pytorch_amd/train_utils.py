@@ -23,10 +23,6 @@ from .nerf_helpers import EmbeddingFunction, get_minibatches, linspace01, ndc_ra
 from .volume_rendering_utils import volume_render_radiance_field
 
 
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
-
-
 def run_network(network_fn, pts, ray_batch, chunksize, embed_fn, embeddirs_fn):
     """nerf/train_utils.py:8-25."""
     pts_flat = pts.reshape((-1, pts.shape[-1]))
@@ -69,15 +65,24 @@ def _fusable(model_coarse, model_fine, enc_xyz, enc_dir, num_fine):
 
 
 class _FusedRender(torch.autograd.Function):
+    """The fused pipeline as one autograd node.  Differentiable outputs: the colour, accumulation and depth maps of both
+    passes (what any loss built on the reference's outputs can touch; disparity is derived from depth and acc by the
+    caller in torch, so it is covered too).  Inputs with a gradient: the parameters of the two nets, passed one by one
+    (they alias each model's flat buffer; backward returns each its slice of the flat gradient).
+
+    The workspace (activation stash, ~4.8 MB per ray for the 8x256 nets) is allocated per call from torch's caching
+    allocator and owned by the autograd node: several nodes may be alive at once (run_one_iter_of_nerf renders a batch
+    in ray chunks and backpropagates afterwards), so it must not be shared between calls."""
+
     @staticmethod
-    def forward(ctx, rays, model_c, model_f, cfg_tuple, rand, flat_c, flat_f):
+    def forward(ctx, rays, model_c, model_f, cfg_tuple, rand, n_params_c, *params):
         lib = L.get_lib()
         nc, nf, perturb, lindisp, white, noise_std = cfg_tuple
         n, stride = rays.shape
         dev = rays.device
         cfg = L.RenderCfg(nc, nf, int(bool(perturb)), int(bool(lindisp)), int(bool(white)), float(noise_std), stride)
         # grad mode is off inside Function.forward: ask autograd whether a parameter gradient will be wanted
-        training = bool(ctx.needs_input_grad[5] or ctx.needs_input_grad[6])
+        training = any(ctx.needs_input_grad[6:])
         plan_f = model_f._plan if nf > 0 else None
         wsb = lib.render_workspace_bytes(model_c._plan, plan_f, C.byref(cfg), n, int(training))
         if wsb < 0:
@@ -90,43 +95,43 @@ class _FusedRender(torch.autograd.Function):
         rr = L.RenderRand(*[None if r is None else r.data_ptr() for r in rand])
         packed_c = model_c._packed()
         packed_f = model_f._packed() if nf > 0 else None
-        lib.render_fwd(model_c._plan, plan_f, C.byref(cfg), rays.data_ptr(), n, packed_c.data_ptr(),
-                       packed_f.data_ptr() if packed_f is not None else None, linspace01(nc, dev).data_ptr(),
-                       linspace01(nf, dev).data_ptr() if nf > 0 else None, C.byref(rr), 0, 0, C.byref(out), ws.data_ptr(),
-                       wsb, int(training), _stream())
-        ctx.keep = (rays, model_c, model_f, cfg, rand, ws, wsb, packed_c, packed_f, training)
-        outs = [bufs[k] for k in names]
-        ctx.mark_non_differentiable(bufs["disp_coarse"], bufs["acc_coarse"], bufs["depth_coarse"], bufs["disp_fine"],
-                                    bufs["acc_fine"], bufs["depth_fine"])
-        return tuple(outs)
+        with L.launch_on(rays, ws, packed_c, packed_f, *[r for r in rand if r is not None]) as st:
+            lib.render_fwd(model_c._plan, plan_f, C.byref(cfg), rays.data_ptr(), n, packed_c.data_ptr(),
+                           packed_f.data_ptr() if packed_f is not None else None, linspace01(nc, dev).data_ptr(),
+                           linspace01(nf, dev).data_ptr() if nf > 0 else None, C.byref(rr), 0, 0, C.byref(out),
+                           ws.data_ptr(), wsb, int(training), st)
+        ctx.keep = (rays, model_c, model_f, cfg, rand, ws, wsb, packed_c, packed_f, training, n_params_c)
+        ctx.mark_non_differentiable(bufs["disp_coarse"], bufs["disp_fine"])
+        return tuple(bufs[k] for k in names)
 
     @staticmethod
     def backward(ctx, g_rgb_c, g_disp_c, g_acc_c, g_depth_c, g_rgb_f, g_disp_f, g_acc_f, g_depth_f):
         lib = L.get_lib()
-        rays, model_c, model_f, cfg, rand, ws, wsb, packed_c, packed_f, training = ctx.keep
+        rays, model_c, model_f, cfg, rand, ws, wsb, packed_c, packed_f, training, n_params_c = ctx.keep
         if not training:
             raise RuntimeError("fused render was run without gradient bookkeeping")
         n = rays.shape[0]
         dev = rays.device
         nf = cfg.num_fine
-        gc = (g_rgb_c if g_rgb_c is not None else torch.zeros((n, 3), device=dev)).contiguous().float()
-        gf = None
-        if nf > 0:
-            gf = (g_rgb_f if g_rgb_f is not None else torch.zeros((n, 3), device=dev)).contiguous().float()
-        rr = L.RenderRand(*[None if r is None else r.data_ptr() for r in rand])
-        gpc = torch.empty(model_c.num_flat_params, dtype=torch.float32, device=dev)
-        gpf = torch.empty(model_f.num_flat_params, dtype=torch.float32, device=dev) if nf > 0 else None
-        lib.render_bwd(model_c._plan, model_f._plan if nf > 0 else None, C.byref(cfg), rays.data_ptr(), n,
-                       packed_c.data_ptr(), packed_f.data_ptr() if nf > 0 else None, C.byref(rr), 0, 0, gc.data_ptr(),
-                       gf.data_ptr() if gf is not None else None, ws.data_ptr(), wsb, gpc.data_ptr(),
-                       gpf.data_ptr() if gpf is not None else None, _stream())
-        return None, None, None, None, None, gpc, gpf
-
-
-def _flat_leaf(model):
-    if torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters()):
-        return torch.cat([p.reshape(-1) for p in model._ordered_params()])
-    return model.flat_params
+        keep = [None if g is None else g.contiguous().float()
+                for g in (g_rgb_c, g_acc_c, g_depth_c, g_rgb_f, g_acc_f, g_depth_f)]
+        parts = 0
+        if any(k is not None for k in keep[:3]):
+            parts |= L.PART_COARSE
+        if nf > 0 and any(k is not None for k in keep[3:]):
+            parts |= L.PART_FINE
+        gpc = torch.zeros(model_c.num_flat_params, dtype=torch.float32, device=dev)
+        gpf = torch.zeros(model_f.num_flat_params, dtype=torch.float32, device=dev) if nf > 0 else None
+        if parts:
+            cot = L.RenderCotangents(*[None if k is None else k.data_ptr() for k in keep])
+            rr = L.RenderRand(*[None if r is None else r.data_ptr() for r in rand])
+            with L.launch_on(rays, ws, gpc, gpf, *[k for k in keep if k is not None]) as st:
+                lib.render_bwd_parts(model_c._plan, model_f._plan if nf > 0 else None, C.byref(cfg), rays.data_ptr(), n,
+                                     packed_c.data_ptr(), packed_f.data_ptr() if nf > 0 else None, C.byref(rr), 0, 0,
+                                     C.byref(cot), ws.data_ptr(), wsb, gpc.data_ptr(),
+                                     gpf.data_ptr() if gpf is not None else None, parts, st)
+        grads = model_c._split_flat(gpc) + (model_f._split_flat(gpf) if nf > 0 else ())
+        return (None,) * 6 + grads
 
 
 def _predict_fused(ray_batch, model_coarse, model_fine, opts):
@@ -142,11 +147,17 @@ def _predict_fused(ray_batch, model_coarse, model_fine, opts):
     u = torch.rand((n, nf), dtype=torch.float32, device=dev) if (nf > 0 and not (perturb == 0.0)) else None
     noise_f = torch.randn((n, nc + nf), dtype=torch.float32, device=dev) if (nf > 0 and noise_std > 0.0) else None
     cfg_tuple = (nc, nf, bool(perturb), bool(opts.lindisp), bool(opts.white_background), float(noise_std))
-    flat_c = _flat_leaf(model_coarse)
-    flat_f = _flat_leaf(model_fine) if nf > 0 else None
+    pc = model_coarse._ordered_params()
+    pf = model_fine._ordered_params() if nf > 0 else []
     outs = _FusedRender.apply(rays, model_coarse, model_fine if nf > 0 else None, cfg_tuple,
-                              (t_rand, noise_c, u, noise_f), flat_c, flat_f)
-    rgb_c, disp_c, acc_c, _, rgb_f, disp_f, acc_f, _ = outs
+                              (t_rand, noise_c, u, noise_f), len(pc), *pc, *pf)
+    rgb_c, disp_c, acc_c, depth_c, rgb_f, disp_f, acc_f, depth_f = outs
+    if rgb_c.requires_grad:
+        # disparity re-derived from the differentiable depth / accumulation maps with the reference's own torch ops
+        # (volume_rendering_utils.py:46-48: same values as the kernel's, and autograd covers a loss on it)
+        disp_c = 1.0 / torch.max(1e-10 * torch.ones_like(depth_c), depth_c / acc_c)
+        if nf > 0:
+            disp_f = 1.0 / torch.max(1e-10 * torch.ones_like(depth_f), depth_f / acc_f)
     if nf > 0:
         return rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f
     return rgb_c, disp_c, acc_c, None, None, None
@@ -170,9 +181,10 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, mo
     nc = opts.num_coarse
     t_rand = torch.rand((num_rays, nc), dtype=torch.float32, device=dev) if opts.perturb else None
     z_vals = torch.empty((num_rays, nc), dtype=torch.float32, device=dev)
-    lib.stratified_z(rays.data_ptr(), rays.shape[1], num_rays, linspace01(nc, dev).data_ptr(), nc, int(bool(opts.lindisp)),
-                     int(bool(opts.perturb)), t_rand.data_ptr() if t_rand is not None else None, 0, 0, z_vals.data_ptr(),
-                     _stream())
+    with L.launch_on(rays, t_rand, z_vals) as st:
+        lib.stratified_z(rays.data_ptr(), rays.shape[1], num_rays, linspace01(nc, dev).data_ptr(), nc,
+                         int(bool(opts.lindisp)), int(bool(opts.perturb)), t_rand.data_ptr() if t_rand is not None else None,
+                         0, 0, z_vals.data_ptr(), st)
     pts = ro[..., None, :] + rd[..., None, :] * z_vals[..., :, None]
     radiance_field = run_network(model_coarse, pts, ray_batch, opts.chunksize, encode_position_fn, encode_direction_fn)
     rgb_coarse, disp_coarse, acc_coarse, weights, _ = volume_render_radiance_field(
@@ -202,8 +214,9 @@ def pack_rays(ray_origins, ray_directions, options, height=None, width=None, foc
     n = rd.shape[0]
     use_view = bool(options.nerf.use_viewdirs)
     rays = torch.empty((n, 11 if use_view else 8), dtype=torch.float32, device=rd.device)
-    lib.pack_rays(ro.data_ptr(), rd.data_ptr(), rd_src.data_ptr() if use_view else None, float(options.dataset.near),
-                  float(options.dataset.far), n, rays.data_ptr(), _stream())
+    with L.launch_on(ro, rd, rd_src, rays) as st:
+        lib.pack_rays(ro.data_ptr(), rd.data_ptr(), rd_src.data_ptr() if use_view else None, float(options.dataset.near),
+                      float(options.dataset.far), n, rays.data_ptr(), st)
     return rays
 
 
@@ -239,9 +252,10 @@ def select_training_rays(height, width, focal_length, pose, image, num_random_ra
     rays = torch.empty((n, 11 if cfg.use_viewdirs else 8), dtype=torch.float32, device=dev)
     target = torch.empty((n, channels), dtype=torch.float32, device=dev) if image is not None else None
     used = torch.empty((n,), dtype=torch.int64, device=dev)
-    lib.select_rays(C.byref(cfg), pose.data_ptr(), pose.stride(-2), image.data_ptr() if image is not None else None,
-                    select_inds.data_ptr() if select_inds is not None else None, n, rays.data_ptr(),
-                    target.data_ptr() if target is not None else None, used.data_ptr(), _stream())
+    with L.launch_on(pose, image, select_inds, rays) as st:
+        lib.select_rays(C.byref(cfg), pose.data_ptr(), pose.stride(-2), image.data_ptr() if image is not None else None,
+                        select_inds.data_ptr() if select_inds is not None else None, n, rays.data_ptr(),
+                        target.data_ptr() if target is not None else None, used.data_ptr(), st)
     return rays, target, used
 
 
@@ -260,9 +274,10 @@ def select_cached_training_rays(cache_dict, num_random_rays, options, select_ind
     rays = torch.empty((n, 11 if cfg.use_viewdirs else 8), dtype=torch.float32, device=dev)
     target = torch.empty((n, 3), dtype=torch.float32, device=dev)
     used = torch.empty((n,), dtype=torch.int64, device=dev)
-    lib.select_cached_rays(C.byref(cfg), ro.data_ptr(), rd.data_ptr(), tgt.data_ptr(), ro.shape[0],
-                           select_inds.data_ptr() if select_inds is not None else None, n, rays.data_ptr(),
-                           target.data_ptr(), used.data_ptr(), _stream())
+    with L.launch_on(ro, rd, tgt, select_inds, rays) as st:
+        lib.select_cached_rays(C.byref(cfg), ro.data_ptr(), rd.data_ptr(), tgt.data_ptr(), ro.shape[0],
+                               select_inds.data_ptr() if select_inds is not None else None, n, rays.data_ptr(),
+                               target.data_ptr(), used.data_ptr(), st)
     return rays, target, used
 
 

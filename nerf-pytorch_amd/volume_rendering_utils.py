@@ -2,11 +2,7 @@
 differentiable w.r.t. ``radiance_field`` (closed-form backward kernel)."""
 import torch
 
-from ._lib import get_lib
-
-
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
+from ._lib import get_lib, launch_on
 
 
 class _VolumeRender(torch.autograd.Function):
@@ -19,9 +15,10 @@ class _VolumeRender(torch.autograd.Function):
         acc = torch.empty((n,), dtype=torch.float32, device=dev)
         depth = torch.empty((n,), dtype=torch.float32, device=dev)
         weights = torch.empty((n, s), dtype=torch.float32, device=dev)
-        lib.volume_render_fwd(raw.data_ptr(), z.data_ptr(), rd.data_ptr(), 3, n, s, float(noise_std),
-                              noise.data_ptr() if noise is not None else None, 0, 1, 0, int(bool(white)),
-                              rgb.data_ptr(), None, acc.data_ptr(), weights.data_ptr(), depth.data_ptr(), _stream())
+        with launch_on(raw, z, rd, noise, rgb) as st:
+            lib.volume_render_fwd(raw.data_ptr(), z.data_ptr(), rd.data_ptr(), 3, n, s, float(noise_std),
+                                  noise.data_ptr() if noise is not None else None, 0, 1, 0, int(bool(white)),
+                                  rgb.data_ptr(), None, acc.data_ptr(), weights.data_ptr(), depth.data_ptr(), st)
         ctx.save_for_backward(raw, z, rd, noise if noise is not None else torch.empty(0, device=dev))
         ctx.cfg = (float(noise_std), bool(white), noise is not None)
         ctx.mark_non_differentiable()
@@ -39,9 +36,10 @@ class _VolumeRender(torch.autograd.Function):
 
         keep = [None if g is None else g.contiguous().float() for g in (g_rgb, g_depth, g_acc, g_weights)]
         g_raw = torch.empty_like(raw)
-        lib.volume_render_bwd(raw.data_ptr(), z.data_ptr(), rd.data_ptr(), 3, n, s, noise_std,
-                              noise.data_ptr() if has_noise else None, 0, 1, 0, int(white),
-                              *[None if k is None else k.data_ptr() for k in keep], g_raw.data_ptr(), _stream())
+        with launch_on(raw, z, rd, g_raw, *keep) as st:
+            lib.volume_render_bwd(raw.data_ptr(), z.data_ptr(), rd.data_ptr(), 3, n, s, noise_std,
+                                  noise.data_ptr() if has_noise else None, 0, 1, 0, int(white),
+                                  *[None if k is None else k.data_ptr() for k in keep], g_raw.data_ptr(), st)
         return g_raw, None, None, None, None, None
 
 

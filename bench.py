@@ -142,6 +142,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hidden", type=int, default=MODEL["hidden_size"])
     ap.add_argument("--layers", type=int, default=MODEL["num_layers"])
+    ap.add_argument("--overlap", type=int, default=1, help="1: two-stream step (coarse backward next to the fine pass); "
+                    "0: single-stream order")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -169,7 +171,7 @@ def main():
     mc = N.FlexibleNeRFModel(**cfg).to(dev)
     mf = N.FlexibleNeRFModel(**cfg).to(dev)
     eng = N.TrainEngine(mc, mf, NC, NF, perturb=True, lindisp=False, white_background=False, noise_std=0.2, lr=5e-3,
-                        seed=1234, world_size=world, rank=rank)
+                        seed=1234, world_size=world, rank=rank, overlap=bool(args.overlap))
     n = args.rays
     opts = N.make_options(NC, NF, num_random_rays=n)
     poses = torch.stack([pose_spherical(th, -30.0, 4.0) for th in torch.linspace(-180, 180, 101)[:-1].tolist()]).to(dev)

@@ -150,12 +150,6 @@ typedef struct nerfhip_model_cfg {
 typedef struct nerfhip_plan* nerfhip_plan_t;
 
 /* Host-only.  Returns NULL (and sets the error string) for an unsupported geometry. */
-/* Developer knobs read from the environment (never required; defaults are the measured-fastest settings):
- *   NERFHIP_MLP=32        at nerfhip_plan_create: build the plan for the 32x32x2-MFMA forward / data-gradient kernels
- *                         (csrc/mlp.hip) and their packed-weight image instead of the default 16x16x4 family
- *                         (csrc/mlp16.hip);
- *   NERFHIP_STAGE=reg|front|mix   how the 32x32x2 kernels stage weight chunks into LDS (default mix);
- *   NERFHIP_WGRAD_COSTS=c0,c1,..  per-job split-K costs of the weight-gradient kernel (tuning aid). */
 nerfhip_plan_t nerfhip_plan_create(const nerfhip_model_cfg* cfg);
 void nerfhip_plan_destroy(nerfhip_plan_t plan);
 /* Number of fp32 parameters of the model = length of the flat parameter/gradient vector, laid out as the

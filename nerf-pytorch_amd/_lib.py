@@ -8,9 +8,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# NERFHIP_LIB_PATH: developer override to load an instrumented HIP build of the same library (e.g. the phase-timing
-# build scripts/phase_timing.py uses).  It is still a gfx950 HIP library; get_lib() rejects emulator builds.
-LIB_PATH = os.environ.get("NERFHIP_LIB_PATH") or os.path.join(_HERE, "libnerfhip.so")
+# (diagnostic scripts under scripts/ that need an instrumented HIP build assign this attribute before the first
+# get_lib(); the product reads no environment variable)
+LIB_PATH = os.path.join(_HERE, "libnerfhip.so")
 
 c_f = C.c_void_p  # device (or, for the emulator, host) pointers are passed as integers
 c_i64 = C.c_int64

@@ -1,18 +1,19 @@
-// mlp16.hip -- FlexibleNeRFModel (nerf/models.py:185-256) forward and data-gradient chain on v_mfma_f32_16x16x4_f32,
-// TWO wavefronts per SIMD.
+// mlp16.hip -- FlexibleNeRFModel (nerf/models.py:185-256) forward and data-gradient chain on v_mfma_f32_16x16x4_f32
+// (exact fp32: a k-ordered fmaf chain), TWO wavefronts per SIMD.
 //
-// Why a second shape: scripts/mfma_rate.hip (profiles/r01_mfma_issue_cost.txt) shows that with one wave per SIMD
-// nothing overlaps a wave's own MFMAs -- every ds_read / VALU / VMEM instruction adds its issue time to the loop, which
-// caps the 32x32x2 kernels of mlp.hip (400 registers per wave, one wave per SIMD) at 80-82 % of the matrix pipe; the
-// same loop on 16x16x4 with two waves per SIMD measures 96.7 %.  With 16-sample waves an activation of F features takes
-// F/4 registers, so a 256-wide layer needs 64 (in) + 64 (out) registers and two waves fit a SIMD.
-//
-// Layout (nh_plan.h, "v16"): lane l = (sample j = l & 15, k-group g = l >> 4); register r of an activation holds feature
+// Layout (nh_plan.h): lane l = (sample j = l & 15, k-group g = l >> 4); register r of an activation holds feature
 // feat16(r,g) = 16*(r>>2) + 4*g + (r&3) -- the C/D layout of the instruction -- and k-step r of the next layer takes
-// register r as its B operand, so activations never leave the register file (as in mlp.hip).  Weights stream L2 -> LDS by LDS-DMA in K-chunks that cover all output tiles ([k-step][quad][lane][4]:
-// one ds_read_b128 = the A operands of four 16-row tiles), double buffered, one barrier per chunk.
-// The stash / gradient images keep the [32-sample tile][sample][rows] format of mlp.hip (two waves fill one tile), so
-// the weight-gradient kernel is shared.
+// register r as its B operand, so activations never leave the register file: the (N*S, 90) encodings and (N*S, 256)
+// hidden states the reference materialises (nerf/train_utils.py:8-25) do not exist.  Weights stream L2 -> LDS by LDS-DMA
+// in K-chunks that cover all output tiles ([k-step][quad][lane][4]: one ds_read_b128 = the A operands of four 16-row
+// tiles), double buffered, one barrier per chunk.  The stash / gradient images are [32-sample tile][sample][rows] (two
+// waves fill one tile): what the weight-gradient kernel (wgrad.hip) reads.
+//
+// What the structure is tuned against (MI355X, scripts/loop_mock.hip, profiles/r02_loop_mock.txt): the bare chunk loop
+// -- 4 ds_read_b128 per 16 MFMAs, two waves per SIMD -- runs at 99 % of the matrix pipe, 95.6 % with the chunk copy and
+// a barrier every 8 k-steps, 98.0 % with 16-k-step chunks.  So: chunks as large as the LDS allows (two 64 KB buffers for
+// 256-wide nets), the copy pieces and the stash stores of a layer issued ONE PER K-STEP between the MFMA groups (never
+// a burst in front of them), and every address of a layer computed once, before its first chunk.
 #include <stdlib.h>
 
 #include "nh_mlp.h"
@@ -20,18 +21,17 @@
 namespace {
 
 // Workgroup shape (measured, profiles/r01_mlp16_ab.txt): 256-wide nets -- ONE 8-wave workgroup per CU (two waves per
-// SIMD; the weight stream is paid once per 128 samples: the LDS-DMA traffic of two independent workgroups cost more,
-// 8 % of the pipe in scripts/mfma_rate.hip's pipeline mock, than their desynchronised epilogues won); 128-wide nets
-// (134 registers per wave, 52 KB of LDS) -- 4-wave workgroups, three per CU.
+// SIMD; the weight stream is paid once per 128 samples); 128-wide nets (134 registers per wave, 52 KB of LDS) -- 4-wave
+// workgroups, three per CU.
 template <int W>
 struct Shape {
     static constexpr int NW = W >= 256 ? 8 : 4;  // waves per workgroup
 };
-// floats of the largest chunk: 256-wide nets 8192 (8 k-steps x 4 quads; 68 KB of LDS per workgroup -> 2 per CU),
-// 128-wide nets 6144 (8 k-steps x 3 quads; 52 KB -> 3 per CU, their 130-register waves fit three to a SIMD)
+// floats of one chunk buffer: 256-wide nets 16384 (16 k-steps x 4 quads; 2 x 64 KB + bias blocks = 132 KB: one
+// workgroup per CU, which the 240-register waves allow anyway), 128-wide nets 6144 (8 k-steps x 3 quads; 52 KB -> 3 per CU)
 template <int W>
 struct Lds {
-    static constexpr int CHUNK_MAX = W >= 256 ? 8192 : 6144;
+    static constexpr int CHUNK_MAX = W >= 256 ? 16384 : 6144;
     static constexpr int BYTES = (2 * CHUNK_MAX + 2 * NH16_BIAS_FLOATS) * 4;
 };
 
@@ -58,61 +58,92 @@ struct Ctx {
     NhDmaSrc dma;  // descriptor over the whole packed image
     int buf, bbuf;  // chunk / bias buffer of the unit being consumed
     int wave, lane, g;
+    // the copy in flight: up to two runs of 1-KiB pieces (a bias block, then a chunk); piece q is issued by wave q % nw
+    int c_np0, c_np;        // pieces of run 0, pieces in total
+    int c_src0, c_src1;     // byte offsets of the runs inside the packed image
+    unsigned c_dst0, c_dst1;  // LDS byte addresses of the runs
     NH_MEMBER float* chunk(int b) const { return lds + b * cmax; }
     NH_MEMBER float* bias(int b) const { return lds + 2 * cmax + b * NH16_BIAS_FLOATS; }
-    // LDS-DMA of nfloats (a multiple of 256) from float offset `off` of the packed image; piece q by wave q % NW
-    NH_MEMBER void copy(int64_t off, int nfloats, float* dst) const {
-        const int np = nfloats >> 8;
-        const int soff = (int)off * 4;
-        const unsigned d = lds_addr + (unsigned)((dst - lds) * 4);
-        for (int q = wave; q < np; q += nw) nh_dma16a(dma, lane * 16, soff + q * 1024, d + q * 1024);
+    NH_MEMBER void plan_copy(int64_t off0, int n0, float* dst0, int64_t off1, int n1, float* dst1) {
+        c_np0 = n0 >> 8;
+        c_np = c_np0 + (n1 >> 8);
+        c_src0 = (int)off0 * 4;
+        c_src1 = (int)off1 * 4;
+        c_dst0 = lds_addr + (unsigned)((dst0 - lds) * 4);
+        c_dst1 = lds_addr + (unsigned)((dst1 - lds) * 4);
     }
+    // chunk `nfloats` at float offset `off` of the packed image -> dst
+    NH_MEMBER void plan_chunk(int64_t off, int nfloats, float* dst) { plan_copy(off, nfloats, dst, 0, 0, dst); }
     // a layer's first unit: its bias block and chunk 0
-    NH_MEMBER void copy_first(int64_t img_off, int first_floats, int b, int bb) const {
-        copy(img_off, NH16_BIAS_FLOATS, bias(bb));
-        copy(img_off + NH16_BIAS_FLOATS, first_floats, chunk(b));
+    NH_MEMBER void plan_first(int64_t img_off, int first_floats, int b, int bb) {
+        plan_copy(img_off, NH16_BIAS_FLOATS, bias(bb), img_off + NH16_BIAS_FLOATS, first_floats, chunk(b));
+    }
+    // this wave's j-th piece of the planned copy (one LDS-DMA instruction, or nothing)
+    NH_MEMBER void issue(int j) const {
+        int q = wave + j * nw;
+#ifndef NERFHIP_EMU
+        // (opaque to the optimiser: otherwise every piece's source / destination address of every chunk is hoisted out of
+        // the layer loop as its own scalar register, and the kernel spills SGPRs into VGPR lanes)
+        asm volatile("" : "+s"(q));
+#endif
+        if (q < c_np0)
+            nh_dma16a(dma, lane * 16, c_src0 + q * 1024, c_dst0 + q * 1024);
+        else if (q < c_np)
+            nh_dma16a(dma, lane * 16, c_src1 + (q - c_np0) * 1024, c_dst1 + (q - c_np0) * 1024);
+    }
+    NH_MEMBER void issue_from(int j0) const {
+        for (int j = j0; wave + j * nw < c_np; ++j) issue(j);
     }
 };
 
-template <int KR, int T>
+// k-steps per chunk: the largest divisor of kr that fits (equal chunks: no ragged tail), unless that wastes more than
+// half of the buffer
+constexpr int nh16_kc(int kr, int kcm) {
+    if (kr <= kcm) return kr;
+    for (int d = kcm; 2 * d > kcm; --d)
+        if (kr % d == 0) return d;
+    return kcm;
+}
+template <int W, int KR, int T>
 struct Geo {
     static constexpr int TQ = (T + 3) / 4;
-    static constexpr int KC = TQ <= 1 ? 16 : (TQ <= 4 ? 8 : 4);
+    static constexpr int KCM = Lds<W>::CHUNK_MAX / (TQ * 256);  // k-steps that fit one chunk buffer
+    static constexpr int KC = nh16_kc(KR, KCM);
     static constexpr int NCH = (KR + KC - 1) / KC;
-    static constexpr int FIRST = (KR < KC ? KR : KC) * TQ * 256;  // floats of chunk 0
-    static constexpr int CHUNK = KC * TQ * 256;  // floats; the kernels check it against Lds<W>::CHUNK_MAX
+    static constexpr int FIRST = KC * TQ * 256;  // floats of chunk 0
+    static_assert(KC >= 1, "one k-step of this layer does not fit the chunk buffer");
 };
 
 // One linear layer for the 16 samples of this wavefront: acc[t] (16 rows x 16 samples) = W_t * in + bias_t, t < T.
-// Precondition: the layer's first unit has been requested into chunk(buf) / bias(bbuf).  While chunk c is multiplied,
-// chunk c+1 -- or the first unit of the next layer (next_first > 0) -- travels to the other buffer.
-// `post(c, NCH)` holds the global stores of the PREVIOUS layer's results (stash rows, masks), cut into NCH shares: share
-// c is issued right after the barrier that starts chunk c, so the stores are spread over the whole layer and drain
-// under the MFMAs instead of sitting in front of a vmcnt(0) (CDNA4's vmcnt counts stores too; the values stored are
-// this layer's input registers, still live).
-template <int KRA, int KRB, int T, class Post>
+// Precondition: the layer's first unit has been requested into chunk(buf) / bias(bbuf) (plan_first + issue_from(0)).
+// While chunk c is multiplied, chunk c+1 -- or the first unit of the next layer (next_first > 0) -- travels to the
+// other buffer, one piece per wave and k-step.
+// `post` holds the global stores of the PREVIOUS layer's results: post.first() (masks, encoding slots) goes out with
+// k-step 0, and its Post::NT row tiles (post.tile(t): one 16-byte store per lane) are spread evenly over the k-steps of
+// this layer, so that they drain under the MFMAs instead of sitting in front of a vmcnt(0) (CDNA4's vmcnt counts
+// stores too; the values stored are this layer's input registers, still live).
+template <int W, int KRA, int KRB, int T, class Post>
 NH_DEVICE void gemm16(Ctx& cx, const float* inA, const float* inB, int64_t img_off, int64_t next_off, int next_first,
-                      f32x4* acc, Post&& post) {
-    constexpr int KR = KRA + KRB;
-    using G = Geo<KR, T>;
+                      f32x4* acc, const Post& post) {
+    constexpr int KR = KRA + KRB, NT = Post::NT;
+    using G = Geo<W, KR, T>;
     constexpr int TQ = G::TQ, KC = G::KC, NCH = G::NCH;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        constexpr int dummy = 0;
-        (void)dummy;
         const int kc = (KR - c * KC) < KC ? (KR - c * KC) : KC;
-        NH16_PH(4);  // [4] between gemms / chunks: epilogue, stores, loop control
+        NH16_PH(4);  // [4] between gemms / chunks: epilogue, loop control
         nh_wait_vmem();
         NH16_PH(2);  // [2] s_waitcnt vmcnt(0)
         nh_block_sync();  // chunk c has landed for every wave; everybody is done with the other buffer
         NH16_PH(3);  // [3] s_barrier
         if (c + 1 < NCH) {
             const int kn = (KR - (c + 1) * KC) < KC ? (KR - (c + 1) * KC) : KC;
-            cx.copy(img_off + NH16_BIAS_FLOATS + (int64_t)(c + 1) * KC * TQ * 256, kn * TQ * 256, cx.chunk(cx.buf ^ 1));
+            cx.plan_chunk(img_off + NH16_BIAS_FLOATS + (int64_t)(c + 1) * KC * TQ * 256, kn * TQ * 256, cx.chunk(cx.buf ^ 1));
         } else if (next_first > 0) {
-            cx.copy_first(next_off, next_first, cx.buf ^ 1, cx.bbuf ^ 1);
+            cx.plan_first(next_off, next_first, cx.buf ^ 1, cx.bbuf ^ 1);
+        } else {
+            cx.c_np0 = cx.c_np = 0;
         }
-        post(c, NCH);
         if (c == 0) {
             const float* bp = cx.bias(cx.bbuf) + 4 * cx.g;
 #pragma unroll
@@ -124,7 +155,7 @@ NH_DEVICE void gemm16(Ctx& cx, const float* inA, const float* inB, int64_t img_o
                 acc[t][3] = b4.w;
             }
         }
-        NH16_PH(0);  // [0] copy issue + previous layer's stores + bias
+        NH16_PH(0);  // [0] copy set-up + bias
         const float4* wp = (const float4*)cx.chunk(cx.buf) + cx.lane;
         // A operands run one k-step ahead of the MFMAs (two k-steps ahead measured no better and costs 16 registers)
         float4 a[2][TQ];
@@ -137,8 +168,15 @@ NH_DEVICE void gemm16(Ctx& cx, const float* inA, const float* inB, int64_t img_o
 #pragma unroll
                     for (int q = 0; q < TQ; ++q) a[(ks + 1) & 1][q] = wp[((ks + 1) * TQ + q) * 64];
                 }
-                nh_sched_fence();  // the operand reads of the next k-step are issued before this k-step's MFMAs
                 const int r = c * KC + ks;
+                cx.issue(ks);  // one copy piece ...
+                if (r == 0) post.first();  // ... and this k-step's share of the previous layer's stores
+                if constexpr (NT > 0) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        if ((t * KR) / NT == r) post.tile(t);
+                }
+                nh_sched_fence();  // reads, copy and stores of this k-step are issued before its MFMAs
                 const float b = r < KRA ? inA[r < KRA ? r : 0] : inB[r >= KRA ? r - KRA : 0];
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
@@ -148,59 +186,109 @@ NH_DEVICE void gemm16(Ctx& cx, const float* inA, const float* inB, int64_t img_o
                 }
             }
         }
-        NH16_PH(1);  // [1] operand reads + MFMAs
+        cx.issue_from(kc);  // a copy with more pieces per wave than this chunk had k-steps
+        NH16_PH(1);  // [1] operand reads + MFMAs (+ copy pieces, stores)
         cx.buf ^= 1;
     }
     cx.bbuf ^= 1;
 }
 
-// epilogue: register r = 4t + c of the activation <- acc[t][c], gated by the stored ReLU mask (data-gradient) and/or
-// ReLU'd (forward); bit r of `bits_out` collects [v > 0]
-template <int T>
-NH_DEVICE void finish(const f32x4* acc, float* act, bool relu, unsigned* bits_out, bool want_bits, const unsigned* mbits,
-                      bool masked) {
+// epilogue: register r = 4t + c of the activation <- acc[t][c], gated by the stored ReLU mask (MASKED: data-gradient)
+// and/or ReLU'd (RELU: forward); BITS: collect [v > 0] of the n = 4T values, 32 per word, by shift-accumulation --
+// value r of a word lands at bit position (values in the word) - 1 - (r & 31) (no per-bit constants in registers).
+NH_DEVICE constexpr int nh16_bitpos(int r, int n) { return ((n - 32 * (r >> 5)) < 32 ? (n - 32 * (r >> 5)) : 32) - 1 - (r & 31); }
+template <int T, bool RELU, bool BITS, bool MASKED>
+NH_DEVICE void finish(const f32x4* acc, float* act, unsigned* bits_out, const unsigned* mbits) {
 #pragma unroll
     for (int r = 0; r < 4 * T; ++r) {
         float v = acc[r >> 2][r & 3];
-        if (masked) v = nh_gate(v, mbits[r >> 5], r & 31);
-        if (relu) v = nh_relu(v);
-        if (want_bits) bits_out[r >> 5] |= nh_pos_bit(v) << (r & 31);  // (v >= 0 here: masks are only taken after a ReLU)
+        if (MASKED) v = nh_gate(v, mbits[r >> 5], nh16_bitpos(r, 4 * T));
+        if (RELU) v = nh_relu(v);
+        if (BITS) bits_out[r >> 5] = (bits_out[r >> 5] << 1) | nh_pos_bit(v);  // (v >= 0 here: masks are only taken after a ReLU)
         act[r] = v;
     }
 }
 
-// rows feat16(4t.., g) = 16t + 4g .. +3 of this lane's sample: one 16-byte store per tile; share c of nch (all: 0 of 1)
-template <int T>
-NH_DEVICE void store_rows(float* __restrict__ row, const float* act, int g, int c = 0, int nch = 1) {
-    if (!row) return;
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        if (t * nch / T != c) continue;
-        float4 x;
-        x.x = act[4 * t + 0];
-        x.y = act[4 * t + 1];
-        x.z = act[4 * t + 2];
-        x.w = act[4 * t + 3];
-        *(float4*)(row + 16 * t + 4 * g) = x;
+// ---- the stores a gemm carries for the previous layer -------------------------------------------------------------------
+// Addresses are (wave-uniform base pointer) + (32-bit per-lane byte offset) + immediate: the base lives in scalar
+// registers, the lane offset is shared by all regions of the same row count, so a store costs no address arithmetic.
+struct RowRef {
+    char* base;    // wave-uniform; NULL: nothing is stored
+    unsigned off;  // this lane's byte offset
+    NH_MEMBER float* at(int float_index) const { return (float*)(base + (size_t)off) + float_index; }
+};
+struct NoPost {
+    static constexpr int NT = 0;
+    NH_MEMBER void first() const {}
+    NH_MEMBER void tile(int) const {}
+};
+// activation rows: tile t = rows feat16(4t.., g) = 16t + 4g .. +3 of this lane's sample, one 16-byte store; `mask`
+// (optional) receives the ReLU bits of the activation first.
+template <int NT_>
+struct RowsPost {
+    static constexpr int NT = NT_;
+    RowRef row;
+    const float* act;
+    RowRef mask;
+    unsigned b0, b1;
+    NH_MEMBER void first() const {
+        if (mask.base) {
+            unsigned* p = (unsigned*)mask.at(0);
+            p[0] = b0;
+            p[1] = b1;
+        }
     }
-}
-// encoding slots: register r of lane (j,g) is row g*KR + r
+    NH_MEMBER void tile(int t) const {
+        if (!row.base) return;
+        *(float4*)row.at(16 * t) = make_float4(act[4 * t], act[4 * t + 1], act[4 * t + 2], act[4 * t + 3]);
+    }
+};
+// encoding slots (register r of lane (j,g) is row g*KR + r; the lane offset already includes g*KR): stored with k-step 0
 template <int KR>
-NH_DEVICE void store_slots(float* __restrict__ row, const float* e, int g, int c = 0) {
-    if (!row || c != 0) return;
+struct SlotsPost {
+    static constexpr int NT = 0;
+    RowRef row;
+    const float* e;
+    NH_MEMBER void first() const {
+        if (!row.base) return;
 #pragma unroll
-    for (int q = 0; q < KR / 4; ++q) {
-        float4 x;
-        x.x = e[4 * q + 0];
-        x.y = e[4 * q + 1];
-        x.z = e[4 * q + 2];
-        x.w = e[4 * q + 3];
-        *(float4*)(row + g * KR + 4 * q) = x;
+        for (int q = 0; q < KR / 4; ++q) *(float4*)row.at(4 * q) = make_float4(e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]);
     }
+    NH_MEMBER void tile(int) const {}
+};
+// H_{L-1} rows + mask AND the direction-encoding slots (computed late: see k_mlp_fwd16)
+template <int NT_, int KD>
+struct RowsAndSlotsPost {
+    static constexpr int NT = RowsPost<NT_>::NT;
+    RowsPost<NT_> rows;
+    SlotsPost<KD> slots;
+    NH_MEMBER void first() const {
+        rows.first();
+        slots.first();
+    }
+    NH_MEMBER void tile(int t) const { rows.tile(t); }
+};
+// d(raw output) rows of the data-gradient chain: 8 rows per lane group (rows 0..3 of group 0 carry the cotangent)
+struct PoutPost {
+    static constexpr int NT = 0;
+    RowRef row;
+    float v0, v1, v2, v3;
+    NH_MEMBER void first() const {
+        *(float4*)row.at(0) = make_float4(v0, v1, v2, v3);
+        *(float4*)row.at(4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    NH_MEMBER void tile(int) const {}
+};
+// all rows of an activation at once (the last store of the data-gradient chain)
+template <int T>
+NH_DEVICE void store_rows(const RowRef& row, const float* act) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) *(float4*)row.at(16 * t) = make_float4(act[4 * t], act[4 * t + 1], act[4 * t + 2], act[4 * t + 3]);
 }
 
-NH_DEVICE float* region_row(float* base, const NhRegion& R, int64_t nt, int64_t tile, int js) {
-    return base + (size_t)32 * (size_t)nt * (size_t)R.row_prefix + ((size_t)tile * 32 + (size_t)js) * (size_t)R.rows;
+// wave-uniform base of a region's rows for the four 32-sample tiles of workgroup `wg` (two tiles for 4-wave workgroups)
+NH_DEVICE char* region_wg_base(float* base, const NhRegion& R, int64_t nt, int64_t tile0) {
+    return (char*)(base + (size_t)32 * (size_t)nt * (size_t)R.row_prefix + (size_t)tile0 * 32 * (size_t)R.rows);
 }
 
 NH_DEVICE float sel3(int a, float x, float y, float z) { return a == 0 ? x : (a == 1 ? y : z); }
@@ -249,12 +337,10 @@ struct Fwd16Args {
     NhStashLayout sl;
 };
 
-template <int W, bool VIEW>
+// TRAIN: the launch writes the activation stash (rows, encoding slots, ReLU masks) for the backward kernels
+template <int W, bool VIEW, bool TRAIN>
 NH_KERNEL void NH_LB(64 * Shape<W>::NW, 2) k_mlp_fwd16(Fwd16Args a) {
     constexpr int KH = W / 4, TW = W / 16, KX = NH16_KRX, KD = NH16_KRD, NW = Shape<W>::NW;
-    static_assert(Geo<KH, TW + 1>::CHUNK <= Lds<W>::CHUNK_MAX && Geo<KH, TW>::CHUNK <= Lds<W>::CHUNK_MAX &&
-                      Geo<KH, TW / 2>::CHUNK <= Lds<W>::CHUNK_MAX && Geo<KH, 1>::CHUNK <= Lds<W>::CHUNK_MAX,
-                  "chunk too large for the LDS buffer");
     NH_DYN_LDS(lds_raw);
     Ctx cx;
     cx.lds = (float*)lds_raw;
@@ -276,63 +362,54 @@ NH_KERNEL void NH_LB(64 * Shape<W>::NW, 2) k_mlp_fwd16(Fwd16Args a) {
     const int64_t m = tile * 32 + js;
     const bool valid = m < a.M;
     const int64_t mc = valid ? m : a.M - 1;
+    const int m_i = (int)m;  // (the host checks M < 2^31)
     const NhPackedOffsets& po = a.off;
 
     // the first weights travel to LDS while the encodings are computed
-    cx.copy_first(po.f_layer1, Geo<KX, TW>::FIRST, 0, 0);
+    cx.plan_first(po.f_layer1, Geo<W, KX, TW>::FIRST, 0, 0);
+    cx.issue_from(0);
 
     float ex[KX];
-    float ed[KD];
+    // (only 32-bit row indices stay live across the hidden layers: the direction encoding re-forms its pointer later)
+    const int xrow_i = (int)mc;                                 // row of x (mode 0)
+    const int ray_i = a.mode == 0 ? 0 : (int)(mc / a.S);       // ray of this sample (mode 1)
     if (a.mode == 0) {
-        const float* xr = a.x + (size_t)mc * (size_t)(a.dx + a.dd);
+        const float* const xr = a.x + (size_t)xrow_i * (size_t)(a.dx + a.dd);
 #pragma unroll
         for (int r = 0; r < KX; ++r) {
             const int c = a.xcol[g][r];
             ex[r] = c >= 0 ? xr[c] : 0.0f;
         }
-#pragma unroll
-        for (int r = 0; r < KD; ++r) {
-            const int c = VIEW ? (int)a.dcol[g][r] : -1;
-            ed[r] = c >= 0 ? xr[a.dx + c] : 0.0f;
-        }
     } else {
-        const int64_t ray = mc / a.S;
-        const float* rr = a.rays + (size_t)ray * a.ray_stride;
+        const float* const rr = a.rays + (size_t)ray_i * a.ray_stride;
         const float zz = a.z[mc];
         // pts = ro + rd * z   (nerf/train_utils.py:67,107)
         const float px = rr[0] + rr[3] * zz, py = rr[1] + rr[4] * zz, pz = rr[2] + rr[5] * zz;
         encode_slots16<KX>(ex, px, py, pz, g, a.fx, a.Lx);
-        if (VIEW) {
-            encode_slots16<KD>(ed, rr[8], rr[9], rr[10], g, a.fd, a.Ld);
-        } else {
-#pragma unroll
-            for (int r = 0; r < KD; ++r) ed[r] = 0.0f;
-        }
     }
-    const bool tr = a.stash != nullptr;
-    auto srow = [&](const NhRegion& R) -> float* { return tr ? region_row(a.stash, R, a.nt, tile, js) : nullptr; };
-
-    unsigned bits[2] = {0u, 0u};
-    // ReLU masks for the data-gradient kernel: 64 bits per lane per layer, [16-sample wave tile][mask][lane][2 words]
-    auto put_mask = [&](int idx) {
-        if (!tr || idx < 0) return;
-        unsigned* p = (unsigned*)(a.stash + (size_t)32 * (size_t)a.nt * (size_t)a.sl.total_rows) +
-                      ((size_t)(((int64_t)blockIdx.x * NW + wave) * a.sl.n_masks + idx) * 64 + lane) * 2;
-        p[0] = bits[0];
-        p[1] = bits[1];
+    constexpr bool tr = TRAIN;
+    // store addresses: wave-uniform region base of this workgroup's tiles + one lane offset per row count
+    const int64_t tile0 = (int64_t)blockIdx.x * (NW / 2);
+    const unsigned lrow = (unsigned)((wave >> 1) * 32 + js);  // this lane's sample row inside the workgroup's tiles
+    auto sref = [&](const NhRegion& R, int rows, int first) -> RowRef {
+        return RowRef{tr ? region_wg_base(a.stash, R, a.nt, tile0) : nullptr, (lrow * (unsigned)rows + (unsigned)first) * 4u};
     };
+    // ReLU masks for the data-gradient kernel: 64 bits per lane per layer, [16-sample wave tile][mask][lane][2 words]
+    char* const mask_base = tr ? (char*)((unsigned*)(a.stash + (size_t)32 * (size_t)a.nt * (size_t)a.sl.total_rows) +
+                                         (size_t)((int64_t)blockIdx.x * NW + wave) * a.sl.n_masks * 128)
+                               : nullptr;
+    unsigned bits[2] = {0u, 0u};
+    auto mref = [&](int idx) -> RowRef { return RowRef{(tr && idx >= 0) ? mask_base + (size_t)idx * 512 : nullptr, (unsigned)lane * 8u}; };
 
     float act[KH];
     f32x4 acc[TW + 1];
     {
         const bool more = a.L > 1;
         // layers_xyz[0] is never a skip layer (i > 0 is required); no activation after layer1 (models.py:238)
-        gemm16<KX, 0, TW>(cx, ex, nullptr, po.f_layer1, more ? po.f_xyz[0] : po.f_head,
-                          more ? Geo<KH, TW>::FIRST : (VIEW ? Geo<KH, TW + 1>::FIRST : Geo<KH, 1>::FIRST), acc, [&](int c, int) {
-                              store_slots<KX>(srow(a.sl.X), ex, g, c);
-                              if (VIEW) store_slots<KD>(srow(a.sl.D), ed, g, c);
-                          });
-        finish<TW>(acc, act, false, bits, false, bits, false);
+        gemm16<W, KX, 0, TW>(cx, ex, nullptr, po.f_layer1, more ? po.f_xyz[0] : po.f_head,
+                             more ? Geo<W, KH, TW>::FIRST : (VIEW ? Geo<W, KH, TW + 1>::FIRST : Geo<W, KH, 1>::FIRST), acc,
+                             SlotsPost<KX>{sref(a.sl.X, 4 * KX, g * KX), ex});
+        finish<TW, false, false, false>(acc, act, bits, bits);
     }
     // every gemm stores its own input rows (= the previous layer's output) and that layer's ReLU mask
     for (int i = 0; i < a.L - 1; ++i) {
@@ -340,57 +417,63 @@ NH_KERNEL void NH_LB(64 * Shape<W>::NW, 2) k_mlp_fwd16(Fwd16Args a) {
         const bool more = i + 1 < a.L - 1;
         const bool nsk = more && ((i + 1) % a.skip == 0);
         const int64_t nxt = more ? po.f_xyz[i + 1] : po.f_head;
-        const int nfirst = more ? (nsk ? Geo<KH + KX, TW>::FIRST : Geo<KH, TW>::FIRST)
-                                : (VIEW ? Geo<KH, TW + 1>::FIRST : Geo<KH, 1>::FIRST);
-        auto post = [&](int c, int nch) {
-            if (c == 0) put_mask(i - 1);  // H_i (none for H_0)
-            store_rows<TW>(srow(a.sl.H[i]), act, g, c, nch);
-        };
+        const int nfirst = more ? (nsk ? Geo<W, KH + KX, TW>::FIRST : Geo<W, KH, TW>::FIRST)
+                                : (VIEW ? Geo<W, KH, TW + 1>::FIRST : Geo<W, KH, 1>::FIRST);
+        // H_i and its ReLU mask (none for H_0)
+        const RowsPost<TW> post{sref(a.sl.H[i], W, 4 * g), act, mref(i - 1), bits[0], bits[1]};
         if (sk)
-            gemm16<KH, KX, TW>(cx, act, ex, po.f_xyz[i], nxt, nfirst, acc, post);
+            gemm16<W, KH, KX, TW>(cx, act, ex, po.f_xyz[i], nxt, nfirst, acc, post);
         else
-            gemm16<KH, 0, TW>(cx, act, nullptr, po.f_xyz[i], nxt, nfirst, acc, post);
+            gemm16<W, KH, 0, TW>(cx, act, nullptr, po.f_xyz[i], nxt, nfirst, acc, post);
         bits[0] = bits[1] = 0u;
-        finish<TW>(acc, act, true, bits, tr, bits, false);
+        finish<TW, true, TRAIN, false>(acc, act, bits, bits);
     }
-    auto post_last_hidden = [&](int c, int nch) {
-        if (c == 0) put_mask(a.L - 2);  // H_{L-1}
-        store_rows<TW>(srow(a.sl.H[a.L - 1]), act, g, c, nch);
-    };
+    const RowsPost<TW> post_last_hidden{sref(a.sl.H[a.L - 1], W, 4 * g), act, mref(a.L - 2), bits[0], bits[1]};  // H_{L-1}
     if (VIEW) {
+        // The direction encoding is first needed by layers_dir: it is formed HERE, after the hidden layers, so that its
+        // registers are not carried through them (its slots go to the stash with the head gemm's first k-step).
+        float ed[KD];
+        if (a.mode == 0) {
+            const float* const xr = a.x + (size_t)xrow_i * (size_t)(a.dx + a.dd);
+#pragma unroll
+            for (int r = 0; r < KD; ++r) {
+                const int c = (int)a.dcol[g][r];
+                ed[r] = c >= 0 ? xr[a.dx + c] : 0.0f;
+            }
+        } else {
+            const float* const rr = a.rays + (size_t)ray_i * a.ray_stride;
+            encode_slots16<KD>(ed, rr[8], rr[9], rr[10], g, a.fd, a.Ld);
+        }
         // tiles 0..TW-1: feat = relu(fc_feat(h)); tile TW row 0: fc_alpha(h), raw (models.py:248-249)
-        gemm16<KH, 0, TW + 1>(cx, act, nullptr, po.f_head, po.f_dir, Geo<KH + KD, TW / 2>::FIRST, acc, post_last_hidden);
+        gemm16<W, KH, 0, TW + 1>(cx, act, nullptr, po.f_head, po.f_dir, Geo<W, KH + KD, TW / 2>::FIRST, acc,
+                                 RowsAndSlotsPost<TW, KD>{post_last_hidden, SlotsPost<KD>{sref(a.sl.D, 4 * KD, g * KD), ed}});
         const float alpha = acc[TW][0];
         bits[0] = bits[1] = 0u;
-        finish<TW>(acc, act, true, bits, tr, bits, false);
+        finish<TW, true, TRAIN, false>(acc, act, bits, bits);
         float dh[KH / 2];
-        gemm16<KH, KD, TW / 2>(cx, act, ed, po.f_dir, po.f_rgb, Geo<KH / 2, 1>::FIRST, acc, [&](int c, int nch) {
-            if (c == 0) put_mask(a.L - 1);
-            store_rows<TW>(srow(a.sl.FEAT), act, g, c, nch);
-        });
+        gemm16<W, KH, KD, TW / 2>(cx, act, ed, po.f_dir, po.f_rgb, Geo<W, KH / 2, 1>::FIRST, acc,
+                                  RowsPost<TW>{sref(a.sl.FEAT, W, 4 * g), act, mref(a.L - 1), bits[0], bits[1]});
         bits[0] = bits[1] = 0u;
-        finish<TW / 2>(acc, dh, true, bits, tr, bits, false);
-        gemm16<KH / 2, 0, 1>(cx, dh, nullptr, po.f_rgb, 0, 0, acc, [&](int c, int nch) {
-            if (c == 0) put_mask(a.L);
-            store_rows<TW / 2>(srow(a.sl.DIRH), dh, g, c, nch);
-        });
+        finish<TW / 2, true, TRAIN, false>(acc, dh, bits, bits);
+        gemm16<W, KH / 2, 0, 1>(cx, dh, nullptr, po.f_rgb, 0, 0, acc,
+                                RowsPost<TW / 2>{sref(a.sl.DIRH, W / 2, 4 * g), dh, mref(a.L), bits[0], bits[1]});
         if (valid && g == 0) {
             float4 r4;
             r4.x = acc[0][0];
             r4.y = acc[0][1];
             r4.z = acc[0][2];
             r4.w = alpha;
-            *(float4*)(a.out + (size_t)m * 4) = r4;
+            *(float4*)(a.out + (size_t)m_i * 4) = r4;
         }
     } else {
-        gemm16<KH, 0, 1>(cx, act, nullptr, po.f_head, 0, 0, acc, post_last_hidden);
+        gemm16<W, KH, 0, 1>(cx, act, nullptr, po.f_head, 0, 0, acc, post_last_hidden);
         if (valid && g == 0) {
             float4 r4;
             r4.x = acc[0][0];
             r4.y = acc[0][1];
             r4.z = acc[0][2];
             r4.w = acc[0][3];
-            *(float4*)(a.out + (size_t)m * 4) = r4;
+            *(float4*)(a.out + (size_t)m_i * 4) = r4;
         }
     }
 #ifdef NH_PHASE_TIMING
@@ -441,25 +524,30 @@ NH_KERNEL void NH_LB(64 * Shape<W>::NW, 2) k_mlp_dgrad16(Dgrad16Args a) {
     const int L = a.L;
     // the transposed images carry no bias: their 512-float bias block is all zero weights (index -1 -> 0.0f)
     if (VIEW)
-        cx.copy_first(po.b_rgb, Geo<1, TW / 2>::FIRST, 0, 0);
+        cx.plan_first(po.b_rgb, Geo<W, 1, TW / 2>::FIRST, 0, 0);
     else
-        cx.copy_first(po.b_head, Geo<1, TW>::FIRST, 0, 0);
+        cx.plan_first(po.b_head, Geo<W, 1, TW>::FIRST, 0, 0);
+    cx.issue_from(0);
 
-    float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid) go = *(const float4*)(a.g_out + (size_t)m * 4);
-    auto grow = [&](const NhRegion& R) -> float* { return region_row(a.grad, R, a.nt, tile, js); };
-    auto store_pout = [&](int c, int) {
-        if (c != 0) return;
-        // POUT (32 rows): rows 0..2 d(rgb raw), row 3 d(sigma raw), rows 4..31 zero; group g writes rows 8g..8g+7
-        float* po_row = grow(a.gl.POUT) + 8 * g;
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        *(float4*)(po_row + 0) = g == 0 ? go : z4;
-        *(float4*)(po_row + 4) = z4;
+    // d(raw output) of this lane's sample as four scalars (kept in registers: no address-taken aggregate)
+    float go0 = 0.f, go1 = 0.f, go2 = 0.f, go3 = 0.f;
+    if (valid) {
+        const float4 t = *(const float4*)(a.g_out + (size_t)m * 4);
+        go0 = t.x, go1 = t.y, go2 = t.z, go3 = t.w;
+    }
+    const int64_t tile0 = (int64_t)blockIdx.x * (NW / 2);
+    const unsigned lrow = (unsigned)((wave >> 1) * 32 + js);
+    auto gref = [&](const NhRegion& R, int rows, int first) -> RowRef {
+        return RowRef{region_wg_base(a.grad, R, a.nt, tile0), (lrow * (unsigned)rows + (unsigned)first) * 4u};
     };
+    // POUT (32 rows): rows 0..2 d(rgb raw), row 3 d(sigma raw), rows 4..31 zero; group g writes rows 8g..8g+7
+    const bool g0 = g == 0;
+    const PoutPost store_pout{gref(a.gl.POUT, 32, 8 * g), g0 ? go0 : 0.f, g0 ? go1 : 0.f, g0 ? go2 : 0.f, g0 ? go3 : 0.f};
+    const char* const mask_base = (const char*)((const unsigned*)(a.stash + (size_t)32 * (size_t)a.nt * (size_t)a.sl.total_rows) +
+                                                (size_t)((int64_t)blockIdx.x * NW + wave) * a.sl.n_masks * 128);
     unsigned mb[2];
     auto get_mask = [&](int idx) {
-        const unsigned* p = (const unsigned*)(a.stash + (size_t)32 * (size_t)a.nt * (size_t)a.sl.total_rows) +
-                            ((size_t)(((int64_t)blockIdx.x * NW + wave) * a.sl.n_masks + idx) * 64 + lane) * 2;
+        const unsigned* p = (const unsigned*)(mask_base + (size_t)idx * 512 + (size_t)((unsigned)lane * 8u));
         mb[0] = p[0];
         mb[1] = p[1];
     };
@@ -467,43 +555,46 @@ NH_KERNEL void NH_LB(64 * Shape<W>::NW, 2) k_mlp_dgrad16(Dgrad16Args a) {
     f32x4 acc[TW];
     float dp[KH];  // d(pre-activation) of the layer just finished = B operand of the next transposed GEMM
     unsigned nobits[2] = {0u, 0u};
-    // every gemm stores its own input rows (= the d(pre-activation) the previous one produced) after its first barrier
+    // every gemm stores its own input rows (= the d(pre-activation) the previous one produced), one tile per few k-steps
     if (VIEW) {
         // one k-step: group g carries d(rgb raw)[g]
         float d1[1];
-        d1[0] = g == 0 ? go.x : (g == 1 ? go.y : (g == 2 ? go.z : 0.0f));
+        d1[0] = g == 0 ? go0 : (g == 1 ? go1 : (g == 2 ? go2 : 0.0f));
         get_mask(L);  // DIRH
         float dpd[KH / 2];
-        gemm16<1, 0, TW / 2>(cx, d1, nullptr, po.b_rgb, po.b_dir, Geo<KH / 2, TW>::FIRST, acc, store_pout);
-        finish<TW / 2>(acc, dpd, false, nobits, false, mb, true);
+        gemm16<W, 1, 0, TW / 2>(cx, d1, nullptr, po.b_rgb, po.b_dir, Geo<W, KH / 2, TW>::FIRST, acc, store_pout);
+        finish<TW / 2, false, false, true>(acc, dpd, nobits, mb);
         get_mask(L - 1);  // FEAT
-        gemm16<KH / 2, 0, TW>(cx, dpd, nullptr, po.b_dir, po.b_head, Geo<KH + 1, TW>::FIRST, acc,
-                              [&](int c, int nch) { store_rows<TW / 2>(grow(a.gl.PDIR), dpd, g, c, nch); });
-        finish<TW>(acc, dp, false, nobits, false, mb, true);
+        gemm16<W, KH / 2, 0, TW>(cx, dpd, nullptr, po.b_dir, po.b_head, Geo<W, KH + 1, TW>::FIRST, acc,
+                                 RowsPost<TW / 2>{gref(a.gl.PDIR, W / 2, 4 * g), dpd, RowRef{nullptr, 0u}, 0u, 0u});
+        finish<TW, false, false, true>(acc, dp, nobits, mb);
         if (L > 1) get_mask(L - 2);  // H_{L-1}
         float da[1];
-        da[0] = g == 0 ? go.w : 0.0f;  // d(sigma raw) enters through fc_alpha's row (k-step KH, group 0)
-        gemm16<KH, 1, TW>(cx, dp, da, po.b_head, L > 1 ? po.b_xyz[L - 2] : 0, L > 1 ? Geo<KH, TW>::FIRST : 0, acc,
-                          [&](int c, int nch) { store_rows<TW>(grow(a.gl.PFEAT), dp, g, c, nch); });
-        finish<TW>(acc, dp, false, nobits, false, mb, L > 1);
+        da[0] = g == 0 ? go3 : 0.0f;  // d(sigma raw) enters through fc_alpha's row (k-step KH, group 0)
+        gemm16<W, KH, 1, TW>(cx, dp, da, po.b_head, L > 1 ? po.b_xyz[L - 2] : 0, L > 1 ? Geo<W, KH, TW>::FIRST : 0, acc,
+                             RowsPost<TW>{gref(a.gl.PFEAT, W, 4 * g), dp, RowRef{nullptr, 0u}, 0u, 0u});
+        if (L <= 1) mb[0] = mb[1] = 0xFFFFFFFFu;  // H_0 = layer1's output has no activation: nothing is gated
+        finish<TW, false, false, true>(acc, dp, nobits, mb);
     } else {
         float d1[1];
-        d1[0] = g == 0 ? go.x : (g == 1 ? go.y : (g == 2 ? go.z : go.w));
+        d1[0] = g == 0 ? go0 : (g == 1 ? go1 : (g == 2 ? go2 : go3));
         if (L > 1) get_mask(L - 2);  // H_{L-1}
-        gemm16<1, 0, TW>(cx, d1, nullptr, po.b_head, L > 1 ? po.b_xyz[L - 2] : 0, L > 1 ? Geo<KH, TW>::FIRST : 0, acc,
-                         store_pout);
-        finish<TW>(acc, dp, false, nobits, false, mb, L > 1);
+        gemm16<W, 1, 0, TW>(cx, d1, nullptr, po.b_head, L > 1 ? po.b_xyz[L - 2] : 0, L > 1 ? Geo<W, KH, TW>::FIRST : 0, acc,
+                            store_pout);
+        if (L <= 1) mb[0] = mb[1] = 0xFFFFFFFFu;  // H_0 = layer1's output has no activation: nothing is gated
+        finish<TW, false, false, true>(acc, dp, nobits, mb);
     }
     // dp = d(pre-activation of H_{L-1}).  Walk down: dpre_{k-1} = relu'(H_{k-1}) * (W_{k-1}^T dpre_k);
     // H_0 = layer1 output has no activation (models.py:238).
     for (int k = L - 1; k >= 1; --k) {
         const bool masked = k - 1 >= 1;
         if (masked) get_mask(k - 2);  // H_{k-1}
-        gemm16<KH, 0, TW>(cx, dp, nullptr, po.b_xyz[k - 1], k >= 2 ? po.b_xyz[k - 2] : 0, k >= 2 ? Geo<KH, TW>::FIRST : 0, acc,
-                          [&](int c, int nch) { store_rows<TW>(grow(a.gl.P[k]), dp, g, c, nch); });
-        finish<TW>(acc, dp, false, nobits, false, mb, masked);
+        gemm16<W, KH, 0, TW>(cx, dp, nullptr, po.b_xyz[k - 1], k >= 2 ? po.b_xyz[k - 2] : 0,
+                             k >= 2 ? Geo<W, KH, TW>::FIRST : 0, acc, RowsPost<TW>{gref(a.gl.P[k], W, 4 * g), dp, RowRef{nullptr, 0u}, 0u, 0u});
+        if (!masked) mb[0] = mb[1] = 0xFFFFFFFFu;
+        finish<TW, false, false, true>(acc, dp, nobits, mb);
     }
-    store_rows<TW>(grow(a.gl.P[0]), dp, g);
+    store_rows<TW>(gref(a.gl.P[0], W, 4 * g), dp);
 #ifdef NH_PHASE_TIMING
     NH16_PH(4);
     if (lane == 0)
@@ -541,6 +632,7 @@ extern "C" int nerfhip_debug_phases16(unsigned long long* host16, int reset) {
 
 int nh_mlp16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
                      nerfhip_stream_t stream) {
+    NH_REQUIRE(M < ((int64_t)1 << 31), "mlp_fwd: at most 2^31 - 1 sample points per call (got %lld)", (long long)M);
     Fwd16Args a;
     memset(&a, 0, sizeof(a));
     a.packed = packed;
@@ -573,17 +665,25 @@ int nh_mlp16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in,
     a.sl = p->stash;
     const int64_t groups = nh_ceil_div(M, 128);  // whole 128-sample groups: every stash tile is written
     int rc = NERFHIP_OK;
-#define NH_FWD16(WW, VV)                                                              \
+#define NH_FWD16_T(WW, VV, TT)                                                        \
     {                                                                                 \
-        rc = lds_limit(k_mlp_fwd16<WW, VV>, Lds<WW>::BYTES);                          \
+        rc = lds_limit(k_mlp_fwd16<WW, VV, TT>, Lds<WW>::BYTES);                      \
         if (rc) return rc;                                                            \
-        NH_LAUNCH((k_mlp_fwd16<WW, VV>), groups * (8 / Shape<WW>::NW), 64 * Shape<WW>::NW, Lds<WW>::BYTES, stream, a); \
+        NH_LAUNCH((k_mlp_fwd16<WW, VV, TT>), groups * (8 / Shape<WW>::NW), 64 * Shape<WW>::NW, Lds<WW>::BYTES, stream, a); \
+    }
+#define NH_FWD16(WW, VV)             \
+    {                                \
+        if (stash)                   \
+            NH_FWD16_T(WW, VV, true) \
+        else                         \
+            NH_FWD16_T(WW, VV, false) \
     }
     if (p->W == 256 && p->view) NH_FWD16(256, true)
     else if (p->W == 256) NH_FWD16(256, false)
     else if (p->view) NH_FWD16(128, true)
     else NH_FWD16(128, false)
 #undef NH_FWD16
+#undef NH_FWD16_T
     return nh_launch_status("mlp_fwd16");
 }
 

@@ -1,17 +1,21 @@
 // nh_plan.h -- host-side description of one FlexibleNeRFModel (nerf/models.py:185-256) mapped onto the MFMA kernels:
 // flat parameter layout, packed-weight image, activation stash layout and the weight-gradient job list.
 //
-// Register/tile vocabulary used everywhere (see DESIGN.md "MLP data layout"):
-//   * a wavefront owns 32 sample points; lane l = (j = l & 31: sample, h = l >> 5: k-half);
-//   * an activation vector of F features lives in F/2 registers per lane: register r of lane (j,h) holds feature
-//       feat(r,h) = 32*(r>>4) + (r&3) + 8*((r>>2)&3) + 4*h       of sample j
-//     which is exactly the C/D layout of v_mfma_f32_32x32x2_f32, so a layer's output registers are the next layer's
-//     B operands with no data movement;
-//   * encodings use "slots": register r of lane (j,h) is slot (r,h); the slot -> reference-column map is baked into
-//     the packed weights (xyz: 32 registers = 64 slots, dir: 16 registers = 32 slots).
+// Register/tile vocabulary (see DESIGN.md "MLP data layout"); the forward / data-gradient kernels (mlp16.hip) run on
+// v_mfma_f32_16x16x4_f32:
+//   * a wavefront owns 16 sample points; lane l = (j = l & 15: sample, g = l >> 4: k-group); an 8-wave workgroup is
+//     128 samples = four 32-sample stash tiles (wave w: tile w >> 1, samples 16*(w & 1) ..);
+//   * an activation of F features lives in F/4 registers per lane: register r of lane (j,g) holds feature
+//       feat16(r,g) = 16*(r>>2) + 4*g + (r&3)
+//     = the C/D layout of the instruction (tile r>>2, register r&3), and k-step r of the next layer consumes exactly
+//     register r as its B operand (B[k=g][j]): activations never leave the register file;
+//   * encodings use "slots": xyz 16 registers = 64 slots, dir 8 registers = 32 slots; the slot -> reference-column map
+//     is baked into the packed weights; slot rows of the stash are numbered g*KR + r;
+//   * a layer image is [bias: 512 floats][k-step][quad of 4 output tiles][64 lanes][4 floats]: one ds_read_b128 yields
+//     the A operands of 4 tiles; the kernel streams it in chunks of a few k-steps covering ALL output tiles;
 //   * stash / gradient regions are sample-major images [tile][32 samples][rows]: a lane's 4 consecutive registers
-//     are 4 consecutive rows (one 16-byte store), and the weight-gradient GEMM reads 32 consecutive rows of one
-//     sample with one fully coalesced dword load.  Slot rows are numbered h*KR + r.
+//     are 4 consecutive rows (one 16-byte store), and the weight-gradient GEMM (wgrad.hip) reads the operands of up to
+//     four 32-row tiles of one sample with one LDS instruction.
 #pragma once
 #include <stdint.h>
 
@@ -20,32 +24,15 @@
 
 #include "../../include/nerfhip.h"
 
-constexpr int NH_KRX = 32;         // registers of the xyz encoding (supports num_encoding_fn_xyz <= 10)
-constexpr int NH_KRD = 16;         // registers of the direction encoding (supports num_encoding_fn_dir <= 4)
 constexpr int NH_MAX_LAYERS = 16;  // num_layers limit
 constexpr int NH_MAX_JOBS = 48;
 
-static inline int nh_feat(int r, int h) { return 32 * (r >> 4) + (r & 3) + 8 * ((r >> 2) & 3) + 4 * h; }
-
-// ---- "v16" layout: forward / data-gradient kernels on v_mfma_f32_16x16x4_f32 (mlp16.hip) -----------------------------
-//   * a wavefront owns 16 sample points; lane l = (j = l & 15: sample, g = l >> 4: k-group); a workgroup is 4 waves
-//     = 64 samples = two 32-sample stash tiles (wave w: tile w >> 1, samples 16*(w & 1) ..), two workgroups per CU;
-//   * an activation of F features lives in F/4 registers per lane: register r of lane (j,g) holds feature
-//       feat16(r,g) = 16*(r>>2) + 4*g + (r&3)
-//     = the C/D layout of the instruction (tile r>>2, register r&3), and k-step r of the next layer consumes exactly
-//     register r as its B operand (B[k=g][j]);
-//   * encodings: xyz 16 registers = 64 slots, dir 8 registers = 32 slots; slot rows are numbered g*KR + r;
-//   * a layer image is [bias: 512 floats][k-step][quad of 4 output tiles][64 lanes][4 floats]: one ds_read_b128 yields
-//     the A operands of 4 tiles; the kernel streams it in chunks of a few k-steps covering ALL output tiles.
 constexpr int NH16_KRX = 16;
 constexpr int NH16_KRD = 8;
 static inline int nh_feat16(int r, int g) { return 16 * (r >> 2) + 4 * g + (r & 3); }
 static inline int nh16_tq(int tiles) { return (tiles + 3) / 4; }
 constexpr int NH16_BIAS_FLOATS = 512;
 static inline int64_t nh16_image_floats(int kr, int tiles) { return NH16_BIAS_FLOATS + (int64_t)kr * nh16_tq(tiles) * 256; }
-// floats of one packed weight chunk (one 32-row output tile): kr*64 weights + 32 biases padded to 256, so that a
-// chunk is a whole number of 1-KiB pieces (one LDS-DMA wave-instruction each)
-static inline int64_t nh_chunk_floats(int kr) { return (int64_t)kr * 64 + 256; }
 
 struct NhTensor {
     std::string name;
@@ -106,17 +93,13 @@ struct NhJob {
 struct nerfhip_plan {
     nerfhip_model_cfg cfg;
     int W, L, skip, Dx, Dd, view;
-    int P0x, P0d;  // pairs handled by lane-half 0
     std::vector<NhTensor> tensors;
     int64_t nparams;
     int t_layer1_w, t_layer1_b, t_xyz_w[NH_MAX_LAYERS], t_xyz_b[NH_MAX_LAYERS];
     int t_dir_w, t_dir_b, t_alpha_w, t_alpha_b, t_rgb_w, t_rgb_b, t_feat_w, t_feat_b, t_out_w, t_out_b;
-    int xyz_col[2][NH_KRX];  // slot (r,h) -> reference column of the xyz encoding, or -1
-    int dir_col[2][NH_KRD];
-    bool v16;                // forward / data-gradient kernels and packed image in the 16x16x4 layout (mlp16.hip)
-    int xyz_col16[4][NH16_KRX];
+    int xyz_col16[4][NH16_KRX];  // slot (r,g) -> reference column of the xyz encoding, or -1
     int dir_col16[4][NH16_KRD];
-    int xyz_slot_col[64];    // stash slot row -> reference column (either layout), used by the weight-gradient scatter
+    int xyz_slot_col[64];    // stash slot row -> reference column, used by the weight-gradient scatter
     int dir_slot_col[32];
     float freqs_xyz[16], freqs_dir[16];
     bool freqs_set;
@@ -126,5 +109,4 @@ struct nerfhip_plan {
     NhGradLayout grad;
     std::vector<NhJob> jobs;
     bool is_skip(int i) const { return i % skip == 0 && i > 0; }
-    int kr_xyz(int i) const { return W / 2 + (is_skip(i) ? NH_KRX : 0); }
 };

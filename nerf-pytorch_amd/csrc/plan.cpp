@@ -20,165 +20,6 @@ int add_tensor(nerfhip_plan* p, const std::string& name, int rows, int cols) {
     return (int)p->tensors.size() - 1;
 }
 
-// slot (r,h) -> reference column of positional_encoding's output (nerf/nerf_helpers.py:130-157), or -1.
-// Registers 0,1 carry the raw coordinates (h=0: x,y; h=1: z,pad); registers 2+2q / 3+2q carry sin / cos of the q-th
-// (frequency, axis) pair owned by that lane half: half 0 owns pairs [0,P0), half 1 owns [P0, 3L); pair p = 3*f + axis.
-void build_slot_map(int L, int include_input, int kr, int* col_h0, int* col_h1, int* p0_out) {
-    const int P = 3 * L, P0 = (P + 1) / 2, base = include_input ? 3 : 0;
-    *p0_out = P0;
-    for (int r = 0; r < kr; ++r) col_h0[r] = col_h1[r] = -1;
-    if (include_input) {
-        col_h0[0] = 0;
-        col_h0[1] = 1;
-        col_h1[0] = 2;
-    }
-    for (int q = 0; 3 + 2 * q < kr; ++q) {
-        for (int h = 0; h < 2; ++h) {
-            int p = q + h * P0;
-            bool valid = h == 0 ? q < P0 : p < P;
-            if (!valid) continue;
-            int f = p / 3, a = p % 3;
-            int* col = h ? col_h1 : col_h0;
-            col[2 + 2 * q] = base + 6 * f + a;
-            col[3 + 2 * q] = base + 6 * f + 3 + a;
-        }
-    }
-}
-
-struct GemmSpec {
-    int kr = 0, tiles = 0;
-    std::function<int64_t(int, int, int)> w;  // (out_row, r, h) -> flat param index or -1
-    std::function<int64_t(int)> b;            // out_row -> flat param index or -1
-};
-
-int64_t spec_floats(const GemmSpec& s) { return (int64_t)s.tiles * nh_chunk_floats(s.kr); }
-
-void fill_spec(const GemmSpec& s, int64_t off, int32_t* table) {
-    for (int t = 0; t < s.tiles; ++t) {
-        int32_t* ch = table + off + (int64_t)t * nh_chunk_floats(s.kr);
-        for (int r = 0; r < s.kr; ++r)
-            for (int lane = 0; lane < 64; ++lane) {
-                int i = lane & 31, h = lane >> 5;
-                int64_t src = s.w(32 * t + i, r, h);
-                ch[((r >> 2) * 64 + lane) * 4 + (r & 3)] = (int32_t)src;
-            }
-        for (int row = 0; row < 256; ++row)
-            ch[(int64_t)s.kr * 64 + row] = (row < 32 && s.b) ? (int32_t)s.b(32 * t + row) : -1;
-    }
-}
-
-struct Specs {
-    GemmSpec f_layer1, f_xyz[NH_MAX_LAYERS], f_head, f_dir, f_rgb, b_rgb, b_dir, b_head, b_xyz[NH_MAX_LAYERS];
-};
-
-void build_specs(const nerfhip_plan* p, Specs& S) {
-    const int W = p->W, KH = W / 2, Dx = p->Dx, Dd = p->Dd, L = p->L;
-    auto T = [p](int idx) { return p->tensors[idx]; };
-    {
-        GemmSpec& s = S.f_layer1;
-        s.kr = NH_KRX;
-        s.tiles = W / 32;
-        NhTensor w = T(p->t_layer1_w), b = T(p->t_layer1_b);
-        s.w = [=](int o, int r, int h) -> int64_t {
-            int c = p->xyz_col[h][r];
-            return (o < W && c >= 0) ? w.off + (int64_t)o * Dx + c : -1;
-        };
-        s.b = [=](int o) -> int64_t { return o < W ? b.off + o : -1; };
-    }
-    for (int i = 0; i < L - 1; ++i) {
-        GemmSpec& s = S.f_xyz[i];
-        const bool sk = p->is_skip(i);
-        s.kr = p->kr_xyz(i);
-        s.tiles = W / 32;
-        NhTensor w = T(p->t_xyz_w[i]), b = T(p->t_xyz_b[i]);
-        const int ld = W + (sk ? Dx : 0);
-        s.w = [=](int o, int r, int h) -> int64_t {
-            if (r < KH) return w.off + (int64_t)o * ld + nh_feat(r, h);
-            int c = p->xyz_col[h][r - KH];
-            return c >= 0 ? w.off + (int64_t)o * ld + W + c : -1;
-        };
-        s.b = [=](int o) -> int64_t { return b.off + o; };
-        GemmSpec& bt = S.b_xyz[i];  // dh_in[f] = sum_u W[u][f] dpre[u]   (hidden columns only)
-        bt.kr = KH;
-        bt.tiles = W / 32;
-        bt.w = [=](int f, int r, int h) -> int64_t { return w.off + (int64_t)nh_feat(r, h) * ld + f; };
-    }
-    if (p->view) {
-        NhTensor fw = T(p->t_feat_w), fb = T(p->t_feat_b), aw = T(p->t_alpha_w), ab = T(p->t_alpha_b);
-        NhTensor dw = T(p->t_dir_w), db = T(p->t_dir_b), rw = T(p->t_rgb_w), rb = T(p->t_rgb_b);
-        {
-            GemmSpec& s = S.f_head;  // rows 0..W-1 = fc_feat, row W = fc_alpha
-            s.kr = KH;
-            s.tiles = W / 32 + 1;
-            s.w = [=](int o, int r, int h) -> int64_t {
-                if (o < W) return fw.off + (int64_t)o * W + nh_feat(r, h);
-                if (o == W) return aw.off + nh_feat(r, h);
-                return -1;
-            };
-            s.b = [=](int o) -> int64_t { return o < W ? fb.off + o : (o == W ? ab.off : -1); };
-        }
-        {
-            GemmSpec& s = S.f_dir;
-            s.kr = KH + NH_KRD;
-            s.tiles = W / 64;
-            const int ld = W + Dd;
-            s.w = [=](int o, int r, int h) -> int64_t {
-                if (r < KH) return dw.off + (int64_t)o * ld + nh_feat(r, h);
-                int c = p->dir_col[h][r - KH];
-                return c >= 0 ? dw.off + (int64_t)o * ld + W + c : -1;
-            };
-            s.b = [=](int o) -> int64_t { return db.off + o; };
-        }
-        {
-            GemmSpec& s = S.f_rgb;
-            s.kr = KH / 2;
-            s.tiles = 1;
-            s.w = [=](int o, int r, int h) -> int64_t { return o < 3 ? rw.off + (int64_t)o * (W / 2) + nh_feat(r, h) : -1; };
-            s.b = [=](int o) -> int64_t { return o < 3 ? rb.off + o : -1; };
-        }
-        {
-            GemmSpec& s = S.b_rgb;  // d(dir hidden)[f] = sum_{rho<3} Wrgb[rho][f] d_rgb[rho]
-            s.kr = 4;
-            s.tiles = W / 64;
-            s.w = [=](int f, int r, int h) -> int64_t {
-                int rho = nh_feat(r, h);
-                return rho < 3 ? rw.off + (int64_t)rho * (W / 2) + f : -1;
-            };
-        }
-        {
-            GemmSpec& s = S.b_dir;  // d(feat)[f] = sum_u Wdir[u][f] dpre_dir[u]
-            s.kr = KH / 2;
-            s.tiles = W / 32;
-            const int ld = W + Dd;
-            s.w = [=](int f, int r, int h) -> int64_t { return dw.off + (int64_t)nh_feat(r, h) * ld + f; };
-        }
-        {
-            GemmSpec& s = S.b_head;  // dh[f] = sum_u Wfeat[u][f] dpre_feat[u] + Walpha[0][f] d_alpha
-            s.kr = KH + 4;
-            s.tiles = W / 32;
-            s.w = [=](int f, int r, int h) -> int64_t {
-                if (r < KH) return fw.off + (int64_t)nh_feat(r, h) * W + f;
-                return nh_feat(r - KH, h) == 0 ? aw.off + f : -1;
-            };
-        }
-    } else {
-        NhTensor ow = T(p->t_out_w), ob = T(p->t_out_b);
-        GemmSpec& s = S.f_head;  // fc_out
-        s.kr = KH;
-        s.tiles = 1;
-        s.w = [=](int o, int r, int h) -> int64_t { return o < 4 ? ow.off + (int64_t)o * W + nh_feat(r, h) : -1; };
-        s.b = [=](int o) -> int64_t { return o < 4 ? ob.off + o : -1; };
-        GemmSpec& bt = S.b_head;
-        bt.kr = 4;
-        bt.tiles = W / 32;
-        bt.w = [=](int f, int r, int h) -> int64_t {
-            int rho = nh_feat(r, h);
-            return rho < 4 ? ow.off + (int64_t)rho * W + f : -1;
-        };
-    }
-}
-
-// ---- v16 layout (mlp16.hip) ------------------------------------------------------------------------------------------
 // slot (r,g) -> reference column.  Group g < 3 owns the (frequency, axis) pairs [g*C, (g+1)*C), C = KR/2; group 3 owns
 // [3C, 3C + (KR-3)/2) and carries the raw coordinates in its last three registers.  Pair p = 3*f + axis sits in
 // registers 2q (sin), 2q+1 (cos), q = p - g*C.
@@ -344,33 +185,12 @@ void for_each_spec(const nerfhip_plan* p, SpecsT& S, NhPackedOffsets& o, Fn fn) 
 void layout_packed(nerfhip_plan* p) {
     int64_t off = 0;
     memset(&p->po, 0, sizeof(p->po));
-    if (p->v16) {
-        Specs16 S;
-        build_specs16(p, S);
-        for_each_spec(p, S, p->po, [&](const GemmSpec16& s, int64_t* dst) {
-            *dst = off;
-            off += nh16_image_floats(s.kr, s.tiles);
-        });
-        p->packed_floats = off;
-        return;
-    }
-    Specs S;
-    build_specs(p, S);
-    auto place = [&](const GemmSpec& s, int64_t* dst) {
+    Specs16 S;
+    build_specs16(p, S);
+    for_each_spec(p, S, p->po, [&](const GemmSpec16& s, int64_t* dst) {
         *dst = off;
-        off += spec_floats(s);
-    };
-    place(S.f_layer1, &p->po.f_layer1);
-    for (int i = 0; i < p->L - 1; ++i) place(S.f_xyz[i], &p->po.f_xyz[i]);
-    place(S.f_head, &p->po.f_head);
-    if (p->view) {
-        place(S.f_dir, &p->po.f_dir);
-        place(S.f_rgb, &p->po.f_rgb);
-        place(S.b_rgb, &p->po.b_rgb);
-        place(S.b_dir, &p->po.b_dir);
-    }
-    place(S.b_head, &p->po.b_head);
-    for (int i = 0; i < p->L - 1; ++i) place(S.b_xyz[i], &p->po.b_xyz[i]);
+        off += nh16_image_floats(s.kr, s.tiles);
+    });
     p->packed_floats = off;
 }
 
@@ -395,10 +215,11 @@ void add_job(nerfhip_plan* p, const NhRegion& A, int a_tiles, const NhRegion& B,
     j.b_tiles = b_tiles;
     // wave grid: the 8 waves of a workgroup (two per SIMD) take equal patches of at most 8 accumulator tiles each
     int best_wo = 1, best_wi = 1, best_cost = 1 << 30;
-    for (int wo = 1; wo <= 8; wo *= 2)
-        for (int wi = 1; wo * wi <= 8; wi *= 2) {
+    for (int wo = 1; wo <= 8 && wo <= a_tiles; wo *= 2)
+        for (int wi = 1; wo * wi <= 8 && wi <= b_tiles; wi *= 2) {
             int po = (a_tiles + wo - 1) / wo, pi = (b_tiles + wi - 1) / wi;
-            if (po > 4 || pi > 4 || po * pi > 8 || po == 3 || pi == 3) continue;
+            // a wave's P tiles are P interleaved row sets of its block (wgrad.hip): the grid must tile the job exactly
+            if (po > 4 || pi > 4 || po * pi > 8 || po == 3 || pi == 3 || po * wo != a_tiles || pi * wi != b_tiles) continue;
             // SIMD time per sample tile ~ (waves per SIMD) * patch
             const int per_simd = (wo * wi + 3) / 4;
             int cost = (per_simd * po * pi) * 64 + (8 - wo * wi) * 4 + (po + pi);  // ties: more waves (two per SIMD overlap), then fewer operand reads
@@ -413,9 +234,13 @@ void add_job(nerfhip_plan* p, const NhRegion& A, int a_tiles, const NhRegion& B,
     j.po = (a_tiles + j.wo - 1) / j.wo;
     j.pi = (b_tiles + j.wi - 1) / j.wi;
     // Relative time one workgroup spends per sample tile (split-K allocation), fitted to per-workgroup timestamps on
-    // MI355X for the 8x256 and 4x128 nets (profiles/r01_wgrad_timeline.txt): t = 0.45 us * (tile pairs of the busiest
-    // SIMD) + 0.79 us fixed per tile (stage hand-over, copy issue), within 9 % for every job.
-    j.cost = 45 * ((j.wo * j.wi + 3) / 4) * j.po * j.pi + 79;
+    // MI355X for the 8x256, 4x128 and 8x128 nets (scripts/wgrad_timeline.py, profiles/r02_wgrad_timeline.txt): per tile
+    // t = 0.30 us * (MFMAs per k-step of the busiest SIMD) + 0.20 us * (operand dwords its waves read per k-step) + 0.45 us
+    // (stage hand-over), within 4 % for every job shape that occurs.
+    {
+        const int per_simd = (j.wo * j.wi + 3) / 4;
+        j.cost = 30 * per_simd * j.po * j.pi + 20 * per_simd * (j.po + j.pi) + 45;
+    }
     j.r_lo = r_lo;
     j.r_hi = r_hi;
     j.w_off = p->tensors[w_tensor].off;
@@ -432,8 +257,8 @@ void build_layouts_and_jobs(nerfhip_plan* p) {
     NhStashLayout& S = p->stash;
     memset(&S, 0, sizeof(S));
     S.total_rows = 0;
-    S.X = add_region(&S.total_rows, 2 * NH_KRX);
-    if (p->view) S.D = add_region(&S.total_rows, 2 * NH_KRD);
+    S.X = add_region(&S.total_rows, 4 * NH16_KRX);  // slot rows g*KR + r
+    if (p->view) S.D = add_region(&S.total_rows, 4 * NH16_KRD);
     for (int k = 0; k < L; ++k) S.H[k] = add_region(&S.total_rows, W);
     if (p->view) {
         S.FEAT = add_region(&S.total_rows, W);
@@ -533,27 +358,17 @@ extern "C" nerfhip_plan_t nerfhip_plan_create(const nerfhip_model_cfg* cfg) {
         p->t_out_w = add_tensor(p, "fc_out.weight", 4, W);
         p->t_out_b = add_tensor(p, "fc_out.bias", 4, 0);
     }
-    build_slot_map(cfg->num_encoding_fn_xyz, cfg->include_input_xyz ? 1 : 0, NH_KRX, p->xyz_col[0], p->xyz_col[1],
-                   &p->P0x);
-    build_slot_map(p->view ? cfg->num_encoding_fn_dir : 0, (p->view && cfg->include_input_dir) ? 1 : 0, NH_KRD,
-                   p->dir_col[0], p->dir_col[1], &p->P0d);
     {
-        // Forward / data-gradient kernel family of this plan: the 16x16x4 kernels (mlp16.hip) by default -- measured
-        // 1-2 % ahead (profiles/r01_mlp16_ab.txt); NERFHIP_MLP=32 selects the 32x32x2 family (mlp.hip) instead.
-        const char* e = getenv("NERFHIP_MLP");
-        p->v16 = !(e && e[0] == '3' && e[1] == '2');
         const bool okx = build_slot_map16(cfg->num_encoding_fn_xyz, cfg->include_input_xyz ? 1 : 0, NH16_KRX, &p->xyz_col16[0][0]);
         const bool okd = build_slot_map16(p->view ? cfg->num_encoding_fn_dir : 0, (p->view && cfg->include_input_dir) ? 1 : 0,
                                           NH16_KRD, &p->dir_col16[0][0]);
-        if (p->v16 && !(okx && okd)) {
+        if (!(okx && okd)) {
             nh_set_error("plan_create: encoding does not fit the slot registers");
             delete p;
             return nullptr;
         }
-        for (int row = 0; row < 64; ++row)
-            p->xyz_slot_col[row] = p->v16 ? p->xyz_col16[row / NH16_KRX][row % NH16_KRX] : p->xyz_col[row / NH_KRX][row % NH_KRX];
-        for (int row = 0; row < 32; ++row)
-            p->dir_slot_col[row] = p->v16 ? p->dir_col16[row / NH16_KRD][row % NH16_KRD] : p->dir_col[row / NH_KRD][row % NH_KRD];
+        for (int row = 0; row < 64; ++row) p->xyz_slot_col[row] = p->xyz_col16[row / NH16_KRX][row % NH16_KRX];
+        for (int row = 0; row < 32; ++row) p->dir_slot_col[row] = p->dir_col16[row / NH16_KRD][row % NH16_KRD];
     }
     for (int k = 0; k < 16; ++k) {
         p->freqs_xyz[k] = 0.f;
@@ -588,27 +403,10 @@ extern "C" int64_t nerfhip_plan_packed_floats(nerfhip_plan_t plan) { return plan
 
 extern "C" int nerfhip_plan_pack_index(nerfhip_plan_t plan, int32_t* host_table) {
     NH_REQUIRE(plan && host_table, "plan_pack_index: bad arguments");
-    if (plan->v16) {
-        Specs16 S16;
-        build_specs16(plan, S16);
-        NhPackedOffsets o = plan->po;
-        for_each_spec(plan, S16, o, [&](const GemmSpec16& s, int64_t* dst) { fill_spec16(s, *dst, host_table); });
-        return NERFHIP_OK;
-    }
-    Specs S;
-    build_specs(plan, S);
-    const NhPackedOffsets& o = plan->po;
-    fill_spec(S.f_layer1, o.f_layer1, host_table);
-    for (int i = 0; i < plan->L - 1; ++i) fill_spec(S.f_xyz[i], o.f_xyz[i], host_table);
-    fill_spec(S.f_head, o.f_head, host_table);
-    if (plan->view) {
-        fill_spec(S.f_dir, o.f_dir, host_table);
-        fill_spec(S.f_rgb, o.f_rgb, host_table);
-        fill_spec(S.b_rgb, o.b_rgb, host_table);
-        fill_spec(S.b_dir, o.b_dir, host_table);
-    }
-    fill_spec(S.b_head, o.b_head, host_table);
-    for (int i = 0; i < plan->L - 1; ++i) fill_spec(S.b_xyz[i], o.b_xyz[i], host_table);
+    Specs16 S16;
+    build_specs16(plan, S16);
+    NhPackedOffsets o = plan->po;
+    for_each_spec(plan, S16, o, [&](const GemmSpec16& s, int64_t* dst) { fill_spec16(s, *dst, host_table); });
     return NERFHIP_OK;
 }
 

@@ -1,0 +1,489 @@
+// wgrad.hip -- weight gradients of FlexibleNeRFModel (what autograd computes for the Linear layers of
+// nerf/models.py:233-256): dW[out, in] = sum over samples of dP[out][sample] * act[in][sample], bias gradient = row sums
+// of dP, as a split-K fp32-MFMA kernel (v_mfma_f32_32x32x2_f32: exact fp32, a k-ordered fmaf chain) over the
+// sample-major images [tile][32 samples][rows] the forward (activation stash) and data-gradient (dP scratch) kernels
+// of mlp16.hip write; a second kernel reduces the split-K partials in a fixed order (bit-reproducible: no atomics) and
+// scatters them into the reference parameter layout.
+//
+// Structure (measured on MI355X: scripts/loop_mock.hip, profiles/r02_loop_mock.txt):
+//  * a workgroup is 8 waves = TWO per SIMD, each owning a patch of PO x PI accumulator tiles (<= 8 tiles = 128 registers);
+//  * the operands of a run of sample tiles are two CONTIGUOUS blocks of HBM ([32 G samples][a_rows] of the gradient
+//    scratch, [32 G samples][b_rows] of the stash: every job covers whole regions), copied once per workgroup into LDS
+//    by LDS-DMA (1 KiB per instruction, no VGPRs), double buffered, one barrier per stage;
+//  * WIDE operand reads: a lane fetches the operands of ALL its tiles of one k-step with ONE LDS instruction.  Tile x of
+//    a wave's block of 32*P rows is defined as rows {P*i + x : i < 32}, so lane (i, k) reads the P consecutive floats
+//    lds[sample 2e+k][32*P*block + P*i ..] -- ds_read_b128 for P = 4, ds_read_b64 for P = 2 -- instead of P separate
+//    ds_read_b32 (the mock: 96.4 % -> 99.0 % of the matrix pipe for the 4 x 2 patch).  Which 32 rows form a tile only
+//    matters to the reduce kernel, which undoes the interleave when it scatters;
+//  * bias sums (VALU adds next to the MFMAs; the mock: -3.6 % when two of the eight waves carry all of them, because
+//    every stage ends in a barrier) are spread over the waves that share an A block: wave (ow, iw) sums tile x = iw only.
+#include <stdlib.h>
+
+#include "nh_mlp.h"
+
+namespace {
+
+struct JobDev {
+    int a_rows, a_prefix, a_tiles;
+    int b_rows, b_prefix, b_tiles;
+    int wo, wi, po, pi;
+    int r_lo, r_hi;
+    int w_off, w_ld;
+    int col_kind, col_base, col_count;
+    int bias_off;
+    int wg_start;
+    int g;  // 32-sample tiles per LDS stage
+};
+constexpr int NH_JOBS_DEV = 32;
+// 8 waves per workgroup (two per SIMD); two LDS stages of at most NH_WG_STAGE_FLOATS floats (+ slack for the operand
+// prefetch that runs one k-step past the end of a stage)
+constexpr int NH_WG_WAVES = 8;
+constexpr int NH_WG_STAGE_FLOATS = 16384;
+constexpr int NH_WG_LDS_BYTES = 2 * NH_WG_STAGE_FLOATS * 4 + 4096;
+// floats of split-K partial per workgroup: 64 output tiles x 16 regs x 64 lanes, + 512 bias partials
+// (+ 128 for the per-wave timeline records of the instrumented build)
+#ifdef NH_WGRAD_TIMELINE
+constexpr int NH_PART = 65536 + 512 + 128;
+#else
+constexpr int NH_PART = 65536 + 512;
+#endif
+
+struct WgradArgs {
+    const float* stash;
+    const float* grad;
+    float* partial;
+    float* g_params;
+    int64_t nt;
+    int njobs, total_wgs;
+    JobDev jobs[NH_JOBS_DEV];
+    short xslot[64];  // stash slot row -> reference column of the encoding, or -1
+    short dslot[32];
+};
+
+// the P operands (one per tile) of one k-step: P consecutive floats of one sample
+template <int P>
+struct WOp {
+    float v[P];
+};
+template <int P>
+NH_DEVICE void wop_load(WOp<P>& o, const float* p) {
+    if constexpr (P == 4) {
+        const float4 t = *(const float4*)p;
+        o.v[0] = t.x, o.v[1] = t.y, o.v[2] = t.z, o.v[3] = t.w;
+    } else if constexpr (P == 2) {
+        const float2 t = *(const float2*)p;
+        o.v[0] = t.x, o.v[1] = t.y;
+    } else {
+        o.v[0] = p[0];
+    }
+}
+template <int PO, int PI>
+struct WStep {
+    WOp<PO> A;
+    WOp<PI> B;
+};
+template <int PO, int PI>
+NH_DEVICE void wstep_load(WStep<PO, PI>& o, const float* pa, const float* pb) {
+    wop_load<PO>(o.A, pa);
+    wop_load<PI>(o.B, pb);
+}
+// BX: which A tiles this wave sums for the bias gradient: -1 none, 0..3 that tile only, 4 all of them
+template <int PO, int PI, int BX>
+NH_DEVICE void wstep_mfma(const WStep<PO, PI>& o, f32x16 (&acc)[PO][PI], float (&bsum)[PO]) {
+#pragma unroll
+    for (int x = 0; x < PO; ++x) {
+        if (BX == 4 || BX == x) bsum[x] += o.A.v[x];
+#pragma unroll
+        for (int y = 0; y < PI; ++y) acc[x][y] = nh_mfma32(o.A.v[x], o.B.v[y], acc[x][y]);
+    }
+}
+
+// One stage copy, cut into 1-KiB pieces (one DMA instruction each): block A (ntile * a_fl floats) -> stage[0 ..), block
+// B (ntile * b_fl floats) -> stage[g * a_fl ..).  Wave w issues pieces w, w+8, ...; `issue(n)` emits the next n of
+// them, so that the copy of stage n+1 is spread over the MFMA groups of stage n.  LDS destinations are byte addresses.
+struct WStageDma {
+    NhDmaSrc sa, sb;
+    unsigned dst;  // LDS byte address of the stage
+    int pa, ptot, boff, q, lane16;
+    NH_MEMBER void init(const float* ga, const float* gb, int a_fl, int b_fl, int ntile, int g, unsigned stage_addr, int wave,
+                        int lane) {
+        sa = nh_dma_src(ga, (unsigned)(ntile * a_fl * 4));
+        sb = nh_dma_src(gb, (unsigned)(ntile * b_fl * 4));
+        dst = stage_addr;
+        pa = ntile * a_fl / 256;
+        ptot = pa + ntile * b_fl / 256;
+        boff = (g * a_fl - pa * 256) * 4;  // piece q >= pa lands at stage + (g*a_fl + (q - pa)*256) floats
+        q = wave;
+        lane16 = lane * 16;
+    }
+    NH_MEMBER void issue(int n) {
+        for (int c = 0; c < n && q < ptot; ++c, q += NH_WG_WAVES) {
+            if (q < pa)
+                nh_dma16a(sa, lane16, q * 1024, dst + q * 1024);
+            else
+                nh_dma16a(sb, lane16, (q - pa) * 1024, dst + boff + q * 1024);
+        }
+    }
+};
+
+// AR / BR: rows of the A / B region when known at compile time (0: read from the job) -- with constant strides the
+// operand addresses of a whole stage are immediates of ONE base register.
+template <int PO, int PI, int AR, int BR, int BX>
+NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int64_t t1, int ow, int iw, int wave, int lane,
+                          int64_t wg, bool active, float* lds) {
+    const int i = lane & 31, k = lane >> 5;
+    f32x16 acc[PO][PI];
+    float bsum[PO];
+#pragma unroll
+    for (int x = 0; x < PO; ++x) {
+        bsum[x] = 0.0f;
+#pragma unroll
+        for (int y = 0; y < PI; ++y)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[x][y][c] = 0.0f;
+    }
+    const int ar = AR ? AR : jb.a_rows, br = BR ? BR : jb.b_rows;
+    const int g = (AR && BR) ? NH_WG_STAGE_FLOATS / (32 * (AR + BR)) : jb.g;
+    const int a_fl = 32 * ar, b_fl = 32 * br;
+    const float* A0 = a.grad + (size_t)32 * (size_t)a.nt * (size_t)jb.a_prefix;
+    const float* B0 = a.stash + (size_t)32 * (size_t)a.nt * (size_t)jb.b_prefix;
+    const int nstage = (int)((t1 - t0 + g - 1) / g);
+    const float* ga = A0 + (size_t)t0 * a_fl;  // stage n+1's blocks (running pointers: one 64-bit add per stage)
+    const float* gb = B0 + (size_t)t0 * b_fl;
+    int left = (int)(t1 - t0);                 // tiles not yet requested
+    const unsigned lds_addr = nh_lds_addr(lds);
+    WStageDma dma;
+    dma.ptot = 0;
+    if (nstage > 0) {
+        const int nt0 = left < g ? left : g;
+        dma.init(ga, gb, a_fl, b_fl, nt0, g, lds_addr, wave, lane);
+        dma.issue(1 << 20);
+        ga += (size_t)nt0 * a_fl, gb += (size_t)nt0 * b_fl, left -= nt0;
+    }
+    int ntile = (int)(t1 - t0) < g ? (int)(t1 - t0) : g;  // tiles of the stage being multiplied
+#ifdef NH_WGRAD_TIMELINE
+    unsigned long long tl_wait = 0, tl_bar = 0, tl_loop = 0, tl_t;
+#define NH_TL(acc)                                   \
+    do {                                             \
+        const unsigned long long _n = nh_core_clock(); \
+        acc += _n - tl_t;                            \
+        tl_t = _n;                                   \
+    } while (0)
+    tl_t = nh_core_clock();
+#else
+#define NH_TL(acc)
+#endif
+    for (int n = 0; n < nstage; ++n) {
+        const float* buf = lds + (n & 1) * NH_WG_STAGE_FLOATS;
+        // lane (i, k): sample 2e + k of k-step e, rows PO*i .. of the wave's A block / PI*i .. of its B block
+        const float* pa = buf + k * ar + 32 * PO * ow + PO * i;
+        const float* pb = buf + g * a_fl + k * br + 32 * PI * iw + PI * i;
+        NH_TL(tl_loop);
+        nh_wait_vmem();
+        NH_TL(tl_wait);
+        nh_block_sync();  // stage n has landed for every wave; everybody is done reading the other buffer
+        NH_TL(tl_bar);
+        WStep<PO, PI> c0, c1;
+        if (active) wstep_load(c0, pa, pb);
+        nh_sched_fence();  // first operand reads leave before the scalar set-up of the next copy
+        const int ntn = left < g ? left : g;
+        dma.ptot = 0;
+        if (ntn > 0)
+            dma.init(ga, gb, a_fl, b_fl, ntn, g, lds_addr + (unsigned)(((n + 1) & 1) * NH_WG_STAGE_FLOATS * 4), wave, lane);
+        ga += (size_t)ntn * a_fl, gb += (size_t)ntn * b_fl, left -= ntn;
+        if (active) {
+            if (AR && BR && NH_WG_STAGE_FLOATS / (32 * (AR + BR)) == 1) {
+                // one tile per stage, constant strides: 16 k-steps fully unrolled, every operand address an immediate
+#pragma unroll
+                for (int s = 0; s < 16; s += 2) {
+                    wstep_load(c1, pa + (s + 1) * 2 * AR, pb + (s + 1) * 2 * BR);
+                    dma.issue(1);
+                    nh_sched_fence();
+                    wstep_mfma<PO, PI, BX>(c0, acc, bsum);
+                    wstep_load(c0, pa + (s + 2) * 2 * AR, pb + (s + 2) * 2 * BR);  // (last: one k-step past the stage, unused)
+                    nh_sched_fence();
+                    wstep_mfma<PO, PI, BX>(c1, acc, bsum);
+                }
+            } else {
+                const int steps = 16 * ntile;  // k-steps of two samples each
+                for (int s = 0; s < steps; s += 2) {
+                    pa += 2 * ar, pb += 2 * br;
+                    wstep_load(c1, pa, pb);
+                    dma.issue(1);  // the next stage streams in underneath the MFMAs (at most 8 pieces per wave and stage)
+                    nh_sched_fence();
+                    wstep_mfma<PO, PI, BX>(c0, acc, bsum);
+                    pa += 2 * ar, pb += 2 * br;
+                    wstep_load(c0, pa, pb);  // the last one reads one k-step past the stage (slack / other block): unused
+                    nh_sched_fence();
+                    wstep_mfma<PO, PI, BX>(c1, acc, bsum);
+                }
+            }
+        }
+        dma.issue(1 << 20);  // idle waves, and whatever a short stage left over
+        ntile = ntn;
+    }
+#ifdef NH_WGRAD_TIMELINE
+    NH_TL(tl_loop);
+    if (lane == 0 && active) {
+        unsigned long long* dbg = (unsigned long long*)(a.partial + (size_t)wg * NH_PART + 65536 + 512) + wave * 8;
+        dbg[6] = (tl_wait << 32) | (tl_bar & 0xffffffffull);
+        dbg[7] = tl_loop;
+    }
+#endif
+#undef NH_TL
+    if (!active) return;
+    // split-K partial of this workgroup: accumulator tile (a_t, b_t) of the job at [(a_t * b_tiles + b_t)][16 regs][64 lanes]
+    float* part = a.partial + (size_t)wg * NH_PART;
+#pragma unroll
+    for (int x = 0; x < PO; ++x) {
+        const int a_t = ow * PO + x;
+        if (a_t >= jb.a_tiles) continue;
+#pragma unroll
+        for (int y = 0; y < PI; ++y) {
+            const int b_t = iw * PI + y;
+            if (b_t >= jb.b_tiles) continue;
+            float* dst = part + (size_t)(a_t * jb.b_tiles + b_t) * 1024 + lane;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) dst[c * 64] = acc[x][y][c];
+        }
+        if (BX == 4 || BX == x) {  // bias gradient = row sums of A over this workgroup's samples
+            const float tot = bsum[x] + nh_shfl_xor(bsum[x], 32);
+            if (k == 0) part[65536 + a_t * 32 + i] = tot;
+        }
+    }
+}
+
+template <int PO, int PI, int AR, int BR>
+NH_DEVICE void wgrad_bias_dispatch(const WgradArgs& a, const JobDev& jb, int64_t t0, int64_t t1, int ow, int iw, int wave,
+                                   int lane, int64_t wg, bool active, float* lds) {
+    // the bias sums of A tile x are taken by the wave of column iw == x % wi: one tile per wave when wi >= PO
+    // (computed even when the job carries no bias tensor: the reduce kernel ignores them)
+    if (jb.wi >= PO && PO > 1) {
+        switch (iw) {
+            case 0: wgrad_body<PO, PI, AR, BR, 0>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+            case 1: wgrad_body<PO, PI, AR, BR, (PO > 1 ? 1 : -1)>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+            case 2: wgrad_body<PO, PI, AR, BR, (PO > 2 ? 2 : -1)>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+            case 3: wgrad_body<PO, PI, AR, BR, (PO > 3 ? 3 : -1)>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+            default: wgrad_body<PO, PI, AR, BR, -1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        }
+    } else if (iw == 0) {
+        wgrad_body<PO, PI, AR, BR, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
+    } else {
+        wgrad_body<PO, PI, AR, BR, -1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
+    }
+}
+
+template <int PO, int PI>
+NH_DEVICE void wgrad_dispatch(const WgradArgs& a, const JobDev& jb, int64_t t0, int64_t t1, int ow, int iw, int wave, int lane,
+                              int64_t wg, bool active, float* lds) {
+    if (PO == 4 && PI == 2 && jb.a_rows == 256 && jb.b_rows == 256)  // the 256x256 jobs: 91 % of the 8x256 FLOPs
+        wgrad_bias_dispatch<PO, PI, 256, 256>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
+    else
+        wgrad_bias_dispatch<PO, PI, 0, 0>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
+}
+
+NH_KERNEL void NH_LB(64 * NH_WG_WAVES, 2) k_wgrad(WgradArgs a) {
+    NH_DYN_LDS(smem);
+    float* lds = (float*)smem;
+#ifdef NH_WGRAD_TIMELINE
+    const unsigned long long t_begin = nh_wall_clock();
+    const unsigned long long c_begin = nh_core_clock();
+#endif
+    const int64_t wg = blockIdx.x;
+    int ji = 0;
+    for (int q = 1; q < a.njobs; ++q)
+        if ((int)wg >= a.jobs[q].wg_start) ji = q;
+    const JobDev jb = a.jobs[ji];
+    const int nks = (ji + 1 < a.njobs ? a.jobs[ji + 1].wg_start : a.total_wgs) - jb.wg_start;
+    const int ks = (int)wg - jb.wg_start;
+    const int64_t t0 = a.nt * ks / nks, t1 = a.nt * (ks + 1) / nks;
+    const int lane = nh_lane(), wave = nh_wave_in_block();
+    const bool active = wave < jb.wo * jb.wi;  // idle waves still copy and synchronise
+    // wave -> patch (ow, iw); the column index is rotated by the row so that the waves of one column (which carry the
+    // same bias tile index) sit on different SIMDs (wave w runs on SIMD w % 4)
+    const int ow = wave / jb.wi, iw = (wave % jb.wi + ow) % jb.wi;
+    const int sel = jb.po * 8 + jb.pi;
+    switch (sel) {
+        case 4 * 8 + 2: wgrad_dispatch<4, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 2 * 8 + 4: wgrad_dispatch<2, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 4 * 8 + 1: wgrad_dispatch<4, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 1 * 8 + 4: wgrad_dispatch<1, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 2 * 8 + 2: wgrad_dispatch<2, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 2 * 8 + 1: wgrad_dispatch<2, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 1 * 8 + 2: wgrad_dispatch<1, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        default: wgrad_dispatch<1, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+    }
+#ifdef NH_WGRAD_TIMELINE
+    if (lane == 0 && active) {  // timeline record (8 x u64 per wave): wall begin/end, job, K-slice, core-clock begin/end
+        unsigned long long* dbg = (unsigned long long*)(a.partial + (size_t)wg * NH_PART + 65536 + 512) + wave * 8;
+        dbg[0] = t_begin;
+        dbg[1] = nh_wall_clock();
+        dbg[2] = (unsigned long long)ji;
+        dbg[3] = (unsigned long long)ks;
+        dbg[4] = c_begin;
+        dbg[5] = nh_core_clock();
+    }
+#endif
+}
+
+// fixed-order split-K reduction + scatter into the reference parameter layout.  Accumulator tile (a_t, b_t), register c,
+// lane l holds dW[out_row][in_row] with (MFMA row m = (c&3) + 8(c>>2) + 4(l>>5), column j = l&31, and the row
+// interleave of the wide operand reads)  out_row = 32*po*(a_t/po) + po*m + a_t%po,  in_row = 32*pi*(b_t/pi) + pi*j + b_t%pi.
+NH_KERNEL void k_wgrad_reduce(WgradArgs a) {
+    const int ji = (int)(blockIdx.x >> 8);
+    const JobDev jb = a.jobs[ji];
+    const int local = (int)((blockIdx.x & 255u) * 256u + threadIdx.x);
+    const int lane = local & 63, c = (local >> 6) & 15, tile = local >> 10;  // accumulator tile (a_t, b_t) = a_t * b_tiles + b_t
+    const int a_t = tile / jb.b_tiles, b_t = tile % jb.b_tiles;
+    if (a_t >= jb.a_tiles) return;
+    const int nks = (ji + 1 < a.njobs ? a.jobs[ji + 1].wg_start : a.total_wgs) - jb.wg_start;
+    const int m = (c & 3) + 8 * (c >> 2) + 4 * (lane >> 5);
+    const int out_row = 32 * jb.po * (a_t / jb.po) + jb.po * m + a_t % jb.po;
+    const int in_row = 32 * jb.pi * (b_t / jb.pi) + jb.pi * (lane & 31) + b_t % jb.pi;
+    if (out_row >= jb.r_lo && out_row < jb.r_hi) {
+        int col = -1;
+        if (jb.col_kind == 0) {
+            if (in_row < jb.col_count) col = jb.col_base + in_row;
+        } else {
+            const int cc = jb.col_kind == 1 ? (int)a.xslot[in_row] : (int)a.dslot[in_row];  // stash slot row -> column
+            if (cc >= 0) col = jb.col_base + cc;
+        }
+        if (col >= 0) {
+            // eight interleaved running sums (a fixed order: bit-reproducible) keep eight loads in flight per lane
+            float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const float* p = a.partial + (size_t)jb.wg_start * NH_PART + ((size_t)tile * 16 + c) * 64 + lane;
+            int q = 0;
+            for (; q + 8 <= nks; q += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sum[u] += p[(size_t)(q + u) * NH_PART];
+            }
+            for (; q < nks; ++q) sum[0] += p[(size_t)q * NH_PART];
+            a.g_params[(size_t)jb.w_off + (size_t)(out_row - jb.r_lo) * jb.w_ld + col] =
+                ((sum[0] + sum[1]) + (sum[2] + sum[3])) + ((sum[4] + sum[5]) + (sum[6] + sum[7]));
+        }
+    }
+    if (jb.bias_off >= 0 && b_t == 0 && c == 0 && lane < 32) {
+        const int brow = 32 * jb.po * (a_t / jb.po) + jb.po * lane + a_t % jb.po;
+        if (brow >= jb.r_lo && brow < jb.r_hi) {
+            float s = 0.0f;
+            const float* p = a.partial + (size_t)jb.wg_start * NH_PART + 65536 + a_t * 32 + lane;
+            for (int q = 0; q < nks; ++q) s += p[(size_t)q * NH_PART];
+            a.g_params[(size_t)jb.bias_off + (brow - jb.r_lo)] = s;
+        }
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------
+constexpr int NH_WGRAD_TARGET_WGS = 1024;
+
+// Split-K allocation: job j gets ks_j workgroups with ks_j proportional to its per-tile cost (every workgroup then
+// runs for about the same time), and sum ks_j == NH_WGRAD_TARGET_WGS exactly (largest-remainder rounding) -- the grid
+// is a whole number of rounds over the 256 CUs (one 8-wave workgroup per CU), with no straggler round.
+void wgrad_schedule(const nerfhip_plan* p, int64_t nt, WgradArgs& w) {
+    w.njobs = (int)p->jobs.size();
+    int64_t cost[NH_JOBS_DEV];
+    for (int q = 0; q < w.njobs; ++q) cost[q] = p->jobs[q].cost;
+    int64_t total_cost = 0;
+    for (int q = 0; q < w.njobs; ++q) total_cost += cost[q];
+    int64_t ks[NH_JOBS_DEV], rem[NH_JOBS_DEV];
+    int64_t used = 0;
+    for (int q = 0; q < w.njobs; ++q) {
+        const int64_t num = (int64_t)NH_WGRAD_TARGET_WGS * cost[q];
+        ks[q] = num / total_cost;
+        rem[q] = num % total_cost;
+        if (ks[q] < 1) {
+            ks[q] = 1;
+            rem[q] = 0;
+        }
+        used += ks[q];
+    }
+    while (used < NH_WGRAD_TARGET_WGS) {  // hand out the remaining workgroups by largest remainder
+        int best = 0;
+        for (int q = 1; q < w.njobs; ++q)
+            if (rem[q] > rem[best]) best = q;
+        ks[best] += 1;
+        rem[best] = -1;
+        used += 1;
+    }
+    while (used > NH_WGRAD_TARGET_WGS) {  // (only if many jobs were lifted to 1) take from the largest
+        int best = 0;
+        for (int q = 1; q < w.njobs; ++q)
+            if (ks[q] > ks[best]) best = q;
+        if (ks[best] <= 1) break;
+        ks[best] -= 1;
+        used -= 1;
+    }
+    int start = 0;
+    for (int q = 0; q < w.njobs; ++q) {
+        const NhJob& j = p->jobs[q];
+        if (ks[q] > nt) ks[q] = nt;
+        JobDev& d = w.jobs[q];
+        d.a_rows = j.a_region_rows;
+        d.a_prefix = (int)j.a_row_prefix;
+        d.a_tiles = j.a_tiles;
+        d.b_rows = j.b_region_rows;
+        d.b_prefix = (int)j.b_row_prefix;
+        d.b_tiles = j.b_tiles;
+        d.wo = j.wo;
+        d.wi = j.wi;
+        d.po = j.po;
+        d.pi = j.pi;
+        d.r_lo = j.r_lo;
+        d.r_hi = j.r_hi;
+        d.w_off = (int)j.w_off;
+        d.w_ld = j.w_ld;
+        d.col_kind = j.col_kind;
+        d.col_base = j.col_base;
+        d.col_count = j.col_count;
+        d.bias_off = (int)j.bias_off;
+        d.wg_start = start;
+        d.g = NH_WG_STAGE_FLOATS / (32 * (j.a_region_rows + j.b_region_rows));
+        if (d.g < 1) d.g = 1;
+        start += (int)ks[q];
+    }
+    w.total_wgs = start;
+    for (int r = 0; r < 64; ++r) w.xslot[r] = (short)p->xyz_slot_col[r];
+    for (int r = 0; r < 32; ++r) w.dslot[r] = (short)p->dir_slot_col[r];
+}
+
+}  // namespace
+
+int64_t nh_wgrad_partial_floats(nerfhip_plan* p, int64_t nt) {
+    WgradArgs w;
+    wgrad_schedule(p, nt > 0 ? nt : 1, w);
+    return (int64_t)w.total_wgs * NH_PART;
+}
+
+int nh_wgrad(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad, float* partial, float* g_params,
+             nerfhip_stream_t stream) {
+    WgradArgs w;
+    memset(&w, 0, sizeof(w));
+    wgrad_schedule(p, nt, w);
+    w.stash = stash;
+    w.grad = grad;
+    w.partial = partial;
+    w.g_params = g_params;
+    w.nt = nt;
+    for (int q = 0; q < w.njobs; ++q) {
+        const NhJob& j = p->jobs[q];
+        NH_REQUIRE(j.b_row0 == 0 && 32 * j.a_tiles == j.a_region_rows && 32 * j.b_tiles == j.b_region_rows &&
+                       32 * (j.a_region_rows + j.b_region_rows) <= NH_WG_STAGE_FLOATS && j.a_tiles * j.b_tiles <= 64 &&
+                       j.wo * j.po == j.a_tiles && j.wi * j.pi == j.b_tiles,
+                   "wgrad: job %d does not tile its regions exactly (%d x %d tiles, %d x %d waves, %d x %d patches)", q,
+                   j.a_tiles, j.b_tiles, j.wo, j.wi, j.po, j.pi);
+    }
+#ifndef NERFHIP_EMU
+    {
+        hipError_t e = hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, NH_WG_LDS_BYTES);
+        if (e != hipSuccess) {
+            nh_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d): %s", NH_WG_LDS_BYTES, hipGetErrorString(e));
+            return NERFHIP_ERR_LAUNCH;
+        }
+    }
+#endif
+    NH_LAUNCH(k_wgrad, w.total_wgs, 64 * NH_WG_WAVES, NH_WG_LDS_BYTES, stream, w);
+    int rc = nh_launch_status("wgrad");
+    if (rc) return rc;
+    NH_LAUNCH(k_wgrad_reduce, w.njobs * 256, 256, 0, stream, w);
+    return nh_launch_status("wgrad_reduce");
+}

@@ -4,6 +4,7 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import nerf_pytorch_amd as N
+N._lib.LIB_PATH = os.path.join(ROOT, "nerf-pytorch_amd", "libnerfhip_dbg.so")  # make -C nerf-pytorch_amd/csrc dbg
 dev = torch.device("cuda", 0)
 lib = N._lib.get_lib()
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 786432
@@ -51,6 +52,15 @@ for j in sorted(jobs):
     print("job %2d  wgs %4d  waves/wg %d  start %8.1f..%8.1f us  end %8.1f..%8.1f us  dur mean %8.1f max %8.1f us" % (
         j, len(v), int(v[0, 3]), v[:, 0].min(), v[:, 0].max(), v[:, 1].min(), v[:, 1].max(), (v[:, 1] - v[:, 0]).mean(), (v[:, 1] - v[:, 0]).max()))
 # per-job time per sample tile of one workgroup -> the split-K costs that would equalise workgroup durations
+# share of a wave's cycles parked in s_waitcnt vmcnt(0) / s_barrier at the stage boundaries, per job
+for j in sorted(jobs):
+    sel = (part[:, :, 1] > 0) & (part[:, :, 2] == j)
+    tot = (part[:, :, 5] - part[:, :, 4])[sel].astype(np.float64)
+    wait = (part[:, :, 6] >> np.uint64(32))[sel].astype(np.float64)
+    bar = (part[:, :, 6] & np.uint64(0xffffffff))[sel].astype(np.float64)
+    loop = part[:, :, 7][sel].astype(np.float64)
+    print("job %2d  wave-cycle shares: vmcnt wait %.3f  barrier %.3f  k-step loop %.3f  rest %.3f" % (
+        j, (wait / tot).mean(), (bar / tot).mean(), (loop / tot).mean(), 1 - ((wait + bar + loop) / tot).mean()))
 tau = {}
 for j in sorted(jobs):
     v = np.array(jobs[j])

@@ -89,25 +89,5 @@ def test_image_output(emu):
     P.case_image_output(emu)
 
 
-# ---- the 32x32x2 kernel family (mlp.hip; plans created with NERFHIP_MLP=32; the default family is mlp16.hip) -----------
-def test_v32_mlp_forward_and_goldens(emu, monkeypatch):
-    monkeypatch.setenv("NERFHIP_MLP", "32")
-    P.case_mlp_forward(emu, names=("default4x128", "fern8x128_skip3_L6", "novw4x128", "noinput_linear"), m=40)
-    P.case_mlp_forward(emu, names=("northstar8x256",), m=33)
-    P.case_mlp_golden(emu)
-
-
-def test_v32_mlp_backward(emu, monkeypatch):
-    monkeypatch.setenv("NERFHIP_MLP", "32")
-    P.case_mlp_backward(emu, names=("default4x128", "fern8x128_skip3_L6", "novw4x128"), m=70)
-
-
-def test_v32_e2e_goldens(emu, monkeypatch):
-    monkeypatch.setenv("NERFHIP_MLP", "32")
-    P.case_e2e_golden(emu, "e2e_a.npz")
-    P.case_e2e_golden(emu, "e2e_d.npz")
-    P.case_internal_rng(emu)
-
-
 def test_e2e_northstar_reference_golden(emu):
     P.case_e2e_northstar_golden(emu)

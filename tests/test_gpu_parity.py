@@ -407,19 +407,5 @@ def test_python_api_select_step_resume_and_writer(tmp_path):
         assert np.array_equal(raw[:, 1:].reshape(want8.shape), want8)
 
 
-# ---- the 32x32x2 kernel family (mlp.hip; plans created with NERFHIP_MLP=32; the default family is mlp16.hip) -----------
-def test_v32_mlp_and_render_parity(gpu, monkeypatch):
-    monkeypatch.setenv("NERFHIP_MLP", "32")
-    P.case_mlp_forward(gpu)
-    P.case_mlp_golden(gpu)
-    P.case_mlp_backward(gpu, names=("default4x128", "deep8x128_skip4", "fern8x128_skip3_L6", "novw4x128", "northstar8x256"),
-                        m=1500)
-    for name in ("e2e_a.npz", "e2e_b.npz", "e2e_c.npz", "e2e_d.npz"):
-        P.case_e2e_golden(gpu, name)
-    P.case_render_vs_oracle(gpu, P.MLP_GEOMETRIES["northstar8x256"], n=48, nc=64, nf=128, with_grads=True)
-    P.case_e2e_northstar_golden(gpu)
-    P.case_internal_rng(gpu)
-
-
 def test_e2e_northstar_reference_golden(gpu):
     P.case_e2e_northstar_golden(gpu)

@@ -61,26 +61,28 @@ def macs_per_sample(cfg, dx=63, dd=27):
     return fwd, dgrad
 
 
-def cpu_baseline(sample_rays=512, reps=2):
-    """The oracle (CPU port of the reference path) forward+backward on `sample_rays` synthetic rays, 64+128, 8x256."""
+def cpu_baseline(sample_rays=RAYS_PER_GPU):
+    """The oracle (kind "port": oracle/nerf_oracle.py, the CPU restatement of the reference path, bit-identical to the
+    reference's own functions on CPU -- tests/test_oracle.py) forward + backward on ONE full batch of `sample_rays`
+    synthetic rays, 64+128 samples, 8x256 nets, after a 64-ray warm-up (thread pool, allocator)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import nerf_oracle as O
-    # 16 threads is the fastest setting on the 256-thread EPYC host of the GPU box (measured: 8 -> 520, 16 -> 709,
-    # 32 -> 576, 64 -> 253, 128 -> 49 rays/s; profiles/r01_cpu_threads.txt): more threads only add fork/join overhead
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    # 16-32 threads is the fastest setting on the 256-thread EPYC host of the GPU box (measured: 8 -> 520, 16 -> 709,
+    # 32 -> 576, 64 -> 253, 128 -> 49 rays/s at 128 rays; profiles/r01_cpu_threads.txt): more threads only add
+    # fork/join overhead
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     cfg = dict(MODEL)
     pc = {k: v.requires_grad_(True) for k, v in O.init_params(cfg, seed=1).items()}
     pf = {k: v.requires_grad_(True) for k, v in O.init_params(cfg, seed=2).items()}
     g = torch.Generator().manual_seed(0)
-    n = sample_rays
-    ro = torch.tensor([0.0, 0.0, 4.0]).expand(n, 3)
-    rd = torch.randn(n, 3, generator=g) * 0.3
-    rd[:, 2] = -1.0
-    rays = O.pack_rays(ro, rd, 2.0, 6.0, rd)
-    tgt = torch.rand(n, 3, generator=g)
     opt = dict(num_coarse=NC, num_fine=NF, perturb=True, lindisp=False, white_background=False, noise_std=0.2)
-    best = float("inf")
-    for it in range(reps + 1):
+
+    def one(n):
+        ro = torch.tensor([0.0, 0.0, 4.0]).expand(n, 3)
+        rd = torch.randn(n, 3, generator=g) * 0.3
+        rd[:, 2] = -1.0
+        rays = O.pack_rays(ro, rd, 2.0, 6.0, rd)
+        tgt = torch.rand(n, 3, generator=g)
         rand = dict(t_rand=torch.rand(n, NC, generator=g), noise_coarse=torch.randn(n, NC, generator=g),
                     u=torch.rand(n, NF, generator=g), noise_fine=torch.randn(n, NC + NF, generator=g))
         t0 = time.perf_counter()
@@ -89,12 +91,74 @@ def cpu_baseline(sample_rays=512, reps=2):
         loss.backward()
         for p in list(pc.values()) + list(pf.values()):
             p.grad = None
-        dt = time.perf_counter() - t0
-        if it > 0:
-            best = min(best, dt)
-    return dict(value=n / best, unit="rays/s", cores=torch.get_num_threads(), kind="port",
-                sample="%d rays x (64 coarse + 128 fine), 8x256 nets, fwd+bwd (no optimizer), best of %d after 1 warm-up; "
-                       "oracle/nerf_oracle.py (torch %s CPU)" % (n, reps, torch.__version__))
+        return time.perf_counter() - t0
+
+    one(64)
+    n = sample_rays
+    dt = one(n)
+    return dict(value=n / dt, unit="rays/s", cores=torch.get_num_threads(), kind="port", seconds=round(dt, 2),
+                sample="one full batch of %d rays x (64 coarse + 128 fine), 8x256 nets, fwd+bwd (no optimizer), after a 64-ray "
+                       "warm-up; oracle/nerf_oracle.py = the reference's functions restated on torch %s CPU ops (bit-identical "
+                       "to the reference on CPU, tests/test_oracle.py)" % (n, torch.__version__))
+
+
+def dropin_route(dev, n=RAYS_PER_GPU, steps=5, warmup=2):
+    """The reference's own loop body on this package's drop-in API: run_one_iter_of_nerf on
+    whole-image rays gathered with torch indexing, img2mse, loss.backward(), torch.optim.Adam.step() -- no TrainEngine."""
+    cfg = dict(MODEL)
+    torch.manual_seed(42)
+    mc, mf = N.FlexibleNeRFModel(**cfg).to(dev), N.FlexibleNeRFModel(**cfg).to(dev)
+    optim = torch.optim.Adam(list(mc.parameters()) + list(mf.parameters()), lr=5e-3)
+    opts = N.make_options(NC, NF, num_random_rays=n)
+    ex, ed = N.get_embedding_function(10, True, True), N.get_embedding_function(4, True, True)
+    pose = pose_spherical(30.0, -30.0, 4.0).to(dev)
+    g = torch.Generator(device=dev).manual_seed(7)
+    image = torch.rand(H, W, 3, generator=g, device=dev)
+
+    def step():
+        ro, rd = N.get_ray_bundle(H, W, FOCAL, pose)                      # train_nerf.py:213
+        sel = torch.randperm(H * W, device=dev)[:n]                        # :218-222 (np.random.choice there)
+        ro, rd, tgt = ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel], image.reshape(-1, 3)[sel]
+        out = N.run_one_iter_of_nerf(H, W, FOCAL, mc, mf, ro, rd, opts, mode="train", encode_position_fn=ex,
+                                     encode_direction_fn=ed)
+        loss = N.img2mse(out[0], tgt) + N.img2mse(out[3], tgt)             # :244-258
+        loss.backward()
+        optim.step()
+        optim.zero_grad()
+        return loss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    del mc, mf, optim
+    torch.cuda.empty_cache()
+    return dict(value=round(n / dt, 1), unit="rays/s", ms_per_step=round(dt * 1e3, 3),
+                what="run_one_iter_of_nerf + img2mse + backward + torch.optim.Adam on %d rays (whole-image get_ray_bundle, "
+                     "torch randperm gather), %d steps after %d warm-up" % (n, steps, warmup))
+
+
+def wgrad_bytes_per_sample(cfg, dx_slots=64, dd_slots=32):
+    """Algorithmic HBM read bytes of k_wgrad per sample point: every job reads its d(pre-activation) rows and its
+    activation rows once (wgrad.hip; rows as laid out by plan.cpp build_layouts_and_jobs)."""
+    Wd, L, sk = cfg["hidden_size"], cfg["num_layers"], cfg["skip_connect_every"]
+    rows = (Wd + dx_slots)                                   # layer1: dP_0 x X
+    for i in range(L - 1):
+        rows += 2 * Wd                                        # dP_{i+1} x H_i
+        if i % sk == 0 and i > 0:
+            rows += Wd + dx_slots                             # ... x X (skip columns)
+    rows += 2 * Wd + (32 + Wd) + (Wd // 2 + Wd) + (Wd // 2 + dd_slots) + (32 + Wd // 2)   # feat, alpha, dir, dir x D, rgb
+    return 4 * rows
+
+
+def stash_bytes_per_sample(cfg, dx_slots=64, dd_slots=32):
+    """Algorithmic HBM write bytes of the training forward per sample point: the activation stash + ReLU masks."""
+    Wd, L = cfg["hidden_size"], cfg["num_layers"]
+    return 4 * (dx_slots + dd_slots + L * Wd + Wd + Wd // 2) + 8 * (L + 1)
 
 
 def pytorch_rocm_reference(dev, n=RAYS_PER_GPU, reps=3):
@@ -142,8 +206,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hidden", type=int, default=MODEL["hidden_size"])
     ap.add_argument("--layers", type=int, default=MODEL["num_layers"])
-    ap.add_argument("--overlap", type=int, default=1, help="1: two-stream step (coarse backward next to the fine pass); "
-                    "0: single-stream order")
+    ap.add_argument("--overlap", type=int, default=-1, help="1: two-stream step (coarse backward next to the fine pass); "
+                    "0: single-stream order; -1: the engine's default for the net width")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -171,7 +235,7 @@ def main():
     mc = N.FlexibleNeRFModel(**cfg).to(dev)
     mf = N.FlexibleNeRFModel(**cfg).to(dev)
     eng = N.TrainEngine(mc, mf, NC, NF, perturb=True, lindisp=False, white_background=False, noise_std=0.2, lr=5e-3,
-                        seed=1234, world_size=world, rank=rank, overlap=bool(args.overlap))
+                        seed=1234, world_size=world, rank=rank, overlap=None if args.overlap < 0 else bool(args.overlap))
     n = args.rays
     opts = N.make_options(NC, NF, num_random_rays=n)
     poses = torch.stack([pose_spherical(th, -30.0, 4.0) for th in torch.linspace(-180, 180, 101)[:-1].tolist()]).to(dev)
@@ -232,8 +296,24 @@ def main():
             launches_per_step = cnt / args.steps
             avg_ms = ms / cnt
             achieved = per_step_flops / launches_per_step / (avg_ms * 1e-3) / 1e12
+            # HBM traffic per launch of that kernel (mean of the coarse- and the fine-sized launch): algorithmic bytes,
+            # and the counter bytes of the tracked rocprofv3 --pmc pass of this same command (scripts/gpu_pmc.sh:
+            # separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes for gfx950)
+            samples_per_launch = (m_c + m_f) / 2.0
+            alg = {"wgrad": wgrad_bytes_per_sample(cfg), "fwd": stash_bytes_per_sample(cfg),
+                   "dgrad": 4 * (cfg["num_layers"] * cfg["hidden_size"] + cfg["hidden_size"] + cfg["hidden_size"] // 2 + 32)}[kind]
+            traffic = dict(algorithmic_gb=round(alg * samples_per_launch / 1e9, 3), counter_gb=None, source=None)
+            pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+            if os.path.exists(pmc_file) and cfg == MODEL and n == RAYS_PER_GPU:
+                pm = json.load(open(pmc_file))
+                rows = [v for v in pm.values() if v["kernel"] == ("k_wgrad" if kind == "wgrad" else "k_mlp_%s16" % kind)]
+                if rows:
+                    per = [(r["fetch_gb_x2"] if kind == "wgrad" else 0.0) + (r["write_gb"] if kind != "wgrad" else 0.0) for r in rows]
+                    traffic["counter_gb"] = round(sum(per) / len(per), 3)
+                    traffic["source"] = "profiles/r02_pmc_summary.json (tracked rocprofv3 --pmc passes of this command: " + \
+                        ("FETCH_SIZE x2" if kind == "wgrad" else "WRITE_SIZE") + ", mean over the launch sizes recorded)"
             roof = dict(bound="mfma", kernel=name.strip("()"), achieved=round(achieved, 3), peak=FP32_MFMA_PEAK_TFLOPS,
-                        unit="TFLOP/s", frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                        unit="TFLOP/s", frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
                         avg_launch_ms=round(avg_ms, 4), launches=cnt,
                         algorithmic_gflop_per_launch=round(per_step_flops / launches_per_step / 1e9, 2),
                         kernel_ms_per_step={nm.strip("()"): round(m / args.steps, 4) for m, nm, _, _ in table})
@@ -250,6 +330,10 @@ def main():
                    final_loss=loss_host, roofline=roof)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
+            try:
+                res["dropin_route"] = dropin_route(dev)
+            except Exception as e:
+                res["dropin_route"] = dict(error=repr(e)[:200])
             try:
                 res["pytorch_rocm_reference"] = pytorch_rocm_reference(dev)
                 res["speedup_vs_pytorch_rocm_fwd_bwd"] = round(res["value"] / res["pytorch_rocm_reference"]["value"], 3)

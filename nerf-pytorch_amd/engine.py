@@ -10,7 +10,8 @@ streams, with no host synchronisation inside the step.  The reference runs every
 the coarse net's backward needs nothing from the fine pass, so it runs next to the fine forward/backward (fills the
 tails of those launches), and with G > 1 ranks the fine net's gradient all-reduce (RCCL) is in flight while the coarse
 backward still computes.  `overlap=False` gives the single-stream order (coarse+fine forward, loss, fine backward,
-coarse backward) with the same collectives.
+coarse backward) with the same collectives -- in both orders the fine net's all-reduce is launched before the coarse
+backward.  Default: two streams for nets narrower than 256 (measured +2.5 %), one stream for 256-wide nets (-0.4 %).
 
 Data parallelism (BASELINE config 3): one process per GPU, weights replicated, each rank renders its own N/G rays;
 the only exchange is the all-reduce (sum) of the 2 x 595,844-float gradient (one collective per net), scaled by 1/G
@@ -29,7 +30,7 @@ from .parallel import allreduce_gradients
 class TrainEngine:
     def __init__(self, model_coarse, model_fine, num_coarse, num_fine, perturb=True, lindisp=False, white_background=False,
                  noise_std=0.0, lr=5e-3, betas=(0.9, 0.999), eps=1e-8, seed=0, process_group=None, world_size=None,
-                 rank=None, overlap=True):
+                 rank=None, overlap=None):
         self.lib = L.get_lib()
         self.mc, self.mf = model_coarse, model_fine if num_fine > 0 else None
         self.dev = model_coarse.flat_params.device
@@ -58,7 +59,9 @@ class TrainEngine:
         self.loss = torch.zeros(3, dtype=torch.float32, device=self.dev)
         self._loss_c = torch.zeros(3, dtype=torch.float32, device=self.dev)
         self._loss_f = torch.zeros(3, dtype=torch.float32, device=self.dev)
-        self.overlap = bool(overlap)
+        # two-stream graph: measured on MI355X (profiles/r02_overlap_ab.txt) +2.5 % for 128-wide nets (the short kernels'
+        # tails fill), -0.4 % for 256-wide nets (every launch already fills the chip for milliseconds) -> default by width
+        self.overlap = (model_coarse.cfg["hidden_size"] < 256) if overlap is None else bool(overlap)
         self._side = None       # second HIP stream of this device (created on first use)
         self._ev = None
         self._pending = []      # in-flight gradient all-reduces of the current step

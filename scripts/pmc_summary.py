@@ -1,7 +1,7 @@
 """Aggregate rocprofv3 --pmc passes (scripts/gpu_pmc.sh) per kernel and launch size into one table.
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads, so the
 x2-corrected column is the one to compare with byte counts (MI355X_MICROARCH.md, HBM section)."""
-import csv, glob, os, sys, collections
+import csv, glob, json, os, sys, collections
 
 root = sys.argv[1]
 
@@ -38,6 +38,7 @@ for sub in ("sq", "fetch", "write"):
             g = int(r["Grid_Size"]) if "Grid_Size" in r else int(r.get("Grid_Size_X", 0))
             dur[(k, g)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 
+summary = {}
 print("%-16s %9s %8s %9s %9s %9s %9s %8s   %s" % ("kernel", "grid", "dur_ms", "mfma_util", "wait_any", "wait_inst", "active", "clk_GHz",
                                                     "HBM traffic per launch"))
 for key in sorted(acc):
@@ -52,3 +53,7 @@ for key in sorted(acc):
     print("%-16s %9d %8.3f %9.3f %9.3f %9.3f %9.3f %8.2f   FETCH %.2f GB (x2 corr %.2f)  WRITE %.2f GB" % (
         key[0], key[1], d, mfma, avg("SQ_WAIT_ANY") / wc if wc else float("nan"), avg("SQ_WAIT_INST_ANY") / wc if wc else float("nan"),
         avg("SQ_ACTIVE_INST_ANY") / wc if wc else float("nan"), gui / (d * 1e6) if d == d and d > 0 else float("nan"), fetch, 2 * fetch, write))
+    summary["%s/%d" % key] = dict(kernel=key[0], grid=key[1], dur_ms=d, mfma_util=mfma, clk_ghz=gui / (d * 1e6) if d == d and d > 0 else None,
+                                  fetch_gb_raw=fetch, fetch_gb_x2=2 * fetch, write_gb=write)
+if len(sys.argv) > 2:
+    json.dump(summary, open(sys.argv[2], "w"), indent=1, sort_keys=True)

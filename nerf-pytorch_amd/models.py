@@ -60,11 +60,11 @@ class _MlpFunction(torch.autograd.Function):
     kernels read); backward hands each one its slice of the flat gradient -- no concatenation in either direction."""
 
     @staticmethod
-    def forward(ctx, model, x, *params):
+    def forward(ctx, model, x, need, *params):
         lib = L.get_lib()
         m = x.shape[0]
         out = torch.empty((m, 4), dtype=torch.float32, device=x.device)
-        need = any(ctx.needs_input_grad[2:])  # (grad mode is off inside Function.forward: ask autograd instead)
+        # `need` (decided by the caller: needs_input_grad ignores torch.no_grad()): keep the stash for a backward
         packed = model._packed()
         stash = None
         if need:
@@ -86,7 +86,7 @@ class _MlpFunction(torch.autograd.Function):
         with L.launch_on(g, scratch, gflat, ctx.packed, ctx.stash) as st:
             lib.mlp_bwd(model._plan, ctx.packed.data_ptr(), g.data_ptr(), m, ctx.stash.data_ptr(), scratch.data_ptr(), sb,
                         gflat.data_ptr(), st)
-        return (None, None) + model._split_flat(gflat)
+        return (None, None, None) + model._split_flat(gflat)
 
 
 class FlexibleNeRFModel(torch.nn.Module):
@@ -237,5 +237,7 @@ class FlexibleNeRFModel(torch.nn.Module):
         x2 = x.reshape(-1, x.shape[-1]).contiguous().float()
         if x2.shape[-1] != self.dim_xyz + self.dim_dir:
             raise RuntimeError("expected %d input columns, got %d" % (self.dim_xyz + self.dim_dir, x2.shape[-1]))
-        y = _MlpFunction.apply(self, x2, *self._ordered_params())
+        params = self._ordered_params()
+        need = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        y = _MlpFunction.apply(self, x2, need, *params)
         return y.reshape(list(lead) + [4])

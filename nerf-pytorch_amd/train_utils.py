@@ -75,14 +75,14 @@ class _FusedRender(torch.autograd.Function):
     in ray chunks and backpropagates afterwards), so it must not be shared between calls."""
 
     @staticmethod
-    def forward(ctx, rays, model_c, model_f, cfg_tuple, rand, n_params_c, *params):
+    def forward(ctx, rays, model_c, model_f, cfg_tuple, rand, training, *params):
         lib = L.get_lib()
         nc, nf, perturb, lindisp, white, noise_std = cfg_tuple
         n, stride = rays.shape
         dev = rays.device
         cfg = L.RenderCfg(nc, nf, int(bool(perturb)), int(bool(lindisp)), int(bool(white)), float(noise_std), stride)
-        # grad mode is off inside Function.forward: ask autograd whether a parameter gradient will be wanted
-        training = any(ctx.needs_input_grad[6:])
+        # `training` (decided by the caller: grad mode is off inside Function.forward, and needs_input_grad ignores
+        # torch.no_grad()): keep the activation stash for a backward
         plan_f = model_f._plan if nf > 0 else None
         wsb = lib.render_workspace_bytes(model_c._plan, plan_f, C.byref(cfg), n, int(training))
         if wsb < 0:
@@ -100,14 +100,14 @@ class _FusedRender(torch.autograd.Function):
                            packed_f.data_ptr() if packed_f is not None else None, linspace01(nc, dev).data_ptr(),
                            linspace01(nf, dev).data_ptr() if nf > 0 else None, C.byref(rr), 0, 0, C.byref(out),
                            ws.data_ptr(), wsb, int(training), st)
-        ctx.keep = (rays, model_c, model_f, cfg, rand, ws, wsb, packed_c, packed_f, training, n_params_c)
+        ctx.keep = (rays, model_c, model_f, cfg, rand, ws, wsb, packed_c, packed_f, training)
         ctx.mark_non_differentiable(bufs["disp_coarse"], bufs["disp_fine"])
         return tuple(bufs[k] for k in names)
 
     @staticmethod
     def backward(ctx, g_rgb_c, g_disp_c, g_acc_c, g_depth_c, g_rgb_f, g_disp_f, g_acc_f, g_depth_f):
         lib = L.get_lib()
-        rays, model_c, model_f, cfg, rand, ws, wsb, packed_c, packed_f, training, n_params_c = ctx.keep
+        rays, model_c, model_f, cfg, rand, ws, wsb, packed_c, packed_f, training = ctx.keep
         if not training:
             raise RuntimeError("fused render was run without gradient bookkeeping")
         n = rays.shape[0]
@@ -149,8 +149,9 @@ def _predict_fused(ray_batch, model_coarse, model_fine, opts):
     cfg_tuple = (nc, nf, bool(perturb), bool(opts.lindisp), bool(opts.white_background), float(noise_std))
     pc = model_coarse._ordered_params()
     pf = model_fine._ordered_params() if nf > 0 else []
+    training = torch.is_grad_enabled() and any(p.requires_grad for p in pc + pf)
     outs = _FusedRender.apply(rays, model_coarse, model_fine if nf > 0 else None, cfg_tuple,
-                              (t_rand, noise_c, u, noise_f), len(pc), *pc, *pf)
+                              (t_rand, noise_c, u, noise_f), training, *pc, *pf)
     rgb_c, disp_c, acc_c, depth_c, rgb_f, disp_f, acc_f, depth_f = outs
     if rgb_c.requires_grad:
         # disparity re-derived from the differentiable depth / accumulation maps with the reference's own torch ops

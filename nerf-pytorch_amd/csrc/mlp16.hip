@@ -23,15 +23,19 @@ namespace {
 // Workgroup shape (measured, profiles/r01_mlp16_ab.txt): 256-wide nets -- ONE 8-wave workgroup per CU (two waves per
 // SIMD; the weight stream is paid once per 128 samples); 128-wide nets (134 registers per wave, 52 KB of LDS) -- 4-wave
 // workgroups, three per CU.
+#ifndef NH16_NARROW_NW  // (overridden by A/B builds only: scripts/build_variant.sh)
+#define NH16_NARROW_NW 4
+#define NH16_NARROW_CHUNK 6144
+#endif
 template <int W>
 struct Shape {
-    static constexpr int NW = W >= 256 ? 8 : 4;  // waves per workgroup
+    static constexpr int NW = W >= 256 ? 8 : NH16_NARROW_NW;  // waves per workgroup
 };
 // floats of one chunk buffer: 256-wide nets 16384 (16 k-steps x 4 quads; 2 x 64 KB + bias blocks = 132 KB: one
 // workgroup per CU, which the 240-register waves allow anyway), 128-wide nets 6144 (8 k-steps x 3 quads; 52 KB -> 3 per CU)
 template <int W>
 struct Lds {
-    static constexpr int CHUNK_MAX = W >= 256 ? 16384 : 6144;
+    static constexpr int CHUNK_MAX = W >= 256 ? 16384 : NH16_NARROW_CHUNK;
     static constexpr int BYTES = (2 * CHUNK_MAX + 2 * NH16_BIAS_FLOATS) * 4;
 };
 
@@ -178,12 +182,14 @@ NH_DEVICE void gemm16(Ctx& cx, const float* inA, const float* inB, int64_t img_o
                 }
                 nh_sched_fence();  // reads, copy and stores of this k-step are issued before its MFMAs
                 const float b = r < KRA ? inA[r < KRA ? r : 0] : inB[r >= KRA ? r - KRA : 0];
+                nh_prio_mfma<1>();
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
                     const float4& w = a[ks & 1][t >> 2];
                     const float av = (t & 3) == 0 ? w.x : ((t & 3) == 1 ? w.y : ((t & 3) == 2 ? w.z : w.w));
                     acc[t] = nh_mfma16(av, b, acc[t]);
                 }
+                nh_prio_mfma<0>();
             }
         }
         cx.issue_from(kc);  // a copy with more pieces per wave than this chunk had k-steps
@@ -216,11 +222,6 @@ struct RowRef {
     char* base;    // wave-uniform; NULL: nothing is stored
     unsigned off;  // this lane's byte offset
     NH_MEMBER float* at(int float_index) const { return (float*)(base + (size_t)off) + float_index; }
-};
-struct NoPost {
-    static constexpr int NT = 0;
-    NH_MEMBER void first() const {}
-    NH_MEMBER void tile(int) const {}
 };
 // activation rows: tile t = rows feat16(4t.., g) = 16t + 4g .. +3 of this lane's sample, one 16-byte store; `mask`
 // (optional) receives the ReLU bits of the activation first.

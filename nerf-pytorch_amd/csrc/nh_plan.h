@@ -108,5 +108,6 @@ struct nerfhip_plan {
     NhStashLayout stash;
     NhGradLayout grad;
     std::vector<NhJob> jobs;
+    int wgrad_waves;         // waves per workgroup of the weight-gradient kernel: 8 (256-wide nets) or 4 (128-wide)
     bool is_skip(int i) const { return i % skip == 0 && i > 0; }
 };

@@ -215,14 +215,15 @@ void add_job(nerfhip_plan* p, const NhRegion& A, int a_tiles, const NhRegion& B,
     j.b_tiles = b_tiles;
     // wave grid: the 8 waves of a workgroup (two per SIMD) take equal patches of at most 8 accumulator tiles each
     int best_wo = 1, best_wi = 1, best_cost = 1 << 30;
-    for (int wo = 1; wo <= 8 && wo <= a_tiles; wo *= 2)
-        for (int wi = 1; wo * wi <= 8 && wi <= b_tiles; wi *= 2) {
+    const int max_waves = p->wgrad_waves;
+    for (int wo = 1; wo <= max_waves && wo <= a_tiles; wo *= 2)
+        for (int wi = 1; wo * wi <= max_waves && wi <= b_tiles; wi *= 2) {
             int po = (a_tiles + wo - 1) / wo, pi = (b_tiles + wi - 1) / wi;
             // a wave's P tiles are P interleaved row sets of its block (wgrad.hip): the grid must tile the job exactly
             if (po > 4 || pi > 4 || po * pi > 8 || po == 3 || pi == 3 || po * wo != a_tiles || pi * wi != b_tiles) continue;
             // SIMD time per sample tile ~ (waves per SIMD) * patch
             const int per_simd = (wo * wi + 3) / 4;
-            int cost = (per_simd * po * pi) * 64 + (8 - wo * wi) * 4 + (po + pi);  // ties: more waves (two per SIMD overlap), then fewer operand reads
+            int cost = (per_simd * po * pi) * 64 + (max_waves - wo * wi) * 4 + (po + pi);  // ties: more waves (two per SIMD overlap), then fewer operand reads
             if (cost < best_cost) {
                 best_cost = cost;
                 best_wo = wo;
@@ -276,6 +277,11 @@ void build_layouts_and_jobs(nerfhip_plan* p) {
     G.POUT = add_region(&G.total_rows, 32);
 
     p->jobs.clear();
+#ifdef NH_WGRAD_WIDE_ONLY  // (A/B builds only: scripts/build_variant.sh)
+    p->wgrad_waves = 8;
+#else
+    p->wgrad_waves = W >= 256 ? 8 : 4;
+#endif
     const int TW = W / 32;
     // layer1: dP_0 x X
     add_job(p, G.P[0], TW, S.X, 0, 2, 0, W, p->t_layer1_w, 1, 0, p->Dx, p->t_layer1_b);

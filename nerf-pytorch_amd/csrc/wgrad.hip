@@ -35,11 +35,17 @@ struct JobDev {
     int g;  // 32-sample tiles per LDS stage
 };
 constexpr int NH_JOBS_DEV = 32;
-// 8 waves per workgroup (two per SIMD); two LDS stages of at most NH_WG_STAGE_FLOATS floats (+ slack for the operand
-// prefetch that runs one k-step past the end of a stage)
-constexpr int NH_WG_WAVES = 8;
-constexpr int NH_WG_STAGE_FLOATS = 16384;
-constexpr int NH_WG_LDS_BYTES = 2 * NH_WG_STAGE_FLOATS * 4 + 4096;
+// Workgroup shapes.  256-wide nets: 8 waves per workgroup (two per SIMD), two LDS stages of 16384 floats (+ slack for
+// the operand prefetch that runs one k-step past the end of a stage): one workgroup per CU.  128-wide nets (jobs of at
+// most 4 x 4 tiles): 4 waves per workgroup with 2 x 2 patches -- 1.0 instead of 1.5 operand dwords per MFMA -- and
+// stages of 8192 floats, so that TWO workgroups share a CU: the two waves of a SIMD then belong to different
+// workgroups and do not meet at the same barriers.
+template <int NWV_, int STAGE_>
+struct WMode {
+    static constexpr int NWV = NWV_, STAGE = STAGE_, LDS_BYTES = 2 * STAGE_ * 4 + 4096;
+};
+using WModeWide = WMode<8, 16384>;
+using WModeNarrow = WMode<4, 8192>;
 // floats of split-K partial per workgroup: 64 output tiles x 16 regs x 64 lanes, + 512 bias partials
 // (+ 128 for the per-wave timeline records of the instrumented build)
 #ifdef NH_WGRAD_TIMELINE
@@ -90,12 +96,14 @@ NH_DEVICE void wstep_load(WStep<PO, PI>& o, const float* pa, const float* pb) {
 // BX: which A tiles this wave sums for the bias gradient: -1 none, 0..3 that tile only, 4 all of them
 template <int PO, int PI, int BX>
 NH_DEVICE void wstep_mfma(const WStep<PO, PI>& o, f32x16 (&acc)[PO][PI], float (&bsum)[PO]) {
+    nh_prio_mfma<1>();
 #pragma unroll
     for (int x = 0; x < PO; ++x) {
         if (BX == 4 || BX == x) bsum[x] += o.A.v[x];
 #pragma unroll
         for (int y = 0; y < PI; ++y) acc[x][y] = nh_mfma32(o.A.v[x], o.B.v[y], acc[x][y]);
     }
+    nh_prio_mfma<0>();
 }
 
 // One stage copy, cut into 1-KiB pieces (one DMA instruction each): block A (ntile * a_fl floats) -> stage[0 ..), block
@@ -116,8 +124,9 @@ struct WStageDma {
         q = wave;
         lane16 = lane * 16;
     }
+    template <int NWV>
     NH_MEMBER void issue(int n) {
-        for (int c = 0; c < n && q < ptot; ++c, q += NH_WG_WAVES) {
+        for (int c = 0; c < n && q < ptot; ++c, q += NWV) {
             if (q < pa)
                 nh_dma16a(sa, lane16, q * 1024, dst + q * 1024);
             else
@@ -128,7 +137,7 @@ struct WStageDma {
 
 // AR / BR: rows of the A / B region when known at compile time (0: read from the job) -- with constant strides the
 // operand addresses of a whole stage are immediates of ONE base register.
-template <int PO, int PI, int AR, int BR, int BX>
+template <class MD, int PO, int PI, int AR, int BR, int BX>
 NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int64_t t1, int ow, int iw, int wave, int lane,
                           int64_t wg, bool active, float* lds) {
     const int i = lane & 31, k = lane >> 5;
@@ -143,6 +152,7 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
             for (int c = 0; c < 16; ++c) acc[x][y][c] = 0.0f;
     }
     const int ar = AR ? AR : jb.a_rows, br = BR ? BR : jb.b_rows;
+    constexpr int NH_WG_STAGE_FLOATS = MD::STAGE;
     const int g = (AR && BR) ? NH_WG_STAGE_FLOATS / (32 * (AR + BR)) : jb.g;
     const int a_fl = 32 * ar, b_fl = 32 * br;
     const float* A0 = a.grad + (size_t)32 * (size_t)a.nt * (size_t)jb.a_prefix;
@@ -157,7 +167,7 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
     if (nstage > 0) {
         const int nt0 = left < g ? left : g;
         dma.init(ga, gb, a_fl, b_fl, nt0, g, lds_addr, wave, lane);
-        dma.issue(1 << 20);
+        dma.template issue<MD::NWV>(1 << 20);
         ga += (size_t)nt0 * a_fl, gb += (size_t)nt0 * b_fl, left -= nt0;
     }
     int ntile = (int)(t1 - t0) < g ? (int)(t1 - t0) : g;  // tiles of the stage being multiplied
@@ -197,7 +207,7 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
 #pragma unroll
                 for (int s = 0; s < 16; s += 2) {
                     wstep_load(c1, pa + (s + 1) * 2 * AR, pb + (s + 1) * 2 * BR);
-                    dma.issue(1);
+                    dma.template issue<MD::NWV>(1);
                     nh_sched_fence();
                     wstep_mfma<PO, PI, BX>(c0, acc, bsum);
                     wstep_load(c0, pa + (s + 2) * 2 * AR, pb + (s + 2) * 2 * BR);  // (last: one k-step past the stage, unused)
@@ -209,7 +219,7 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
                 for (int s = 0; s < steps; s += 2) {
                     pa += 2 * ar, pb += 2 * br;
                     wstep_load(c1, pa, pb);
-                    dma.issue(1);  // the next stage streams in underneath the MFMAs (at most 8 pieces per wave and stage)
+                    dma.template issue<MD::NWV>(1);  // the next stage streams in underneath the MFMAs (at most 8 pieces per wave and stage)
                     nh_sched_fence();
                     wstep_mfma<PO, PI, BX>(c0, acc, bsum);
                     pa += 2 * ar, pb += 2 * br;
@@ -219,7 +229,7 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
                 }
             }
         }
-        dma.issue(1 << 20);  // idle waves, and whatever a short stage left over
+        dma.template issue<MD::NWV>(1 << 20);  // idle waves, and whatever a short stage left over
         ntile = ntn;
     }
 #ifdef NH_WGRAD_TIMELINE
@@ -253,36 +263,39 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
     }
 }
 
-template <int PO, int PI, int AR, int BR>
+template <class MD, int PO, int PI, int AR, int BR>
 NH_DEVICE void wgrad_bias_dispatch(const WgradArgs& a, const JobDev& jb, int64_t t0, int64_t t1, int ow, int iw, int wave,
                                    int lane, int64_t wg, bool active, float* lds) {
     // the bias sums of A tile x are taken by the wave of column iw == x % wi: one tile per wave when wi >= PO
     // (computed even when the job carries no bias tensor: the reduce kernel ignores them)
     if (jb.wi >= PO && PO > 1) {
         switch (iw) {
-            case 0: wgrad_body<PO, PI, AR, BR, 0>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
-            case 1: wgrad_body<PO, PI, AR, BR, (PO > 1 ? 1 : -1)>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
-            case 2: wgrad_body<PO, PI, AR, BR, (PO > 2 ? 2 : -1)>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
-            case 3: wgrad_body<PO, PI, AR, BR, (PO > 3 ? 3 : -1)>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
-            default: wgrad_body<PO, PI, AR, BR, -1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+            case 0: wgrad_body<MD, PO, PI, AR, BR, 0>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+            case 1: wgrad_body<MD, PO, PI, AR, BR, (PO > 1 ? 1 : -1)>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+            case 2: wgrad_body<MD, PO, PI, AR, BR, (PO > 2 ? 2 : -1)>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+            case 3: wgrad_body<MD, PO, PI, AR, BR, (PO > 3 ? 3 : -1)>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+            default: wgrad_body<MD, PO, PI, AR, BR, -1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
         }
     } else if (iw == 0) {
-        wgrad_body<PO, PI, AR, BR, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
+        wgrad_body<MD, PO, PI, AR, BR, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
     } else {
-        wgrad_body<PO, PI, AR, BR, -1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
+        wgrad_body<MD, PO, PI, AR, BR, -1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
     }
 }
 
-template <int PO, int PI>
+template <class MD, int PO, int PI>
 NH_DEVICE void wgrad_dispatch(const WgradArgs& a, const JobDev& jb, int64_t t0, int64_t t1, int ow, int iw, int wave, int lane,
                               int64_t wg, bool active, float* lds) {
-    if (PO == 4 && PI == 2 && jb.a_rows == 256 && jb.b_rows == 256)  // the 256x256 jobs: 91 % of the 8x256 FLOPs
-        wgrad_bias_dispatch<PO, PI, 256, 256>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
+    if (MD::NWV == 8 && PO == 4 && PI == 2 && jb.a_rows == 256 && jb.b_rows == 256)  // the 256x256 jobs: 91 % of the 8x256 FLOPs
+        wgrad_bias_dispatch<MD, PO, PI, 256, 256>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
+    else if (MD::NWV == 4 && PO == 2 && PI == 2 && jb.a_rows == 128 && jb.b_rows == 128)  // the 128x128 jobs of 128-wide nets
+        wgrad_bias_dispatch<MD, PO, PI, 128, 128>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
     else
-        wgrad_bias_dispatch<PO, PI, 0, 0>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
+        wgrad_bias_dispatch<MD, PO, PI, 0, 0>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
 }
 
-NH_KERNEL void NH_LB(64 * NH_WG_WAVES, 2) k_wgrad(WgradArgs a) {
+template <class MD>
+NH_KERNEL void NH_LB(64 * MD::NWV, 2) k_wgrad(WgradArgs a) {
     NH_DYN_LDS(smem);
     float* lds = (float*)smem;
 #ifdef NH_WGRAD_TIMELINE
@@ -304,14 +317,14 @@ NH_KERNEL void NH_LB(64 * NH_WG_WAVES, 2) k_wgrad(WgradArgs a) {
     const int ow = wave / jb.wi, iw = (wave % jb.wi + ow) % jb.wi;
     const int sel = jb.po * 8 + jb.pi;
     switch (sel) {
-        case 4 * 8 + 2: wgrad_dispatch<4, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
-        case 2 * 8 + 4: wgrad_dispatch<2, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
-        case 4 * 8 + 1: wgrad_dispatch<4, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
-        case 1 * 8 + 4: wgrad_dispatch<1, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
-        case 2 * 8 + 2: wgrad_dispatch<2, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
-        case 2 * 8 + 1: wgrad_dispatch<2, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
-        case 1 * 8 + 2: wgrad_dispatch<1, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
-        default: wgrad_dispatch<1, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 4 * 8 + 2: wgrad_dispatch<MD, 4, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 2 * 8 + 4: wgrad_dispatch<MD, 2, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 4 * 8 + 1: wgrad_dispatch<MD, 4, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 1 * 8 + 4: wgrad_dispatch<MD, 1, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 2 * 8 + 2: wgrad_dispatch<MD, 2, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 2 * 8 + 1: wgrad_dispatch<MD, 2, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        case 1 * 8 + 2: wgrad_dispatch<MD, 1, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+        default: wgrad_dispatch<MD, 1, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
     }
 #ifdef NH_WGRAD_TIMELINE
     if (lane == 0 && active) {  // timeline record (8 x u64 per wave): wall begin/end, job, K-slice, core-clock begin/end
@@ -380,6 +393,7 @@ constexpr int NH_WGRAD_TARGET_WGS = 1024;
 // runs for about the same time), and sum ks_j == NH_WGRAD_TARGET_WGS exactly (largest-remainder rounding) -- the grid
 // is a whole number of rounds over the 256 CUs (one 8-wave workgroup per CU), with no straggler round.
 void wgrad_schedule(const nerfhip_plan* p, int64_t nt, WgradArgs& w) {
+    const int stage_floats = p->wgrad_waves == 4 ? WModeNarrow::STAGE : WModeWide::STAGE;
     w.njobs = (int)p->jobs.size();
     int64_t cost[NH_JOBS_DEV];
     for (int q = 0; q < w.njobs; ++q) cost[q] = p->jobs[q].cost;
@@ -437,13 +451,26 @@ void wgrad_schedule(const nerfhip_plan* p, int64_t nt, WgradArgs& w) {
         d.col_count = j.col_count;
         d.bias_off = (int)j.bias_off;
         d.wg_start = start;
-        d.g = NH_WG_STAGE_FLOATS / (32 * (j.a_region_rows + j.b_region_rows));
+        d.g = stage_floats / (32 * (j.a_region_rows + j.b_region_rows));
         if (d.g < 1) d.g = 1;
         start += (int)ks[q];
     }
     w.total_wgs = start;
     for (int r = 0; r < 64; ++r) w.xslot[r] = (short)p->xyz_slot_col[r];
     for (int r = 0; r < 32; ++r) w.dslot[r] = (short)p->dir_slot_col[r];
+}
+
+template <class MD>
+int launch_wgrad(const WgradArgs& w, nerfhip_stream_t stream) {
+#ifndef NERFHIP_EMU
+    hipError_t e = hipFuncSetAttribute((const void*)k_wgrad<MD>, hipFuncAttributeMaxDynamicSharedMemorySize, MD::LDS_BYTES);
+    if (e != hipSuccess) {
+        nh_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d): %s", MD::LDS_BYTES, hipGetErrorString(e));
+        return NERFHIP_ERR_LAUNCH;
+    }
+#endif
+    NH_LAUNCH((k_wgrad<MD>), w.total_wgs, 64 * MD::NWV, MD::LDS_BYTES, stream, w);
+    return nh_launch_status("wgrad");
 }
 
 }  // namespace
@@ -467,22 +494,17 @@ int nh_wgrad(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad,
     for (int q = 0; q < w.njobs; ++q) {
         const NhJob& j = p->jobs[q];
         NH_REQUIRE(j.b_row0 == 0 && 32 * j.a_tiles == j.a_region_rows && 32 * j.b_tiles == j.b_region_rows &&
-                       32 * (j.a_region_rows + j.b_region_rows) <= NH_WG_STAGE_FLOATS && j.a_tiles * j.b_tiles <= 64 &&
+                       32 * (j.a_region_rows + j.b_region_rows) <= (p->wgrad_waves == 4 ? WModeNarrow::STAGE : WModeWide::STAGE) &&
+                       j.a_tiles * j.b_tiles <= 64 && j.wo * j.wi <= p->wgrad_waves &&
                        j.wo * j.po == j.a_tiles && j.wi * j.pi == j.b_tiles,
                    "wgrad: job %d does not tile its regions exactly (%d x %d tiles, %d x %d waves, %d x %d patches)", q,
                    j.a_tiles, j.b_tiles, j.wo, j.wi, j.po, j.pi);
     }
-#ifndef NERFHIP_EMU
-    {
-        hipError_t e = hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, NH_WG_LDS_BYTES);
-        if (e != hipSuccess) {
-            nh_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d): %s", NH_WG_LDS_BYTES, hipGetErrorString(e));
-            return NERFHIP_ERR_LAUNCH;
-        }
-    }
-#endif
-    NH_LAUNCH(k_wgrad, w.total_wgs, 64 * NH_WG_WAVES, NH_WG_LDS_BYTES, stream, w);
-    int rc = nh_launch_status("wgrad");
+    int rc = NERFHIP_OK;
+    if (p->wgrad_waves == 4)
+        rc = launch_wgrad<WModeNarrow>(w, stream);
+    else
+        rc = launch_wgrad<WModeWide>(w, stream);
     if (rc) return rc;
     NH_LAUNCH(k_wgrad_reduce, w.njobs * 256, 256, 0, stream, w);
     return nh_launch_status("wgrad_reduce");

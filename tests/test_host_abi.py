@@ -123,6 +123,25 @@ def test_product_package_never_imports_the_oracle():
             assert "libnerfhip_emu" not in src, fn
 
 
+def test_product_reads_no_environment_and_ships_one_kernel_set():
+    """no developer knobs in the shipped library -- neither the Python package nor the C/HIP sources
+    read the environment, and the instrumentation (timelines, phase stamps) only exists behind the `make dbg` macros."""
+    pkg = os.path.join(ROOT, "nerf-pytorch_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "os.environ" not in src and "getenv" not in src, fn
+    csrc = os.path.join(pkg, "csrc")
+    for fn in os.listdir(csrc):
+        if fn.endswith((".hip", ".cpp", ".h")):
+            src = open(os.path.join(csrc, fn)).read()
+            assert "getenv" not in src, fn
+    wg = open(os.path.join(csrc, "wgrad.hip")).read()
+    assert wg.count("#ifdef NH_WGRAD_TIMELINE") >= 3 and "nh_wall_clock()" in wg  # instrumentation is debug-build only
+    assert sorted(f for f in os.listdir(csrc) if f.endswith(".hip")) == [
+        "dataio.hip", "elementwise.hip", "fused.hip", "mlp.hip", "mlp16.hip", "render.hip", "sample.hip", "wgrad.hip"]
+
+
 def test_shard_bounds():
     from nerf_pytorch_amd.parallel import shard_bounds
     for n, w in ((8192, 8), (4096, 3), (10, 4), (3, 8)):

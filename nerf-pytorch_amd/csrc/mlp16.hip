@@ -182,15 +182,13 @@ NH_DEVICE void gemm16(Ctx& cx, const float* inA, const float* inB, int64_t img_o
                 }
                 nh_sched_fence();  // reads, copy and stores of this k-step are issued before its MFMAs
                 const float b = r < KRA ? inA[r < KRA ? r : 0] : inB[r >= KRA ? r - KRA : 0];
-                nh_prio_mfma<1>();
-#pragma unroll
+            #pragma unroll
                 for (int t = 0; t < T; ++t) {
                     const float4& w = a[ks & 1][t >> 2];
                     const float av = (t & 3) == 0 ? w.x : ((t & 3) == 1 ? w.y : ((t & 3) == 2 ? w.z : w.w));
                     acc[t] = nh_mfma16(av, b, acc[t]);
                 }
-                nh_prio_mfma<0>();
-            }
+                        }
         }
         cx.issue_from(kc);  // a copy with more pieces per wave than this chunk had k-steps
         NH16_PH(1);  // [1] operand reads + MFMAs (+ copy pieces, stores)

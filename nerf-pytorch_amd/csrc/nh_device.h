@@ -104,14 +104,6 @@ NH_DEVICE void nh_dma16a(const NhDmaSrc& s, int voff, int soff, unsigned lds_wav
         : "memory");
 }
 NH_DEVICE void nh_wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// wave priority for the CU's issue arbitration (priority first, then age)
-#ifdef NH_PRIO_PINGPONG
-template <int P>
-NH_DEVICE void nh_prio_mfma() { __builtin_amdgcn_s_setprio(P); }
-#else
-template <int P>
-NH_DEVICE void nh_prio_mfma() {}
-#endif
 // nothing is scheduled across this point (pins "issue the prefetch BEFORE the MFMAs")
 NH_DEVICE void nh_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 NH_DEVICE void nh_sincos(float x, float* s, float* c) { sincosf(x, s, c); }

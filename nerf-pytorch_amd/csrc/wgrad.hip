@@ -96,14 +96,12 @@ NH_DEVICE void wstep_load(WStep<PO, PI>& o, const float* pa, const float* pb) {
 // BX: which A tiles this wave sums for the bias gradient: -1 none, 0..3 that tile only, 4 all of them
 template <int PO, int PI, int BX>
 NH_DEVICE void wstep_mfma(const WStep<PO, PI>& o, f32x16 (&acc)[PO][PI], float (&bsum)[PO]) {
-    nh_prio_mfma<1>();
 #pragma unroll
     for (int x = 0; x < PO; ++x) {
         if (BX == 4 || BX == x) bsum[x] += o.A.v[x];
 #pragma unroll
         for (int y = 0; y < PI; ++y) acc[x][y] = nh_mfma32(o.A.v[x], o.B.v[y], acc[x][y]);
     }
-    nh_prio_mfma<0>();
 }
 
 // One stage copy, cut into 1-KiB pieces (one DMA instruction each): block A (ntile * a_fl floats) -> stage[0 ..), block

@@ -17,7 +17,8 @@ PSNR = -10 log10(coarse_mse + fine_mse) (train_nerf.py:258-260): on the training
 iterations) and by the validation-image protocol of train_nerf.py:336-347 (whole 400x400 held-out views rendered with
 the validation options: perturb off, noise 0), at fixed iteration counts.
 
-    python scripts/psnr400.py ARM SEED ITERS OUT.json
+    python scripts/psnr400.py ARM SEED ITERS OUT.json [DRAW_SEED]
+(DRAW_SEED: other random draws for the same init / data order -- how much of an arm-to-arm difference is the draws alone)
 """
 import json
 import math
@@ -141,7 +142,7 @@ def record(hist, i, recent, vals, t_train, t0):
     print(i, hist[i], flush=True)
 
 
-def run(arm, seed, iters, check):
+def run(arm, seed, iters, check, draw_seed=None):
     poses, imgs, train, val = teacher_dataset()
     views = val[:VAL_PER_CHECK]
     torch.manual_seed(seed)
@@ -163,7 +164,7 @@ def run(arm, seed, iters, check):
         mc, mf = mc.to(dev), mf.to(dev)
         eng = N.TrainEngine(mc, mf, NC, NF, perturb=True, white_background=True, noise_std=0.2, lr=5e-3, seed=seed)
         opts = N.make_options(NC, NF, white_background=True)
-    torch.manual_seed(seed + 12345)  # the draws of the training loop (arms "ref" and "dropin" consume the same numbers)
+    torch.manual_seed(seed + 12345 if draw_seed is None else draw_seed)  # the draws of the training loop (arms "ref" and "dropin" consume the same numbers)
     for i in range(1, iters + 1):
         ro, rd, tgt = next(stream)
         if arm == "ref":
@@ -208,6 +209,7 @@ if __name__ == "__main__":
     arm, seed, iters, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     check = [i for i in (250, 500, 1000, 2000, 3000, 4000, 5000, 7500, 10000) if i <= iters]
     check = check or [iters]
-    hist = run(arm, seed, iters, check)
-    json.dump(dict(arm=arm, seed=seed, iters=iters, rays_per_iter=RAYS, image="%dx%d" % (H, W), train_views=N_TRAIN,
+    draw_seed = int(sys.argv[5]) if len(sys.argv) > 5 else None
+    hist = run(arm, seed, iters, check, draw_seed)
+    json.dump(dict(arm=arm, seed=seed, draw_seed=draw_seed, iters=iters, rays_per_iter=RAYS, image="%dx%d" % (H, W), train_views=N_TRAIN,
                    val_views_per_check=VAL_PER_CHECK, checkpoints=hist), open(out, "w"), indent=1)

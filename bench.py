@@ -324,7 +324,8 @@ def main():
                    config=dict(workload="lego 400x400 synthetic views (BASELINE configs[1]): %d rays/GPU/iter, %d coarse + "
                                         "%d fine samples, %dx%d coarse+fine nets, perturb, noise 0.2, Adam, full iteration"
                                         % (n, NC, NF, cfg["num_layers"], cfg["hidden_size"]),
-                               rays_per_gpu=n, global_rays=n * world, parallelism="dp%d" % world),
+                               rays_per_gpu=n, global_rays=n * world, parallelism="dp%d" % world,
+                               two_stream_step=bool(eng.overlap)),
                    step_tflops=round(total_flops / (dt / args.steps) / 1e12, 2),
                    step_frac_of_fp32_mfma_peak=round(total_flops / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                    final_loss=loss_host, roofline=roof)

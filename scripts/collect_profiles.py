@@ -1,0 +1,73 @@
+"""Copies the judged summaries of a scripts/gpu_suite.sh (+ gpu_pmc.sh) run from gpurun_out/ (scratch) into profiles/
+(tracked):  python scripts/collect_profiles.py r02"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+tag = sys.argv[1]
+
+
+def last_json_line(path):
+    with open(path) as f:
+        lines = [l for l in f if l.startswith("{")]
+    return json.loads(lines[-1])
+
+
+def copy(src, dst):
+    if os.path.exists(os.path.join(G, src)):
+        shutil.copyfile(os.path.join(G, src), os.path.join(P, "%s_%s" % (tag, dst)))
+
+
+def kernel_stats(src_dir, dst):
+    path = os.path.join(G, src_dir, "bench_kernel_stats.csv")
+    if not os.path.exists(path):
+        return
+    rows = list(csv.DictReader(open(path)))
+    with open(os.path.join(P, "%s_%s" % (tag, dst)), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline%s   (20 steps after 3 warm-up: the same run length as the bench line)\n" %
+                (" --hidden 128 --layers 4" if "128" in src_dir else ""))
+        f.write("%-64s %8s %14s %12s %8s\n" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
+        for r in rows:
+            f.write("%-64s %8s %14s %12.0f %8s\n" % (r["Name"][:64], r["Calls"], r["TotalDurationNs"], float(r["AverageNs"]),
+                                                    r["Percentage"]))
+
+
+for src, dst in (("bench.log", "bench_line.json"), ("bench_4x128.log", "bench_line_4x128.json")):
+    json.dump(last_json_line(os.path.join(G, src)), open(os.path.join(P, "%s_%s" % (tag, dst)), "w"), indent=1)
+with open(os.path.join(P, tag + "_bench_rays.txt"), "w") as f:
+    f.write("# python bench.py --rays R --no-cpu-baseline  (per-GPU batch of a 2- / 4-GPU strong-scaling split of 4096 rays)\n")
+    for r in (4096, 2048, 1024):
+        j = last_json_line(os.path.join(G, "bench.log" if r == 4096 else "bench_rays%d.log" % r))
+        f.write("rays/GPU %5d  %9.0f rays/s  %7.3f ms/step  step frac %.4f  kernels(ms/step) %s\n" %
+                (r, j["value"], j["ms_per_step"], j["step_frac_of_fp32_mfma_peak"],
+                 {k: v for k, v in list(j["roofline"]["kernel_ms_per_step"].items())[:4]}))
+with open(os.path.join(P, tag + "_overlap_ab.txt"), "w") as f:
+    f.write("# bench.py --overlap 0|1 (single-stream step | coarse backward on a second stream next to the fine pass), "
+            "interleaved twice; kernel times overlap in the two-stream runs\n")
+    for l in open(os.path.join(G, "overlap_ab.jsonl")):
+        j = json.loads(l)
+        f.write("%s two-stream %d  %9.0f rays/s  %7.3f ms/step  step frac %.4f\n" %
+                ("8x256" if "8x256" in j["config"]["workload"] else "4x128", int(j["config"].get("two_stream_step", -1)), j["value"],
+                 j["ms_per_step"], j["step_frac_of_fp32_mfma_peak"]))
+kernel_stats("prof", "bench_kernel_stats.txt")
+kernel_stats("prof128", "bench_kernel_stats_4x128.txt")
+copy("eval.log", "eval_800x800.txt")
+copy("wgrad_timeline.txt", "wgrad_timeline.txt")
+copy("phase_timing.txt", "phase_timing.txt")
+copy("pmc_summary.txt", "pmc_summary.txt")
+copy("pmc_summary.json", "pmc_summary.json")
+copy("r2c1/loop_mock.txt", "loop_mock.txt")
+with open(os.path.join(P, tag + "_gpu_tests.txt"), "w") as f:
+    f.write("# python -m pytest tests -m gpu -q ; python __graft_entry__.py smoke   (MI355X, scripts/gpu_suite.sh)\n")
+    f.write("".join(open(os.path.join(G, "pytest_gpu.log")).readlines()[-4:]))
+    f.write("".join(open(os.path.join(G, "smoke.log")).readlines()[-2:]))
+par = {}
+for path in sorted(glob.glob(os.path.join(G, "parity_fullsize_*.json"))):
+    par[os.path.basename(path)[len("parity_fullsize_"):-5]] = json.load(open(path))
+json.dump(par, open(os.path.join(P, tag + "_parity_fullsize.json"), "w"), indent=1)
+print("\n".join(sorted(os.listdir(P))))

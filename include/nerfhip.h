@@ -136,7 +136,7 @@ int nerfhip_hierarchical_z(const float* z_coarse, const float* weights, int64_t 
 /* ---- K4/K8: the MLP (models.FlexibleNeRFModel, nerf/models.py:185-256) ----------------------------------------- */
 typedef struct nerfhip_model_cfg {
     int num_layers;         /* models.py:188 */
-    int hidden_size;        /* models.py:189; 128 or 256 */
+    int hidden_size;        /* models.py:189; 2..256 (kernel widths 128 / 256; narrower models ride zero-padded) */
     int skip_connect_every; /* models.py:190; cat(h, xyz) before layers_xyz[i] iff i % skip == 0 and i > 0 */
     int num_encoding_fn_xyz;
     int num_encoding_fn_dir;
@@ -183,6 +183,12 @@ int nerfhip_mlp_fwd(nerfhip_plan_t plan, const float* packed, const float* x, in
  * flat gradient vector (overwritten); scratch: dev, nerfhip_plan_bwd_scratch_bytes. */
 int nerfhip_mlp_bwd(nerfhip_plan_t plan, const float* packed, const float* g_out, int64_t m, const void* stash,
                     void* scratch, int64_t scratch_bytes, float* g_params, nerfhip_stream_t stream);
+/* Gradient w.r.t. the encoded input x of the same forward (autograd gives it for models.py:233-256 when x requires
+ * grad; the render path never does): call after nerfhip_mlp_bwd with the same m and scratch (it reads the
+ * d(pre-activation) images left there).  params: dev flat parameter vector (reference layout, not the packed image);
+ * g_x: dev [m, dim_xyz+dim_dir] (overwritten). */
+int nerfhip_mlp_bwd_input(nerfhip_plan_t plan, const float* params, int64_t m, const void* scratch, float* g_x,
+                          nerfhip_stream_t stream);
 
 /* ---- fused render (predict_and_render_radiance, nerf/train_utils.py:28-127, + run_network :8-25) --------------- */
 typedef struct nerfhip_render_cfg {

@@ -93,6 +93,7 @@ _PROTOS = {
     "nerfhip_plan_set_freqs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "nerfhip_mlp_fwd": (C.c_int, [C.c_void_p, c_f, c_f, c_i64, c_f, c_f, c_f]),
     "nerfhip_mlp_bwd": (C.c_int, [C.c_void_p, c_f, c_f, c_i64, c_f, c_f, c_i64, c_f, c_f]),
+    "nerfhip_mlp_bwd_input": (C.c_int, [C.c_void_p, c_f, c_i64, c_f, c_f, c_f]),
     "nerfhip_render_workspace_bytes": (c_i64, [C.c_void_p, C.c_void_p, C.POINTER(RenderCfg), c_i64, C.c_int]),
     "nerfhip_render_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(RenderCfg), c_f, c_i64, c_f, c_f, c_f, c_f,
                                       C.POINTER(RenderRand), c_u64, c_u64, C.POINTER(RenderOut), c_f, c_i64, C.c_int,

@@ -1,9 +1,52 @@
 // mlp.hip -- host side of the FlexibleNeRFModel kernels (nerf/models.py:185-256): argument checks and the launch
 // sequences  forward = k_mlp_fwd16 (mlp16.hip),  backward = k_mlp_dgrad16 (mlp16.hip) -> k_wgrad -> k_wgrad_reduce
-// (wgrad.hip), and the C-ABI entry points nerfhip_mlp_fwd / nerfhip_mlp_bwd.
+// (wgrad.hip), and the C-ABI entry points nerfhip_mlp_fwd / nerfhip_mlp_bwd; plus the gradient w.r.t. the encoded input
+// (nerfhip_mlp_bwd_input: off the hot path -- the render path never differentiates its encodings).
 #include <stdlib.h>
 
 #include "nh_mlp.h"
+
+namespace {
+
+// d(loss)/d(x) of FlexibleNeRFModel.forward (nerf/models.py:233-256): x = cat(xyz, dirs) enters layer1, every skip layer
+// (xyz columns) and layers_dir[0] (direction columns), so
+//   g_x[m, c] = sum over those layers  sum_u dpre[m, u] * W[u, col0 + c - out0]
+// with dpre = the d(pre-activation) image the data-gradient kernel left in the backward scratch ([sample][rows]).
+constexpr int NH_INGRAD_MAX_TERMS = NH_MAX_LAYERS + 2;
+struct InGradTerm {
+    int64_t a_prefix;  // region offset = 32 * nt * a_prefix floats
+    int a_rows, nu;    // row count of the region, real units
+    int64_t w_off;     // flat offset of the weight tensor
+    int w_ld, col0;    // its column count, first column that multiplies x
+    int out0, ncols;   // g_x columns [out0, out0 + ncols)
+};
+struct InGradArgs {
+    InGradTerm t[NH_INGRAD_MAX_TERMS];
+    int nterms;
+    const float* scratch;
+    const float* params;
+    int64_t M, nt;
+    int D;
+    float* g_x;
+};
+
+NH_KERNEL void k_mlp_input_grad(InGradArgs a) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.M * a.D) return;
+    const int64_t m = idx / a.D;
+    const int c = (int)(idx - m * a.D);
+    float s = 0.0f;
+    for (int k = 0; k < a.nterms; ++k) {
+        const InGradTerm& t = a.t[k];
+        if (c < t.out0 || c >= t.out0 + t.ncols) continue;
+        const float* dp = a.scratch + (size_t)32 * (size_t)a.nt * (size_t)t.a_prefix + (size_t)m * (size_t)t.a_rows;
+        const float* w = a.params + t.w_off + t.col0 + (c - t.out0);
+        for (int u = 0; u < t.nu; ++u) s = fmaf(dp[u], w[(size_t)u * t.w_ld], s);
+    }
+    a.g_x[idx] = s;
+}
+
+}  // namespace
 
 // scratch of a backward over M sample points: the d(pre-activation) images the data-gradient kernel writes for the
 // weight-gradient kernel, then the split-K partials
@@ -54,4 +97,35 @@ extern "C" int nerfhip_mlp_bwd(nerfhip_plan_t plan, const float* packed, const f
                                const void* stash, void* scratch, int64_t scratch_bytes, float* g_params,
                                nerfhip_stream_t stream) {
     return nh_mlp_backward(plan, packed, g_out, m, (const float*)stash, (float*)scratch, scratch_bytes, g_params, stream);
+}
+
+extern "C" int nerfhip_mlp_bwd_input(nerfhip_plan_t p, const float* params, int64_t m, const void* scratch, float* g_x,
+                                     nerfhip_stream_t stream) {
+    NH_REQUIRE(p && params && scratch && g_x && m > 0, "mlp_bwd_input: bad arguments");
+    InGradArgs a;
+    memset(&a, 0, sizeof(a));
+    const int H = p->H;
+    auto add = [&](const NhRegion& R, int nu, int tensor, int col0, int out0, int ncols) {
+        InGradTerm& t = a.t[a.nterms++];
+        t.a_prefix = R.row_prefix;
+        t.a_rows = R.rows;
+        t.nu = nu;
+        t.w_off = p->tensors[tensor].off;
+        t.w_ld = p->tensors[tensor].cols;
+        t.col0 = col0;
+        t.out0 = out0;
+        t.ncols = ncols;
+    };
+    add(p->grad.P[0], H, p->t_layer1_w, 0, 0, p->Dx);
+    for (int i = 0; i < p->L - 1; ++i)
+        if (p->is_skip(i)) add(p->grad.P[i + 1], H, p->t_xyz_w[i], H, 0, p->Dx);
+    if (p->view && p->Dd > 0) add(p->grad.PDIR, H / 2, p->t_dir_w, H, p->Dx, p->Dd);
+    a.scratch = (const float*)scratch;
+    a.params = params;
+    a.M = m;
+    a.nt = nh_ceil_div(m, 128) * 4;
+    a.D = p->Dx + p->Dd;
+    a.g_x = g_x;
+    NH_LAUNCH(k_mlp_input_grad, nh_ceil_div(m * a.D, 256), 256, 0, stream, a);
+    return nh_launch_status("mlp_input_grad");
 }

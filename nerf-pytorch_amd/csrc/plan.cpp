@@ -66,8 +66,11 @@ struct Specs16 {
     GemmSpec16 f_layer1, f_xyz[NH_MAX_LAYERS], f_head, f_dir, f_rgb, b_rgb, b_dir, b_head, b_xyz[NH_MAX_LAYERS];
 };
 
+// Kernel width W (128 or 256) >= the model's hidden_size H: units H..W-1 (H/2..W/2-1 of the direction layer) are
+// padding -- every weight and bias of a padded unit is the constant 0 (index -1), so it stays exactly 0 through the
+// forward chain, its ReLU bit is 0, and nothing flows through it in the backward chain.
 void build_specs16(const nerfhip_plan* p, Specs16& S) {
-    const int W = p->W, KH = W / 4, Dx = p->Dx, Dd = p->Dd, L = p->L, TW = W / 16;
+    const int W = p->W, H = p->H, H2 = H / 2, KH = W / 4, Dx = p->Dx, Dd = p->Dd, L = p->L, TW = W / 16;
     auto T = [p](int idx) { return p->tensors[idx]; };
     {
         GemmSpec16& s = S.f_layer1;
@@ -76,9 +79,9 @@ void build_specs16(const nerfhip_plan* p, Specs16& S) {
         NhTensor w = T(p->t_layer1_w), b = T(p->t_layer1_b);
         s.w = [=](int o, int r, int g) -> int64_t {
             int c = p->xyz_col16[g][r];
-            return (o < W && c >= 0) ? w.off + (int64_t)o * Dx + c : -1;
+            return (o < H && c >= 0) ? w.off + (int64_t)o * Dx + c : -1;
         };
-        s.b = [=](int o) -> int64_t { return o < W ? b.off + o : -1; };
+        s.b = [=](int o) -> int64_t { return o < H ? b.off + o : -1; };
     }
     for (int i = 0; i < L - 1; ++i) {
         GemmSpec16& s = S.f_xyz[i];
@@ -86,17 +89,20 @@ void build_specs16(const nerfhip_plan* p, Specs16& S) {
         s.kr = KH + (sk ? NH16_KRX : 0);
         s.tiles = TW;
         NhTensor w = T(p->t_xyz_w[i]), b = T(p->t_xyz_b[i]);
-        const int ld = W + (sk ? Dx : 0);
+        const int ld = H + (sk ? Dx : 0);
         s.w = [=](int o, int r, int g) -> int64_t {
-            if (r < KH) return w.off + (int64_t)o * ld + nh_feat16(r, g);
+            if (o >= H) return -1;
+            if (r < KH) return nh_feat16(r, g) < H ? w.off + (int64_t)o * ld + nh_feat16(r, g) : -1;
             int c = p->xyz_col16[g][r - KH];
-            return c >= 0 ? w.off + (int64_t)o * ld + W + c : -1;
+            return c >= 0 ? w.off + (int64_t)o * ld + H + c : -1;
         };
-        s.b = [=](int o) -> int64_t { return b.off + o; };
+        s.b = [=](int o) -> int64_t { return o < H ? b.off + o : -1; };
         GemmSpec16& bt = S.b_xyz[i];  // dh_in[f] = sum_u W[u][f] dpre[u]   (hidden columns only)
         bt.kr = KH;
         bt.tiles = TW;
-        bt.w = [=](int f, int r, int g) -> int64_t { return w.off + (int64_t)nh_feat16(r, g) * ld + f; };
+        bt.w = [=](int f, int r, int g) -> int64_t {
+            return (nh_feat16(r, g) < H && f < H) ? w.off + (int64_t)nh_feat16(r, g) * ld + f : -1;
+        };
     }
     if (p->view) {
         NhTensor fw = T(p->t_feat_w), fb = T(p->t_feat_b), aw = T(p->t_alpha_w), ab = T(p->t_alpha_b);
@@ -106,50 +112,58 @@ void build_specs16(const nerfhip_plan* p, Specs16& S) {
             s.kr = KH;
             s.tiles = TW + 1;
             s.w = [=](int o, int r, int g) -> int64_t {
-                if (o < W) return fw.off + (int64_t)o * W + nh_feat16(r, g);
-                if (o == W) return aw.off + nh_feat16(r, g);
+                const int f = nh_feat16(r, g);
+                if (f >= H) return -1;
+                if (o < H) return fw.off + (int64_t)o * H + f;
+                if (o == W) return aw.off + f;
                 return -1;
             };
-            s.b = [=](int o) -> int64_t { return o < W ? fb.off + o : (o == W ? ab.off : -1); };
+            s.b = [=](int o) -> int64_t { return o < H ? fb.off + o : (o == W ? ab.off : -1); };
         }
         {
             GemmSpec16& s = S.f_dir;
             s.kr = KH + NH16_KRD;
             s.tiles = TW / 2;
-            const int ld = W + Dd;
+            const int ld = H + Dd;
             s.w = [=](int o, int r, int g) -> int64_t {
-                if (r < KH) return dw.off + (int64_t)o * ld + nh_feat16(r, g);
+                if (o >= H2) return -1;
+                if (r < KH) return nh_feat16(r, g) < H ? dw.off + (int64_t)o * ld + nh_feat16(r, g) : -1;
                 int c = p->dir_col16[g][r - KH];
-                return c >= 0 ? dw.off + (int64_t)o * ld + W + c : -1;
+                return c >= 0 ? dw.off + (int64_t)o * ld + H + c : -1;
             };
-            s.b = [=](int o) -> int64_t { return db.off + o; };
+            s.b = [=](int o) -> int64_t { return o < H2 ? db.off + o : -1; };
         }
         {
             GemmSpec16& s = S.f_rgb;
             s.kr = KH / 2;
             s.tiles = 1;
-            s.w = [=](int o, int r, int g) -> int64_t { return o < 3 ? rw.off + (int64_t)o * (W / 2) + nh_feat16(r, g) : -1; };
+            s.w = [=](int o, int r, int g) -> int64_t {
+                return (o < 3 && nh_feat16(r, g) < H2) ? rw.off + (int64_t)o * H2 + nh_feat16(r, g) : -1;
+            };
             s.b = [=](int o) -> int64_t { return o < 3 ? rb.off + o : -1; };
         }
         {
             GemmSpec16& s = S.b_rgb;  // d(dir hidden)[f] = sum_{rho<3} Wrgb[rho][f] d_rgb[rho]; ONE k-step: group g carries rho = g
             s.kr = 1;
             s.tiles = TW / 2;
-            s.w = [=](int f, int r, int g) -> int64_t { return (r == 0 && g < 3) ? rw.off + (int64_t)g * (W / 2) + f : -1; };
+            s.w = [=](int f, int r, int g) -> int64_t { return (r == 0 && g < 3 && f < H2) ? rw.off + (int64_t)g * H2 + f : -1; };
         }
         {
             GemmSpec16& s = S.b_dir;  // d(feat)[f] = sum_u Wdir[u][f] dpre_dir[u]
             s.kr = KH / 2;
             s.tiles = TW;
-            const int ld = W + Dd;
-            s.w = [=](int f, int r, int g) -> int64_t { return dw.off + (int64_t)nh_feat16(r, g) * ld + f; };
+            const int ld = H + Dd;
+            s.w = [=](int f, int r, int g) -> int64_t {
+                return (nh_feat16(r, g) < H2 && f < H) ? dw.off + (int64_t)nh_feat16(r, g) * ld + f : -1;
+            };
         }
         {
             GemmSpec16& s = S.b_head;  // dh[f] = sum_u Wfeat[u][f] dpre_feat[u] + Walpha[0][f] d_alpha (k-step KH, group 0)
             s.kr = KH + 1;
             s.tiles = TW;
             s.w = [=](int f, int r, int g) -> int64_t {
-                if (r < KH) return fw.off + (int64_t)nh_feat16(r, g) * W + f;
+                if (f >= H) return -1;
+                if (r < KH) return nh_feat16(r, g) < H ? fw.off + (int64_t)nh_feat16(r, g) * H + f : -1;
                 return g == 0 ? aw.off + f : -1;
             };
         }
@@ -158,12 +172,14 @@ void build_specs16(const nerfhip_plan* p, Specs16& S) {
         GemmSpec16& s = S.f_head;  // fc_out
         s.kr = KH;
         s.tiles = 1;
-        s.w = [=](int o, int r, int g) -> int64_t { return o < 4 ? ow.off + (int64_t)o * W + nh_feat16(r, g) : -1; };
+        s.w = [=](int o, int r, int g) -> int64_t {
+            return (o < 4 && nh_feat16(r, g) < H) ? ow.off + (int64_t)o * H + nh_feat16(r, g) : -1;
+        };
         s.b = [=](int o) -> int64_t { return o < 4 ? ob.off + o : -1; };
         GemmSpec16& bt = S.b_head;  // ONE k-step: group g carries d(out row g)
         bt.kr = 1;
         bt.tiles = TW;
-        bt.w = [=](int f, int r, int g) -> int64_t { return r == 0 ? ow.off + (int64_t)g * W + f : -1; };
+        bt.w = [=](int f, int r, int g) -> int64_t { return (r == 0 && f < H) ? ow.off + (int64_t)g * H + f : -1; };
     }
 }
 
@@ -282,21 +298,22 @@ void build_layouts_and_jobs(nerfhip_plan* p) {
 #else
     p->wgrad_waves = W >= 256 ? 8 : 4;
 #endif
-    const int TW = W / 32;
+    // (tiles cover the kernel width W; only the rows / columns of the real H hidden units are unpacked)
+    const int TW = W / 32, H = p->H, H2 = H / 2;
     // layer1: dP_0 x X
-    add_job(p, G.P[0], TW, S.X, 0, 2, 0, W, p->t_layer1_w, 1, 0, p->Dx, p->t_layer1_b);
+    add_job(p, G.P[0], TW, S.X, 0, 2, 0, H, p->t_layer1_w, 1, 0, p->Dx, p->t_layer1_b);
     for (int i = 0; i < L - 1; ++i) {
-        add_job(p, G.P[i + 1], TW, S.H[i], 0, TW, 0, W, p->t_xyz_w[i], 0, 0, W, p->t_xyz_b[i]);
-        if (p->is_skip(i)) add_job(p, G.P[i + 1], TW, S.X, 0, 2, 0, W, p->t_xyz_w[i], 1, W, p->Dx, -1);
+        add_job(p, G.P[i + 1], TW, S.H[i], 0, TW, 0, H, p->t_xyz_w[i], 0, 0, H, p->t_xyz_b[i]);
+        if (p->is_skip(i)) add_job(p, G.P[i + 1], TW, S.X, 0, 2, 0, H, p->t_xyz_w[i], 1, H, p->Dx, -1);
     }
     if (p->view) {
-        add_job(p, G.PFEAT, TW, S.H[L - 1], 0, TW, 0, W, p->t_feat_w, 0, 0, W, p->t_feat_b);
-        add_job(p, G.POUT, 1, S.H[L - 1], 0, TW, 3, 4, p->t_alpha_w, 0, 0, W, p->t_alpha_b);
-        add_job(p, G.PDIR, TW / 2, S.FEAT, 0, TW, 0, W / 2, p->t_dir_w, 0, 0, W, p->t_dir_b);
-        add_job(p, G.PDIR, TW / 2, S.D, 0, 1, 0, W / 2, p->t_dir_w, 2, W, p->Dd, -1);
-        add_job(p, G.POUT, 1, S.DIRH, 0, TW / 2, 0, 3, p->t_rgb_w, 0, 0, W / 2, p->t_rgb_b);
+        add_job(p, G.PFEAT, TW, S.H[L - 1], 0, TW, 0, H, p->t_feat_w, 0, 0, H, p->t_feat_b);
+        add_job(p, G.POUT, 1, S.H[L - 1], 0, TW, 3, 4, p->t_alpha_w, 0, 0, H, p->t_alpha_b);
+        add_job(p, G.PDIR, TW / 2, S.FEAT, 0, TW, 0, H2, p->t_dir_w, 0, 0, H, p->t_dir_b);
+        add_job(p, G.PDIR, TW / 2, S.D, 0, 1, 0, H2, p->t_dir_w, 2, H, p->Dd, -1);
+        add_job(p, G.POUT, 1, S.DIRH, 0, TW / 2, 0, 3, p->t_rgb_w, 0, 0, H2, p->t_rgb_b);
     } else {
-        add_job(p, G.POUT, 1, S.H[L - 1], 0, TW, 0, 4, p->t_out_w, 0, 0, W, p->t_out_b);
+        add_job(p, G.POUT, 1, S.H[L - 1], 0, TW, 0, 4, p->t_out_w, 0, 0, H, p->t_out_b);
     }
 }
 
@@ -307,8 +324,8 @@ extern "C" nerfhip_plan_t nerfhip_plan_create(const nerfhip_model_cfg* cfg) {
         nh_set_error("plan_create: cfg is NULL");
         return nullptr;
     }
-    if (cfg->hidden_size != 128 && cfg->hidden_size != 256) {
-        nh_set_error("plan_create: hidden_size must be 128 or 256 (got %d)", cfg->hidden_size);
+    if (cfg->hidden_size < 2 || cfg->hidden_size > 256) {
+        nh_set_error("plan_create: hidden_size must be in [2,256] (got %d)", cfg->hidden_size);
         return nullptr;
     }
     if (cfg->num_layers < 1 || cfg->num_layers > NH_MAX_LAYERS) {
@@ -327,7 +344,8 @@ extern "C" nerfhip_plan_t nerfhip_plan_create(const nerfhip_model_cfg* cfg) {
     }
     nerfhip_plan* p = new nerfhip_plan();
     p->cfg = *cfg;
-    p->W = cfg->hidden_size;
+    p->H = cfg->hidden_size;
+    p->W = p->H <= 128 ? 128 : 256;  // the kernels exist for two widths; narrower models ride zero-padded (build_specs16)
     p->L = cfg->num_layers;
     p->skip = cfg->skip_connect_every;
     p->view = cfg->use_viewdirs ? 1 : 0;
@@ -340,7 +358,7 @@ extern "C" nerfhip_plan_t nerfhip_plan_create(const nerfhip_model_cfg* cfg) {
     }
     p->nparams = 0;
     p->freqs_set = false;
-    const int W = p->W, L = p->L;
+    const int W = p->H, L = p->L;  // (tensor shapes: the model's own hidden_size)
     // registration order of nerf/models.py:205-229
     p->t_layer1_w = add_tensor(p, "layer1.weight", W, p->Dx);
     p->t_layer1_b = add_tensor(p, "layer1.bias", W, 0);

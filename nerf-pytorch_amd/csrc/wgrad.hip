@@ -151,7 +151,9 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
     }
     const int ar = AR ? AR : jb.a_rows, br = BR ? BR : jb.b_rows;
     constexpr int NH_WG_STAGE_FLOATS = MD::STAGE;
-    const int g = (AR && BR) ? NH_WG_STAGE_FLOATS / (32 * (AR + BR)) : jb.g;
+    constexpr int G_FIXED = NH_WG_STAGE_FLOATS / (32 * ((AR && BR) ? AR + BR : 1));  // fixed row counts: tiles per stage
+    static_assert(G_FIXED >= 1, "a fixed-shape body must fit the mode's stage buffer");
+    const int g = (AR && BR) ? G_FIXED : jb.g;
     const int a_fl = 32 * ar, b_fl = 32 * br;
     const float* A0 = a.grad + (size_t)32 * (size_t)a.nt * (size_t)jb.a_prefix;
     const float* B0 = a.stash + (size_t)32 * (size_t)a.nt * (size_t)jb.b_prefix;
@@ -284,12 +286,16 @@ NH_DEVICE void wgrad_bias_dispatch(const WgradArgs& a, const JobDev& jb, int64_t
 template <class MD, int PO, int PI>
 NH_DEVICE void wgrad_dispatch(const WgradArgs& a, const JobDev& jb, int64_t t0, int64_t t1, int ow, int iw, int wave, int lane,
                               int64_t wg, bool active, float* lds) {
-    if (MD::NWV == 8 && PO == 4 && PI == 2 && jb.a_rows == 256 && jb.b_rows == 256)  // the 256x256 jobs: 91 % of the 8x256 FLOPs
-        wgrad_bias_dispatch<MD, PO, PI, 256, 256>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
-    else if (MD::NWV == 4 && PO == 2 && PI == 2 && jb.a_rows == 128 && jb.b_rows == 128)  // the 128x128 jobs of 128-wide nets
-        wgrad_bias_dispatch<MD, PO, PI, 128, 128>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
-    else
-        wgrad_bias_dispatch<MD, PO, PI, 0, 0>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
+    // fixed-shape bodies only where they are launched (and fit the mode's stage buffer)
+    if constexpr (MD::NWV == 8 && PO == 4 && PI == 2) {
+        if (jb.a_rows == 256 && jb.b_rows == 256)  // the 256x256 jobs: 91 % of the 8x256 FLOPs
+            return wgrad_bias_dispatch<MD, PO, PI, 256, 256>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
+    }
+    if constexpr (MD::NWV == 4 && PO == 2 && PI == 2) {
+        if (jb.a_rows == 128 && jb.b_rows == 128)  // the 128x128 jobs of 128-wide nets
+            return wgrad_bias_dispatch<MD, PO, PI, 128, 128>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
+    }
+    wgrad_bias_dispatch<MD, PO, PI, 0, 0>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
 }
 
 template <class MD>

@@ -55,12 +55,12 @@ class _PlanHandle:
 
 
 class _MlpFunction(torch.autograd.Function):
-    """y = FlexibleNeRFModel(x).  Gradients flow to the parameters only (x is an encoding: no gradient in the hot path).
-    The parameters are passed as individual autograd inputs (they alias the model's flat buffer, which is what the
+    """y = FlexibleNeRFModel(x).  Gradients flow to the parameters and -- when x requires grad (never in the render path:
+    x is an encoding of constants) -- to x.  The parameters are passed as individual autograd inputs (they alias the model's flat buffer, which is what the
     kernels read); backward hands each one its slice of the flat gradient -- no concatenation in either direction."""
 
     @staticmethod
-    def forward(ctx, model, x, need, *params):
+    def forward(ctx, model, x, need, need_x, *params):
         lib = L.get_lib()
         m = x.shape[0]
         out = torch.empty((m, 4), dtype=torch.float32, device=x.device)
@@ -73,6 +73,8 @@ class _MlpFunction(torch.autograd.Function):
             lib.mlp_fwd(model._plan, packed.data_ptr(), x.data_ptr(), m, out.data_ptr(),
                         stash.data_ptr() if stash is not None else None, st)
         ctx.model, ctx.m, ctx.stash, ctx.packed = model, m, stash, packed
+        # (the input gradient multiplies by the weights of this forward: keep a copy only if it will be asked for)
+        ctx.flat = model._flat.clone() if (need and need_x) else None
         return out
 
     @staticmethod
@@ -86,7 +88,12 @@ class _MlpFunction(torch.autograd.Function):
         with L.launch_on(g, scratch, gflat, ctx.packed, ctx.stash) as st:
             lib.mlp_bwd(model._plan, ctx.packed.data_ptr(), g.data_ptr(), m, ctx.stash.data_ptr(), scratch.data_ptr(), sb,
                         gflat.data_ptr(), st)
-        return (None, None, None) + model._split_flat(gflat)
+        gx = None
+        if ctx.flat is not None and ctx.needs_input_grad[1]:
+            gx = torch.empty((m, model.dim_xyz + model.dim_dir), dtype=torch.float32, device=g.device)
+            with L.launch_on(scratch, ctx.flat, gx) as st:
+                lib.mlp_bwd_input(model._plan, ctx.flat.data_ptr(), m, scratch.data_ptr(), gx.data_ptr(), st)
+        return (None, gx, None, None) + model._split_flat(gflat)
 
 
 class FlexibleNeRFModel(torch.nn.Module):
@@ -231,13 +238,12 @@ class FlexibleNeRFModel(torch.nn.Module):
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("FlexibleNeRFModel.forward needs CUDA (HIP) tensors: nerf_pytorch_amd has no CPU path")
-        if x.requires_grad:
-            raise RuntimeError("gradients w.r.t. the encoded input are not supported (the hot path never needs them)")
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1]).contiguous().float()
         if x2.shape[-1] != self.dim_xyz + self.dim_dir:
             raise RuntimeError("expected %d input columns, got %d" % (self.dim_xyz + self.dim_dir, x2.shape[-1]))
         params = self._ordered_params()
-        need = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-        y = _MlpFunction.apply(self, x2, need, *params)
+        need_x = torch.is_grad_enabled() and x2.requires_grad
+        need = need_x or (torch.is_grad_enabled() and any(p.requires_grad for p in params))
+        y = _MlpFunction.apply(self, x2, need, need_x, *params)
         return y.reshape(list(lead) + [4])

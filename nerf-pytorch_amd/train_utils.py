@@ -135,6 +135,9 @@ class _FusedRender(torch.autograd.Function):
 
 
 def _predict_fused(ray_batch, model_coarse, model_fine, opts):
+    if ray_batch.requires_grad and torch.is_grad_enabled():
+        raise RuntimeError("the fused render produces no gradients w.r.t. the rays (pose optimisation is outside this "
+                           "path); detach() the ray batch")
     rays = ray_batch.detach().contiguous().float()
     n = rays.shape[0]
     dev = rays.device

@@ -265,7 +265,8 @@ class Backend:
         self.lib.mlp_fwd(plan, self.ptr(packed), self.ptr(dx), m, self.ptr(out), self.p(stash), self.stream())
         return self.host(out), stash
 
-    def mlp_bwd(self, plan, packed, g_out, stash):
+    def mlp_bwd(self, plan, packed, g_out, stash, flat_for_input_grad=None):
+        """Flat parameter gradient; with `flat_for_input_grad` (the flat parameter vector) also d(loss)/d(x)."""
         m = g_out.shape[0]
         dg = self.dev(np.ascontiguousarray(g_out, np.float32))
         sb = self.lib.plan_bwd_scratch_bytes(plan, m)
@@ -273,7 +274,13 @@ class Backend:
         gp = self.empty((self.lib.plan_num_params(plan),))
         self.lib.mlp_bwd(plan, self.ptr(packed), self.ptr(dg), m, self.ptr(stash), self.ptr(scratch), sb, self.ptr(gp),
                          self.stream())
-        return self.host(gp)
+        if flat_for_input_grad is None:
+            return self.host(gp)
+        d = self.lib.plan_dim_xyz(plan) + self.lib.plan_dim_dir(plan)
+        gx = self.empty((m, d))
+        dflat = self.dev(np.ascontiguousarray(flat_for_input_grad, np.float32))
+        self.lib.mlp_bwd_input(plan, self.ptr(dflat), m, self.ptr(scratch), self.ptr(gx), self.stream())
+        return self.host(gp), self.host(gx)
 
     # -- fused render ---------------------------------------------------------------------------------------------------
     def render(self, plan_c, plan_f, packed_c, packed_f, rays, opt, rand=None, seed=0, ray_offset=0, training=False,

@@ -236,6 +236,11 @@ MLP_GEOMETRIES = {
     "noinput_linear": model_cfg(3, 128, 2, 5, 3, include_input_xyz=False, include_input_dir=False,
                                 log_sampling_xyz=False),
     "northstar8x256": model_cfg(8, 256, 4, 10, 4),
+    # hidden sizes between the two kernel widths ride zero-padded (plan.cpp build_specs16)
+    "narrow3x40": model_cfg(3, 40, 2, 4, 2),
+    "odd5x99_skip2": model_cfg(5, 99, 2, 10, 4),
+    "wide3x200_skip1": model_cfg(3, 200, 1, 6, 3),
+    "novw2x130": model_cfg(2, 130, 4, 5, 0, use_viewdirs=False),
 }
 
 
@@ -280,6 +285,23 @@ def case_mlp_backward(b, names=None, m=150):
             ref = v.grad.numpy()
             scale = float(np.abs(ref).max()) + 1e-12
             close(grads[k], ref, 2e-5 * scale + 1e-7, 2e-4, what="mlp bwd %s %s" % (name, k))
+        b.lib.plan_destroy(plan)
+
+
+def case_mlp_input_grad(b, names=None, m=150):
+    """d(loss)/d(x) of FlexibleNeRFModel.forward vs the oracle's autograd (x enters layer1, the skip layers, layers_dir)."""
+    for name in names or ("default4x128", "fern8x128_skip3_L6", "novw4x128", "odd5x99_skip2"):
+        cfg = MLP_GEOMETRIES[name]
+        plan, params, flat, packed = mlp_setup(b, cfg, seed=43)
+        dx, dd = O.model_dims(cfg)
+        gen = rng(44)
+        x = torch.randn(m, dx + dd, generator=gen).requires_grad_(True)
+        go = torch.randn(m, 4, generator=gen)
+        (O.mlp_forward(params, x, cfg) * go).sum().backward()
+        ref = x.grad.numpy()
+        _, stash = b.mlp_fwd(plan, packed, x.detach().numpy(), want_stash=True)
+        _, gx = b.mlp_bwd(plan, packed, go.numpy(), stash, flat_for_input_grad=flat)
+        close(gx, ref, 2e-5 * float(np.abs(ref).max()) + 1e-7, 2e-4, what="mlp input grad " + name)
         b.lib.plan_destroy(plan)
 
 

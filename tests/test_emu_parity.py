@@ -53,6 +53,17 @@ def test_mlp_extreme_geometries(emu):
     P.case_mlp_backward(emu, names=names, m=45)
 
 
+def test_mlp_padded_hidden_sizes(emu):
+    """hidden_size other than 128 / 256 (the reference constructor takes any: nerf/models.py:185-196), odd included."""
+    names = ("narrow3x40", "odd5x99_skip2", "wide3x200_skip1", "novw2x130")
+    P.case_mlp_forward(emu, names=names, m=37)
+    P.case_mlp_backward(emu, names=names, m=45)
+
+
+def test_mlp_input_gradient(emu):
+    P.case_mlp_input_grad(emu, m=45)
+
+
 def test_mlp_golden(emu):
     P.case_mlp_golden(emu)
 

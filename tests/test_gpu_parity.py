@@ -59,6 +59,17 @@ def test_mlp_forward_reference_goldens(gpu):
     P.case_mlp_golden(gpu)
 
 
+def test_mlp_padded_hidden_sizes(gpu):
+    names = ("narrow3x40", "odd5x99_skip2", "wide3x200_skip1", "novw2x130")
+    P.case_mlp_forward(gpu, names=names, m=700)
+    P.case_mlp_backward(gpu, names=names, m=1500)
+
+
+def test_mlp_input_gradient(gpu):
+    P.case_mlp_input_grad(gpu, names=("default4x128", "fern8x128_skip3_L6", "novw4x128", "odd5x99_skip2", "northstar8x256"),
+                          m=1500)
+
+
 def test_mlp_backward(gpu):
     P.case_mlp_backward(gpu, names=("default4x128", "deep8x128_skip4", "fern8x128_skip3_L6", "novw4x128",
                                     "northstar8x256"), m=1500)
@@ -246,10 +257,22 @@ def test_python_api_unfused_composition_and_model_autograd():
                                    encode_direction_fn=ed)
     for u, v in zip(a, b):
         P.close(u.cpu().numpy(), v.cpu().numpy(), 2e-5, 2e-5, what="generic vs fused")
-    # gradients w.r.t. the encoded inputs are not computed by the kernels: asking for them fails loudly
-    xin = torch.randn(8, m.dim_xyz + m.dim_dir, device=dev, requires_grad=True)
-    with pytest.raises(RuntimeError, match="encoded input are not supported"):
-        m(xin)
+    # gradients w.r.t. the encoded inputs (autograd gives them for nerf/models.py:233-256): parameters frozen or not
+    for freeze in (False, True):
+        m.zero_grad()
+        for q in m.parameters():
+            q.requires_grad_(not freeze)
+        xin = x.to(dev).requires_grad_(True)
+        (m(xin) * go.to(dev)).sum().backward()
+        xr = x.clone().requires_grad_(True)
+        (O.mlp_forward({k: v.detach() for k, v in p.items()}, xr, cfg) * go).sum().backward()
+        ref = xr.grad.numpy()
+        P.close(xin.grad.cpu().numpy(), ref, 2e-5 * float(np.abs(ref).max()) + 1e-7, 2e-4, what="input grad")
+        assert all((q.grad is None or not freeze) for q in m.parameters())
+    # the fused render does not differentiate its rays: asking for that fails loudly
+    rays_g = N.pack_rays(ro.to(dev), rd.to(dev), opts).requires_grad_(True)
+    with pytest.raises(RuntimeError, match="no gradients w.r.t. the rays"):
+        N.predict_and_render_radiance(rays_g, m, m, opts, encode_position_fn=ex, encode_direction_fn=ed)
 
 
 def test_pretrained_lego_checkpoint_renders_like_the_reference():

@@ -41,7 +41,7 @@ def test_library_exports_every_declared_symbol(lib):
 def test_errors_are_reported_not_thrown(lib):
     with pytest.raises(L.NerfHipError, match="bad arguments"):
         lib.cumprod_exclusive(None, 1, 4, None, None)
-    bad = L.ModelCfg(4, 100, 4, 10, 4, 1, 1, 1, 1, 1)
+    bad = L.ModelCfg(4, 300, 4, 10, 4, 1, 1, 1, 1, 1)
     assert not lib.plan_create(C.byref(bad))
     assert b"hidden_size" in lib.last_error()
     bad = L.ModelCfg(4, 128, 4, 11, 4, 1, 1, 1, 1, 1)

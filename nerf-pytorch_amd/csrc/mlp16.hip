@@ -126,10 +126,35 @@ struct Geo {
 // k-step 0, and its Post::NT row tiles (post.tile(t): one 16-byte store per lane) are spread evenly over the k-steps of
 // this layer, so that they drain under the MFMAs instead of sitting in front of a vmcnt(0) (CDNA4's vmcnt counts
 // stores too; the values stored are this layer's input registers, still live).
-template <int W, int KRA, int KRB, int T, class Post>
+// ReLU bit of value r among the n = 4T values of a layer, 32 per word: bit position inside word r >> 5 (see finish())
+NH_DEVICE constexpr int nh16_bitpos(int r, int n) { return ((n - 32 * (r >> 5)) < 32 ? (n - 32 * (r >> 5)) : 32) - 1 - (r & 31); }
+
+// `pre` finishes the INPUT registers just in time: group t (registers 4t..4t+3 of inA) is processed one group ahead of
+// the k-step that first consumes it, in the shadow of the MFMAs (GatePre: the ReLU gate of the data-gradient chain --
+// the epilogue between two layers is then a pure register renaming).
+struct NoPre {
+    static constexpr int N = 0;
+    NH_MEMBER void group(int) const {}
+};
+template <int N_>
+struct GatePre {
+    static constexpr int N = N_;  // groups of four registers
+    float* v;
+    unsigned m0, m1;  // stored ReLU bits of the 4 N values (finish(): value r at nh16_bitpos(r, 4 N) of word r >> 5)
+    NH_MEMBER void group(int t) const {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int r = 4 * t + c;
+            v[r] = nh_gate(v[r], (r >> 5) == 0 ? m0 : m1, nh16_bitpos(r, 4 * N));
+        }
+    }
+};
+
+template <int W, int KRA, int KRB, int T, class Post, class Pre = NoPre>
 NH_DEVICE void gemm16(Ctx& cx, const float* inA, const float* inB, int64_t img_off, int64_t next_off, int next_first,
-                      f32x4* acc, const Post& post) {
+                      f32x4* acc, const Post& post, const Pre& pre = Pre()) {
     constexpr int KR = KRA + KRB, NT = Post::NT;
+    static_assert(4 * Pre::N <= KRA, "pre-processed registers are inA's");
     using G = Geo<W, KR, T>;
     constexpr int TQ = G::TQ, KC = G::KC, NCH = G::NCH;
 #pragma unroll
@@ -173,6 +198,14 @@ NH_DEVICE void gemm16(Ctx& cx, const float* inA, const float* inB, int64_t img_o
                     for (int q = 0; q < TQ; ++q) a[(ks + 1) & 1][q] = wp[((ks + 1) * TQ + q) * 64];
                 }
                 const int r = c * KC + ks;
+                if constexpr (Pre::N > 0) {
+                    if (r == 0) {
+                        pre.group(0);
+                        if (Pre::N > 1) pre.group(1);
+                    } else if ((r & 3) == 0 && (r >> 2) + 1 < Pre::N) {
+                        pre.group((r >> 2) + 1);
+                    }
+                }
                 cx.issue(ks);  // one copy piece ...
                 if (r == 0) post.first();  // ... and this k-step's share of the previous layer's stores
                 if constexpr (NT > 0) {
@@ -200,7 +233,6 @@ NH_DEVICE void gemm16(Ctx& cx, const float* inA, const float* inB, int64_t img_o
 // epilogue: register r = 4t + c of the activation <- acc[t][c], gated by the stored ReLU mask (MASKED: data-gradient)
 // and/or ReLU'd (RELU: forward); BITS: collect [v > 0] of the n = 4T values, 32 per word, by shift-accumulation --
 // value r of a word lands at bit position (values in the word) - 1 - (r & 31) (no per-bit constants in registers).
-NH_DEVICE constexpr int nh16_bitpos(int r, int n) { return ((n - 32 * (r >> 5)) < 32 ? (n - 32 * (r >> 5)) : 32) - 1 - (r & 31); }
 template <int T, bool RELU, bool BITS, bool MASKED>
 NH_DEVICE void finish(const f32x4* acc, float* act, unsigned* bits_out, const unsigned* mbits) {
 #pragma unroll
@@ -544,16 +576,21 @@ NH_KERNEL void NH_LB(64 * Shape<W>::NW, 2) k_mlp_dgrad16(Dgrad16Args a) {
     const PoutPost store_pout{gref(a.gl.POUT, 32, 8 * g), g0 ? go0 : 0.f, g0 ? go1 : 0.f, g0 ? go2 : 0.f, g0 ? go3 : 0.f};
     const char* const mask_base = (const char*)((const unsigned*)(a.stash + (size_t)32 * (size_t)a.nt * (size_t)a.sl.total_rows) +
                                                 (size_t)((int64_t)blockIdx.x * NW + wave) * a.sl.n_masks * 128);
-    unsigned mb[2];
+    // ReLU masks: `mb` gates the d(pre-activation) currently held in registers -- applied by the NEXT gemm, group by
+    // group, just before it consumes / stores them (GatePre) -- while `mn` is fetched for the one being accumulated
+    unsigned mb[2], mn[2];
     auto get_mask = [&](int idx) {
         const unsigned* p = (const unsigned*)(mask_base + (size_t)idx * 512 + (size_t)((unsigned)lane * 8u));
-        mb[0] = p[0];
-        mb[1] = p[1];
+        mn[0] = p[0];
+        mn[1] = p[1];
     };
-    mb[0] = mb[1] = 0u;
+    auto ones = [&]() { mn[0] = mn[1] = 0xFFFFFFFFu; };  // a layer without activation: nothing is gated
+    auto rotate = [&]() { mb[0] = mn[0], mb[1] = mn[1]; };
+    mb[0] = mb[1] = mn[0] = mn[1] = 0xFFFFFFFFu;
     f32x4 acc[TW];
     float dp[KH];  // d(pre-activation) of the layer just finished = B operand of the next transposed GEMM
     unsigned nobits[2] = {0u, 0u};
+    const RowRef none{nullptr, 0u};
     // every gemm stores its own input rows (= the d(pre-activation) the previous one produced), one tile per few k-steps
     if (VIEW) {
         // one k-step: group g carries d(rgb raw)[g]
@@ -562,37 +599,50 @@ NH_KERNEL void NH_LB(64 * Shape<W>::NW, 2) k_mlp_dgrad16(Dgrad16Args a) {
         get_mask(L);  // DIRH
         float dpd[KH / 2];
         gemm16<W, 1, 0, TW / 2>(cx, d1, nullptr, po.b_rgb, po.b_dir, Geo<W, KH / 2, TW>::FIRST, acc, store_pout);
-        finish<TW / 2, false, false, true>(acc, dpd, nobits, mb);
+        finish<TW / 2, false, false, false>(acc, dpd, nobits, nobits);
+        rotate();
         get_mask(L - 1);  // FEAT
         gemm16<W, KH / 2, 0, TW>(cx, dpd, nullptr, po.b_dir, po.b_head, Geo<W, KH + 1, TW>::FIRST, acc,
-                                 RowsPost<TW / 2>{gref(a.gl.PDIR, W / 2, 4 * g), dpd, RowRef{nullptr, 0u}, 0u, 0u});
-        finish<TW, false, false, true>(acc, dp, nobits, mb);
-        if (L > 1) get_mask(L - 2);  // H_{L-1}
+                                 RowsPost<TW / 2>{gref(a.gl.PDIR, W / 2, 4 * g), dpd, none, 0u, 0u},
+                                 GatePre<TW / 2>{dpd, mb[0], mb[1]});
+        finish<TW, false, false, false>(acc, dp, nobits, nobits);
+        rotate();
+        if (L > 1)
+            get_mask(L - 2);  // H_{L-1}
+        else
+            ones();  // H_0 = layer1's output has no activation
         float da[1];
         da[0] = g == 0 ? go3 : 0.0f;  // d(sigma raw) enters through fc_alpha's row (k-step KH, group 0)
         gemm16<W, KH, 1, TW>(cx, dp, da, po.b_head, L > 1 ? po.b_xyz[L - 2] : 0, L > 1 ? Geo<W, KH, TW>::FIRST : 0, acc,
-                             RowsPost<TW>{gref(a.gl.PFEAT, W, 4 * g), dp, RowRef{nullptr, 0u}, 0u, 0u});
-        if (L <= 1) mb[0] = mb[1] = 0xFFFFFFFFu;  // H_0 = layer1's output has no activation: nothing is gated
-        finish<TW, false, false, true>(acc, dp, nobits, mb);
+                             RowsPost<TW>{gref(a.gl.PFEAT, W, 4 * g), dp, none, 0u, 0u}, GatePre<TW>{dp, mb[0], mb[1]});
+        finish<TW, false, false, false>(acc, dp, nobits, nobits);
+        rotate();
     } else {
         float d1[1];
         d1[0] = g == 0 ? go0 : (g == 1 ? go1 : (g == 2 ? go2 : go3));
-        if (L > 1) get_mask(L - 2);  // H_{L-1}
+        if (L > 1)
+            get_mask(L - 2);  // H_{L-1}
+        else
+            ones();
         gemm16<W, 1, 0, TW>(cx, d1, nullptr, po.b_head, L > 1 ? po.b_xyz[L - 2] : 0, L > 1 ? Geo<W, KH, TW>::FIRST : 0, acc,
                             store_pout);
-        if (L <= 1) mb[0] = mb[1] = 0xFFFFFFFFu;  // H_0 = layer1's output has no activation: nothing is gated
-        finish<TW, false, false, true>(acc, dp, nobits, mb);
+        finish<TW, false, false, false>(acc, dp, nobits, nobits);
+        rotate();
     }
-    // dp = d(pre-activation of H_{L-1}).  Walk down: dpre_{k-1} = relu'(H_{k-1}) * (W_{k-1}^T dpre_k);
-    // H_0 = layer1 output has no activation (models.py:238).
+    // dp = W^T d(pre-activation) for H_{L-1}, still to be gated by mb.  Walk down:
+    // dpre_{k-1} = relu'(H_{k-1}) * (W_{k-1}^T dpre_k); H_0 = layer1 output has no activation (models.py:238).
     for (int k = L - 1; k >= 1; --k) {
-        const bool masked = k - 1 >= 1;
-        if (masked) get_mask(k - 2);  // H_{k-1}
+        if (k - 1 >= 1)
+            get_mask(k - 2);  // H_{k-1}
+        else
+            ones();
         gemm16<W, KH, 0, TW>(cx, dp, nullptr, po.b_xyz[k - 1], k >= 2 ? po.b_xyz[k - 2] : 0,
-                             k >= 2 ? Geo<W, KH, TW>::FIRST : 0, acc, RowsPost<TW>{gref(a.gl.P[k], W, 4 * g), dp, RowRef{nullptr, 0u}, 0u, 0u});
-        if (!masked) mb[0] = mb[1] = 0xFFFFFFFFu;
-        finish<TW, false, false, true>(acc, dp, nobits, mb);
+                             k >= 2 ? Geo<W, KH, TW>::FIRST : 0, acc, RowsPost<TW>{gref(a.gl.P[k], W, 4 * g), dp, none, 0u, 0u},
+                             GatePre<TW>{dp, mb[0], mb[1]});
+        finish<TW, false, false, false>(acc, dp, nobits, nobits);
+        rotate();
     }
+    // (mb is all ones here: d(pre-activation) of layer1 needs no gate)
     store_rows<TW>(gref(a.gl.P[0], W, 4 * g), dp);
 #ifdef NH_PHASE_TIMING
     NH16_PH(4);

@@ -131,7 +131,8 @@ NH_DEVICE unsigned nh_pos_bit(float v) {
     return u < 1u ? u : 1u;
 }
 NH_DEVICE float nh_gate(float v, unsigned word, int k) {
-    const int m = ((int)(word << (31 - k))) >> 31;
+    int m = ((int)(word << (31 - k))) >> 31;
+    asm("" : "+v"(m));  // (keeps the two-instruction form: otherwise the AND is rewritten into and + compare + select)
     int i;
     memcpy(&i, &v, 4);
     i &= m;

@@ -153,13 +153,12 @@ NH_KERNEL void k_pack_rays(const float* __restrict__ ro, const float* __restrict
     if (i >= n) return;
     float o[3] = {ro[i * 3], ro[i * 3 + 1], ro[i * 3 + 2]};
     float d[3] = {rd[i * 3], rd[i * 3 + 1], rd[i * 3 + 2]};
-    float v[3];
     if (vsrc) {
-        v[0] = vsrc[i * 3];
-        v[1] = vsrc[i * 3 + 1];
-        v[2] = vsrc[i * 3 + 2];
+        const float v[3] = {vsrc[i * 3], vsrc[i * 3 + 1], vsrc[i * 3 + 2]};
+        nh_write_ray_row(rays + i * 11, o, d, near, far, v);
+    } else {
+        nh_write_ray_row(rays + i * 8, o, d, near, far, nullptr);
     }
-    nh_write_ray_row(rays + i * (vsrc ? 11 : 8), o, d, near, far, vsrc ? v : nullptr);
 }
 
 extern "C" int nerfhip_pack_rays(const float* rays_o, const float* rays_d, const float* viewdir_src, float near,

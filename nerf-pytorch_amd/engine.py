@@ -11,7 +11,7 @@ the coarse net's backward needs nothing from the fine pass, so it runs next to t
 tails of those launches), and with G > 1 ranks the fine net's gradient all-reduce (RCCL) is in flight while the coarse
 backward still computes.  `overlap=False` gives the single-stream order (coarse+fine forward, loss, fine backward,
 coarse backward) with the same collectives -- in both orders the fine net's all-reduce is launched before the coarse
-backward.  Default: two streams for nets narrower than 256 (measured +2.5 %), one stream for 256-wide nets (-0.4 %).
+backward.  Default: two streams for nets narrower than 256 (measured +3.5 %), one stream for 256-wide nets (-0.4 %).
 
 Data parallelism (BASELINE config 3): one process per GPU, weights replicated, each rank renders its own N/G rays;
 the only exchange is the all-reduce (sum) of the 2 x 595,844-float gradient (one collective per net), scaled by 1/G
@@ -59,7 +59,7 @@ class TrainEngine:
         self.loss = torch.zeros(3, dtype=torch.float32, device=self.dev)
         self._loss_c = torch.zeros(3, dtype=torch.float32, device=self.dev)
         self._loss_f = torch.zeros(3, dtype=torch.float32, device=self.dev)
-        # two-stream graph: measured on MI355X (profiles/r02_overlap_ab.txt) +2.5 % for 128-wide nets (the short kernels'
+        # two-stream graph: measured on MI355X (profiles/r02_overlap_ab.txt) +3.5 % for 128-wide nets (the short kernels'
         # tails fill), -0.4 % for 256-wide nets (every launch already fills the chip for milliseconds) -> default by width
         self.overlap = (model_coarse.cfg["hidden_size"] < 256) if overlap is None else bool(overlap)
         self._side = None       # second HIP stream of this device (created on first use)

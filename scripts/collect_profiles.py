@@ -28,13 +28,22 @@ def kernel_stats(src_dir, dst):
     if not os.path.exists(path):
         return
     rows = list(csv.DictReader(open(path)))
+    # the same trace without the warm-up launches (first 3 of 23 steps): what bench.py's own event timing covers
+    per = {}
+    for r in csv.DictReader(open(os.path.join(G, src_dir, "bench_kernel_trace.csv"))):
+        per.setdefault(r["Kernel_Name"], []).append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    timed = {}
+    for k, v in per.items():
+        v.sort()
+        keep = v[len(v) * 3 // 23:] if len(v) >= 23 else v
+        timed[k] = sum(d for _, d in keep) / len(keep)
     with open(os.path.join(P, "%s_%s" % (tag, dst)), "w") as f:
         f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline%s   (20 steps after 3 warm-up: the same run length as the bench line)\n" %
                 (" --hidden 128 --layers 4" if "128" in src_dir else ""))
-        f.write("%-64s %8s %14s %12s %8s\n" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
+        f.write("%-64s %8s %14s %12s %8s %16s\n" % ("kernel", "calls", "total_ns", "avg_ns", "pct", "avg_ns_20_timed"))
         for r in rows:
-            f.write("%-64s %8s %14s %12.0f %8s\n" % (r["Name"][:64], r["Calls"], r["TotalDurationNs"], float(r["AverageNs"]),
-                                                    r["Percentage"]))
+            f.write("%-64s %8s %14s %12.0f %8s %16.0f\n" % (r["Name"][:64], r["Calls"], r["TotalDurationNs"],
+                                                           float(r["AverageNs"]), r["Percentage"], timed.get(r["Name"], 0.0)))
 
 
 for src, dst in (("bench.log", "bench_line.json"), ("bench_4x128.log", "bench_line_4x128.json")):

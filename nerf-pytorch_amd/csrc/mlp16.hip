@@ -129,6 +129,16 @@ struct Geo {
 // ReLU bit of value r among the n = 4T values of a layer, 32 per word: bit position inside word r >> 5 (see finish())
 NH_DEVICE constexpr int nh16_bitpos(int r, int n) { return ((n - 32 * (r >> 5)) < 32 ? (n - 32 * (r >> 5)) : 32) - 1 - (r & 31); }
 
+// k-step at which row tile t of the previous layer is stored.  When the tiles divide evenly over the chunks, a chunk's
+// tiles go out in its SECOND half: its first half carries the copy pieces of the next chunk, and a weight copy queued
+// behind stash stores is what the store stream really costs (scripts/loop_mock.hip F_DMA_ST*, profiles/r02_loop_mock.txt:
+// copy alone 98.0 % of the pipe, stores alone 97.6 %, both 93.2 %; stores late in the chunk 94.4 %).
+constexpr int nh16_store_kstep(int t, int nt, int kr, int kc, int nch) {
+    if (nt % nch != 0 || kr != kc * nch || (kc / 2) < (nt / nch)) return (t * kr) / nt;
+    const int per = nt / nch, c = t / per, i = t % per;
+    return c * kc + kc / 2 + (i * (kc / 2)) / per;
+}
+
 // `pre` finishes the INPUT registers just in time: group t (registers 4t..4t+3 of inA) is processed one group ahead of
 // the k-step that first consumes it, in the shadow of the MFMAs (GatePre: the ReLU gate of the data-gradient chain --
 // the epilogue between two layers is then a pure register renaming).
@@ -211,7 +221,7 @@ NH_DEVICE void gemm16(Ctx& cx, const float* inA, const float* inB, int64_t img_o
                 if constexpr (NT > 0) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
-                        if ((t * KR) / NT == r) post.tile(t);
+                        if (nh16_store_kstep(t, NT, KR, KC, NCH) == r) post.tile(t);
                 }
                 nh_sched_fence();  // reads, copy and stores of this k-step are issued before its MFMAs
                 const float b = r < KRA ? inA[r < KRA ? r : 0] : inB[r >= KRA ? r - KRA : 0];

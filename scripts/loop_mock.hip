@@ -59,11 +59,28 @@ enum {
     F_DMA = 8,       // F_BASE + the chunk copy traffic (4 LDS-DMA pieces per wave and chunk into the other buffer)
     F_MIDBAR_DMA = 9,// F_MIDBAR + copy traffic into a third buffer
     F_AHEAD2 = 10,   // reads two k-steps ahead
+    // F_DMA + the stash stores of the training forward: one 16-byte-per-lane store per wave every 4 k-steps, 128 KB per
+    // workgroup and layer, a fresh region per layer (2 GB per launch)
+    F_DMA_ST = 11,   //   product pattern: lane (sample j, group g) -> 16 B at sample*1 KB + (16 t + 4 g)*4: 16 segments of 64 B
+    F_DMA_STC = 12,  //   the same bytes as ONE contiguous 1 KB block per instruction
+    F_DMA_STNT = 13, //   product pattern, non-temporal
+    F_DMA_ST1 = 14,  //   product pattern, but all layers of a workgroup overwrite ONE 128 KB region (no fresh HBM pages)
+    F_DMA_ST_V4 = 15,  // product pattern; the chunk hand-over waits with vmcnt(4): for the copy pieces (all issued before the
+                       // chunk's four stores), not for the write acknowledgements of those stores
+    F_DMA_ST_LATE = 16,  // F_DMA_ST_V4 with the four stores at k-steps 8, 10, 12, 14
+    F_ST_NODMA = 17,     // product stores, no copy traffic (wait + barrier kept)
+    F_DMA_ST_PAIR = 18,  // two adjacent tiles (one full 128-byte line per sample row) stored back to back every 8 k-steps
+    F_DMA_ST_SC01 = 19,  // product pattern, stores with sc0 sc1 (system scope: write-through)
+    F_DMA_ST_SC1 = 20,   // ... sc1
+    F_DMA_ST_SC01NT = 21,  // ... sc0 sc1 nt
+    F_MIDBAR_DMA_ST = 22,  // F_MIDBAR_DMA (three-buffer ring) + product stores
 };
+constexpr bool f_is_dma(int v) { return v == F_DMA || (v >= F_DMA_ST && v != F_MIDBAR_DMA_ST); }
+constexpr bool f_is_mid(int v) { return v == F_MIDBAR || v == F_MIDBAR_DMA || v == F_MIDBAR_DMA_ST; }
 
 template <int VAR, int KC, int NW>
 __global__ __launch_bounds__(64 * NW, NW / 4) void kF(const float* __restrict__ gsrc, float* out, unsigned long long* cyc,
-                                                     int nchunks) {
+                                                     int nchunks, float* big) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int TQ = 4, T = 16;
     constexpr int CH = KC * TQ * 256;  // floats per chunk buffer
@@ -88,12 +105,15 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void kF(const float* __restrict__ 
     for (int layer = 0; layer < nchunks / NCH; ++layer) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        if (VAR == F_BASE || VAR == F_ILV || VAR == F_PRIO || VAR == F_AACC || VAR == F_AOPS || VAR == F_DMA ||
+        if (VAR == F_BASE || VAR == F_ILV || VAR == F_PRIO || VAR == F_AACC || VAR == F_AOPS || f_is_dma(VAR) ||
             VAR == F_AHEAD2) {
-            if (VAR == F_DMA) wait_vm0();
+            if (VAR == F_DMA_ST_V4 || VAR == F_DMA_ST_LATE)
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (f_is_dma(VAR))
+                wait_vm0();
             __builtin_amdgcn_s_barrier();
         }
-        if (VAR == F_DMA) {
+        if (f_is_dma(VAR) && VAR != F_ST_NODMA) {
             const int nb = buf ^ 1;
             for (int q = wave; q < KC * TQ; q += NW) dma16(src, lane * 16, (c & 3) * 65536 + q * 1024, lbase + nb * CH * 4 + q * 1024);
         }
@@ -151,6 +171,41 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void kF(const float* __restrict__ 
 #pragma unroll
                     for (int q = 0; q < TQ; ++q) a[(ks + AH) % 3][q] = wp[((ks + AH) * TQ + q) * 64];
                 }
+                if constexpr (VAR >= F_DMA_ST) {
+                    const int r = c * KC + ks;
+                    if constexpr (VAR == F_DMA_ST_PAIR) {
+                        if ((r & 7) == 0) {
+                            const int j = lane & 15, g = lane >> 4;
+                            char* blk = (char*)big + ((size_t)layer * gridDim.x + blockIdx.x) * (128u * 1024u);
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                const int t = (r >> 2) + u;
+                                char* p = blk + ((wave >> 1) * 32 + 16 * (wave & 1) + j) * 1024 + (16 * t + 4 * g) * 4;
+                                *(f32x4*)p = f32x4{act[4 * t], act[4 * t + 1], act[4 * t + 2], act[4 * t + 3]};
+                            }
+                        }
+                    }
+                    const bool now = VAR == F_DMA_ST_PAIR ? false : VAR == F_DMA_ST_LATE ? (ks >= KC / 2 && (ks & 1) == 0) : (r & 3) == 0;
+                    if (now) {
+                        const int t = VAR == F_DMA_ST_LATE ? (c * (KC / 4) + (ks - KC / 2) / 2) & 15 : r >> 2;
+                        const int j = lane & 15, g = lane >> 4;
+                        const size_t region = VAR == F_DMA_ST1 ? (size_t)blockIdx.x : (size_t)layer * gridDim.x + blockIdx.x;
+                        char* blk = (char*)big + region * (128u * 1024u);
+                        char* p = VAR == F_DMA_STC ? blk + (t * NW + wave) * 1024 + lane * 16
+                                                   : blk + ((wave >> 1) * 32 + 16 * (wave & 1) + j) * 1024 + (16 * t + 4 * g) * 4;
+                        f32x4 v = {act[4 * t], act[4 * t + 1], act[4 * t + 2], act[4 * t + 3]};
+                        if (VAR == F_DMA_STNT)
+                            __builtin_nontemporal_store(v, (f32x4*)p);
+                        else if (VAR == F_DMA_ST_SC01)
+                            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+                        else if (VAR == F_DMA_ST_SC1)
+                            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+                        else if (VAR == F_DMA_ST_SC01NT)
+                            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
+                        else
+                            *(f32x4*)p = v;
+                    }
+                }
                 FENCE();
                 const float b = act[(c * KC + ks) & 63];
 #pragma unroll
@@ -167,11 +222,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void kF(const float* __restrict__ 
                         FENCE();
                     }
                 }
-                if ((VAR == F_MIDBAR || VAR == F_MIDBAR_DMA) && ks == KC / 2 - 1) {
+                if (f_is_mid(VAR) && ks == KC / 2 - 1) {
                     FENCE();
-                    if (VAR == F_MIDBAR_DMA) wait_vm0();
+                    if (VAR == F_MIDBAR_DMA || VAR == F_MIDBAR_DMA_ST) wait_vm0();
                     __builtin_amdgcn_s_barrier();
-                    if (VAR == F_MIDBAR_DMA) {
+                    if (VAR == F_MIDBAR_DMA || VAR == F_MIDBAR_DMA_ST) {
                         const int nb = (buf + 2) % 3;
                         for (int q = wave; q < KC * TQ; q += NW)
                             dma16(src, lane * 16, (c & 3) * 65536 + q * 1024, lbase + nb * CH * 4 + q * 1024);
@@ -180,7 +235,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void kF(const float* __restrict__ 
                 }
             }
         }
-        if (VAR == F_MIDBAR || VAR == F_MIDBAR_DMA)
+        if (f_is_mid(VAR))
             buf = (buf + 1) % 3;
         else
             buf ^= 1;
@@ -212,7 +267,8 @@ enum {
 };
 
 template <int VAR, int KS>
-__global__ __launch_bounds__(512, 2) void kW(const float* __restrict__ gsrc, float* out, unsigned long long* cyc, int nstages) {
+__global__ __launch_bounds__(512, 2) void kW(const float* __restrict__ gsrc, float* out, unsigned long long* cyc, int nstages,
+                                             float* /*big: kF's store target*/) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int PO = 4, PI = 2, ROWS = 512, ST = 2 * KS * ROWS;  // floats per stage: 2*KS samples x (256 + 256) rows
     constexpr int NPIECE = ST / 256;                                // 1-KiB copy pieces per stage
@@ -406,7 +462,7 @@ __global__ __launch_bounds__(512, 2) void kW(const float* __restrict__ gsrc, flo
     } while (0)
 
 struct Bufs {
-    float *src, *out;
+    float *src, *out, *big;
     unsigned long long* cyc;
 };
 
@@ -423,7 +479,7 @@ void run(const char* name, K kern, int threads, int lds_bytes, int loops, double
     std::vector<unsigned long long> h(grid * nw);
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds_bytes, 0, b.src, b.out, b.cyc, loops);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds_bytes, 0, b.src, b.out, b.cyc, loops, b.big);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         CK(hipGetLastError());
@@ -453,6 +509,7 @@ int main(int argc, char** argv) {
     CK(hipMemset(b.src, 0, 4 << 20));
     CK(hipMalloc(&b.out, 1024 * 512 * 4));
     CK(hipMalloc(&b.cyc, 1024 * 16 * 8));
+    CK(hipMalloc(&b.big, (size_t)1024 * 64 * 128 * 1024));  // 8 GB: 1024 workgroups x 64 layers x 128 KB
     const char* only = argc > 1 ? argv[1] : "";
     // F: KC = 8 -> 3 buffers of 32 KB (+ force one workgroup per CU with a 100 KB request); per chunk and wave 128 MFMAs
     {
@@ -473,12 +530,25 @@ int main(int argc, char** argv) {
         RF(F_AHEAD2);
         RF(F_DMA);
         RF(F_MIDBAR_DMA);
+        RF(F_MIDBAR_DMA_ST);
+        RF(F_DMA_ST);
 #undef RF
         // chunks of 16 k-steps (two 64 KB buffers): half the barriers
         const int nch16 = 256;
         if (!*only || strstr("F16", only)) {
             run("F_BASE KC=16", kF<F_BASE, 16, 8>, 512, 140 * 1024, nch16, cyc, 2, fl, b);
             run("F_DMA KC=16", kF<F_DMA, 16, 8>, 512, 140 * 1024, nch16, cyc, 2, fl, b);
+            run("F_DMA_ST KC=16 (product stores)", kF<F_DMA_ST, 16, 8>, 512, 140 * 1024, nch16, cyc, 2, fl, b);
+            run("F_DMA_STC KC=16 (contiguous 1 KB)", kF<F_DMA_STC, 16, 8>, 512, 140 * 1024, nch16, cyc, 2, fl, b);
+            run("F_DMA_STNT KC=16 (non-temporal)", kF<F_DMA_STNT, 16, 8>, 512, 140 * 1024, nch16, cyc, 2, fl, b);
+            run("F_DMA_ST1 KC=16 (one region)", kF<F_DMA_ST1, 16, 8>, 512, 140 * 1024, nch16, cyc, 2, fl, b);
+            run("F_DMA_ST_V4 KC=16 (wait vmcnt(4))", kF<F_DMA_ST_V4, 16, 8>, 512, 140 * 1024, nch16, cyc, 2, fl, b);
+            run("F_DMA_ST_LATE KC=16 (stores late)", kF<F_DMA_ST_LATE, 16, 8>, 512, 140 * 1024, nch16, cyc, 2, fl, b);
+            run("F_ST_NODMA KC=16 (stores, no copy)", kF<F_ST_NODMA, 16, 8>, 512, 140 * 1024, nch16, cyc, 2, fl, b);
+            run("F_DMA_ST_PAIR KC=16 (full lines)", kF<F_DMA_ST_PAIR, 16, 8>, 512, 140 * 1024, nch16, cyc, 2, fl, b);
+            run("F_DMA_ST_SC01 KC=16", kF<F_DMA_ST_SC01, 16, 8>, 512, 140 * 1024, nch16, cyc, 2, fl, b);
+            run("F_DMA_ST_SC1 KC=16", kF<F_DMA_ST_SC1, 16, 8>, 512, 140 * 1024, nch16, cyc, 2, fl, b);
+            run("F_DMA_ST_SC01NT KC=16", kF<F_DMA_ST_SC01NT, 16, 8>, 512, 140 * 1024, nch16, cyc, 2, fl, b);
         }
         // one wave per SIMD (4-wave workgroup, one per CU)
         if (!*only || strstr("F4W", only)) {

@@ -129,15 +129,26 @@ struct Geo {
 // ReLU bit of value r among the n = 4T values of a layer, 32 per word: bit position inside word r >> 5 (see finish())
 NH_DEVICE constexpr int nh16_bitpos(int r, int n) { return ((n - 32 * (r >> 5)) < 32 ? (n - 32 * (r >> 5)) : 32) - 1 - (r & 31); }
 
-// k-step at which row tile t of the previous layer is stored.  When the tiles divide evenly over the chunks, a chunk's
-// tiles go out in its SECOND half: its first half carries the copy pieces of the next chunk, and a weight copy queued
-// behind stash stores is what the store stream really costs (scripts/loop_mock.hip F_DMA_ST*, profiles/r02_loop_mock.txt:
-// copy alone 98.0 % of the pipe, stores alone 97.6 %, both 93.2 %; stores late in the chunk 94.4 %).
+// k-step at which row tile t (of nt) of the previous layer is stored.  The tiles are dealt evenly to the chunks and go
+// out in the SECOND half of their chunk: its first half carries the copy pieces of the next chunk (one per k-step), and
+// a weight copy queued behind stash stores is what the store stream really costs (scripts/loop_mock.hip F_DMA_ST*,
+// profiles/r02_loop_mock.txt: copy alone 98.0 % of the pipe, stores alone 97.6 %, both with the stores spread over the
+// chunk 93.2 %, copy pieces in the first half and stores in the second 97.8 %).
 constexpr int nh16_store_kstep(int t, int nt, int kr, int kc, int nch) {
-    if (nt % nch != 0 || kr != kc * nch || (kc / 2) < (nt / nch)) return (t * kr) / nt;
-    const int per = nt / nch, c = t / per, i = t % per;
-    return c * kc + kc / 2 + (i * (kc / 2)) / per;
+    if (kr != kc * nch) return (t * kr) / nt;  // (ragged chunks do not occur: nh16_kc)
+    int c = 0;
+    while (((c + 1) * nt) / nch <= t) ++c;  // chunk c holds tiles [c nt / nch, (c + 1) nt / nch)
+    const int b0 = (c * nt) / nch, per = ((c + 1) * nt) / nch - b0, half = kc / 2, room = kc - half;
+    return c * kc + half + ((t - b0) * room) / per;
 }
+// (GatePre processes group t at k-step 4 (t - 1), groups 0 and 1 at k-step 0: tile t must not be stored earlier)
+constexpr bool nh16_stores_follow_pre(int nt, int kr, int kc, int nch) {
+    for (int t = 0; t < nt; ++t)
+        if (nh16_store_kstep(t, nt, kr, kc, nch) < (t <= 1 ? 0 : 4 * (t - 1))) return false;
+    return true;
+}
+// the one-off stores of a layer (ReLU mask, encoding slots) go with the same k-step of its first chunk
+constexpr int nh16_first_kstep(int kc) { return kc / 2; }
 
 // `pre` finishes the INPUT registers just in time: group t (registers 4t..4t+3 of inA) is processed one group ahead of
 // the k-step that first consumes it, in the shadow of the MFMAs (GatePre: the ReLU gate of the data-gradient chain --
@@ -165,6 +176,8 @@ NH_DEVICE void gemm16(Ctx& cx, const float* inA, const float* inB, int64_t img_o
                       f32x4* acc, const Post& post, const Pre& pre = Pre()) {
     constexpr int KR = KRA + KRB, NT = Post::NT;
     static_assert(4 * Pre::N <= KRA, "pre-processed registers are inA's");
+    static_assert(Pre::N == 0 || nh16_stores_follow_pre(NT, KR, Geo<W, KR, T>::KC, Geo<W, KR, T>::NCH),
+                  "a row tile is stored before its registers were pre-processed");
     using G = Geo<W, KR, T>;
     constexpr int TQ = G::TQ, KC = G::KC, NCH = G::NCH;
 #pragma unroll
@@ -217,7 +230,7 @@ NH_DEVICE void gemm16(Ctx& cx, const float* inA, const float* inB, int64_t img_o
                     }
                 }
                 cx.issue(ks);  // one copy piece ...
-                if (r == 0) post.first();  // ... and this k-step's share of the previous layer's stores
+                if (r == nh16_first_kstep(KC)) post.first();  // ... and this k-step's share of the previous layer's stores
                 if constexpr (NT > 0) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t)

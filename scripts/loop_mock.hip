@@ -74,6 +74,9 @@ enum {
     F_DMA_ST_SC1 = 20,   // ... sc1
     F_DMA_ST_SC01NT = 21,  // ... sc0 sc1 nt
     F_MIDBAR_DMA_ST = 22,  // F_MIDBAR_DMA (three-buffer ring) + product stores
+    F_DMA_ST_END = 23,     // the four stores at k-steps 12..15
+    F_DMA_ST_MID = 24,     // the four stores at k-steps 4, 6, 8, 10
+    F_DMA_ST_LATE_SPREAD = 25,  // stores at 8, 10, 12, 14; the copy pieces one per k-step (k-steps 0..7) instead of a burst
 };
 constexpr bool f_is_dma(int v) { return v == F_DMA || (v >= F_DMA_ST && v != F_MIDBAR_DMA_ST); }
 constexpr bool f_is_mid(int v) { return v == F_MIDBAR || v == F_MIDBAR_DMA || v == F_MIDBAR_DMA_ST; }
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void kF(const float* __restrict__ 
                 wait_vm0();
             __builtin_amdgcn_s_barrier();
         }
-        if (f_is_dma(VAR) && VAR != F_ST_NODMA) {
+        if (f_is_dma(VAR) && VAR != F_ST_NODMA && VAR != F_DMA_ST_LATE_SPREAD) {
             const int nb = buf ^ 1;
             for (int q = wave; q < KC * TQ; q += NW) dma16(src, lane * 16, (c & 3) * 65536 + q * 1024, lbase + nb * CH * 4 + q * 1024);
         }
@@ -171,6 +174,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void kF(const float* __restrict__ 
 #pragma unroll
                     for (int q = 0; q < TQ; ++q) a[(ks + AH) % 3][q] = wp[((ks + AH) * TQ + q) * 64];
                 }
+                if constexpr (VAR == F_DMA_ST_LATE_SPREAD) {
+                    const int q = wave + ks * NW;
+                    if (q < KC * TQ) dma16(src, lane * 16, (c & 3) * 65536 + q * 1024, lbase + (buf ^ 1) * CH * 4 + q * 1024);
+                }
                 if constexpr (VAR >= F_DMA_ST) {
                     const int r = c * KC + ks;
                     if constexpr (VAR == F_DMA_ST_PAIR) {
@@ -185,9 +192,17 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void kF(const float* __restrict__ 
                             }
                         }
                     }
-                    const bool now = VAR == F_DMA_ST_PAIR ? false : VAR == F_DMA_ST_LATE ? (ks >= KC / 2 && (ks & 1) == 0) : (r & 3) == 0;
+                    constexpr bool late = VAR == F_DMA_ST_LATE || VAR == F_DMA_ST_LATE_SPREAD;
+                    const bool now = VAR == F_DMA_ST_PAIR  ? false
+                                     : late                ? (ks >= KC / 2 && (ks & 1) == 0)
+                                     : VAR == F_DMA_ST_END ? ks >= KC - 4
+                                     : VAR == F_DMA_ST_MID ? (ks >= 4 && ks <= 10 && (ks & 1) == 0)
+                                                           : (r & 3) == 0;
                     if (now) {
-                        const int t = VAR == F_DMA_ST_LATE ? (c * (KC / 4) + (ks - KC / 2) / 2) & 15 : r >> 2;
+                        const int t = late                  ? (c * (KC / 4) + (ks - KC / 2) / 2) & 15
+                                      : VAR == F_DMA_ST_END ? (c * 4 + ks - (KC - 4)) & 15
+                                      : VAR == F_DMA_ST_MID ? (c * 4 + (ks - 4) / 2) & 15
+                                                            : r >> 2;
                         const int j = lane & 15, g = lane >> 4;
                         const size_t region = VAR == F_DMA_ST1 ? (size_t)blockIdx.x : (size_t)layer * gridDim.x + blockIdx.x;
                         char* blk = (char*)big + region * (128u * 1024u);
@@ -547,8 +562,9 @@ int main(int argc, char** argv) {
             run("F_ST_NODMA KC=16 (stores, no copy)", kF<F_ST_NODMA, 16, 8>, 512, 140 * 1024, nch16, cyc, 2, fl, b);
             run("F_DMA_ST_PAIR KC=16 (full lines)", kF<F_DMA_ST_PAIR, 16, 8>, 512, 140 * 1024, nch16, cyc, 2, fl, b);
             run("F_DMA_ST_SC01 KC=16", kF<F_DMA_ST_SC01, 16, 8>, 512, 140 * 1024, nch16, cyc, 2, fl, b);
-            run("F_DMA_ST_SC1 KC=16", kF<F_DMA_ST_SC1, 16, 8>, 512, 140 * 1024, nch16, cyc, 2, fl, b);
-            run("F_DMA_ST_SC01NT KC=16", kF<F_DMA_ST_SC01NT, 16, 8>, 512, 140 * 1024, nch16, cyc, 2, fl, b);
+            run("F_DMA_ST_END KC=16 (stores 12..15)", kF<F_DMA_ST_END, 16, 8>, 512, 140 * 1024, nch16, cyc, 2, fl, b);
+            run("F_DMA_ST_MID KC=16 (stores 4..10)", kF<F_DMA_ST_MID, 16, 8>, 512, 140 * 1024, nch16, cyc, 2, fl, b);
+            run("F_DMA_ST_LATE_SPREAD KC=16", kF<F_DMA_ST_LATE_SPREAD, 16, 8>, 512, 140 * 1024, nch16, cyc, 2, fl, b);
         }
         // one wave per SIMD (4-wave workgroup, one per CU)
         if (!*only || strstr("F4W", only)) {

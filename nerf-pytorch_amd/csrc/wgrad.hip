@@ -46,12 +46,12 @@ struct WMode {
 };
 using WModeWide = WMode<8, 16384>;
 using WModeNarrow = WMode<4, 8192>;
-// floats of split-K partial per workgroup: 64 output tiles x 16 regs x 64 lanes, + 512 bias partials
-// (+ 128 for the per-wave timeline records of the instrumented build)
+// split-K partial of one workgroup: [accumulator tiles of the largest job][16 regs][64 lanes], then 512 bias partials
+// (then 128 floats of per-wave timeline records in the instrumented build); WgradArgs::part_bias / part_stride
 #ifdef NH_WGRAD_TIMELINE
-constexpr int NH_PART = 65536 + 512 + 128;
+constexpr int NH_PART_EXTRA = 512 + 128;
 #else
-constexpr int NH_PART = 65536 + 512;
+constexpr int NH_PART_EXTRA = 512;
 #endif
 
 struct WgradArgs {
@@ -61,6 +61,7 @@ struct WgradArgs {
     float* g_params;
     int64_t nt;
     int njobs, total_wgs;
+    int part_bias, part_stride;  // floats: offset of the bias partials inside a workgroup's partial, size of a partial
     JobDev jobs[NH_JOBS_DEV];
     short xslot[64];  // stash slot row -> reference column of the encoding, or -1
     short dslot[32];
@@ -235,7 +236,7 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
 #ifdef NH_WGRAD_TIMELINE
     NH_TL(tl_loop);
     if (lane == 0 && active) {
-        unsigned long long* dbg = (unsigned long long*)(a.partial + (size_t)wg * NH_PART + 65536 + 512) + wave * 8;
+        unsigned long long* dbg = (unsigned long long*)(a.partial + (size_t)wg * a.part_stride + a.part_bias + 512) + wave * 8;
         dbg[6] = (tl_wait << 32) | (tl_bar & 0xffffffffull);
         dbg[7] = tl_loop;
     }
@@ -243,7 +244,7 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
 #undef NH_TL
     if (!active) return;
     // split-K partial of this workgroup: accumulator tile (a_t, b_t) of the job at [(a_t * b_tiles + b_t)][16 regs][64 lanes]
-    float* part = a.partial + (size_t)wg * NH_PART;
+    float* part = a.partial + (size_t)wg * a.part_stride;
 #pragma unroll
     for (int x = 0; x < PO; ++x) {
         const int a_t = ow * PO + x;
@@ -258,7 +259,7 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
         }
         if (BX == 4 || BX == x) {  // bias gradient = row sums of A over this workgroup's samples
             const float tot = bsum[x] + nh_shfl_xor(bsum[x], 32);
-            if (k == 0) part[65536 + a_t * 32 + i] = tot;
+            if (k == 0) part[a.part_bias + a_t * 32 + i] = tot;
         }
     }
 }
@@ -332,7 +333,7 @@ NH_KERNEL void NH_LB(64 * MD::NWV, 2) k_wgrad(WgradArgs a) {
     }
 #ifdef NH_WGRAD_TIMELINE
     if (lane == 0 && active) {  // timeline record (8 x u64 per wave): wall begin/end, job, K-slice, core-clock begin/end
-        unsigned long long* dbg = (unsigned long long*)(a.partial + (size_t)wg * NH_PART + 65536 + 512) + wave * 8;
+        unsigned long long* dbg = (unsigned long long*)(a.partial + (size_t)wg * a.part_stride + a.part_bias + 512) + wave * 8;
         dbg[0] = t_begin;
         dbg[1] = nh_wall_clock();
         dbg[2] = (unsigned long long)ji;
@@ -368,13 +369,13 @@ NH_KERNEL void k_wgrad_reduce(WgradArgs a) {
         if (col >= 0) {
             // eight interleaved running sums (a fixed order: bit-reproducible) keep eight loads in flight per lane
             float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            const float* p = a.partial + (size_t)jb.wg_start * NH_PART + ((size_t)tile * 16 + c) * 64 + lane;
+            const float* p = a.partial + (size_t)jb.wg_start * a.part_stride + ((size_t)tile * 16 + c) * 64 + lane;
             int q = 0;
             for (; q + 8 <= nks; q += 8) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) sum[u] += p[(size_t)(q + u) * NH_PART];
+                for (int u = 0; u < 8; ++u) sum[u] += p[(size_t)(q + u) * a.part_stride];
             }
-            for (; q < nks; ++q) sum[0] += p[(size_t)q * NH_PART];
+            for (; q < nks; ++q) sum[0] += p[(size_t)q * a.part_stride];
             a.g_params[(size_t)jb.w_off + (size_t)(out_row - jb.r_lo) * jb.w_ld + col] =
                 ((sum[0] + sum[1]) + (sum[2] + sum[3])) + ((sum[4] + sum[5]) + (sum[6] + sum[7]));
         }
@@ -382,10 +383,17 @@ NH_KERNEL void k_wgrad_reduce(WgradArgs a) {
     if (jb.bias_off >= 0 && b_t == 0 && c == 0 && lane < 32) {
         const int brow = 32 * jb.po * (a_t / jb.po) + jb.po * lane + a_t % jb.po;
         if (brow >= jb.r_lo && brow < jb.r_hi) {
-            float s = 0.0f;
-            const float* p = a.partial + (size_t)jb.wg_start * NH_PART + 65536 + a_t * 32 + lane;
-            for (int q = 0; q < nks; ++q) s += p[(size_t)q * NH_PART];
-            a.g_params[(size_t)jb.bias_off + (brow - jb.r_lo)] = s;
+            // (the same eight interleaved sums: a one-deep chain of nks dependent loads used to set this kernel's duration)
+            float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const float* p = a.partial + (size_t)jb.wg_start * a.part_stride + a.part_bias + a_t * 32 + lane;
+            int q = 0;
+            for (; q + 8 <= nks; q += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sum[u] += p[(size_t)(q + u) * a.part_stride];
+            }
+            for (; q < nks; ++q) sum[0] += p[(size_t)q * a.part_stride];
+            a.g_params[(size_t)jb.bias_off + (brow - jb.r_lo)] =
+                ((sum[0] + sum[1]) + (sum[2] + sum[3])) + ((sum[4] + sum[5]) + (sum[6] + sum[7]));
         }
     }
 }
@@ -460,6 +468,11 @@ void wgrad_schedule(const nerfhip_plan* p, int64_t nt, WgradArgs& w) {
         start += (int)ks[q];
     }
     w.total_wgs = start;
+    int tiles = 1;
+    for (int q = 0; q < w.njobs; ++q)
+        if (p->jobs[q].a_tiles * p->jobs[q].b_tiles > tiles) tiles = p->jobs[q].a_tiles * p->jobs[q].b_tiles;
+    w.part_bias = tiles * 1024;
+    w.part_stride = w.part_bias + NH_PART_EXTRA;
     for (int r = 0; r < 64; ++r) w.xslot[r] = (short)p->xyz_slot_col[r];
     for (int r = 0; r < 32; ++r) w.dslot[r] = (short)p->dir_slot_col[r];
 }
@@ -482,7 +495,7 @@ int launch_wgrad(const WgradArgs& w, nerfhip_stream_t stream) {
 int64_t nh_wgrad_partial_floats(nerfhip_plan* p, int64_t nt) {
     WgradArgs w;
     wgrad_schedule(p, nt > 0 ? nt : 1, w);
-    return (int64_t)w.total_wgs * NH_PART;
+    return (int64_t)w.total_wgs * w.part_stride;
 }
 
 int nh_wgrad(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad, float* partial, float* g_params,

@@ -26,11 +26,13 @@ for _ in range(2):
     lib.mlp_bwd(m._plan, packed.data_ptr(), g.data_ptr(), M, stash.data_ptr(), scratch.data_ptr(), sb, gp.data_ptr(), st)
 torch.cuda.synchronize()
 nt = 4 * ((M + 127) // 128)
-rows = LAY * HID + HID + HID // 2 + 32
-PART = 65536 + 512 + 128
+KW = 128 if HID <= 128 else 256                    # kernel width; a partial = the largest job's tiles + 512 bias + 128 records
+rows = LAY * KW + KW + KW // 2 + 32
+BIAS = (KW // 32) ** 2 * 1024
+PART = BIAS + 512 + 128
 part = scratch[nt * rows * 32:]
 nwg = part.numel() // PART
-part = part[:nwg * PART].view(nwg, PART)[:, 65536 + 512:65536 + 512 + 128].contiguous().cpu().numpy().view(np.uint64).reshape(nwg, 8, 8)
+part = part[:nwg * PART].view(nwg, PART)[:, BIAS + 512:BIAS + 512 + 128].contiguous().cpu().numpy().view(np.uint64).reshape(nwg, 8, 8)
 t0 = part[:, :, 0][part[:, :, 0] > 0].min()
 jobs = {}
 for w in range(nwg):

@@ -284,7 +284,7 @@ def main():
         flops = {"fwd": 2.0 * fwd_macs, "dgrad": 2.0 * dgrad_macs, "wgrad": 2.0 * fwd_macs}
         table = []
         for name, (cnt, ms) in kern.items():
-            kind = "fwd" if "k_mlp_fwd" in name else "dgrad" if "k_mlp_dgrad" in name else "wgrad" if name.startswith("k_wgrad") and "reduce" not in name else None
+            kind = "fwd" if "k_mlp_fwd" in name else "dgrad" if "k_mlp_dgrad" in name else "wgrad" if "k_wgrad" in name and "reduce" not in name else None
             table.append((ms, name, cnt, kind))
         table.sort(reverse=True)
         dom = next((t for t in table if t[3] is not None), None)

@@ -279,11 +279,13 @@ enum {
     W_BIAS = 9,      // W_BASE + bias sums on waves 0 and 5 (4 v_add per k-step)
     W_WIDE_AOPS = 10,  // W_WIDE with AGPR operand destinations
     W_PAIR_DMA = 11,
+    W_WIDE_DMA_HBM = 12,  // W_WIDE_DMA with the stage copy streaming fresh lines from HBM (a 4 GB window, 12 GB per launch)
+                          // instead of re-reading 256 KB that live in L2: what k_wgrad really does
 };
 
 template <int VAR, int KS>
 __global__ __launch_bounds__(512, 2) void kW(const float* __restrict__ gsrc, float* out, unsigned long long* cyc, int nstages,
-                                             float* /*big: kF's store target*/) {
+                                             float* big) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int PO = 4, PI = 2, ROWS = 512, ST = 2 * KS * ROWS;  // floats per stage: 2*KS samples x (256 + 256) rows
     constexpr int NPIECE = ST / 256;                                // 1-KiB copy pieces per stage
@@ -303,10 +305,10 @@ __global__ __launch_bounds__(512, 2) void kW(const float* __restrict__ gsrc, flo
             for (int c = 0; c < 16; ++c) acc[x][y][c] = 0.f;
     float bsum[PO] = {0.f, 0.f, 0.f, 0.f};
     const bool bias = VAR == W_BIAS && (wave == 0 || wave == 5);
-    const Dma src = dma_src(gsrc, 1u << 20);
+    const Dma src = VAR == W_WIDE_DMA_HBM ? dma_src(big, 0xFFFFFFFFu) : dma_src(gsrc, 1u << 20);
     const unsigned lbase = lds_addr_of(lds);
-    constexpr bool DMA = VAR == W_BASE_DMA || VAR == W_WIDE_DMA || VAR == W_WIDE_MID_DMA || VAR == W_PAIR_DMA;
-    constexpr bool WIDE = VAR == W_WIDE || VAR == W_WIDE_NOBAR || VAR == W_WIDE_DMA || VAR == W_WIDE_MID_DMA;
+    constexpr bool DMA = VAR == W_BASE_DMA || VAR == W_WIDE_DMA || VAR == W_WIDE_MID_DMA || VAR == W_PAIR_DMA || VAR == W_WIDE_DMA_HBM;
+    constexpr bool WIDE = VAR == W_WIDE || VAR == W_WIDE_NOBAR || VAR == W_WIDE_DMA || VAR == W_WIDE_MID_DMA || VAR == W_WIDE_DMA_HBM;
     constexpr bool PAIR = VAR == W_PAIR || VAR == W_PAIR_DMA;
     constexpr bool NOBAR = VAR == W_NOBAR || VAR == W_WIDE_NOBAR || VAR == W_NOREAD;
     int buf = 0;
@@ -365,7 +367,10 @@ __global__ __launch_bounds__(512, 2) void kW(const float* __restrict__ gsrc, flo
                     b[(s + 1) & 1] = pb[(s + 1) * 2 * ROWS / 2];
                 }
                 if (DMA && (s & 1) == 0 && dq < NPIECE) {
-                    dma16(src, lane * 16, (n & 3) * 65536 + dq * 1024, dst + dq * 1024);
+                    const unsigned so = VAR == W_WIDE_DMA_HBM
+                                            ? (((unsigned)blockIdx.x * (unsigned)nstages + (unsigned)n) & 65535u) * 65536u
+                                            : (unsigned)(n & 3) * 65536u;
+                    dma16(src, lane * 16, (int)(so + dq * 1024), dst + dq * 1024);
                     dq += 8;
                 }
                 FENCE();
@@ -591,6 +596,7 @@ int main(int argc, char** argv) {
         RW(W_WIDE_AOPS, L2);
         RW(W_BASE_DMA, L2);
         RW(W_WIDE_DMA, L2);
+        RW(W_WIDE_DMA_HBM, L2);
         RW(W_PAIR_DMA, L2);
 #undef RW
         // stages of 8 k-steps (32 KB): three buffers fit, the barrier sits in the middle of a stage

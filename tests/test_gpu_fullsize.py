@@ -128,7 +128,25 @@ def fern(gpu):
     c.close()
 
 
-def _end_to_end(c, coarse_grad_tol, fine_grad_tol):
+@pytest.fixture(scope="module")
+def lego_default_nets(gpu):
+    """The nets the reference's scripts really build (FlexibleNeRFModel defaults: 4 x 128, skip 4 -- SURVEY 0.2) on the
+    lego batch geometry."""
+    n = _batch_size(3.0e6)
+    c = _Case(gpu, "lego_4x128_64+128", P.MLP_GEOMETRIES["default4x128"], n, 64, 128, 0.2, False, seed=303)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def lego_padded_nets(gpu):
+    """A hidden size between the kernel widths (5 x 99, skip 2: rides zero-padded on the 128-wide kernels), 2048 rays."""
+    c = _Case(gpu, "lego_5x99_64+128", P.MLP_GEOMETRIES["odd5x99_skip2"], 2048, 64, 128, 0.2, False, seed=404)
+    yield c
+    c.close()
+
+
+def _end_to_end(c, coarse_grad_tol, fine_grad_tol, rgb_fine_tol=(1e-4, 1e-4)):
     gpu = c.gpu
     out = gpu.render(c.plan_c, c.plan_f, c.packed_c, c.packed_f, c.rays.numpy(), c.opt, c.rnp, training=True)
     l3, gc, gf = gpu.mse_loss(out["rgb_coarse"], out["rgb_fine"], c.tgt.numpy())
@@ -152,7 +170,8 @@ def _end_to_end(c, coarse_grad_tol, fine_grad_tol):
     for k in ("rgb_coarse", "acc_coarse", "depth_coarse"):
         assert rec["outputs"][k]["max"] <= 1e-5, (k, rec["outputs"][k])
     # the north-star bar on colour; acc / depth of the fine pass carry the sampler's conditioning
-    assert rec["outputs"]["rgb_fine"]["max"] <= 1e-4, rec["outputs"]["rgb_fine"]
+    assert rec["outputs"]["rgb_fine"]["max"] <= rgb_fine_tol[0] and rec["outputs"]["rgb_fine"]["p999"] <= rgb_fine_tol[1], \
+        rec["outputs"]["rgb_fine"]
     assert rec["outputs"]["acc_fine"]["max"] <= 5e-4 and rec["outputs"]["depth_fine"]["max"] <= 2e-3, rec["outputs"]
     assert abs(float(l3[2]) - float(c.loss)) < 1e-5
     assert gcw["max"] <= coarse_grad_tol[0] and gcw["p999"] <= coarse_grad_tol[1], gcw
@@ -166,6 +185,22 @@ def test_lego_full_batch_every_ray_vs_oracle(lego):
     max 1.4e-4 / p99.9 3.6e-5 of max|g| (two fp32 sums of 262,144 terms in different orders); fine-net gradients max
     6.5e-4 / p99.9 3.6e-4 (behind the sampler)."""
     _end_to_end(lego, coarse_grad_tol=(2e-4, 5e-5), fine_grad_tol=(5e-3, 1e-3))
+
+
+def test_lego_default_4x128_nets_full_batch_vs_oracle(lego_default_nets):
+    _end_to_end(lego_default_nets, coarse_grad_tol=(2e-4, 5e-5), fine_grad_tol=(5e-3, 1e-3))
+
+
+def test_lego_padded_hidden_size_batch_vs_oracle(lego_padded_nets):
+    """Not a BASELINE configuration: the coarse pass (no sampler in front of it) is held to the same bounds as above;
+    behind the sampler ONE ray of 2048 exceeds the 1e-4 colour bar of the BASELINE configurations (measured max 1.6e-4,
+    p99.9 7.6e-5 -- a fine sample that lands in a neighbouring bin), so this case asserts p99.9 <= 1e-4 and max <= 3e-4;
+    the teacher-forced fine pass below pins the kernels themselves."""
+    _end_to_end(lego_padded_nets, coarse_grad_tol=(2e-4, 5e-5), fine_grad_tol=(5e-3, 1e-3), rgb_fine_tol=(3e-4, 1e-4))
+
+
+def test_lego_padded_hidden_size_teacher_forced_fine_pass(lego_padded_nets):
+    _teacher_forced(lego_padded_nets)
 
 
 def test_fern_full_batch_every_ray_vs_oracle(fern):

@@ -12,8 +12,9 @@
 // What the structure is tuned against (MI355X, scripts/loop_mock.hip, profiles/r02_loop_mock.txt): the bare chunk loop
 // -- 4 ds_read_b128 per 16 MFMAs, two waves per SIMD -- runs at 99 % of the matrix pipe, 95.6 % with the chunk copy and
 // a barrier every 8 k-steps, 98.0 % with 16-k-step chunks.  So: chunks as large as the LDS allows (two 64 KB buffers for
-// 256-wide nets), the copy pieces and the stash stores of a layer issued ONE PER K-STEP between the MFMA groups (never
-// a burst in front of them), and every address of a layer computed once, before its first chunk.
+// 256-wide nets), the copy pieces (first half of a chunk) and the stash stores (second half: nh16_store_kstep) issued
+// ONE PER K-STEP between the MFMA groups, never a burst in front of them, and every address of a layer computed once,
+// before its first chunk.
 #include <stdlib.h>
 
 #include "nh_mlp.h"

@@ -15,7 +15,7 @@ for hid, lay in ((256, 8), (128, 4)):
     m = N.FlexibleNeRFModel(lay, hid, 4, 10, 4).to(dev)
     x = torch.randn(M, 90, device=dev)
     y = torch.empty(M, 4, device=dev)
-    stash = torch.empty(lib.plan_stash_bytes(m._plan, M) // 4, device=dev)
+    stash = torch.empty(int(lib.plan_stash_bytes(m._plan, M) // 4 * 1.1) + (1 << 22), device=dev)  # (slack: layout-experiment builds)
     st = torch.cuda.current_stream().cuda_stream
     packed = m._packed()
     macs = sum(p.numel() for n, p in m.named_parameters() if n.endswith("weight"))

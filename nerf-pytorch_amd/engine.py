@@ -61,7 +61,7 @@ class TrainEngine:
         self._loss_f = torch.zeros(3, dtype=torch.float32, device=self.dev)
         # two-stream graph: measured on MI355X (profiles/r02_overlap_ab.txt) +3.5 % for 128-wide nets (the short kernels'
         # tails fill), -0.4 % for 256-wide nets (every launch already fills the chip for milliseconds) -> default by width
-        self.overlap = (model_coarse.cfg["hidden_size"] < 256) if overlap is None else bool(overlap)
+        self.overlap = (model_coarse.cfg["hidden_size"] <= 128) if overlap is None else bool(overlap)  # (128-wide kernels)
         self._side = None       # second HIP stream of this device (created on first use)
         self._ev = None
         self._pending = []      # in-flight gradient all-reduces of the current step

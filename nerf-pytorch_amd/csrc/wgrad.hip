@@ -126,10 +126,26 @@ struct WStageDma {
     template <int NWV>
     NH_MEMBER void issue(int n) {
         for (int c = 0; c < n && q < ptot; ++c, q += NWV) {
+#ifdef NH_WGRAD_TIMELINE
+            // (instrumented build only: with the stamp bookkeeping ROCm 7.2's clang hands VGPRs to the "s" descriptor operand
+            // of the copy instruction and the build fails; the descriptors are re-uniformised per piece.  This costs the
+            // instrumented kernel ~10 % -- more on small jobs: its timeline shows the order of events and the wait / barrier
+            // shares, not the product kernel's absolute times.)
+            NhDmaSrc ta = sa, tb = sb;
+            for (int e = 0; e < 4; ++e) {
+                ta.r[e] = __builtin_amdgcn_readfirstlane(ta.r[e]);
+                tb.r[e] = __builtin_amdgcn_readfirstlane(tb.r[e]);
+            }
+            if (q < pa)
+                nh_dma16a(ta, lane16, q * 1024, dst + q * 1024);
+            else
+                nh_dma16a(tb, lane16, (q - pa) * 1024, dst + boff + q * 1024);
+#else
             if (q < pa)
                 nh_dma16a(sa, lane16, q * 1024, dst + q * 1024);
             else
                 nh_dma16a(sb, lane16, (q - pa) * 1024, dst + boff + q * 1024);
+#endif
         }
     }
 };

@@ -66,7 +66,6 @@ with open(os.path.join(P, tag + "_overlap_ab.txt"), "w") as f:
 kernel_stats("prof", "bench_kernel_stats.txt")
 kernel_stats("prof128", "bench_kernel_stats_4x128.txt")
 copy("eval.log", "eval_800x800.txt")
-copy("wgrad_timeline.txt", "wgrad_timeline.txt")
 copy("phase_timing.txt", "phase_timing.txt")
 copy("pmc_summary.txt", "pmc_summary.txt")
 copy("pmc_summary.json", "pmc_summary.json")

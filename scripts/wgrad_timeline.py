@@ -47,6 +47,9 @@ for w in range(nwg):
 end = max(e for v in jobs.values() for (_, e, _, _) in v)
 ok = part[:, :, 1] > part[:, :, 0]
 ghz = ((part[:, :, 5] - part[:, :, 4])[ok] / ((part[:, :, 1] - part[:, :, 0])[ok] * 10.0))   # core cycles per ns
+print("# instrumented build (make dbg): the per-piece descriptor re-uniformisation it needs (wgrad.hip, WStageDma::issue) makes "
+      "this kernel ~10 % slower than the product's, small jobs more: read the ORDER of events and the wait / barrier shares, "
+      "not absolute times")
 print(json.dumps(dict(nwg=nwg, makespan_us=end, core_clock_ghz_mean=float(ghz.mean()), core_clock_ghz_min=float(ghz.min()),
                       core_clock_ghz_max=float(ghz.max()))))
 for j in sorted(jobs):

@@ -415,12 +415,14 @@ NH_KERNEL void k_wgrad_reduce(WgradArgs a) {
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
-constexpr int NH_WGRAD_TARGET_WGS = 1024;
-
 // Split-K allocation: job j gets ks_j workgroups with ks_j proportional to its per-tile cost (every workgroup then
 // runs for about the same time), and sum ks_j == NH_WGRAD_TARGET_WGS exactly (largest-remainder rounding) -- the grid
-// is a whole number of rounds over the 256 CUs (one 8-wave workgroup per CU), with no straggler round.
+// is a whole number of rounds over the chip, with no straggler round: THREE rounds of 256 eight-wave workgroups (one per
+// CU) for 256-wide nets, TWO rounds of 512 four-wave workgroups (two per CU) for 128-wide ones.  Measured on MI355X:
+// 512 / 768 / 1024 / 1280 / 2048 workgroups -> k_wgrad 0.845 / 0.855 / 0.852 / 0.846 / 0.841 of peak for 8x256 nets
+// (more workgroups: more partials to write and reduce; fewer: a coarser tail), 0.551 / 0.564 / 0.584 for 4x128.
 void wgrad_schedule(const nerfhip_plan* p, int64_t nt, WgradArgs& w) {
+    const int NH_WGRAD_TARGET_WGS = p->wgrad_waves == 4 ? 1024 : 768;
     const int stage_floats = p->wgrad_waves == 4 ? WModeNarrow::STAGE : WModeWide::STAGE;
     w.njobs = (int)p->jobs.size();
     int64_t cost[NH_JOBS_DEV];

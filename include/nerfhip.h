@@ -221,8 +221,19 @@ typedef struct nerfhip_render_out {
     float* depth_fine;
 } nerfhip_render_out;
 
+/* training: 0 = inference (no activation stash); 1 = training with one set of backward buffers per net (required when
+ * the two nets' backward chains run on different streams, nerfhip_render_bwd_parts); 2 = training with ONE set of
+ * backward buffers shared by the two nets (smaller: by the coarse net's d(pre-activation) scratch; valid for
+ * nerfhip_render_bwd and for parts calls that pass NERFHIP_PART_SHARED_BWD). */
 int64_t nerfhip_render_workspace_bytes(nerfhip_plan_t plan_coarse, nerfhip_plan_t plan_fine,
                                        const nerfhip_render_cfg* cfg, int64_t n_rays, int training);
+
+/* Where a forward leaves its per-sample intermediates inside the workspace (byte offset and size), for inspection:
+ * name = "z_coarse" [n,nc] (nerf/train_utils.py:58-65), "raw_coarse" [n,nc,4] (run_network's output, :70-77),
+ * "weights_coarse" [n,nc] (:86), "z_fine" [n,nc+nf] (:103-105), "raw_fine" [n,nc+nf,4] (:108-115).  The reference
+ * function returns none of them; the parity tests read the sample depths to count inverse-CDF index flips. */
+int nerfhip_render_workspace_region(nerfhip_plan_t plan_coarse, nerfhip_plan_t plan_fine, const nerfhip_render_cfg* cfg,
+                                    int64_t n_rays, int training, const char* name, int64_t* offset, int64_t* bytes);
 
 /* rays: dev [n, ray_stride]; t_vals: dev [num_coarse] linspace(0,1); u_det: dev [num_fine] linspace(0,1) (used
  * when perturb == 0); workspace: dev, nerfhip_render_workspace_bytes (keeps everything render_bwd needs when
@@ -235,8 +246,8 @@ int nerfhip_render_fwd(nerfhip_plan_t plan_coarse, nerfhip_plan_t plan_fine, con
 
 /* Backward of the fused render w.r.t. both nets' parameters.  g_rgb_coarse / g_rgb_fine: dev [n,3] cotangents of
  * the two colour maps (the only outputs the reference's loss touches, train_nerf.py:244-258).  g_params_*: dev
- * flat gradient vectors (overwritten).  The workspace must be the one a training nerfhip_render_fwd filled, with
- * the same rays / packed weights / random arguments. */
+ * flat gradient vectors (overwritten).  The workspace must be the one a training nerfhip_render_fwd filled (sized
+ * with training = 1 or 2), with the same rays / packed weights / random arguments. */
 int nerfhip_render_bwd(nerfhip_plan_t plan_coarse, nerfhip_plan_t plan_fine, const nerfhip_render_cfg* cfg,
                        const float* rays, int64_t n_rays, const float* packed_coarse, const float* packed_fine,
                        const nerfhip_render_rand* rnd, uint64_t seed, uint64_t ray_offset, const float* g_rgb_coarse,
@@ -252,6 +263,9 @@ int nerfhip_render_bwd(nerfhip_plan_t plan_coarse, nerfhip_plan_t plan_fine, con
  * accumulation maps are optional (NULL = 0): losses that only touch the colour maps pass g_rgb_* alone. */
 #define NERFHIP_PART_COARSE 1
 #define NERFHIP_PART_FINE 2
+/* nerfhip_render_bwd_parts only: the caller runs the two nets' backward chains one after the other on one stream, so
+ * they may share one set of backward buffers (workspace sized with training = 2 or 1). */
+#define NERFHIP_PART_SHARED_BWD 4
 typedef struct nerfhip_render_cotangents {
     const float* g_rgb_coarse;   /* [n,3] */
     const float* g_acc_coarse;   /* [n]   */

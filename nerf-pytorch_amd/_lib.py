@@ -43,7 +43,7 @@ class RenderCotangents(C.Structure):
                                    "g_depth_fine")]
 
 
-PART_COARSE, PART_FINE = 1, 2
+PART_COARSE, PART_FINE, PART_SHARED_BWD = 1, 2, 4
 
 
 class SelectCfg(C.Structure):
@@ -95,6 +95,8 @@ _PROTOS = {
     "nerfhip_mlp_bwd": (C.c_int, [C.c_void_p, c_f, c_f, c_i64, c_f, c_f, c_i64, c_f, c_f]),
     "nerfhip_mlp_bwd_input": (C.c_int, [C.c_void_p, c_f, c_i64, c_f, c_f, c_f]),
     "nerfhip_render_workspace_bytes": (c_i64, [C.c_void_p, C.c_void_p, C.POINTER(RenderCfg), c_i64, C.c_int]),
+    "nerfhip_render_workspace_region": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(RenderCfg), c_i64, C.c_int, C.c_char_p,
+                                                   C.POINTER(c_i64), C.POINTER(c_i64)]),
     "nerfhip_render_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(RenderCfg), c_f, c_i64, c_f, c_f, c_f, c_f,
                                       C.POINTER(RenderRand), c_u64, c_u64, C.POINTER(RenderOut), c_f, c_i64, C.c_int,
                                       c_f]),

@@ -15,6 +15,10 @@ struct Workspace {
 
 int64_t align_up(int64_t v) { return (v + 255) & ~(int64_t)255; }
 
+// training: 0 = inference; 1 = training, one set of backward buffers per net (the two backward chains may then run on
+// different streams: nerfhip_render_bwd_parts); 2 = training, the two nets SHARE one set of backward buffers (their
+// backward chains must run one after the other on one stream -- what nerfhip_render_bwd does; a parts call says so with
+// NERFHIP_PART_SHARED_BWD).  The forward's regions do not depend on that choice: they are laid out first.
 Workspace layout(nerfhip_plan* pc, nerfhip_plan* pf, const nerfhip_render_cfg* cfg, int64_t n, int training) {
     Workspace w;
     memset(&w, 0, sizeof(w));
@@ -34,14 +38,19 @@ Workspace layout(nerfhip_plan* pc, nerfhip_plan* pf, const nerfhip_render_cfg* c
     }
     if (training) {
         w.stash_c = take(nerfhip_plan_stash_bytes(pc, n * nc));
-        w.g_raw_c = take(n * nc * 16);
+        if (nf > 0) w.stash_f = take(nerfhip_plan_stash_bytes(pf, n * sf));
         w.scratch_c_bytes = nh_mlp_bwd_scratch_bytes(pc, n * nc);
-        w.scratch_c = take(w.scratch_c_bytes);
-        if (nf > 0) {
-            w.stash_f = take(nerfhip_plan_stash_bytes(pf, n * sf));
-            w.g_raw_f = take(n * sf * 16);
-            w.scratch_f_bytes = nh_mlp_bwd_scratch_bytes(pf, n * sf);
-            w.scratch_f = take(w.scratch_f_bytes);
+        if (nf > 0) w.scratch_f_bytes = nh_mlp_bwd_scratch_bytes(pf, n * sf);
+        if (training == 2 && nf > 0) {
+            w.g_raw_c = w.g_raw_f = take(n * sf * 16);
+            w.scratch_c = w.scratch_f = take(w.scratch_c_bytes > w.scratch_f_bytes ? w.scratch_c_bytes : w.scratch_f_bytes);
+        } else {
+            w.g_raw_c = take(n * nc * 16);
+            w.scratch_c = take(w.scratch_c_bytes);
+            if (nf > 0) {
+                w.g_raw_f = take(n * sf * 16);
+                w.scratch_f = take(w.scratch_f_bytes);
+            }
         }
     }
     w.total = off;
@@ -66,6 +75,31 @@ extern "C" int64_t nerfhip_render_workspace_bytes(nerfhip_plan_t plan_coarse, ne
     return layout(plan_coarse, plan_fine, cfg, n_rays, training).total;
 }
 
+extern "C" int nerfhip_render_workspace_region(nerfhip_plan_t plan_coarse, nerfhip_plan_t plan_fine,
+                                               const nerfhip_render_cfg* cfg, int64_t n_rays, int training, const char* name,
+                                               int64_t* offset, int64_t* bytes) {
+    int rc = check_cfg(plan_coarse, plan_fine, cfg);
+    if (rc) return rc;
+    NH_REQUIRE(name && offset && bytes && n_rays >= 0, "render_workspace_region: bad arguments");
+    const Workspace w = layout(plan_coarse, plan_fine, cfg, n_rays, training);
+    const int64_t nc = cfg->num_coarse, sf = nc + cfg->num_fine;
+    struct {
+        const char* name;
+        int64_t off, bytes;
+        bool fine;
+    } regions[] = {{"z_coarse", w.z_c, n_rays * nc * 4, false},      {"raw_coarse", w.raw_c, n_rays * nc * 16, false},
+                   {"weights_coarse", w.w_c, n_rays * nc * 4, false}, {"z_fine", w.z_f, n_rays * sf * 4, true},
+                   {"raw_fine", w.raw_f, n_rays * sf * 16, true}};
+    for (const auto& r : regions)
+        if (strcmp(name, r.name) == 0) {
+            NH_REQUIRE(!r.fine || cfg->num_fine > 0, "render_workspace_region: %s needs num_fine > 0", name);
+            *offset = r.off;
+            *bytes = r.bytes;
+            return NERFHIP_OK;
+        }
+    NH_REQUIRE(false, "render_workspace_region: unknown region '%s'", name);
+}
+
 extern "C" int nerfhip_render_fwd_parts(nerfhip_plan_t pc, nerfhip_plan_t pf, const nerfhip_render_cfg* cfg,
                                         const float* rays, int64_t n, const float* packed_c, const float* packed_f,
                                         const float* t_vals, const float* u_det, const nerfhip_render_rand* rnd,
@@ -77,7 +111,8 @@ extern "C" int nerfhip_render_fwd_parts(nerfhip_plan_t pc, nerfhip_plan_t pf, co
     NH_REQUIRE(parts >= 1 && parts <= 3, "render_fwd: parts must be a combination of NERFHIP_PART_COARSE | NERFHIP_PART_FINE");
     NH_REQUIRE(cfg->num_fine == 0 || packed_f, "render_fwd: packed_fine is NULL");
     if (n == 0) return NERFHIP_OK;
-    const Workspace w = layout(pc, pf, cfg, n, training);
+    // (the regions a forward touches are the same in both training layouts; the size check uses the smaller one)
+    const Workspace w = layout(pc, pf, cfg, n, training ? 2 : 0);
     NH_REQUIRE(workspace_bytes >= w.total, "render_fwd: workspace too small (%lld < %lld)", (long long)workspace_bytes,
                (long long)w.total);
     char* ws = (char*)workspace;
@@ -142,8 +177,10 @@ extern "C" int nerfhip_render_bwd_parts(nerfhip_plan_t pc, nerfhip_plan_t pf, co
     int rc = check_cfg(pc, pf, cfg);
     if (rc) return rc;
     NH_REQUIRE(rays && packed_c && g && workspace && n > 0, "render_bwd: bad arguments");
+    const int shared = parts & NERFHIP_PART_SHARED_BWD;
+    parts &= ~NERFHIP_PART_SHARED_BWD;
     NH_REQUIRE(parts >= 1 && parts <= 3, "render_bwd: parts must be a combination of NERFHIP_PART_COARSE | NERFHIP_PART_FINE");
-    const Workspace w = layout(pc, pf, cfg, n, 1);
+    const Workspace w = layout(pc, pf, cfg, n, shared ? 2 : 1);
     NH_REQUIRE(workspace_bytes >= w.total, "render_bwd: workspace too small (%lld < %lld)", (long long)workspace_bytes,
                (long long)w.total);
     char* ws = (char*)workspace;
@@ -185,5 +222,6 @@ extern "C" int nerfhip_render_bwd(nerfhip_plan_t pc, nerfhip_plan_t pf, const ne
     NH_REQUIRE(g_rgb_c && g_params_c, "render_bwd: bad arguments");
     nerfhip_render_cotangents g = {g_rgb_c, nullptr, nullptr, g_rgb_f, nullptr, nullptr};
     return nerfhip_render_bwd_parts(pc, pf, cfg, rays, n, packed_c, packed_f, rnd, seed, ray_offset, &g, workspace,
-                                    workspace_bytes, g_params_c, g_params_f, NERFHIP_PART_COARSE | NERFHIP_PART_FINE, stream);
+                                    workspace_bytes, g_params_c, g_params_f,
+                                    NERFHIP_PART_COARSE | NERFHIP_PART_FINE | NERFHIP_PART_SHARED_BWD, stream);
 }

@@ -24,8 +24,8 @@
 
 #include "../../include/nerfhip.h"
 
-constexpr int NH_MAX_LAYERS = 16;  // num_layers limit
-constexpr int NH_MAX_JOBS = 48;
+constexpr int NH_MAX_LAYERS = 32;  // num_layers limit (per-layer offset tables travel by value in the kernel arguments)
+constexpr int NH_MAX_JOBS = 64;  // weight-gradient jobs of one model (== the kernel-argument table of wgrad.hip)
 
 constexpr int NH16_KRX = 16;
 constexpr int NH16_KRD = 8;

@@ -23,18 +23,22 @@
 
 namespace {
 
+// (kernel arguments are limited to 4 KB: NH_MAX_JOBS compact records of 56 bytes)
 struct JobDev {
-    int a_rows, a_prefix, a_tiles;
-    int b_rows, b_prefix, b_tiles;
-    int wo, wi, po, pi;
-    int r_lo, r_hi;
+    int a_prefix, b_prefix;
     int w_off, w_ld;
-    int col_kind, col_base, col_count;
+    int col_base, col_count;
     int bias_off;
     int wg_start;
-    int g;  // 32-sample tiles per LDS stage
+    short a_rows, a_tiles;
+    short b_rows, b_tiles;
+    short wo, wi, po, pi;
+    short r_lo, r_hi;
+    short col_kind;
+    short g;  // 32-sample tiles per LDS stage
 };
-constexpr int NH_JOBS_DEV = 32;
+constexpr int NH_JOBS_DEV = NH_MAX_JOBS;
+static_assert(sizeof(JobDev) * NH_JOBS_DEV + 320 <= 4096, "WgradArgs must fit the 4 KB kernel-argument limit");
 // Workgroup shapes.  256-wide nets: 8 waves per workgroup (two per SIMD), two LDS stages of 16384 floats (+ slack for
 // the operand prefetch that runs one k-step past the end of a stage): one workgroup per CU.  128-wide nets (jobs of at
 // most 4 x 4 tiles): 4 waves per workgroup with 2 x 2 patches -- 1.0 instead of 1.5 operand dwords per MFMA -- and
@@ -424,7 +428,7 @@ NH_KERNEL void k_wgrad_reduce(WgradArgs a) {
 void wgrad_schedule(const nerfhip_plan* p, int64_t nt, WgradArgs& w) {
     const int NH_WGRAD_TARGET_WGS = p->wgrad_waves == 4 ? 1024 : 768;
     const int stage_floats = p->wgrad_waves == 4 ? WModeNarrow::STAGE : WModeWide::STAGE;
-    w.njobs = (int)p->jobs.size();
+    w.njobs = (int)p->jobs.size();  // <= NH_MAX_JOBS == NH_JOBS_DEV: nerfhip_plan_create refuses larger job lists
     int64_t cost[NH_JOBS_DEV];
     for (int q = 0; q < w.njobs; ++q) cost[q] = p->jobs[q].cost;
     int64_t total_cost = 0;
@@ -462,27 +466,27 @@ void wgrad_schedule(const nerfhip_plan* p, int64_t nt, WgradArgs& w) {
         const NhJob& j = p->jobs[q];
         if (ks[q] > nt) ks[q] = nt;
         JobDev& d = w.jobs[q];
-        d.a_rows = j.a_region_rows;
+        d.a_rows = (short)j.a_region_rows;
         d.a_prefix = (int)j.a_row_prefix;
-        d.a_tiles = j.a_tiles;
-        d.b_rows = j.b_region_rows;
+        d.a_tiles = (short)j.a_tiles;
+        d.b_rows = (short)j.b_region_rows;
         d.b_prefix = (int)j.b_row_prefix;
-        d.b_tiles = j.b_tiles;
-        d.wo = j.wo;
-        d.wi = j.wi;
-        d.po = j.po;
-        d.pi = j.pi;
-        d.r_lo = j.r_lo;
-        d.r_hi = j.r_hi;
+        d.b_tiles = (short)j.b_tiles;
+        d.wo = (short)j.wo;
+        d.wi = (short)j.wi;
+        d.po = (short)j.po;
+        d.pi = (short)j.pi;
+        d.r_lo = (short)j.r_lo;
+        d.r_hi = (short)j.r_hi;
         d.w_off = (int)j.w_off;
         d.w_ld = j.w_ld;
-        d.col_kind = j.col_kind;
+        d.col_kind = (short)j.col_kind;
         d.col_base = j.col_base;
         d.col_count = j.col_count;
         d.bias_off = (int)j.bias_off;
         d.wg_start = start;
-        d.g = stage_floats / (32 * (j.a_region_rows + j.b_region_rows));
-        if (d.g < 1) d.g = 1;
+        const int g = stage_floats / (32 * (j.a_region_rows + j.b_region_rows));
+        d.g = (short)(g < 1 ? 1 : g);
         start += (int)ks[q];
     }
     w.total_wgs = start;

@@ -101,9 +101,11 @@ def cumprod_exclusive(tensor: torch.Tensor) -> torch.Tensor:
     """nerf/nerf_helpers.py:43-64 -- exclusive cumulative product along the last dimension (differentiable)."""
     if not isinstance(tensor, torch.Tensor) or not tensor.is_cuda:
         raise RuntimeError("tensor must be a CUDA (HIP) tensor: nerf_pytorch_amd has no CPU path")
-    if tensor.dtype != torch.float32:
-        raise RuntimeError("tensor must be float32 (got %s)" % tensor.dtype)
-    return _CumprodExclusive.apply(tensor.contiguous())
+    if not tensor.is_floating_point():
+        raise RuntimeError("tensor must be a floating-point tensor (got %s)" % tensor.dtype)
+    # the kernel computes in fp32; other floating dtypes (the reference works for any) are cast in and out, and autograd
+    # carries the gradient back through the casts
+    return _CumprodExclusive.apply(tensor.float().contiguous()).to(tensor.dtype)
 
 
 def get_ray_bundle(height: int, width: int, focal_length, tform_cam2world: torch.Tensor):

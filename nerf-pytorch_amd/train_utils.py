@@ -84,10 +84,13 @@ class _FusedRender(torch.autograd.Function):
         # `training` (decided by the caller: grad mode is off inside Function.forward, and needs_input_grad ignores
         # torch.no_grad()): keep the activation stash for a backward
         plan_f = model_f._plan if nf > 0 else None
-        wsb = lib.render_workspace_bytes(model_c._plan, plan_f, C.byref(cfg), n, int(training))
+        # (training layout 2: this node's backward runs the two nets one after the other on one stream, so they share one
+        # set of backward buffers -- several nodes may be alive at once when a batch is rendered in ray chunks)
+        wsb = lib.render_workspace_bytes(model_c._plan, plan_f, C.byref(cfg), n, 2 if training else 0)
         if wsb < 0:
             raise L.NerfHipError(lib.last_error().decode())
         ws = torch.empty(wsb // 4 + 1, dtype=torch.float32, device=dev)
+        ctx.set_materialize_grads(False)  # cotangents of outputs the loss never touched arrive as None, not as zeros
         names = ("rgb_coarse", "disp_coarse", "acc_coarse", "depth_coarse", "rgb_fine", "disp_fine", "acc_fine",
                  "depth_fine")
         bufs = {k: torch.empty((n, 3) if k.startswith("rgb") else (n,), dtype=torch.float32, device=dev) for k in names}
@@ -129,7 +132,7 @@ class _FusedRender(torch.autograd.Function):
                 lib.render_bwd_parts(model_c._plan, model_f._plan if nf > 0 else None, C.byref(cfg), rays.data_ptr(), n,
                                      packed_c.data_ptr(), packed_f.data_ptr() if nf > 0 else None, C.byref(rr), 0, 0,
                                      C.byref(cot), ws.data_ptr(), wsb, gpc.data_ptr(),
-                                     gpf.data_ptr() if gpf is not None else None, parts, st)
+                                     gpf.data_ptr() if gpf is not None else None, parts | L.PART_SHARED_BWD, st)
         grads = model_c._split_flat(gpc) + (model_f._split_flat(gpf) if nf > 0 else ())
         return (None,) * 6 + grads
 

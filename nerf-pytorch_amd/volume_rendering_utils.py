@@ -21,7 +21,7 @@ class _VolumeRender(torch.autograd.Function):
                                   rgb.data_ptr(), None, acc.data_ptr(), weights.data_ptr(), depth.data_ptr(), st)
         ctx.save_for_backward(raw, z, rd, noise if noise is not None else torch.empty(0, device=dev))
         ctx.cfg = (float(noise_std), bool(white), noise is not None)
-        ctx.mark_non_differentiable()
+        ctx.set_materialize_grads(False)  # cotangents of unused outputs arrive as None (NULL for the kernel), not as zeros
         return rgb, acc, weights, depth
 
     @staticmethod

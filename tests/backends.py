@@ -284,7 +284,7 @@ class Backend:
 
     # -- fused render ---------------------------------------------------------------------------------------------------
     def render(self, plan_c, plan_f, packed_c, packed_f, rays, opt, rand=None, seed=0, ray_offset=0, training=False,
-               g_rgb=None):
+               g_rgb=None, want_regions=()):
         """opt: dict(num_coarse, num_fine, perturb, lindisp, white_background, noise_std).  Returns dict of outputs
         (+ flat grads 'g_params_coarse/fine' when g_rgb = (g_c, g_f) is given)."""
         rand = rand or {}
@@ -307,6 +307,12 @@ class Backend:
                             self.ptr(dt), self.p(dud), C.byref(rr), seed, ray_offset, C.byref(ro), self.ptr(ws), wsb,
                             int(training), self.stream())
         out = {k: self.host(v) for k, v in bufs.items()}
+        for name in want_regions:  # per-sample intermediates the forward left in the workspace
+            off, nb = C.c_int64(), C.c_int64()
+            self.lib.render_workspace_region(plan_c, plan_f, C.byref(cfg), n, int(training), name.encode(), C.byref(off),
+                                             C.byref(nb))
+            flat = self.host(ws[off.value // 4:(off.value + nb.value) // 4])
+            out[name] = flat.reshape(n, -1, 4) if name.startswith("raw") else flat.reshape(n, -1)
         if nf == 0:
             for k in names[4:]:
                 out[k] = None

@@ -37,6 +37,25 @@ def rng(seed):
     return torch.Generator().manual_seed(seed)
 
 
+# measured quantities the cases want on record next to their bounds (the GPU session writes them to
+# gpurun_out/parity_small_cases.json -> profiles/): {case: {quantity: value}}
+RECORD = {}
+
+
+def note(case, **kv):
+    RECORD.setdefault(case, {}).update({k: (float(v) if not isinstance(v, (int, str)) else v) for k, v in kv.items()})
+
+
+def grad_close(got, ref, max_rel, what, case, key):
+    """Gradient tensor against the reference's: |got - ref| <= max_rel * max|ref| (+ 5e-4 |ref| elementwise); the
+    measured worst ratio goes on record."""
+    scale = float(np.abs(ref).max()) + 1e-12
+    worst = float(np.abs(np.asarray(got, np.float64) - np.asarray(ref, np.float64)).max()) / scale
+    prev = RECORD.get(case, {}).get(key, 0.0)
+    note(case, **{key: max(prev, worst)})
+    close(got, ref, max_rel * scale + 1e-9, 5e-4, what=what)
+
+
 # ---- geometry ----------------------------------------------------------------------------------------------------------
 def case_rays(b):
     g = gold("helpers.npz")
@@ -190,8 +209,14 @@ def case_sample_pdf(b):
     # (3) vs the reference: identical except where a 1-ulp cdf difference flips an index
     _, oi, oc = O.sample_pdf(T(bins), T(w), 128, u=T(u), return_aux=True)
     close(cdf, oc.numpy(), 2.5e-7, what="cdf vs torch")
-    flips = float((inds != oi.numpy()).mean())
-    assert flips < 2e-3, flips
+    # Measured: 0 flipped indices of 1,408 here and 0 of 524,288 on a 4096-ray batch (test_gpu_fullsize.py), although 41 %
+    # of the CDF entries differ from torch's by one ulp (torch.sum's vectorised fp32 cascade vs the declared sequential
+    # order): a flip needs u within an ulp of a CDF entry, ~4e-6 per index and ulp.  The kernel equals the C
+    # restatement bit for bit, so this count is deterministic: none is allowed.
+    nflip = int((inds != oi.numpy()).sum())
+    note("sample_pdf_golden_%s" % b.name, indices=int(inds.size), flipped_vs_torch=nflip,
+         cdf_entries_differing_from_torch=float((cdf != oc.numpy()).mean()), cdf_max_abs_diff=float(np.abs(cdf - oc.numpy()).max()))
+    assert nflip == 0, nflip
     same = inds == oi.numpy()
     close(s[same], g["sp_rand"][same], 1e-5, what="samples vs reference")
     sd, _, _ = b.sample_pdf(bins, w, 128, det=True)
@@ -233,6 +258,9 @@ MLP_GEOMETRIES = {
     "one_layer_novw_256": model_cfg(1, 256, 4, 3, 0, use_viewdirs=False),
     "sixteen_layers_skip5": model_cfg(16, 128, 5, 10, 4),
     "skip_every_layer_256": model_cfg(3, 256, 1, 2, 1),
+    # 35 weight-gradient jobs: the job tables of wgrad.hip used to hold 32
+    "sixteen_layers_skip1": model_cfg(16, 128, 1, 10, 4),
+    "twenty_layers_skip7": model_cfg(20, 128, 7, 6, 2),
     "noinput_linear": model_cfg(3, 128, 2, 5, 3, include_input_xyz=False, include_input_dir=False,
                                 log_sampling_xyz=False),
     "northstar8x256": model_cfg(8, 256, 4, 10, 4),
@@ -322,6 +350,13 @@ def e2e_inputs(name):
     return g, meta, cfg_c, cfg_f, rays, rand, opt
 
 
+# Bounds on max|g_hip - g_ref| / max|g_ref| per parameter tensor of the reference-generated end-to-end goldens: (coarse
+# net, fine net).  The fine net sits behind the inverse-CDF sampler; the bounds are <= 5x the worst
+# value measured on MI355X (profiles/r03_parity_small_cases.json), not the 3e-2 placeholder of earlier rounds.
+E2E_GRAD_TOL = {"e2e_a.npz": (1e-5, 1e-4), "e2e_b.npz": (1e-5, 3e-3), "e2e_c.npz": (1e-5, 1e-4), "e2e_d.npz": (1e-5, 1e-4),
+                "e2e_northstar.npz": (1e-5, 8e-3)}
+
+
 def case_e2e_golden(b, name, with_grads=True):
     """Fused render (+ backward) against outputs and gradients recorded from the REAL reference."""
     g, meta, cfg_c, cfg_f, rays, rand, opt = e2e_inputs(name)
@@ -338,12 +373,11 @@ def case_e2e_golden(b, name, with_grads=True):
         loss, gc, gf = b.mse_loss(out["rgb_coarse"], out["rgb_fine"], tgt)
         assert abs(float(loss[2]) - float(g["loss"])) < 1e-5
         out = b.render(pc, pf, packed_c, packed_f, rays, opt, rand, training=True, g_rgb=(gc, gf))
-        for tag, plan, key, gt in (("gc_", pc, "g_params_coarse", 1e-4), ("gf_", pf, "g_params_fine", 3e-2)):
+        gc_tol, gf_tol = E2E_GRAD_TOL[name]
+        for tag, plan, key, gt in (("gc_", pc, "g_params_coarse", gc_tol), ("gf_", pf, "g_params_fine", gf_tol)):
             grads = b.unflatten(plan, out[key])
             for k, v in grads.items():
-                ref = g[tag + k]
-                scale = float(np.abs(ref).max()) + 1e-12
-                close(v, ref, gt * scale + 1e-9, 5e-4, what="%s grad %s%s" % (name, tag, k))
+                grad_close(v, g[tag + k], gt, "%s grad %s%s" % (name, tag, k), "%s_%s" % (name, b.name), key)
     b.lib.plan_destroy(pc)
     b.lib.plan_destroy(pf)
 
@@ -361,11 +395,14 @@ def case_e2e_northstar_golden(b):
     loss, gc, gf = b.mse_loss(out["rgb_coarse"], out["rgb_fine"], g["target"])
     assert abs(float(loss[2]) - float(g["loss"])) < 1e-5
     out = b.render(pc, pf, packed_c, packed_f, rays, opt, rand, training=True, g_rgb=(gc, gf))
-    for tag, plan, key, gt in (("gc_", pc, "g_params_coarse", 1e-4), ("gf_", pf, "g_params_fine", 3e-2)):
+    gc_tol, gf_tol = E2E_GRAD_TOL[name]
+    for tag, plan, key, gt in (("gc_", pc, "g_params_coarse", gc_tol), ("gf_", pf, "g_params_fine", gf_tol)):
         for k, v in b.unflatten(plan, out[key]).items():
             sums, idx, val = g["s" + tag + k], g["i" + tag + k], g["v" + tag + k]
             scale = float(sums[2]) + 1e-12                      # max |grad| of the tensor in the reference
             flat = np.asarray(v).reshape(-1)
+            worst = float(np.abs(flat[idx].astype(np.float64) - val).max()) / scale
+            note("%s_%s" % (name, b.name), **{key: max(RECORD.get("%s_%s" % (name, b.name), {}).get(key, 0.0), worst)})
             close(flat[idx], val, gt * scale + 1e-9, 5e-4, what="%s sampled grad %s%s" % (name, tag, k))
             # sums over the tensor: errors average out, so a tighter relative bound on the absolute sum
             assert abs(float(np.abs(flat).sum()) - float(sums[1])) <= (gt * 0.5) * float(sums[1]) + 1e-9, (tag, k)
@@ -374,7 +411,8 @@ def case_e2e_northstar_golden(b):
     b.lib.plan_destroy(pf)
 
 
-def case_render_vs_oracle(b, cfg, n, nc, nf, seed=5, white=False, noise=0.3, with_grads=False, tol=1e-4):
+def case_render_vs_oracle(b, cfg, n, nc, nf, seed=5, white=False, noise=0.3, with_grads=False, tol=1e-4,
+                          grad_tol=(1e-3, 5e-3), tag=""):
     """Fused render against the oracle on random-init nets of an arbitrary geometry (e.g. the 8x256 north star)."""
     gen = rng(seed)
     pc, par_c, _, packed_c = mlp_setup(b, cfg, seed=seed + 1)
@@ -411,12 +449,10 @@ def case_render_vs_oracle(b, cfg, n, nc, nf, seed=5, white=False, noise=0.3, wit
         # a fine sample moves): any two fp32 implementations differ by ~1e-3 there (see DESIGN.md "parity tolerances").
         # (1e-3 for the coarse net: with noise_std up to 1.0 and a white background the per-sample cotangents nearly
         # cancel in the early layers; the teacher-forced case_mlp_backward keeps the tight 2e-5 bound on the kernels.)
-        for plan, par, key, gt in ((pc, par_c, "g_params_coarse", 1e-3), (pf, par_f, "g_params_fine", 3e-2)):
+        for plan, par, key, gt in ((pc, par_c, "g_params_coarse", grad_tol[0]), (pf, par_f, "g_params_fine", grad_tol[1])):
             grads = b.unflatten(plan, out[key])
             for k, v in grads.items():
-                ref = par[k].grad.numpy()
-                scale = float(np.abs(ref).max()) + 1e-12
-                close(v, ref, gt * scale + 1e-9, 5e-4, what="grad %s %s" % (key, k))
+                grad_close(v, par[k].grad.numpy(), gt, "grad %s %s" % (key, k), "render_vs_oracle_%s_%s" % (tag or n, b.name), key)
     b.lib.plan_destroy(pc)
     b.lib.plan_destroy(pf)
 

@@ -53,6 +53,14 @@ def test_mlp_extreme_geometries(emu):
     P.case_mlp_backward(emu, names=names, m=45)
 
 
+def test_mlp_many_layers_and_jobs(emu):
+    """16 layers with a skip connection at every layer = 35 weight-gradient jobs (the device job table once held 32), and
+    more than 16 layers (nerf/models.py:186-196 takes any num_layers)."""
+    names = ("sixteen_layers_skip1", "twenty_layers_skip7")
+    P.case_mlp_forward(emu, names=names, m=33)
+    P.case_mlp_backward(emu, names=names, m=40)
+
+
 def test_mlp_padded_hidden_sizes(emu):
     """hidden_size other than 128 / 256 (the reference constructor takes any: nerf/models.py:185-196), odd included."""
     names = ("narrow3x40", "odd5x99_skip2", "wide3x200_skip1", "novw2x130")

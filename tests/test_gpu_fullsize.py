@@ -46,6 +46,36 @@ def _grad_stats(got, ref):
     return worst, per
 
 
+def _over(got, want, bar=1e-4):
+    """Number of rays whose output differs by more than the north star's 1e-4 bar (any channel)."""
+    err = np.abs(np.nan_to_num(np.asarray(got, np.float64)) - np.nan_to_num(np.asarray(want, np.float64)))
+    return int((err.reshape(err.shape[0], -1).max(axis=1) > bar).sum())
+
+
+def _moved(z_got, z_want, span):
+    """How far the merged fine depths sit from the oracle's: entries / rays with a sample further than 1e-3 of a coarse
+    bin away (an inverse-CDF index flip moves a sample by up to a whole bin), and the bulk statistics."""
+    d = np.abs(np.asarray(z_got, np.float64) - np.asarray(z_want, np.float64)) / span
+    big = d > 1e-3 / 64.0
+    return dict(entries=int(d.size), entries_moved=int(big.sum()), rays_moved=int(big.any(axis=1).sum()),
+                max_over_span=float(d.max()), p999_over_span=float(np.quantile(d, 0.999)), mean_over_span=float(d.mean()))
+
+
+def _torch_cuda_yardstick(c, keys, params=None):
+    """The reference's OWN GPU path as the yardstick: the oracle's torch ops (== the reference, op for op) on cuda with
+    the same weights and draws, against the same ops on the CPU.  Whatever separates these two is the cross-device
+    spread of the reference itself (rocBLAS vs MKL summation order, device libm), amplified by the inverse-CDF sampler
+    and the 2^9 encoding frequency exactly like the HIP-vs-CPU differences are."""
+    dev = torch.device("cuda", 0) if torch.cuda.is_available() else torch.device("cpu")  # (cpu: dry runs of this file only)
+    par_c, par_f = params or (c.par_c, c.par_f)
+    pc = {k: v.detach().to(dev) for k, v in par_c.items()}
+    pf = {k: v.detach().to(dev) for k, v in par_f.items()}
+    with torch.no_grad():
+        out = O.render_rays(c.rays.to(dev), pc, pf, c.cfg, c.cfg, c.opt, {k: v.to(dev) for k, v in c.rand.items()},
+                            chunksize=131072)
+    return {k: out[k].cpu().numpy() for k in keys}
+
+
 def _record(name, payload):
     out = os.path.join(ROOT, "gpurun_out")
     try:
@@ -148,7 +178,8 @@ def lego_padded_nets(gpu):
 
 def _end_to_end(c, coarse_grad_tol, fine_grad_tol, rgb_fine_tol=(1e-4, 1e-4)):
     gpu = c.gpu
-    out = gpu.render(c.plan_c, c.plan_f, c.packed_c, c.packed_f, c.rays.numpy(), c.opt, c.rnp, training=True)
+    out = gpu.render(c.plan_c, c.plan_f, c.packed_c, c.packed_f, c.rays.numpy(), c.opt, c.rnp, training=True,
+                     want_regions=("z_fine",))
     l3, gc, gf = gpu.mse_loss(out["rgb_coarse"], out["rgb_fine"], c.tgt.numpy())
     out2 = gpu.render(c.plan_c, c.plan_f, c.packed_c, c.packed_f, c.rays.numpy(), c.opt, c.rnp, training=True, g_rgb=(gc, gf))
     w = {k: v.detach().numpy() for k, v in c.want.items() if v is not None}
@@ -160,6 +191,14 @@ def _end_to_end(c, coarse_grad_tol, fine_grad_tol, rgb_fine_tol=(1e-4, 1e-4)):
         assert np.array_equal(np.isnan(out[k]), np.isnan(w[k])), k
         rel = np.abs(np.nan_to_num(out[k]) - np.nan_to_num(w[k])) / (1.0 + np.abs(np.nan_to_num(w[k])))
         rec["outputs"][k + "_rel"] = dict(max=float(rel.max()), p999=float(np.quantile(rel, 0.999)))
+    # the reference's own cross-device spread on the same batch, and where the fine samples sit
+    fine_keys = ("rgb_fine", "acc_fine", "depth_fine")
+    yard = _torch_cuda_yardstick(c, fine_keys + ("z_fine",))
+    span = float((c.rays[:, 7] - c.rays[:, 6]).max())
+    rec["torch_cuda_vs_cpu"] = {k: dict(_stats(yard[k], w[k]), rays_over_1e4=_over(yard[k], w[k])) for k in fine_keys}
+    for k in fine_keys:
+        rec["outputs"][k]["rays_over_1e4"] = _over(out[k], w[k])
+    rec["z_fine_vs_oracle"] = dict(hip=_moved(out["z_fine"], w["z_fine"], span), torch_cuda=_moved(yard["z_fine"], w["z_fine"], span))
     gcw, gcp = _grad_stats(gpu.unflatten(c.plan_c, out2["g_params_coarse"]), c.ref_gc)
     gfw, gfp = _grad_stats(gpu.unflatten(c.plan_f, out2["g_params_fine"]), c.ref_gf)
     rec["grad_coarse_worst_rel"] = gcw
@@ -173,6 +212,14 @@ def _end_to_end(c, coarse_grad_tol, fine_grad_tol, rgb_fine_tol=(1e-4, 1e-4)):
     assert rec["outputs"]["rgb_fine"]["max"] <= rgb_fine_tol[0] and rec["outputs"]["rgb_fine"]["p999"] <= rgb_fine_tol[1], \
         rec["outputs"]["rgb_fine"]
     assert rec["outputs"]["acc_fine"]["max"] <= 5e-4 and rec["outputs"]["depth_fine"]["max"] <= 2e-3, rec["outputs"]
+    # ... and must sit inside the reference's own cross-device spread (torch on this GPU vs torch on the CPU): no more
+    # rays beyond the 1e-4 bar than that pair has (x2 + 3: both counts are a handful of chaotic events), bulk no wider
+    for k in fine_keys:
+        h, y = rec["outputs"][k], rec["torch_cuda_vs_cpu"][k]
+        assert h["rays_over_1e4"] <= 2 * y["rays_over_1e4"] + 3, (k, h, y)
+        assert h["p999"] <= 2.0 * y["p999"] + 2e-6, (k, h, y)
+    zm = rec["z_fine_vs_oracle"]
+    assert zm["hip"]["rays_moved"] <= 2 * zm["torch_cuda"]["rays_moved"] + 3, zm
     assert abs(float(l3[2]) - float(c.loss)) < 1e-5
     assert gcw["max"] <= coarse_grad_tol[0] and gcw["p999"] <= coarse_grad_tol[1], gcw
     assert gfw["max"] <= fine_grad_tol[0] and gfw["p999"] <= fine_grad_tol[1], gfw
@@ -184,11 +231,12 @@ def test_lego_full_batch_every_ray_vs_oracle(lego):
     Measured on MI355X (profiles/r02_parity_fullsize.json): rgb_fine max 7.9e-5 / p99.9 4.7e-5; coarse-net gradients
     max 1.4e-4 / p99.9 3.6e-5 of max|g| (two fp32 sums of 262,144 terms in different orders); fine-net gradients max
     6.5e-4 / p99.9 3.6e-4 (behind the sampler)."""
-    _end_to_end(lego, coarse_grad_tol=(2e-4, 5e-5), fine_grad_tol=(5e-3, 1e-3))
+    _end_to_end(lego, coarse_grad_tol=(2e-4, 5e-5), fine_grad_tol=(3e-3, 1e-3))
 
 
 def test_lego_default_4x128_nets_full_batch_vs_oracle(lego_default_nets):
-    _end_to_end(lego_default_nets, coarse_grad_tol=(2e-4, 5e-5), fine_grad_tol=(5e-3, 1e-3))
+    """Measured (profiles/r02_parity_fullsize.json): coarse-net gradients 2.0e-5 / 1.0e-5, fine-net 2.6e-4 / 1.9e-4."""
+    _end_to_end(lego_default_nets, coarse_grad_tol=(1e-4, 5e-5), fine_grad_tol=(1.3e-3, 9e-4))
 
 
 def test_lego_padded_hidden_size_batch_vs_oracle(lego_padded_nets):
@@ -196,7 +244,7 @@ def test_lego_padded_hidden_size_batch_vs_oracle(lego_padded_nets):
     behind the sampler ONE ray of 2048 exceeds the 1e-4 colour bar of the BASELINE configurations (measured max 1.6e-4,
     p99.9 7.6e-5 -- a fine sample that lands in a neighbouring bin), so this case asserts p99.9 <= 1e-4 and max <= 3e-4;
     the teacher-forced fine pass below pins the kernels themselves."""
-    _end_to_end(lego_padded_nets, coarse_grad_tol=(2e-4, 5e-5), fine_grad_tol=(5e-3, 1e-3), rgb_fine_tol=(3e-4, 1e-4))
+    _end_to_end(lego_padded_nets, coarse_grad_tol=(1.7e-4, 5e-5), fine_grad_tol=(3e-3, 2e-3), rgb_fine_tol=(3e-4, 1e-4))
 
 
 def test_lego_padded_hidden_size_teacher_forced_fine_pass(lego_padded_nets):
@@ -205,8 +253,9 @@ def test_lego_padded_hidden_size_teacher_forced_fine_pass(lego_padded_nets):
 
 def test_fern_full_batch_every_ray_vs_oracle(fern):
     """BASELINE configs[3] (NDC, Dx = 39, 64 + 64, noise 1.0): with sigma noise of std 1.0 the per-sample cotangents of
-    the early layers nearly cancel, hence the wider coarse-gradient bound (see case_render_vs_oracle)."""
-    _end_to_end(fern, coarse_grad_tol=(1e-3, 3e-4), fine_grad_tol=(3e-2, 1e-2))
+    the early layers nearly cancel (case_render_vs_oracle).  Measured (profiles/r02_parity_fullsize.json): coarse-net
+    gradients max 3.5e-6 / p99.9 3.4e-6 of max|g|, fine-net 3.2e-5 / 1.8e-5: the bounds are 5x those."""
+    _end_to_end(fern, coarse_grad_tol=(1.75e-5, 1.75e-5), fine_grad_tol=(1.6e-4, 9e-5))
 
 
 def _fine_pass_units(c, sel, z, tgt):
@@ -227,7 +276,7 @@ def _fine_pass_units(c, sel, z, tgt):
     g_raw = gpu.volume_render_bwd(raw.reshape(n, s, 4), z.numpy(), rd.numpy(), g_rgb=g_rgb, noise_std=c.opt["noise_std"],
                                   noise=noise)
     gflat = gpu.mlp_bwd(c.plan_f, c.packed_f, g_raw.reshape(-1, 4), stash)
-    return raw, rgb, acc, gpu.unflatten(c.plan_f, gflat)
+    return raw, rgb, acc, gpu.unflatten(c.plan_f, gflat), dep, disp
 
 
 def _oracle_fine_grads(c, sel, z, tgt, dtype):
@@ -251,16 +300,22 @@ def _teacher_forced(c):
     paths are 2.6e-3 of max|g| away from fp64 in the SAME entry -- hence quantiles, not maxima, on the slice.)"""
     n = c.n
     z = c.want["z_fine"].detach()
-    raw, rgb, acc, grads = _fine_pass_units(c, slice(0, n), z, c.tgt)
+    raw, rgb, acc, grads, dep, disp = _fine_pass_units(c, slice(0, n), z, c.tgt)
+    far = float(c.rays[:, 7].max())
+    wd = c.want["disp_fine"].detach().numpy()
+    assert np.array_equal(np.isnan(disp), np.isnan(wd)), "disparity NaN masks differ (volume_rendering_utils.py:48)"
+    drel = np.abs(np.nan_to_num(disp) - np.nan_to_num(wd)) / (1e-30 + np.abs(np.nan_to_num(wd)))
     rec = dict(rays=n, samples_per_ray=c.nc + c.nf, raw=_stats(raw, c.want["raw_fine"].detach().numpy().reshape(-1, 4)),
                rgb_fine=_stats(rgb, c.want["rgb_fine"].detach().numpy()),
-               acc_fine=_stats(acc, c.want["acc_fine"].detach().numpy()))
+               acc_fine=_stats(acc, c.want["acc_fine"].detach().numpy()),
+               depth_fine=_stats(dep, c.want["depth_fine"].detach().numpy()), far=far,
+               disp_fine_rel=dict(max=float(drel.max()), p999=float(np.quantile(drel, 0.999))))
     worst, per = _grad_stats(grads, c.ref_gf)
     rec["grad_fine_worst_rel"] = worst
     rec["grad_fine_per_tensor"] = per
     m = 256
     sel = slice(0, m)
-    _, _, _, g_hip = _fine_pass_units(c, sel, z[sel], c.tgt[sel])
+    g_hip = _fine_pass_units(c, sel, z[sel], c.tgt[sel])[3]
     g32 = _oracle_fine_grads(c, sel, z[sel], c.tgt[sel], torch.float32)
     g64 = _oracle_fine_grads(c, sel, z[sel], c.tgt[sel], torch.float64)
     rec["slice_rays"] = m
@@ -270,6 +325,9 @@ def _teacher_forced(c):
     _record(c.name + "_teacher_forced", rec)
     assert rec["raw"]["max"] <= 1e-6, rec["raw"]
     assert rec["rgb_fine"]["max"] <= 2e-6 and rec["acc_fine"]["max"] <= 2e-6, rec
+    # depth = sum w z (volume_rendering_utils.py:44) and disparity (:46-48) on the SAME depths: fp32 round-off only
+    assert rec["depth_fine"]["max"] <= 2e-6 * far, rec["depth_fine"]
+    assert rec["disp_fine_rel"]["max"] <= 1e-5, rec["disp_fine_rel"]
     # a gradient entry is a sum over 786,432 (lego) samples: the two fp32 summation orders differ by ~sqrt(N) eps
     assert worst["max"] <= 1e-4 and worst["p999"] <= 5e-5, worst
     assert rec["slice_hip_vs_fp64"]["p999"] <= 1.5 * rec["slice_torch_fp32_vs_fp64"]["p999"] + 1e-6, rec
@@ -350,3 +408,165 @@ def test_tiny_nerf_geometry_through_the_helpers_vs_oracle():
         ref = b.grad.numpy()
         scale = float(np.abs(ref).max()) + 1e-12
         P.close(a.grad.cpu().numpy(), ref, 2e-4 * scale + 1e-9, 1e-3, what="tiny_nerf grad")
+
+
+# ---- inverse-CDF indices at full size -----------------------------------------------------------------------------------
+def test_lego_full_batch_sampler_index_flips(lego):
+    """sample_pdf_2 + the torchsearchsorted call (nerf/nerf_helpers.py:260-302) on the ORACLE's coarse depths and
+    weights of the whole lego batch (4096 rays x 128 draws): the kernel's searchsorted indices against torch's, counted.
+    Measured: 0 of 524,288.  The kernel equals the declared-order C restatement bit for bit (case_sample_pdf), so the
+    count is a property of that restatement vs torch's CPU kernels, not of the hardware."""
+    c = lego
+    z, w = c.want["z_coarse"].detach(), c.want["weights_coarse"].detach()
+    bins = 0.5 * (z[..., 1:] + z[..., :-1])                       # nerf/train_utils.py:97
+    wts = w[..., 1:-1]                                            # :99
+    u = c.rand["u"]
+    s, inds, cdf = c.gpu.sample_pdf(bins.numpy(), wts.numpy(), c.nf, u=u.numpy())
+    ws, wi, wc = O.sample_pdf(bins, wts, c.nf, u=u, return_aux=True)
+    cs, ci, cc = P.run_c_oracle(bins.numpy(), wts.numpy(), u.numpy())
+    assert np.array_equal(inds, ci) and np.array_equal(cdf, cc) and np.array_equal(s, cs), "kernel != C restatement"
+    flips = int((inds != wi.numpy()).sum())
+    d = np.abs(s - ws.numpy())
+    rec = dict(indices=int(inds.size), flipped_vs_torch=flips, rate=flips / inds.size,
+               cdf_entries_differing_from_torch=float((cdf != wc.numpy()).mean()),
+               samples_vs_torch=dict(max=float(d.max()), p999=float(np.quantile(d, 0.999)), mean=float(d.mean())))
+    _record(c.name + "_sampler_indices", rec)
+    assert flips <= 5, rec   # <= 1e-5 of the indices (SURVEY H3: 3.8e-6 per ulp of CDF perturbation)
+
+
+# ---- BASELINE configs[4]: eval_nerf.py at 800x800, inference instantiation ----------------------------------------------
+class _EvalCase:
+    """16,384 rays spread over one 800x800 pose of the 360-degree path (eval_nerf.py:158-190: perturb off, noise 0),
+    forward only: the inference instantiation of the MLP kernel (no stash) against the oracle, next to the reference's
+    own GPU path (the oracle's torch ops on cuda) as the yardstick."""
+
+    def __init__(self, gpu, name, cfg, params_c, params_f, nc, nf, white, n=16384):
+        import math
+        self.gpu, self.name, self.cfg, self.nc, self.nf = gpu, name, cfg, nc, nf
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+        H = W = 800
+        focal = 0.5 * W / math.tan(0.5 * 0.6911112070083618)
+        th, ph = math.radians(30.0), math.radians(-30.0)          # pose_spherical(30, -30, 4) (load_blender.py:32-37)
+        t = torch.eye(4)
+        t[2, 3] = 4.0
+        rp = torch.tensor([[1, 0, 0, 0], [0, math.cos(ph), -math.sin(ph), 0], [0, math.sin(ph), math.cos(ph), 0], [0, 0, 0, 1.0]])
+        rt = torch.tensor([[math.cos(th), 0, -math.sin(th), 0], [0, 1, 0, 0], [math.sin(th), 0, math.cos(th), 0], [0, 0, 0, 1.0]])
+        flip = torch.tensor([[-1.0, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]])
+        pose = flip @ rt @ rp @ t
+        ro, rd = O.get_ray_bundle(H, W, focal, pose)
+        pix = torch.arange(n) * ((H * W) // n) + 7                  # every 39th pixel: all image regions
+        ro, rd = ro.reshape(-1, 3)[pix], rd.reshape(-1, 3)[pix]
+        self.rays = O.pack_rays(ro, rd, 2.0, 6.0, rd)
+        self.n = n
+        self.opt = dict(num_coarse=nc, num_fine=nf, perturb=False, lindisp=False, white_background=white, noise_std=0.0)
+        self.rand = {}
+        self.par_c, self.par_f = params_c, params_f
+        self.plan_c, self.plan_f = gpu.make_plan(cfg), gpu.make_plan(cfg)
+        self.packed_c = gpu.pack(self.plan_c, gpu.flatten_params(self.plan_c, {k: v.numpy() for k, v in params_c.items()}))
+        self.packed_f = gpu.pack(self.plan_f, gpu.flatten_params(self.plan_f, {k: v.numpy() for k, v in params_f.items()}))
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            self.want = O.render_rays(self.rays, params_c, params_f, cfg, cfg, self.opt, None, chunksize=131072)
+        self.oracle_seconds = time.perf_counter() - t0
+
+    def close(self):
+        self.gpu.lib.plan_destroy(self.plan_c)
+        self.gpu.lib.plan_destroy(self.plan_f)
+
+
+def _eval_parity(c):
+    gpu = c.gpu
+    keys = ("rgb_coarse", "acc_coarse", "depth_coarse", "rgb_fine", "acc_fine", "depth_fine")
+    out = gpu.render(c.plan_c, c.plan_f, c.packed_c, c.packed_f, c.rays.numpy(), c.opt, None, training=False,
+                     want_regions=("z_fine",))
+    w = {k: v.numpy() for k, v in c.want.items() if v is not None}
+    yard = _torch_cuda_yardstick(c, keys + ("z_fine", "disp_fine"))
+    span = 4.0
+    rec = dict(rays=c.n, image="800x800", samples="%d+%d" % (c.nc, c.nf), oracle_seconds=round(c.oracle_seconds, 1),
+               hip_vs_cpu={k: dict(_stats(out[k], w[k]), rays_over_1e4=_over(out[k], w[k])) for k in keys},
+               torch_cuda_vs_cpu={k: dict(_stats(yard[k], w[k]), rays_over_1e4=_over(yard[k], w[k])) for k in keys},
+               z_fine_vs_oracle=dict(hip=_moved(out["z_fine"], w["z_fine"], span), torch_cuda=_moved(yard["z_fine"], w["z_fine"], span)))
+    for k in ("disp_coarse", "disp_fine"):  # NaN where acc == 0 (volume_rendering_utils.py:48): same pixels
+        assert np.array_equal(np.isnan(out[k]), np.isnan(w[k])), k
+    rec["nan_disparity_pixels"] = int(np.isnan(w["disp_fine"]).sum())
+    rec["scene"] = dict(acc_coarse_quantiles=[float(q) for q in np.quantile(w["acc_coarse"], [0.1, 0.5, 0.9])],
+                        acc_fine_quantiles=[float(q) for q in np.quantile(w["acc_fine"], [0.1, 0.5, 0.9])])
+    assert 0.05 < rec["scene"]["acc_fine_quantiles"][1] < 0.95, "degenerate scene: nothing is being tested"
+    _record(c.name, rec)
+    h, y = rec["hip_vs_cpu"], rec["torch_cuda_vs_cpu"]
+    for k in ("rgb_coarse", "acc_coarse", "depth_coarse"):      # no sampler in front: fp32 round-off
+        assert h[k]["max"] <= 1e-5, (k, h[k])
+    # the north-star bar on colour for the bulk -- unless the reference's own CPU-vs-GPU pair is wider than that on this
+    # scene; whatever exceeds the bar must be inside that spread
+    assert h["rgb_fine"]["p999"] <= max(1e-4, 2.0 * y["rgb_fine"]["p999"]), (h["rgb_fine"], y["rgb_fine"])
+    for k in ("rgb_fine", "acc_fine", "depth_fine"):
+        assert h[k]["rays_over_1e4"] <= 2 * y[k]["rays_over_1e4"] + 3, (k, h[k], y[k])
+        assert h[k]["p999"] <= 2.0 * y[k]["p999"] + 2e-6, (k, h[k], y[k])
+    return rec
+
+
+def _scene_params(cfg, seed, gain=2.45, head_gain=4.0, sigma_shift=-2.0):
+    """Random nets that hold a SCENE.  torch's default nn.Linear init shrinks the activations layer by layer, so a fresh
+    FlexibleNeRFModel renders (without sigma noise) an image that is empty or saturated at the last sample -- every ray
+    alike, nothing for the sampler to do (measured: acc_fine == 0 or == 1 for every ray of four seeds).  Scaling the
+    hidden weights by sqrt(6) (variance preserving), the two heads by 4 and shifting the sigma bias by -2 gives a
+    high-frequency density field: acc_coarse 0.77 .. 1, acc_fine 0.18 .. 1 (median 0.45), sigma > 0 on 58 % / 23 % of the
+    samples, strongly peaked coarse weights -- a harder input for the inverse CDF than a trained scene."""
+    p = O.init_params(cfg, seed=seed)
+    for k in p:
+        if k.endswith("weight") and not k.startswith(("fc_alpha", "fc_rgb")):
+            p[k] = p[k] * gain
+    p["fc_alpha.weight"] = p["fc_alpha.weight"] * head_gain
+    p["fc_rgb.weight"] = p["fc_rgb.weight"] * head_gain
+    p["fc_alpha.bias"] = p["fc_alpha.bias"] + sigma_shift
+    return p
+
+
+def test_eval_800x800_northstar_nets_inference_vs_oracle(gpu):
+    """Config 5 with the north-star geometry (8x256, 64 + 128): synthetic scene nets (_scene_params)."""
+    cfg = P.MLP_GEOMETRIES["northstar8x256"]
+    c = _EvalCase(gpu, "eval800_8x256_64+128", cfg, _scene_params(cfg, 505), _scene_params(cfg, 502), 64, 128, False)
+    try:
+        _eval_parity(c)
+    finally:
+        c.close()
+
+
+def test_eval_800x800_pretrained_lego_nets_inference_vs_oracle(gpu):
+    """Config 5 with TRAINED weights: the reference's pretrained lego-lowres nets (4x128, white background, 64 + 64 --
+    pretrained/lego-lowres/config.yml) at 800x800: sharp surfaces and empty space, the sampler's worst case."""
+    from conftest import gold
+    wts = gold("lego_lowres_weights.npz")
+    cfg = P.MLP_GEOMETRIES["default4x128"]
+    pc = {k[2:]: torch.from_numpy(wts[k]) for k in wts.files if k.startswith("c_")}
+    pf = {k[2:]: torch.from_numpy(wts[k]) for k in wts.files if k.startswith("f_")}
+    c = _EvalCase(gpu, "eval800_pretrained_4x128_64+64", cfg, pc, pf, 64, 64, True)
+    try:
+        rec = _eval_parity_trained(c)
+    finally:
+        c.close()
+    assert rec["hip_vs_cpu"]["rgb_fine"]["p999"] <= 2e-4
+
+
+def _eval_parity_trained(c):
+    """Trained nets: the reference itself moves by 6e-4 between fp32 and fp64 on this checkpoint, so only the
+    yardstick-relative statements are asserted (plus p99.9 <= 2e-4 by the caller)."""
+    gpu = c.gpu
+    keys = ("rgb_coarse", "acc_coarse", "depth_coarse", "rgb_fine", "acc_fine", "depth_fine")
+    out = gpu.render(c.plan_c, c.plan_f, c.packed_c, c.packed_f, c.rays.numpy(), c.opt, None, training=False,
+                     want_regions=("z_fine",))
+    w = {k: v.numpy() for k, v in c.want.items() if v is not None}
+    yard = _torch_cuda_yardstick(c, keys + ("z_fine",))
+    rec = dict(rays=c.n, image="800x800", samples="%d+%d" % (c.nc, c.nf), oracle_seconds=round(c.oracle_seconds, 1),
+               hip_vs_cpu={k: dict(_stats(out[k], w[k]), rays_over_1e4=_over(out[k], w[k])) for k in keys},
+               torch_cuda_vs_cpu={k: dict(_stats(yard[k], w[k]), rays_over_1e4=_over(yard[k], w[k])) for k in keys},
+               z_fine_vs_oracle=dict(hip=_moved(out["z_fine"], w["z_fine"], 4.0), torch_cuda=_moved(yard["z_fine"], w["z_fine"], 4.0)),
+               rays_hitting_the_object=int((w["acc_fine"] > 0.5).sum()))
+    _record(c.name, rec)
+    h, y = rec["hip_vs_cpu"], rec["torch_cuda_vs_cpu"]
+    for k in ("rgb_coarse", "acc_coarse"):
+        assert h[k]["max"] <= 2e-5, (k, h[k])
+    for k in ("rgb_fine", "acc_fine", "depth_fine"):
+        assert h[k]["rays_over_1e4"] <= 2 * y[k]["rays_over_1e4"] + 8, (k, h[k], y[k])
+        assert h[k]["p999"] <= 2.0 * y[k]["p999"] + 5e-6, (k, h[k], y[k])
+    return rec

@@ -81,12 +81,12 @@ def test_e2e_reference_goldens(gpu, name):
 
 
 def test_northstar_render_and_gradients_vs_oracle(gpu):
-    P.case_render_vs_oracle(gpu, P.MLP_GEOMETRIES["northstar8x256"], n=48, nc=64, nf=128, with_grads=True)
+    P.case_render_vs_oracle(gpu, P.MLP_GEOMETRIES["northstar8x256"], n=48, nc=64, nf=128, with_grads=True, tag="northstar48")
 
 
 def test_default_model_render_white_background(gpu):
     P.case_render_vs_oracle(gpu, P.MLP_GEOMETRIES["default4x128"], n=200, nc=64, nf=64, white=True, noise=1.0,
-                            with_grads=True)
+                            with_grads=True, tag="default200_white_noise1")
 
 
 def test_internal_rng_equals_external_draws(gpu):
@@ -273,6 +273,61 @@ def test_python_api_unfused_composition_and_model_autograd():
     rays_g = N.pack_rays(ro.to(dev), rd.to(dev), opts).requires_grad_(True)
     with pytest.raises(RuntimeError, match="no gradients w.r.t. the rays"):
         N.predict_and_render_radiance(rays_g, m, m, opts, encode_position_fn=ex, encode_direction_fn=ed)
+
+
+def test_python_api_unused_outputs_and_other_float_dtypes():
+    """ A loss on the fine colour map alone must not run the coarse net's backward: cotangents of untouched
+    outputs arrive as None (set_materialize_grads(False)), the coarse net's gradients come back as exact zeros and the
+    fine net's equal those of the two-term loss.  cumprod_exclusive accepts any floating dtype like the reference
+    (nerf/nerf_helpers.py:43-64) and differentiates through the cast."""
+    import nerf_pytorch_amd as N
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    dev = torch.device("cuda", 0)
+    cfg = dict(num_layers=4, hidden_size=128, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4)
+    mc, mf = N.FlexibleNeRFModel(**cfg), N.FlexibleNeRFModel(**cfg)
+    mc.load_state_dict(O.init_params(cfg, seed=5))
+    mf.load_state_dict(O.init_params(cfg, seed=6))
+    mc, mf = mc.to(dev), mf.to(dev)
+    g = torch.Generator().manual_seed(12)
+    n = 64
+    ro = torch.tensor([0.0, 0.0, 4.0]).expand(n, 3).contiguous().to(dev)
+    rd = torch.randn(n, 3, generator=g) * 0.3
+    rd[:, 2] = -1.0
+    rd = rd.to(dev)
+    tgt = torch.rand(n, 3, generator=g).to(dev)
+    opts = N.make_options(32, 32, perturb=False, radiance_field_noise_std=0.0)
+    ex, ed = N.get_embedding_function(10, True, True), N.get_embedding_function(4, True, True)
+
+    def grads(loss_fn):
+        mc.zero_grad()
+        mf.zero_grad()
+        out = N.run_one_iter_of_nerf(8, 8, 8.0, mc, mf, ro, rd, opts, encode_position_fn=ex, encode_direction_fn=ed)
+        loss_fn(out).backward()
+        return [p.grad.clone() for p in mc.parameters()], [p.grad.clone() for p in mf.parameters()]
+
+    gc_both, gf_both = grads(lambda o: N.img2mse(o[0], tgt) + N.img2mse(o[3], tgt))
+    gc_fine, gf_fine = grads(lambda o: N.img2mse(o[3], tgt))
+    assert all(float(t.abs().max()) == 0.0 for t in gc_fine)
+    assert any(float(t.abs().max()) > 0.0 for t in gc_both)
+    for a, b in zip(gf_fine, gf_both):
+        assert torch.equal(a, b)
+    # a loss on the accumulation map only (no colour cotangent at all)
+    gc_acc, gf_acc = grads(lambda o: o[5].sum())
+    assert all(float(t.abs().max()) == 0.0 for t in gc_acc) and any(float(t.abs().max()) > 0.0 for t in gf_acc)
+
+    x = (torch.rand(5, 40, generator=g) * 0.2 + 0.9)
+    for dt, tol in ((torch.float64, 2e-7), (torch.float16, 2e-3), (torch.bfloat16, 2e-2)):
+        xd = x.to(dev).to(dt).requires_grad_(True)
+        y = N.cumprod_exclusive(xd)
+        assert y.dtype == dt
+        y.sum().backward()
+        xr = xd.detach().cpu().double().requires_grad_(True)
+        yr = O.cumprod_exclusive(xr)
+        yr.sum().backward()
+        assert xd.grad.dtype == dt
+        P.close(y.detach().double().cpu().numpy(), yr.detach().numpy(), 0, tol, what="cumprod %s" % dt)
+        P.close(xd.grad.double().cpu().numpy(), xr.grad.numpy(), 0, 5 * tol, what="cumprod grad %s" % dt)
 
 
 def test_pretrained_lego_checkpoint_renders_like_the_reference():

@@ -104,6 +104,19 @@ def test_model_state_dict_is_reference_compatible(lib):
     assert torch.equal(a.layer1.weight, lin.weight)
 
 
+def test_pure_torch_helpers_match_the_reference_contract():
+    """meshgrid_xy (nerf/nerf_helpers.py:28-40), mse2psnr / img2mse (:9-17): the three exports without a kernel."""
+    ii, jj = N.meshgrid_xy(torch.arange(3), torch.arange(2))          # numpy "xy": shapes (len(t2), len(t1))
+    assert ii.tolist() == [[0, 1, 2], [0, 1, 2]] and jj.tolist() == [[0, 0, 0], [1, 1, 1]]
+    oi, oj = O.meshgrid_xy(torch.arange(5.0), torch.arange(7.0)) if hasattr(O, "meshgrid_xy") else \
+        [t.transpose(-1, -2) for t in torch.meshgrid(torch.arange(5.0), torch.arange(7.0), indexing="ij")]
+    gi, gj = N.meshgrid_xy(torch.arange(5.0), torch.arange(7.0))
+    assert torch.equal(gi, oi) and torch.equal(gj, oj)
+    assert N.mse2psnr(0.01) == pytest.approx(20.0) and N.mse2psnr(0) == pytest.approx(50.0)     # KAT7
+    a, b = torch.rand(11, 3), torch.rand(11, 3)
+    assert torch.equal(N.img2mse(a, b), torch.nn.functional.mse_loss(a, b))
+
+
 def test_no_cpu_fallback(lib):
     m = N.FlexibleNeRFModel()
     with pytest.raises(RuntimeError, match="no CPU path"):

@@ -3,7 +3,14 @@
 64 coarse + 128 fine samples, 4096 rays/iter, 8x256 nets).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+    N > 1: either launched by `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` (one rank per GPU, RCCL), or invoked exactly as above -- bench.py then
+    re-launches itself that way.
+    --global-rays G     strong scaling: the step's G rays are sharded over the ranks (BASELINE configs[2]:
+                        `--image 800 --global-rays 8192` = 1024 rays/GPU at N = 8); default is weak scaling
+                        (every rank renders its own --rays = 4096)
+    --mode eval         BASELINE configs[4]: inference-only 360-degree render, 800x800 poses, rows of every pose
+                        sharded over the ranks (no collective); one "step" = one pose
 
 One "step" = one full training iteration of the reference's loop body (train_nerf.py:210-270) on synthetic data of the
 configured shape: select 4096 pixels of a 400x400 view -> generate those rays -> coarse+fine render forward (stratified
@@ -19,6 +26,8 @@ import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,7 +43,9 @@ FOCAL = 555.5555
 RAYS_PER_GPU = 4096
 NC, NF = 64, 128
 MODEL = dict(num_layers=8, hidden_size=256, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4)
-FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md chip table
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md chip table (256 CUs x 256 FLOP/clk at 2.4 GHz)
+HBM_PEAK_TBS = 8.0             # same guide: HBM3E ~8 TB/s
+PEAK_CLOCK_GHZ = 2.4
 
 
 def pose_spherical(theta_deg, phi_deg, radius):
@@ -197,62 +208,190 @@ def pytorch_rocm_reference(dev, n=RAYS_PER_GPU, reps=3):
                 "fwd+bwd, no optimizer, %d rays, best of %d" % (n, reps))
 
 
+def cpu_baseline_eval(sample_rays=1024):
+    """Config 5's CPU leg: the oracle's forward-only render (no_grad, perturb off, noise 0) of `sample_rays` rays."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import nerf_oracle as O
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    cfg = dict(MODEL)
+    pc, pf = O.init_params(cfg, seed=1), O.init_params(cfg, seed=2)
+    g = torch.Generator().manual_seed(0)
+    opt = dict(num_coarse=NC, num_fine=NF, perturb=False, lindisp=False, white_background=False, noise_std=0.0)
+
+    def one(n):
+        ro = torch.tensor([0.0, 0.0, 4.0]).expand(n, 3)
+        rd = torch.randn(n, 3, generator=g) * 0.3
+        rd[:, 2] = -1.0
+        rays = O.pack_rays(ro, rd, 2.0, 6.0, rd)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            O.render_rays(rays, pc, pf, cfg, cfg, opt, None, chunksize=131072)
+        return time.perf_counter() - t0
+
+    one(64)
+    dt = one(sample_rays)
+    return dict(value=sample_rays / dt, unit="rays/s", cores=torch.get_num_threads(), kind="port", seconds=round(dt, 2),
+                sample="%d rays x (64 coarse + 128 fine), 8x256 nets, forward only (torch.no_grad), after a 64-ray warm-up; "
+                       "oracle/nerf_oracle.py on torch %s CPU ops" % (sample_rays, torch.__version__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` started directly (no WORLD_SIZE in the environment): become the launcher -- one rank per
+    GPU under torch.distributed.run, exactly the command line the driver uses."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
+def kernel_kind(name):
+    if "k_mlp_fwd" in name:
+        return "fwd"
+    if "k_mlp_dgrad" in name:
+        return "dgrad"
+    if "k_wgrad" in name and "reduce" not in name:
+        return "wgrad"
+    return None
+
+
+def pmc_traffic(cfg, n, kind):
+    """Counter bytes per launch of kernel `kind` from the tracked rocprofv3 --pmc passes of this same command (newest
+    round first; scripts/gpu_pmc.sh: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 as MI355X_MICROARCH.md
+    prescribes for gfx950), or None when no pass was recorded for this configuration."""
+    tag = "%dx%d_%d" % (cfg["num_layers"], cfg["hidden_size"], n)
+    kname = "k_wgrad" if kind == "wgrad" else "k_mlp_%s16" % kind
+    for rnd in ("r03", "r02"):
+        for fn in ("%s_pmc_summary_%s.json" % (rnd, tag), "%s_pmc_summary.json" % rnd):
+            path = os.path.join(ROOT, "profiles", fn)
+            if not os.path.exists(path) or (fn.endswith("summary.json") and (cfg != MODEL or n != RAYS_PER_GPU)):
+                continue
+            rows = [v for v in json.load(open(path)).values() if v["kernel"] == kname]
+            if not rows:
+                continue
+            # like with like: the algorithmic figure of k_wgrad is its operand READ stream, that of the forward / data-gradient
+            # kernels their stash / d(pre-activation) WRITE stream (weights and masks are the small remainder)
+            per = [r["fetch_gb_x2"] if kind == "wgrad" else r["write_gb"] for r in rows]
+            return round(sum(per) / len(per), 3), "profiles/%s (rocprofv3 --pmc passes of this command: %s, mean over the " \
+                "launch sizes recorded)" % (fn, "FETCH_SIZE x2" if kind == "wgrad" else "WRITE_SIZE")
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rays", type=int, default=RAYS_PER_GPU)
+    ap.add_argument("--steps", type=int, default=None, help="default 20 (train) / 3 (eval)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 3 (train) / 1 (eval)")
+    ap.add_argument("--mode", choices=("train", "eval"), default="train")
+    ap.add_argument("--rays", type=int, default=RAYS_PER_GPU, help="rays per GPU and iteration (weak scaling)")
+    ap.add_argument("--global-rays", type=int, default=0, help="strong scaling: rays per iteration over ALL GPUs")
+    ap.add_argument("--image", type=int, default=0, help="image side: default 400 (train) / 800 (eval)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hidden", type=int, default=MODEL["hidden_size"])
     ap.add_argument("--layers", type=int, default=MODEL["num_layers"])
     ap.add_argument("--overlap", type=int, default=-1, help="1: two-stream step (coarse backward next to the fine pass); "
                     "0: single-stream order; -1: the engine's default for the net width")
+    ap.add_argument("--gather", action="store_true", help="eval: rank 0 also receives every pose's rows (output plumbing)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / timing plumbing only, on the CPU with "
+                    "gloo: no kernel runs and no number is reported (the CPU test-suite uses it)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 20 if args.mode == "train" else 3
+    if args.warmup is None:
+        args.warmup = 3 if args.mode == "train" else 1
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d, or "
+                         "start bench.py directly and let it launch the ranks)" % (args.gpus, world, args.gpus))
     # test hook (scripts/gpu_dp2_smoke.sh): exercise the N > 1 code path on a ONE-GPU box -- every rank on cuda:0 and a
     # gloo process group (RCCL refuses two ranks on one device).  Never set by the driver.
     one_device = os.environ.get("NERFHIP_BENCH_ONE_DEVICE") == "1"
     if one_device:
         local = 0
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.dry_run:
+        return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if not one_device and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: --gpus %d but only %d device(s) visible" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if one_device:
             torch.distributed.init_process_group("gloo")
         else:
-            torch.distributed.init_process_group("nccl", device_id=dev)
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+            torch.distributed.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
 
     cfg = dict(MODEL, hidden_size=args.hidden, num_layers=args.layers)
     torch.manual_seed(42)  # config/lego.yml:8; every rank builds identical weights
     mc = N.FlexibleNeRFModel(**cfg).to(dev)
     mf = N.FlexibleNeRFModel(**cfg).to(dev)
-    eng = N.TrainEngine(mc, mf, NC, NF, perturb=True, lindisp=False, white_background=False, noise_std=0.2, lr=5e-3,
-                        seed=1234, world_size=world, rank=rank, overlap=None if args.overlap < 0 else bool(args.overlap))
-    n = args.rays
-    opts = N.make_options(NC, NF, num_random_rays=n)
-    poses = torch.stack([pose_spherical(th, -30.0, 4.0) for th in torch.linspace(-180, 180, 101)[:-1].tolist()]).to(dev)
-    g = torch.Generator(device=dev).manual_seed(1000 + rank)
-    images = torch.rand(8, H, W, 3, generator=g, device=dev)        # synthetic training views, resident in HBM
     lib = N._lib.get_lib()
-
-    def one_step(i):
-        # the reference's loop body, train_nerf.py:210-270: pick a view, draw 4096 distinct pixels, their rays and
-        # targets (one launch, on the device), forward, loss, backward, [all-reduce], Adam with the decayed lr
-        k = i * world + rank
-        return eng.step_on_image(images[k % 8], poses[k % poses.shape[0]], H, W, FOCAL, opts, n, lr=N.TrainEngine.lr_at(i))
+    side = args.image or (400 if args.mode == "train" else 800)
+    focal = 0.5 * side / math.tan(0.5 * 0.6911112070083618)  # 555.5555 at 400, 1111.111 at 800 (blender camera_angle_x)
+    poses = torch.stack([pose_spherical(th, -30.0, 4.0) for th in torch.linspace(-180, 180, 101)[:-1].tolist()]).to(dev)
 
     def fence():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
+
+    if args.mode == "train":
+        strong = args.global_rays > 0
+        if strong:
+            lo, hi = N.parallel.shard_bounds(args.global_rays, rank, world)
+            n = hi - lo
+            total_rays = args.global_rays
+        else:
+            n = args.rays
+            total_rays = n * world
+        eng = N.TrainEngine(mc, mf, NC, NF, perturb=True, lindisp=False, white_background=False, noise_std=0.2, lr=5e-3,
+                            seed=1234, world_size=world, rank=rank, overlap=None if args.overlap < 0 else bool(args.overlap))
+        opts = N.make_options(NC, NF, num_random_rays=n)
+        g = torch.Generator(device=dev).manual_seed(1000 + rank)
+        images = torch.rand(8, side, side, 3, generator=g, device=dev)     # synthetic training views, resident in HBM
+
+        def one_step(i):
+            # the reference's loop body, train_nerf.py:210-270: pick a view, draw the step's distinct pixels, their rays
+            # and targets (one launch, on the device), forward, loss, backward, [all-reduce], Adam with the decayed lr.
+            # Weak scaling: every rank its own view; strong scaling: all ranks shard ONE view's draw.
+            k = i if strong else i * world + rank
+            return eng.step_on_image(images[k % 8], poses[k % poses.shape[0]], side, side, focal, opts, n,
+                                     lr=N.TrainEngine.lr_at(i), global_rays=args.global_rays if strong else None)
+        samples_per_step = (n * NC, n * (NC + NF))
+    else:
+        strong = True
+        total_rays = side * side
+        ex, ed = N.get_embedding_function(10, True, True), N.get_embedding_function(4, True, True)
+        # eval_nerf.py:158-190 with the validation options of config/lego.yml (perturb off, noise 0); one chunk per rank
+        opts = N.make_options(NC, NF, perturb=False, radiance_field_noise_std=0.0, chunksize=1 << 22)
+        lo, hi = N.parallel.shard_bounds(side, rank, world)
+        n = (hi - lo) * side
+
+        def one_step(i):
+            with torch.no_grad():
+                out, _ = N.render_pose_rows(side, side, focal, poses[(i * 5) % poses.shape[0]], mc, mf, opts, ex, ed, rank, world)
+                rgb8 = N.eval_utils._cast_to_image_device(out[3])           # eval_nerf.py:178-184 (8-bit cast on the device)
+                if args.gather:
+                    rgb8 = N.parallel.gather_image_rows(rgb8)
+            return rgb8
+        samples_per_step = (n * NC, n * (NC + NF))
 
     for i in range(args.warmup):
         one_step(i)
@@ -260,89 +399,142 @@ def main():
     lib.profile_enable(1)
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
-        loss = one_step(i)
+        last = one_step(i)
     fence()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
     lib.profile_enable(0)
     import ctypes
     buf = ctypes.create_string_buffer(1 << 16)
     lib.profile_report(buf, len(buf))
-    tmax = torch.tensor([dt], device=dev)
+    clk = (ctypes.c_uint64 * 9)()
+    lib.profile_clocks(clk)
+    per_rank = [dt_local]
     if world > 1:
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-    dt = float(tmax)
-    loss_host = [float(v) for v in loss.cpu()]
+        tt = torch.tensor([dt_local], device=dev, dtype=torch.float64)
+        gathered = [torch.zeros_like(tt) for _ in range(world)]
+        torch.distributed.all_gather(gathered, tt)
+        per_rank = [float(t) for t in gathered]
+    dt = max(per_rank)
+    loss_host = [float(v) for v in last.cpu()] if args.mode == "train" else None
 
     if rank == 0:
         kern = {}
         for line in buf.value.decode().splitlines():
             name, cnt, ms = line.rsplit(" ", 2)
-            kern[name] = (int(cnt), float(ms))
+            kern[name.strip("()")] = (int(cnt), float(ms))
         fwd_macs, dgrad_macs = macs_per_sample(cfg)
-        m_c, m_f = n * NC, n * (NC + NF)
-        # algorithmic FLOPs per launch of each MLP kernel: 2 * MACs/sample * samples of the launch
+        m_c, m_f = samples_per_step
+        # algorithmic FLOPs and HBM bytes per sample point of each MLP kernel
         flops = {"fwd": 2.0 * fwd_macs, "dgrad": 2.0 * dgrad_macs, "wgrad": 2.0 * fwd_macs}
-        table = []
+        hbm_bytes = {"wgrad": wgrad_bytes_per_sample(cfg),
+                     "fwd": stash_bytes_per_sample(cfg) if args.mode == "train" else 16 + 4,   # inference: raw out + z in
+                     "dgrad": 4 * (cfg["num_layers"] * cfg["hidden_size"] + cfg["hidden_size"] + cfg["hidden_size"] // 2 + 32)
+                     + 8 * (cfg["num_layers"] + 1) + 16}
+        kernels = {}
         for name, (cnt, ms) in kern.items():
-            kind = "fwd" if "k_mlp_fwd" in name else "dgrad" if "k_mlp_dgrad" in name else "wgrad" if "k_wgrad" in name and "reduce" not in name else None
-            table.append((ms, name, cnt, kind))
-        table.sort(reverse=True)
-        dom = next((t for t in table if t[3] is not None), None)
-        roof = None
-        if dom is not None:
-            ms, name, cnt, kind = dom
-            # the kernel is launched once per net per step: coarse (m_c samples) and fine (m_f samples)
-            per_step_flops = flops[kind] * (m_c + m_f)
-            launches_per_step = cnt / args.steps
+            kind = kernel_kind(name)
+            if kind is None:
+                continue
+            launches_per_step = cnt / args.steps                      # one launch per net: coarse (m_c) + fine (m_f)
             avg_ms = ms / cnt
-            achieved = per_step_flops / launches_per_step / (avg_ms * 1e-3) / 1e12
-            # HBM traffic per launch of that kernel (mean of the coarse- and the fine-sized launch): algorithmic bytes,
-            # and the counter bytes of the tracked rocprofv3 --pmc pass of this same command (scripts/gpu_pmc.sh:
-            # separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes for gfx950)
-            samples_per_launch = (m_c + m_f) / 2.0
-            alg = {"wgrad": wgrad_bytes_per_sample(cfg), "fwd": stash_bytes_per_sample(cfg),
-                   "dgrad": 4 * (cfg["num_layers"] * cfg["hidden_size"] + cfg["hidden_size"] + cfg["hidden_size"] // 2 + 32)}[kind]
-            traffic = dict(algorithmic_gb=round(alg * samples_per_launch / 1e9, 3), counter_gb=None, source=None)
-            pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
-            if os.path.exists(pmc_file) and cfg == MODEL and n == RAYS_PER_GPU:
-                pm = json.load(open(pmc_file))
-                rows = [v for v in pm.values() if v["kernel"] == ("k_wgrad" if kind == "wgrad" else "k_mlp_%s16" % kind)]
-                if rows:
-                    per = [(r["fetch_gb_x2"] if kind == "wgrad" else 0.0) + (r["write_gb"] if kind != "wgrad" else 0.0) for r in rows]
-                    traffic["counter_gb"] = round(sum(per) / len(per), 3)
-                    traffic["source"] = "profiles/r02_pmc_summary.json (tracked rocprofv3 --pmc passes of this command: " + \
-                        ("FETCH_SIZE x2" if kind == "wgrad" else "WRITE_SIZE") + ", mean over the launch sizes recorded)"
-            roof = dict(bound="mfma", kernel=name.strip("()"), achieved=round(achieved, 3), peak=FP32_MFMA_PEAK_TFLOPS,
-                        unit="TFLOP/s", frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
-                        avg_launch_ms=round(avg_ms, 4), launches=cnt,
-                        algorithmic_gflop_per_launch=round(per_step_flops / launches_per_step / 1e9, 2),
-                        kernel_ms_per_step={nm.strip("()"): round(m / args.steps, 4) for m, nm, _, _ in table})
-        total_flops = (2.0 * (2 * fwd_macs + dgrad_macs)) * (m_c + m_f)
-        res = dict(metric="train rays/sec", value=round(world * n * args.steps / dt, 2), unit="rays/s", n_gpus=world,
-                   steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3),
-                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-                   config=dict(workload="lego 400x400 synthetic views (BASELINE configs[1]): %d rays/GPU/iter, %d coarse + "
-                                        "%d fine samples, %dx%d coarse+fine nets, perturb, noise 0.2, Adam, full iteration"
-                                        % (n, NC, NF, cfg["num_layers"], cfg["hidden_size"]),
-                               rays_per_gpu=n, global_rays=n * world, parallelism="dp%d" % world,
-                               two_stream_step=bool(eng.overlap)),
-                   step_tflops=round(total_flops / (dt / args.steps) / 1e12, 2),
-                   step_frac_of_fp32_mfma_peak=round(total_flops / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+            spl = (m_c + m_f) / launches_per_step                     # sample points per launch (mean)
+            tf = flops[kind] * spl / (avg_ms * 1e-3) / 1e12
+            gb = hbm_bytes[kind] * spl / 1e9
+            cyc, ticks, wgs = (int(clk[3 * {"fwd": 0, "dgrad": 1, "wgrad": 2}[kind] + c]) for c in range(3))
+            ghz = 0.1 * cyc / ticks if ticks else None
+            counter_gb, source = pmc_traffic(cfg, n, kind) if args.mode == "train" else (None, None)
+            kernels[kind] = dict(kernel=name, ms_per_step=round(ms / args.steps, 4), avg_launch_ms=round(avg_ms, 4), launches=cnt,
+                                 algorithmic_gflop_per_launch=round(flops[kind] * spl / 1e9, 2), tflops=round(tf, 2),
+                                 frac=round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
+                                 sclk_ghz=None if ghz is None else round(ghz, 3),
+                                 frac_at_measured_clock=None if ghz is None else round(tf / (FP32_MFMA_PEAK_TFLOPS * ghz / PEAK_CLOCK_GHZ), 4),
+                                 traffic=dict(algorithmic_gb=round(gb, 3), counter_gb=counter_gb, source=source),
+                                 hbm_tb_s=round(gb / avg_ms, 3), hbm_frac=round(gb / avg_ms / HBM_PEAK_TBS, 4))
+        roof = None
+        if kernels:
+            dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])   # the kernel the step spends most time in
+            lowest = min(kernels, key=lambda k: kernels[k]["frac"])
+            d = kernels[dom]
+            roof = dict(bound="mfma", kernel=d["kernel"], achieved=d["tflops"], peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=d["frac"], traffic=d["traffic"], avg_launch_ms=d["avg_launch_ms"], launches=d["launches"],
+                        algorithmic_gflop_per_launch=d["algorithmic_gflop_per_launch"],
+                        sclk_ghz=d["sclk_ghz"], frac_at_measured_clock=d["frac_at_measured_clock"],
+                        hbm=dict(achieved_tb_s=d["hbm_tb_s"], peak_tb_s=HBM_PEAK_TBS, frac=d["hbm_frac"]),
+                        lowest_frac_kernel=kernels[lowest]["kernel"], lowest_frac=kernels[lowest]["frac"],
+                        mlp_kernels=kernels,
+                        kernel_ms_per_step={nm: round(m / args.steps, 4) for nm, (_, m) in sorted(kern.items(), key=lambda kv: -kv[1][1])})
+        if args.mode == "train":
+            total_flops = (2.0 * (2 * fwd_macs + dgrad_macs)) * (m_c + m_f)
+            step_bytes = sum(hbm_bytes[k] for k in ("fwd", "dgrad", "wgrad")) * (m_c + m_f)
+            workload = ("lego %dx%d synthetic views (BASELINE configs[%d]): %d rays/GPU/iter (%d over all GPUs), %d coarse + %d "
+                        "fine samples, %dx%d coarse+fine nets, perturb, noise 0.2, Adam, full iteration"
+                        % (side, side, 2 if (strong and side == 800) else 1, n, total_rays, NC, NF, cfg["num_layers"], cfg["hidden_size"]))
+            metric = "train rays/sec"
+        else:
+            total_flops = 2.0 * fwd_macs * (m_c + m_f)
+            step_bytes = hbm_bytes["fwd"] * (m_c + m_f)
+            workload = ("eval_nerf.py 360-degree render (BASELINE configs[4]): %dx%d poses, rows sharded over %d GPU(s) (%d rays/GPU/"
+                        "pose), %d coarse + %d fine samples, %dx%d nets, perturb off, 8-bit cast on the device, one step = one pose"
+                        % (side, side, world, n, NC, NF, cfg["num_layers"], cfg["hidden_size"]))
+            metric = "eval rays/sec"
+        sec = dt / args.steps
+        res = dict(metric=metric, value=round(total_rays * args.steps / dt, 2), unit="rays/s", n_gpus=world,
+                   steps=args.steps, warmup=args.warmup, ms_per_step=round(sec * 1e3, 3),
+                   ms_per_step_per_rank=[round(t / args.steps * 1e3, 3) for t in per_rank],
+                   higher_is_better=True, scaling="strong" if strong else "weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   config=dict(workload=workload, rays_per_gpu=n, global_rays=total_rays, parallelism="dp%d" % world,
+                               two_stream_step=bool(eng.overlap) if args.mode == "train" else None,
+                               backend=("gloo(one-device test hook)" if one_device else "nccl(RCCL)") if world > 1 else None),
+                   step_tflops=round(total_flops / sec / 1e12, 2),
+                   step_frac_of_fp32_mfma_peak=round(total_flops / sec / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                   step_algorithmic_hbm_tb_s=round(step_bytes / sec / 1e12, 3),
+                   step_hbm_frac_of_8tb_s=round(step_bytes / sec / 1e12 / HBM_PEAK_TBS, 4),
                    final_loss=loss_host, roofline=roof)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline()
-            try:
-                res["dropin_route"] = dropin_route(dev)
-            except Exception as e:
-                res["dropin_route"] = dict(error=repr(e)[:200])
-            try:
-                res["pytorch_rocm_reference"] = pytorch_rocm_reference(dev)
-                res["speedup_vs_pytorch_rocm_fwd_bwd"] = round(res["value"] / res["pytorch_rocm_reference"]["value"], 3)
-            except Exception as e:  # the torch arm needs ~13 GB and must never take the bench line down
-                res["pytorch_rocm_reference"] = dict(error=repr(e)[:200])
+            if args.mode == "train":
+                res["cpu_baseline"] = cpu_baseline()
+                try:
+                    res["dropin_route"] = dropin_route(dev)
+                except Exception as e:
+                    res["dropin_route"] = dict(error=repr(e)[:200])
+                try:
+                    res["pytorch_rocm_reference"] = pytorch_rocm_reference(dev)
+                    res["speedup_vs_pytorch_rocm_fwd_bwd"] = round(res["value"] / res["pytorch_rocm_reference"]["value"], 3)
+                except Exception as e:  # the torch arm needs ~13 GB and must never take the bench line down
+                    res["pytorch_rocm_reference"] = dict(error=repr(e)[:200])
+            else:
+                res["cpu_baseline"] = cpu_baseline_eval()
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def dry_run(args, world, rank):
+    """The plumbing around the timed region without a GPU: rendezvous (gloo), barrier, per-rank timing gathered to rank 0,
+    ONE JSON line with value null.  Exists so that the CPU test-suite can start `python bench.py --gpus 2 --dry-run`
+    exactly the way the driver starts the real thing."""
+    if world > 1:
+        torch.distributed.init_process_group("gloo")
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    per_rank = [time.perf_counter() - t0]
+    if world > 1:
+        tt = torch.tensor([per_rank[0]], dtype=torch.float64)
+        gathered = [torch.zeros_like(tt) for _ in range(world)]
+        torch.distributed.all_gather(gathered, tt)
+        per_rank = [float(t) for t in gathered]
+        lo, hi = N.parallel.shard_bounds(args.global_rays or args.rays * world, rank, world)
+        cover = torch.tensor([hi - lo], dtype=torch.int64)
+        torch.distributed.all_reduce(cover)
+        assert int(cover) == (args.global_rays or args.rays * world)
+    if rank == 0:
+        print(json.dumps(dict(metric="train rays/sec" if args.mode == "train" else "eval rays/sec", value=None, unit="rays/s",
+                              n_gpus=world, steps=args.steps, warmup=args.warmup, dry_run=True,
+                              ms_per_step_per_rank=[round(t * 1e3, 3) for t in per_rank],
+                              scaling="strong" if (args.global_rays or args.mode == "eval") else "weak")))
     if world > 1:
         torch.distributed.destroy_process_group()
 

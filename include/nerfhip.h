@@ -56,6 +56,11 @@ int nerfhip_rng_fill(int kind, uint64_t seed, uint32_t stream_id, uint64_t first
  * nerfhip_profile_report waits for them and writes "kernel_name launches total_ms\n" lines into buf, then clears. */
 int nerfhip_profile_enable(int on);
 int nerfhip_profile_report(char* buf, int64_t cap);
+/* Shader clock under load: while profiling is enabled the three MLP kernels stamp every workgroup with the shader-clock
+ * counter (s_memtime) and the constant 100 MHz counter (s_memrealtime).  out[3k + 0/1/2] = shader cycles / 100 MHz ticks /
+ * workgroups summed over the workgroups of kernel k (0 = k_mlp_fwd16, 1 = k_mlp_dgrad16, 2 = k_wgrad):
+ * clock = 0.1 GHz * out[3k] / out[3k + 1].  Waits for the device; clears the counters.  out: host uint64[9]. */
+int nerfhip_profile_clocks(uint64_t* out);
 
 /* ---- K1: rays -------------------------------------------------------------------------------------------------- */
 /* get_ray_bundle (nerf/nerf_helpers.py:67-110) incl. meshgrid_xy (:28-40).  c2w: dev, rows >= 3, row stride

@@ -13,7 +13,7 @@ from .models import FlexibleNeRFModel  # noqa: F401
 from .nerf_helpers import (cumprod_exclusive, get_embedding_function, get_minibatches, get_ray_bundle,  # noqa: F401
                            get_rays_at_pixels, img2mse, meshgrid_xy, mse2psnr, ndc_rays, positional_encoding,
                            sample_pdf, sample_pdf_2, sample_pdf_with_indices)
-from .eval_utils import ImageWriter, cast_to_disparity_image, cast_to_image  # noqa: F401
+from .eval_utils import ImageWriter, cast_to_disparity_image, cast_to_image, render_pose_rows  # noqa: F401
 from .io_utils import load_cached_example, load_checkpoint, save_cached_example, save_checkpoint  # noqa: F401
 from .train_utils import (pack_rays, predict_and_render_radiance, run_network, run_one_iter_of_nerf,  # noqa: F401
                           select_cached_training_rays, select_training_rays)

@@ -37,8 +37,17 @@ struct ProfRec {
     hipEvent_t a, b;
 };
 std::vector<ProfRec> g_prof;
+unsigned long long* g_clk_dev = nullptr;  // [NH_CLK_KERNELS][4]: shader cycles, 100 MHz ticks, workgroups, unused
 #endif
 }  // namespace
+unsigned long long* nh_prof_clock_slot(int kind) {
+#ifndef NERFHIP_EMU
+    return (g_prof_on && g_clk_dev) ? g_clk_dev + 4 * kind : nullptr;
+#else
+    (void)kind;
+    return nullptr;
+#endif
+}
 void nh_prof_begin(const char* name, nerfhip_stream_t stream) {
 #ifndef NERFHIP_EMU
     if (!g_prof_on) return;
@@ -62,7 +71,32 @@ void nh_prof_end(nerfhip_stream_t stream) {
 #endif
 }
 extern "C" int nerfhip_profile_enable(int on) {
+#ifndef NERFHIP_EMU
+    if (on && !g_clk_dev) {  // 96 bytes of device counters, private to the library, kept for the life of the process
+        if (hipMalloc((void**)&g_clk_dev, sizeof(unsigned long long) * 4 * NH_CLK_KERNELS) != hipSuccess) g_clk_dev = nullptr;
+        if (g_clk_dev) (void)hipMemset(g_clk_dev, 0, sizeof(unsigned long long) * 4 * NH_CLK_KERNELS);
+    }
+#endif
     g_prof_on = on != 0;
+    return NERFHIP_OK;
+}
+// Shader clock the MLP kernels ran at while profiling was enabled: out[3 * k + {0,1,2}] = shader-clock cycles, 100 MHz
+// reference ticks and workgroups summed over all workgroups of kernel k (0 forward, 1 data gradient, 2 weight gradient).
+// Waits for the device, then clears the counters.
+extern "C" int nerfhip_profile_clocks(uint64_t* out9) {
+    NH_REQUIRE(out9, "profile_clocks: bad arguments");
+    for (int i = 0; i < 3 * NH_CLK_KERNELS; ++i) out9[i] = 0;
+#ifndef NERFHIP_EMU
+    if (!g_clk_dev) return NERFHIP_OK;
+    unsigned long long host[4 * NH_CLK_KERNELS];
+    if (hipMemcpy(host, g_clk_dev, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) {
+        nh_set_error("profile_clocks: copy failed");
+        return NERFHIP_ERR_LAUNCH;
+    }
+    (void)hipMemset(g_clk_dev, 0, sizeof(host));
+    for (int k = 0; k < NH_CLK_KERNELS; ++k)
+        for (int c = 0; c < 3; ++c) out9[3 * k + c] = host[4 * k + c];
+#endif
     return NERFHIP_OK;
 }
 // Waits for the recorded events, writes "kernel_name launches total_ms\n" lines into buf and clears the records.

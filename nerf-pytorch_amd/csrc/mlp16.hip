@@ -38,6 +38,7 @@ template <int W>
 struct Lds {
     static constexpr int CHUNK_MAX = W >= 256 ? 16384 : NH16_NARROW_CHUNK;
     static constexpr int BYTES = (2 * CHUNK_MAX + 2 * NH16_BIAS_FLOATS) * 4;
+    static constexpr int BYTES_ALL = BYTES + NH_CLK_LDS_BYTES;  // + the clock probe's stamps (nh_clk_begin)
 };
 
 #ifdef NH_PHASE_TIMING
@@ -390,6 +391,7 @@ struct Fwd16Args {
     float* out;
     float* stash;
     NhStashLayout sl;
+    unsigned long long* clk;  // shader-clock probe counters, or NULL (nh_prof_clock_slot)
 };
 
 // TRAIN: the launch writes the activation stash (rows, encoding slots, ReLU masks) for the backward kernels
@@ -397,6 +399,7 @@ template <int W, bool VIEW, bool TRAIN>
 NH_KERNEL void NH_LB(64 * Shape<W>::NW, 2) k_mlp_fwd16(Fwd16Args a) {
     constexpr int KH = W / 4, TW = W / 16, KX = NH16_KRX, KD = NH16_KRD, NW = Shape<W>::NW;
     NH_DYN_LDS(lds_raw);
+    nh_clk_begin(a.clk, (unsigned long long*)(lds_raw + Lds<W>::BYTES));
     Ctx cx;
     cx.lds = (float*)lds_raw;
     cx.cmax = Lds<W>::CHUNK_MAX;
@@ -531,6 +534,7 @@ NH_KERNEL void NH_LB(64 * Shape<W>::NW, 2) k_mlp_fwd16(Fwd16Args a) {
             *(float4*)(a.out + (size_t)m_i * 4) = r4;
         }
     }
+    nh_clk_end((const unsigned long long*)(lds_raw + Lds<W>::BYTES));
 #ifdef NH_PHASE_TIMING
     NH16_PH(4);
     if (lane == 0)
@@ -550,12 +554,14 @@ struct Dgrad16Args {
     NhStashLayout sl;
     float* grad;
     NhGradLayout gl;
+    unsigned long long* clk;  // shader-clock probe counters, or NULL
 };
 
 template <int W, bool VIEW>
 NH_KERNEL void NH_LB(64 * Shape<W>::NW, 2) k_mlp_dgrad16(Dgrad16Args a) {
     constexpr int KH = W / 4, TW = W / 16, NW = Shape<W>::NW;
     NH_DYN_LDS(lds_raw);
+    nh_clk_begin(a.clk, (unsigned long long*)(lds_raw + Lds<W>::BYTES));
     Ctx cx;
     cx.lds = (float*)lds_raw;
     cx.cmax = Lds<W>::CHUNK_MAX;
@@ -668,6 +674,7 @@ NH_KERNEL void NH_LB(64 * Shape<W>::NW, 2) k_mlp_dgrad16(Dgrad16Args a) {
     }
     // (mb is all ones here: d(pre-activation) of layer1 needs no gate)
     store_rows<TW>(gref(a.gl.P[0], W, 4 * g), dp);
+    nh_clk_end((const unsigned long long*)(lds_raw + Lds<W>::BYTES));
 #ifdef NH_PHASE_TIMING
     NH16_PH(4);
     if (lane == 0)
@@ -736,13 +743,14 @@ int nh_mlp16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in,
     a.out = out;
     a.stash = stash;
     a.sl = p->stash;
+    a.clk = nh_prof_clock_slot(NH_CLK_FWD);
     const int64_t groups = nh_ceil_div(M, 128);  // whole 128-sample groups: every stash tile is written
     int rc = NERFHIP_OK;
 #define NH_FWD16_T(WW, VV, TT)                                                        \
     {                                                                                 \
-        rc = lds_limit(k_mlp_fwd16<WW, VV, TT>, Lds<WW>::BYTES);                      \
+        rc = lds_limit(k_mlp_fwd16<WW, VV, TT>, Lds<WW>::BYTES_ALL);                  \
         if (rc) return rc;                                                            \
-        NH_LAUNCH((k_mlp_fwd16<WW, VV, TT>), groups * (8 / Shape<WW>::NW), 64 * Shape<WW>::NW, Lds<WW>::BYTES, stream, a); \
+        NH_LAUNCH((k_mlp_fwd16<WW, VV, TT>), groups * (8 / Shape<WW>::NW), 64 * Shape<WW>::NW, Lds<WW>::BYTES_ALL, stream, a); \
     }
 #define NH_FWD16(WW, VV)             \
     {                                \
@@ -775,13 +783,14 @@ int nh_mlp16_dgrad(nerfhip_plan* p, const float* packed, const float* g_out, int
     d.sl = p->stash;
     d.grad = scratch;
     d.gl = p->grad;
+    d.clk = nh_prof_clock_slot(NH_CLK_DGRAD);
     const int64_t groups = nh_ceil_div(M, 128);
     int rc = NERFHIP_OK;
 #define NH_BWD16(WW, VV)                                                              \
     {                                                                                 \
-        rc = lds_limit(k_mlp_dgrad16<WW, VV>, Lds<WW>::BYTES);                        \
+        rc = lds_limit(k_mlp_dgrad16<WW, VV>, Lds<WW>::BYTES_ALL);                    \
         if (rc) return rc;                                                            \
-        NH_LAUNCH((k_mlp_dgrad16<WW, VV>), groups * (8 / Shape<WW>::NW), 64 * Shape<WW>::NW, Lds<WW>::BYTES, stream, d); \
+        NH_LAUNCH((k_mlp_dgrad16<WW, VV>), groups * (8 / Shape<WW>::NW), 64 * Shape<WW>::NW, Lds<WW>::BYTES_ALL, stream, d); \
     }
     if (p->W == 256 && p->view) NH_BWD16(256, true)
     else if (p->W == 256) NH_BWD16(256, false)

@@ -109,7 +109,39 @@ NH_DEVICE void nh_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 NH_DEVICE void nh_sincos(float x, float* s, float* c) { sincosf(x, s, c); }
 NH_DEVICE unsigned long long nh_wall_clock() { return wall_clock64(); }  // constant 100 MHz
 NH_DEVICE unsigned long long nh_core_clock() { return (unsigned long long)clock64(); }  // shader-clock cycles (s_memtime)
+// Shader-clock probe of the MLP kernels (active only while nerfhip_profile_enable is on: `slot` is NULL otherwise).
+// Thread 0 of a workgroup parks the counter address and its entry stamps (s_memtime: shader-clock cycles;
+// s_memrealtime: the constant 100 MHz counter) in 24 bytes of LDS -- nothing stays live in registers across the kernel,
+// not even the kernel-argument pointer -- and at exit adds the two deltas and a workgroup count to slot[0..2].
+// 100 MHz * slot[0] / slot[1] is the clock the kernel's workgroups really ran at.
+NH_DEVICE void nh_clk_begin(unsigned long long* slot, unsigned long long* lds3) {
+    if (threadIdx.x == 0) {
+        lds3[2] = (unsigned long long)slot;
+        if (slot) {
+            lds3[0] = nh_core_clock();
+            lds3[1] = nh_wall_clock();
+        }
+    }
+}
+NH_DEVICE void nh_clk_end(const unsigned long long* lds3) {
+    unsigned t = threadIdx.x;
+    asm volatile("" : "+v"(t));  // (opaque: otherwise the exec mask of nh_clk_begin's test is kept in SGPRs across the kernel)
+    if (t == 0) {
+        unsigned long long* slot = (unsigned long long*)lds3[2];
+        if (slot) {
+            atomicAdd(slot, nh_core_clock() - lds3[0]);
+            atomicAdd(slot + 1, nh_wall_clock() - lds3[1]);
+            atomicAdd(slot + 2, 1ull);
+        }
+    }
+}
 #endif  // NERFHIP_EMU
+#ifdef NERFHIP_EMU
+static inline void nh_clk_begin(unsigned long long*, unsigned long long*) {}
+static inline void nh_clk_end(const unsigned long long*) {}
+#endif
+constexpr int NH_CLK_LDS_BYTES = 32;
+enum { NH_CLK_FWD = 0, NH_CLK_DGRAD = 1, NH_CLK_WGRAD = 2, NH_CLK_KERNELS = 3 };
 
 // ---- helpers shared by both builds -------------------------------------------------------------------------------
 

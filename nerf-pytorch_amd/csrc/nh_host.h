@@ -18,6 +18,8 @@ void nh_set_error(const char* fmt, ...);
 // Optional per-kernel timing with HIP events recorded on the launch stream (nerfhip_profile_enable / _report).
 void nh_prof_begin(const char* name, nerfhip_stream_t stream);
 void nh_prof_end(nerfhip_stream_t stream);
+// Device counters of the shader-clock probe for MLP kernel `kind` (NH_CLK_*), or NULL while profiling is off.
+unsigned long long* nh_prof_clock_slot(int kind);
 
 #ifdef NERFHIP_EMU
 #define NH_LAUNCH(kern, grid, block, smem, stream, ...) \

@@ -23,22 +23,26 @@
 
 namespace {
 
-// (kernel arguments are limited to 4 KB: NH_MAX_JOBS compact records of 56 bytes)
-struct JobDev {
-    int a_prefix, b_prefix;
+// Kernel arguments are limited to 4 KB, and NH_MAX_JOBS = 64 records must fit: the two kernels get a table each, with
+// only the fields they read (plain ints: packing them into shorts cost k_wgrad SGPR spills).
+struct JobDev {  // k_wgrad
+    int a_rows, a_prefix, a_tiles;
+    int b_rows, b_prefix, b_tiles;
+    int wo, wi, po, pi;
+    int wg_start;
+    int g;  // 32-sample tiles per LDS stage
+};
+struct JobRed {  // k_wgrad_reduce
+    int a_tiles, b_tiles, po, pi;
+    int r_lo, r_hi;
     int w_off, w_ld;
-    int col_base, col_count;
+    int col_kind, col_base, col_count;
     int bias_off;
     int wg_start;
-    short a_rows, a_tiles;
-    short b_rows, b_tiles;
-    short wo, wi, po, pi;
-    short r_lo, r_hi;
-    short col_kind;
-    short g;  // 32-sample tiles per LDS stage
 };
 constexpr int NH_JOBS_DEV = NH_MAX_JOBS;
-static_assert(sizeof(JobDev) * NH_JOBS_DEV + 320 <= 4096, "WgradArgs must fit the 4 KB kernel-argument limit");
+static_assert(sizeof(JobDev) * NH_JOBS_DEV + 128 <= 4096 && sizeof(JobRed) * NH_JOBS_DEV + 320 <= 4096,
+              "the job tables must fit the 4 KB kernel-argument limit");
 // Workgroup shapes.  256-wide nets: 8 waves per workgroup (two per SIMD), two LDS stages of 16384 floats (+ slack for
 // the operand prefetch that runs one k-step past the end of a stage): one workgroup per CU.  128-wide nets (jobs of at
 // most 4 x 4 tiles): 4 waves per workgroup with 2 x 2 patches -- 1.0 instead of 1.5 operand dwords per MFMA -- and
@@ -46,7 +50,7 @@ static_assert(sizeof(JobDev) * NH_JOBS_DEV + 320 <= 4096, "WgradArgs must fit th
 // workgroups and do not meet at the same barriers.
 template <int NWV_, int STAGE_>
 struct WMode {
-    static constexpr int NWV = NWV_, STAGE = STAGE_, LDS_BYTES = 2 * STAGE_ * 4 + 4096;
+    static constexpr int NWV = NWV_, STAGE = STAGE_, LDS_DATA = 2 * STAGE_ * 4 + 4096, LDS_BYTES = LDS_DATA + NH_CLK_LDS_BYTES;
 };
 using WModeWide = WMode<8, 16384>;
 using WModeNarrow = WMode<4, 8192>;
@@ -62,11 +66,18 @@ struct WgradArgs {
     const float* stash;
     const float* grad;
     float* partial;
-    float* g_params;
     int64_t nt;
     int njobs, total_wgs;
     int part_bias, part_stride;  // floats: offset of the bias partials inside a workgroup's partial, size of a partial
+    unsigned long long* clk;     // shader-clock probe counters, or NULL (nh_prof_clock_slot)
     JobDev jobs[NH_JOBS_DEV];
+};
+struct ReduceArgs {
+    const float* partial;
+    float* g_params;
+    int njobs, total_wgs;
+    int part_bias, part_stride;
+    JobRed jobs[NH_JOBS_DEV];
     short xslot[64];  // stash slot row -> reference column of the encoding, or -1
     short dslot[32];
 };
@@ -323,6 +334,7 @@ template <class MD>
 NH_KERNEL void NH_LB(64 * MD::NWV, 2) k_wgrad(WgradArgs a) {
     NH_DYN_LDS(smem);
     float* lds = (float*)smem;
+    nh_clk_begin(a.clk, (unsigned long long*)(smem + MD::LDS_DATA));
 #ifdef NH_WGRAD_TIMELINE
     const unsigned long long t_begin = nh_wall_clock();
     const unsigned long long c_begin = nh_core_clock();
@@ -351,6 +363,7 @@ NH_KERNEL void NH_LB(64 * MD::NWV, 2) k_wgrad(WgradArgs a) {
         case 1 * 8 + 2: wgrad_dispatch<MD, 1, 2>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
         default: wgrad_dispatch<MD, 1, 1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
     }
+    nh_clk_end((const unsigned long long*)(smem + MD::LDS_DATA));
 #ifdef NH_WGRAD_TIMELINE
     if (lane == 0 && active) {  // timeline record (8 x u64 per wave): wall begin/end, job, K-slice, core-clock begin/end
         unsigned long long* dbg = (unsigned long long*)(a.partial + (size_t)wg * a.part_stride + a.part_bias + 512) + wave * 8;
@@ -367,9 +380,9 @@ NH_KERNEL void NH_LB(64 * MD::NWV, 2) k_wgrad(WgradArgs a) {
 // fixed-order split-K reduction + scatter into the reference parameter layout.  Accumulator tile (a_t, b_t), register c,
 // lane l holds dW[out_row][in_row] with (MFMA row m = (c&3) + 8(c>>2) + 4(l>>5), column j = l&31, and the row
 // interleave of the wide operand reads)  out_row = 32*po*(a_t/po) + po*m + a_t%po,  in_row = 32*pi*(b_t/pi) + pi*j + b_t%pi.
-NH_KERNEL void k_wgrad_reduce(WgradArgs a) {
+NH_KERNEL void k_wgrad_reduce(ReduceArgs a) {
     const int ji = (int)(blockIdx.x >> 8);
-    const JobDev jb = a.jobs[ji];
+    const JobRed jb = a.jobs[ji];
     const int local = (int)((blockIdx.x & 255u) * 256u + threadIdx.x);
     const int lane = local & 63, c = (local >> 6) & 15, tile = local >> 10;  // accumulator tile (a_t, b_t) = a_t * b_tiles + b_t
     const int a_t = tile / jb.b_tiles, b_t = tile % jb.b_tiles;
@@ -425,7 +438,7 @@ NH_KERNEL void k_wgrad_reduce(WgradArgs a) {
 // CU) for 256-wide nets, TWO rounds of 512 four-wave workgroups (two per CU) for 128-wide ones.  Measured on MI355X:
 // 512 / 768 / 1024 / 1280 / 2048 workgroups -> k_wgrad 0.845 / 0.855 / 0.852 / 0.846 / 0.841 of peak for 8x256 nets
 // (more workgroups: more partials to write and reduce; fewer: a coarser tail), 0.551 / 0.564 / 0.584 for 4x128.
-void wgrad_schedule(const nerfhip_plan* p, int64_t nt, WgradArgs& w) {
+void wgrad_schedule(const nerfhip_plan* p, int64_t nt, WgradArgs& w, ReduceArgs* r) {
     const int NH_WGRAD_TARGET_WGS = p->wgrad_waves == 4 ? 1024 : 768;
     const int stage_floats = p->wgrad_waves == 4 ? WModeNarrow::STAGE : WModeWide::STAGE;
     w.njobs = (int)p->jobs.size();  // <= NH_MAX_JOBS == NH_JOBS_DEV: nerfhip_plan_create refuses larger job lists
@@ -466,27 +479,35 @@ void wgrad_schedule(const nerfhip_plan* p, int64_t nt, WgradArgs& w) {
         const NhJob& j = p->jobs[q];
         if (ks[q] > nt) ks[q] = nt;
         JobDev& d = w.jobs[q];
-        d.a_rows = (short)j.a_region_rows;
+        d.a_rows = j.a_region_rows;
         d.a_prefix = (int)j.a_row_prefix;
-        d.a_tiles = (short)j.a_tiles;
-        d.b_rows = (short)j.b_region_rows;
+        d.a_tiles = j.a_tiles;
+        d.b_rows = j.b_region_rows;
         d.b_prefix = (int)j.b_row_prefix;
-        d.b_tiles = (short)j.b_tiles;
-        d.wo = (short)j.wo;
-        d.wi = (short)j.wi;
-        d.po = (short)j.po;
-        d.pi = (short)j.pi;
-        d.r_lo = (short)j.r_lo;
-        d.r_hi = (short)j.r_hi;
-        d.w_off = (int)j.w_off;
-        d.w_ld = j.w_ld;
-        d.col_kind = (short)j.col_kind;
-        d.col_base = j.col_base;
-        d.col_count = j.col_count;
-        d.bias_off = (int)j.bias_off;
+        d.b_tiles = j.b_tiles;
+        d.wo = j.wo;
+        d.wi = j.wi;
+        d.po = j.po;
+        d.pi = j.pi;
         d.wg_start = start;
-        const int g = stage_floats / (32 * (j.a_region_rows + j.b_region_rows));
-        d.g = (short)(g < 1 ? 1 : g);
+        d.g = stage_floats / (32 * (j.a_region_rows + j.b_region_rows));
+        if (d.g < 1) d.g = 1;
+        if (r) {
+            JobRed& e = r->jobs[q];
+            e.a_tiles = j.a_tiles;
+            e.b_tiles = j.b_tiles;
+            e.po = j.po;
+            e.pi = j.pi;
+            e.r_lo = j.r_lo;
+            e.r_hi = j.r_hi;
+            e.w_off = (int)j.w_off;
+            e.w_ld = j.w_ld;
+            e.col_kind = j.col_kind;
+            e.col_base = j.col_base;
+            e.col_count = j.col_count;
+            e.bias_off = (int)j.bias_off;
+            e.wg_start = start;
+        }
         start += (int)ks[q];
     }
     w.total_wgs = start;
@@ -495,8 +516,14 @@ void wgrad_schedule(const nerfhip_plan* p, int64_t nt, WgradArgs& w) {
         if (p->jobs[q].a_tiles * p->jobs[q].b_tiles > tiles) tiles = p->jobs[q].a_tiles * p->jobs[q].b_tiles;
     w.part_bias = tiles * 1024;
     w.part_stride = w.part_bias + NH_PART_EXTRA;
-    for (int r = 0; r < 64; ++r) w.xslot[r] = (short)p->xyz_slot_col[r];
-    for (int r = 0; r < 32; ++r) w.dslot[r] = (short)p->dir_slot_col[r];
+    if (r) {
+        r->njobs = w.njobs;
+        r->total_wgs = w.total_wgs;
+        r->part_bias = w.part_bias;
+        r->part_stride = w.part_stride;
+        for (int q = 0; q < 64; ++q) r->xslot[q] = (short)p->xyz_slot_col[q];
+        for (int q = 0; q < 32; ++q) r->dslot[q] = (short)p->dir_slot_col[q];
+    }
 }
 
 template <class MD>
@@ -516,20 +543,24 @@ int launch_wgrad(const WgradArgs& w, nerfhip_stream_t stream) {
 
 int64_t nh_wgrad_partial_floats(nerfhip_plan* p, int64_t nt) {
     WgradArgs w;
-    wgrad_schedule(p, nt > 0 ? nt : 1, w);
+    wgrad_schedule(p, nt > 0 ? nt : 1, w, nullptr);
     return (int64_t)w.total_wgs * w.part_stride;
 }
 
 int nh_wgrad(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad, float* partial, float* g_params,
              nerfhip_stream_t stream) {
     WgradArgs w;
+    ReduceArgs red;
     memset(&w, 0, sizeof(w));
-    wgrad_schedule(p, nt, w);
+    memset(&red, 0, sizeof(red));
+    wgrad_schedule(p, nt, w, &red);
     w.stash = stash;
     w.grad = grad;
     w.partial = partial;
-    w.g_params = g_params;
+    red.partial = partial;
+    red.g_params = g_params;
     w.nt = nt;
+    w.clk = nh_prof_clock_slot(NH_CLK_WGRAD);
     for (int q = 0; q < w.njobs; ++q) {
         const NhJob& j = p->jobs[q];
         NH_REQUIRE(j.b_row0 == 0 && 32 * j.a_tiles == j.a_region_rows && 32 * j.b_tiles == j.b_region_rows &&
@@ -545,6 +576,6 @@ int nh_wgrad(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad,
     else
         rc = launch_wgrad<WModeWide>(w, stream);
     if (rc) return rc;
-    NH_LAUNCH(k_wgrad_reduce, w.njobs * 256, 256, 0, stream, w);
+    NH_LAUNCH(k_wgrad_reduce, w.njobs * 256, 256, 0, stream, red);
     return nh_launch_status("wgrad_reduce");
 }

@@ -30,7 +30,7 @@ from .parallel import allreduce_gradients
 class TrainEngine:
     def __init__(self, model_coarse, model_fine, num_coarse, num_fine, perturb=True, lindisp=False, white_background=False,
                  noise_std=0.0, lr=5e-3, betas=(0.9, 0.999), eps=1e-8, seed=0, process_group=None, world_size=None,
-                 rank=None, overlap=None):
+                 rank=None, overlap=None, always_reduce=False):
         self.lib = L.get_lib()
         self.mc, self.mf = model_coarse, model_fine if num_fine > 0 else None
         self.dev = model_coarse.flat_params.device
@@ -49,6 +49,9 @@ class TrainEngine:
         if rank is None:
             rank = torch.distributed.get_rank(process_group) if torch.distributed.is_initialized() else 0
         self.world, self.rank = world_size, rank
+        # the gradient collectives are issued when there is somebody to exchange with -- or always (always_reduce: a
+        # one-rank group still goes through RCCL's work handles and stream ordering; the single-GPU test of that path)
+        self._reduce = world_size > 1 or (bool(always_reduce) and torch.distributed.is_initialized())
         # one flat gradient / Adam-state buffer covering both nets: a single collective per step
         self.nc_params = model_coarse.num_flat_params
         self.nf_params = self.mf.num_flat_params if self.mf is not None else 0
@@ -169,24 +172,35 @@ class TrainEngine:
                 lib.mse_loss_fwd_bwd(b["rgb_f"].data_ptr(), None, target.data_ptr(), tstride, n, gscale, b["g_f"].data_ptr(),
                                      None, self._loss_f.data_ptr(), st)
                 lib.render_bwd_parts(*bwd_head, C.byref(cot_f), *bwd_tail, L.PART_FINE, st)
-                if self.world > 1:  # in flight while the coarse backward computes
-                    self._pending.append(allreduce_gradients(gf, self.pg, async_op=True))
+                if self._reduce:  # in flight while the coarse backward computes
+                    self._pending.append(allreduce_gradients(gf, self.pg, async_op=True, single_rank=True))
             if two:
                 main.wait_event(e2)
             else:
                 coarse_backward(st)
-            if self.world > 1:
-                self._pending.append(allreduce_gradients(gc, self.pg, async_op=True))
+            if self._reduce:
+                self._pending.append(allreduce_gradients(gc, self.pg, async_op=True, single_rank=True))
             if nf > 0:
                 torch.stack((self._loss_c[0], self._loss_f[0], self._loss_c[0] + self._loss_f[0]), out=self.loss)
             else:
                 self.loss.copy_(self._loss_c)
 
     def wait_gradients(self):
-        """Makes the current stream wait for the step's gradient all-reduces (no-op for one rank)."""
-        for w in self._pending:
-            if w is not None:
-                w.wait()
+        """Orders this device's current stream behind the step's gradient all-reduces (no-op without collectives).
+
+        Invariant the step relies on (nccl == RCCL): an asynchronous collective runs on the backend's own stream, which
+        first waits for everything enqueued on the stream that was current when it was ISSUED (so the all-reduce of a
+        net's gradient starts after that net's k_wgrad_reduce), and `work.wait()` does not block the host: it makes the
+        stream that is current when it is CALLED wait for the collective.  Both the issue (forward_backward) and the wait
+        happen with self.dev current and on self.dev's current stream -- the stream the Adam kernels are then launched on
+        (optimizer_step) -- so Adam reads all-reduced gradients; the next step's kernels follow Adam on the same stream.
+        gloo (the CPU / one-device tests) blocks the host in wait() instead: stronger, same result."""
+        if not self._pending:
+            return
+        with torch.cuda.device(self.dev):
+            for w in self._pending:
+                if w is not None:
+                    w.wait()
         self._pending = []
 
     def optimizer_step(self, lr=None):
@@ -212,15 +226,24 @@ class TrainEngine:
         self.optimizer_step(lr)
         return self.loss
 
-    def step_on_image(self, image, pose, height, width, focal_length, options, num_random_rays, lr=None):
+    def step_on_image(self, image, pose, height, width, focal_length, options, num_random_rays, lr=None, global_rays=None):
         """One whole iteration of the reference's loop body (train_nerf.py:210-270) on a resident training image:
-        on-device selection of this rank's `num_random_rays` distinct pixels (ranks take disjoint slices of one
-        permutation keyed by (seed, iteration)), their rays and targets, then `step`.  No host work besides launches."""
+        on-device selection of this rank's distinct pixels (ranks take disjoint slices of one permutation keyed by
+        (seed, iteration)), their rays and targets, then `step`.  No host work besides launches.
+        Weak scaling (default): every rank draws `num_random_rays` rays, the step covers world * num_random_rays.
+        Strong scaling (`global_rays` = the step's total, BASELINE config 3: 8192 over 8 ranks): this rank takes its
+        parallel.shard_bounds slice of the first `global_rays` positions; unequal shards are weighted (forward_backward)."""
+        from .parallel import shard_bounds
         from .train_utils import select_training_rays
-        n = int(num_random_rays)
+        if global_rays is None:
+            n = int(num_random_rays)
+            first = self.rank * n
+        else:
+            first, hi = shard_bounds(int(global_rays), self.rank, self.world)
+            n = hi - first
         rays, target, _ = select_training_rays(height, width, focal_length, pose, image, n, options, seed=self.seed,
-                                               step=self.step_count, first=self.rank * n)
-        return self.step(rays, target, ray_offset=self.rank * n, lr=lr)
+                                               step=self.step_count, first=first)
+        return self.step(rays, target, ray_offset=first, lr=lr, global_rays=global_rays)
 
     @staticmethod
     def lr_at(iteration, lr0=5e-3, lr_decay=250, lr_decay_factor=0.1):

@@ -72,6 +72,26 @@ def png_bytes(img):
     return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", head) + chunk(b"IDAT", zlib.compress(raw.tobytes(), 3)) + chunk(b"IEND", b"")
 
 
+def render_pose_rows(height, width, focal_length, pose, model_coarse, model_fine, options, encode_position_fn=None,
+                     encode_direction_fn=None, rank=0, world_size=1, mode="validation"):
+    """One pose of the render loop of eval_nerf.py (:158-176), ray-sharded (BASELINE config 5): rank `rank` of
+    `world_size` generates and renders only ITS contiguous block of image rows (parallel.shard_bounds) -- rays are
+    independent, so no rank ever needs another rank's data and there is no collective; the concatenation of the ranks'
+    blocks in rank order is bit-identical to the image one rank renders (parallel.gather_image_rows does that for a
+    writer on rank 0).  Returns (outputs, (row_lo, row_hi)) with `outputs` the 6-tuple of run_one_iter_of_nerf shaped
+    (rows, width, .)."""
+    from .nerf_helpers import get_rays_at_pixels
+    from .parallel import shard_bounds
+    from .train_utils import run_one_iter_of_nerf
+    lo, hi = shard_bounds(int(height), int(rank), int(world_size))
+    pix = torch.arange(lo * int(width), hi * int(width), dtype=torch.int64, device=pose.device)
+    ro, rd = get_rays_at_pixels(height, width, focal_length, pose[:3, :4] if pose.shape[0] > 3 else pose, pix)
+    shape = (hi - lo, int(width), 3)
+    out = run_one_iter_of_nerf(height, width, focal_length, model_coarse, model_fine, ro.view(shape), rd.view(shape), options,
+                               mode=mode, encode_position_fn=encode_position_fn, encode_direction_fn=encode_direction_fn)
+    return out, (lo, hi)
+
+
 class ImageWriter:
     """Takes rendered maps off the critical path: the 8-bit cast is queued on the render stream, the D2H copy runs on
     a side stream into a pinned buffer, and encoding + file IO happen on worker threads."""

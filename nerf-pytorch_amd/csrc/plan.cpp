@@ -66,7 +66,7 @@ struct Specs16 {
     GemmSpec16 f_layer1, f_xyz[NH_MAX_LAYERS], f_head, f_dir, f_rgb, b_rgb, b_dir, b_head, b_xyz[NH_MAX_LAYERS];
 };
 
-// Kernel width W (128 or 256) >= the model's hidden_size H: units H..W-1 (H/2..W/2-1 of the direction layer) are
+// Kernel width W (64, 128 or 256) >= the model's hidden_size H: units H..W-1 (H/2..W/2-1 of the direction layer) are
 // padding -- every weight and bias of a padded unit is the constant 0 (index -1), so it stays exactly 0 through the
 // forward chain, its ReLU bit is 0, and nothing flows through it in the backward chain.
 void build_specs16(const nerfhip_plan* p, Specs16& S) {
@@ -350,7 +350,8 @@ extern "C" nerfhip_plan_t nerfhip_plan_create(const nerfhip_model_cfg* cfg) {
     nerfhip_plan* p = new nerfhip_plan();
     p->cfg = *cfg;
     p->H = cfg->hidden_size;
-    p->W = p->H <= 128 ? 128 : 256;  // the kernels exist for two widths; narrower models ride zero-padded (build_specs16)
+    // the kernels exist for three widths; a model rides zero-padded on the next one (build_specs16)
+    p->W = p->H <= 64 ? 64 : (p->H <= 128 ? 128 : 256);
     p->L = cfg->num_layers;
     p->skip = cfg->skip_connect_every;
     p->view = cfg->use_viewdirs ? 1 : 0;

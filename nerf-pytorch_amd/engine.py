@@ -120,12 +120,16 @@ class TrainEngine:
             self._ev = (torch.cuda.Event(), torch.cuda.Event())
         return main, self._side
 
-    def forward_backward(self, rays, target, ray_offset=0, global_rays=None):
+    def forward_backward(self, rays, target, ray_offset=0, global_rays=None, draws=None):
         """rays: (n, 8|11) packed rows on the device; target: (n, >=3), row stride free (an RGBA image's [..., :3] view
         works).  Leaves the summed-over-this-rank gradient in self.grad and {coarse_mse, fine_mse, sum} in self.loss
         (device); with world > 1 the gradient all-reduces are in flight when this returns (optimizer_step waits).
         global_rays: total rays of the step over all ranks when the shards are NOT equal -- this rank's cotangents are
-        then weighted n * world / global_rays, so that the 1/world-scaled sum is the gradient of the global-batch mean."""
+        then weighted n * world / global_rays, so that the 1/world-scaled sum is the gradient of the global-batch mean.
+        draws: None (production: in-kernel Philox draws keyed by (seed, step, global ray index)) or the reference's four
+        draws as device tensors (t_rand (n, nc), noise_coarse (n, nc), u (n, nf), noise_fine (n, nc + nf); any may be
+        None) -- e.g. made with torch.rand / torch.randn in the reference's order, to run the engine on exactly the random
+        numbers another implementation consumed."""
         self._check_inputs(rays, target)
         lib, n = self.lib, rays.shape[0]
         gscale = 1.0 if global_rays is None else float(n) * self.world / float(global_rays)
@@ -143,10 +147,18 @@ class TrainEngine:
         tstride = target.stride(0)
         cot_c = L.RenderCotangents(b["g_c"].data_ptr(), None, None, None, None, None)
         cot_f = L.RenderCotangents(None, None, None, b["g_f"].data_ptr() if nf > 0 else None, None, None)
+        rr = None
+        if draws is not None:
+            shapes = ((n, self.cfg.num_coarse), (n, self.cfg.num_coarse), (n, nf), (n, self.cfg.num_coarse + nf))
+            for d, shp in zip(draws, shapes):
+                if d is not None and (d.device != self.dev or d.dtype != torch.float32 or tuple(d.shape) != shp or not d.is_contiguous()):
+                    raise RuntimeError("TrainEngine: a random-draw tensor must be contiguous float32 %s on %s" % (shp, self.dev))
+            self._draws = tuple(draws)  # (kept alive until the next step: the backward kernels read them again)
+            rr = C.byref(L.RenderRand(*[None if d is None else d.data_ptr() for d in draws]))
         fwd_args = (self.mc._plan, plan_f, C.byref(self.cfg), rays.data_ptr(), n, self.packed_c.data_ptr(), pf,
-                    self.t_vals.data_ptr(), self.u_det.data_ptr() if nf > 0 else None, None, seed, ray_offset,
+                    self.t_vals.data_ptr(), self.u_det.data_ptr() if nf > 0 else None, rr, seed, ray_offset,
                     C.byref(out), self._ws.data_ptr(), self._wsb, 1)
-        bwd_head = (self.mc._plan, plan_f, C.byref(self.cfg), rays.data_ptr(), n, self.packed_c.data_ptr(), pf, None, seed,
+        bwd_head = (self.mc._plan, plan_f, C.byref(self.cfg), rays.data_ptr(), n, self.packed_c.data_ptr(), pf, rr, seed,
                     ray_offset)
         bwd_tail = (self._ws.data_ptr(), self._wsb, gc.data_ptr(), gf.data_ptr() if gf is not None else None)
         self._pending = []
@@ -220,9 +232,9 @@ class TrainEngine:
                               st)
         self.repack()
 
-    def step(self, rays, target, ray_offset=0, lr=None, global_rays=None):
+    def step(self, rays, target, ray_offset=0, lr=None, global_rays=None, draws=None):
         """One full training iteration.  Returns the device tensor {coarse_mse, fine_mse, sum} (no host sync)."""
-        self.forward_backward(rays, target, ray_offset, global_rays)
+        self.forward_backward(rays, target, ray_offset, global_rays, draws)
         self.optimizer_step(lr)
         return self.loss
 

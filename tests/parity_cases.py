@@ -353,8 +353,10 @@ def e2e_inputs(name):
 # Bounds on max|g_hip - g_ref| / max|g_ref| per parameter tensor of the reference-generated end-to-end goldens: (coarse
 # net, fine net).  The fine net sits behind the inverse-CDF sampler; the bounds are <= 5x the worst
 # value measured on MI355X (profiles/r03_parity_small_cases.json), not the 3e-2 placeholder of earlier rounds.
-E2E_GRAD_TOL = {"e2e_a.npz": (1e-5, 1e-4), "e2e_b.npz": (1e-5, 3e-3), "e2e_c.npz": (1e-5, 1e-4), "e2e_d.npz": (1e-5, 1e-4),
-                "e2e_northstar.npz": (1e-5, 8e-3)}
+# Measured (coarse / fine; MI355X | CPU wave emulator):  a 4.6e-7 / 3.5e-6 | 3.8e-7 / 3.5e-6;  b 7.9e-7 / 4.9e-6 | 5.5e-7 / 4.5e-4;
+# c 4.8e-7 / 1.5e-6 | 4.7e-7 / 8.6e-7;  d 6.5e-7 / 2.2e-6 | 4.8e-7 / 2.3e-6;  northstar 3.1e-7 / 1.7e-3 | 3.1e-7 / 1.7e-3.
+E2E_GRAD_TOL = {"e2e_a.npz": (4e-6, 2e-5), "e2e_b.npz": (4e-6, 2.3e-3), "e2e_c.npz": (4e-6, 8e-6), "e2e_d.npz": (4e-6, 1.2e-5),
+                "e2e_northstar.npz": (4e-6, 8.6e-3)}
 
 
 def case_e2e_golden(b, name, with_grads=True):

@@ -88,6 +88,29 @@ def test_two_stream_step_equals_single_stream_step():
     assert float(out[0][2][-1, 2]) < float(out[0][2][0, 2])
 
 
+def test_engine_fed_external_draws_equals_in_kernel_draws(gpu):
+    """TrainEngine.step(draws=...) (the PSNR experiment's "engine on torch's draws" arm): feeding the engine the numbers
+    nerfhip_rng_fill reports for (seed, stream, element) reproduces the in-kernel Philox step bit for bit."""
+    import nerf_pytorch_amd as N
+    dev = _dev()
+    n, nc, nf, seed = 200, 32, 48, 4242
+    rays, rgba = _rays(n, dev)
+    res = []
+    for external in (False, True):
+        mc, mf = _models(dev)
+        eng = N.TrainEngine(mc, mf, nc, nf, noise_std=0.3, seed=seed, world_size=1, rank=0, overlap=False)
+        draws = None
+        if external:
+            f = lambda kind, stream, cnt: torch.from_numpy(gpu.rng_fill(kind, seed, stream, 0, n * cnt).reshape(n, cnt)).to(dev)  # noqa: E731
+            draws = (f(0, 0, nc), f(1, 1, nc), f(0, 2, nf), f(1, 3, nc + nf))
+        eng.forward_backward(rays, rgba[:, :3], draws=draws)
+        torch.cuda.synchronize()
+        res.append((eng.grad.clone(), eng.loss.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    with pytest.raises(RuntimeError, match="random-draw tensor"):
+        eng.forward_backward(rays, rgba[:, :3], draws=(torch.rand(n, nc + 1, device=dev), None, None, None))
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -81,12 +81,14 @@ def test_e2e_reference_goldens(gpu, name):
 
 
 def test_northstar_render_and_gradients_vs_oracle(gpu):
-    P.case_render_vs_oracle(gpu, P.MLP_GEOMETRIES["northstar8x256"], n=48, nc=64, nf=128, with_grads=True, tag="northstar48")
+    P.case_render_vs_oracle(gpu, P.MLP_GEOMETRIES["northstar8x256"], n=48, nc=64, nf=128, with_grads=True, tag="northstar48",
+                            grad_tol=(3.4e-3, 5.6e-3))  # measured 6.8e-4 / 1.1e-3 (profiles/r03_parity_small_cases.json)
 
 
 def test_default_model_render_white_background(gpu):
     P.case_render_vs_oracle(gpu, P.MLP_GEOMETRIES["default4x128"], n=200, nc=64, nf=64, white=True, noise=1.0,
-                            with_grads=True, tag="default200_white_noise1")
+                            with_grads=True, tag="default200_white_noise1",
+                            grad_tol=(1e-5, 5.5e-3))    # measured 2.1e-6 / 1.1e-3
 
 
 def test_internal_rng_equals_external_draws(gpu):

@@ -264,7 +264,12 @@ MLP_GEOMETRIES = {
     "noinput_linear": model_cfg(3, 128, 2, 5, 3, include_input_xyz=False, include_input_dir=False,
                                 log_sampling_xyz=False),
     "northstar8x256": model_cfg(8, 256, 4, 10, 4),
-    # hidden sizes between the two kernel widths ride zero-padded (plan.cpp build_specs16)
+    # the 64-wide kernel instances: config/llff.yml:49,74 and pretrained/{fern,hotdog}-lowres/config.yml:19,31
+    "llff4x64_skip3_L6": model_cfg(4, 64, 3, 6, 4),
+    "deep8x64_skip4": model_cfg(8, 64, 4, 10, 4),
+    "novw3x64_skip1": model_cfg(3, 64, 1, 10, 0, use_viewdirs=False),
+    "one_layer_64": model_cfg(1, 64, 4, 4, 2),
+    # other hidden sizes ride zero-padded on the next kernel width (plan.cpp build_specs16)
     "narrow3x40": model_cfg(3, 40, 2, 4, 2),
     "odd5x99_skip2": model_cfg(5, 99, 2, 10, 4),
     "wide3x200_skip1": model_cfg(3, 200, 1, 6, 3),

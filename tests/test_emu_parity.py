@@ -61,6 +61,20 @@ def test_mlp_many_layers_and_jobs(emu):
     P.case_mlp_backward(emu, names=names, m=40)
 
 
+def test_mlp_64_wide_instances(emu):
+    """hidden_size 64 (config/llff.yml:49, pretrained/fern-lowres/config.yml:19): its own kernel instances, not the
+    128-wide ones with 4x the FLOPs."""
+    names = ("llff4x64_skip3_L6", "deep8x64_skip4", "novw3x64_skip1", "one_layer_64")
+    P.case_mlp_forward(emu, names=names, m=70)
+    P.case_mlp_backward(emu, names=names, m=150)
+    P.case_mlp_input_grad(emu, names=("llff4x64_skip3_L6",), m=45)
+
+
+def test_render_64_wide_vs_oracle(emu):
+    P.case_render_vs_oracle(emu, P.MLP_GEOMETRIES["llff4x64_skip3_L6"], n=12, nc=16, nf=16, with_grads=True, tag="llff64",
+                            grad_tol=(1e-3, 2e-2))
+
+
 def test_mlp_padded_hidden_sizes(emu):
     """hidden_size other than 128 / 256 (the reference constructor takes any: nerf/models.py:185-196), odd included."""
     names = ("narrow3x40", "odd5x99_skip2", "wide3x200_skip1", "novw2x130")

@@ -59,6 +59,19 @@ def test_mlp_forward_reference_goldens(gpu):
     P.case_mlp_golden(gpu)
 
 
+def test_mlp_64_wide_instances(gpu):
+    names = ("llff4x64_skip3_L6", "deep8x64_skip4", "novw3x64_skip1", "one_layer_64")
+    P.case_mlp_forward(gpu, names=names, m=1000)
+    P.case_mlp_backward(gpu, names=names, m=1500)
+    P.case_mlp_input_grad(gpu, names=("llff4x64_skip3_L6",), m=1500)
+
+
+def test_render_64_wide_llff_config_vs_oracle(gpu):
+    """config/llff.yml nets (4x64, skip 3, 6 xyz frequencies) on 64 + 64 samples with gradients."""
+    P.case_render_vs_oracle(gpu, P.MLP_GEOMETRIES["llff4x64_skip3_L6"], n=300, nc=64, nf=64, noise=1.0, with_grads=True,
+                            tag="llff64_300", grad_tol=(1e-3, 2e-2))
+
+
 def test_mlp_padded_hidden_sizes(gpu):
     names = ("narrow3x40", "odd5x99_skip2", "wide3x200_skip1", "novw2x130")
     P.case_mlp_forward(gpu, names=names, m=700)

@@ -290,6 +290,22 @@ int nerfhip_render_bwd_parts(nerfhip_plan_t plan_coarse, nerfhip_plan_t plan_fin
                              const nerfhip_render_cotangents* g, void* workspace, int64_t workspace_bytes,
                              float* g_params_coarse, float* g_params_fine, int parts, nerfhip_stream_t stream);
 
+/* nerfhip_render_bwd_parts that ALSO returns d(loss)/d(rays): under autograd the reference differentiates
+ * pts = ro + rd * z (nerf/train_utils.py:67,107) and dists * ||rd|| (nerf/volume_rendering_utils.py:24) w.r.t. the ray
+ * batch (pose optimisation).  params_*: dev flat parameter vectors (reference layout -- the packed images do not hold
+ * the encoding columns in a usable order); tmp: dev scratch of nerfhip_render_bwd_rays_tmp_bytes; g_rays: dev
+ * [n, ray_stride], overwritten: columns 0..2 d/d(origin), 3..5 d/d(direction), 8..10 d/d(viewdirs), the rest 0 (the
+ * depths are constants of the ray: near / far carry no gradient, as for every loss the reference's scripts build).
+ * g_rays == NULL (then params_* / tmp may be NULL) is exactly nerfhip_render_bwd_parts. */
+int64_t nerfhip_render_bwd_rays_tmp_bytes(nerfhip_plan_t plan_coarse, nerfhip_plan_t plan_fine, const nerfhip_render_cfg* cfg,
+                                          int64_t n_rays);
+int nerfhip_render_bwd_rays(nerfhip_plan_t plan_coarse, nerfhip_plan_t plan_fine, const nerfhip_render_cfg* cfg,
+                            const float* rays, int64_t n_rays, const float* packed_coarse, const float* packed_fine,
+                            const nerfhip_render_rand* rnd, uint64_t seed, uint64_t ray_offset,
+                            const nerfhip_render_cotangents* g, void* workspace, int64_t workspace_bytes,
+                            float* g_params_coarse, float* g_params_fine, int parts, const float* params_coarse,
+                            const float* params_fine, void* tmp, int64_t tmp_bytes, float* g_rays, nerfhip_stream_t stream);
+
 /* ---- loss + optimiser (train_nerf.py:244-270) ------------------------------------------------------------------ */
 /* mse_loss(rgb_coarse, target) + mse_loss(rgb_fine, target) and its cotangents; loss_out: dev float[3] =
  * {coarse_mse, fine_mse, sum}.  target rows have target_stride floats (RGB or RGBA; only [:3] is used). */

@@ -109,6 +109,10 @@ _PROTOS = {
     "nerfhip_render_bwd_parts": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(RenderCfg), c_f, c_i64, c_f, c_f,
                                             C.POINTER(RenderRand), c_u64, c_u64, C.POINTER(RenderCotangents), c_f, c_i64,
                                             c_f, c_f, C.c_int, c_f]),
+    "nerfhip_render_bwd_rays_tmp_bytes": (c_i64, [C.c_void_p, C.c_void_p, C.POINTER(RenderCfg), c_i64]),
+    "nerfhip_render_bwd_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(RenderCfg), c_f, c_i64, c_f, c_f,
+                                           C.POINTER(RenderRand), c_u64, c_u64, C.POINTER(RenderCotangents), c_f, c_i64,
+                                           c_f, c_f, C.c_int, c_f, c_f, c_f, c_i64, c_f, c_f]),
     "nerfhip_mse_loss_fwd_bwd": (C.c_int, [c_f, c_f, c_f, C.c_int, c_i64, C.c_float, c_f, c_f, c_f, c_f]),
     "nerfhip_adam_step": (C.c_int, [c_f, c_f, c_f, c_f, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, c_i64,
                                      C.c_float, c_f]),

@@ -11,6 +11,7 @@ struct Workspace {
     // backward buffers, one set per net: the coarse and the fine backward chains are independent and may run on
     // different streams (nerfhip_render_bwd_parts)
     int64_t g_raw_c, scratch_c, scratch_c_bytes, g_raw_f, scratch_f, scratch_f_bytes;
+    int64_t gnorm_c, gnorm_f;  // dL/d||rd|| per ray of the two compositing backwards (read by the ray-gradient pass)
 };
 
 int64_t align_up(int64_t v) { return (v + 255) & ~(int64_t)255; }
@@ -37,6 +38,8 @@ Workspace layout(nerfhip_plan* pc, nerfhip_plan* pf, const nerfhip_render_cfg* c
         w.raw_f = take(n * sf * 16);
     }
     if (training) {
+        w.gnorm_c = take(n * 4);
+        if (nf > 0) w.gnorm_f = take(n * 4);
         w.stash_c = take(nerfhip_plan_stash_bytes(pc, n * nc));
         if (nf > 0) w.stash_f = take(nerfhip_plan_stash_bytes(pf, n * sf));
         w.scratch_c_bytes = nh_mlp_bwd_scratch_bytes(pc, n * nc);
@@ -169,11 +172,42 @@ extern "C" int nerfhip_render_fwd(nerfhip_plan_t pc, nerfhip_plan_t pf, const ne
                                     workspace, workspace_bytes, training, NERFHIP_PART_COARSE | NERFHIP_PART_FINE, stream);
 }
 
-extern "C" int nerfhip_render_bwd_parts(nerfhip_plan_t pc, nerfhip_plan_t pf, const nerfhip_render_cfg* cfg,
-                                        const float* rays, int64_t n, const float* packed_c, const float* packed_f,
-                                        const nerfhip_render_rand* rnd, uint64_t seed, uint64_t ray_offset,
-                                        const nerfhip_render_cotangents* g, void* workspace, int64_t workspace_bytes,
-                                        float* g_params_c, float* g_params_f, int parts, nerfhip_stream_t stream) {
+namespace {
+
+// d(loss)/d(rays) of one net's pass: dL/d(encoded input) from the d(pre-activation) images its backward just left in the
+// scratch (nerfhip_mlp_bwd_input), then the positional encoding's backward and pts = ro + rd * z (nh_ray_grad).
+int ray_grad_of_pass(nerfhip_plan* p, const float* params, const float* rays, int stride, int64_t n, const float* z, int S,
+                     const float* scratch, const float* g_norm, void* tmp, int64_t tmp_bytes, float* g_rays, int accumulate,
+                     nerfhip_stream_t stream) {
+    const int64_t M = n * S, need = M * (int64_t)(p->Dx + p->Dd) * 4;
+    NH_REQUIRE(params && tmp && tmp_bytes >= need, "render_bwd: the ray gradient needs the flat parameters and %lld bytes of tmp",
+               (long long)need);
+    int rc = nerfhip_mlp_bwd_input(p, params, M, scratch, (float*)tmp, stream);
+    if (rc) return rc;
+    return nh_ray_grad(rays, stride, n, z, S, (const float*)tmp, p->Dx, p->Dd, p->cfg.include_input_xyz ? 1 : 0,
+                       (p->view && p->cfg.include_input_dir) ? 1 : 0, p->cfg.num_encoding_fn_xyz,
+                       p->view ? p->cfg.num_encoding_fn_dir : 0, p->freqs_xyz, p->freqs_dir, g_norm, g_rays, accumulate, stream);
+}
+
+}  // namespace
+
+extern "C" int64_t nerfhip_render_bwd_rays_tmp_bytes(nerfhip_plan_t pc, nerfhip_plan_t pf, const nerfhip_render_cfg* cfg,
+                                                     int64_t n) {
+    if (check_cfg(pc, pf, cfg) != NERFHIP_OK || n < 0) return -1;
+    int64_t b = n * cfg->num_coarse * (int64_t)(pc->Dx + pc->Dd) * 4;
+    if (cfg->num_fine > 0) {
+        const int64_t f = n * (cfg->num_coarse + cfg->num_fine) * (int64_t)(pf->Dx + pf->Dd) * 4;
+        if (f > b) b = f;
+    }
+    return b;
+}
+
+extern "C" int nerfhip_render_bwd_rays(nerfhip_plan_t pc, nerfhip_plan_t pf, const nerfhip_render_cfg* cfg, const float* rays,
+                                       int64_t n, const float* packed_c, const float* packed_f, const nerfhip_render_rand* rnd,
+                                       uint64_t seed, uint64_t ray_offset, const nerfhip_render_cotangents* g, void* workspace,
+                                       int64_t workspace_bytes, float* g_params_c, float* g_params_f, int parts,
+                                       const float* params_c, const float* params_f, void* tmp, int64_t tmp_bytes,
+                                       float* g_rays, nerfhip_stream_t stream) {
     int rc = check_cfg(pc, pf, cfg);
     if (rc) return rc;
     NH_REQUIRE(rays && packed_c && g && workspace && n > 0, "render_bwd: bad arguments");
@@ -187,31 +221,54 @@ extern "C" int nerfhip_render_bwd_parts(nerfhip_plan_t pc, nerfhip_plan_t pf, co
     const int nc = cfg->num_coarse, nf = cfg->num_fine, sf = nc + nf, stride = cfg->ray_stride;
     nerfhip_render_rand none = {nullptr, nullptr, nullptr, nullptr};
     const nerfhip_render_rand* r = rnd ? rnd : &none;
+    int wrote_rays = 0;  // the first pass that runs overwrites g_rays, the second accumulates
     if (nf > 0 && (parts & NERFHIP_PART_FINE)) {
         NH_REQUIRE(packed_f && g_params_f && (g->g_rgb_fine || g->g_acc_fine || g->g_depth_fine),
                    "render_bwd: fine arguments missing");
         float* g_raw = (float*)(ws + w.g_raw_f);
-        rc = nerfhip_volume_render_bwd((const float*)(ws + w.raw_f), (const float*)(ws + w.z_f), rays + 3, stride, n, sf,
-                                       cfg->noise_std, r->noise_fine, seed, 3u, ray_offset, cfg->white_background,
-                                       g->g_rgb_fine, g->g_depth_fine, g->g_acc_fine, nullptr, g_raw, stream);
+        rc = nh_volume_render_bwd((const float*)(ws + w.raw_f), (const float*)(ws + w.z_f), rays + 3, stride, n, sf,
+                                  cfg->noise_std, r->noise_fine, seed, 3u, ray_offset, cfg->white_background, g->g_rgb_fine,
+                                  g->g_depth_fine, g->g_acc_fine, nullptr, g_raw, g_rays ? (float*)(ws + w.gnorm_f) : nullptr, stream);
         if (rc) return rc;
         rc = nh_mlp_backward(pf, packed_f, g_raw, n * sf, (const float*)(ws + w.stash_f), (float*)(ws + w.scratch_f),
                              w.scratch_f_bytes, g_params_f, stream);
         if (rc) return rc;
+        if (g_rays) {
+            rc = ray_grad_of_pass(pf, params_f, rays, stride, n, (const float*)(ws + w.z_f), sf, (const float*)(ws + w.scratch_f),
+                                  (const float*)(ws + w.gnorm_f), tmp, tmp_bytes, g_rays, wrote_rays, stream);
+            if (rc) return rc;
+            wrote_rays = 1;
+        }
     }
     if (parts & NERFHIP_PART_COARSE) {
         NH_REQUIRE(g_params_c && (g->g_rgb_coarse || g->g_acc_coarse || g->g_depth_coarse),
                    "render_bwd: coarse arguments missing");
         float* g_raw = (float*)(ws + w.g_raw_c);
-        rc = nerfhip_volume_render_bwd((const float*)(ws + w.raw_c), (const float*)(ws + w.z_c), rays + 3, stride, n, nc,
-                                       cfg->noise_std, r->noise_coarse, seed, 1u, ray_offset, cfg->white_background,
-                                       g->g_rgb_coarse, g->g_depth_coarse, g->g_acc_coarse, nullptr, g_raw, stream);
+        rc = nh_volume_render_bwd((const float*)(ws + w.raw_c), (const float*)(ws + w.z_c), rays + 3, stride, n, nc,
+                                  cfg->noise_std, r->noise_coarse, seed, 1u, ray_offset, cfg->white_background, g->g_rgb_coarse,
+                                  g->g_depth_coarse, g->g_acc_coarse, nullptr, g_raw, g_rays ? (float*)(ws + w.gnorm_c) : nullptr,
+                                  stream);
         if (rc) return rc;
         rc = nh_mlp_backward(pc, packed_c, g_raw, n * nc, (const float*)(ws + w.stash_c), (float*)(ws + w.scratch_c),
                              w.scratch_c_bytes, g_params_c, stream);
         if (rc) return rc;
+        if (g_rays) {
+            rc = ray_grad_of_pass(pc, params_c, rays, stride, n, (const float*)(ws + w.z_c), nc, (const float*)(ws + w.scratch_c),
+                                  (const float*)(ws + w.gnorm_c), tmp, tmp_bytes, g_rays, wrote_rays, stream);
+            if (rc) return rc;
+            wrote_rays = 1;
+        }
     }
     return NERFHIP_OK;
+}
+
+extern "C" int nerfhip_render_bwd_parts(nerfhip_plan_t pc, nerfhip_plan_t pf, const nerfhip_render_cfg* cfg,
+                                        const float* rays, int64_t n, const float* packed_c, const float* packed_f,
+                                        const nerfhip_render_rand* rnd, uint64_t seed, uint64_t ray_offset,
+                                        const nerfhip_render_cotangents* g, void* workspace, int64_t workspace_bytes,
+                                        float* g_params_c, float* g_params_f, int parts, nerfhip_stream_t stream) {
+    return nerfhip_render_bwd_rays(pc, pf, cfg, rays, n, packed_c, packed_f, rnd, seed, ray_offset, g, workspace, workspace_bytes,
+                                   g_params_c, g_params_f, parts, nullptr, nullptr, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int nerfhip_render_bwd(nerfhip_plan_t pc, nerfhip_plan_t pf, const nerfhip_render_cfg* cfg, const float* rays,

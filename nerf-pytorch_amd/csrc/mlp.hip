@@ -12,7 +12,7 @@ namespace {
 // (xyz columns) and layers_dir[0] (direction columns), so
 //   g_x[m, c] = sum over those layers  sum_u dpre[m, u] * W[u, col0 + c - out0]
 // with dpre = the d(pre-activation) image the data-gradient kernel left in the backward scratch ([sample][rows]).
-constexpr int NH_INGRAD_MAX_TERMS = NH_MAX_LAYERS + 2;
+constexpr int NH_INGRAD_MAX_TERMS = 2 * (NH_MAX_LAYERS + 2);  // (512-wide nets: one term per 256-row half)
 struct InGradTerm {
     int64_t a_prefix;  // region offset = 32 * nt * a_prefix floats
     int a_rows, nu;    // row count of the region, real units
@@ -106,15 +106,18 @@ extern "C" int nerfhip_mlp_bwd_input(nerfhip_plan_t p, const float* params, int6
     memset(&a, 0, sizeof(a));
     const int H = p->H;
     auto add = [&](const NhRegion& R, int nu, int tensor, int col0, int out0, int ncols) {
-        InGradTerm& t = a.t[a.nterms++];
-        t.a_prefix = R.row_prefix;
-        t.a_rows = R.rows;
-        t.nu = nu;
-        t.w_off = p->tensors[tensor].off;
-        t.w_ld = p->tensors[tensor].cols;
-        t.col0 = col0;
-        t.out0 = out0;
-        t.ncols = ncols;
+        // (units beyond 256 of a 512-wide net live in the second 256-row region of the activation)
+        for (int u0 = 0; u0 < nu; u0 += 256) {
+            InGradTerm& t = a.t[a.nterms++];
+            t.a_prefix = R.row_prefix + u0;
+            t.a_rows = R.rows;
+            t.nu = nu - u0 < 256 ? nu - u0 : 256;
+            t.w_ld = p->tensors[tensor].cols;
+            t.w_off = p->tensors[tensor].off + (int64_t)u0 * t.w_ld;
+            t.col0 = col0;
+            t.out0 = out0;
+            t.ncols = ncols;
+        }
     };
     add(p->grad.P[0], H, p->t_layer1_w, 0, 0, p->Dx);
     for (int i = 0; i < p->L - 1; ++i)

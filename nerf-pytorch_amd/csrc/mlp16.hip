@@ -31,7 +31,11 @@ namespace {
 #endif
 template <int W>
 struct Shape {
-    static constexpr int NW = W >= 256 ? 8 : NH16_NARROW_NW;  // waves per workgroup
+    // waves per workgroup.  512-wide nets (132 accumulator + 128 activation registers per 16 samples): ONE wave per SIMD
+    // with the whole unified register file (accumulators in AGPRs), 4-wave workgroups, one per CU
+    static constexpr int NW = W >= 512 ? 4 : (W >= 256 ? 8 : NH16_NARROW_NW);
+    static constexpr int WAVES_PER_SIMD = W >= 512 ? 1 : 2;  // launch bound (minimum occupancy the registers must allow)
+    static constexpr int MW = nh16_mask_words(W);            // 32-bit words of ReLU bits per lane and layer
 };
 // floats of one chunk buffer: 256-wide nets 16384 (16 k-steps x 4 quads; 2 x 64 KB + bias blocks = 132 KB: one
 // workgroup per CU, which the 240-register waves allow anyway), 128-wide nets 6144 (8 k-steps x 3 quads; 52 KB -> 3 per CU),
@@ -39,7 +43,8 @@ struct Shape {
 template <int W>
 struct Lds {
     static constexpr int CHUNK_MAX = W >= 256 ? 16384 : (W >= 128 ? NH16_NARROW_CHUNK : 4096);
-    static constexpr int BYTES = (2 * CHUNK_MAX + 2 * NH16_BIAS_FLOATS) * 4;
+    static constexpr int BIAS = nh16_bias_floats(W);
+    static constexpr int BYTES = (2 * CHUNK_MAX + 2 * BIAS) * 4;
     static constexpr int BYTES_ALL = BYTES + NH_CLK_LDS_BYTES;  // + the clock probe's stamps (nh_clk_begin)
 };
 
@@ -61,6 +66,7 @@ struct Ctx {
 #endif
     float* lds;
     int cmax;           // floats per chunk buffer (Lds<W>::CHUNK_MAX)
+    int bfl;            // floats of a layer image's bias block (Lds<W>::BIAS)
     int nw;             // waves per workgroup
     unsigned lds_addr;  // LDS byte address of `lds`
     NhDmaSrc dma;  // descriptor over the whole packed image
@@ -71,7 +77,7 @@ struct Ctx {
     int c_src0, c_src1;     // byte offsets of the runs inside the packed image
     unsigned c_dst0, c_dst1;  // LDS byte addresses of the runs
     NH_MEMBER float* chunk(int b) const { return lds + b * cmax; }
-    NH_MEMBER float* bias(int b) const { return lds + 2 * cmax + b * NH16_BIAS_FLOATS; }
+    NH_MEMBER float* bias(int b) const { return lds + 2 * cmax + b * bfl; }
     NH_MEMBER void plan_copy(int64_t off0, int n0, float* dst0, int64_t off1, int n1, float* dst1) {
         c_np0 = n0 >> 8;
         c_np = c_np0 + (n1 >> 8);
@@ -84,7 +90,7 @@ struct Ctx {
     NH_MEMBER void plan_chunk(int64_t off, int nfloats, float* dst) { plan_copy(off, nfloats, dst, 0, 0, dst); }
     // a layer's first unit: its bias block and chunk 0
     NH_MEMBER void plan_first(int64_t img_off, int first_floats, int b, int bb) {
-        plan_copy(img_off, NH16_BIAS_FLOATS, bias(bb), img_off + NH16_BIAS_FLOATS, first_floats, chunk(b));
+        plan_copy(img_off, bfl, bias(bb), img_off + bfl, first_floats, chunk(b));
     }
     // this wave's j-th piece of the planned copy (one LDS-DMA instruction, or nothing)
     NH_MEMBER void issue(int j) const {
@@ -161,16 +167,21 @@ struct NoPre {
     static constexpr int N = 0;
     NH_MEMBER void group(int) const {}
 };
-template <int N_>
+// the ReLU bits of one activation: MW words per lane, value r at bit nh16_bitpos(r, n) of word r >> 5 (see finish())
+template <int MW>
+struct MaskBits {
+    unsigned w[MW];
+};
+template <int N_, int MW = 2>
 struct GatePre {
     static constexpr int N = N_;  // groups of four registers
     float* v;
-    unsigned m0, m1;  // stored ReLU bits of the 4 N values (finish(): value r at nh16_bitpos(r, 4 N) of word r >> 5)
+    MaskBits<MW> m;  // stored ReLU bits of the 4 N values
     NH_MEMBER void group(int t) const {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int r = 4 * t + c;
-            v[r] = nh_gate(v[r], (r >> 5) == 0 ? m0 : m1, nh16_bitpos(r, 4 * N));
+            v[r] = nh_gate(v[r], m.w[r >> 5], nh16_bitpos(r, 4 * N));
         }
     }
 };
@@ -194,7 +205,7 @@ NH_DEVICE void gemm16(Ctx& cx, const float* inA, const float* inB, int64_t img_o
         NH16_PH(3);  // [3] s_barrier
         if (c + 1 < NCH) {
             const int kn = (KR - (c + 1) * KC) < KC ? (KR - (c + 1) * KC) : KC;
-            cx.plan_chunk(img_off + NH16_BIAS_FLOATS + (int64_t)(c + 1) * KC * TQ * 256, kn * TQ * 256, cx.chunk(cx.buf ^ 1));
+            cx.plan_chunk(img_off + Lds<W>::BIAS + (int64_t)(c + 1) * KC * TQ * 256, kn * TQ * 256, cx.chunk(cx.buf ^ 1));
         } else if (next_first > 0) {
             cx.plan_first(next_off, next_first, cx.buf ^ 1, cx.bbuf ^ 1);
         } else {
@@ -282,23 +293,26 @@ struct RowRef {
 };
 // activation rows: tile t = rows feat16(4t.., g) = 16t + 4g .. +3 of this lane's sample, one 16-byte store; `mask`
 // (optional) receives the ReLU bits of the activation first.
-template <int NT_>
+// NT > 16 (512 rows: 512-wide nets): tiles 16.. go to the activation's second 256-row region, `hi_bytes` further on
+template <int NT_, int MW = 2>
 struct RowsPost {
     static constexpr int NT = NT_;
     RowRef row;
     const float* act;
     RowRef mask;
-    unsigned b0, b1;
+    MaskBits<MW> b;
+    size_t hi_bytes;
     NH_MEMBER void first() const {
         if (mask.base) {
             unsigned* p = (unsigned*)mask.at(0);
-            p[0] = b0;
-            p[1] = b1;
+#pragma unroll
+            for (int w = 0; w < MW; ++w) p[w] = b.w[w];
         }
     }
     NH_MEMBER void tile(int t) const {
         if (!row.base) return;
-        *(float4*)row.at(16 * t) = make_float4(act[4 * t], act[4 * t + 1], act[4 * t + 2], act[4 * t + 3]);
+        float* dst = t < 16 ? row.at(16 * t) : (float*)((char*)row.at(16 * (t - 16)) + hi_bytes);
+        *(float4*)dst = make_float4(act[4 * t], act[4 * t + 1], act[4 * t + 2], act[4 * t + 3]);
     }
 };
 // encoding slots (register r of lane (j,g) is row g*KR + r; the lane offset already includes g*KR): stored with k-step 0
@@ -315,10 +329,10 @@ struct SlotsPost {
     NH_MEMBER void tile(int) const {}
 };
 // H_{L-1} rows + mask AND the direction-encoding slots (computed late: see k_mlp_fwd16)
-template <int NT_, int KD>
+template <int NT_, int KD, int MW = 2>
 struct RowsAndSlotsPost {
-    static constexpr int NT = RowsPost<NT_>::NT;
-    RowsPost<NT_> rows;
+    static constexpr int NT = RowsPost<NT_, MW>::NT;
+    RowsPost<NT_, MW> rows;
     SlotsPost<KD> slots;
     NH_MEMBER void first() const {
         rows.first();
@@ -339,9 +353,12 @@ struct PoutPost {
 };
 // all rows of an activation at once (the last store of the data-gradient chain)
 template <int T>
-NH_DEVICE void store_rows(const RowRef& row, const float* act) {
+NH_DEVICE void store_rows(const RowRef& row, const float* act, size_t hi_bytes) {
 #pragma unroll
-    for (int t = 0; t < T; ++t) *(float4*)row.at(16 * t) = make_float4(act[4 * t], act[4 * t + 1], act[4 * t + 2], act[4 * t + 3]);
+    for (int t = 0; t < T; ++t) {
+        float* dst = t < 16 ? row.at(16 * t) : (float*)((char*)row.at(16 * (t - 16)) + hi_bytes);
+        *(float4*)dst = make_float4(act[4 * t], act[4 * t + 1], act[4 * t + 2], act[4 * t + 3]);
+    }
 }
 
 // wave-uniform base of a region's rows for the four 32-sample tiles of workgroup `wg` (two tiles for 4-wave workgroups)
@@ -398,13 +415,14 @@ struct Fwd16Args {
 
 // TRAIN: the launch writes the activation stash (rows, encoding slots, ReLU masks) for the backward kernels
 template <int W, bool VIEW, bool TRAIN>
-NH_KERNEL void NH_LB(64 * Shape<W>::NW, 2) k_mlp_fwd16(Fwd16Args a) {
-    constexpr int KH = W / 4, TW = W / 16, KX = NH16_KRX, KD = NH16_KRD, NW = Shape<W>::NW;
+NH_KERNEL void NH_LB(64 * Shape<W>::NW, Shape<W>::WAVES_PER_SIMD) k_mlp_fwd16(Fwd16Args a) {
+    constexpr int KH = W / 4, TW = W / 16, KX = NH16_KRX, KD = NH16_KRD, NW = Shape<W>::NW, MW = Shape<W>::MW;
     NH_DYN_LDS(lds_raw);
     nh_clk_begin(a.clk, (unsigned long long*)(lds_raw + Lds<W>::BYTES));
     Ctx cx;
     cx.lds = (float*)lds_raw;
     cx.cmax = Lds<W>::CHUNK_MAX;
+    cx.bfl = Lds<W>::BIAS;
     cx.nw = Shape<W>::NW;
     cx.lds_addr = nh_lds_addr(cx.lds);
     cx.dma = nh_dma_src(a.packed, a.packed_bytes);
@@ -454,12 +472,22 @@ NH_KERNEL void NH_LB(64 * Shape<W>::NW, 2) k_mlp_fwd16(Fwd16Args a) {
     auto sref = [&](const NhRegion& R, int rows, int first) -> RowRef {
         return RowRef{tr ? region_wg_base(a.stash, R, a.nt, tile0) : nullptr, (lrow * (unsigned)rows + (unsigned)first) * 4u};
     };
-    // ReLU masks for the data-gradient kernel: 64 bits per lane per layer, [16-sample wave tile][mask][lane][2 words]
+    constexpr int RW = W > 256 ? 256 : W;                        // rows of one stash region of a W-row activation
+    const size_t hi = (size_t)32 * (size_t)a.nt * 256 * 4;       // bytes from a 512-row activation's first region to its second
+    // ReLU masks for the data-gradient kernel: one bit per activation register, MW words per lane and layer,
+    // [16-sample wave tile][mask][lane][MW words]
     char* const mask_base = tr ? (char*)((unsigned*)(a.stash + (size_t)32 * (size_t)a.nt * (size_t)a.sl.total_rows) +
-                                         (size_t)((int64_t)blockIdx.x * NW + wave) * a.sl.n_masks * 128)
+                                         (size_t)((int64_t)blockIdx.x * NW + wave) * a.sl.n_masks * (64 * MW))
                                : nullptr;
-    unsigned bits[2] = {0u, 0u};
-    auto mref = [&](int idx) -> RowRef { return RowRef{(tr && idx >= 0) ? mask_base + (size_t)idx * 512 : nullptr, (unsigned)lane * 8u}; };
+    MaskBits<MW> bits;
+    auto clear_bits = [&]() {
+#pragma unroll
+        for (int w = 0; w < MW; ++w) bits.w[w] = 0u;
+    };
+    clear_bits();
+    auto mref = [&](int idx) -> RowRef {
+        return RowRef{(tr && idx >= 0) ? mask_base + (size_t)idx * (256 * MW) : nullptr, (unsigned)lane * (4u * MW)};
+    };
 
     float act[KH];
     f32x4 acc[TW + 1];
@@ -469,7 +497,7 @@ NH_KERNEL void NH_LB(64 * Shape<W>::NW, 2) k_mlp_fwd16(Fwd16Args a) {
         gemm16<W, KX, 0, TW>(cx, ex, nullptr, po.f_layer1, more ? po.f_xyz[0] : po.f_head,
                              more ? Geo<W, KH, TW>::FIRST : (VIEW ? Geo<W, KH, TW + 1>::FIRST : Geo<W, KH, 1>::FIRST), acc,
                              SlotsPost<KX>{sref(a.sl.X, 4 * KX, g * KX), ex});
-        finish<TW, false, false, false>(acc, act, bits, bits);
+        finish<TW, false, false, false>(acc, act, bits.w, bits.w);
     }
     // every gemm stores its own input rows (= the previous layer's output) and that layer's ReLU mask
     for (int i = 0; i < a.L - 1; ++i) {
@@ -480,15 +508,15 @@ NH_KERNEL void NH_LB(64 * Shape<W>::NW, 2) k_mlp_fwd16(Fwd16Args a) {
         const int nfirst = more ? (nsk ? Geo<W, KH + KX, TW>::FIRST : Geo<W, KH, TW>::FIRST)
                                 : (VIEW ? Geo<W, KH, TW + 1>::FIRST : Geo<W, KH, 1>::FIRST);
         // H_i and its ReLU mask (none for H_0)
-        const RowsPost<TW> post{sref(a.sl.H[i], W, 4 * g), act, mref(i - 1), bits[0], bits[1]};
+        const RowsPost<TW, MW> post{sref(a.sl.H[i], RW, 4 * g), act, mref(i - 1), bits, hi};
         if (sk)
             gemm16<W, KH, KX, TW>(cx, act, ex, po.f_xyz[i], nxt, nfirst, acc, post);
         else
             gemm16<W, KH, 0, TW>(cx, act, nullptr, po.f_xyz[i], nxt, nfirst, acc, post);
-        bits[0] = bits[1] = 0u;
-        finish<TW, true, TRAIN, false>(acc, act, bits, bits);
+        clear_bits();
+        finish<TW, true, TRAIN, false>(acc, act, bits.w, bits.w);
     }
-    const RowsPost<TW> post_last_hidden{sref(a.sl.H[a.L - 1], W, 4 * g), act, mref(a.L - 2), bits[0], bits[1]};  // H_{L-1}
+    const RowsPost<TW, MW> post_last_hidden{sref(a.sl.H[a.L - 1], RW, 4 * g), act, mref(a.L - 2), bits, hi};  // H_{L-1}
     if (VIEW) {
         // The direction encoding is first needed by layers_dir: it is formed HERE, after the hidden layers, so that its
         // registers are not carried through them (its slots go to the stash with the head gemm's first k-step).
@@ -506,17 +534,17 @@ NH_KERNEL void NH_LB(64 * Shape<W>::NW, 2) k_mlp_fwd16(Fwd16Args a) {
         }
         // tiles 0..TW-1: feat = relu(fc_feat(h)); tile TW row 0: fc_alpha(h), raw (models.py:248-249)
         gemm16<W, KH, 0, TW + 1>(cx, act, nullptr, po.f_head, po.f_dir, Geo<W, KH + KD, TW / 2>::FIRST, acc,
-                                 RowsAndSlotsPost<TW, KD>{post_last_hidden, SlotsPost<KD>{sref(a.sl.D, 4 * KD, g * KD), ed}});
+                                 RowsAndSlotsPost<TW, KD, MW>{post_last_hidden, SlotsPost<KD>{sref(a.sl.D, 4 * KD, g * KD), ed}});
         const float alpha = acc[TW][0];
-        bits[0] = bits[1] = 0u;
-        finish<TW, true, TRAIN, false>(acc, act, bits, bits);
+        clear_bits();
+        finish<TW, true, TRAIN, false>(acc, act, bits.w, bits.w);
         float dh[KH / 2];
         gemm16<W, KH, KD, TW / 2>(cx, act, ed, po.f_dir, po.f_rgb, Geo<W, KH / 2, 1>::FIRST, acc,
-                                  RowsPost<TW>{sref(a.sl.FEAT, W, 4 * g), act, mref(a.L - 1), bits[0], bits[1]});
-        bits[0] = bits[1] = 0u;
-        finish<TW / 2, true, TRAIN, false>(acc, dh, bits, bits);
+                                  RowsPost<TW, MW>{sref(a.sl.FEAT, RW, 4 * g), act, mref(a.L - 1), bits, hi});
+        clear_bits();
+        finish<TW / 2, true, TRAIN, false>(acc, dh, bits.w, bits.w);
         gemm16<W, KH / 2, 0, 1>(cx, dh, nullptr, po.f_rgb, 0, 0, acc,
-                                RowsPost<TW / 2>{sref(a.sl.DIRH, W / 2, 4 * g), dh, mref(a.L), bits[0], bits[1]});
+                                RowsPost<TW / 2, MW>{sref(a.sl.DIRH, W / 2, 4 * g), dh, mref(a.L), bits, hi});
         if (valid && g == 0) {
             float4 r4;
             r4.x = acc[0][0];
@@ -560,13 +588,14 @@ struct Dgrad16Args {
 };
 
 template <int W, bool VIEW>
-NH_KERNEL void NH_LB(64 * Shape<W>::NW, 2) k_mlp_dgrad16(Dgrad16Args a) {
-    constexpr int KH = W / 4, TW = W / 16, NW = Shape<W>::NW;
+NH_KERNEL void NH_LB(64 * Shape<W>::NW, Shape<W>::WAVES_PER_SIMD) k_mlp_dgrad16(Dgrad16Args a) {
+    constexpr int KH = W / 4, TW = W / 16, NW = Shape<W>::NW, MW = Shape<W>::MW;
     NH_DYN_LDS(lds_raw);
     nh_clk_begin(a.clk, (unsigned long long*)(lds_raw + Lds<W>::BYTES));
     Ctx cx;
     cx.lds = (float*)lds_raw;
     cx.cmax = Lds<W>::CHUNK_MAX;
+    cx.bfl = Lds<W>::BIAS;
     cx.nw = Shape<W>::NW;
     cx.lds_addr = nh_lds_addr(cx.lds);
     cx.dma = nh_dma_src(a.packed, a.packed_bytes);
@@ -603,25 +632,32 @@ NH_KERNEL void NH_LB(64 * Shape<W>::NW, 2) k_mlp_dgrad16(Dgrad16Args a) {
     auto gref = [&](const NhRegion& R, int rows, int first) -> RowRef {
         return RowRef{region_wg_base(a.grad, R, a.nt, tile0), (lrow * (unsigned)rows + (unsigned)first) * 4u};
     };
+    constexpr int RW = W > 256 ? 256 : W;
+    const size_t hi = (size_t)32 * (size_t)a.nt * 256 * 4;
     // POUT (32 rows): rows 0..2 d(rgb raw), row 3 d(sigma raw), rows 4..31 zero; group g writes rows 8g..8g+7
     const bool g0 = g == 0;
     const PoutPost store_pout{gref(a.gl.POUT, 32, 8 * g), g0 ? go0 : 0.f, g0 ? go1 : 0.f, g0 ? go2 : 0.f, g0 ? go3 : 0.f};
     const char* const mask_base = (const char*)((const unsigned*)(a.stash + (size_t)32 * (size_t)a.nt * (size_t)a.sl.total_rows) +
-                                                (size_t)((int64_t)blockIdx.x * NW + wave) * a.sl.n_masks * 128);
+                                                (size_t)((int64_t)blockIdx.x * NW + wave) * a.sl.n_masks * (64 * MW));
     // ReLU masks: `mb` gates the d(pre-activation) currently held in registers -- applied by the NEXT gemm, group by
     // group, just before it consumes / stores them (GatePre) -- while `mn` is fetched for the one being accumulated
-    unsigned mb[2], mn[2];
+    MaskBits<MW> mb, mn;
     auto get_mask = [&](int idx) {
-        const unsigned* p = (const unsigned*)(mask_base + (size_t)idx * 512 + (size_t)((unsigned)lane * 8u));
-        mn[0] = p[0];
-        mn[1] = p[1];
+        const unsigned* p = (const unsigned*)(mask_base + (size_t)idx * (256 * MW) + (size_t)((unsigned)lane * (4u * MW)));
+#pragma unroll
+        for (int w = 0; w < MW; ++w) mn.w[w] = p[w];
     };
-    auto ones = [&]() { mn[0] = mn[1] = 0xFFFFFFFFu; };  // a layer without activation: nothing is gated
-    auto rotate = [&]() { mb[0] = mn[0], mb[1] = mn[1]; };
-    mb[0] = mb[1] = mn[0] = mn[1] = 0xFFFFFFFFu;
+    auto ones = [&]() {  // a layer without activation: nothing is gated
+#pragma unroll
+        for (int w = 0; w < MW; ++w) mn.w[w] = 0xFFFFFFFFu;
+    };
+    auto rotate = [&]() { mb = mn; };
+    ones();
+    rotate();
     f32x4 acc[TW];
     float dp[KH];  // d(pre-activation) of the layer just finished = B operand of the next transposed GEMM
-    unsigned nobits[2] = {0u, 0u};
+    unsigned nobits[MW] = {};
+    const MaskBits<MW> zero_bits = {};
     const RowRef none{nullptr, 0u};
     // every gemm stores its own input rows (= the d(pre-activation) the previous one produced), one tile per few k-steps
     if (VIEW) {
@@ -635,8 +671,8 @@ NH_KERNEL void NH_LB(64 * Shape<W>::NW, 2) k_mlp_dgrad16(Dgrad16Args a) {
         rotate();
         get_mask(L - 1);  // FEAT
         gemm16<W, KH / 2, 0, TW>(cx, dpd, nullptr, po.b_dir, po.b_head, Geo<W, KH + 1, TW>::FIRST, acc,
-                                 RowsPost<TW / 2>{gref(a.gl.PDIR, W / 2, 4 * g), dpd, none, 0u, 0u},
-                                 GatePre<TW / 2>{dpd, mb[0], mb[1]});
+                                 RowsPost<TW / 2, MW>{gref(a.gl.PDIR, W / 2, 4 * g), dpd, none, zero_bits, hi},
+                                 GatePre<TW / 2, MW>{dpd, mb});
         finish<TW, false, false, false>(acc, dp, nobits, nobits);
         rotate();
         if (L > 1)
@@ -646,7 +682,7 @@ NH_KERNEL void NH_LB(64 * Shape<W>::NW, 2) k_mlp_dgrad16(Dgrad16Args a) {
         float da[1];
         da[0] = g == 0 ? go3 : 0.0f;  // d(sigma raw) enters through fc_alpha's row (k-step KH, group 0)
         gemm16<W, KH, 1, TW>(cx, dp, da, po.b_head, L > 1 ? po.b_xyz[L - 2] : 0, L > 1 ? Geo<W, KH, TW>::FIRST : 0, acc,
-                             RowsPost<TW>{gref(a.gl.PFEAT, W, 4 * g), dp, none, 0u, 0u}, GatePre<TW>{dp, mb[0], mb[1]});
+                             RowsPost<TW, MW>{gref(a.gl.PFEAT, RW, 4 * g), dp, none, zero_bits, hi}, GatePre<TW, MW>{dp, mb});
         finish<TW, false, false, false>(acc, dp, nobits, nobits);
         rotate();
     } else {
@@ -669,13 +705,13 @@ NH_KERNEL void NH_LB(64 * Shape<W>::NW, 2) k_mlp_dgrad16(Dgrad16Args a) {
         else
             ones();
         gemm16<W, KH, 0, TW>(cx, dp, nullptr, po.b_xyz[k - 1], k >= 2 ? po.b_xyz[k - 2] : 0,
-                             k >= 2 ? Geo<W, KH, TW>::FIRST : 0, acc, RowsPost<TW>{gref(a.gl.P[k], W, 4 * g), dp, none, 0u, 0u},
-                             GatePre<TW>{dp, mb[0], mb[1]});
+                             k >= 2 ? Geo<W, KH, TW>::FIRST : 0, acc, RowsPost<TW, MW>{gref(a.gl.P[k], RW, 4 * g), dp, none, zero_bits, hi},
+                             GatePre<TW, MW>{dp, mb});
         finish<TW, false, false, false>(acc, dp, nobits, nobits);
         rotate();
     }
     // (mb is all ones here: d(pre-activation) of layer1 needs no gate)
-    store_rows<TW>(gref(a.gl.P[0], W, 4 * g), dp);
+    store_rows<TW>(gref(a.gl.P[0], RW, 4 * g), dp, hi);
     nh_clk_end((const unsigned long long*)(lds_raw + Lds<W>::BYTES));
 #ifdef NH_PHASE_TIMING
     NH16_PH(4);
@@ -701,7 +737,7 @@ int lds_limit(K kern, int bytes) {
 
 }  // namespace
 
-#ifdef NH_PHASE_TIMING
+#if defined(NH_PHASE_TIMING) && !defined(NH16_W512_TU)
 extern "C" int nerfhip_debug_phases16(unsigned long long* host16, int reset) {
     (void)hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_phase16), sizeof(unsigned long long) * 16);
     if (reset) {
@@ -712,10 +748,13 @@ extern "C" int nerfhip_debug_phases16(unsigned long long* host16, int reset) {
 }
 #endif
 
-int nh_mlp16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
-                     nerfhip_stream_t stream) {
-    NH_REQUIRE(M < ((int64_t)1 << 31), "mlp_fwd: at most 2^31 - 1 sample points per call (got %lld)", (long long)M);
-    Fwd16Args a;
+// ---- host side ------------------------------------------------------------------------------------------------------
+// The 512-wide instantiations (three kernels, ~2.5 minutes of compile time) live in their own translation unit,
+// mlp16_w512.hip, which includes this file with NH16_W512_TU defined: it compiles the same templates for W = 512 only and
+// exports nh_mlp16_forward_w512 / nh_mlp16_dgrad_w512; this unit holds the widths 64 / 128 / 256 and the dispatch.
+namespace {
+
+void fill_fwd_args(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash, Fwd16Args& a) {
     memset(&a, 0, sizeof(a));
     a.packed = packed;
     a.packed_bytes = (unsigned)(p->packed_floats * 4);
@@ -746,35 +785,10 @@ int nh_mlp16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in,
     a.stash = stash;
     a.sl = p->stash;
     a.clk = nh_prof_clock_slot(NH_CLK_FWD);
-    const int64_t groups = nh_ceil_div(M, 128);  // whole 128-sample groups: every stash tile is written
-    int rc = NERFHIP_OK;
-#define NH_FWD16_T(WW, VV, TT)                                                        \
-    {                                                                                 \
-        rc = lds_limit(k_mlp_fwd16<WW, VV, TT>, Lds<WW>::BYTES_ALL);                  \
-        if (rc) return rc;                                                            \
-        NH_LAUNCH((k_mlp_fwd16<WW, VV, TT>), groups * (8 / Shape<WW>::NW), 64 * Shape<WW>::NW, Lds<WW>::BYTES_ALL, stream, a); \
-    }
-#define NH_FWD16(WW, VV)             \
-    {                                \
-        if (stash)                   \
-            NH_FWD16_T(WW, VV, true) \
-        else                         \
-            NH_FWD16_T(WW, VV, false) \
-    }
-    if (p->W == 256 && p->view) NH_FWD16(256, true)
-    else if (p->W == 256) NH_FWD16(256, false)
-    else if (p->W == 128 && p->view) NH_FWD16(128, true)
-    else if (p->W == 128) NH_FWD16(128, false)
-    else if (p->view) NH_FWD16(64, true)
-    else NH_FWD16(64, false)
-#undef NH_FWD16
-#undef NH_FWD16_T
-    return nh_launch_status("mlp_fwd16");
 }
 
-int nh_mlp16_dgrad(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
-                   nerfhip_stream_t stream) {
-    Dgrad16Args d;
+void fill_dgrad_args(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
+                     Dgrad16Args& d) {
     memset(&d, 0, sizeof(d));
     d.packed = packed;
     d.packed_bytes = (unsigned)(p->packed_floats * 4);
@@ -788,20 +802,92 @@ int nh_mlp16_dgrad(nerfhip_plan* p, const float* packed, const float* g_out, int
     d.grad = scratch;
     d.gl = p->grad;
     d.clk = nh_prof_clock_slot(NH_CLK_DGRAD);
-    const int64_t groups = nh_ceil_div(M, 128);
-    int rc = NERFHIP_OK;
-#define NH_BWD16(WW, VV)                                                              \
-    {                                                                                 \
-        rc = lds_limit(k_mlp_dgrad16<WW, VV>, Lds<WW>::BYTES_ALL);                    \
-        if (rc) return rc;                                                            \
+}
+
+// whole 128-sample groups are launched: every stash tile is written
+#define NH_FWD16_T(WW, VV, TT)                                                                                        \
+    {                                                                                                                 \
+        rc = lds_limit(k_mlp_fwd16<WW, VV, TT>, Lds<WW>::BYTES_ALL);                                                  \
+        if (rc) return rc;                                                                                            \
+        NH_LAUNCH((k_mlp_fwd16<WW, VV, TT>), groups * (8 / Shape<WW>::NW), 64 * Shape<WW>::NW, Lds<WW>::BYTES_ALL, stream, a); \
+    }
+#define NH_FWD16(WW, VV)              \
+    {                                 \
+        if (stash)                    \
+            NH_FWD16_T(WW, VV, true)  \
+        else                          \
+            NH_FWD16_T(WW, VV, false) \
+    }
+#define NH_BWD16(WW, VV)                                                                                              \
+    {                                                                                                                 \
+        rc = lds_limit(k_mlp_dgrad16<WW, VV>, Lds<WW>::BYTES_ALL);                                                    \
+        if (rc) return rc;                                                                                            \
         NH_LAUNCH((k_mlp_dgrad16<WW, VV>), groups * (8 / Shape<WW>::NW), 64 * Shape<WW>::NW, Lds<WW>::BYTES_ALL, stream, d); \
     }
+
+}  // namespace
+
+int nh_mlp16_forward_w512(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
+                          nerfhip_stream_t stream);
+int nh_mlp16_dgrad_w512(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
+                        nerfhip_stream_t stream);
+
+#ifdef NH16_W512_TU
+int nh_mlp16_forward_w512(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
+                          nerfhip_stream_t stream) {
+    Fwd16Args a;
+    fill_fwd_args(p, packed, in, M, out, stash, a);
+    const int64_t groups = nh_ceil_div(M, 128);
+    int rc = NERFHIP_OK;
+    if (p->view) NH_FWD16(512, true)
+    else NH_FWD16(512, false)
+    return nh_launch_status("mlp_fwd16");
+}
+
+int nh_mlp16_dgrad_w512(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
+                        nerfhip_stream_t stream) {
+    Dgrad16Args d;
+    fill_dgrad_args(p, packed, g_out, M, stash, scratch, d);
+    const int64_t groups = nh_ceil_div(M, 128);
+    int rc = NERFHIP_OK;
+    if (p->view) NH_BWD16(512, true)
+    else NH_BWD16(512, false)
+    return nh_launch_status("mlp_dgrad16");
+}
+#else
+int nh_mlp16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
+                     nerfhip_stream_t stream) {
+    NH_REQUIRE(M < ((int64_t)1 << 31), "mlp_fwd: at most 2^31 - 1 sample points per call (got %lld)", (long long)M);
+    if (p->W == 512) return nh_mlp16_forward_w512(p, packed, in, M, out, stash, stream);
+    Fwd16Args a;
+    fill_fwd_args(p, packed, in, M, out, stash, a);
+    const int64_t groups = nh_ceil_div(M, 128);
+    int rc = NERFHIP_OK;
+    if (p->W == 256 && p->view) NH_FWD16(256, true)
+    else if (p->W == 256) NH_FWD16(256, false)
+    else if (p->W == 128 && p->view) NH_FWD16(128, true)
+    else if (p->W == 128) NH_FWD16(128, false)
+    else if (p->view) NH_FWD16(64, true)
+    else NH_FWD16(64, false)
+    return nh_launch_status("mlp_fwd16");
+}
+
+int nh_mlp16_dgrad(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
+                   nerfhip_stream_t stream) {
+    if (p->W == 512) return nh_mlp16_dgrad_w512(p, packed, g_out, M, stash, scratch, stream);
+    Dgrad16Args d;
+    fill_dgrad_args(p, packed, g_out, M, stash, scratch, d);
+    const int64_t groups = nh_ceil_div(M, 128);
+    int rc = NERFHIP_OK;
     if (p->W == 256 && p->view) NH_BWD16(256, true)
     else if (p->W == 256) NH_BWD16(256, false)
     else if (p->W == 128 && p->view) NH_BWD16(128, true)
     else if (p->W == 128) NH_BWD16(128, false)
     else if (p->view) NH_BWD16(64, true)
     else NH_BWD16(64, false)
-#undef NH_BWD16
     return nh_launch_status("mlp_dgrad16");
 }
+#endif
+#undef NH_FWD16
+#undef NH_FWD16_T
+#undef NH_BWD16

@@ -28,3 +28,12 @@ int nh_mlp16_dgrad(nerfhip_plan* p, const float* packed, const float* g_out, int
 int64_t nh_wgrad_partial_floats(nerfhip_plan* p, int64_t nt);
 int nh_wgrad(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad, float* partial, float* g_params,
              nerfhip_stream_t stream);
+
+// render.hip: compositing backward with the optional dL/d||rd|| output, and the gradient w.r.t. the packed rays
+int nh_volume_render_bwd(const float* raw, const float* z, const float* rd, int rd_stride, int64_t n, int s, float noise_std,
+                         const float* noise, uint64_t seed, uint32_t rng_stream, uint64_t ray_offset, int white_background,
+                         const float* g_rgb, const float* g_depth, const float* g_acc, const float* g_weights, float* g_raw,
+                         float* g_norm, nerfhip_stream_t stream);
+int nh_ray_grad(const float* rays, int stride, int64_t n, const float* z, int S, const float* g_x, int dx, int dd, int inc_x,
+                int inc_d, int Lx, int Ld, const float* fx, const float* fd, const float* g_norm, float* g_rays, int accumulate,
+                nerfhip_stream_t stream);

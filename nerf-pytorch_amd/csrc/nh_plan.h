@@ -31,8 +31,12 @@ constexpr int NH16_KRX = 16;
 constexpr int NH16_KRD = 8;
 static inline int nh_feat16(int r, int g) { return 16 * (r >> 2) + 4 * g + (r & 3); }
 static inline int nh16_tq(int tiles) { return (tiles + 3) / 4; }
-constexpr int NH16_BIAS_FLOATS = 512;
-static inline int64_t nh16_image_floats(int kr, int tiles) { return NH16_BIAS_FLOATS + (int64_t)kr * nh16_tq(tiles) * 256; }
+// bias block in front of every layer image (one float per output row, 16 per tile): 512 floats cover the 17 tiles of a
+// 256-wide head, the 33 tiles of a 512-wide one need 1024
+constexpr int nh16_bias_floats(int W) { return W >= 512 ? 1024 : 512; }
+static inline int64_t nh16_image_floats(int kr, int tiles, int W) { return nh16_bias_floats(W) + (int64_t)kr * nh16_tq(tiles) * 256; }
+// 32-bit words of ReLU bits per lane and layer: one bit per activation register (W / 4 of them), at least two words
+constexpr int nh16_mask_words(int W) { return W >= 512 ? 4 : 2; }
 
 struct NhTensor {
     std::string name;
@@ -53,7 +57,10 @@ struct NhPackedOffsets {
     int64_t b_xyz[NH_MAX_LAYERS];
 };
 
-// Activation stash regions: [tiles][rows][32 samples] each, `row_prefix` rows precede it inside a tile group.
+// Activation stash regions: [tiles][32 samples][rows] each, `row_prefix` rows precede it inside a tile group.
+// 512-wide nets: a 512-row activation is stored as TWO consecutive 256-row regions (rows 0..255 at row_prefix, rows
+// 256..511 at row_prefix + 256; NhRegion::rows == 256 names the first half): the weight-gradient kernel reads whole
+// regions as contiguous blocks and its workgroups hold at most 8 x 8 accumulator tiles.
 struct NhRegion {
     int rows;
     int64_t row_prefix;  // offset (floats) = 32 * n_tiles * row_prefix
@@ -61,8 +68,8 @@ struct NhRegion {
 struct NhStashLayout {
     NhRegion X, D, H[NH_MAX_LAYERS], FEAT, DIRH;
     int64_t total_rows;
-    // After the row regions: ReLU bit masks, [tile][n_masks][64 lanes][4 words]; mask index k-1 = H_k (k >= 1),
-    // L-1 = FEAT, L = DIRH.
+    // After the row regions: ReLU bit masks, [16-sample wave tile][n_masks][64 lanes][nh16_mask_words(W)]; mask index
+    // k-1 = H_k (k >= 1), L-1 = FEAT, L = DIRH.
     int n_masks;
 };
 struct NhGradLayout {  // d(pre-activation) scratch written by the data-gradient kernel
@@ -92,7 +99,7 @@ struct NhJob {
 
 struct nerfhip_plan {
     nerfhip_model_cfg cfg;
-    int W, H, L, skip, Dx, Dd, view;  // W: kernel width (64 | 128 | 256) >= H: the model's hidden_size (units H..W-1 are zero padding)
+    int W, H, L, skip, Dx, Dd, view;  // W: kernel width (64 | 128 | 256 | 512) >= H: the model's hidden_size (units H..W-1 are zero padding)
     std::vector<NhTensor> tensors;
     int64_t nparams;
     int t_layer1_w, t_layer1_b, t_xyz_w[NH_MAX_LAYERS], t_xyz_b[NH_MAX_LAYERS];
@@ -108,6 +115,6 @@ struct nerfhip_plan {
     NhStashLayout stash;
     NhGradLayout grad;
     std::vector<NhJob> jobs;
-    int wgrad_waves;         // waves per workgroup of the weight-gradient kernel: 8 (256-wide nets) or 4 (128-wide)
+    int wgrad_waves;         // waves per workgroup of the weight-gradient kernel: 8 (256- and 512-wide nets) or 4 (narrower)
     bool is_skip(int i) const { return i % skip == 0 && i > 0; }
 };

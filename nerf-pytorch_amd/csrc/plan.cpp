@@ -48,10 +48,10 @@ struct GemmSpec16 {
     std::function<int64_t(int)> b;            // out_row -> flat param index or -1
 };
 
-void fill_spec16(const GemmSpec16& s, int64_t off, int32_t* table) {
-    const int tq = nh16_tq(s.tiles);
-    for (int i = 0; i < NH16_BIAS_FLOATS; ++i) table[off + i] = (i < 16 * s.tiles && s.b) ? (int32_t)s.b(i) : -1;
-    int32_t* img = table + off + NH16_BIAS_FLOATS;
+void fill_spec16(const GemmSpec16& s, int64_t off, int32_t* table, int W) {
+    const int tq = nh16_tq(s.tiles), bfl = nh16_bias_floats(W);
+    for (int i = 0; i < bfl; ++i) table[off + i] = (i < 16 * s.tiles && s.b) ? (int32_t)s.b(i) : -1;
+    int32_t* img = table + off + bfl;
     for (int r = 0; r < s.kr; ++r)
         for (int q = 0; q < tq; ++q)
             for (int lane = 0; lane < 64; ++lane)
@@ -66,7 +66,7 @@ struct Specs16 {
     GemmSpec16 f_layer1, f_xyz[NH_MAX_LAYERS], f_head, f_dir, f_rgb, b_rgb, b_dir, b_head, b_xyz[NH_MAX_LAYERS];
 };
 
-// Kernel width W (64, 128 or 256) >= the model's hidden_size H: units H..W-1 (H/2..W/2-1 of the direction layer) are
+// Kernel width W (64, 128, 256 or 512) >= the model's hidden_size H: units H..W-1 (H/2..W/2-1 of the direction layer) are
 // padding -- every weight and bias of a padded unit is the constant 0 (index -1), so it stays exactly 0 through the
 // forward chain, its ReLU bit is 0, and nothing flows through it in the backward chain.
 void build_specs16(const nerfhip_plan* p, Specs16& S) {
@@ -205,21 +205,21 @@ void layout_packed(nerfhip_plan* p) {
     build_specs16(p, S);
     for_each_spec(p, S, p->po, [&](const GemmSpec16& s, int64_t* dst) {
         *dst = off;
-        off += nh16_image_floats(s.kr, s.tiles);
+        off += nh16_image_floats(s.kr, s.tiles, p->W);
     });
     p->packed_floats = off;
 }
 
 NhRegion add_region(int64_t* total, int rows) {
     NhRegion r;
-    r.rows = rows;
+    r.rows = rows > 256 ? 256 : rows;  // a 512-row activation: two consecutive 256-row regions, named by the first
     r.row_prefix = *total;
     *total += rows;
     return r;
 }
 
-void add_job(nerfhip_plan* p, const NhRegion& A, int a_tiles, const NhRegion& B, int b_row0, int b_tiles, int r_lo,
-             int r_hi, int w_tensor, int col_kind, int col_base, int col_count, int bias_tensor) {
+void add_job1(nerfhip_plan* p, const NhRegion& A, int a_tiles, const NhRegion& B, int b_row0, int b_tiles,
+              int r_lo, int r_hi, int w_tensor, int col_kind, int col_base, int col_count, int bias_tensor) {
     NhJob j;
     memset(&j, 0, sizeof(j));
     j.a_region_rows = A.rows;
@@ -272,6 +272,24 @@ void add_job(nerfhip_plan* p, const NhRegion& A, int a_tiles, const NhRegion& B,
     j.col_count = col_count;
     j.bias_off = bias_tensor >= 0 ? p->tensors[bias_tensor].off : -1;
     p->jobs.push_back(j);
+}
+
+// One weight block = one job -- or, for 512-row activations (512-wide nets: two consecutive 256-row regions each), one
+// job per pair of halves.  `a_rows` / `b_rows`: rows of the whole activation (A.rows / B.rows name its first region).  Row
+// and column bounds of the job are the block's, shifted into the half's local indices; the bias gradient (row sums of A)
+// rides with the first B half only.
+void add_job(nerfhip_plan* p, const NhRegion& A, int a_tiles, const NhRegion& B, int b_row0, int b_tiles, int r_lo,
+             int r_hi, int w_tensor, int col_kind, int col_base, int col_count, int bias_tensor) {
+    for (int a0 = 0; a0 < a_tiles; a0 += 8)
+        for (int b0 = 0; b0 < b_tiles; b0 += 8) {
+            NhRegion Ah = A, Bh = B;
+            Ah.row_prefix += 32 * a0;  // (a0, b0 > 0 only for the second 256-row region of a 512-row activation)
+            Bh.row_prefix += 32 * b0;
+            const int ar = 32 * a0, bc = 32 * b0;
+            add_job1(p, Ah, a_tiles - a0 < 8 ? a_tiles - a0 : 8, Bh, b_row0, b_tiles - b0 < 8 ? b_tiles - b0 : 8, r_lo - ar,
+                     r_hi - ar, w_tensor, col_kind, col_base + (col_kind == 0 ? bc : 0), col_kind == 0 ? col_count - bc : col_count,
+                     b0 == 0 ? bias_tensor : -1);
+        }
 }
 
 void build_layouts_and_jobs(nerfhip_plan* p) {
@@ -329,8 +347,8 @@ extern "C" nerfhip_plan_t nerfhip_plan_create(const nerfhip_model_cfg* cfg) {
         nh_set_error("plan_create: cfg is NULL");
         return nullptr;
     }
-    if (cfg->hidden_size < 2 || cfg->hidden_size > 256) {
-        nh_set_error("plan_create: hidden_size must be in [2,256] (got %d)", cfg->hidden_size);
+    if (cfg->hidden_size < 2 || cfg->hidden_size > 512) {
+        nh_set_error("plan_create: hidden_size must be in [2,512] (got %d)", cfg->hidden_size);
         return nullptr;
     }
     if (cfg->num_layers < 1 || cfg->num_layers > NH_MAX_LAYERS) {
@@ -350,8 +368,8 @@ extern "C" nerfhip_plan_t nerfhip_plan_create(const nerfhip_model_cfg* cfg) {
     nerfhip_plan* p = new nerfhip_plan();
     p->cfg = *cfg;
     p->H = cfg->hidden_size;
-    // the kernels exist for three widths; a model rides zero-padded on the next one (build_specs16)
-    p->W = p->H <= 64 ? 64 : (p->H <= 128 ? 128 : 256);
+    // the kernels exist for four widths; a model rides zero-padded on the next one (build_specs16)
+    p->W = p->H <= 64 ? 64 : (p->H <= 128 ? 128 : (p->H <= 256 ? 256 : 512));
     p->L = cfg->num_layers;
     p->skip = cfg->skip_connect_every;
     p->view = cfg->use_viewdirs ? 1 : 0;
@@ -436,7 +454,7 @@ extern "C" int nerfhip_plan_pack_index(nerfhip_plan_t plan, int32_t* host_table)
     Specs16 S16;
     build_specs16(plan, S16);
     NhPackedOffsets o = plan->po;
-    for_each_spec(plan, S16, o, [&](const GemmSpec16& s, int64_t* dst) { fill_spec16(s, *dst, host_table); });
+    for_each_spec(plan, S16, o, [&](const GemmSpec16& s, int64_t* dst) { fill_spec16(s, *dst, host_table, plan->W); });
     return NERFHIP_OK;
 }
 
@@ -453,5 +471,6 @@ extern "C" int nerfhip_plan_set_freqs(nerfhip_plan_t plan, const float* freqs_xy
 extern "C" int64_t nerfhip_plan_stash_bytes(nerfhip_plan_t plan, int64_t m) {
     if (!plan || m < 0) return -1;
     int64_t tiles = nh_ceil_div(m, 128) * 4;
-    return tiles * (plan->stash.total_rows * 32 + (int64_t)plan->stash.n_masks * 256) * (int64_t)sizeof(float);
+    // per 32-sample tile: the row regions, then the ReLU masks of its two 16-sample wave tiles
+    return tiles * (plan->stash.total_rows * 32 + (int64_t)plan->stash.n_masks * 128 * nh16_mask_words(plan->W)) * (int64_t)sizeof(float);
 }

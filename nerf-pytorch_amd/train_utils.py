@@ -70,12 +70,16 @@ class _FusedRender(torch.autograd.Function):
     caller in torch, so it is covered too).  Inputs with a gradient: the parameters of the two nets, passed one by one
     (they alias each model's flat buffer; backward returns each its slice of the flat gradient).
 
+    With `rays_grad` the ray batch itself receives a gradient (pose optimisation: under autograd the reference
+    differentiates pts = ro + rd * z, train_utils.py:67,107, and dists * ||rd||, volume_rendering_utils.py:24): columns
+    0..5 (origin, direction) and 8..10 (viewdirs) of d(loss)/d(rays); near / far are constants of the ray.
+
     The workspace (activation stash, ~4.8 MB per ray for the 8x256 nets) is allocated per call from torch's caching
     allocator and owned by the autograd node: several nodes may be alive at once (run_one_iter_of_nerf renders a batch
     in ray chunks and backpropagates afterwards), so it must not be shared between calls."""
 
     @staticmethod
-    def forward(ctx, rays, model_c, model_f, cfg_tuple, rand, training, *params):
+    def forward(ctx, rays, model_c, model_f, cfg_tuple, rand, training, rays_grad, *params):
         lib = L.get_lib()
         nc, nf, perturb, lindisp, white, noise_std = cfg_tuple
         n, stride = rays.shape
@@ -103,14 +107,16 @@ class _FusedRender(torch.autograd.Function):
                            packed_f.data_ptr() if packed_f is not None else None, linspace01(nc, dev).data_ptr(),
                            linspace01(nf, dev).data_ptr() if nf > 0 else None, C.byref(rr), 0, 0, C.byref(out),
                            ws.data_ptr(), wsb, int(training), st)
-        ctx.keep = (rays, model_c, model_f, cfg, rand, ws, wsb, packed_c, packed_f, training)
+        # (the ray gradient multiplies by the weights of THIS forward: keep copies only if it will be asked for)
+        flats = (model_c._flat.clone(), model_f._flat.clone() if nf > 0 else None) if (training and rays_grad) else None
+        ctx.keep = (rays, model_c, model_f, cfg, rand, ws, wsb, packed_c, packed_f, training, flats)
         ctx.mark_non_differentiable(bufs["disp_coarse"], bufs["disp_fine"])
         return tuple(bufs[k] for k in names)
 
     @staticmethod
     def backward(ctx, g_rgb_c, g_disp_c, g_acc_c, g_depth_c, g_rgb_f, g_disp_f, g_acc_f, g_depth_f):
         lib = L.get_lib()
-        rays, model_c, model_f, cfg, rand, ws, wsb, packed_c, packed_f, training = ctx.keep
+        rays, model_c, model_f, cfg, rand, ws, wsb, packed_c, packed_f, training, flats = ctx.keep
         if not training:
             raise RuntimeError("fused render was run without gradient bookkeeping")
         n = rays.shape[0]
@@ -125,23 +131,31 @@ class _FusedRender(torch.autograd.Function):
             parts |= L.PART_FINE
         gpc = torch.zeros(model_c.num_flat_params, dtype=torch.float32, device=dev)
         gpf = torch.zeros(model_f.num_flat_params, dtype=torch.float32, device=dev) if nf > 0 else None
+        g_rays = torch.zeros_like(rays) if flats is not None else None
         if parts:
             cot = L.RenderCotangents(*[None if k is None else k.data_ptr() for k in keep])
             rr = L.RenderRand(*[None if r is None else r.data_ptr() for r in rand])
-            with L.launch_on(rays, ws, gpc, gpf, *[k for k in keep if k is not None]) as st:
-                lib.render_bwd_parts(model_c._plan, model_f._plan if nf > 0 else None, C.byref(cfg), rays.data_ptr(), n,
-                                     packed_c.data_ptr(), packed_f.data_ptr() if nf > 0 else None, C.byref(rr), 0, 0,
-                                     C.byref(cot), ws.data_ptr(), wsb, gpc.data_ptr(),
-                                     gpf.data_ptr() if gpf is not None else None, parts | L.PART_SHARED_BWD, st)
+            plan_f = model_f._plan if nf > 0 else None
+            tmp, tmpb = None, 0
+            if g_rays is not None:
+                tmpb = lib.render_bwd_rays_tmp_bytes(model_c._plan, plan_f, C.byref(cfg), n)
+                tmp = torch.empty(tmpb // 4 + 1, dtype=torch.float32, device=dev)
+            with L.launch_on(rays, ws, gpc, gpf, tmp, *[k for k in keep if k is not None]) as st:
+                lib.render_bwd_rays(model_c._plan, plan_f, C.byref(cfg), rays.data_ptr(), n,
+                                    packed_c.data_ptr(), packed_f.data_ptr() if nf > 0 else None, C.byref(rr), 0, 0,
+                                    C.byref(cot), ws.data_ptr(), wsb, gpc.data_ptr(),
+                                    gpf.data_ptr() if gpf is not None else None, parts | L.PART_SHARED_BWD,
+                                    flats[0].data_ptr() if flats is not None else None,
+                                    flats[1].data_ptr() if (flats is not None and flats[1] is not None) else None,
+                                    tmp.data_ptr() if tmp is not None else None, tmpb,
+                                    g_rays.data_ptr() if g_rays is not None else None, st)
         grads = model_c._split_flat(gpc) + (model_f._split_flat(gpf) if nf > 0 else ())
-        return (None,) * 6 + grads
+        return (g_rays,) + (None,) * 6 + grads
 
 
 def _predict_fused(ray_batch, model_coarse, model_fine, opts):
-    if ray_batch.requires_grad and torch.is_grad_enabled():
-        raise RuntimeError("the fused render produces no gradients w.r.t. the rays (pose optimisation is outside this "
-                           "path); detach() the ray batch")
-    rays = ray_batch.detach().contiguous().float()
+    rays_grad = bool(ray_batch.requires_grad and torch.is_grad_enabled())
+    rays = ray_batch.contiguous().float() if rays_grad else ray_batch.detach().contiguous().float()
     n = rays.shape[0]
     dev = rays.device
     nc, nf = opts.num_coarse, opts.num_fine
@@ -155,9 +169,9 @@ def _predict_fused(ray_batch, model_coarse, model_fine, opts):
     cfg_tuple = (nc, nf, bool(perturb), bool(opts.lindisp), bool(opts.white_background), float(noise_std))
     pc = model_coarse._ordered_params()
     pf = model_fine._ordered_params() if nf > 0 else []
-    training = torch.is_grad_enabled() and any(p.requires_grad for p in pc + pf)
+    training = torch.is_grad_enabled() and (rays_grad or any(p.requires_grad for p in pc + pf))
     outs = _FusedRender.apply(rays, model_coarse, model_fine if nf > 0 else None, cfg_tuple,
-                              (t_rand, noise_c, u, noise_f), training, *pc, *pf)
+                              (t_rand, noise_c, u, noise_f), training, rays_grad, *pc, *pf)
     rgb_c, disp_c, acc_c, depth_c, rgb_f, disp_f, acc_f, depth_f = outs
     if rgb_c.requires_grad:
         # disparity re-derived from the differentiable depth / accumulation maps with the reference's own torch ops
@@ -210,16 +224,51 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, mo
     return rgb_coarse, disp_coarse, acc_coarse, rgb_fine, disp_fine, acc_fine
 
 
+class _PackRays(torch.autograd.Function):
+    """rows [o d near far (d/||d||)] (train_utils.py:143-168) with the gradient autograd gives the reference for the
+    blender (no-NDC) branch: d(rays)/d(o) = I on columns 0..2, d/d(d) = I on columns 3..5 plus the normalisation of the
+    viewdirs columns, (g_v - v (v . g_v)) / ||d||."""
+
+    @staticmethod
+    def forward(ctx, ro, rd, near, far, use_view):
+        n = rd.shape[0]
+        rays = torch.empty((n, 11 if use_view else 8), dtype=torch.float32, device=rd.device)
+        with L.launch_on(ro, rd, rays) as st:
+            L.get_lib().pack_rays(ro.data_ptr(), rd.data_ptr(), rd.data_ptr() if use_view else None, near, far, n,
+                                  rays.data_ptr(), st)
+        ctx.save_for_backward(rd)
+        ctx.use_view = use_view
+        return rays
+
+    @staticmethod
+    def backward(ctx, g):
+        (rd,) = ctx.saved_tensors
+        g_ro, g_rd = g[:, 0:3].contiguous(), g[:, 3:6].clone()
+        if ctx.use_view:
+            nrm = rd.norm(p=2, dim=-1, keepdim=True)
+            v, gv = rd / nrm, g[:, 8:11]
+            g_rd = g_rd + (gv - v * (v * gv).sum(-1, keepdim=True)) / nrm
+        return g_ro, g_rd, None, None, None
+
+
 def pack_rays(ray_origins, ray_directions, options, height=None, width=None, focal_length=None):
-    """The ray packing of run_one_iter_of_nerf (nerf/train_utils.py:143-168): rows [o d near far (d/||d||)]."""
+    """The ray packing of run_one_iter_of_nerf (nerf/train_utils.py:143-168): rows [o d near far (d/||d||)].
+    Differentiable w.r.t. origins and directions for the blender (no-NDC) branch -- what pose optimisation needs."""
     lib = L.get_lib()
+    want_grad = torch.is_grad_enabled() and (ray_origins.requires_grad or ray_directions.requires_grad)
+    use_view = bool(options.nerf.use_viewdirs)
+    if want_grad:
+        if options.dataset.no_ndc is False:
+            raise RuntimeError("gradients w.r.t. the rays through ndc_rays are not implemented (no_ndc: False); detach() the rays")
+        ro = ray_origins.reshape(-1, 3).contiguous().float()
+        rd = ray_directions.reshape(-1, 3).contiguous().float()
+        return _PackRays.apply(ro, rd, float(options.dataset.near), float(options.dataset.far), use_view)
     rd_src = ray_directions.detach().reshape(-1, 3).contiguous().float()
     ro = ray_origins.detach().reshape(-1, 3).contiguous().float()
     rd = rd_src
     if options.dataset.no_ndc is False:
         ro, rd = ndc_rays(height, width, focal_length, 1.0, ro, rd_src)
     n = rd.shape[0]
-    use_view = bool(options.nerf.use_viewdirs)
     rays = torch.empty((n, 11 if use_view else 8), dtype=torch.float32, device=rd.device)
     with L.launch_on(ro, rd, rd_src, rays) as st:
         lib.pack_rays(ro.data_ptr(), rd.data_ptr(), rd_src.data_ptr() if use_view else None, float(options.dataset.near),

@@ -284,7 +284,7 @@ class Backend:
 
     # -- fused render ---------------------------------------------------------------------------------------------------
     def render(self, plan_c, plan_f, packed_c, packed_f, rays, opt, rand=None, seed=0, ray_offset=0, training=False,
-               g_rgb=None, want_regions=()):
+               g_rgb=None, want_regions=(), ray_grad_params=None):
         """opt: dict(num_coarse, num_fine, perturb, lindisp, white_background, noise_std).  Returns dict of outputs
         (+ flat grads 'g_params_coarse/fine' when g_rgb = (g_c, g_f) is given)."""
         rand = rand or {}
@@ -320,9 +320,20 @@ class Backend:
             gc, gf = self.dev(np.ascontiguousarray(g_rgb[0], np.float32)), self.devopt(g_rgb[1])
             gpc = self.empty((self.lib.plan_num_params(plan_c),))
             gpf = self.empty((self.lib.plan_num_params(plan_f),)) if nf > 0 else None
-            self.lib.render_bwd(plan_c, plan_f, C.byref(cfg), self.ptr(dr), n, self.ptr(packed_c), self.p(packed_f),
-                                C.byref(rr), seed, ray_offset, self.ptr(gc), self.p(gf), self.ptr(ws), wsb, self.ptr(gpc),
-                                self.p(gpf), self.stream())
+            if ray_grad_params is None:
+                self.lib.render_bwd(plan_c, plan_f, C.byref(cfg), self.ptr(dr), n, self.ptr(packed_c), self.p(packed_f),
+                                    C.byref(rr), seed, ray_offset, self.ptr(gc), self.p(gf), self.ptr(ws), wsb, self.ptr(gpc),
+                                    self.p(gpf), self.stream())
+            else:  # ... and d(loss)/d(rays): ray_grad_params = the two flat parameter vectors
+                fc, ff = self.dev(ray_grad_params[0]), self.devopt(ray_grad_params[1])
+                tb = self.lib.render_bwd_rays_tmp_bytes(plan_c, plan_f, C.byref(cfg), n)
+                tmp, g_rays = self.empty((tb // 4 + 1,)), self.empty((n, stride))
+                cot = L.RenderCotangents(self.ptr(gc), None, None, self.p(gf), None, None)
+                self.lib.render_bwd_rays(plan_c, plan_f, C.byref(cfg), self.ptr(dr), n, self.ptr(packed_c), self.p(packed_f),
+                                         C.byref(rr), seed, ray_offset, C.byref(cot), self.ptr(ws), wsb, self.ptr(gpc),
+                                         self.p(gpf), L.PART_COARSE | (L.PART_FINE if nf > 0 else 0), self.ptr(fc), self.p(ff),
+                                         self.ptr(tmp), tb, self.ptr(g_rays), self.stream())
+                out["g_rays"] = self.host(g_rays)
             out["g_params_coarse"] = self.host(gpc)
             out["g_params_fine"] = self.host(gpf) if gpf is not None else None
         return out

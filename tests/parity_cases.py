@@ -269,6 +269,10 @@ MLP_GEOMETRIES = {
     "deep8x64_skip4": model_cfg(8, 64, 4, 10, 4),
     "novw3x64_skip1": model_cfg(3, 64, 1, 10, 0, use_viewdirs=False),
     "one_layer_64": model_cfg(1, 64, 4, 4, 2),
+    # hidden_size in (256, 512]: the 512-wide instances (one wave per SIMD, accumulators in AGPRs), split weight-gradient jobs
+    "wide3x512_skip2": model_cfg(3, 512, 2, 10, 4),
+    "wide2x320": model_cfg(2, 320, 4, 6, 2),
+    "novw2x512": model_cfg(2, 512, 4, 4, 0, use_viewdirs=False),
     # other hidden sizes ride zero-padded on the next kernel width (plan.cpp build_specs16)
     "narrow3x40": model_cfg(3, 40, 2, 4, 2),
     "odd5x99_skip2": model_cfg(5, 99, 2, 10, 4),
@@ -460,6 +464,42 @@ def case_render_vs_oracle(b, cfg, n, nc, nf, seed=5, white=False, noise=0.3, wit
             grads = b.unflatten(plan, out[key])
             for k, v in grads.items():
                 grad_close(v, par[k].grad.numpy(), gt, "grad %s %s" % (key, k), "render_vs_oracle_%s_%s" % (tag or n, b.name), key)
+    b.lib.plan_destroy(pc)
+    b.lib.plan_destroy(pf)
+
+
+def case_ray_grad(b, cfg, n=24, nc=16, nf=16, seed=61, white=False, noise=0.0):
+    """nerfhip_render_bwd_rays: d(loss)/d(rays) -- origin, direction and viewdirs columns -- against the oracle's autograd
+    (nerf/train_utils.py:67,107: pts = ro + rd * z;  nerf/volume_rendering_utils.py:24: dists * ||rd||)."""
+    gen = rng(seed)
+    pc, par_c, flat_c, packed_c = mlp_setup(b, cfg, seed=seed + 1)
+    pf, par_f, flat_f, packed_f = mlp_setup(b, cfg, seed=seed + 2)
+    ro = torch.tensor([0.2, -0.1, 4.0]).expand(n, 3) + 0.05 * torch.randn(n, 3, generator=gen)
+    rd = torch.randn(n, 3, generator=gen) * 0.3
+    rd[:, 2] = -1.0
+    view = cfg["use_viewdirs"]
+    rays = O.pack_rays(ro, rd, 2.0, 6.0, rd if view else None).requires_grad_(True)
+    rand = dict(t_rand=torch.rand(n, nc, generator=gen), noise_coarse=torch.randn(n, nc, generator=gen),
+                u=torch.rand(n, nf, generator=gen), noise_fine=torch.randn(n, nc + nf, generator=gen))
+    opt = dict(num_coarse=nc, num_fine=nf, perturb=True, lindisp=False, white_background=white, noise_std=noise)
+    tgt = torch.rand(n, 3, generator=gen)
+    want = O.render_rays(rays, par_c, par_f, cfg, cfg, opt, rand)
+    loss, _, _, _ = O.loss_and_psnr(want["rgb_coarse"], want["rgb_fine"], tgt)
+    loss.backward()
+    ref = rays.grad.numpy()
+    rnp = {k: v.numpy() for k, v in rand.items()}
+    rays_np = rays.detach().numpy()
+    out = b.render(pc, pf, packed_c, packed_f, rays_np, opt, rnp, training=True)
+    l3, gc, gf = b.mse_loss(out["rgb_coarse"], out["rgb_fine"], tgt.numpy())
+    out = b.render(pc, pf, packed_c, packed_f, rays_np, opt, rnp, training=True, g_rgb=(gc, gf), ray_grad_params=(flat_c, flat_f))
+    got = out["g_rays"]
+    cols = [0, 1, 2, 3, 4, 5] + ([8, 9, 10] if view else [])
+    # (near / far, columns 6 and 7, are constants of the ray here; the oracle's autograd also differentiates the depths)
+    for lo, hi, what in ((0, 3, "origin"), (3, 6, "direction")) + (((8, 11, "viewdirs"),) if view else ()):
+        scale = float(np.abs(ref[:, lo:hi]).max()) + 1e-12
+        close(got[:, lo:hi], ref[:, lo:hi], 2e-3 * scale, what="d loss / d ray %s" % what)
+    assert np.all(got[:, 6:8] == 0.0)
+    assert len(cols) in (6, 9)
     b.lib.plan_destroy(pc)
     b.lib.plan_destroy(pf)
 

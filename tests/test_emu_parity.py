@@ -75,6 +75,15 @@ def test_render_64_wide_vs_oracle(emu):
                             grad_tol=(1e-3, 2e-2))
 
 
+def test_mlp_512_wide_instances(emu):
+    """hidden_size above 256 (nerf/models.py:186-196 takes any): 512-wide kernel instances, 512-row stash regions read
+    by the weight-gradient kernel one 256-row half at a time, four 32-bit words of ReLU bits per lane."""
+    names = ("wide3x512_skip2", "wide2x320", "novw2x512")
+    P.case_mlp_forward(emu, names=names, m=37)
+    P.case_mlp_backward(emu, names=names, m=70)
+    P.case_mlp_input_grad(emu, names=("wide3x512_skip2", "wide2x320"), m=45)
+
+
 def test_mlp_padded_hidden_sizes(emu):
     """hidden_size other than 128 / 256 (the reference constructor takes any: nerf/models.py:185-196), odd included."""
     names = ("narrow3x40", "odd5x99_skip2", "wide3x200_skip1", "novw2x130")
@@ -124,3 +133,8 @@ def test_image_output(emu):
 
 def test_e2e_northstar_reference_golden(emu):
     P.case_e2e_northstar_golden(emu)
+
+
+def test_ray_gradients(emu):
+    P.case_ray_grad(emu, P.MLP_GEOMETRIES["default4x128"])
+    P.case_ray_grad(emu, P.MLP_GEOMETRIES["novw3x64_skip1"], n=10, white=True, noise=0.5)

@@ -72,6 +72,19 @@ def test_render_64_wide_llff_config_vs_oracle(gpu):
                             tag="llff64_300", grad_tol=(1e-3, 2e-2))
 
 
+def test_mlp_512_wide_instances(gpu):
+    names = ("wide3x512_skip2", "wide2x320", "novw2x512")
+    P.case_mlp_forward(gpu, names=names, m=1000)
+    P.case_mlp_backward(gpu, names=names, m=1500)
+    P.case_mlp_input_grad(gpu, names=("wide3x512_skip2", "wide2x320"), m=1500)
+
+
+def test_render_512_wide_vs_oracle(gpu):
+    """An 8x512 net pair (hidden_size 512: nerf/models.py:186-196 takes it) through the fused render with gradients."""
+    P.case_render_vs_oracle(gpu, model_cfg(8, 512, 4, 10, 4), n=96, nc=64, nf=64, with_grads=True, tag="wide8x512_96",
+                            grad_tol=(3.4e-3, 2e-2))
+
+
 def test_mlp_padded_hidden_sizes(gpu):
     names = ("narrow3x40", "odd5x99_skip2", "wide3x200_skip1", "novw2x130")
     P.case_mlp_forward(gpu, names=names, m=700)
@@ -102,6 +115,13 @@ def test_default_model_render_white_background(gpu):
     P.case_render_vs_oracle(gpu, P.MLP_GEOMETRIES["default4x128"], n=200, nc=64, nf=64, white=True, noise=1.0,
                             with_grads=True, tag="default200_white_noise1",
                             grad_tol=(1e-5, 5.5e-3))    # measured 2.1e-6 / 1.1e-3
+
+
+def test_ray_gradients_c_abi(gpu):
+    P.case_ray_grad(gpu, P.MLP_GEOMETRIES["default4x128"], n=300, nc=64, nf=64)
+    P.case_ray_grad(gpu, P.MLP_GEOMETRIES["northstar8x256"], n=64, nc=32, nf=32, noise=0.2)
+    P.case_ray_grad(gpu, P.MLP_GEOMETRIES["novw3x64_skip1"], n=100, white=True, noise=0.5)
+    P.case_ray_grad(gpu, P.MLP_GEOMETRIES["wide2x320"], n=40)
 
 
 def test_internal_rng_equals_external_draws(gpu):
@@ -284,10 +304,6 @@ def test_python_api_unfused_composition_and_model_autograd():
         ref = xr.grad.numpy()
         P.close(xin.grad.cpu().numpy(), ref, 2e-5 * float(np.abs(ref).max()) + 1e-7, 2e-4, what="input grad")
         assert all((q.grad is None or not freeze) for q in m.parameters())
-    # the fused render does not differentiate its rays: asking for that fails loudly
-    rays_g = N.pack_rays(ro.to(dev), rd.to(dev), opts).requires_grad_(True)
-    with pytest.raises(RuntimeError, match="no gradients w.r.t. the rays"):
-        N.predict_and_render_radiance(rays_g, m, m, opts, encode_position_fn=ex, encode_direction_fn=ed)
 
 
 def test_python_api_unused_outputs_and_other_float_dtypes():
@@ -343,6 +359,59 @@ def test_python_api_unused_outputs_and_other_float_dtypes():
         assert xd.grad.dtype == dt
         P.close(y.detach().double().cpu().numpy(), yr.detach().numpy(), 0, tol, what="cumprod %s" % dt)
         P.close(xd.grad.double().cpu().numpy(), xr.grad.numpy(), 0, 5 * tol, what="cumprod grad %s" % dt)
+
+
+def test_gradients_wrt_rays_through_the_fused_render_vs_oracle_autograd():
+    """nerf/train_utils.py:67,107 and nerf/volume_rendering_utils.py:24: under autograd the reference differentiates
+    pts = ro + rd * z, the viewdirs and dists * ||rd|| w.r.t. the ray batch (pose optimisation).  The fused render's
+    d(loss)/d(ray_origins, ray_directions) through run_one_iter_of_nerf against the oracle's autograd on 256 rays, for a
+    loss on colour, accumulation and depth-derived disparity of both passes."""
+    import nerf_pytorch_amd as N
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    dev = torch.device("cuda", 0)
+    for cfg, seeds in ((model_cfg(4, 128, 4, 10, 4), (5, 6)), (model_cfg(8, 256, 4, 6, 2), (7, 8))):
+        kw = {k: cfg[k] for k in ("num_layers", "hidden_size", "skip_connect_every", "num_encoding_fn_xyz", "num_encoding_fn_dir")}
+        mc, mf = N.FlexibleNeRFModel(**kw), N.FlexibleNeRFModel(**kw)
+        par_c, par_f = O.init_params(cfg, seed=seeds[0]), O.init_params(cfg, seed=seeds[1])
+        mc.load_state_dict(par_c)
+        mf.load_state_dict(par_f)
+        mc, mf = mc.to(dev), mf.to(dev)
+        g = torch.Generator().manual_seed(21)
+        n, nc, nf = 256, 32, 32
+        ro = (torch.tensor([0.1, -0.2, 4.0]).expand(n, 3) + 0.05 * torch.randn(n, 3, generator=g)).contiguous()
+        rd = torch.randn(n, 3, generator=g) * 0.3
+        rd[:, 2] = -1.0
+        tgt = torch.rand(n, 3, generator=g)
+        opts = N.make_options(nc, nf, perturb=False, radiance_field_noise_std=0.0)
+        ex = N.get_embedding_function(cfg["num_encoding_fn_xyz"], True, True)
+        ed = N.get_embedding_function(cfg["num_encoding_fn_dir"], True, True)
+
+        def loss_of(o):
+            rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f = o
+            return ((rgb_f - tgt.to(rgb_f.device)) ** 2).mean() + ((rgb_c - tgt.to(rgb_f.device)) ** 2).mean() \
+                + 0.3 * (acc_f ** 2).mean() + 0.1 * torch.nan_to_num(disp_f).mean() + 0.2 * (acc_c ** 2).mean()
+
+        ro_g, rd_g = ro.to(dev).requires_grad_(True), rd.to(dev).requires_grad_(True)
+        out = N.run_one_iter_of_nerf(16, 16, 16.0, mc, mf, ro_g, rd_g, opts, encode_position_fn=ex, encode_direction_fn=ed)
+        loss_of(out).backward()
+        ro_r, rd_r = ro.clone().requires_grad_(True), rd.clone().requires_grad_(True)
+        rays = O.pack_rays(ro_r, rd_r, 2.0, 6.0, rd_r)
+        want = O.render_rays(rays, par_c, par_f, cfg, cfg, dict(num_coarse=nc, num_fine=nf, perturb=False, lindisp=False,
+                                                                 white_background=False, noise_std=0.0))
+        loss_of((want["rgb_coarse"], want["disp_coarse"], want["acc_coarse"], want["rgb_fine"], want["disp_fine"],
+                 want["acc_fine"])).backward()
+        for name, got, ref in (("ray_origins", ro_g.grad, ro_r.grad), ("ray_directions", rd_g.grad, rd_r.grad)):
+            ref = ref.numpy()
+            scale = float(np.abs(ref).max())
+            assert scale > 0
+            P.close(got.cpu().numpy(), ref, 2e-3 * scale, what="d loss / d %s (%dx%d)" % (name, cfg["num_layers"], cfg["hidden_size"]))
+        # the parameters got their gradients in the same backward
+        assert all(p.grad is not None and float(p.grad.abs().max()) > 0 for p in mf.parameters())
+    # NDC rays: stated limit, loud
+    opts_ndc = N.make_options(nc, nf, no_ndc=False)
+    with pytest.raises(RuntimeError, match="ndc_rays are not implemented"):
+        N.run_one_iter_of_nerf(16, 16, 16.0, mc, mf, ro_g, rd_g, opts_ndc, encode_position_fn=ex, encode_direction_fn=ed)
 
 
 def test_pretrained_lego_checkpoint_renders_like_the_reference():

@@ -41,7 +41,7 @@ def test_library_exports_every_declared_symbol(lib):
 def test_errors_are_reported_not_thrown(lib):
     with pytest.raises(L.NerfHipError, match="bad arguments"):
         lib.cumprod_exclusive(None, 1, 4, None, None)
-    bad = L.ModelCfg(4, 300, 4, 10, 4, 1, 1, 1, 1, 1)
+    bad = L.ModelCfg(4, 600, 4, 10, 4, 1, 1, 1, 1, 1)
     assert not lib.plan_create(C.byref(bad))
     assert b"hidden_size" in lib.last_error()
     bad = L.ModelCfg(4, 128, 4, 11, 4, 1, 1, 1, 1, 1)
@@ -152,7 +152,8 @@ def test_product_reads_no_environment_and_ships_one_kernel_set():
     wg = open(os.path.join(csrc, "wgrad.hip")).read()
     assert wg.count("#ifdef NH_WGRAD_TIMELINE") >= 3 and "nh_wall_clock()" in wg  # instrumentation is debug-build only
     assert sorted(f for f in os.listdir(csrc) if f.endswith(".hip")) == [
-        "dataio.hip", "elementwise.hip", "fused.hip", "mlp.hip", "mlp16.hip", "render.hip", "sample.hip", "wgrad.hip"]
+        "dataio.hip", "elementwise.hip", "fused.hip", "mlp.hip", "mlp16.hip", "mlp16_w512.hip", "render.hip", "sample.hip",
+        "wgrad.hip"]
 
 
 def test_shard_bounds():

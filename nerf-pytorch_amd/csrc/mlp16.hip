@@ -29,11 +29,15 @@ namespace {
 #define NH16_NARROW_NW 4
 #define NH16_NARROW_CHUNK 6144
 #endif
+#ifndef NH16_WIDE_NW  // (A/B builds only; e.g. 4 waves and 8192-float chunks: two independent workgroups per CU)
+#define NH16_WIDE_NW 8
+#define NH16_WIDE_CHUNK 16384
+#endif
 template <int W>
 struct Shape {
     // waves per workgroup.  512-wide nets (132 accumulator + 128 activation registers per 16 samples): ONE wave per SIMD
     // with the whole unified register file (accumulators in AGPRs), 4-wave workgroups, one per CU
-    static constexpr int NW = W >= 512 ? 4 : (W >= 256 ? 8 : NH16_NARROW_NW);
+    static constexpr int NW = W >= 512 ? 4 : (W >= 256 ? NH16_WIDE_NW : NH16_NARROW_NW);
     static constexpr int WAVES_PER_SIMD = W >= 512 ? 1 : 2;  // launch bound (minimum occupancy the registers must allow)
     static constexpr int MW = nh16_mask_words(W);            // 32-bit words of ReLU bits per lane and layer
 };
@@ -42,7 +46,7 @@ struct Shape {
 // 64-wide nets 4096 (a whole 64 x 64 layer = 16 k-steps x 1 quad: one chunk per layer)
 template <int W>
 struct Lds {
-    static constexpr int CHUNK_MAX = W >= 256 ? 16384 : (W >= 128 ? NH16_NARROW_CHUNK : 4096);
+    static constexpr int CHUNK_MAX = W >= 512 ? 16384 : (W >= 256 ? NH16_WIDE_CHUNK : (W >= 128 ? NH16_NARROW_CHUNK : 4096));
     static constexpr int BIAS = nh16_bias_floats(W);
     static constexpr int BYTES = (2 * CHUNK_MAX + 2 * BIAS) * 4;
     static constexpr int BYTES_ALL = BYTES + NH_CLK_LDS_BYTES;  // + the clock probe's stamps (nh_clk_begin)

@@ -39,9 +39,10 @@ struct JobRed {  // k_wgrad_reduce
     int col_kind, col_base, col_count;
     int bias_off;
     int wg_start;
+    int ks_log;  // log2 of the K-slices per element in k_wgrad_reduce: 0, 2 or 4 (fewer accumulator tiles -> more slices)
 };
 constexpr int NH_JOBS_DEV = NH_MAX_JOBS;
-static_assert(sizeof(JobDev) * NH_JOBS_DEV + 128 <= 4096 && sizeof(JobRed) * NH_JOBS_DEV + 320 <= 4096,
+static_assert(sizeof(JobDev) * NH_JOBS_DEV + 128 <= 4096 && sizeof(JobRed) * NH_JOBS_DEV + 232 <= 4096,
               "the job tables must fit the 4 KB kernel-argument limit");
 // Workgroup shapes.  256-wide nets: 8 waves per workgroup (two per SIMD), two LDS stages of 16384 floats (+ slack for
 // the operand prefetch that runs one k-step past the end of a stage): one workgroup per CU.  128-wide nets (jobs of at
@@ -381,39 +382,56 @@ NH_KERNEL void NH_LB(64 * MD::NWV, 2) k_wgrad(WgradArgs a) {
 // lane l holds dW[out_row][in_row] with (MFMA row m = (c&3) + 8(c>>2) + 4(l>>5), column j = l&31, and the row
 // interleave of the wide operand reads)  out_row = 32*po*(a_t/po) + po*m + a_t%po,  in_row = 32*pi*(b_t/pi) + pi*j + b_t%pi.
 NH_KERNEL void k_wgrad_reduce(ReduceArgs a) {
+    NH_SHARED float part[256];
     const int ji = (int)(blockIdx.x >> 8);
     const JobRed jb = a.jobs[ji];
-    const int local = (int)((blockIdx.x & 255u) * 256u + threadIdx.x);
+    // A job owns 256 blocks of 256 threads.  Jobs with few accumulator tiles would leave most of them idle and a handful of
+    // threads with ~150 dependent partial loads each (the 64- and 128-wide nets: this kernel was 3-6 % of their step), so a
+    // block covers 256 >> ksl elements with (1 << ksl) K-slices per element: slice s sums partials s, s + KS, ... and the
+    // slices are combined through LDS in slice order -- a fixed order: bit-reproducible, no atomics.
+    const int ksl = jb.ks_log, epb = 256 >> ksl, nsl = 1 << ksl;
+    const int e_local = (int)threadIdx.x & (epb - 1), slice = (int)threadIdx.x >> (8 - ksl);
+    const int local = (int)(blockIdx.x & 255u) * epb + e_local;
     const int lane = local & 63, c = (local >> 6) & 15, tile = local >> 10;  // accumulator tile (a_t, b_t) = a_t * b_tiles + b_t
     const int a_t = tile / jb.b_tiles, b_t = tile % jb.b_tiles;
-    if (a_t >= jb.a_tiles) return;
+    const bool in_job = a_t < jb.a_tiles;
     const int nks = (ji + 1 < a.njobs ? a.jobs[ji + 1].wg_start : a.total_wgs) - jb.wg_start;
     const int m = (c & 3) + 8 * (c >> 2) + 4 * (lane >> 5);
     const int out_row = 32 * jb.po * (a_t / jb.po) + jb.po * m + a_t % jb.po;
     const int in_row = 32 * jb.pi * (b_t / jb.pi) + jb.pi * (lane & 31) + b_t % jb.pi;
-    if (out_row >= jb.r_lo && out_row < jb.r_hi) {
-        int col = -1;
+    int col = -1;
+    if (in_job && out_row >= jb.r_lo && out_row < jb.r_hi) {
         if (jb.col_kind == 0) {
             if (in_row < jb.col_count) col = jb.col_base + in_row;
         } else {
             const int cc = jb.col_kind == 1 ? (int)a.xslot[in_row] : (int)a.dslot[in_row];  // stash slot row -> column
             if (cc >= 0) col = jb.col_base + cc;
         }
-        if (col >= 0) {
-            // eight interleaved running sums (a fixed order: bit-reproducible) keep eight loads in flight per lane
-            float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            const float* p = a.partial + (size_t)jb.wg_start * a.part_stride + ((size_t)tile * 16 + c) * 64 + lane;
-            int q = 0;
-            for (; q + 8 <= nks; q += 8) {
+    }
+    float total = 0.0f;
+    if (col >= 0) {
+        // eight interleaved running sums (a fixed order) keep eight loads in flight per lane
+        float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float* p = a.partial + (size_t)jb.wg_start * a.part_stride + ((size_t)tile * 16 + c) * 64 + lane;
+        const size_t step = (size_t)nsl * a.part_stride;
+        int q = slice;
+        for (; q + 7 * nsl < nks; q += 8 * nsl) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) sum[u] += p[(size_t)(q + u) * a.part_stride];
-            }
-            for (; q < nks; ++q) sum[0] += p[(size_t)q * a.part_stride];
-            a.g_params[(size_t)jb.w_off + (size_t)(out_row - jb.r_lo) * jb.w_ld + col] =
-                ((sum[0] + sum[1]) + (sum[2] + sum[3])) + ((sum[4] + sum[5]) + (sum[6] + sum[7]));
+            for (int u = 0; u < 8; ++u) sum[u] += p[(size_t)q * a.part_stride + u * step];
+        }
+        for (; q < nks; q += nsl) sum[0] += p[(size_t)q * a.part_stride];
+        total = ((sum[0] + sum[1]) + (sum[2] + sum[3])) + ((sum[4] + sum[5]) + (sum[6] + sum[7]));
+    }
+    if (ksl > 0) {
+        part[threadIdx.x] = total;
+        nh_block_sync();
+        if (slice == 0) {
+            total = 0.0f;
+            for (int sidx = 0; sidx < nsl; ++sidx) total += part[sidx * epb + e_local];
         }
     }
-    if (jb.bias_off >= 0 && b_t == 0 && c == 0 && lane < 32) {
+    if (col >= 0 && slice == 0) a.g_params[(size_t)jb.w_off + (size_t)(out_row - jb.r_lo) * jb.w_ld + col] = total;
+    if (slice == 0 && in_job && jb.bias_off >= 0 && b_t == 0 && c == 0 && lane < 32) {
         const int brow = 32 * jb.po * (a_t / jb.po) + jb.po * lane + a_t % jb.po;
         if (brow >= jb.r_lo && brow < jb.r_hi) {
             // (the same eight interleaved sums: a one-deep chain of nks dependent loads used to set this kernel's duration)
@@ -507,6 +525,8 @@ void wgrad_schedule(const nerfhip_plan* p, int64_t nt, WgradArgs& w, ReduceArgs*
             e.col_count = j.col_count;
             e.bias_off = (int)j.bias_off;
             e.wg_start = start;
+            const int tiles = j.a_tiles * j.b_tiles;  // 256 blocks x (256 >> ks_log) elements must cover tiles * 1024
+            e.ks_log = tiles <= 4 ? 4 : (tiles <= 16 ? 2 : 0);
         }
         start += (int)ks[q];
     }

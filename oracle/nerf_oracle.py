@@ -240,6 +240,32 @@ def mlp_forward(params, x, cfg):
     return F.linear(h, params["fc_out.weight"], params["fc_out.bias"])
 
 
+def mlp_relu_margin(params, x, cfg):
+    """Per input row: the smallest |pre-activation| among everything FlexibleNeRFModel.forward (nerf/models.py:233-256)
+    passes through a ReLU, relative to the largest one of the row.  A row whose margin is ~1e-7 has a unit whose ReLU
+    branch is decided by fp32 round-off: two fp32 implementations with different summation orders may take different
+    branches there, and that row's gradient then differs by O(1) of the unit's contribution (tests exclude such rows)."""
+    dx, dd = model_dims(cfg)
+    L = cfg["num_layers"]
+    xyz = x[..., :dx]
+    h = F.linear(xyz, params["layer1.weight"], params["layer1.bias"])
+    pres = []
+    for i in range(L - 1):
+        if is_skip_layer(i, cfg):
+            h = torch.cat((h, xyz), dim=-1)
+        pre = F.linear(h, params["layers_xyz.%d.weight" % i], params["layers_xyz.%d.bias" % i])
+        pres.append(pre)
+        h = F.relu(pre)
+    if cfg.get("use_viewdirs", True):
+        pre = F.linear(h, params["fc_feat.weight"], params["fc_feat.bias"])
+        pres.append(pre)
+        pres.append(F.linear(torch.cat((F.relu(pre), x[..., dx:]), dim=-1), params["layers_dir.0.weight"], params["layers_dir.0.bias"]))
+    if not pres:
+        return torch.ones(x.shape[0])
+    allp = torch.cat(pres, dim=-1)
+    return allp.abs().min(dim=-1).values / (allp.abs().max(dim=-1).values + 1e-30)
+
+
 def run_network(params, pts, rays, cfg, chunksize=None):
     """nerf/train_utils.py:8-25: encode points (+ per-ray view directions broadcast over samples), run the MLP."""
     flat = pts.reshape(-1, 3)

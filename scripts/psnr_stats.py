@@ -1,8 +1,9 @@
 """Paired statistics of scripts/psnr_arms.py runs:  python scripts/psnr_stats.py gpurun_out/psnr_arms > profiles/r03_psnr_400.txt
 Per checkpoint and arm pair: mean paired difference of validation PSNR over the usable seeds, its 95 % confidence
-interval (Student t), and an exact two-sided sign test.  A seed is dropped (and reported) when the COARSE net collapsed in
-the reference-draw arms: validation coarse+fine PSNR below 12 dB at the last checkpoint while the fine-only PSNR is above
-20 dB (the failure mode round 2 met with seed 0: the coarse net renders a constant, the fine net still learns)."""
+interval (Student t), and an exact two-sided sign test.  A seed is dropped (and reported) when one of its nets COLLAPSED in
+any arm: validation coarse+fine PSNR below 12 dB at the last checkpoint -- one of the two nets renders a constant (dead
+ReLUs under lr 5e-3: round 2 met it with the coarse net of seed 0, the 8x256 students of round 3 with the fine net of
+seeds 3 and 4), which the reference's own path does from the same initial weights."""
 import glob
 import json
 import math
@@ -36,10 +37,13 @@ def main(root):
     collapsed = []
     for s, j in sorted(runs.items()):
         for arm, h in j["arms"].items():
-            if h[last]["val_psnr"] < 12.0 and h[last]["val_psnr_fine"] > 20.0:
-                collapsed.append((s, arm, round(h[last]["val_psnr"], 2), round(h[last]["val_psnr_fine"], 2)))
-    bad = sorted({s for s, _, _, _ in collapsed})
-    print("# collapsed coarse nets (val < 12 dB, fine-only > 20 dB at iteration %s): %s" % (last, collapsed or "none"))
+            if h[last]["val_psnr"] < 12.0:
+                which = "fine" if h[last]["val_psnr_fine"] < 12.0 else "coarse"
+                collapsed.append((s, arm, which, round(h[last]["val_psnr"], 2), round(h[last]["val_psnr_fine"], 2),
+                                  round(h[last].get("val_psnr_coarse", float("nan")), 2)))
+    bad = sorted({c[0] for c in collapsed})
+    print("# collapsed nets (validation PSNR < 12 dB at iteration %s) as (seed, arm, net, val, val fine-only, val coarse-only): %s"
+          % (last, collapsed or "none"))
     print("# seeds dropped from the paired statistics: %s" % (bad or "none"))
     use = [s for s in sorted(runs) if s not in bad]
     arms = [a for a in ("ref", "dropin", "engine_td", "engine") if any(a in runs[s]["arms"] for s in use)]

@@ -313,6 +313,12 @@ def case_mlp_backward(b, names=None, m=150):
         gen = rng(42)
         x = torch.randn(m, dx + dd, generator=gen)
         go = torch.randn(m, 4, generator=gen)
+        # rows with a ReLU input within 1e-6 (relative) of zero are dropped: their branch is decided by fp32 round-off, the
+        # kernel's k-ordered sums and torch's GEMM may disagree, and ONE such unit moves the gradient by 1e-2 of max|g|
+        # (seen on MI355X and on the emulator alike: sample 136 of seed 42 for the 3x512 net, pre-activation 3.7e-9)
+        keep = O.mlp_relu_margin(params, x, cfg) > 1e-6
+        x, go = x[keep].contiguous(), go[keep].contiguous()
+        assert x.shape[0] >= m - 8
         p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
         (O.mlp_forward(p, x, cfg) * go).sum().backward()
         got_y, stash = b.mlp_fwd(plan, packed, x.numpy(), want_stash=True)
@@ -487,19 +493,34 @@ def case_ray_grad(b, cfg, n=24, nc=16, nf=16, seed=61, white=False, noise=0.0):
     loss, _, _, _ = O.loss_and_psnr(want["rgb_coarse"], want["rgb_fine"], tgt)
     loss.backward()
     ref = rays.grad.numpy()
+    # the yardstick: the same autograd in fp64.  Ray gradients are ill-conditioned (d/dp of sin(2^9 p), ReLU branches decided
+    # by round-off): the oracle's OWN fp32 run differs from its fp64 run by 1e-2 of max|g| on a few per cent of the rays
+    # (measured: 15 of 256 rays beyond 2e-3, median 1.5e-5), so the kernel is held to that distribution, not to a max
+    r64 = rays.detach().double().requires_grad_(True)
+    w64 = O.render_rays(r64, {k: v.double() for k, v in par_c.items()}, {k: v.double() for k, v in par_f.items()}, cfg, cfg, opt,
+                        {k: v.double() for k, v in rand.items()})
+    l64, _, _, _ = O.loss_and_psnr(w64["rgb_coarse"], w64["rgb_fine"], tgt.double())
+    l64.backward()
+    ref64 = r64.grad.numpy()
     rnp = {k: v.numpy() for k, v in rand.items()}
     rays_np = rays.detach().numpy()
     out = b.render(pc, pf, packed_c, packed_f, rays_np, opt, rnp, training=True)
     l3, gc, gf = b.mse_loss(out["rgb_coarse"], out["rgb_fine"], tgt.numpy())
     out = b.render(pc, pf, packed_c, packed_f, rays_np, opt, rnp, training=True, g_rgb=(gc, gf), ray_grad_params=(flat_c, flat_f))
     got = out["g_rays"]
-    cols = [0, 1, 2, 3, 4, 5] + ([8, 9, 10] if view else [])
     # (near / far, columns 6 and 7, are constants of the ray here; the oracle's autograd also differentiates the depths)
+    rec = {}
     for lo, hi, what in ((0, 3, "origin"), (3, 6, "direction")) + (((8, 11, "viewdirs"),) if view else ()):
-        scale = float(np.abs(ref[:, lo:hi]).max()) + 1e-12
-        close(got[:, lo:hi], ref[:, lo:hi], 2e-3 * scale, what="d loss / d ray %s" % what)
+        scale = float(np.abs(ref64[:, lo:hi]).max()) + 1e-30
+        e_hip = np.abs(got[:, lo:hi] - ref[:, lo:hi]).max(axis=1) / scale            # kernel vs the oracle's fp32 autograd
+        e_yard = np.abs(ref[:, lo:hi] - ref64[:, lo:hi]).max(axis=1) / scale         # the oracle's fp32 vs its fp64 autograd
+        rec[what] = dict(hip_median=float(np.median(e_hip)), yard_median=float(np.median(e_yard)), hip_over=int((e_hip > 2e-3).sum()),
+                         yard_over=int((e_yard > 2e-3).sum()), hip_max=float(e_hip.max()), yard_max=float(e_yard.max()))
+        assert np.median(e_hip) <= 3.0 * np.median(e_yard) + 2e-6, (what, rec[what])
+        assert (e_hip > 2e-3).sum() <= 2 * (e_yard > 2e-3).sum() + 3, (what, rec[what])
+    note("ray_grad_%dx%d_n%d_%s" % (cfg["num_layers"], cfg["hidden_size"], n, b.name), **{"%s_%s" % (w_, k): v for w_, d in rec.items()
+                                                                                            for k, v in d.items()})
     assert np.all(got[:, 6:8] == 0.0)
-    assert len(cols) in (6, 9)
     b.lib.plan_destroy(pc)
     b.lib.plan_destroy(pf)
 

@@ -208,7 +208,7 @@ def pytorch_rocm_reference(dev, n=RAYS_PER_GPU, reps=3):
                 "fwd+bwd, no optimizer, %d rays, best of %d" % (n, reps))
 
 
-def cpu_baseline_eval(sample_rays=1024):
+def cpu_baseline_eval(sample_rays=8192):
     """Config 5's CPU leg: the oracle's forward-only render (no_grad, perturb off, noise 0) of `sample_rays` rays."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import nerf_oracle as O

@@ -166,6 +166,9 @@ int nerfhip_plan_dim_dir(nerfhip_plan_t plan);
 /* Number of tensors and, for tensor i, its name, offset into the flat vector and 2-D shape (cols = 0 for a bias). */
 int nerfhip_plan_num_tensors(nerfhip_plan_t plan);
 int nerfhip_plan_tensor_info(nerfhip_plan_t plan, int i, const char** name, int64_t* offset, int* rows, int* cols);
+/* Human-readable kernel schedule of the plan (host-only): kernel width, and one line per weight-gradient job -- tiles, wave
+ * grid, per-wave patch, split-K cost, and the thin weight block riding on it as side tiles, if any. */
+int nerfhip_plan_describe(nerfhip_plan_t plan, char* buf, int64_t cap);
 /* MFMA-packed weight image: number of floats, and the gather table (host int32[packed_floats]: source index into
  * the flat parameter vector, or -1 for zero padding). */
 int64_t nerfhip_plan_packed_floats(nerfhip_plan_t plan);

@@ -87,6 +87,7 @@ _PROTOS = {
     "nerfhip_plan_tensor_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(c_i64),
                                             C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "nerfhip_plan_packed_floats": (c_i64, [C.c_void_p]),
+    "nerfhip_plan_describe": (C.c_int, [C.c_void_p, C.c_char_p, c_i64]),
     "nerfhip_plan_pack_index": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nerfhip_pack_weights": (C.c_int, [c_f, c_f, c_i64, c_f, c_f]),
     "nerfhip_plan_stash_bytes": (c_i64, [C.c_void_p, c_i64]),

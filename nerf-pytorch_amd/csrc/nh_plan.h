@@ -95,6 +95,13 @@ struct NhJob {
     int col_base, col_count;
     int64_t bias_off;     // flat offset of the bias tensor, or -1 (only one job per layer carries the bias)
     int cost;             // relative time one workgroup spends per sample tile (split-K allocation)
+    // A second, thin weight block riding on this job (wgrad.hip "side tiles"): kind 1 = ONE extra A tile (a 32-row region of
+    // the gradient scratch) against this job's B tiles; kind 2 = side_tiles (1 | 2) extra B tiles (a 32- / 64-row region of
+    // the stash) against this job's A tiles.  s_*: how the reduce kernel unpacks it (as r_lo .. bias_off above).
+    int side_kind, side_rows, side_tiles;
+    int64_t side_row_prefix;
+    int s_r_lo, s_r_hi, s_w_ld, s_col_kind, s_col_base, s_col_count;
+    int64_t s_w_off, s_bias_off;
 };
 
 struct nerfhip_plan {

@@ -292,6 +292,60 @@ void add_job(nerfhip_plan* p, const NhRegion& A, int a_tiles, const NhRegion& B,
         }
 }
 
+// Thin weight blocks become side tiles of the job that streams the same region anyway (wgrad.hip): a block with ONE A
+// tile (fc_alpha: POUT x H_{L-1}) rides on the job with the same B region (fc_feat) when every B tile of a column's patch
+// finds a wave (pi <= wo); a block with one or two B tiles (the direction columns: PDIR x D; a skip layer's encoding
+// columns: P_{i+1} x X) rides on the job with the same A region when its po * tiles pairs per wave row fit two per wave,
+// and when the stage still holds one sample tile of all three regions.  The guest's job disappears from the list.
+void attach_sides(nerfhip_plan* p, int stage_floats) {
+    if (p->W > 256) return;  // (512-wide nets: the hosts are half-region jobs; their stages are full)
+    std::vector<NhJob>& J = p->jobs;
+    for (size_t gi = 0; gi < J.size(); ++gi) {
+        const NhJob g = J[gi];
+        if (g.side_kind) continue;
+        int host = -1, kind = 0;
+        for (size_t hi = 0; hi < J.size() && host < 0; ++hi) {
+            const NhJob& h = J[hi];
+            if (hi == gi || h.side_kind || h.a_tiles * h.b_tiles < 8) continue;
+            if (32 * (h.a_region_rows + h.b_region_rows + 32 * (g.a_tiles == 1 ? 1 : g.b_tiles)) > stage_floats) continue;
+            if (g.a_tiles == 1 && g.a_region_rows == 32 && h.b_row_prefix == g.b_row_prefix && h.b_tiles == g.b_tiles && h.pi <= h.wo &&
+                ((p->wgrad_waves == 8 && h.po == 4 && h.pi == 2) || (p->wgrad_waves == 4 && h.po == 2 && h.pi == 2))) {
+                host = (int)hi, kind = 1;
+            } else if (g.b_tiles <= 2 && g.b_region_rows == 32 * g.b_tiles && g.a_tiles > 1 && h.a_row_prefix == g.a_row_prefix &&
+                       h.a_tiles == g.a_tiles) {
+#ifdef NH_WGRAD_SIDE2  // (A/B builds only; see wgrad.hip)
+                const bool two = g.b_tiles == 2 && p->wgrad_waves == 8 && h.po == 4 && h.pi == 2 && h.wi == 4;
+#else
+                const bool two = false;
+#endif
+                const bool one = g.b_tiles == 1 && h.po <= h.wi &&
+                                 ((p->wgrad_waves == 8 && h.po == 2 && h.pi == 2) ||
+                                  (p->wgrad_waves == 4 && ((h.po == 1 && h.pi == 2) || (h.po == 2 && h.pi == 1))));
+                if (two || one) host = (int)hi, kind = 2;
+            }
+        }
+        if (host < 0) continue;
+        NhJob& h = J[host];
+        h.side_kind = kind;
+        h.side_rows = kind == 1 ? g.a_region_rows : g.b_region_rows;
+        h.side_tiles = kind == 1 ? 1 : g.b_tiles;
+        h.side_row_prefix = kind == 1 ? g.a_row_prefix : g.b_row_prefix;
+        h.s_r_lo = g.r_lo;
+        h.s_r_hi = g.r_hi;
+        h.s_w_off = g.w_off;
+        h.s_w_ld = g.w_ld;
+        h.s_col_kind = g.col_kind;
+        h.s_col_base = g.col_base;
+        h.s_col_count = g.col_count;
+        h.s_bias_off = g.bias_off;
+        // its MFMAs now run inside the host's k-steps: one or two more per wave, one more operand
+        const int per_simd = (h.wo * h.wi + 3) / 4;
+        h.cost += 30 * per_simd * (kind == 2 && g.b_tiles == 2 ? 2 : 1) + 20 * per_simd;
+        J.erase(J.begin() + gi);
+        --gi;
+    }
+}
+
 void build_layouts_and_jobs(nerfhip_plan* p) {
     const int W = p->W, L = p->L;
     NhStashLayout& S = p->stash;
@@ -338,6 +392,9 @@ void build_layouts_and_jobs(nerfhip_plan* p) {
     } else {
         add_job(p, G.POUT, 1, S.H[L - 1], 0, TW, 0, 4, p->t_out_w, 0, 0, H, p->t_out_b);
     }
+#ifndef NH_WGRAD_NO_SIDES  // (A/B builds only)
+    attach_sides(p, p->wgrad_waves == 4 ? 9216 : 18432);  // (the stage sizes of wgrad.hip's two modes)
+#endif
 }
 
 }  // namespace
@@ -448,6 +505,24 @@ extern "C" int nerfhip_plan_tensor_info(nerfhip_plan_t plan, int i, const char**
     return NERFHIP_OK;
 }
 extern "C" int64_t nerfhip_plan_packed_floats(nerfhip_plan_t plan) { return plan ? plan->packed_floats : -1; }
+
+extern "C" int nerfhip_plan_describe(nerfhip_plan_t plan, char* buf, int64_t cap) {
+    NH_REQUIRE(plan && buf && cap > 0, "plan_describe: bad arguments");
+    int64_t used = 0;
+    auto put = [&](const char* fmt, auto... v) {
+        if (used >= cap - 1) return;
+        const int w = snprintf(buf + used, (size_t)(cap - used), fmt, v...);
+        if (w > 0) used += w < cap - used ? w : cap - used - 1;
+    };
+    put("kernel_width %d hidden_size %d layers %d params %lld packed_floats %lld wgrad_waves %d jobs %d\n", plan->W, plan->H, plan->L,
+        (long long)plan->nparams, (long long)plan->packed_floats, plan->wgrad_waves, (int)plan->jobs.size());
+    for (size_t q = 0; q < plan->jobs.size(); ++q) {
+        const NhJob& j = plan->jobs[q];
+        put("job %d tiles %dx%d waves %dx%d patch %dx%d cost %d side %d side_tiles %d\n", (int)q, j.a_tiles, j.b_tiles, j.wo, j.wi, j.po,
+            j.pi, j.cost, j.side_kind, j.side_kind ? j.side_tiles : 0);
+    }
+    return NERFHIP_OK;
+}
 
 extern "C" int nerfhip_plan_pack_index(nerfhip_plan_t plan, int32_t* host_table) {
     NH_REQUIRE(plan && host_table, "plan_pack_index: bad arguments");

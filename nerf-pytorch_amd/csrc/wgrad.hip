@@ -15,6 +15,13 @@
 //    lds[sample 2e+k][32*P*block + P*i ..] -- ds_read_b128 for P = 4, ds_read_b64 for P = 2 -- instead of P separate
 //    ds_read_b32 (the mock: 96.4 % -> 99.0 % of the matrix pipe for the 4 x 2 patch).  Which 32 rows form a tile only
 //    matters to the reduce kernel, which undoes the interleave when it scatters;
+//  * SIDE tiles (round 3): a weight block with one or two tiles on one side -- fc_alpha (1 x TW tiles), the direction
+//    columns of layers_dir (TW/2 x 1), the encoding columns of a skip layer (TW x 2) -- used to be a job of its own that
+//    paid the full per-stage hand-over for one or two MFMAs per k-step (the cost model, plan.cpp: 22 % of this kernel's
+//    time for 4 % of its work on the 4x128 nets).  Such a block now rides on the job that streams the same A (or B)
+//    region anyway: the side region's rows are a third block of the stage, and every wave carries one or two extra
+//    accumulator tiles fed by an A (or B) operand it already holds -- picked with v_cndmask on the wave's grid
+//    position -- and the side operand;
 //  * bias sums (VALU adds next to the MFMAs; the mock: -3.6 % when two of the eight waves carry all of them, because
 //    every stage ends in a barrier) are spread over the waves that share an A block: wave (ow, iw) sums tile x = iw only.
 #include <stdlib.h>
@@ -31,6 +38,8 @@ struct JobDev {  // k_wgrad
     int wo, wi, po, pi;
     int wg_start;
     int g;  // 32-sample tiles per LDS stage
+    int side;         // kind (0 none, 1 one extra A tile, 2 extra B tiles) | tiles << 8 | rows of the side region << 16
+    int side_prefix;  // its row prefix (A-side: in the gradient scratch, B-side: in the stash)
 };
 struct JobRed {  // k_wgrad_reduce
     int a_tiles, b_tiles, po, pi;
@@ -38,11 +47,13 @@ struct JobRed {  // k_wgrad_reduce
     int w_off, w_ld;
     int col_kind, col_base, col_count;
     int bias_off;
-    int wg_start;
-    int ks_log;  // log2 of the K-slices per element in k_wgrad_reduce: 0, 2 or 4 (fewer accumulator tiles -> more slices)
+    int wg_start;  // (a side block follows its host job in this table with the SAME wg_start: it shares those workgroups)
+    int ks_log;    // log2 of the K-slices per element in k_wgrad_reduce: 0, 2 or 4 (fewer accumulator tiles -> more slices)
+                   // | (first bias tile inside a workgroup's bias partials) << 8
+    int tile0;     // first accumulator tile of this block inside a workgroup's partial (0, or behind the host job's tiles)
 };
 constexpr int NH_JOBS_DEV = NH_MAX_JOBS;
-static_assert(sizeof(JobDev) * NH_JOBS_DEV + 128 <= 4096 && sizeof(JobRed) * NH_JOBS_DEV + 232 <= 4096,
+static_assert(sizeof(JobDev) * NH_JOBS_DEV + 64 <= 4096 && sizeof(JobRed) * NH_JOBS_DEV + 232 <= 4096,
               "the job tables must fit the 4 KB kernel-argument limit");
 // Workgroup shapes.  256-wide nets: 8 waves per workgroup (two per SIMD), two LDS stages of 16384 floats (+ slack for
 // the operand prefetch that runs one k-step past the end of a stage): one workgroup per CU.  128-wide nets (jobs of at
@@ -53,8 +64,9 @@ template <int NWV_, int STAGE_>
 struct WMode {
     static constexpr int NWV = NWV_, STAGE = STAGE_, LDS_DATA = 2 * STAGE_ * 4 + 4096, LDS_BYTES = LDS_DATA + NH_CLK_LDS_BYTES;
 };
-using WModeWide = WMode<8, 16384>;
-using WModeNarrow = WMode<4, 8192>;
+// (stage = one 32-sample tile of a 256 + 256 (128 + 128) row job plus a 64-row side region)
+using WModeWide = WMode<8, 18432>;
+using WModeNarrow = WMode<4, 9216>;
 // split-K partial of one workgroup: [accumulator tiles of the largest job][16 regs][64 lanes], then 512 bias partials
 // (then 128 floats of per-wave timeline records in the instrumented build); WgradArgs::part_bias / part_stride
 #ifdef NH_WGRAD_TIMELINE
@@ -100,24 +112,56 @@ NH_DEVICE void wop_load(WOp<P>& o, const float* p) {
         o.v[0] = p[0];
     }
 }
-template <int PO, int PI>
+// SK: 0 no side block; 1: ONE extra A tile (its operand S.v[0]) against the job's B tiles; 2: SB extra B tiles (operands
+// S.v[0..SB-1], interleaved rows like every block) against the job's A tiles.  NSP: side accumulator tiles per wave.
+template <int SK_, int SB_, int NSP_>
+struct WSide {
+    static constexpr int SK = SK_, SB = SB_, NSP = NSP_, SW = SK_ == 2 ? SB_ : 1, NACC = SK_ ? NSP_ : 1;
+    static constexpr int SR = SK_ ? 32 * SW : 0;  // rows of the side region
+};
+using NoSide = WSide<0, 1, 1>;
+template <int PO, int PI, class SD>
 struct WStep {
     WOp<PO> A;
     WOp<PI> B;
+    WOp<SD::SW> S;
 };
-template <int PO, int PI>
-NH_DEVICE void wstep_load(WStep<PO, PI>& o, const float* pa, const float* pb) {
+template <int PO, int PI, class SD>
+NH_DEVICE void wstep_load(WStep<PO, PI, SD>& o, const float* pa, const float* pb, const float* ps) {
     wop_load<PO>(o.A, pa);
     wop_load<PI>(o.B, pb);
+    if constexpr (SD::SK != 0) wop_load<SD::SW>(o.S, ps);
 }
+// wave-uniform pick of one of P register values (v_cndmask chain: one or three VALU instructions)
+template <int P>
+NH_DEVICE float wop_pick(const WOp<P>& o, int idx) {
+    float r = o.v[0];
+#pragma unroll
+    for (int q = 1; q < P; ++q) r = idx == q ? o.v[q] : r;
+    return r;
+}
+// which (A tile x, side tile y) / B tile a wave's j-th side accumulator belongs to (see WSideMap)
+struct WSideSel {
+    int x[2], y[2];
+    bool on[2], bias;
+};
 // BX: which A tiles this wave sums for the bias gradient: -1 none, 0..3 that tile only, 4 all of them
-template <int PO, int PI, int BX>
-NH_DEVICE void wstep_mfma(const WStep<PO, PI>& o, f32x16 (&acc)[PO][PI], float (&bsum)[PO]) {
+template <int PO, int PI, int BX, class SD>
+NH_DEVICE void wstep_mfma(const WStep<PO, PI, SD>& o, f32x16 (&acc)[PO][PI], float (&bsum)[PO], f32x16 (&sacc)[SD::NACC], float& sbsum,
+                          const WSideSel& ss) {
 #pragma unroll
     for (int x = 0; x < PO; ++x) {
         if (BX == 4 || BX == x) bsum[x] += o.A.v[x];
 #pragma unroll
         for (int y = 0; y < PI; ++y) acc[x][y] = nh_mfma32(o.A.v[x], o.B.v[y], acc[x][y]);
+    }
+    if constexpr (SD::SK == 1) {  // (side A tile) x (B tile ss.x[0] of this wave's patch)
+        if (ss.bias) sbsum += o.S.v[0];
+        if (ss.on[0]) sacc[0] = nh_mfma32(o.S.v[0], wop_pick<PI>(o.B, ss.x[0]), sacc[0]);
+    } else if constexpr (SD::SK == 2) {  // (A tile ss.x[j] of this wave's patch) x (side B tile ss.y[j])
+#pragma unroll
+        for (int j = 0; j < SD::NSP; ++j)
+            if (ss.on[j]) sacc[j] = nh_mfma32(wop_pick<PO>(o.A, ss.x[j]), wop_pick<SD::SW>(o.S, ss.y[j]), sacc[j]);
     }
 }
 
@@ -125,21 +169,29 @@ NH_DEVICE void wstep_mfma(const WStep<PO, PI>& o, f32x16 (&acc)[PO][PI], float (
 // B (ntile * b_fl floats) -> stage[g * a_fl ..).  Wave w issues pieces w, w+8, ...; `issue(n)` emits the next n of
 // them, so that the copy of stage n+1 is spread over the MFMA groups of stage n.  LDS destinations are byte addresses.
 struct WStageDma {
-    NhDmaSrc sa, sb;
+    NhDmaSrc sa, sb, sc;
     unsigned dst;  // LDS byte address of the stage
-    int pa, ptot, boff, q, lane16;
-    NH_MEMBER void init(const float* ga, const float* gb, int a_fl, int b_fl, int ntile, int g, unsigned stage_addr, int wave,
-                        int lane) {
+    int pa, pab, ptot, boff, coff, q, lane16;
+    // blocks A, B and (s_fl > 0) the side block: ntile * {a,b,s}_fl floats each, landing at stage + 0, g*a_fl, g*(a_fl+b_fl)
+    NH_MEMBER void init(const float* ga, const float* gb, const float* gs, int a_fl, int b_fl, int s_fl, int ntile, int g,
+                        unsigned stage_addr, int wave, int lane) {
         sa = nh_dma_src(ga, (unsigned)(ntile * a_fl * 4));
         sb = nh_dma_src(gb, (unsigned)(ntile * b_fl * 4));
         dst = stage_addr;
         pa = ntile * a_fl / 256;
-        ptot = pa + ntile * b_fl / 256;
+        pab = pa + ntile * b_fl / 256;
+        ptot = pab;
         boff = (g * a_fl - pa * 256) * 4;  // piece q >= pa lands at stage + (g*a_fl + (q - pa)*256) floats
+        coff = 0;
+        if (s_fl > 0) {
+            sc = nh_dma_src(gs, (unsigned)(ntile * s_fl * 4));
+            ptot = pab + ntile * s_fl / 256;
+            coff = (g * (a_fl + b_fl) - pab * 256) * 4;
+        }
         q = wave;
         lane16 = lane * 16;
     }
-    template <int NWV>
+    template <int NWV, bool SIDE>
     NH_MEMBER void issue(int n) {
         for (int c = 0; c < n && q < ptot; ++c, q += NWV) {
 #ifdef NH_WGRAD_TIMELINE
@@ -147,20 +199,25 @@ struct WStageDma {
             // of the copy instruction and the build fails; the descriptors are re-uniformised per piece.  This costs the
             // instrumented kernel ~10 % -- more on small jobs: its timeline shows the order of events and the wait / barrier
             // shares, not the product kernel's absolute times.)
-            NhDmaSrc ta = sa, tb = sb;
+            NhDmaSrc ta = sa, tb = sb, tc = sc;
             for (int e = 0; e < 4; ++e) {
                 ta.r[e] = __builtin_amdgcn_readfirstlane(ta.r[e]);
                 tb.r[e] = __builtin_amdgcn_readfirstlane(tb.r[e]);
+                if (SIDE) tc.r[e] = __builtin_amdgcn_readfirstlane(tc.r[e]);
             }
             if (q < pa)
                 nh_dma16a(ta, lane16, q * 1024, dst + q * 1024);
-            else
+            else if (!SIDE || q < pab)
                 nh_dma16a(tb, lane16, (q - pa) * 1024, dst + boff + q * 1024);
+            else
+                nh_dma16a(tc, lane16, (q - pab) * 1024, dst + coff + q * 1024);
 #else
             if (q < pa)
                 nh_dma16a(sa, lane16, q * 1024, dst + q * 1024);
-            else
+            else if (!SIDE || q < pab)
                 nh_dma16a(sb, lane16, (q - pa) * 1024, dst + boff + q * 1024);
+            else
+                nh_dma16a(sc, lane16, (q - pab) * 1024, dst + coff + q * 1024);
 #endif
         }
     }
@@ -168,12 +225,40 @@ struct WStageDma {
 
 // AR / BR: rows of the A / B region when known at compile time (0: read from the job) -- with constant strides the
 // operand addresses of a whole stage are immediates of ONE base register.
-template <class MD, int PO, int PI, int AR, int BR, int BX>
+template <class MD, int PO, int PI, int AR, int BR, int BX, class SD>
 NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int64_t t1, int ow, int iw, int wave, int lane,
                           int64_t wg, bool active, float* lds) {
     const int i = lane & 31, k = lane >> 5;
     f32x16 acc[PO][PI];
     float bsum[PO];
+    // side block (SD::SK != 0): which pairs this wave carries.  A-side: the side A tile against B tile y of every column's
+    // patch goes to the wave of row ow == y (the plan guarantees pi <= wo).  B-side: the po * SB pairs (A tile x, side
+    // tile y) of a wave row are dealt to its wi waves, e = iw + j * wi -> x = e / SB, y = e % SB.
+    constexpr bool SIDE = SD::SK != 0;
+    f32x16 sacc[SD::NACC];
+    float sbsum = 0.0f;
+    WSideSel ss;
+    ss.bias = false;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) ss.x[j] = ss.y[j] = 0, ss.on[j] = false;
+    constexpr int srows = SD::SR;
+    if constexpr (SD::SK == 1) {
+        ss.on[0] = active && ow < PI && iw * PI + ow < jb.b_tiles;
+        ss.x[0] = ow;
+        ss.bias = active && ow == 0 && iw == 0;
+    } else if constexpr (SD::SK == 2) {
+#pragma unroll
+        for (int j = 0; j < SD::NSP; ++j) {
+            const int e = iw + j * jb.wi;
+            ss.on[j] = active && e < PO * SD::SB && ow * PO + e / SD::SB < jb.a_tiles;
+            ss.x[j] = e / SD::SB;
+            ss.y[j] = e % SD::SB;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < SD::NACC; ++j)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) sacc[j][c] = 0.0f;
 #pragma unroll
     for (int x = 0; x < PO; ++x) {
         bsum[x] = 0.0f;
@@ -184,24 +269,29 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
     }
     const int ar = AR ? AR : jb.a_rows, br = BR ? BR : jb.b_rows;
     constexpr int NH_WG_STAGE_FLOATS = MD::STAGE;
-    constexpr int G_FIXED = NH_WG_STAGE_FLOATS / (32 * ((AR && BR) ? AR + BR : 1));  // fixed row counts: tiles per stage
+    // fixed row counts: tiles per stage
+    constexpr int G_FIXED = NH_WG_STAGE_FLOATS / (32 * ((AR && BR) ? AR + BR + SD::SR : 1));
     static_assert(G_FIXED >= 1, "a fixed-shape body must fit the mode's stage buffer");
     const int g = (AR && BR) ? G_FIXED : jb.g;
-    const int a_fl = 32 * ar, b_fl = 32 * br;
+    const int a_fl = 32 * ar, b_fl = 32 * br, s_fl = 32 * srows;
     const float* A0 = a.grad + (size_t)32 * (size_t)a.nt * (size_t)jb.a_prefix;
     const float* B0 = a.stash + (size_t)32 * (size_t)a.nt * (size_t)jb.b_prefix;
+    // (an A-side region lives in the gradient scratch, a B-side region in the activation stash)
+    const float* S0 = SIDE ? (SD::SK == 1 ? a.grad : a.stash) + (size_t)32 * (size_t)a.nt * (size_t)jb.side_prefix : nullptr;
     const int nstage = (int)((t1 - t0 + g - 1) / g);
     const float* ga = A0 + (size_t)t0 * a_fl;  // stage n+1's blocks (running pointers: one 64-bit add per stage)
     const float* gb = B0 + (size_t)t0 * b_fl;
+    const float* gs = SIDE ? S0 + (size_t)t0 * s_fl : nullptr;
     int left = (int)(t1 - t0);                 // tiles not yet requested
     const unsigned lds_addr = nh_lds_addr(lds);
     WStageDma dma;
     dma.ptot = 0;
     if (nstage > 0) {
         const int nt0 = left < g ? left : g;
-        dma.init(ga, gb, a_fl, b_fl, nt0, g, lds_addr, wave, lane);
-        dma.template issue<MD::NWV>(1 << 20);
+        dma.init(ga, gb, gs, a_fl, b_fl, s_fl, nt0, g, lds_addr, wave, lane);
+        dma.template issue<MD::NWV, SIDE>(1 << 20);
         ga += (size_t)nt0 * a_fl, gb += (size_t)nt0 * b_fl, left -= nt0;
+        if (SIDE) gs += (size_t)nt0 * s_fl;
     }
     int ntile = (int)(t1 - t0) < g ? (int)(t1 - t0) : g;  // tiles of the stage being multiplied
 #ifdef NH_WGRAD_TIMELINE
@@ -221,48 +311,51 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
         // lane (i, k): sample 2e + k of k-step e, rows PO*i .. of the wave's A block / PI*i .. of its B block
         const float* pa = buf + k * ar + 32 * PO * ow + PO * i;
         const float* pb = buf + g * a_fl + k * br + 32 * PI * iw + PI * i;
+        const float* ps = SIDE ? buf + g * (a_fl + b_fl) + k * srows + SD::SW * i : buf;  // side operand(s) of lane (i, k)
         NH_TL(tl_loop);
         nh_wait_vmem();
         NH_TL(tl_wait);
         nh_block_sync();  // stage n has landed for every wave; everybody is done reading the other buffer
         NH_TL(tl_bar);
-        WStep<PO, PI> c0, c1;
-        if (active) wstep_load(c0, pa, pb);
+        WStep<PO, PI, SD> c0, c1;
+        if (active) wstep_load(c0, pa, pb, ps);
         nh_sched_fence();  // first operand reads leave before the scalar set-up of the next copy
         const int ntn = left < g ? left : g;
         dma.ptot = 0;
         if (ntn > 0)
-            dma.init(ga, gb, a_fl, b_fl, ntn, g, lds_addr + (unsigned)(((n + 1) & 1) * NH_WG_STAGE_FLOATS * 4), wave, lane);
+            dma.init(ga, gb, gs, a_fl, b_fl, s_fl, ntn, g, lds_addr + (unsigned)(((n + 1) & 1) * NH_WG_STAGE_FLOATS * 4), wave, lane);
         ga += (size_t)ntn * a_fl, gb += (size_t)ntn * b_fl, left -= ntn;
+        if (SIDE) gs += (size_t)ntn * s_fl;
         if (active) {
-            if (AR && BR && NH_WG_STAGE_FLOATS / (32 * (AR + BR)) == 1) {
+            if (AR && BR && G_FIXED == 1) {
                 // one tile per stage, constant strides: 16 k-steps fully unrolled, every operand address an immediate
 #pragma unroll
                 for (int s = 0; s < 16; s += 2) {
-                    wstep_load(c1, pa + (s + 1) * 2 * AR, pb + (s + 1) * 2 * BR);
-                    dma.template issue<MD::NWV>(1);
+                    wstep_load(c1, pa + (s + 1) * 2 * AR, pb + (s + 1) * 2 * BR, ps + (s + 1) * 2 * srows);
+                    dma.template issue<MD::NWV, SIDE>(1);
                     nh_sched_fence();
-                    wstep_mfma<PO, PI, BX>(c0, acc, bsum);
-                    wstep_load(c0, pa + (s + 2) * 2 * AR, pb + (s + 2) * 2 * BR);  // (last: one k-step past the stage, unused)
+                    wstep_mfma<PO, PI, BX, SD>(c0, acc, bsum, sacc, sbsum, ss);
+                    // (last: one k-step past the stage, unused)
+                    wstep_load(c0, pa + (s + 2) * 2 * AR, pb + (s + 2) * 2 * BR, ps + (s + 2) * 2 * srows);
                     nh_sched_fence();
-                    wstep_mfma<PO, PI, BX>(c1, acc, bsum);
+                    wstep_mfma<PO, PI, BX, SD>(c1, acc, bsum, sacc, sbsum, ss);
                 }
             } else {
                 const int steps = 16 * ntile;  // k-steps of two samples each
                 for (int s = 0; s < steps; s += 2) {
-                    pa += 2 * ar, pb += 2 * br;
-                    wstep_load(c1, pa, pb);
-                    dma.template issue<MD::NWV>(1);  // the next stage streams in underneath the MFMAs (at most 8 pieces per wave and stage)
+                    pa += 2 * ar, pb += 2 * br, ps += 2 * srows;
+                    wstep_load(c1, pa, pb, ps);
+                    dma.template issue<MD::NWV, SIDE>(1);  // the next stage streams in underneath the MFMAs (at most 9 pieces per wave and stage)
                     nh_sched_fence();
-                    wstep_mfma<PO, PI, BX>(c0, acc, bsum);
-                    pa += 2 * ar, pb += 2 * br;
-                    wstep_load(c0, pa, pb);  // the last one reads one k-step past the stage (slack / other block): unused
+                    wstep_mfma<PO, PI, BX, SD>(c0, acc, bsum, sacc, sbsum, ss);
+                    pa += 2 * ar, pb += 2 * br, ps += 2 * srows;
+                    wstep_load(c0, pa, pb, ps);  // the last one reads one k-step past the stage (slack / other block): unused
                     nh_sched_fence();
-                    wstep_mfma<PO, PI, BX>(c1, acc, bsum);
+                    wstep_mfma<PO, PI, BX, SD>(c1, acc, bsum, sacc, sbsum, ss);
                 }
             }
         }
-        dma.template issue<MD::NWV>(1 << 20);  // idle waves, and whatever a short stage left over
+        dma.template issue<MD::NWV, SIDE>(1 << 20);  // idle waves, and whatever a short stage left over
         ntile = ntn;
     }
 #ifdef NH_WGRAD_TIMELINE
@@ -294,26 +387,67 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
             if (k == 0) part[a.part_bias + a_t * 32 + i] = tot;
         }
     }
+    if constexpr (SIDE) {
+        // side accumulator tiles behind the job's own: A-side (S, b_t) at a_tiles * b_tiles + b_t; B-side (a_t, y) at
+        // a_tiles * b_tiles + a_t * SB + y; the side A tile's row sums (its bias gradient) behind the job's bias partials
+        const int base = jb.a_tiles * jb.b_tiles;
+#pragma unroll
+        for (int j = 0; j < SD::NACC; ++j) {
+            if (!ss.on[j]) continue;
+            const int idx = SD::SK == 1 ? base + iw * PI + ss.x[j] : base + (ow * PO + ss.x[j]) * SD::SB + ss.y[j];
+            float* dst = part + (size_t)idx * 1024 + lane;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) dst[c * 64] = sacc[j][c];
+        }
+        if (SD::SK == 1 && ss.bias) {
+            const float tot = sbsum + nh_shfl_xor(sbsum, 32);
+            if (k == 0) part[a.part_bias + jb.a_tiles * 32 + i] = tot;
+        }
+    }
 }
 
-template <class MD, int PO, int PI, int AR, int BR>
+template <class MD, int PO, int PI, int AR, int BR, class SD>
 NH_DEVICE void wgrad_bias_dispatch(const WgradArgs& a, const JobDev& jb, int64_t t0, int64_t t1, int ow, int iw, int wave,
                                    int lane, int64_t wg, bool active, float* lds) {
     // the bias sums of A tile x are taken by the wave of column iw == x % wi: one tile per wave when wi >= PO
     // (computed even when the job carries no bias tensor: the reduce kernel ignores them)
     if (jb.wi >= PO && PO > 1) {
         switch (iw) {
-            case 0: wgrad_body<MD, PO, PI, AR, BR, 0>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
-            case 1: wgrad_body<MD, PO, PI, AR, BR, (PO > 1 ? 1 : -1)>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
-            case 2: wgrad_body<MD, PO, PI, AR, BR, (PO > 2 ? 2 : -1)>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
-            case 3: wgrad_body<MD, PO, PI, AR, BR, (PO > 3 ? 3 : -1)>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
-            default: wgrad_body<MD, PO, PI, AR, BR, -1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+            case 0: wgrad_body<MD, PO, PI, AR, BR, 0, SD>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+            case 1: wgrad_body<MD, PO, PI, AR, BR, (PO > 1 ? 1 : -1), SD>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+            case 2: wgrad_body<MD, PO, PI, AR, BR, (PO > 2 ? 2 : -1), SD>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+            case 3: wgrad_body<MD, PO, PI, AR, BR, (PO > 3 ? 3 : -1), SD>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
+            default: wgrad_body<MD, PO, PI, AR, BR, -1, SD>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds); break;
         }
     } else if (iw == 0) {
-        wgrad_body<MD, PO, PI, AR, BR, 4>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
+        wgrad_body<MD, PO, PI, AR, BR, 4, SD>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
     } else {
-        wgrad_body<MD, PO, PI, AR, BR, -1>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
+        wgrad_body<MD, PO, PI, AR, BR, -1, SD>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
     }
+}
+
+// side blocks exist for the patches they occur with (plan.cpp attach_sides): A-side (fc_alpha) on the fc_feat job and
+// B-side with two tiles (a skip layer's encoding columns) on a hidden job -- 4 x 2 patches (8 waves) / 2 x 2 (4 waves) --,
+// B-side with one tile (the direction columns) on the layers_dir job -- 2 x 2 / 1 x 2 patches
+template <class MD, int PO, int PI, int AR, int BR>
+NH_DEVICE void wgrad_side_dispatch(const WgradArgs& a, const JobDev& jb, int64_t t0, int64_t t1, int ow, int iw, int wave, int lane,
+                                   int64_t wg, bool active, float* lds) {
+    const int kind = jb.side & 255, st = (jb.side >> 8) & 255;
+    constexpr bool host = (MD::NWV == 8 && PO == 4 && PI == 2) || (MD::NWV == 4 && PO == 2 && PI == 2);
+    constexpr bool dirj = (MD::NWV == 8 && PO == 2 && PI == 2) || (MD::NWV == 4 && ((PO == 1 && PI == 2) || (PO == 2 && PI == 1)));
+    if constexpr (host) {
+        if (kind == 1) return wgrad_bias_dispatch<MD, PO, PI, AR, BR, WSide<1, 1, 1>>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
+#ifdef NH_WGRAD_SIDE2  // (A/B builds only: two more accumulator tiles per wave push the 4 x 2 patch body over 256 VGPRs)
+        if constexpr (MD::NWV == 8) {  // (a 64-row side region next to 128 + 128 rows does not fit the 4-wave mode's stage)
+            if (kind == 2 && st == 2)
+                return wgrad_bias_dispatch<MD, PO, PI, AR, BR, WSide<2, 2, 2>>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
+        }
+#endif
+    }
+    if constexpr (dirj && AR == 0) {
+        if (kind == 2 && st == 1) return wgrad_bias_dispatch<MD, PO, PI, AR, BR, WSide<2, 1, 1>>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
+    }
+    wgrad_bias_dispatch<MD, PO, PI, AR, BR, NoSide>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
 }
 
 template <class MD, int PO, int PI>
@@ -322,13 +456,13 @@ NH_DEVICE void wgrad_dispatch(const WgradArgs& a, const JobDev& jb, int64_t t0, 
     // fixed-shape bodies only where they are launched (and fit the mode's stage buffer)
     if constexpr (MD::NWV == 8 && PO == 4 && PI == 2) {
         if (jb.a_rows == 256 && jb.b_rows == 256)  // the 256x256 jobs: 91 % of the 8x256 FLOPs
-            return wgrad_bias_dispatch<MD, PO, PI, 256, 256>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
+            return wgrad_side_dispatch<MD, PO, PI, 256, 256>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
     }
     if constexpr (MD::NWV == 4 && PO == 2 && PI == 2) {
         if (jb.a_rows == 128 && jb.b_rows == 128)  // the 128x128 jobs of 128-wide nets
-            return wgrad_bias_dispatch<MD, PO, PI, 128, 128>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
+            return wgrad_side_dispatch<MD, PO, PI, 128, 128>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
     }
-    wgrad_bias_dispatch<MD, PO, PI, 0, 0>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
+    wgrad_side_dispatch<MD, PO, PI, 0, 0>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
 }
 
 template <class MD>
@@ -389,13 +523,15 @@ NH_KERNEL void k_wgrad_reduce(ReduceArgs a) {
     // threads with ~150 dependent partial loads each (the 64- and 128-wide nets: this kernel was 3-6 % of their step), so a
     // block covers 256 >> ksl elements with (1 << ksl) K-slices per element: slice s sums partials s, s + KS, ... and the
     // slices are combined through LDS in slice order -- a fixed order: bit-reproducible, no atomics.
-    const int ksl = jb.ks_log, epb = 256 >> ksl, nsl = 1 << ksl;
+    const int ksl = jb.ks_log & 255, bias_t0 = jb.ks_log >> 8, epb = 256 >> ksl, nsl = 1 << ksl;
     const int e_local = (int)threadIdx.x & (epb - 1), slice = (int)threadIdx.x >> (8 - ksl);
     const int local = (int)(blockIdx.x & 255u) * epb + e_local;
     const int lane = local & 63, c = (local >> 6) & 15, tile = local >> 10;  // accumulator tile (a_t, b_t) = a_t * b_tiles + b_t
     const int a_t = tile / jb.b_tiles, b_t = tile % jb.b_tiles;
     const bool in_job = a_t < jb.a_tiles;
-    const int nks = (ji + 1 < a.njobs ? a.jobs[ji + 1].wg_start : a.total_wgs) - jb.wg_start;
+    int nxt = ji + 1;  // (a side block shares its host's workgroups: skip entries with the same wg_start)
+    while (nxt < a.njobs && a.jobs[nxt].wg_start == jb.wg_start) ++nxt;
+    const int nks = (nxt < a.njobs ? a.jobs[nxt].wg_start : a.total_wgs) - jb.wg_start;
     const int m = (c & 3) + 8 * (c >> 2) + 4 * (lane >> 5);
     const int out_row = 32 * jb.po * (a_t / jb.po) + jb.po * m + a_t % jb.po;
     const int in_row = 32 * jb.pi * (b_t / jb.pi) + jb.pi * (lane & 31) + b_t % jb.pi;
@@ -412,7 +548,7 @@ NH_KERNEL void k_wgrad_reduce(ReduceArgs a) {
     if (col >= 0) {
         // eight interleaved running sums (a fixed order) keep eight loads in flight per lane
         float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const float* p = a.partial + (size_t)jb.wg_start * a.part_stride + ((size_t)tile * 16 + c) * 64 + lane;
+        const float* p = a.partial + (size_t)jb.wg_start * a.part_stride + ((size_t)(jb.tile0 + tile) * 16 + c) * 64 + lane;
         const size_t step = (size_t)nsl * a.part_stride;
         int q = slice;
         for (; q + 7 * nsl < nks; q += 8 * nsl) {
@@ -436,7 +572,7 @@ NH_KERNEL void k_wgrad_reduce(ReduceArgs a) {
         if (brow >= jb.r_lo && brow < jb.r_hi) {
             // (the same eight interleaved sums: a one-deep chain of nks dependent loads used to set this kernel's duration)
             float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            const float* p = a.partial + (size_t)jb.wg_start * a.part_stride + a.part_bias + a_t * 32 + lane;
+            const float* p = a.partial + (size_t)jb.wg_start * a.part_stride + a.part_bias + (bias_t0 + a_t) * 32 + lane;
             int q = 0;
             for (; q + 8 <= nks; q += 8) {
 #pragma unroll
@@ -492,7 +628,7 @@ void wgrad_schedule(const nerfhip_plan* p, int64_t nt, WgradArgs& w, ReduceArgs*
         ks[best] -= 1;
         used -= 1;
     }
-    int start = 0;
+    int start = 0, nred = 0;
     for (int q = 0; q < w.njobs; ++q) {
         const NhJob& j = p->jobs[q];
         if (ks[q] > nt) ks[q] = nt;
@@ -508,10 +644,13 @@ void wgrad_schedule(const nerfhip_plan* p, int64_t nt, WgradArgs& w, ReduceArgs*
         d.po = j.po;
         d.pi = j.pi;
         d.wg_start = start;
-        d.g = stage_floats / (32 * (j.a_region_rows + j.b_region_rows));
+        d.side = j.side_kind | (j.side_tiles << 8) | (j.side_rows << 16);
+        d.side_prefix = (int)j.side_row_prefix;
+        d.g = stage_floats / (32 * (j.a_region_rows + j.b_region_rows + (j.side_kind ? j.side_rows : 0)));
         if (d.g < 1) d.g = 1;
         if (r) {
-            JobRed& e = r->jobs[q];
+            auto ks_log = [](int tiles) { return tiles <= 4 ? 4 : (tiles <= 16 ? 2 : 0); };  // 256 blocks x (256 >> ks_log) elements cover tiles * 1024
+            JobRed& e = r->jobs[nred++];
             e.a_tiles = j.a_tiles;
             e.b_tiles = j.b_tiles;
             e.po = j.po;
@@ -525,19 +664,40 @@ void wgrad_schedule(const nerfhip_plan* p, int64_t nt, WgradArgs& w, ReduceArgs*
             e.col_count = j.col_count;
             e.bias_off = (int)j.bias_off;
             e.wg_start = start;
-            const int tiles = j.a_tiles * j.b_tiles;  // 256 blocks x (256 >> ks_log) elements must cover tiles * 1024
-            e.ks_log = tiles <= 4 ? 4 : (tiles <= 16 ? 2 : 0);
+            e.ks_log = ks_log(j.a_tiles * j.b_tiles);
+            e.tile0 = 0;
+            if (j.side_kind) {  // the side block: a second weight block unpacked from the same workgroups' partials
+                JobRed& f = r->jobs[nred++];
+                f.a_tiles = j.side_kind == 1 ? 1 : j.a_tiles;
+                f.b_tiles = j.side_kind == 1 ? j.b_tiles : j.side_tiles;
+                f.po = j.side_kind == 1 ? 1 : j.po;
+                f.pi = j.side_kind == 1 ? j.pi : j.side_tiles;
+                f.r_lo = j.s_r_lo;
+                f.r_hi = j.s_r_hi;
+                f.w_off = (int)j.s_w_off;
+                f.w_ld = j.s_w_ld;
+                f.col_kind = j.s_col_kind;
+                f.col_base = j.s_col_base;
+                f.col_count = j.s_col_count;
+                f.bias_off = (int)j.s_bias_off;
+                f.wg_start = start;
+                f.ks_log = ks_log(f.a_tiles * f.b_tiles) | ((j.side_kind == 1 ? j.a_tiles : 0) << 8);
+                f.tile0 = j.a_tiles * j.b_tiles;
+            }
         }
         start += (int)ks[q];
     }
     w.total_wgs = start;
     int tiles = 1;
-    for (int q = 0; q < w.njobs; ++q)
-        if (p->jobs[q].a_tiles * p->jobs[q].b_tiles > tiles) tiles = p->jobs[q].a_tiles * p->jobs[q].b_tiles;
+    for (int q = 0; q < w.njobs; ++q) {
+        const NhJob& j = p->jobs[q];
+        const int tq = j.a_tiles * j.b_tiles + (j.side_kind == 1 ? j.b_tiles : (j.side_kind == 2 ? j.a_tiles * j.side_tiles : 0));
+        if (tq > tiles) tiles = tq;
+    }
     w.part_bias = tiles * 1024;
     w.part_stride = w.part_bias + NH_PART_EXTRA;
     if (r) {
-        r->njobs = w.njobs;
+        r->njobs = nred;
         r->total_wgs = w.total_wgs;
         r->part_bias = w.part_bias;
         r->part_stride = w.part_stride;
@@ -584,7 +744,8 @@ int nh_wgrad(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad,
     for (int q = 0; q < w.njobs; ++q) {
         const NhJob& j = p->jobs[q];
         NH_REQUIRE(j.b_row0 == 0 && 32 * j.a_tiles == j.a_region_rows && 32 * j.b_tiles == j.b_region_rows &&
-                       32 * (j.a_region_rows + j.b_region_rows) <= (p->wgrad_waves == 4 ? WModeNarrow::STAGE : WModeWide::STAGE) &&
+                       32 * (j.a_region_rows + j.b_region_rows + (j.side_kind ? j.side_rows : 0)) <=
+                           (p->wgrad_waves == 4 ? WModeNarrow::STAGE : WModeWide::STAGE) &&
                        j.a_tiles * j.b_tiles <= 64 && j.wo * j.wi <= p->wgrad_waves &&
                        j.wo * j.po == j.a_tiles && j.wi * j.pi == j.b_tiles,
                    "wgrad: job %d does not tile its regions exactly (%d x %d tiles, %d x %d waves, %d x %d patches)", q,
@@ -596,6 +757,6 @@ int nh_wgrad(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad,
     else
         rc = launch_wgrad<WModeWide>(w, stream);
     if (rc) return rc;
-    NH_LAUNCH(k_wgrad_reduce, w.njobs * 256, 256, 0, stream, red);
+    NH_LAUNCH(k_wgrad_reduce, red.njobs * 256, 256, 0, stream, red);
     return nh_launch_status("wgrad_reduce");
 }

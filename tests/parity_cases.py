@@ -318,7 +318,7 @@ def case_mlp_backward(b, names=None, m=150):
         # (seen on MI355X and on the emulator alike: sample 136 of seed 42 for the 3x512 net, pre-activation 3.7e-9)
         keep = O.mlp_relu_margin(params, x, cfg) > 1e-6
         x, go = x[keep].contiguous(), go[keep].contiguous()
-        assert x.shape[0] >= 0.97 * m, (x.shape[0], m)
+        assert x.shape[0] >= 0.9 * m, (x.shape[0], m)
         p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
         (O.mlp_forward(p, x, cfg) * go).sum().backward()
         got_y, stash = b.mlp_fwd(plan, packed, x.numpy(), want_stash=True)

@@ -80,6 +80,29 @@ def test_plan_layout_and_pack_table(lib, geo):
     lib.plan_destroy(plan)
 
 
+def test_thin_weight_blocks_ride_as_side_tiles(lib):
+    """wgrad.hip side tiles: fc_alpha and the direction columns have no weight-gradient job of their own; 512-wide nets
+    (half-region jobs) and 64-wide nets (no job of 8 tiles) keep them."""
+    def describe(*geo):
+        plan = lib.plan_create(C.byref(L.ModelCfg(*geo, 1, 1, 1, 1, 1)))
+        assert plan
+        buf = C.create_string_buffer(1 << 14)
+        lib.plan_describe(plan, buf, len(buf))
+        lib.plan_destroy(plan)
+        lines = buf.value.decode().splitlines()
+        jobs = [dict(zip(l.split()[0::2], l.split()[1::2])) for l in lines[1:]]
+        return lines[0], jobs
+    head, jobs = describe(8, 256, 4, 10, 4)
+    assert "kernel_width 256" in head and len(jobs) == 12                       # 14 weight blocks, two of them side tiles
+    assert sorted((j["side"], j["side_tiles"]) for j in jobs if j["side"] != "0") == [("1", "1"), ("2", "1")]
+    head, jobs = describe(4, 128, 4, 10, 4)
+    assert "kernel_width 128" in head and len(jobs) == 7 and sum(j["side"] != "0" for j in jobs) == 2
+    head, jobs = describe(8, 128, 4, 10, 4)                                      # the skip layer's 64-row block does not fit the 4-wave stage
+    assert len(jobs) == 12 and sum(j["side"] != "0" for j in jobs) == 2
+    for geo in ((4, 64, 3, 6, 4), (3, 512, 2, 10, 4)):
+        assert all(j["side"] == "0" for j in describe(*geo)[1])
+
+
 def test_model_state_dict_is_reference_compatible(lib):
     w = gold("lego_lowres_weights.npz")
     m = N.FlexibleNeRFModel(num_layers=4, hidden_size=128, skip_connect_every=4, num_encoding_fn_xyz=10,

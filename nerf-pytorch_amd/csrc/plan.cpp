@@ -260,7 +260,10 @@ void add_job1(nerfhip_plan* p, const NhRegion& A, int a_tiles, const NhRegion& B
         // residuals of that fit in the final timeline (profiles/r02_wgrad_timeline.txt): one-tile patches run 4-7 % longer
         // than modelled, the 2 x 1 patches of the encoding-column jobs 3 % shorter, the 2 x 2 patches 2 % longer
         if (j.po * j.pi == 1) j.cost += 7;
-        if (j.po == 2 && j.pi == 1) j.cost -= 9;
+#ifndef NH_COST_21_ADJ  // (A/B builds only)
+#define NH_COST_21_ADJ (-9)
+#endif
+        if (j.po == 2 && j.pi == 1) j.cost += NH_COST_21_ADJ;
         if (j.po == 2 && j.pi == 2 && per_simd == 2) j.cost += 8;
     }
     j.r_lo = r_lo;
@@ -340,7 +343,15 @@ void attach_sides(nerfhip_plan* p, int stage_floats) {
         h.s_bias_off = g.bias_off;
         // its MFMAs now run inside the host's k-steps: one or two more per wave, one more operand
         const int per_simd = (h.wo * h.wi + 3) / 4;
-        h.cost += 30 * per_simd * (kind == 2 && g.b_tiles == 2 ? 2 : 1) + 20 * per_simd;
+        // measured on MI355X by A/B of the split-K allocation (profiles/r03_variant_ab.txt): what a side tile adds to its
+        // host's time per sample tile, in the cost model's units -- 4-wave mode: A-side 60, B-side 140 (k_wgrad<128> 0.589 ->
+        // 0.611 of peak; with 50 / 50 the side hosts finished last and the kernel was SLOWER than without sides);
+        // 8-wave mode: 50 / 80 (0.840 -> 0.846)
+#ifndef NH_SIDE_COST_A  // (A/B builds only)
+#define NH_SIDE_COST_A (p->wgrad_waves == 4 ? 60 : 50)
+#define NH_SIDE_COST_B (p->wgrad_waves == 4 ? 140 : 80)
+#endif
+        h.cost += per_simd * (kind == 1 ? NH_SIDE_COST_A : NH_SIDE_COST_B) * (kind == 2 && g.b_tiles == 2 ? 2 : 1);
         J.erase(J.begin() + gi);
         --gi;
     }

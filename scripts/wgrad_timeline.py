@@ -28,7 +28,15 @@ torch.cuda.synchronize()
 nt = 4 * ((M + 127) // 128)
 KW = 128 if HID <= 128 else 256                    # kernel width; a partial = the largest job's tiles + 512 bias + 128 records
 rows = LAY * KW + KW + KW // 2 + 32
-BIAS = (KW // 32) ** 2 * 1024
+buf = C.create_string_buffer(1 << 14)
+lib.plan_describe(m._plan, buf, len(buf))
+tiles = 1
+for line in buf.value.decode().splitlines()[1:]:
+    f = dict(zip(line.split()[0::2], line.split()[1::2]))
+    ta, tb = (int(v) for v in f["tiles"].split("x"))
+    tiles = max(tiles, ta * tb + (tb if f["side"] == "1" else (ta * int(f["side_tiles"]) if f["side"] == "2" else 0)))
+print(buf.value.decode())
+BIAS = tiles * 1024                                # a partial = the largest job's accumulator tiles (its side tiles included)
 PART = BIAS + 512 + 128
 part = scratch[nt * rows * 32:]
 nwg = part.numel() // PART

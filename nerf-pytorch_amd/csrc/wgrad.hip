@@ -592,8 +592,14 @@ NH_KERNEL void k_wgrad_reduce(ReduceArgs a) {
 // CU) for 256-wide nets, TWO rounds of 512 four-wave workgroups (two per CU) for 128-wide ones.  Measured on MI355X:
 // 512 / 768 / 1024 / 1280 / 2048 workgroups -> k_wgrad 0.845 / 0.855 / 0.852 / 0.846 / 0.841 of peak for 8x256 nets
 // (more workgroups: more partials to write and reduce; fewer: a coarser tail), 0.551 / 0.564 / 0.584 for 4x128.
+// Round 3, with the side tiles (7 jobs for 4x128): 768 / 1024 / 1280 / 1536 -> 0.600 / 0.607 / 0.618 / 0.607 for 4x128
+// (1280 taken), 512 / 640 / 768 / 1024 -> 0.846 / 0.710 / 0.851 / 0.849 for 8x256 (768 stays; profiles/r03_variant_ab.txt).
 void wgrad_schedule(const nerfhip_plan* p, int64_t nt, WgradArgs& w, ReduceArgs* r) {
-    const int NH_WGRAD_TARGET_WGS = p->wgrad_waves == 4 ? 1024 : 768;
+#ifndef NH_WGS_NARROW  // (A/B builds only)
+#define NH_WGS_NARROW 1280
+#define NH_WGS_WIDE 768
+#endif
+    const int NH_WGRAD_TARGET_WGS = p->wgrad_waves == 4 ? NH_WGS_NARROW : NH_WGS_WIDE;
     const int stage_floats = p->wgrad_waves == 4 ? WModeNarrow::STAGE : WModeWide::STAGE;
     w.njobs = (int)p->jobs.size();  // <= NH_MAX_JOBS == NH_JOBS_DEV: nerfhip_plan_create refuses larger job lists
     int64_t cost[NH_JOBS_DEV];

@@ -311,7 +311,8 @@ void attach_sides(nerfhip_plan* p, int stage_floats) {
             const NhJob& h = J[hi];
             if (hi == gi || h.side_kind || h.a_tiles * h.b_tiles < 8) continue;
             if (32 * (h.a_region_rows + h.b_region_rows + 32 * (g.a_tiles == 1 ? 1 : g.b_tiles)) > stage_floats) continue;
-            if (g.a_tiles == 1 && g.a_region_rows == 32 && h.b_row_prefix == g.b_row_prefix && h.b_tiles == g.b_tiles && h.pi <= h.wo &&
+            if (g.a_tiles == 1 && g.a_region_rows == 32 && g.r_hi - g.r_lo == 1 && h.b_row_prefix == g.b_row_prefix && h.b_tiles == g.b_tiles &&
+                h.a_region_rows == h.b_region_rows && h.a_region_rows == (p->wgrad_waves == 8 ? 256 : 128) &&
                 ((p->wgrad_waves == 8 && h.po == 4 && h.pi == 2) || (p->wgrad_waves == 4 && h.po == 2 && h.pi == 2))) {
                 host = (int)hi, kind = 1;
             } else if (g.b_tiles <= 2 && g.b_region_rows == 32 * g.b_tiles && g.a_tiles > 1 && h.a_row_prefix == g.a_row_prefix &&
@@ -343,12 +344,12 @@ void attach_sides(nerfhip_plan* p, int stage_floats) {
         h.s_bias_off = g.bias_off;
         // its MFMAs now run inside the host's k-steps: one or two more per wave, one more operand
         const int per_simd = (h.wo * h.wi + 3) / 4;
-        // measured on MI355X by A/B of the split-K allocation (profiles/r03_variant_ab.txt): what a side tile adds to its
-        // host's time per sample tile, in the cost model's units -- 4-wave mode: A-side 60, B-side 140 (k_wgrad<128> 0.589 ->
-        // 0.611 of peak; with 50 / 50 the side hosts finished last and the kernel was SLOWER than without sides);
-        // 8-wave mode: 50 / 80 (0.840 -> 0.846)
+        // measured on MI355X by A/B of the split-K allocation (profiles/r03_variant_ab.txt): what a B-side tile adds to its
+        // host's time per sample tile, in the cost model's units -- 4-wave mode 140 (k_wgrad<128> 0.589 -> 0.611 of peak; with
+        // 50 the side hosts finished last and the kernel was SLOWER than without sides), 8-wave mode 80 (0.840 -> 0.846).
+        // The A-side row is a few VALU instructions per k-step of one wave per column.
 #ifndef NH_SIDE_COST_A  // (A/B builds only)
-#define NH_SIDE_COST_A (p->wgrad_waves == 4 ? 60 : 50)
+#define NH_SIDE_COST_A 10
 #define NH_SIDE_COST_B (p->wgrad_waves == 4 ? 140 : 80)
 #endif
         h.cost += per_simd * (kind == 1 ? NH_SIDE_COST_A : NH_SIDE_COST_B) * (kind == 2 && g.b_tiles == 2 ? 2 : 1);

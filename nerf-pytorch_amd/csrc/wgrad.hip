@@ -19,9 +19,12 @@
 //    columns of layers_dir (TW/2 x 1), the encoding columns of a skip layer (TW x 2) -- used to be a job of its own that
 //    paid the full per-stage hand-over for one or two MFMAs per k-step (the cost model, plan.cpp: 22 % of this kernel's
 //    time for 4 % of its work on the 4x128 nets).  Such a block now rides on the job that streams the same A (or B)
-//    region anyway: the side region's rows are a third block of the stage, and every wave carries one or two extra
-//    accumulator tiles fed by an A (or B) operand it already holds -- picked with v_cndmask on the wave's grid
-//    position -- and the side operand;
+//    region anyway: the side region's rows are a third block of the stage.  Extra B tiles (the direction columns) become
+//    one more accumulator tile per wave, fed by an A operand the wave already holds -- picked with v_cndmask on its grid
+//    position -- and the side operand.  An extra A tile with ONE useful row (fc_alpha: row 3 of the 32-row d(raw output)
+//    region; an MFMA tile would be 31/32 waste) is not multiplied on the matrix pipe at all: the row's value of the
+//    lane's sample is a broadcast LDS read, and the wave of row 0 of each column adds value * B operand to PI scalars per
+//    k-step in the shadow of its MFMAs; the sums land where the reduce kernel expects that row of an accumulator tile;
 //  * bias sums (VALU adds next to the MFMAs; the mock: -3.6 % when two of the eight waves carry all of them, because
 //    every stage ends in a barrier) are spread over the waves that share an A block: wave (ow, iw) sums tile x = iw only.
 #include <stdlib.h>
@@ -116,7 +119,7 @@ NH_DEVICE void wop_load(WOp<P>& o, const float* p) {
 // S.v[0..SB-1], interleaved rows like every block) against the job's A tiles.  NSP: side accumulator tiles per wave.
 template <int SK_, int SB_, int NSP_>
 struct WSide {
-    static constexpr int SK = SK_, SB = SB_, NSP = NSP_, SW = SK_ == 2 ? SB_ : 1, NACC = SK_ ? NSP_ : 1;
+    static constexpr int SK = SK_, SB = SB_, NSP = NSP_, SW = SK_ == 2 ? SB_ : 1, NACC = SK_ == 2 ? NSP_ : 1;
     static constexpr int SR = SK_ ? 32 * SW : 0;  // rows of the side region
 };
 using NoSide = WSide<0, 1, 1>;
@@ -148,16 +151,19 @@ struct WSideSel {
 // BX: which A tiles this wave sums for the bias gradient: -1 none, 0..3 that tile only, 4 all of them
 template <int PO, int PI, int BX, class SD>
 NH_DEVICE void wstep_mfma(const WStep<PO, PI, SD>& o, f32x16 (&acc)[PO][PI], float (&bsum)[PO], f32x16 (&sacc)[SD::NACC], float& sbsum,
-                          const WSideSel& ss) {
+                          float (&srow)[PI], const WSideSel& ss) {
 #pragma unroll
     for (int x = 0; x < PO; ++x) {
         if (BX == 4 || BX == x) bsum[x] += o.A.v[x];
 #pragma unroll
         for (int y = 0; y < PI; ++y) acc[x][y] = nh_mfma32(o.A.v[x], o.B.v[y], acc[x][y]);
     }
-    if constexpr (SD::SK == 1) {  // (side A tile) x (B tile ss.x[0] of this wave's patch)
-        if (ss.bias) sbsum += o.S.v[0];
-        if (ss.on[0]) sacc[0] = nh_mfma32(o.S.v[0], wop_pick<PI>(o.B, ss.x[0]), sacc[0]);
+    if constexpr (SD::SK == 1) {  // (the side region's one useful row: S.v[0] = its value for this lane's sample) x (the B operands)
+        // (unconditional in every wave: a wave-uniform `if` here is if-converted into a select per value, which costs more
+        // than the PI + 1 redundant VALU instructions; only the waves of grid row 0 store their sums)
+        sbsum += o.S.v[0];
+#pragma unroll
+        for (int y = 0; y < PI; ++y) srow[y] = fmaf(o.S.v[0], o.B.v[y], srow[y]);
     } else if constexpr (SD::SK == 2) {  // (A tile ss.x[j] of this wave's patch) x (side B tile ss.y[j])
 #pragma unroll
         for (int j = 0; j < SD::NSP; ++j)
@@ -231,20 +237,20 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
     const int i = lane & 31, k = lane >> 5;
     f32x16 acc[PO][PI];
     float bsum[PO];
-    // side block (SD::SK != 0): which pairs this wave carries.  A-side: the side A tile against B tile y of every column's
-    // patch goes to the wave of row ow == y (the plan guarantees pi <= wo).  B-side: the po * SB pairs (A tile x, side
-    // tile y) of a wave row are dealt to its wi waves, e = iw + j * wi -> x = e / SB, y = e % SB.
+    // side block (SD::SK != 0).  A-side: see wstep_mfma.  B-side: the po * SB pairs (A tile x, side tile y) of a wave row
+    // are dealt to its wi waves, e = iw + j * wi -> x = e / SB, y = e % SB.
     constexpr bool SIDE = SD::SK != 0;
     f32x16 sacc[SD::NACC];
-    float sbsum = 0.0f;
+    float sbsum = 0.0f, srow[PI];
+#pragma unroll
+    for (int y = 0; y < PI; ++y) srow[y] = 0.0f;
     WSideSel ss;
     ss.bias = false;
 #pragma unroll
     for (int j = 0; j < 2; ++j) ss.x[j] = ss.y[j] = 0, ss.on[j] = false;
     constexpr int srows = SD::SR;
     if constexpr (SD::SK == 1) {
-        ss.on[0] = active && ow < PI && iw * PI + ow < jb.b_tiles;
-        ss.x[0] = ow;
+        ss.on[0] = active && ow == 0;  // one wave per column of the grid carries the row for the column's PI tiles
         ss.bias = active && ow == 0 && iw == 0;
     } else if constexpr (SD::SK == 2) {
 #pragma unroll
@@ -311,7 +317,8 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
         // lane (i, k): sample 2e + k of k-step e, rows PO*i .. of the wave's A block / PI*i .. of its B block
         const float* pa = buf + k * ar + 32 * PO * ow + PO * i;
         const float* pb = buf + g * a_fl + k * br + 32 * PI * iw + PI * i;
-        const float* ps = SIDE ? buf + g * (a_fl + b_fl) + k * srows + SD::SW * i : buf;  // side operand(s) of lane (i, k)
+        // side operand(s) of lane (i, k): its rows SW * i .. of the side B tiles, or (A-side) THE row of the side region
+        const float* ps = SIDE ? buf + g * (a_fl + b_fl) + k * srows + (SD::SK == 1 ? (jb.side >> 24) : SD::SW * i) : buf;
         NH_TL(tl_loop);
         nh_wait_vmem();
         NH_TL(tl_wait);
@@ -334,11 +341,11 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
                     wstep_load(c1, pa + (s + 1) * 2 * AR, pb + (s + 1) * 2 * BR, ps + (s + 1) * 2 * srows);
                     dma.template issue<MD::NWV, SIDE>(1);
                     nh_sched_fence();
-                    wstep_mfma<PO, PI, BX, SD>(c0, acc, bsum, sacc, sbsum, ss);
+                    wstep_mfma<PO, PI, BX, SD>(c0, acc, bsum, sacc, sbsum, srow, ss);
                     // (last: one k-step past the stage, unused)
                     wstep_load(c0, pa + (s + 2) * 2 * AR, pb + (s + 2) * 2 * BR, ps + (s + 2) * 2 * srows);
                     nh_sched_fence();
-                    wstep_mfma<PO, PI, BX, SD>(c1, acc, bsum, sacc, sbsum, ss);
+                    wstep_mfma<PO, PI, BX, SD>(c1, acc, bsum, sacc, sbsum, srow, ss);
                 }
             } else {
                 const int steps = 16 * ntile;  // k-steps of two samples each
@@ -347,11 +354,11 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
                     wstep_load(c1, pa, pb, ps);
                     dma.template issue<MD::NWV, SIDE>(1);  // the next stage streams in underneath the MFMAs (at most 9 pieces per wave and stage)
                     nh_sched_fence();
-                    wstep_mfma<PO, PI, BX, SD>(c0, acc, bsum, sacc, sbsum, ss);
+                    wstep_mfma<PO, PI, BX, SD>(c0, acc, bsum, sacc, sbsum, srow, ss);
                     pa += 2 * ar, pb += 2 * br, ps += 2 * srows;
                     wstep_load(c0, pa, pb, ps);  // the last one reads one k-step past the stage (slack / other block): unused
                     nh_sched_fence();
-                    wstep_mfma<PO, PI, BX, SD>(c1, acc, bsum, sacc, sbsum, ss);
+                    wstep_mfma<PO, PI, BX, SD>(c1, acc, bsum, sacc, sbsum, srow, ss);
                 }
             }
         }
@@ -387,19 +394,30 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
             if (k == 0) part[a.part_bias + a_t * 32 + i] = tot;
         }
     }
-    if constexpr (SIDE) {
-        // side accumulator tiles behind the job's own: A-side (S, b_t) at a_tiles * b_tiles + b_t; B-side (a_t, y) at
-        // a_tiles * b_tiles + a_t * SB + y; the side A tile's row sums (its bias gradient) behind the job's bias partials
+    if constexpr (SD::SK == 2) {
+        // side accumulator tiles behind the job's own: pair (a_t, y) at a_tiles * b_tiles + a_t * SB + y
         const int base = jb.a_tiles * jb.b_tiles;
 #pragma unroll
         for (int j = 0; j < SD::NACC; ++j) {
             if (!ss.on[j]) continue;
-            const int idx = SD::SK == 1 ? base + iw * PI + ss.x[j] : base + (ow * PO + ss.x[j]) * SD::SB + ss.y[j];
-            float* dst = part + (size_t)idx * 1024 + lane;
+            float* dst = part + (size_t)(base + (ow * PO + ss.x[j]) * SD::SB + ss.y[j]) * 1024 + lane;
 #pragma unroll
             for (int c = 0; c < 16; ++c) dst[c * 64] = sacc[j][c];
         }
-        if (SD::SK == 1 && ss.bias) {
+    } else if constexpr (SD::SK == 1) {
+        // The side row as the reduce kernel reads it: row r of the side A tile against B tile b_t is accumulator tile
+        // a_tiles * b_tiles + b_t, register c / lane half h with (c & 3) + 8 (c >> 2) + 4 h == r, lane & 31 = the B row index
+        // i.  (Nothing else of those tiles is ever read: the reduce kernel only unpacks rows r_lo .. r_hi - 1 = r.)
+        const int r = jb.side >> 24, c = (r & 3) + 4 * (r >> 3), h = (r >> 2) & 1;
+        if (ss.on[0]) {
+#pragma unroll
+            for (int y = 0; y < PI; ++y) {
+                const float tot = srow[y] + nh_shfl_xor(srow[y], 32);
+                const int b_t = iw * PI + y;
+                if (k == 0 && b_t < jb.b_tiles) part[(size_t)(jb.a_tiles * jb.b_tiles + b_t) * 1024 + c * 64 + 32 * h + i] = tot;
+            }
+        }
+        if (ss.bias) {  // the side region's row sums (its bias gradient) behind the job's bias partials (every entry: the sum)
             const float tot = sbsum + nh_shfl_xor(sbsum, 32);
             if (k == 0) part[a.part_bias + jb.a_tiles * 32 + i] = tot;
         }
@@ -435,8 +453,10 @@ NH_DEVICE void wgrad_side_dispatch(const WgradArgs& a, const JobDev& jb, int64_t
     const int kind = jb.side & 255, st = (jb.side >> 8) & 255;
     constexpr bool host = (MD::NWV == 8 && PO == 4 && PI == 2) || (MD::NWV == 4 && PO == 2 && PI == 2);
     constexpr bool dirj = (MD::NWV == 8 && PO == 2 && PI == 2) || (MD::NWV == 4 && ((PO == 1 && PI == 2) || (PO == 2 && PI == 1)));
-    if constexpr (host) {
+    if constexpr (host && AR != 0) {  // (fixed-shape bodies only: plan.cpp attaches a side row to 256 x 256 / 128 x 128 jobs)
         if (kind == 1) return wgrad_bias_dispatch<MD, PO, PI, AR, BR, WSide<1, 1, 1>>(a, jb, t0, t1, ow, iw, wave, lane, wg, active, lds);
+    }
+    if constexpr (host) {
 #ifdef NH_WGRAD_SIDE2  // (A/B builds only: two more accumulator tiles per wave push the 4 x 2 patch body over 256 VGPRs)
         if constexpr (MD::NWV == 8) {  // (a 64-row side region next to 128 + 128 rows does not fit the 4-wave mode's stage)
             if (kind == 2 && st == 2)
@@ -650,7 +670,7 @@ void wgrad_schedule(const nerfhip_plan* p, int64_t nt, WgradArgs& w, ReduceArgs*
         d.po = j.po;
         d.pi = j.pi;
         d.wg_start = start;
-        d.side = j.side_kind | (j.side_tiles << 8) | (j.side_rows << 16);
+        d.side = j.side_kind | (j.side_tiles << 8) | (j.side_rows << 16) | ((j.side_kind == 1 ? j.s_r_lo : 0) << 24);
         d.side_prefix = (int)j.side_row_prefix;
         d.g = stage_floats / (32 * (j.a_region_rows + j.b_region_rows + (j.side_kind ? j.side_rows : 0)));
         if (d.g < 1) d.g = 1;

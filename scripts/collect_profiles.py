@@ -96,7 +96,8 @@ def rays_and_overlap():
 maybe(rays_and_overlap)
 maybe(lambda: kernel_stats("prof", "bench_kernel_stats.txt"))
 maybe(lambda: kernel_stats("prof128", "bench_kernel_stats_4x128.txt"))
-for src, dst in (("eval.log", "eval_800x800.txt"), ("phase_timing.txt", "phase_timing.txt"), ("pmc_summary_8x256_4096.txt", "pmc_summary.txt"),
+for src, dst in (("eval.log", "eval_800x800.txt"), ("phase_timing.txt", "phase_timing.txt"), ("wgrad_timeline.txt", "wgrad_timeline.txt"),
+                 ("wgrad_timeline_4x128.txt", "wgrad_timeline_4x128.txt"), ("pmc_summary_8x256_4096.txt", "pmc_summary.txt"),
                  ("pmc_summary_8x256_4096.json", "pmc_summary_8x256_4096.json"), ("pmc_summary_4x128_4096.txt", "pmc_summary_4x128_4096.txt"),
                  ("pmc_summary_4x128_4096.json", "pmc_summary_4x128_4096.json"), ("split_bf16_mock.txt", "split_bf16_mock.txt"),
                  ("ab/ab_summary.txt", "variant_ab.txt")):

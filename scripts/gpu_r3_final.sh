@@ -25,6 +25,11 @@ PMC_BENCH_ARGS="" bash scripts/gpu_pmc.sh > $R/pmc_8x256.log 2>&1
 cp $R/pmc_summary.json $R/pmc_summary_8x256_4096.json; cp $R/pmc_summary.txt $R/pmc_summary_8x256_4096.txt
 PMC_BENCH_ARGS="--hidden 128 --layers 4" bash scripts/gpu_pmc.sh > $R/pmc_4x128.log 2>&1
 cp $R/pmc_summary.json $R/pmc_summary_4x128_4096.json; cp $R/pmc_summary.txt $R/pmc_summary_4x128_4096.txt
+if [ -f nerf-pytorch_amd/libnerfhip_dbg.so ]; then
+  timeout 200 python scripts/wgrad_timeline.py 786432 256 8 > $R/wgrad_timeline.txt 2>&1
+  timeout 200 python scripts/wgrad_timeline.py 786432 128 4 > $R/wgrad_timeline_4x128.txt 2>&1
+  timeout 200 python scripts/phase_timing.py > $R/phase_timing.txt 2>&1
+fi
 grep -E "passed|failed|error" $R/pytest_gpu.log | tail -3; tail -2 $R/smoke.log; tail -2 $R/bench.log | cut -c1-1500
 for f in bench_4x128 bench_4x128_single bench_4x64 bench_8x512 bench_eval bench_rays2048 bench_rays1024 dp2_weak dp2_strong dp2_eval; do echo "== $f"; grep "^{" $R/$f.log | tail -1 | cut -c1-260; done
 cat $R/pmc_summary_8x256_4096.txt $R/pmc_summary_4x128_4096.txt; ls $R/prof $R/prof128 | head

@@ -407,8 +407,8 @@ struct Fwd16Args {
     int ray_stride;
     const float* z;
     int S;
-    short xcol[4][NH16_KRX];
-    short dcol[4][NH16_KRD];
+    signed char xcol[4][NH16_KRX_EXT];  // (rows of KX / KD entries; reference columns < 100)
+    signed char dcol[4][NH16_KRD_EXT];
     float fx[16], fd[16];
     int Lx, Ld;
     float* out;
@@ -418,9 +418,11 @@ struct Fwd16Args {
 };
 
 // TRAIN: the launch writes the activation stash (rows, encoding slots, ReLU masks) for the backward kernels
-template <int W, bool VIEW, bool TRAIN>
+// EXT: the extended encoding registers (num_encoding_fn_xyz > 10 or num_encoding_fn_dir > 4: nh_plan.h)
+template <int W, bool VIEW, bool TRAIN, bool EXT = false>
 NH_KERNEL void NH_LB(64 * Shape<W>::NW, Shape<W>::WAVES_PER_SIMD) k_mlp_fwd16(Fwd16Args a) {
-    constexpr int KH = W / 4, TW = W / 16, KX = NH16_KRX, KD = NH16_KRD, NW = Shape<W>::NW, MW = Shape<W>::MW;
+    constexpr int KH = W / 4, TW = W / 16, KX = EXT ? NH16_KRX_EXT : NH16_KRX, KD = EXT ? NH16_KRD_EXT : NH16_KRD;
+    constexpr int NW = Shape<W>::NW, MW = Shape<W>::MW;
     NH_DYN_LDS(lds_raw);
     nh_clk_begin(a.clk, (unsigned long long*)(lds_raw + Lds<W>::BYTES));
     Ctx cx;
@@ -741,7 +743,7 @@ int lds_limit(K kern, int bytes) {
 
 }  // namespace
 
-#if defined(NH_PHASE_TIMING) && !defined(NH16_W512_TU)
+#if defined(NH_PHASE_TIMING) && !defined(NH16_W512_TU) && !defined(NH16_EXT_TU)
 extern "C" int nerfhip_debug_phases16(unsigned long long* host16, int reset) {
     (void)hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_phase16), sizeof(unsigned long long) * 16);
     if (reset) {
@@ -756,6 +758,7 @@ extern "C" int nerfhip_debug_phases16(unsigned long long* host16, int reset) {
 // The 512-wide instantiations (three kernels, ~2.5 minutes of compile time) live in their own translation unit,
 // mlp16_w512.hip, which includes this file with NH16_W512_TU defined: it compiles the same templates for W = 512 only and
 // exports nh_mlp16_forward_w512 / nh_mlp16_dgrad_w512; this unit holds the widths 64 / 128 / 256 and the dispatch.
+// mlp16_ext.hip (NH16_EXT_TU) likewise holds the forward kernels with the extended encoding registers, every width.
 namespace {
 
 void fill_fwd_args(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash, Fwd16Args& a) {
@@ -776,8 +779,8 @@ void fill_fwd_args(nerfhip_plan* p, const float* packed, const NhMlpInput& in, i
     a.z = in.z;
     a.S = in.S;
     for (int g = 0; g < 4; ++g) {
-        for (int r = 0; r < NH16_KRX; ++r) a.xcol[g][r] = (short)p->xyz_col16[g][r];
-        for (int r = 0; r < NH16_KRD; ++r) a.dcol[g][r] = (short)p->dir_col16[g][r];
+        for (int r = 0; r < NH16_KRX_EXT; ++r) a.xcol[g][r] = (signed char)p->xyz_col16[g][r];
+        for (int r = 0; r < NH16_KRD_EXT; ++r) a.dcol[g][r] = (signed char)p->dir_col16[g][r];
     }
     for (int k = 0; k < 16; ++k) {
         a.fx[k] = p->freqs_xyz[k];
@@ -809,19 +812,20 @@ void fill_dgrad_args(nerfhip_plan* p, const float* packed, const float* g_out, i
 }
 
 // whole 128-sample groups are launched: every stash tile is written
-#define NH_FWD16_T(WW, VV, TT)                                                                                        \
+#define NH_FWD16_T(WW, VV, TT, EE)                                                                                    \
     {                                                                                                                 \
-        rc = lds_limit(k_mlp_fwd16<WW, VV, TT>, Lds<WW>::BYTES_ALL);                                                  \
+        rc = lds_limit(k_mlp_fwd16<WW, VV, TT, EE>, Lds<WW>::BYTES_ALL);                                              \
         if (rc) return rc;                                                                                            \
-        NH_LAUNCH((k_mlp_fwd16<WW, VV, TT>), groups * (8 / Shape<WW>::NW), 64 * Shape<WW>::NW, Lds<WW>::BYTES_ALL, stream, a); \
+        NH_LAUNCH((k_mlp_fwd16<WW, VV, TT, EE>), groups * (8 / Shape<WW>::NW), 64 * Shape<WW>::NW, Lds<WW>::BYTES_ALL, stream, a); \
     }
-#define NH_FWD16(WW, VV)              \
-    {                                 \
-        if (stash)                    \
-            NH_FWD16_T(WW, VV, true)  \
-        else                          \
-            NH_FWD16_T(WW, VV, false) \
+#define NH_FWD16_E(WW, VV, EE)            \
+    {                                     \
+        if (stash)                        \
+            NH_FWD16_T(WW, VV, true, EE)  \
+        else                              \
+            NH_FWD16_T(WW, VV, false, EE) \
     }
+#define NH_FWD16(WW, VV) NH_FWD16_E(WW, VV, false)
 #define NH_BWD16(WW, VV)                                                                                              \
     {                                                                                                                 \
         rc = lds_limit(k_mlp_dgrad16<WW, VV>, Lds<WW>::BYTES_ALL);                                                    \
@@ -835,8 +839,28 @@ int nh_mlp16_forward_w512(nerfhip_plan* p, const float* packed, const NhMlpInput
                           nerfhip_stream_t stream);
 int nh_mlp16_dgrad_w512(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
                         nerfhip_stream_t stream);
+int nh_mlp16_forward_ext(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
+                         nerfhip_stream_t stream);
 
-#ifdef NH16_W512_TU
+#if defined(NH16_EXT_TU)
+// every width with the extended encoding registers (mlp16_ext.hip)
+int nh_mlp16_forward_ext(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
+                         nerfhip_stream_t stream) {
+    Fwd16Args a;
+    fill_fwd_args(p, packed, in, M, out, stash, a);
+    const int64_t groups = nh_ceil_div(M, 128);
+    int rc = NERFHIP_OK;
+    if (p->W == 512 && p->view) NH_FWD16_E(512, true, true)
+    else if (p->W == 512) NH_FWD16_E(512, false, true)
+    else if (p->W == 256 && p->view) NH_FWD16_E(256, true, true)
+    else if (p->W == 256) NH_FWD16_E(256, false, true)
+    else if (p->W == 128 && p->view) NH_FWD16_E(128, true, true)
+    else if (p->W == 128) NH_FWD16_E(128, false, true)
+    else if (p->view) NH_FWD16_E(64, true, true)
+    else NH_FWD16_E(64, false, true)
+    return nh_launch_status("mlp_fwd16");
+}
+#elif defined(NH16_W512_TU)
 int nh_mlp16_forward_w512(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
                           nerfhip_stream_t stream) {
     Fwd16Args a;
@@ -862,6 +886,7 @@ int nh_mlp16_dgrad_w512(nerfhip_plan* p, const float* packed, const float* g_out
 int nh_mlp16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
                      nerfhip_stream_t stream) {
     NH_REQUIRE(M < ((int64_t)1 << 31), "mlp_fwd: at most 2^31 - 1 sample points per call (got %lld)", (long long)M);
+    if (p->krx != NH16_KRX) return nh_mlp16_forward_ext(p, packed, in, M, out, stash, stream);
     if (p->W == 512) return nh_mlp16_forward_w512(p, packed, in, M, out, stash, stream);
     Fwd16Args a;
     fill_fwd_args(p, packed, in, M, out, stash, a);
@@ -893,5 +918,6 @@ int nh_mlp16_dgrad(nerfhip_plan* p, const float* packed, const float* g_out, int
 }
 #endif
 #undef NH_FWD16
+#undef NH_FWD16_E
 #undef NH_FWD16_T
 #undef NH_BWD16

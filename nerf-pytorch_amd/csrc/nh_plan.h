@@ -27,8 +27,11 @@
 constexpr int NH_MAX_LAYERS = 32;  // num_layers limit (per-layer offset tables travel by value in the kernel arguments)
 constexpr int NH_MAX_JOBS = 64;  // weight-gradient jobs of one model (== the kernel-argument table of wgrad.hip)
 
-constexpr int NH16_KRX = 16;
-constexpr int NH16_KRD = 8;
+// Encoding registers per lane group (slots = 4 x that) of the forward kernel: 16 / 8 cover the reference's defaults and
+// every config/*.yml (num_encoding_fn_xyz <= 10, num_encoding_fn_dir <= 4); the extended instantiation (32 / 16) covers
+// num_encoding_fn_xyz <= 16 and num_encoding_fn_dir <= 10.  nerfhip_plan::krx / krd say which one a plan uses.
+constexpr int NH16_KRX = 16, NH16_KRX_EXT = 32;
+constexpr int NH16_KRD = 8, NH16_KRD_EXT = 16;
 static inline int nh_feat16(int r, int g) { return 16 * (r >> 2) + 4 * g + (r & 3); }
 static inline int nh16_tq(int tiles) { return (tiles + 3) / 4; }
 // bias block in front of every layer image (one float per output row, 16 per tile): 512 floats cover the 17 tiles of a
@@ -111,10 +114,11 @@ struct nerfhip_plan {
     int64_t nparams;
     int t_layer1_w, t_layer1_b, t_xyz_w[NH_MAX_LAYERS], t_xyz_b[NH_MAX_LAYERS];
     int t_dir_w, t_dir_b, t_alpha_w, t_alpha_b, t_rgb_w, t_rgb_b, t_feat_w, t_feat_b, t_out_w, t_out_b;
-    int xyz_col16[4][NH16_KRX];  // slot (r,g) -> reference column of the xyz encoding, or -1
-    int dir_col16[4][NH16_KRD];
-    int xyz_slot_col[64];    // stash slot row -> reference column, used by the weight-gradient scatter
-    int dir_slot_col[32];
+    int krx, krd;                     // encoding registers per lane group: NH16_KRX / NH16_KRD or the _EXT pair
+    int xyz_col16[4][NH16_KRX_EXT];  // slot (r,g) -> reference column of the xyz encoding, or -1  (rows of krx entries)
+    int dir_col16[4][NH16_KRD_EXT];
+    int xyz_slot_col[4 * NH16_KRX_EXT];  // stash slot row g*krx + r -> reference column, used by the weight-gradient scatter
+    int dir_slot_col[4 * NH16_KRD_EXT];
     float freqs_xyz[16], freqs_dir[16];
     bool freqs_set;
     NhPackedOffsets po;

@@ -23,12 +23,12 @@ int add_tensor(nerfhip_plan* p, const std::string& name, int rows, int cols) {
 // slot (r,g) -> reference column.  Group g < 3 owns the (frequency, axis) pairs [g*C, (g+1)*C), C = KR/2; group 3 owns
 // [3C, 3C + (KR-3)/2) and carries the raw coordinates in its last three registers.  Pair p = 3*f + axis sits in
 // registers 2q (sin), 2q+1 (cos), q = p - g*C.
-bool build_slot_map16(int L, int include_input, int kr, int* col_flat) {
-    auto col = [&](int g) { return col_flat + g * kr; };
+bool build_slot_map16(int L, int include_input, int kr, int* col_flat, int row_stride) {
+    auto col = [&](int g) { return col_flat + g * row_stride; };
     const int P = 3 * L, C = kr / 2, C3 = (kr - 3) / 2, base = include_input ? 3 : 0;
     if (P > 3 * C + C3) return false;
     for (int g = 0; g < 4; ++g)
-        for (int r = 0; r < kr; ++r) col(g)[r] = -1;
+        for (int r = 0; r < row_stride; ++r) col(g)[r] = -1;
     for (int g = 0; g < 4; ++g)
         for (int q = 0; q < (g < 3 ? C : C3); ++q) {
             const int pr = g * C + q;
@@ -74,7 +74,7 @@ void build_specs16(const nerfhip_plan* p, Specs16& S) {
     auto T = [p](int idx) { return p->tensors[idx]; };
     {
         GemmSpec16& s = S.f_layer1;
-        s.kr = NH16_KRX;
+        s.kr = p->krx;
         s.tiles = TW;
         NhTensor w = T(p->t_layer1_w), b = T(p->t_layer1_b);
         s.w = [=](int o, int r, int g) -> int64_t {
@@ -86,7 +86,7 @@ void build_specs16(const nerfhip_plan* p, Specs16& S) {
     for (int i = 0; i < L - 1; ++i) {
         GemmSpec16& s = S.f_xyz[i];
         const bool sk = p->is_skip(i);
-        s.kr = KH + (sk ? NH16_KRX : 0);
+        s.kr = KH + (sk ? p->krx : 0);
         s.tiles = TW;
         NhTensor w = T(p->t_xyz_w[i]), b = T(p->t_xyz_b[i]);
         const int ld = H + (sk ? Dx : 0);
@@ -122,7 +122,7 @@ void build_specs16(const nerfhip_plan* p, Specs16& S) {
         }
         {
             GemmSpec16& s = S.f_dir;
-            s.kr = KH + NH16_KRD;
+            s.kr = KH + p->krd;
             s.tiles = TW / 2;
             const int ld = H + Dd;
             s.w = [=](int o, int r, int g) -> int64_t {
@@ -363,8 +363,8 @@ void build_layouts_and_jobs(nerfhip_plan* p) {
     NhStashLayout& S = p->stash;
     memset(&S, 0, sizeof(S));
     S.total_rows = 0;
-    S.X = add_region(&S.total_rows, 4 * NH16_KRX);  // slot rows g*KR + r
-    if (p->view) S.D = add_region(&S.total_rows, 4 * NH16_KRD);
+    S.X = add_region(&S.total_rows, 4 * p->krx);  // slot rows g*KR + r
+    if (p->view) S.D = add_region(&S.total_rows, 4 * p->krd);
     for (int k = 0; k < L; ++k) S.H[k] = add_region(&S.total_rows, W);
     if (p->view) {
         S.FEAT = add_region(&S.total_rows, W);
@@ -390,16 +390,16 @@ void build_layouts_and_jobs(nerfhip_plan* p) {
     // (tiles cover the kernel width W; only the rows / columns of the real H hidden units are unpacked)
     const int TW = W / 32, H = p->H, H2 = H / 2;
     // layer1: dP_0 x X
-    add_job(p, G.P[0], TW, S.X, 0, 2, 0, H, p->t_layer1_w, 1, 0, p->Dx, p->t_layer1_b);
+    add_job(p, G.P[0], TW, S.X, 0, p->krx / 8, 0, H, p->t_layer1_w, 1, 0, p->Dx, p->t_layer1_b);
     for (int i = 0; i < L - 1; ++i) {
         add_job(p, G.P[i + 1], TW, S.H[i], 0, TW, 0, H, p->t_xyz_w[i], 0, 0, H, p->t_xyz_b[i]);
-        if (p->is_skip(i)) add_job(p, G.P[i + 1], TW, S.X, 0, 2, 0, H, p->t_xyz_w[i], 1, H, p->Dx, -1);
+        if (p->is_skip(i)) add_job(p, G.P[i + 1], TW, S.X, 0, p->krx / 8, 0, H, p->t_xyz_w[i], 1, H, p->Dx, -1);
     }
     if (p->view) {
         add_job(p, G.PFEAT, TW, S.H[L - 1], 0, TW, 0, H, p->t_feat_w, 0, 0, H, p->t_feat_b);
         add_job(p, G.POUT, 1, S.H[L - 1], 0, TW, 3, 4, p->t_alpha_w, 0, 0, H, p->t_alpha_b);
         add_job(p, G.PDIR, TW / 2, S.FEAT, 0, TW, 0, H2, p->t_dir_w, 0, 0, H, p->t_dir_b);
-        add_job(p, G.PDIR, TW / 2, S.D, 0, 1, 0, H2, p->t_dir_w, 2, H, p->Dd, -1);
+        add_job(p, G.PDIR, TW / 2, S.D, 0, p->krd / 8, 0, H2, p->t_dir_w, 2, H, p->Dd, -1);
         add_job(p, G.POUT, 1, S.DIRH, 0, TW / 2, 0, 3, p->t_rgb_w, 0, 0, H2, p->t_rgb_b);
     } else {
         add_job(p, G.POUT, 1, S.H[L - 1], 0, TW, 0, 4, p->t_out_w, 0, 0, H, p->t_out_b);
@@ -428,9 +428,9 @@ extern "C" nerfhip_plan_t nerfhip_plan_create(const nerfhip_model_cfg* cfg) {
         nh_set_error("plan_create: skip_connect_every must be >= 1");
         return nullptr;
     }
-    if (cfg->num_encoding_fn_xyz < 0 || cfg->num_encoding_fn_xyz > 10 || cfg->num_encoding_fn_dir < 0 ||
-        cfg->num_encoding_fn_dir > 4) {
-        nh_set_error("plan_create: num_encoding_fn_xyz must be <= 10 and num_encoding_fn_dir <= 4 (got %d, %d)",
+    if (cfg->num_encoding_fn_xyz < 0 || cfg->num_encoding_fn_xyz > 16 || cfg->num_encoding_fn_dir < 0 ||
+        cfg->num_encoding_fn_dir > 10) {
+        nh_set_error("plan_create: num_encoding_fn_xyz must be <= 16 and num_encoding_fn_dir <= 10 (got %d, %d)",
                      cfg->num_encoding_fn_xyz, cfg->num_encoding_fn_dir);
         return nullptr;
     }
@@ -476,16 +476,24 @@ extern "C" nerfhip_plan_t nerfhip_plan_create(const nerfhip_model_cfg* cfg) {
         p->t_out_b = add_tensor(p, "fc_out.bias", 4, 0);
     }
     {
-        const bool okx = build_slot_map16(cfg->num_encoding_fn_xyz, cfg->include_input_xyz ? 1 : 0, NH16_KRX, &p->xyz_col16[0][0]);
+        // the default slot registers hold the reference's own settings; anything longer takes the extended instantiation
+        // of the forward kernel (both encodings together: one extra template instance, not two)
+        const bool ext = cfg->num_encoding_fn_xyz > 10 || (p->view && cfg->num_encoding_fn_dir > 4);
+        p->krx = ext ? NH16_KRX_EXT : NH16_KRX;
+        p->krd = ext ? NH16_KRD_EXT : NH16_KRD;
+        const bool okx = build_slot_map16(cfg->num_encoding_fn_xyz, cfg->include_input_xyz ? 1 : 0, p->krx, &p->xyz_col16[0][0],
+                                          NH16_KRX_EXT);
         const bool okd = build_slot_map16(p->view ? cfg->num_encoding_fn_dir : 0, (p->view && cfg->include_input_dir) ? 1 : 0,
-                                          NH16_KRD, &p->dir_col16[0][0]);
+                                          p->krd, &p->dir_col16[0][0], NH16_KRD_EXT);
         if (!(okx && okd)) {
             nh_set_error("plan_create: encoding does not fit the slot registers");
             delete p;
             return nullptr;
         }
-        for (int row = 0; row < 64; ++row) p->xyz_slot_col[row] = p->xyz_col16[row / NH16_KRX][row % NH16_KRX];
-        for (int row = 0; row < 32; ++row) p->dir_slot_col[row] = p->dir_col16[row / NH16_KRD][row % NH16_KRD];
+        for (int row = 0; row < 4 * NH16_KRX_EXT; ++row)
+            p->xyz_slot_col[row] = row < 4 * p->krx ? p->xyz_col16[row / p->krx][row % p->krx] : -1;
+        for (int row = 0; row < 4 * NH16_KRD_EXT; ++row)
+            p->dir_slot_col[row] = row < 4 * p->krd ? p->dir_col16[row / p->krd][row % p->krd] : -1;
     }
     for (int k = 0; k < 16; ++k) {
         p->freqs_xyz[k] = 0.f;

@@ -94,8 +94,8 @@ struct ReduceArgs {
     int njobs, total_wgs;
     int part_bias, part_stride;
     JobRed jobs[NH_JOBS_DEV];
-    short xslot[64];  // stash slot row -> reference column of the encoding, or -1
-    short dslot[32];
+    signed char xslot[4 * NH16_KRX_EXT];  // stash slot row -> reference column of the encoding (< 100), or -1
+    signed char dslot[4 * NH16_KRD_EXT];
 };
 
 // the P operands (one per tile) of one k-step: P consecutive floats of one sample
@@ -727,8 +727,8 @@ void wgrad_schedule(const nerfhip_plan* p, int64_t nt, WgradArgs& w, ReduceArgs*
         r->total_wgs = w.total_wgs;
         r->part_bias = w.part_bias;
         r->part_stride = w.part_stride;
-        for (int q = 0; q < 64; ++q) r->xslot[q] = (short)p->xyz_slot_col[q];
-        for (int q = 0; q < 32; ++q) r->dslot[q] = (short)p->dir_slot_col[q];
+        for (int q = 0; q < 4 * NH16_KRX_EXT; ++q) r->xslot[q] = (signed char)p->xyz_slot_col[q];
+        for (int q = 0; q < 4 * NH16_KRD_EXT; ++q) r->dslot[q] = (signed char)p->dir_slot_col[q];
     }
 }
 

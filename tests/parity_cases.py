@@ -278,7 +278,15 @@ MLP_GEOMETRIES = {
     "odd5x99_skip2": model_cfg(5, 99, 2, 10, 4),
     "wide3x200_skip1": model_cfg(3, 200, 1, 6, 3),
     "novw2x130": model_cfg(2, 130, 4, 5, 0, use_viewdirs=False),
+    # more frequencies than the reference's configs use (nerf/models.py:198-201 takes any): the forward kernel's extended
+    # encoding registers (128 + 64 stash slot rows instead of 64 + 32; four / two B tiles in the encoding-column jobs)
+    "L12_4x128": model_cfg(4, 128, 4, 12, 4),
+    "L16_Ld6_8x256": model_cfg(8, 256, 4, 16, 6),
+    "L11_novw3x64_skip1": model_cfg(3, 64, 1, 11, 0, use_viewdirs=False),
+    "L12_Ld10_2x512": model_cfg(2, 512, 4, 12, 10),
+    "Ld5_4x128_skip2": model_cfg(4, 128, 2, 10, 5),
 }
+EXT_GEOMETRIES = ("L12_4x128", "L16_Ld6_8x256", "L11_novw3x64_skip1", "L12_Ld10_2x512", "Ld5_4x128_skip2")
 
 
 def case_mlp_forward(b, names=None, m=70):

@@ -84,6 +84,16 @@ def test_mlp_512_wide_instances(emu):
     P.case_mlp_input_grad(emu, names=("wide3x512_skip2", "wide2x320"), m=45)
 
 
+def test_mlp_extended_encodings(emu):
+    """num_encoding_fn_xyz up to 16, num_encoding_fn_dir up to 10 (nerf/models.py:198-201 takes any): the extended slot
+    registers of the forward kernel, every width."""
+    P.case_mlp_forward(emu, names=P.EXT_GEOMETRIES, m=37)
+    P.case_mlp_backward(emu, names=P.EXT_GEOMETRIES, m=45)
+    P.case_mlp_input_grad(emu, names=("L12_4x128", "Ld5_4x128_skip2"), m=45)
+    P.case_render_vs_oracle(emu, P.MLP_GEOMETRIES["L12_4x128"], n=10, nc=8, nf=8, with_grads=True, tag="L12_emu")
+    P.case_ray_grad(emu, P.MLP_GEOMETRIES["L12_4x128"], n=8)
+
+
 def test_mlp_padded_hidden_sizes(emu):
     """hidden_size other than 128 / 256 (the reference constructor takes any: nerf/models.py:185-196), odd included."""
     names = ("narrow3x40", "odd5x99_skip2", "wide3x200_skip1", "novw2x130")

@@ -85,6 +85,15 @@ def test_render_512_wide_vs_oracle(gpu):
                             grad_tol=(3.4e-3, 2e-2))
 
 
+def test_mlp_extended_encodings(gpu):
+    """num_encoding_fn_xyz up to 16 / num_encoding_fn_dir up to 10: the extended slot registers, every kernel width."""
+    P.case_mlp_forward(gpu, names=P.EXT_GEOMETRIES, m=1000)
+    P.case_mlp_backward(gpu, names=P.EXT_GEOMETRIES, m=1500)
+    P.case_mlp_input_grad(gpu, names=("L12_4x128", "Ld5_4x128_skip2", "L16_Ld6_8x256"), m=1500)
+    P.case_render_vs_oracle(gpu, P.MLP_GEOMETRIES["L12_4x128"], n=200, nc=64, nf=64, with_grads=True, tag="L12_200")
+    P.case_ray_grad(gpu, P.MLP_GEOMETRIES["L12_4x128"], n=100, nc=32, nf=32)
+
+
 def test_mlp_padded_hidden_sizes(gpu):
     names = ("narrow3x40", "odd5x99_skip2", "wide3x200_skip1", "novw2x130")
     P.case_mlp_forward(gpu, names=names, m=700)

@@ -44,12 +44,13 @@ def test_errors_are_reported_not_thrown(lib):
     bad = L.ModelCfg(4, 600, 4, 10, 4, 1, 1, 1, 1, 1)
     assert not lib.plan_create(C.byref(bad))
     assert b"hidden_size" in lib.last_error()
-    bad = L.ModelCfg(4, 128, 4, 11, 4, 1, 1, 1, 1, 1)
+    bad = L.ModelCfg(4, 128, 4, 17, 4, 1, 1, 1, 1, 1)
     assert not lib.plan_create(C.byref(bad))
 
 
 @pytest.mark.parametrize("geo", [(8, 256, 4, 10, 4, True), (4, 128, 4, 10, 4, True), (8, 128, 3, 6, 4, True),
-                                 (4, 128, 4, 10, 4, False), (6, 256, 2, 10, 4, True)])
+                                 (4, 128, 4, 10, 4, False), (6, 256, 2, 10, 4, True), (4, 128, 4, 12, 4, True),
+                                 (8, 256, 4, 16, 6, True), (3, 64, 1, 11, 0, False), (2, 512, 4, 12, 10, True)])
 def test_plan_layout_and_pack_table(lib, geo):
     Lr, W, sk, lx, ld, view = geo
     cfg = dict(num_layers=Lr, hidden_size=W, skip_connect_every=sk, num_encoding_fn_xyz=lx, num_encoding_fn_dir=ld,
@@ -75,7 +76,7 @@ def test_plan_layout_and_pack_table(lib, geo):
     dx, dd = O.model_dims(cfg)
     counts = np.bincount(table[table >= 0], minlength=off)
     assert counts.min() >= 1
-    if (Lr, W) == (8, 256) and view:
+    if (Lr, W, lx, ld) == (8, 256, 10, 4) and view:
         assert off == 595844
     lib.plan_destroy(plan)
 
@@ -175,7 +176,7 @@ def test_product_reads_no_environment_and_ships_one_kernel_set():
     wg = open(os.path.join(csrc, "wgrad.hip")).read()
     assert wg.count("#ifdef NH_WGRAD_TIMELINE") >= 3 and "nh_wall_clock()" in wg  # instrumentation is debug-build only
     assert sorted(f for f in os.listdir(csrc) if f.endswith(".hip")) == [
-        "dataio.hip", "elementwise.hip", "fused.hip", "mlp.hip", "mlp16.hip", "mlp16_w512.hip", "render.hip", "sample.hip",
+        "dataio.hip", "elementwise.hip", "fused.hip", "mlp.hip", "mlp16.hip", "mlp16_ext.hip", "mlp16_w512.hip", "render.hip", "sample.hip",
         "wgrad.hip"]
 
 

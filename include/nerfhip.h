@@ -74,6 +74,11 @@ int nerfhip_ray_bundle(int height, int width, float focal, const float* c2w, int
  * neg_two_near = -2*near are evaluated by the caller exactly as the reference's Python scalar arithmetic does. */
 int nerfhip_ndc_rays(float near, float cw, float ch, float two_near, float neg_two_near, const float* rays_o,
                      const float* rays_d, int64_t n, float* out_o, float* out_d, nerfhip_stream_t stream);
+/* Its vector-Jacobian product (what autograd computes through nerf/nerf_helpers.py:170-197 when the rays require grad --
+ * pose optimisation on LLFF scenes): g_rays_o/d [n,3] = J^T (g_out_o, g_out_d) at (rays_o, rays_d). */
+int nerfhip_ndc_rays_bwd(float near, float cw, float ch, float two_near, float neg_two_near, const float* rays_o,
+                         const float* rays_d, const float* g_out_o, const float* g_out_d, int64_t n, float* g_rays_o,
+                         float* g_rays_d, nerfhip_stream_t stream);
 
 /* viewdirs + ray packing of run_one_iter_of_nerf (nerf/train_utils.py:143-168):
  * rays[n, 8|11] = [o(3) d(3) near far (d/||d||)(3)].  viewdir_src (dev [n,3]) is the PRE-ndc direction the

@@ -64,6 +64,7 @@ _PROTOS = {
     "nerfhip_rng_fill": (C.c_int, [C.c_int, c_u64, c_u32, c_u64, c_i64, c_f, c_f]),
     "nerfhip_ray_bundle": (C.c_int, [C.c_int, C.c_int, C.c_float, c_f, C.c_int, c_f, c_i64, c_f, c_f, c_f]),
     "nerfhip_ndc_rays": (C.c_int, [C.c_float] * 5 + [c_f, c_f, c_i64, c_f, c_f, c_f]),
+    "nerfhip_ndc_rays_bwd": (C.c_int, [C.c_float] * 5 + [c_f, c_f, c_f, c_f, c_i64, c_f, c_f, c_f]),
     "nerfhip_pack_rays": (C.c_int, [c_f, c_f, c_f, C.c_float, C.c_float, c_i64, c_f, c_f]),
     "nerfhip_positional_encoding": (C.c_int, [c_f, c_i64, C.c_int, c_f, C.c_int, C.c_int, c_f, c_f]),
     "nerfhip_stratified_z": (C.c_int, [c_f, C.c_int, c_i64, c_f, C.c_int, C.c_int, C.c_int, c_f, c_u64, c_u64, c_f,

@@ -180,6 +180,52 @@ extern "C" int nerfhip_ndc_rays(float near, float cw, float ch, float two_near, 
     return nh_launch_status("ndc_rays");
 }
 
+// Vector-Jacobian product of ndc_rays: the chain rule through the statements of nh_ndc_ray in reverse order, which is what
+// autograd does to nerf/nerf_helpers.py:170-197 (t = -(near + oz)/dz; p = o + t d; the six outputs are rational in p, d).
+NH_KERNEL void k_ndc_rays_bwd(NhNdc k, const float* __restrict__ ro, const float* __restrict__ rd,
+                              const float* __restrict__ g_oo, const float* __restrict__ g_od, int64_t n,
+                              float* __restrict__ g_ro, float* __restrict__ g_rd) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float ox = ro[i * 3], oy = ro[i * 3 + 1], oz = ro[i * 3 + 2];
+    const float dx = rd[i * 3], dy = rd[i * 3 + 1], dz = rd[i * 3 + 2];
+    const float gO0 = g_oo[i * 3], gO1 = g_oo[i * 3 + 1], gO2 = g_oo[i * 3 + 2];
+    const float gD0 = g_od[i * 3], gD1 = g_od[i * 3 + 1], gD2 = g_od[i * 3 + 2];
+    const float t = -(k.near + oz) / dz;
+    const float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;
+    const float ipz = 1.0f / pz, idz = 1.0f / dz;
+    // outputs -> p, d
+    const float ax = k.cw * (gO0 - gD0), ay = k.ch * (gO1 - gD1);  // d/d(px/pz), d/d(py/pz)
+    float gpx = ax * ipz, gpy = ay * ipz;
+    float gpz = -(ax * px + ay * py + k.two_near * gO2 + k.neg_two_near * gD2) * ipz * ipz;
+    float gdx = k.cw * gD0 * idz, gdy = k.ch * gD1 * idz;
+    float gdz = -(k.cw * gD0 * dx + k.ch * gD1 * dy) * idz * idz;
+    // p = o + t d
+    const float gt = gpx * dx + gpy * dy + gpz * dz;
+    gdx += t * gpx;
+    gdy += t * gpy;
+    gdz += t * gpz;
+    // t = -(near + oz) / dz
+    gpz += -gt * idz;                         // (g wrt oz: through p and through t)
+    gdz += gt * (k.near + oz) * idz * idz;
+    g_ro[i * 3] = gpx;
+    g_ro[i * 3 + 1] = gpy;
+    g_ro[i * 3 + 2] = gpz;
+    g_rd[i * 3] = gdx;
+    g_rd[i * 3 + 1] = gdy;
+    g_rd[i * 3 + 2] = gdz;
+}
+
+extern "C" int nerfhip_ndc_rays_bwd(float near, float cw, float ch, float two_near, float neg_two_near, const float* rays_o,
+                                    const float* rays_d, const float* g_out_o, const float* g_out_d, int64_t n, float* g_rays_o,
+                                    float* g_rays_d, nerfhip_stream_t stream) {
+    if (n == 0) return NERFHIP_OK;
+    NH_REQUIRE(rays_o && rays_d && g_out_o && g_out_d && g_rays_o && g_rays_d && n >= 0, "ndc_rays_bwd: bad arguments");
+    NhNdc k = {near, cw, ch, two_near, neg_two_near};
+    NH_LAUNCH(k_ndc_rays_bwd, nh_ceil_div(n, 256), 256, 0, stream, k, rays_o, rays_d, g_out_o, g_out_d, n, g_rays_o, g_rays_d);
+    return nh_launch_status("ndc_rays_bwd");
+}
+
 // ---- viewdirs + ray packing (nerf/train_utils.py:143-168) ------------------------------------------------------------
 NH_KERNEL void k_pack_rays(const float* __restrict__ ro, const float* __restrict__ rd, const float* __restrict__ vsrc,
                            float near, float far, int64_t n, float* __restrict__ rays) {

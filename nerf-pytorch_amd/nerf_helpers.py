@@ -171,10 +171,38 @@ def get_embedding_function(num_encoding_functions=6, include_input=True, log_sam
     return EmbeddingFunction(num_encoding_functions, include_input, log_sampling)
 
 
+class _NdcRays(torch.autograd.Function):
+    """ndc_rays with its vector-Jacobian product (nerfhip_ndc_rays_bwd)."""
+
+    @staticmethod
+    def forward(ctx, o, d, consts):
+        oo, od = torch.empty_like(o), torch.empty_like(d)
+        with launch_on(o, d, oo, od) as st:
+            get_lib().ndc_rays(*consts, o.data_ptr(), d.data_ptr(), o.numel() // 3, oo.data_ptr(), od.data_ptr(), st)
+        ctx.save_for_backward(o, d)
+        ctx.consts = consts
+        ctx.set_materialize_grads(False)
+        return oo, od
+
+    @staticmethod
+    def backward(ctx, g_oo, g_od):
+        o, d = ctx.saved_tensors
+        if g_oo is None and g_od is None:
+            return None, None, None
+        g_oo = torch.zeros_like(o) if g_oo is None else g_oo.contiguous().float()
+        g_od = torch.zeros_like(d) if g_od is None else g_od.contiguous().float()
+        g_o, g_d = torch.empty_like(o), torch.empty_like(d)
+        with launch_on(o, d, g_oo, g_od, g_o, g_d) as st:
+            get_lib().ndc_rays_bwd(*ctx.consts, o.data_ptr(), d.data_ptr(), g_oo.data_ptr(), g_od.data_ptr(), o.numel() // 3,
+                                   g_o.data_ptr(), g_d.data_ptr(), st)
+        return g_o, g_d, None
+
+
 def ndc_rays(H, W, focal, near, rays_o, rays_d):
-    """nerf/nerf_helpers.py:170-197."""
-    o = _dev32(rays_o, "rays_o")
-    d = _dev32(rays_d, "rays_d")
+    """nerf/nerf_helpers.py:170-197.  Differentiable w.r.t. rays_o / rays_d, as the reference's tensor arithmetic is."""
+    want_grad = torch.is_grad_enabled() and (rays_o.requires_grad or rays_d.requires_grad)
+    o = rays_o.contiguous().float() if want_grad else _dev32(rays_o, "rays_o")
+    d = rays_d.contiguous().float() if want_grad else _dev32(rays_d, "rays_d")
     if isinstance(focal, torch.Tensor):  # the reference then evaluates the constants in fp32 tensor arithmetic
         f = focal.detach().float().cpu()
         cw = float(-1.0 / (W / (2.0 * f)))
@@ -182,6 +210,10 @@ def ndc_rays(H, W, focal, near, rays_o, rays_d):
     else:
         cw = -1.0 / (W / (2.0 * focal))
         ch = -1.0 / (H / (2.0 * focal))
+    if want_grad:
+        if o.device.type != "cuda":
+            raise RuntimeError("ndc_rays: rays_o must live on the GPU (got %s)" % o.device)
+        return _NdcRays.apply(o, d, (float(near), cw, ch, 2.0 * near, -2.0 * near))
     n = o.numel() // 3
     oo, od = torch.empty_like(o), torch.empty_like(d)
     with launch_on(o, d, oo, od) as st:

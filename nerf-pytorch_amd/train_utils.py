@@ -225,44 +225,46 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, mo
 
 
 class _PackRays(torch.autograd.Function):
-    """rows [o d near far (d/||d||)] (train_utils.py:143-168) with the gradient autograd gives the reference for the
-    blender (no-NDC) branch: d(rays)/d(o) = I on columns 0..2, d/d(d) = I on columns 3..5 plus the normalisation of the
-    viewdirs columns, (g_v - v (v . g_v)) / ||d||."""
+    """rows [o d near far (v/||v||)] (train_utils.py:143-168) with the gradient autograd gives the reference:
+    d(rays)/d(o) = I on columns 0..2, d/d(d) = I on columns 3..5, and the normalisation of the viewdirs columns,
+    (g_v - u (u . g_v)) / ||v|| with u = v/||v||, w.r.t. the direction v the reference normalises -- the ray direction itself
+    (blender branch) or the PRE-ndc direction (LLFF branch: `vsrc` is a different tensor from `rd` then)."""
 
     @staticmethod
-    def forward(ctx, ro, rd, near, far, use_view):
+    def forward(ctx, ro, rd, vsrc, near, far, use_view):
         n = rd.shape[0]
         rays = torch.empty((n, 11 if use_view else 8), dtype=torch.float32, device=rd.device)
-        with L.launch_on(ro, rd, rays) as st:
-            L.get_lib().pack_rays(ro.data_ptr(), rd.data_ptr(), rd.data_ptr() if use_view else None, near, far, n,
+        with L.launch_on(ro, rd, vsrc, rays) as st:
+            L.get_lib().pack_rays(ro.data_ptr(), rd.data_ptr(), vsrc.data_ptr() if use_view else None, near, far, n,
                                   rays.data_ptr(), st)
-        ctx.save_for_backward(rd)
+        ctx.save_for_backward(vsrc)
         ctx.use_view = use_view
         return rays
 
     @staticmethod
     def backward(ctx, g):
-        (rd,) = ctx.saved_tensors
-        g_ro, g_rd = g[:, 0:3].contiguous(), g[:, 3:6].clone()
+        (vsrc,) = ctx.saved_tensors
+        g_ro, g_rd, g_v = g[:, 0:3].contiguous(), g[:, 3:6].contiguous(), None
         if ctx.use_view:
-            nrm = rd.norm(p=2, dim=-1, keepdim=True)
-            v, gv = rd / nrm, g[:, 8:11]
-            g_rd = g_rd + (gv - v * (v * gv).sum(-1, keepdim=True)) / nrm
-        return g_ro, g_rd, None, None, None
+            nrm = vsrc.norm(p=2, dim=-1, keepdim=True)
+            u, gv = vsrc / nrm, g[:, 8:11]
+            g_v = (gv - u * (u * gv).sum(-1, keepdim=True)) / nrm
+        return g_ro, g_rd, g_v, None, None, None
 
 
 def pack_rays(ray_origins, ray_directions, options, height=None, width=None, focal_length=None):
     """The ray packing of run_one_iter_of_nerf (nerf/train_utils.py:143-168): rows [o d near far (d/||d||)].
-    Differentiable w.r.t. origins and directions for the blender (no-NDC) branch -- what pose optimisation needs."""
+    Differentiable w.r.t. origins and directions (both branches, ndc_rays included) -- what pose optimisation needs."""
     lib = L.get_lib()
     want_grad = torch.is_grad_enabled() and (ray_origins.requires_grad or ray_directions.requires_grad)
     use_view = bool(options.nerf.use_viewdirs)
     if want_grad:
-        if options.dataset.no_ndc is False:
-            raise RuntimeError("gradients w.r.t. the rays through ndc_rays are not implemented (no_ndc: False); detach() the rays")
         ro = ray_origins.reshape(-1, 3).contiguous().float()
-        rd = ray_directions.reshape(-1, 3).contiguous().float()
-        return _PackRays.apply(ro, rd, float(options.dataset.near), float(options.dataset.far), use_view)
+        rd_src = ray_directions.reshape(-1, 3).contiguous().float()
+        rd = rd_src
+        if options.dataset.no_ndc is False:  # (train_utils.py:156-160; viewdirs come from the pre-ndc directions: :146-150)
+            ro, rd = ndc_rays(height, width, focal_length, 1.0, ro, rd_src)
+        return _PackRays.apply(ro, rd, rd_src, float(options.dataset.near), float(options.dataset.far), use_view)
     rd_src = ray_directions.detach().reshape(-1, 3).contiguous().float()
     ro = ray_origins.detach().reshape(-1, 3).contiguous().float()
     rd = rd_src

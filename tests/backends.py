@@ -134,6 +134,16 @@ class Backend:
                           self.ptr(dro), self.ptr(drd), n, self.ptr(oo), self.ptr(od), self.stream())
         return self.host(oo), self.host(od)
 
+    def ndc_rays_bwd(self, H, W, focal, near, ro, rd, g_oo, g_od):
+        cw = np.float32(-1.0 / (W / (2.0 * focal)))
+        ch = np.float32(-1.0 / (H / (2.0 * focal)))
+        n = ro.shape[0]
+        d = [self.dev(np.ascontiguousarray(a, np.float32)) for a in (ro, rd, g_oo, g_od)]
+        g_ro, g_rd = self.empty((n, 3)), self.empty((n, 3))
+        self.lib.ndc_rays_bwd(float(near), float(cw), float(ch), float(np.float32(2.0 * near)), float(np.float32(-2.0 * near)),
+                              *[self.ptr(a) for a in d], n, self.ptr(g_ro), self.ptr(g_rd), self.stream())
+        return self.host(g_ro), self.host(g_rd)
+
     def pack_rays(self, ro, rd, near, far, viewdir_src=None):
         n = ro.shape[0]
         dro, drd, dv = self.dev(ro), self.dev(rd), self.devopt(viewdir_src)

@@ -248,6 +248,31 @@ def mlp_setup(b, cfg, seed):
     return plan, params, flat, packed
 
 
+def case_ndc_rays_bwd(b, n=300):
+    """nerfhip_ndc_rays_bwd against autograd through the oracle's ndc_rays (nerf/nerf_helpers.py:170-197), fp32 and fp64."""
+    gen = rng(77)
+    H, W, focal = 378, 504, 407.5
+    ro = (torch.tensor([0.1, -0.2, 0.3]).expand(n, 3) + 0.2 * torch.randn(n, 3, generator=gen)).contiguous()
+    rd = torch.randn(n, 3, generator=gen) * 0.4
+    rd[:, 2] = -1.0 - 0.3 * torch.rand(n, generator=gen)
+    g_oo, g_od = torch.randn(n, 3, generator=gen), torch.randn(n, 3, generator=gen)
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        o, d = ro.detach().clone().to(dt).requires_grad_(True), rd.detach().clone().to(dt).requires_grad_(True)
+        oo, od = O.ndc_rays(H, W, focal, 1.0, o, d)
+        ((oo * g_oo.to(dt)).sum() + (od * g_od.to(dt)).sum()).backward()
+        res[dt] = (o.grad.double().numpy(), d.grad.double().numpy())
+    got = b.ndc_rays_bwd(H, W, focal, 1.0, ro.numpy(), rd.numpy(), g_oo.numpy(), g_od.numpy())
+    for name, g, r32, r64 in zip(("g_rays_o", "g_rays_d"), got, res[torch.float32], res[torch.float64]):
+        scale = np.abs(r64).max(axis=1, keepdims=True) + 1e-30
+        e_hip, e_ref = float((np.abs(g - r64) / scale).max()), float((np.abs(r32 - r64) / scale).max())
+        note("ndc_rays_bwd_%s" % b.name, **{name + "_hip_vs_fp64": e_hip, name + "_oracle_fp32_vs_fp64": e_ref})
+        assert e_hip <= 4.0 * e_ref + 2e-6, (name, e_hip, e_ref)
+    # empty input
+    z = np.zeros((0, 3), np.float32)
+    assert b.ndc_rays_bwd(H, W, focal, 1.0, z, z, z, z)[0].shape == (0, 3)
+
+
 MLP_GEOMETRIES = {
     "default4x128": model_cfg(4, 128, 4, 10, 4),
     "deep8x128_skip4": model_cfg(8, 128, 4, 10, 4),

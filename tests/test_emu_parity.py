@@ -84,6 +84,10 @@ def test_mlp_512_wide_instances(emu):
     P.case_mlp_input_grad(emu, names=("wide3x512_skip2", "wide2x320"), m=45)
 
 
+def test_ndc_rays_backward(emu):
+    P.case_ndc_rays_bwd(emu, n=200)
+
+
 def test_mlp_extended_encodings(emu):
     """num_encoding_fn_xyz up to 16, num_encoding_fn_dir up to 10 (nerf/models.py:198-201 takes any): the extended slot
     registers of the forward kernel, every width."""

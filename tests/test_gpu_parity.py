@@ -85,6 +85,10 @@ def test_render_512_wide_vs_oracle(gpu):
                             grad_tol=(3.4e-3, 2e-2))
 
 
+def test_ndc_rays_backward(gpu):
+    P.case_ndc_rays_bwd(gpu, n=5000)
+
+
 def test_mlp_extended_encodings(gpu):
     """num_encoding_fn_xyz up to 16 / num_encoding_fn_dir up to 10: the extended slot registers, every kernel width."""
     P.case_mlp_forward(gpu, names=P.EXT_GEOMETRIES, m=1000)
@@ -432,10 +436,37 @@ def test_gradients_wrt_rays_through_the_fused_render_vs_oracle_autograd():
             assert (e_hip > 2e-3).sum() <= 2 * (e_yard > 2e-3).sum() + 3, what
         # the parameters got their gradients in the same backward
         assert all(p.grad is not None and float(p.grad.abs().max()) > 0 for p in mf.parameters())
-    # NDC rays: stated limit, loud
-    opts_ndc = N.make_options(nc, nf, no_ndc=False)
-    with pytest.raises(RuntimeError, match="ndc_rays are not implemented"):
-        N.run_one_iter_of_nerf(16, 16, 16.0, mc, mf, ro_g, rd_g, opts_ndc, encode_position_fn=ex, encode_direction_fn=ed)
+    # LLFF branch (no_ndc: False): the gradient flows through ndc_rays too (train_utils.py:156-160, nerf_helpers.py:170-197)
+    Hn, Wn, fn = 378, 504, 407.5
+    opts_ndc = N.make_options(nc, nf, perturb=False, radiance_field_noise_std=0.0, no_ndc=False, near=0.0, far=1.0)
+    g = torch.Generator().manual_seed(22)
+    ro = (torch.tensor([0.1, -0.2, 0.3]).expand(n, 3) + 0.1 * torch.randn(n, 3, generator=g)).contiguous()
+    rd = torch.randn(n, 3, generator=g) * 0.3
+    rd[:, 2] = -1.0
+    ro_g, rd_g = ro.to(dev).requires_grad_(True), rd.to(dev).requires_grad_(True)
+    out = N.run_one_iter_of_nerf(Hn, Wn, fn, mc, mf, ro_g, rd_g, opts_ndc, encode_position_fn=ex, encode_direction_fn=ed)
+    loss_of(out).backward()
+    ropt = dict(num_coarse=nc, num_fine=nf, perturb=False, lindisp=False, white_background=False, noise_std=0.0)
+    grads = {}
+    for dt in (torch.float32, torch.float64):
+        o_r, d_r = ro.to(dt).clone().requires_grad_(True), rd.to(dt).clone().requires_grad_(True)
+        no, nd = O.ndc_rays(Hn, Wn, fn, 1.0, o_r, d_r)
+        want = O.render_rays(O.pack_rays(no, nd, 0.0, 1.0, d_r), {k: v.to(dt) for k, v in par_c.items()},
+                             {k: v.to(dt) for k, v in par_f.items()}, cfg, cfg, ropt)
+        t = tgt.to(dt)
+        (((want["rgb_fine"] - t) ** 2).mean() + ((want["rgb_coarse"] - t) ** 2).mean() + 0.3 * (want["acc_fine"] ** 2).mean()
+         + 0.1 * torch.nan_to_num(want["disp_fine"]).mean() + 0.2 * (want["acc_coarse"] ** 2).mean()).backward()
+        grads[dt] = (o_r.grad.double().numpy(), d_r.grad.double().numpy())
+    for name, got, ref, r64 in (("ray_origins", ro_g.grad, grads[torch.float32][0], grads[torch.float64][0]),
+                                ("ray_directions", rd_g.grad, grads[torch.float32][1], grads[torch.float64][1])):
+        scale = float(np.abs(r64).max())
+        assert scale > 0 and got is not None
+        e_hip = np.abs(got.cpu().double().numpy() - ref).max(axis=1) / scale
+        e_yard = np.abs(ref - r64).max(axis=1) / scale
+        what = "ndc d loss / d %s: %s" % (name, dict(hip_median=float(np.median(e_hip)), yard_median=float(np.median(e_yard)),
+                                                   hip_over=int((e_hip > 2e-3).sum()), yard_over=int((e_yard > 2e-3).sum())))
+        assert np.median(e_hip) <= 3.0 * np.median(e_yard) + 2e-6, what
+        assert (e_hip > 2e-3).sum() <= 2 * (e_yard > 2e-3).sum() + 3, what
 
 
 def test_pretrained_lego_checkpoint_renders_like_the_reference():

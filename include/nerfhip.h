@@ -161,6 +161,18 @@ typedef struct nerfhip_plan* nerfhip_plan_t;
 
 /* Host-only.  Returns NULL (and sets the error string) for an unsupported geometry. */
 nerfhip_plan_t nerfhip_plan_create(const nerfhip_model_cfg* cfg);
+/* Arithmetic of the plan's FORWARD (inference) GEMMs.  FP32 (= nerfhip_plan_create): exact fp32 products on
+ * v_mfma_f32_16x16x4_f32 -- the path every parity claim and the headline benchmark refer to.  BF16X3: an INFERENCE-ONLY
+ * plan whose forward kernel multiplies on v_mfma_f32_32x32x16_bf16 with every operand split into two bf16 pieces,
+ * x.w ~ xh.wh + xh.wl + xl.wh with fp32 accumulation (the xl.wl term, ~2^-16 relative, is dropped): ~2^-16 relative error
+ * per product instead of fp32's 2^-24 -- NOT the reference's arithmetic, never selected implicitly.  Such a plan has its own
+ * packed image (nerfhip_plan_packed_floats / nerfhip_plan_pack_index / nerfhip_pack_weights_plan), serves
+ * nerfhip_mlp_fwd without a stash and the render entry points with training = 0, and every training / backward entry
+ * point refuses it.  Supported for kernel widths 128 and 256, num_encoding_fn_xyz <= 10, num_encoding_fn_dir <= 4. */
+#define NERFHIP_PRECISION_FP32 0
+#define NERFHIP_PRECISION_BF16X3 1
+nerfhip_plan_t nerfhip_plan_create_ex(const nerfhip_model_cfg* cfg, int precision);
+int nerfhip_plan_precision(nerfhip_plan_t plan);
 void nerfhip_plan_destroy(nerfhip_plan_t plan);
 /* Number of fp32 parameters of the model = length of the flat parameter/gradient vector, laid out as the
  * concatenation of the reference state_dict tensors in registration order (layer1.weight, layer1.bias,
@@ -180,6 +192,11 @@ int64_t nerfhip_plan_packed_floats(nerfhip_plan_t plan);
 int nerfhip_plan_pack_index(nerfhip_plan_t plan, int32_t* host_table);
 /* packed[i] = table[i] >= 0 ? params[table[i]] : 0   (run once per optimiser step). */
 int nerfhip_pack_weights(const float* params, const int32_t* table, int64_t n, float* packed, nerfhip_stream_t stream);
+/* The same for any plan: fp32 plans gather as above; BF16X3 plans write, per table entry, the bias word or the two bf16
+ * pieces hi = bf16(w), lo = bf16(w - hi) of the weight into the high / low blocks of the image.  table: dev
+ * int32[packed_floats] (nerfhip_plan_pack_index), packed: dev, packed_floats 32-bit words. */
+int nerfhip_pack_weights_plan(nerfhip_plan_t plan, const float* params, const int32_t* table, float* packed,
+                              nerfhip_stream_t stream);
 /* Bytes of activation stash a training forward over m sample points needs (0-filled is not required). */
 int64_t nerfhip_plan_stash_bytes(nerfhip_plan_t plan, int64_t m);
 /* Bytes of scratch nerfhip_mlp_bwd needs for m sample points. */

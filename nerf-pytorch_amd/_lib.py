@@ -64,6 +64,9 @@ _PROTOS = {
     "nerfhip_rng_fill": (C.c_int, [C.c_int, c_u64, c_u32, c_u64, c_i64, c_f, c_f]),
     "nerfhip_ray_bundle": (C.c_int, [C.c_int, C.c_int, C.c_float, c_f, C.c_int, c_f, c_i64, c_f, c_f, c_f]),
     "nerfhip_ndc_rays": (C.c_int, [C.c_float] * 5 + [c_f, c_f, c_i64, c_f, c_f, c_f]),
+    "nerfhip_plan_create_ex": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "nerfhip_plan_precision": (C.c_int, [C.c_void_p]),
+    "nerfhip_pack_weights_plan": (C.c_int, [C.c_void_p, c_f, c_f, c_f, c_f]),
     "nerfhip_ndc_rays_bwd": (C.c_int, [C.c_float] * 5 + [c_f, c_f, c_f, c_f, c_i64, c_f, c_f, c_f]),
     "nerfhip_pack_rays": (C.c_int, [c_f, c_f, c_f, C.c_float, C.c_float, c_i64, c_f, c_f]),
     "nerfhip_positional_encoding": (C.c_int, [c_f, c_i64, C.c_int, c_f, C.c_int, C.c_int, c_f, c_f]),
@@ -148,7 +151,7 @@ class NerfHipLib:
             fn.restype = res
             fn.argtypes = args
             if res is C.c_int and name not in ("nerfhip_version", "nerfhip_is_emulated", "nerfhip_plan_dim_xyz",
-                                              "nerfhip_plan_dim_dir", "nerfhip_plan_num_tensors"):
+                                              "nerfhip_plan_dim_dir", "nerfhip_plan_num_tensors", "nerfhip_plan_precision"):
                 setattr(self, name[len("nerfhip_"):], self._checked(fn, name))
             else:
                 setattr(self, name[len("nerfhip_"):], fn)

@@ -1,0 +1,370 @@
+// mlp_bf16.hip -- the split-bf16 ("bf16x3") INFERENCE forward of FlexibleNeRFModel (nerf/models.py:233-258) for plans created
+// with NERFHIP_PRECISION_BF16X3 (include/nerfhip.h).  Separate from, and never a substitute for, the fp32 kernels of
+// mlp16.hip: those multiply exactly in fp32 (157 TFLOP/s peak); this one multiplies on v_mfma_f32_32x32x16_bf16 (2.5 PFLOP/s
+// peak) with every operand split into two bf16 pieces and three MFMAs per product block,
+//     x . w  ~  xh.wh + xh.wl + xl.wh          (fp32 accumulation; the dropped xl.wl term is ~2^-16 relative),
+// so its own roofline is 2.5 PF / 3 fp32-equivalent FLOP/s and its products carry ~2^-16 instead of 2^-24 relative error.
+//
+// Shape (profiles/r03_split_bf16_mock.txt measured the loop before this kernel existed): a wave owns 32 samples; its
+// activations live in registers as the B operands of the next layer -- the accumulator registers c = 8*(kb&1) + e of output
+// tile kb>>1, converted to (hi, lo) pieces, ARE k-block kb of the next layer when the packed weights use the matching unit
+// permutation nhb_unit (nh_plan.h) -- so nothing but the weights moves through memory between layers.  Weights stream
+// L2 -> LDS by LDS-DMA in chunks of whole k-blocks, double buffered, one barrier per chunk; a layer's bias block rides in
+// front of its first chunk.  256-wide nets: 4-wave workgroups, one wave per SIMD (144 accumulator + 128 operand registers);
+// 128-wide nets: two such workgroups per CU.  No activation stash: inference only.
+#include "nh_device.h"
+#include "nh_mlp.h"
+
+namespace {
+
+template <int W>
+struct BShape {
+    static constexpr int TH = W / 32, KBH = W / 16, CHUNK = nhb_chunk_bytes(W), BUF = CHUNK + 2048, LDS_BYTES = 2 * BUF;
+    static constexpr int WAVES_PER_SIMD = W >= 256 ? 1 : 2;
+};
+
+struct BCtx {
+    char* lds;
+    unsigned lds_addr;
+    NhDmaSrc dma;
+    int buf, lane, wave, h;
+};
+
+// `bytes` (a multiple of 1 KiB) of the image, from byte offset `src`, into chunk buffer b at byte offset dst_off: one 1-KiB
+// piece per wave-instruction, pieces dealt round-robin to the four waves
+template <int BUF>
+NH_DEVICE void b_issue(const BCtx& cx, int64_t src, int bytes, int b, int dst_off) {
+    const int pieces = bytes >> 10;
+    for (int p = cx.wave; p < pieces; p += 4)
+        nh_dma16a(cx.dma, cx.lane * 16, (int)src + p * 1024, cx.lds_addr + (unsigned)(b * BUF + dst_off + p * 1024));
+}
+
+// acc[t] = bias + sum over NKA activation k-blocks (ah/al) and NKB encoding k-blocks (xh/xl) of this layer's image at byte
+// offset `base`; while the last chunk is multiplied the first chunk of the next layer (next_base, next_first bytes) travels.
+template <int W, int NT, int NKA, int NKB>
+NH_DEVICE void gemm_b(BCtx& cx, const nh_bf16x8* ah, const nh_bf16x8* al, const nh_bf16x8* xh, const nh_bf16x8* xl, int64_t base,
+                      int64_t next_base, int next_first, f32x16* acc) {
+    constexpr int NK = NKA + NKB, BUF = BShape<W>::BUF, CH = BShape<W>::CHUNK / (NT * 2048), NCH = (NK + CH - 1) / CH;
+    static_assert(CH >= 1, "a k-block of every tile must fit one chunk buffer");
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        nh_wait_vmem();    // this wave's pieces of the current chunk have landed ...
+        nh_block_sync();   // ... and everyone's; nobody still reads the other buffer
+        if (c + 1 < NCH) {
+            const int nkb = NK - (c + 1) * CH < CH ? NK - (c + 1) * CH : CH;
+            b_issue<BUF>(cx, base + 2048 + (int64_t)(c + 1) * CH * NT * 2048, nkb * NT * 2048, cx.buf ^ 1, 2048);
+        } else if (next_first > 0) {
+            b_issue<BUF>(cx, next_base, next_first, cx.buf ^ 1, 0);
+        }
+        const char* const buf = cx.lds + cx.buf * BUF;
+        if (c == 0) {  // the accumulators start at the bias of their rows: register 4 j + i of tile t holds row 32 t + 8 j + 4 h + i
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 b4 = *(const float4*)(buf + (32 * t + 8 * j + 4 * cx.h) * 4);
+                    acc[t][4 * j] = b4.x;
+                    acc[t][4 * j + 1] = b4.y;
+                    acc[t][4 * j + 2] = b4.z;
+                    acc[t][4 * j + 3] = b4.w;
+                }
+        }
+        const char* const wb = buf + 2048 + cx.lane * 16;
+#pragma unroll
+        for (int kk = 0; kk < CH; ++kk) {
+            const int kb = c * CH + kk;
+            if (kb < NK) {
+                const nh_bf16x8 bh = kb < NKA ? ah[kb < NKA ? kb : 0] : xh[kb >= NKA ? kb - NKA : 0];
+                const nh_bf16x8 bl = kb < NKA ? al[kb < NKA ? kb : 0] : xl[kb >= NKA ? kb - NKA : 0];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const nh_bf16x8 wh = *(const nh_bf16x8*)(wb + ((kk * NT + t) * 2) * 1024);
+                    const nh_bf16x8 wl = *(const nh_bf16x8*)(wb + ((kk * NT + t) * 2 + 1) * 1024);
+                    acc[t] = nh_mfma_bf16(wl, bh, acc[t]);  // (the small terms first)
+                    acc[t] = nh_mfma_bf16(wh, bl, acc[t]);
+                    acc[t] = nh_mfma_bf16(wh, bh, acc[t]);
+                }
+            }
+        }
+        cx.buf ^= 1;
+    }
+}
+
+// accumulators -> the next layer's operand pieces: hi = bf16(v), lo = bf16(v - hi)
+template <int NT, bool RELU>
+NH_DEVICE void to_operands(const f32x16* acc, nh_bf16x8* oh, nh_bf16x8* ol) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = acc[t][half * 8 + j];
+                if (RELU) v = nh_relu(v);
+                const nh_bf16 hi = nh_to_bf16(v);
+                oh[2 * t + half][j] = hi;
+                ol[2 * t + half][j] = nh_to_bf16(v - nh_from_bf16(hi));
+            }
+}
+
+NH_DEVICE void put_pair(nh_bf16x8& oh, nh_bf16x8& ol, int e, float v) {
+    const nh_bf16 hi = nh_to_bf16(v);
+    oh[e] = hi;
+    ol[e] = nh_to_bf16(v - nh_from_bf16(hi));
+}
+
+NH_DEVICE float bsel3(int a, float x, float y, float z) { return a == 0 ? x : (a == 1 ? y : z); }
+
+// the encoding slots of lane half h (plan.cpp build_slot_map_b): slot 16 kb + 8 h + e; pair slot >> 1 = 3 f + axis
+template <int NB>
+NH_DEVICE void encode_b(nh_bf16x8* oh, nh_bf16x8* ol, float x, float y, float z, int h, const float* freqs, int Lf) {
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int pr = 8 * kb + 4 * h + q;
+            const bool valid = pr < 3 * Lf;
+            const int f = pr / 3, ax = pr - 3 * f;
+            float s, c;
+            nh_sincos(bsel3(ax, x, y, z) * freqs[f < 16 ? f : 15], &s, &c);
+            float v0 = valid ? s : 0.0f, v1 = valid ? c : 0.0f;
+            if (kb == NB - 1 && q == 2 && h == 1) v0 = x, v1 = y;  // slots NS-4, NS-3 (never a valid pair: 6 L <= NS - 4)
+            if (kb == NB - 1 && q == 3 && h == 1) v0 = z, v1 = 0.0f;
+            put_pair(oh[kb], ol[kb], 2 * q, v0);
+            put_pair(oh[kb], ol[kb], 2 * q + 1, v1);
+        }
+}
+// the same slots gathered from a caller-encoded row (mode 0)
+template <int NB>
+NH_DEVICE void gather_b(nh_bf16x8* oh, nh_bf16x8* ol, const float* row, const signed char* col, int h) {
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = (int)col[16 * kb + 8 * h + e];
+            put_pair(oh[kb], ol[kb], e, c >= 0 ? row[c] : 0.0f);
+        }
+}
+
+struct FwdBArgs {
+    const float* packed;
+    unsigned packed_bytes;
+    NhPackedOffsets off;  // (32-bit word offsets)
+    int L, skip;
+    int64_t M;
+    int mode;
+    const float* x;
+    int dx, dd;
+    const float* rays;
+    int ray_stride;
+    const float* z;
+    int S;
+    signed char xcol[16 * NHB_XBLOCKS];
+    signed char dcol[16 * NHB_DBLOCKS];
+    float fx[16], fd[16];
+    int Lx, Ld;
+    float* out;
+};
+
+template <int W, bool VIEW>
+NH_KERNEL void NH_LB(256, BShape<W>::WAVES_PER_SIMD) k_mlp_fwd_bf16x3(FwdBArgs a) {
+    constexpr int TH = BShape<W>::TH, KBH = BShape<W>::KBH, BUF = BShape<W>::BUF, XB = NHB_XBLOCKS, DB = NHB_DBLOCKS;
+    NH_DYN_LDS(lds_raw);
+    BCtx cx;
+    cx.lds = lds_raw;
+    cx.lds_addr = nh_lds_addr((const float*)lds_raw);
+    cx.dma = nh_dma_src(a.packed, a.packed_bytes);
+    cx.buf = 0;
+    cx.lane = nh_lane();
+    cx.wave = nh_wave_in_block();
+    cx.h = cx.lane >> 5;
+    const int h = cx.h;
+    const int64_t m = (int64_t)blockIdx.x * 128 + cx.wave * 32 + (cx.lane & 31);
+    const bool valid = m < a.M;
+    const int64_t mc = valid ? m : a.M - 1;
+    const NhPackedOffsets& po = a.off;
+    auto first = [](int nk, int nt) { return nhb_first_bytes(nk, nt, W); };
+
+    // the first weights travel while the encodings are formed
+    b_issue<BUF>(cx, po.f_layer1 * 4, first(XB, TH), 0, 0);
+
+    nh_bf16x8 xh[XB], xl[XB];
+    const int ray_i = a.mode == 0 ? 0 : (int)(mc / a.S);
+    if (a.mode == 0) {
+        gather_b<XB>(xh, xl, a.x + (size_t)mc * (size_t)(a.dx + a.dd), a.xcol, h);
+    } else {
+        const float* const rr = a.rays + (size_t)ray_i * a.ray_stride;
+        const float zz = a.z[mc];
+        // pts = ro + rd * z   (nerf/train_utils.py:67,107)
+        encode_b<XB>(xh, xl, rr[0] + rr[3] * zz, rr[1] + rr[4] * zz, rr[2] + rr[5] * zz, h, a.fx, a.Lx);
+    }
+
+    f32x16 acc[TH + 1];
+    nh_bf16x8 hh[KBH], hl[KBH];
+    {
+        const bool more = a.L > 1;
+        // no activation after layer1 (models.py:238)
+        gemm_b<W, TH, 0, XB>(cx, nullptr, nullptr, xh, xl, po.f_layer1 * 4, (more ? po.f_xyz[0] : po.f_head) * 4,
+                             more ? first(KBH, TH) : (VIEW ? first(KBH, TH + 1) : first(KBH, 1)), acc);
+        to_operands<TH, false>(acc, hh, hl);
+    }
+    for (int i = 0; i < a.L - 1; ++i) {
+        const bool sk = (i % a.skip == 0) && i > 0;
+        const bool more = i + 1 < a.L - 1;
+        const bool nsk = more && ((i + 1) % a.skip == 0);
+        const int64_t nxt = (more ? po.f_xyz[i + 1] : po.f_head) * 4;
+        const int nfirst = more ? (nsk ? first(KBH + XB, TH) : first(KBH, TH)) : (VIEW ? first(KBH, TH + 1) : first(KBH, 1));
+        if (sk)
+            gemm_b<W, TH, KBH, XB>(cx, hh, hl, xh, xl, po.f_xyz[i] * 4, nxt, nfirst, acc);
+        else
+            gemm_b<W, TH, KBH, 0>(cx, hh, hl, nullptr, nullptr, po.f_xyz[i] * 4, nxt, nfirst, acc);
+        to_operands<TH, true>(acc, hh, hl);
+    }
+    if (VIEW) {
+        nh_bf16x8 dh[DB], dl[DB];
+        if (a.mode == 0) {
+            gather_b<DB>(dh, dl, a.x + (size_t)mc * (size_t)(a.dx + a.dd) + a.dx, a.dcol, h);
+        } else {
+            const float* const rr = a.rays + (size_t)ray_i * a.ray_stride;
+            encode_b<DB>(dh, dl, rr[8], rr[9], rr[10], h, a.fd, a.Ld);
+        }
+        // tiles 0..TH-1: feat = relu(fc_feat(h)); tile TH row 0: fc_alpha(h), raw (models.py:248-249)
+        gemm_b<W, TH + 1, KBH, 0>(cx, hh, hl, nullptr, nullptr, po.f_head * 4, po.f_dir * 4, first(KBH + DB, TH / 2), acc);
+        const float alpha = acc[TH][0];
+        to_operands<TH, true>(acc, hh, hl);
+        gemm_b<W, TH / 2, KBH, DB>(cx, hh, hl, dh, dl, po.f_dir * 4, po.f_rgb * 4, first(KBH / 2, 1), acc);
+        to_operands<TH / 2, true>(acc, hh, hl);
+        gemm_b<W, 1, KBH / 2, 0>(cx, hh, hl, nullptr, nullptr, po.f_rgb * 4, 0, 0, acc);
+        if (valid && h == 0) {
+            float4 r4;
+            r4.x = acc[0][0];
+            r4.y = acc[0][1];
+            r4.z = acc[0][2];
+            r4.w = alpha;
+            *(float4*)(a.out + (size_t)m * 4) = r4;
+        }
+    } else {
+        gemm_b<W, 1, KBH, 0>(cx, hh, hl, nullptr, nullptr, po.f_head * 4, 0, 0, acc);  // fc_out (models.py:256)
+        if (valid && h == 0) {
+            float4 r4;
+            r4.x = acc[0][0];
+            r4.y = acc[0][1];
+            r4.z = acc[0][2];
+            r4.w = acc[0][3];
+            *(float4*)(a.out + (size_t)m * 4) = r4;
+        }
+    }
+}
+
+// ---- weight image --------------------------------------------------------------------------------------------------
+struct PackBArgs {
+    int n_layers;
+    int64_t base[NH_MAX_LAYERS + 5];  // word offset of every layer image, ascending
+};
+
+NH_KERNEL void k_pack_bf16x3(const float* __restrict__ params, const int32_t* __restrict__ table, int64_t n, PackBArgs la,
+                             float* __restrict__ packed) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int l = 0;
+    while (l + 1 < la.n_layers && i >= la.base[l + 1]) ++l;
+    const int64_t r = i - la.base[l];
+    const int32_t s = table[i];
+    const float v = s >= 0 ? params[s] : 0.0f;
+    if (r < 512) {  // bias word
+        packed[i] = v;
+        return;
+    }
+    const int64_t w = r - 512, blk = w >> 9;  // (kb * nt + t), element lane * 8 + e inside it
+    const int q = (int)(w & 511);
+    nh_bf16* const img = (nh_bf16*)(packed + la.base[l] + 512);
+    const nh_bf16 hi = nh_to_bf16(v);
+    img[(2 * blk) * 512 + q] = hi;
+    img[(2 * blk + 1) * 512 + q] = nh_to_bf16(v - nh_from_bf16(hi));
+}
+
+template <class K>
+int b_lds_limit(K kern, int bytes) {
+#ifndef NERFHIP_EMU
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        nh_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d): %s", bytes, hipGetErrorString(e));
+        return NERFHIP_ERR_LAUNCH;
+    }
+#else
+    (void)kern;
+    (void)bytes;
+#endif
+    return NERFHIP_OK;
+}
+
+}  // namespace
+
+int nh_mlp_bf16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out,
+                        nerfhip_stream_t stream) {
+    NH_REQUIRE(M < ((int64_t)1 << 31), "mlp_fwd: at most 2^31 - 1 sample points per call (got %lld)", (long long)M);
+    FwdBArgs a;
+    memset(&a, 0, sizeof(a));
+    a.packed = packed;
+    a.packed_bytes = (unsigned)(p->packed_floats * 4);
+    a.off = p->po;
+    a.L = p->L;
+    a.skip = p->skip;
+    a.M = M;
+    a.mode = in.mode;
+    a.x = in.x;
+    a.dx = p->Dx;
+    a.dd = p->Dd;
+    a.rays = in.rays;
+    a.ray_stride = in.ray_stride;
+    a.z = in.z;
+    a.S = in.S;
+    for (int s = 0; s < 16 * NHB_XBLOCKS; ++s) a.xcol[s] = (signed char)p->xyz_slot_b[s];
+    for (int s = 0; s < 16 * NHB_DBLOCKS; ++s) a.dcol[s] = (signed char)p->dir_slot_b[s];
+    for (int k = 0; k < 16; ++k) {
+        a.fx[k] = p->freqs_xyz[k];
+        a.fd[k] = p->freqs_dir[k];
+    }
+    a.Lx = p->cfg.num_encoding_fn_xyz;
+    a.Ld = p->view ? p->cfg.num_encoding_fn_dir : 0;
+    a.out = out;
+    const int64_t groups = nh_ceil_div(M, 128);
+    int rc = NERFHIP_OK;
+#define NH_FWDB(WW, VV)                                                                                    \
+    {                                                                                                      \
+        rc = b_lds_limit(k_mlp_fwd_bf16x3<WW, VV>, BShape<WW>::LDS_BYTES);                                 \
+        if (rc) return rc;                                                                                 \
+        NH_LAUNCH((k_mlp_fwd_bf16x3<WW, VV>), groups, 256, BShape<WW>::LDS_BYTES, stream, a);             \
+    }
+    if (p->W == 256 && p->view) NH_FWDB(256, true)
+    else if (p->W == 256) NH_FWDB(256, false)
+    else if (p->W == 128 && p->view) NH_FWDB(128, true)
+    else if (p->W == 128) NH_FWDB(128, false)
+    else {
+        nh_set_error("mlp_fwd: no bf16x3 kernel for kernel width %d", p->W);
+        return NERFHIP_ERR_UNSUPPORTED;
+    }
+#undef NH_FWDB
+    return nh_launch_status("mlp_fwd_bf16x3");
+}
+
+extern "C" int nerfhip_pack_weights_plan(nerfhip_plan_t plan, const float* params, const int32_t* table, float* packed,
+                                         nerfhip_stream_t stream) {
+    NH_REQUIRE(plan && params && table && packed, "pack_weights_plan: bad arguments");
+    const int64_t n = plan->packed_floats;
+    if (plan->precision != NERFHIP_PRECISION_BF16X3) return nerfhip_pack_weights(params, table, n, packed, stream);
+    PackBArgs la;
+    memset(&la, 0, sizeof(la));
+    const NhPackedOffsets& o = plan->po;
+    int k = 0;
+    la.base[k++] = o.f_layer1;
+    for (int i = 0; i < plan->L - 1; ++i) la.base[k++] = o.f_xyz[i];
+    la.base[k++] = o.f_head;
+    if (plan->view) {
+        la.base[k++] = o.f_dir;
+        la.base[k++] = o.f_rgb;
+    }
+    la.n_layers = k;
+    NH_LAUNCH(k_pack_bf16x3, nh_ceil_div(n, 256), 256, 0, stream, params, table, n, la, packed);
+    return nh_launch_status("pack_weights_plan");
+}

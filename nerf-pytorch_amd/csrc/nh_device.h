@@ -51,6 +51,17 @@ NH_DEVICE f32x16 nh_mfma32(float a, float b, f32x16 c) {
 // D[4*(l>>4) + c][l&15].  32 cycles per instruction, 40 cycles dependent latency.
 NH_DEVICE f32x4 nh_mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
+// bf16 pieces of the split-precision inference kernel (mlp_bf16.hip).  nh_to_bf16: round-to-nearest-even
+// (v_cvt_pk_bf16_f32).  nh_mfma_bf16: D = A(32x16) * B(16x32) + C on v_mfma_f32_32x32x16_bf16, fp32 accumulation; lane l
+// supplies A[l&31][8*(l>>5) + e] and B[8*(l>>5) + e][l&31], e = 0..7; D registers as for nh_mfma32.
+typedef __bf16 nh_bf16;
+typedef __bf16 nh_bf16x8 __attribute__((ext_vector_type(8)));
+NH_DEVICE nh_bf16 nh_to_bf16(float v) { return (nh_bf16)v; }
+NH_DEVICE float nh_from_bf16(nh_bf16 h) { return (float)h; }
+NH_DEVICE f32x16 nh_mfma_bf16(nh_bf16x8 a, nh_bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 NH_DEVICE void nh_atomic_add(float* p, float v) { atomicAdd(p, v); }
 // Asynchronous global -> LDS copy of 16 bytes per lane (global_load_lds_dwordx4): lane l's 16 bytes at `g` land at
 // lds_wave_base + 16*l (the LDS destination is wave-uniform base + lane*16).  Completion: nh_wait_vmem() + barrier.

@@ -41,6 +41,24 @@ static inline int64_t nh16_image_floats(int kr, int tiles, int W) { return nh16_
 // 32-bit words of ReLU bits per lane and layer: one bit per activation register (W / 4 of them), at least two words
 constexpr int nh16_mask_words(int W) { return W >= 512 ? 4 : 2; }
 
+// ---- split-bf16 inference images (mlp_bf16.hip; plans created with NERFHIP_PRECISION_BF16X3) -----------------------------
+// A layer image = 512 fp32 bias words (one per output row, 32 per tile) + per (k-block kb, 32-row tile t): a 1-KiB block
+// of bf16 HIGH pieces and a 1-KiB block of bf16 LOW pieces, lane l of a block holding the 8 elements
+// W[32 t + (l & 31)][in(kb, l >> 5, e)], e = 0..7.  Hidden inputs: in = nhb_unit(kb, h, e) -- the unit that accumulator
+// register 8*(kb & 1) + e of output tile kb >> 1 holds for lane half h, so a layer's converted accumulators ARE the next
+// layer's B operands.  Encoding inputs: slot 16 kb + 8 h + e (sin / cos of pair slot >> 1 = 3 f + axis in slots 2p, 2p+1;
+// the raw coordinates in slots NS-4 .. NS-2).  Every weight element gives two bf16 pieces = one 32-bit word of image, so an
+// image has 512 + nk * nt * 512 words -- which is also the length of its gather table (nerfhip_plan_pack_index: one source
+// index per bias word, then one per weight element in (kb, t, lane, e) order).
+static inline int nhb_unit(int kb, int h, int e) { return 32 * (kb >> 1) + 16 * (kb & 1) + 8 * (e >> 2) + 4 * h + (e & 3); }
+static inline int64_t nhb_image_words(int nk, int nt) { return 512 + (int64_t)nk * nt * 512; }
+constexpr int NHB_XBLOCKS = 4, NHB_DBLOCKS = 2;  // k-blocks of the xyz (64 slots) / direction (32 slots) encodings
+constexpr int nhb_chunk_bytes(int W) { return W >= 256 ? 65536 : 32768; }  // weight blocks per LDS chunk buffer
+// bytes of a layer's first chunk: its bias block + as many whole k-blocks as fit
+constexpr int nhb_first_bytes(int nk, int nt, int W) {
+    return 2048 + (nk < nhb_chunk_bytes(W) / (nt * 2048) ? nk : nhb_chunk_bytes(W) / (nt * 2048)) * nt * 2048;
+}
+
 struct NhTensor {
     std::string name;
     int64_t off;
@@ -114,6 +132,9 @@ struct nerfhip_plan {
     int64_t nparams;
     int t_layer1_w, t_layer1_b, t_xyz_w[NH_MAX_LAYERS], t_xyz_b[NH_MAX_LAYERS];
     int t_dir_w, t_dir_b, t_alpha_w, t_alpha_b, t_rgb_w, t_rgb_b, t_feat_w, t_feat_b, t_out_w, t_out_b;
+    int precision;                    // NERFHIP_PRECISION_FP32 | NERFHIP_PRECISION_BF16X3 (inference-only plan: mlp_bf16.hip)
+    int xyz_slot_b[16 * NHB_XBLOCKS];  // bf16x3 plans: encoding slot -> reference column, or -1
+    int dir_slot_b[16 * NHB_DBLOCKS];
     int krx, krd;                     // encoding registers per lane group: NH16_KRX / NH16_KRD or the _EXT pair
     int xyz_col16[4][NH16_KRX_EXT];  // slot (r,g) -> reference column of the xyz encoding, or -1  (rows of krx entries)
     int dir_col16[4][NH16_KRD_EXT];

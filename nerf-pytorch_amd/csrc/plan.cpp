@@ -210,6 +210,144 @@ void layout_packed(nerfhip_plan* p) {
     p->packed_floats = off;
 }
 
+// ---- split-bf16 inference images (nh_plan.h "split-bf16 inference images", mlp_bf16.hip) -------------------------------
+struct GemmSpecB {
+    int nk = 0, nt = 0;                            // k-blocks of 16 inputs, 32-row output tiles
+    std::function<int64_t(int, int, int, int)> w;  // (out_row, kb, h, e) -> flat param index or -1
+    std::function<int64_t(int)> b;                 // out_row -> flat param index or -1
+};
+struct SpecsB {
+    GemmSpecB f_layer1, f_xyz[NH_MAX_LAYERS], f_head, f_dir, f_rgb;
+};
+
+// encoding slot -> reference column (nerf/nerf_helpers.py:130-157: [x], then per frequency sin(3), cos(3))
+bool build_slot_map_b(int L, int include_input, int nslots, int* col) {
+    if (6 * L > nslots - 4) return false;
+    for (int s = 0; s < nslots; ++s) col[s] = -1;
+    const int base = include_input ? 3 : 0;
+    for (int pr = 0; pr < 3 * L; ++pr) {
+        col[2 * pr] = base + 6 * (pr / 3) + pr % 3;
+        col[2 * pr + 1] = base + 6 * (pr / 3) + 3 + pr % 3;
+    }
+    if (include_input)
+        for (int a = 0; a < 3; ++a) col[nslots - 4 + a] = a;
+    return true;
+}
+
+void build_specs_b(const nerfhip_plan* p, SpecsB& S) {
+    const int W = p->W, H = p->H, H2 = H / 2, KBH = W / 16, TH = W / 32, Dx = p->Dx, Dd = p->Dd, L = p->L;
+    auto T = [p](int idx) { return p->tensors[idx]; };
+    auto xcol = [p](int kb, int h, int e) { return p->xyz_slot_b[16 * kb + 8 * h + e]; };
+    auto dcol = [p](int kb, int h, int e) { return p->dir_slot_b[16 * kb + 8 * h + e]; };
+    {
+        GemmSpecB& s = S.f_layer1;
+        s.nk = NHB_XBLOCKS;
+        s.nt = TH;
+        NhTensor w = T(p->t_layer1_w), b = T(p->t_layer1_b);
+        s.w = [=](int o, int kb, int h, int e) -> int64_t {
+            const int c = xcol(kb, h, e);
+            return (o < H && c >= 0) ? w.off + (int64_t)o * Dx + c : -1;
+        };
+        s.b = [=](int o) -> int64_t { return o < H ? b.off + o : -1; };
+    }
+    for (int i = 0; i < L - 1; ++i) {
+        GemmSpecB& s = S.f_xyz[i];
+        const bool sk = p->is_skip(i);
+        s.nk = KBH + (sk ? NHB_XBLOCKS : 0);
+        s.nt = TH;
+        NhTensor w = T(p->t_xyz_w[i]), b = T(p->t_xyz_b[i]);
+        const int ld = H + (sk ? Dx : 0);
+        s.w = [=](int o, int kb, int h, int e) -> int64_t {
+            if (o >= H) return -1;
+            if (kb < KBH) return nhb_unit(kb, h, e) < H ? w.off + (int64_t)o * ld + nhb_unit(kb, h, e) : -1;
+            const int c = xcol(kb - KBH, h, e);
+            return c >= 0 ? w.off + (int64_t)o * ld + H + c : -1;
+        };
+        s.b = [=](int o) -> int64_t { return o < H ? b.off + o : -1; };
+    }
+    if (p->view) {
+        NhTensor fw = T(p->t_feat_w), fb = T(p->t_feat_b), aw = T(p->t_alpha_w), ab = T(p->t_alpha_b);
+        NhTensor dw = T(p->t_dir_w), db = T(p->t_dir_b), rw = T(p->t_rgb_w), rb = T(p->t_rgb_b);
+        {
+            GemmSpecB& s = S.f_head;  // rows 0..W-1 = fc_feat, row W = fc_alpha (models.py:248-249)
+            s.nk = KBH;
+            s.nt = TH + 1;
+            s.w = [=](int o, int kb, int h, int e) -> int64_t {
+                const int f = nhb_unit(kb, h, e);
+                if (f >= H) return -1;
+                if (o < H) return fw.off + (int64_t)o * H + f;
+                if (o == W) return aw.off + f;
+                return -1;
+            };
+            s.b = [=](int o) -> int64_t { return o < H ? fb.off + o : (o == W ? ab.off : -1); };
+        }
+        {
+            GemmSpecB& s = S.f_dir;
+            s.nk = KBH + NHB_DBLOCKS;
+            s.nt = TH / 2;
+            const int ld = H + Dd;
+            s.w = [=](int o, int kb, int h, int e) -> int64_t {
+                if (o >= H2) return -1;
+                if (kb < KBH) return nhb_unit(kb, h, e) < H ? dw.off + (int64_t)o * ld + nhb_unit(kb, h, e) : -1;
+                const int c = dcol(kb - KBH, h, e);
+                return c >= 0 ? dw.off + (int64_t)o * ld + H + c : -1;
+            };
+            s.b = [=](int o) -> int64_t { return o < H2 ? db.off + o : -1; };
+        }
+        {
+            GemmSpecB& s = S.f_rgb;
+            s.nk = KBH / 2;
+            s.nt = 1;
+            s.w = [=](int o, int kb, int h, int e) -> int64_t {
+                return (o < 3 && nhb_unit(kb, h, e) < H2) ? rw.off + (int64_t)o * H2 + nhb_unit(kb, h, e) : -1;
+            };
+            s.b = [=](int o) -> int64_t { return o < 3 ? rb.off + o : -1; };
+        }
+    } else {
+        NhTensor ow = T(p->t_out_w), ob = T(p->t_out_b);
+        GemmSpecB& s = S.f_head;  // fc_out
+        s.nk = KBH;
+        s.nt = 1;
+        s.w = [=](int o, int kb, int h, int e) -> int64_t {
+            return (o < 4 && nhb_unit(kb, h, e) < H) ? ow.off + (int64_t)o * H + nhb_unit(kb, h, e) : -1;
+        };
+        s.b = [=](int o) -> int64_t { return o < 4 ? ob.off + o : -1; };
+    }
+}
+
+template <class Fn>
+void for_each_spec_b(const nerfhip_plan* p, SpecsB& S, NhPackedOffsets& o, Fn fn) {
+    fn(S.f_layer1, &o.f_layer1);
+    for (int i = 0; i < p->L - 1; ++i) fn(S.f_xyz[i], &o.f_xyz[i]);
+    fn(S.f_head, &o.f_head);
+    if (p->view) {
+        fn(S.f_dir, &o.f_dir);
+        fn(S.f_rgb, &o.f_rgb);
+    }
+}
+
+void fill_spec_b(const GemmSpecB& s, int64_t off, int32_t* table) {
+    for (int i = 0; i < 512; ++i) table[off + i] = (i < 32 * s.nt && s.b) ? (int32_t)s.b(i) : -1;
+    int32_t* img = table + off + 512;
+    for (int kb = 0; kb < s.nk; ++kb)
+        for (int t = 0; t < s.nt; ++t)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e)
+                    img[(((int64_t)kb * s.nt + t) * 64 + lane) * 8 + e] = (int32_t)s.w(32 * t + (lane & 31), kb, lane >> 5, e);
+}
+
+void layout_packed_b(nerfhip_plan* p) {
+    int64_t off = 0;
+    memset(&p->po, 0, sizeof(p->po));
+    SpecsB S;
+    build_specs_b(p, S);
+    for_each_spec_b(p, S, p->po, [&](const GemmSpecB& s, int64_t* dst) {
+        *dst = off;
+        off += nhb_image_words(s.nk, s.nt);
+    });
+    p->packed_floats = off;
+}
+
 NhRegion add_region(int64_t* total, int rows) {
     NhRegion r;
     r.rows = rows > 256 ? 256 : rows;  // a 512-row activation: two consecutive 256-row regions, named by the first
@@ -411,7 +549,18 @@ void build_layouts_and_jobs(nerfhip_plan* p) {
 
 }  // namespace
 
-extern "C" nerfhip_plan_t nerfhip_plan_create(const nerfhip_model_cfg* cfg) {
+static nerfhip_plan_t plan_create_impl(const nerfhip_model_cfg* cfg, int precision);
+extern "C" nerfhip_plan_t nerfhip_plan_create(const nerfhip_model_cfg* cfg) { return plan_create_impl(cfg, NERFHIP_PRECISION_FP32); }
+extern "C" nerfhip_plan_t nerfhip_plan_create_ex(const nerfhip_model_cfg* cfg, int precision) {
+    if (precision != NERFHIP_PRECISION_FP32 && precision != NERFHIP_PRECISION_BF16X3) {
+        nh_set_error("plan_create_ex: unknown precision %d", precision);
+        return nullptr;
+    }
+    return plan_create_impl(cfg, precision);
+}
+extern "C" int nerfhip_plan_precision(nerfhip_plan_t plan) { return plan ? plan->precision : -1; }
+
+static nerfhip_plan_t plan_create_impl(const nerfhip_model_cfg* cfg, int precision) {
     if (!cfg) {
         nh_set_error("plan_create: cfg is NULL");
         return nullptr;
@@ -436,6 +585,7 @@ extern "C" nerfhip_plan_t nerfhip_plan_create(const nerfhip_model_cfg* cfg) {
     }
     nerfhip_plan* p = new nerfhip_plan();
     p->cfg = *cfg;
+    p->precision = precision;
     p->H = cfg->hidden_size;
     // the kernels exist for four widths; a model rides zero-padded on the next one (build_specs16)
     p->W = p->H <= 64 ? 64 : (p->H <= 128 ? 128 : (p->H <= 256 ? 256 : 512));
@@ -499,7 +649,22 @@ extern "C" nerfhip_plan_t nerfhip_plan_create(const nerfhip_model_cfg* cfg) {
         p->freqs_xyz[k] = 0.f;
         p->freqs_dir[k] = 0.f;
     }
-    layout_packed(p);
+    if (precision == NERFHIP_PRECISION_BF16X3) {
+        // inference-only plan: the split-bf16 forward kernel exists for the 128- and 256-wide nets with the reference's own
+        // encoding sizes; everything else is the fp32 path's business
+        const bool okx = build_slot_map_b(cfg->num_encoding_fn_xyz, cfg->include_input_xyz ? 1 : 0, 16 * NHB_XBLOCKS, p->xyz_slot_b);
+        const bool okd = build_slot_map_b(p->view ? cfg->num_encoding_fn_dir : 0, (p->view && cfg->include_input_dir) ? 1 : 0,
+                                          16 * NHB_DBLOCKS, p->dir_slot_b);
+        if (!(okx && okd) || (p->W != 128 && p->W != 256)) {
+            nh_set_error("plan_create_ex: bf16x3 plans need hidden_size in (64, 256], num_encoding_fn_xyz <= 10 and "
+                         "num_encoding_fn_dir <= 4 (got %d, %d, %d)", cfg->hidden_size, cfg->num_encoding_fn_xyz, cfg->num_encoding_fn_dir);
+            delete p;
+            return nullptr;
+        }
+        layout_packed_b(p);
+    } else {
+        layout_packed(p);
+    }
     build_layouts_and_jobs(p);
     if ((int)p->jobs.size() > NH_MAX_JOBS) {
         nh_set_error("plan_create: too many gradient jobs");
@@ -534,8 +699,8 @@ extern "C" int nerfhip_plan_describe(nerfhip_plan_t plan, char* buf, int64_t cap
         const int w = snprintf(buf + used, (size_t)(cap - used), fmt, v...);
         if (w > 0) used += w < cap - used ? w : cap - used - 1;
     };
-    put("kernel_width %d hidden_size %d layers %d params %lld packed_floats %lld wgrad_waves %d jobs %d\n", plan->W, plan->H, plan->L,
-        (long long)plan->nparams, (long long)plan->packed_floats, plan->wgrad_waves, (int)plan->jobs.size());
+    put("kernel_width %d hidden_size %d layers %d params %lld packed_floats %lld wgrad_waves %d jobs %d precision %d\n", plan->W, plan->H,
+        plan->L, (long long)plan->nparams, (long long)plan->packed_floats, plan->wgrad_waves, (int)plan->jobs.size(), plan->precision);
     for (size_t q = 0; q < plan->jobs.size(); ++q) {
         const NhJob& j = plan->jobs[q];
         put("job %d tiles %dx%d waves %dx%d patch %dx%d cost %d side %d side_tiles %d\n", (int)q, j.a_tiles, j.b_tiles, j.wo, j.wi, j.po,
@@ -546,6 +711,13 @@ extern "C" int nerfhip_plan_describe(nerfhip_plan_t plan, char* buf, int64_t cap
 
 extern "C" int nerfhip_plan_pack_index(nerfhip_plan_t plan, int32_t* host_table) {
     NH_REQUIRE(plan && host_table, "plan_pack_index: bad arguments");
+    if (plan->precision == NERFHIP_PRECISION_BF16X3) {
+        SpecsB S;
+        build_specs_b(plan, S);
+        NhPackedOffsets o = plan->po;
+        for_each_spec_b(plan, S, o, [&](const GemmSpecB& s, int64_t* dst) { fill_spec_b(s, *dst, host_table); });
+        return NERFHIP_OK;
+    }
     Specs16 S16;
     build_specs16(plan, S16);
     NhPackedOffsets o = plan->po;

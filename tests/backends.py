@@ -220,10 +220,10 @@ class Backend:
         return torch.linspace(0.0, 1.0, n).numpy()
 
     # -- MLP ------------------------------------------------------------------------------------------------------------
-    def make_plan(self, cfg):
+    def make_plan(self, cfg, precision=0):
         import torch
         mc = L.ModelCfg(**{k: int(v) for k, v in cfg.items()})
-        plan = self.lib.plan_create(C.byref(mc))
+        plan = self.lib.plan_create_ex(C.byref(mc), int(precision)) if precision else self.lib.plan_create(C.byref(mc))
         if not plan:
             raise L.NerfHipError(self.lib.last_error().decode())
         import nerf_oracle as O
@@ -264,7 +264,10 @@ class Backend:
         self.lib.plan_pack_index(plan, table.ctypes.data)
         dt, dp = self.dev(table), self.dev(flat)
         packed = self.empty((n,))
-        self.lib.pack_weights(self.ptr(dp), self.ptr(dt), n, self.ptr(packed), self.stream())
+        if self.lib.plan_precision(plan) != 0:  # (fp32 plans keep exercising the plan-independent entry point)
+            self.lib.pack_weights_plan(plan, self.ptr(dp), self.ptr(dt), self.ptr(packed), self.stream())
+        else:
+            self.lib.pack_weights(self.ptr(dp), self.ptr(dt), n, self.ptr(packed), self.stream())
         return packed  # device array
 
     def mlp_fwd(self, plan, packed, x, want_stash=False):

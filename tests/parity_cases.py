@@ -13,9 +13,11 @@ import os
 import subprocess
 
 import numpy as np
+import pytest
 import torch
 
 import nerf_oracle as O
+import nerf_pytorch_amd._lib as L
 from backends import ROOT, model_cfg
 from conftest import gold
 
@@ -240,8 +242,8 @@ def case_sample_pdf(b):
 
 
 # ---- MLP ---------------------------------------------------------------------------------------------------------------
-def mlp_setup(b, cfg, seed):
-    plan = b.make_plan(cfg)
+def mlp_setup(b, cfg, seed, precision=0):
+    plan = b.make_plan(cfg, precision)
     params = O.init_params(cfg, seed=seed)
     flat = b.flatten_params(plan, {k: v.numpy() for k, v in params.items()})
     packed = b.pack(plan, flat)
@@ -324,6 +326,40 @@ def case_mlp_forward(b, names=None, m=70):
         got, _ = b.mlp_fwd(plan, packed, x.numpy())
         close(got, want, 2e-5, 2e-5, what="mlp fwd " + name)
         b.lib.plan_destroy(plan)
+
+
+BF16X3 = 1  # NERFHIP_PRECISION_BF16X3
+BF16X3_GEOMETRIES = ("default4x128", "northstar8x256", "fern8x128_skip3_L6", "novw4x128", "two_layer_L4_L2", "one_layer",
+                     "one_layer_novw_256", "skip_every_layer_256", "noinput_linear", "odd5x99_skip2", "wide3x200_skip1",
+                     "novw2x130")
+
+
+def case_mlp_forward_bf16x3(b, names=None, m=70):
+    """The split-bf16 inference forward (mlp_bf16.hip) against the oracle's fp32 forward.  Its products carry ~2^-16
+    relative error by construction (three of the four piece products, fp32 accumulation), so the bound is relative to the
+    output scale and ~50x the fp32 kernels'; what the case pins is the index algebra -- unit permutation, slot map, chunking,
+    bias rows, skip / head / direction layers -- where any slip is an O(1) error."""
+    for name in names or BF16X3_GEOMETRIES:
+        cfg = MLP_GEOMETRIES[name]
+        plan, params, flat, packed = mlp_setup(b, cfg, seed=31, precision=BF16X3)
+        dx, dd = O.model_dims(cfg)
+        x = torch.randn(m, dx + dd, generator=rng(32))
+        want = O.mlp_forward(params, x, cfg).numpy()
+        want64 = O.mlp_forward({k: v.double() for k, v in params.items()}, x.double(), cfg).numpy()
+        got, _ = b.mlp_fwd(plan, packed, x.numpy())
+        scale = float(np.abs(want64).max())
+        err = float(np.abs(got - want64).max()) / scale
+        note("mlp_fwd_bf16x3_%s_%s" % (name, b.name), max_err_over_scale=err,
+             fp32_oracle_err_over_scale=float(np.abs(want - want64).max()) / scale)
+        assert err < 5e-5, (name, err)
+        # a training forward (stash) and a backward are refused
+        with pytest.raises(L.NerfHipError, match="inference-only"):
+            b.mlp_fwd(plan, packed, x.numpy(), want_stash=True)
+        b.lib.plan_destroy(plan)
+    with pytest.raises(L.NerfHipError, match="bf16x3 plans need"):
+        b.make_plan(MLP_GEOMETRIES["llff4x64_skip3_L6"], BF16X3)
+    with pytest.raises(L.NerfHipError, match="bf16x3 plans need"):
+        b.make_plan(MLP_GEOMETRIES["L12_4x128"], BF16X3)
 
 
 def case_mlp_golden(b):
@@ -505,6 +541,44 @@ def case_render_vs_oracle(b, cfg, n, nc, nf, seed=5, white=False, noise=0.3, wit
                 grad_close(v, par[k].grad.numpy(), gt, "grad %s %s" % (key, k), "render_vs_oracle_%s_%s" % (tag or n, b.name), key)
     b.lib.plan_destroy(pc)
     b.lib.plan_destroy(pf)
+
+
+def case_render_bf16x3(b, cfg, n, nc, nf, seed=5, white=False, noise=0.0, tag=""):
+    """Inference render (training = 0) with both nets on NERFHIP_PRECISION_BF16X3 plans against the oracle, beside the fp32
+    plans' result on the same inputs: what the split-bf16 products cost against the 1e-4 bar (recorded per output)."""
+    gen = rng(seed)
+    ro = torch.tensor([0.2, -0.1, 4.0]).expand(n, 3) + 0.05 * torch.randn(n, 3, generator=gen)
+    rd = torch.randn(n, 3, generator=gen) * 0.3
+    rd[:, 2] = -1.0
+    rays = O.pack_rays(ro, rd, 2.0, 6.0, rd if cfg["use_viewdirs"] else None)
+    rand = dict(t_rand=torch.rand(n, nc, generator=gen), noise_coarse=torch.randn(n, nc, generator=gen),
+                u=torch.rand(n, nf, generator=gen), noise_fine=torch.randn(n, nc + nf, generator=gen))
+    opt = dict(num_coarse=nc, num_fine=nf, perturb=True, lindisp=False, white_background=white, noise_std=noise)
+    rnp = {k: v.numpy() for k, v in rand.items()}
+    outs = {}
+    for prec in (0, BF16X3):
+        pc, par_c, _, packed_c = mlp_setup(b, cfg, seed=seed + 1, precision=prec)
+        pf, par_f, _, packed_f = mlp_setup(b, cfg, seed=seed + 2, precision=prec)
+        outs[prec] = b.render(pc, pf, packed_c, packed_f, rays.numpy(), opt, rnp, training=False)
+        if prec:  # a training render is refused
+            with pytest.raises(L.NerfHipError, match="inference-only"):
+                b.render(pc, pf, packed_c, packed_f, rays.numpy(), opt, rnp, training=True)
+        b.lib.plan_destroy(pc)
+        b.lib.plan_destroy(pf)
+    want = O.render_rays(rays, par_c, par_f, cfg, cfg, opt, rand)
+    rec = {}
+    for k in ("rgb_coarse", "acc_coarse", "rgb_fine", "acc_fine", "depth_fine"):
+        w = want[k].detach().numpy()
+        for prec, nm in ((0, "fp32"), (BF16X3, "bf16x3")):
+            e = np.abs(outs[prec][k] - w).reshape(n, -1).max(axis=1)
+            rec["%s_%s_max" % (k, nm)] = float(e.max())
+            rec["%s_%s_rays_over_1e-4" % (k, nm)] = int((e > 1e-4).sum())
+    note("render_bf16x3_%s_%s" % (tag or n, b.name), rays=n, **rec)
+    # coarse pass: only the products differ -- well inside the bar; fine pass: the sampler amplifies the coarse weights'
+    # differences for BOTH arithmetic variants, the split-bf16 one starts from ~30x larger ones
+    assert rec["rgb_coarse_bf16x3_max"] <= 1e-4 and rec["acc_coarse_bf16x3_max"] <= 1e-4, rec
+    assert rec["rgb_fine_bf16x3_max"] <= 2e-3, rec
+    assert rec["rgb_fine_bf16x3_rays_over_1e-4"] <= max(2, n // 20), rec
 
 
 def case_ray_grad(b, cfg, n=24, nc=16, nf=16, seed=61, white=False, noise=0.0):

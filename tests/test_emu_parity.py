@@ -84,6 +84,12 @@ def test_mlp_512_wide_instances(emu):
     P.case_mlp_input_grad(emu, names=("wide3x512_skip2", "wide2x320"), m=45)
 
 
+def test_mlp_forward_bf16x3(emu):
+    """NERFHIP_PRECISION_BF16X3 plans: the split-bf16 inference forward, both kernel widths, every layer kind."""
+    P.case_mlp_forward_bf16x3(emu, m=37)
+    P.case_render_bf16x3(emu, P.MLP_GEOMETRIES["default4x128"], n=10, nc=8, nf=8, tag="4x128_emu")
+
+
 def test_ndc_rays_backward(emu):
     P.case_ndc_rays_bwd(emu, n=200)
 

@@ -85,6 +85,12 @@ def test_render_512_wide_vs_oracle(gpu):
                             grad_tol=(3.4e-3, 2e-2))
 
 
+def test_mlp_forward_bf16x3(gpu):
+    P.case_mlp_forward_bf16x3(gpu, m=3000)
+    P.case_render_bf16x3(gpu, P.MLP_GEOMETRIES["default4x128"], n=300, nc=64, nf=64, tag="4x128_300")
+    P.case_render_bf16x3(gpu, P.MLP_GEOMETRIES["northstar8x256"], n=128, nc=64, nf=128, tag="8x256_128")
+
+
 def test_ndc_rays_backward(gpu):
     P.case_ndc_rays_bwd(gpu, n=5000)
 

@@ -44,6 +44,7 @@ RAYS_PER_GPU = 4096
 NC, NF = 64, 128
 MODEL = dict(num_layers=8, hidden_size=256, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md chip table (256 CUs x 256 FLOP/clk at 2.4 GHz)
+BF16X3_PEAK_TFLOPS = 2500.0 / 3.0  # dense bf16 MFMA peak (same table) / three MFMAs per fp32-equivalent product block
 HBM_PEAK_TBS = 8.0             # same guide: HBM3E ~8 TB/s
 PEAK_CLOCK_GHZ = 2.4
 
@@ -300,6 +301,9 @@ def main():
     ap.add_argument("--layers", type=int, default=MODEL["num_layers"])
     ap.add_argument("--overlap", type=int, default=-1, help="1: two-stream step (coarse backward next to the fine pass); "
                     "0: single-stream order; -1: the engine's default for the net width")
+    ap.add_argument("--precision", choices=("fp32", "bf16x3"), default="fp32",
+                    help="eval only: arithmetic of the inference forward -- fp32 (default, the reference's) or the split-bf16 "
+                         "kernels (NERFHIP_PRECISION_BF16X3: NOT the reference's arithmetic; a separate, labelled line)")
     ap.add_argument("--gather", action="store_true", help="eval: rank 0 also receives every pose's rows (output plumbing)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / timing plumbing only, on the CPU with "
                     "gloo: no kernel runs and no number is reported (the CPU test-suite uses it)")
@@ -352,6 +356,8 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    if args.mode == "train" and args.precision != "fp32":
+        raise SystemExit("--precision bf16x3 is an inference arithmetic: use it with --mode eval")
     if args.mode == "train":
         strong = args.global_rays > 0
         if strong:
@@ -383,6 +389,8 @@ def main():
         opts = N.make_options(NC, NF, perturb=False, radiance_field_noise_std=0.0, chunksize=1 << 22)
         lo, hi = N.parallel.shard_bounds(side, rank, world)
         n = (hi - lo) * side
+        mc.set_inference_precision(args.precision)
+        mf.set_inference_precision(args.precision)
 
         def one_step(i):
             with torch.no_grad():
@@ -443,9 +451,11 @@ def main():
             cyc, ticks, wgs = (int(clk[3 * {"fwd": 0, "dgrad": 1, "wgrad": 2}[kind] + c]) for c in range(3))
             ghz = 0.1 * cyc / ticks if ticks else None
             counter_gb, source = pmc_traffic(cfg, n, kind) if args.mode == "train" else (None, None)
+            # a kernel is priced against ITS OWN matrix pipe: fp32 MFMA, or the bf16 MFMA at three instructions per product block
+            peak = BF16X3_PEAK_TFLOPS if "bf16x3" in name else FP32_MFMA_PEAK_TFLOPS
             kernels[kind] = dict(kernel=name, ms_per_step=round(ms / args.steps, 4), avg_launch_ms=round(avg_ms, 4), launches=cnt,
                                  algorithmic_gflop_per_launch=round(flops[kind] * spl / 1e9, 2), tflops=round(tf, 2),
-                                 frac=round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
+                                 peak=round(peak, 1), frac=round(tf / peak, 4),
                                  sclk_ghz=None if ghz is None else round(ghz, 3),
                                  frac_at_measured_clock=None if ghz is None else round(tf / (FP32_MFMA_PEAK_TFLOPS * ghz / PEAK_CLOCK_GHZ), 4),
                                  traffic=dict(algorithmic_gb=round(gb, 3), counter_gb=counter_gb, source=source),
@@ -455,7 +465,7 @@ def main():
             dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])   # the kernel the step spends most time in
             lowest = min(kernels, key=lambda k: kernels[k]["frac"])
             d = kernels[dom]
-            roof = dict(bound="mfma", kernel=d["kernel"], achieved=d["tflops"], peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+            roof = dict(bound="mfma", kernel=d["kernel"], achieved=d["tflops"], peak=d["peak"], unit="TFLOP/s",
                         frac=d["frac"], traffic=d["traffic"], avg_launch_ms=d["avg_launch_ms"], launches=d["launches"],
                         algorithmic_gflop_per_launch=d["algorithmic_gflop_per_launch"],
                         sclk_ghz=d["sclk_ghz"], frac_at_measured_clock=d["frac_at_measured_clock"],
@@ -481,7 +491,10 @@ def main():
         res = dict(metric=metric, value=round(total_rays * args.steps / dt, 2), unit="rays/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(sec * 1e3, 3),
                    ms_per_step_per_rank=[round(t / args.steps * 1e3, 3) for t in per_rank],
-                   higher_is_better=True, scaling="strong" if strong else "weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   higher_is_better=True, scaling="strong" if strong else "weak", vs_baseline=None,
+                   dtype="f32" if (args.mode == "train" or args.precision == "fp32") else
+                   "bf16x3 (fp32 operands split into two bf16 pieces, three bf16 MFMAs per product block, f32 accumulate; "
+                   "fp32-equivalent FLOPs)", data="synthetic",
                    config=dict(workload=workload, rays_per_gpu=n, global_rays=total_rays, parallelism="dp%d" % world,
                                two_stream_step=bool(eng.overlap) if args.mode == "train" else None,
                                backend=("gloo(one-device test hook)" if one_device else "nccl(RCCL)") if world > 1 else None),

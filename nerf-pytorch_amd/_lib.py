@@ -43,6 +43,7 @@ class RenderCotangents(C.Structure):
                                    "g_depth_fine")]
 
 
+PRECISION_FP32, PRECISION_BF16X3 = 0, 1  # NERFHIP_PRECISION_*
 PART_COARSE, PART_FINE, PART_SHARED_BWD = 1, 2, 4
 
 

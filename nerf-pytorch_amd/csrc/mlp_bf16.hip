@@ -34,16 +34,43 @@ struct BCtx {
 // piece per wave-instruction, pieces dealt round-robin to the four waves
 template <int BUF>
 NH_DEVICE void b_issue(const BCtx& cx, int64_t src, int bytes, int b, int dst_off) {
+#ifdef NHB_EXP_NO_STREAM  // (diagnostic builds only, wrong results: what the kernel costs without the weight stream)
+    const int pieces = (bytes >> 10) < 4 ? (bytes >> 10) : 4;
+#else
     const int pieces = bytes >> 10;
+#endif
     for (int p = cx.wave; p < pieces; p += 4)
         nh_dma16a(cx.dma, cx.lane * 16, (int)src + p * 1024, cx.lds_addr + (unsigned)(b * BUF + dst_off + p * 1024));
 }
 
+// one accumulator tile -> two k-blocks of the next layer's operand pieces: hi = bf16(v), lo = bf16(v - hi)
+template <bool RELU>
+NH_DEVICE void convert_tile(const f32x16& acc, nh_bf16x8* oh, nh_bf16x8* ol) {
+#ifdef NHB_EXP_NO_EPI  // (diagnostic builds only, wrong results: what the kernel costs without the conversions)
+    oh[0][0] = nh_to_bf16(acc[0]);
+    ol[1][0] = nh_to_bf16(acc[8]);
+    return;
+#endif
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = acc[half * 8 + j];
+            if (RELU) v = nh_relu(v);
+            const nh_bf16 hi = nh_to_bf16(v);
+            oh[half][j] = hi;
+            ol[half][j] = nh_to_bf16(v - nh_from_bf16(hi));
+        }
+}
+
+// EPI (0: none; 1: ReLU; 2: identity): the first NTE output tiles leave as the next layer's operand pieces oh / ol (k-blocks
+// 2 t, 2 t + 1 from tile t; oh / ol must not alias the inputs).  The LAST chunk is multiplied tile by tile, so that a tile's
+// conversion (VALU) runs in the shadow of the next tile's MFMAs instead of after the layer.
 // acc[t] = bias + sum over NKA activation k-blocks (ah/al) and NKB encoding k-blocks (xh/xl) of this layer's image at byte
 // offset `base`; while the last chunk is multiplied the first chunk of the next layer (next_base, next_first bytes) travels.
-template <int W, int NT, int NKA, int NKB>
+template <int W, int NT, int NKA, int NKB, int EPI = 0, int NTE = 0>
 NH_DEVICE void gemm_b(BCtx& cx, const nh_bf16x8* ah, const nh_bf16x8* al, const nh_bf16x8* xh, const nh_bf16x8* xl, int64_t base,
-                      int64_t next_base, int next_first, f32x16* acc) {
+                      int64_t next_base, int next_first, f32x16* acc, nh_bf16x8* oh = nullptr, nh_bf16x8* ol = nullptr) {
     constexpr int NK = NKA + NKB, BUF = BShape<W>::BUF, CH = BShape<W>::CHUNK / (NT * 2048), NCH = (NK + CH - 1) / CH;
     static_assert(CH >= 1, "a k-block of every tile must fit one chunk buffer");
 #pragma unroll
@@ -70,41 +97,51 @@ NH_DEVICE void gemm_b(BCtx& cx, const nh_bf16x8* ah, const nh_bf16x8* al, const 
                 }
         }
         const char* const wb = buf + 2048 + cx.lane * 16;
-#pragma unroll
-        for (int kk = 0; kk < CH; ++kk) {
+        auto block = [&](int kk, int t) {
             const int kb = c * CH + kk;
-            if (kb < NK) {
-                const nh_bf16x8 bh = kb < NKA ? ah[kb < NKA ? kb : 0] : xh[kb >= NKA ? kb - NKA : 0];
-                const nh_bf16x8 bl = kb < NKA ? al[kb < NKA ? kb : 0] : xl[kb >= NKA ? kb - NKA : 0];
+            const nh_bf16x8 bh = kb < NKA ? ah[kb < NKA ? kb : 0] : xh[kb >= NKA ? kb - NKA : 0];
+            const nh_bf16x8 bl = kb < NKA ? al[kb < NKA ? kb : 0] : xl[kb >= NKA ? kb - NKA : 0];
+            const nh_bf16x8 wh = *(const nh_bf16x8*)(wb + ((kk * NT + t) * 2) * 1024);
+            const nh_bf16x8 wl = *(const nh_bf16x8*)(wb + ((kk * NT + t) * 2 + 1) * 1024);
+            acc[t] = nh_mfma_bf16(wl, bh, acc[t]);  // (the small terms first)
+            acc[t] = nh_mfma_bf16(wh, bl, acc[t]);
+            acc[t] = nh_mfma_bf16(wh, bh, acc[t]);
+        };
+#ifndef NHB_LATE_EPI  // (A/B builds only)
+        if (EPI != 0 && c == NCH - 1) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const nh_bf16x8 wh = *(const nh_bf16x8*)(wb + ((kk * NT + t) * 2) * 1024);
-                    const nh_bf16x8 wl = *(const nh_bf16x8*)(wb + ((kk * NT + t) * 2 + 1) * 1024);
-                    acc[t] = nh_mfma_bf16(wl, bh, acc[t]);  // (the small terms first)
-                    acc[t] = nh_mfma_bf16(wh, bl, acc[t]);
-                    acc[t] = nh_mfma_bf16(wh, bh, acc[t]);
-                }
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int kk = 0; kk < CH; ++kk)
+                    if (c * CH + kk < NK) block(kk, t);
+                if (t < NTE) convert_tile<EPI == 1>(acc[t], oh + 2 * t, ol + 2 * t);
             }
+        } else
+#endif
+        {
+#pragma unroll
+            for (int kk = 0; kk < CH; ++kk)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (c * CH + kk < NK) block(kk, t);
         }
         cx.buf ^= 1;
     }
+#ifdef NHB_LATE_EPI
+    if (EPI != 0) {
+#pragma unroll
+        for (int t = 0; t < NTE; ++t) convert_tile<EPI == 1>(acc[t], oh + 2 * t, ol + 2 * t);
+    }
+#endif
 }
 
-// accumulators -> the next layer's operand pieces: hi = bf16(v), lo = bf16(v - hi)
-template <int NT, bool RELU>
-NH_DEVICE void to_operands(const f32x16* acc, nh_bf16x8* oh, nh_bf16x8* ol) {
+template <int NB>
+NH_DEVICE void copy_blocks(nh_bf16x8* dh, nh_bf16x8* dl, const nh_bf16x8* sh, const nh_bf16x8* sl) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int half = 0; half < 2; ++half)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float v = acc[t][half * 8 + j];
-                if (RELU) v = nh_relu(v);
-                const nh_bf16 hi = nh_to_bf16(v);
-                oh[2 * t + half][j] = hi;
-                ol[2 * t + half][j] = nh_to_bf16(v - nh_from_bf16(hi));
-            }
+    for (int k = 0; k < NB; ++k) {
+        dh[k] = sh[k];
+        dl[k] = sl[k];
+    }
 }
 
 NH_DEVICE void put_pair(nh_bf16x8& oh, nh_bf16x8& ol, int e, float v) {
@@ -200,13 +237,13 @@ NH_KERNEL void NH_LB(256, BShape<W>::WAVES_PER_SIMD) k_mlp_fwd_bf16x3(FwdBArgs a
     }
 
     f32x16 acc[TH + 1];
-    nh_bf16x8 hh[KBH], hl[KBH];
+    nh_bf16x8 hh[KBH], hl[KBH];  // the current activations as operand pieces
+    nh_bf16x8 nh[KBH], nl[KBH];  // the next ones, filled tile by tile while the layer's last chunk is multiplied
     {
         const bool more = a.L > 1;
         // no activation after layer1 (models.py:238)
-        gemm_b<W, TH, 0, XB>(cx, nullptr, nullptr, xh, xl, po.f_layer1 * 4, (more ? po.f_xyz[0] : po.f_head) * 4,
-                             more ? first(KBH, TH) : (VIEW ? first(KBH, TH + 1) : first(KBH, 1)), acc);
-        to_operands<TH, false>(acc, hh, hl);
+        gemm_b<W, TH, 0, XB, 2, TH>(cx, nullptr, nullptr, xh, xl, po.f_layer1 * 4, (more ? po.f_xyz[0] : po.f_head) * 4,
+                                    more ? first(KBH, TH) : (VIEW ? first(KBH, TH + 1) : first(KBH, 1)), acc, hh, hl);
     }
     for (int i = 0; i < a.L - 1; ++i) {
         const bool sk = (i % a.skip == 0) && i > 0;
@@ -215,10 +252,10 @@ NH_KERNEL void NH_LB(256, BShape<W>::WAVES_PER_SIMD) k_mlp_fwd_bf16x3(FwdBArgs a
         const int64_t nxt = (more ? po.f_xyz[i + 1] : po.f_head) * 4;
         const int nfirst = more ? (nsk ? first(KBH + XB, TH) : first(KBH, TH)) : (VIEW ? first(KBH, TH + 1) : first(KBH, 1));
         if (sk)
-            gemm_b<W, TH, KBH, XB>(cx, hh, hl, xh, xl, po.f_xyz[i] * 4, nxt, nfirst, acc);
+            gemm_b<W, TH, KBH, XB, 1, TH>(cx, hh, hl, xh, xl, po.f_xyz[i] * 4, nxt, nfirst, acc, nh, nl);
         else
-            gemm_b<W, TH, KBH, 0>(cx, hh, hl, nullptr, nullptr, po.f_xyz[i] * 4, nxt, nfirst, acc);
-        to_operands<TH, true>(acc, hh, hl);
+            gemm_b<W, TH, KBH, 0, 1, TH>(cx, hh, hl, nullptr, nullptr, po.f_xyz[i] * 4, nxt, nfirst, acc, nh, nl);
+        copy_blocks<KBH>(hh, hl, nh, nl);
     }
     if (VIEW) {
         nh_bf16x8 dh[DB], dl[DB];
@@ -229,11 +266,9 @@ NH_KERNEL void NH_LB(256, BShape<W>::WAVES_PER_SIMD) k_mlp_fwd_bf16x3(FwdBArgs a
             encode_b<DB>(dh, dl, rr[8], rr[9], rr[10], h, a.fd, a.Ld);
         }
         // tiles 0..TH-1: feat = relu(fc_feat(h)); tile TH row 0: fc_alpha(h), raw (models.py:248-249)
-        gemm_b<W, TH + 1, KBH, 0>(cx, hh, hl, nullptr, nullptr, po.f_head * 4, po.f_dir * 4, first(KBH + DB, TH / 2), acc);
+        gemm_b<W, TH + 1, KBH, 0, 1, TH>(cx, hh, hl, nullptr, nullptr, po.f_head * 4, po.f_dir * 4, first(KBH + DB, TH / 2), acc, nh, nl);
         const float alpha = acc[TH][0];
-        to_operands<TH, true>(acc, hh, hl);
-        gemm_b<W, TH / 2, KBH, DB>(cx, hh, hl, dh, dl, po.f_dir * 4, po.f_rgb * 4, first(KBH / 2, 1), acc);
-        to_operands<TH / 2, true>(acc, hh, hl);
+        gemm_b<W, TH / 2, KBH, DB, 1, TH / 2>(cx, nh, nl, dh, dl, po.f_dir * 4, po.f_rgb * 4, first(KBH / 2, 1), acc, hh, hl);
         gemm_b<W, 1, KBH / 2, 0>(cx, hh, hl, nullptr, nullptr, po.f_rgb * 4, 0, 0, acc);
         if (valid && h == 0) {
             float4 r4;

@@ -16,16 +16,20 @@ from . import _lib as L
 from .nerf_helpers import frequency_bands_cpu
 
 
+PRECISIONS = {"fp32": L.PRECISION_FP32, "bf16x3": L.PRECISION_BF16X3}
+
+
 class _PlanHandle:
     """Owner of one native ``nerfhip_plan`` (host-only object: packing tables, kernel schedules).  The handle is never
     duplicated: copying or unpickling an owner builds a NEW plan from the model configuration, so ``copy.deepcopy(model)``
     (EMA / best-model snapshots) and ``torch.save(model)`` cannot double-free or revive a stale address."""
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, precision=0):
         self.cfg = dict(cfg)
+        self.precision = int(precision)
         lib = L.get_lib()
         mc = L.ModelCfg(**{k: int(v) for k, v in self.cfg.items()})
-        self.ptr = lib.plan_create(C.byref(mc))
+        self.ptr = lib.plan_create_ex(C.byref(mc), self.precision) if self.precision else lib.plan_create(C.byref(mc))
         if not self.ptr:
             raise L.NerfHipError("unsupported FlexibleNeRFModel geometry: " + lib.last_error().decode())
         fx = torch.zeros(16)
@@ -45,13 +49,13 @@ class _PlanHandle:
             pass
 
     def __deepcopy__(self, memo):
-        return _PlanHandle(self.cfg)
+        return _PlanHandle(self.cfg, self.precision)
 
     def __copy__(self):
-        return _PlanHandle(self.cfg)
+        return _PlanHandle(self.cfg, self.precision)
 
     def __reduce__(self):
-        return (_PlanHandle, (self.cfg,))
+        return (_PlanHandle, (self.cfg, self.precision))
 
 
 class _MlpFunction(torch.autograd.Function):
@@ -65,12 +69,14 @@ class _MlpFunction(torch.autograd.Function):
         m = x.shape[0]
         out = torch.empty((m, 4), dtype=torch.float32, device=x.device)
         # `need` (decided by the caller: needs_input_grad ignores torch.no_grad()): keep the stash for a backward
-        packed = model._packed()
+        # (no backward will follow: the model's inference plan -- the fp32 one unless set_inference_precision chose otherwise)
+        plan = model._plan if need else model._inference_plan()
+        packed = model._packed() if need else model._inference_packed()
         stash = None
         if need:
             stash = torch.empty(max(lib.plan_stash_bytes(model._plan, m), 4) // 4, dtype=torch.float32, device=x.device)
         with L.launch_on(x, out, packed, stash) as st:
-            lib.mlp_fwd(model._plan, packed.data_ptr(), x.data_ptr(), m, out.data_ptr(),
+            lib.mlp_fwd(plan, packed.data_ptr(), x.data_ptr(), m, out.data_ptr(),
                         stash.data_ptr() if stash is not None else None, st)
         ctx.model, ctx.m, ctx.stash, ctx.packed = model, m, stash, packed
         # (the input gradient multiplies by the weights of this forward: keep a copy only if it will be asked for)
@@ -148,17 +154,58 @@ class FlexibleNeRFModel(torch.nn.Module):
         self._flat_grad = None
         self._pack_table = None
         self._packed_buf = None
+        self._inf_owner = None
+        self._inf_table = None
+        self._inf_packed = None
+        if getattr(self, "inference_precision", "fp32") != "fp32":
+            self._inf_owner = _PlanHandle(self.cfg, PRECISIONS[self.inference_precision])
         self._flatten()
 
     @property
     def _plan(self):
         return self._plan_owner.ptr
 
+    # ---- inference arithmetic -----------------------------------------------------------------------------------------
+    inference_precision = "fp32"
+
+    def set_inference_precision(self, precision):
+        """Arithmetic of this model's forward passes that no backward follows (torch.no_grad() / mode="validation"):
+        "fp32" (default: the kernels every parity claim refers to) or "bf16x3" (NERFHIP_PRECISION_BF16X3: split-bf16
+        products on the bf16 MFMAs, ~2^-16 instead of 2^-24 relative error per product, > 2x the inference throughput;
+        include/nerfhip.h).  Training forwards are always fp32.  Raises for geometries the bf16x3 kernels do not cover."""
+        if precision not in PRECISIONS:
+            raise ValueError("inference precision must be one of %s (got %r)" % (sorted(PRECISIONS), precision))
+        owner = _PlanHandle(self.cfg, PRECISIONS[precision]) if precision != "fp32" else None
+        self.inference_precision = precision
+        self._inf_owner, self._inf_table, self._inf_packed = owner, None, None
+        return self
+
+    def _inference_plan(self):
+        return self._plan if self._inf_owner is None else self._inf_owner.ptr
+
+    def _inference_packed(self):
+        if self._inf_owner is None:
+            return self._packed()
+        lib = L.get_lib()
+        dev = self._flat.device
+        if dev.type != "cuda":
+            raise RuntimeError("FlexibleNeRFModel must live on a CUDA (HIP) device: nerf_pytorch_amd has no CPU path")
+        plan = self._inf_owner.ptr
+        if self._inf_table is None or self._inf_table.device != dev:
+            n = int(lib.plan_packed_floats(plan))
+            host = torch.empty(n, dtype=torch.int32)
+            lib.plan_pack_index(plan, host.data_ptr())
+            self._inf_table = host.to(dev)
+            self._inf_packed = torch.empty(n, dtype=torch.float32, device=dev)
+        with L.launch_on(self._flat, self._inf_table, self._inf_packed) as st:
+            lib.pack_weights_plan(plan, self._flat.data_ptr(), self._inf_table.data_ptr(), self._inf_packed.data_ptr(), st)
+        return self._inf_packed
+
     def __getstate__(self):
         # copy.deepcopy / pickle: the native handle and every cache derived from it stay behind; the parameters travel
         # as ordinary tensors and are re-homed into a fresh flat buffer by __setstate__
         state = self.__dict__.copy()
-        for k in ("_plan_owner", "_flat", "_flat_grad", "_pack_table", "_packed_buf"):
+        for k in ("_plan_owner", "_flat", "_flat_grad", "_pack_table", "_packed_buf", "_inf_owner", "_inf_table", "_inf_packed"):
             state[k] = None
         return state
 
@@ -184,6 +231,8 @@ class FlexibleNeRFModel(torch.nn.Module):
         self._flat_grad = None
         self._pack_table = None
         self._packed_buf = None
+        self._inf_table = None
+        self._inf_packed = None
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)

@@ -87,10 +87,13 @@ class _FusedRender(torch.autograd.Function):
         cfg = L.RenderCfg(nc, nf, int(bool(perturb)), int(bool(lindisp)), int(bool(white)), float(noise_std), stride)
         # `training` (decided by the caller: grad mode is off inside Function.forward, and needs_input_grad ignores
         # torch.no_grad()): keep the activation stash for a backward
-        plan_f = model_f._plan if nf > 0 else None
+        # (inference -- no backward follows -- runs on each model's inference plan: fp32 unless set_inference_precision
+        # chose the split-bf16 kernels)
+        plan_c = model_c._plan if training else model_c._inference_plan()
+        plan_f = (model_f._plan if training else model_f._inference_plan()) if nf > 0 else None
         # (training layout 2: this node's backward runs the two nets one after the other on one stream, so they share one
         # set of backward buffers -- several nodes may be alive at once when a batch is rendered in ray chunks)
-        wsb = lib.render_workspace_bytes(model_c._plan, plan_f, C.byref(cfg), n, 2 if training else 0)
+        wsb = lib.render_workspace_bytes(plan_c, plan_f, C.byref(cfg), n, 2 if training else 0)
         if wsb < 0:
             raise L.NerfHipError(lib.last_error().decode())
         ws = torch.empty(wsb // 4 + 1, dtype=torch.float32, device=dev)
@@ -100,10 +103,10 @@ class _FusedRender(torch.autograd.Function):
         bufs = {k: torch.empty((n, 3) if k.startswith("rgb") else (n,), dtype=torch.float32, device=dev) for k in names}
         out = L.RenderOut(*[bufs[k].data_ptr() for k in names])
         rr = L.RenderRand(*[None if r is None else r.data_ptr() for r in rand])
-        packed_c = model_c._packed()
-        packed_f = model_f._packed() if nf > 0 else None
+        packed_c = model_c._packed() if training else model_c._inference_packed()
+        packed_f = (model_f._packed() if training else model_f._inference_packed()) if nf > 0 else None
         with L.launch_on(rays, ws, packed_c, packed_f, *[r for r in rand if r is not None]) as st:
-            lib.render_fwd(model_c._plan, plan_f, C.byref(cfg), rays.data_ptr(), n, packed_c.data_ptr(),
+            lib.render_fwd(plan_c, plan_f, C.byref(cfg), rays.data_ptr(), n, packed_c.data_ptr(),
                            packed_f.data_ptr() if packed_f is not None else None, linspace01(nc, dev).data_ptr(),
                            linspace01(nf, dev).data_ptr() if nf > 0 else None, C.byref(rr), 0, 0, C.byref(out),
                            ws.data_ptr(), wsb, int(training), st)

@@ -18,6 +18,9 @@ import nerf_pytorch_amd._lib as L  # noqa: E402
 
 def main():
     dev = torch.device("cuda", 0)
+    if len(sys.argv) > 2:  # an A/B build of the library (scripts/build_bf16_variant.sh)
+        L.LIB_PATH = os.path.join(ROOT, "nerf-pytorch_amd", sys.argv[2])
+        print("# " + sys.argv[2])
     lib = L.get_lib()
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 4096 * 192
     reps = 10

@@ -17,6 +17,13 @@
 
 namespace {
 
+#ifndef NHB_DMA_EVERY  // (A/B builds only) a wave issues one 1-KiB piece of the next chunk every so many blocks; 0: all at once
+#define NHB_DMA_EVERY 1
+#endif
+#ifndef NHB_PREFETCH  // (A/B builds only) blocks of weight pieces in flight LDS -> registers ahead of the MFMAs
+#define NHB_PREFETCH 2
+#endif
+
 template <int W>
 struct BShape {
     static constexpr int TH = W / 32, KBH = W / 16, CHUNK = nhb_chunk_bytes(W), BUF = CHUNK + 2048, LDS_BYTES = 2 * BUF;
@@ -64,8 +71,9 @@ NH_DEVICE void convert_tile(const f32x16& acc, nh_bf16x8* oh, nh_bf16x8* ol) {
 }
 
 // EPI (0: none; 1: ReLU; 2: identity): the first NTE output tiles leave as the next layer's operand pieces oh / ol (k-blocks
-// 2 t, 2 t + 1 from tile t; oh / ol must not alias the inputs).  The LAST chunk is multiplied tile by tile, so that a tile's
-// conversion (VALU) runs in the shadow of the next tile's MFMAs instead of after the layer.
+// 2 t, 2 t + 1 from tile t), converted after the layer's last chunk.  (Converting each tile of the last chunk as it
+// completes, in the shadow of the next tile's MFMAs, measured 3 % SLOWER on MI355X: the second set of operand registers it
+// needs takes the VGPR file to its limit -- profiles/r03_variant_ab.txt section 7.)
 // acc[t] = bias + sum over NKA activation k-blocks (ah/al) and NKB encoding k-blocks (xh/xl) of this layer's image at byte
 // offset `base`; while the last chunk is multiplied the first chunk of the next layer (next_base, next_first bytes) travels.
 template <int W, int NT, int NKA, int NKB, int EPI = 0, int NTE = 0>
@@ -77,12 +85,30 @@ NH_DEVICE void gemm_b(BCtx& cx, const nh_bf16x8* ah, const nh_bf16x8* al, const 
     for (int c = 0; c < NCH; ++c) {
         nh_wait_vmem();    // this wave's pieces of the current chunk have landed ...
         nh_block_sync();   // ... and everyone's; nobody still reads the other buffer
+        // The next chunk (or the next layer's first one) goes to the other buffer WHILE this one is multiplied: its 1-KiB
+        // pieces are dealt to the waves round-robin and each wave issues one piece every NHB_DMA_EVERY blocks, so that the
+        // copy's LDS writes interleave with the MFMAs' LDS reads instead of arriving as one burst at the chunk's start.
+        int64_t dsrc = 0;
+        int dpieces = 0, ddst = 0;
         if (c + 1 < NCH) {
             const int nkb = NK - (c + 1) * CH < CH ? NK - (c + 1) * CH : CH;
-            b_issue<BUF>(cx, base + 2048 + (int64_t)(c + 1) * CH * NT * 2048, nkb * NT * 2048, cx.buf ^ 1, 2048);
+            dsrc = base + 2048 + (int64_t)(c + 1) * CH * NT * 2048, dpieces = nkb * NT * 2, ddst = 2048;
         } else if (next_first > 0) {
-            b_issue<BUF>(cx, next_base, next_first, cx.buf ^ 1, 0);
+            dsrc = next_base, dpieces = next_first >> 10, ddst = 0;
         }
+#ifdef NHB_EXP_NO_STREAM
+        dpieces = dpieces < 4 ? dpieces : 4;
+#endif
+        int dnext = cx.wave;  // this wave's next piece
+        auto dma_step = [&]() {
+            if (dnext < dpieces) {
+                nh_dma16a(cx.dma, cx.lane * 16, (int)dsrc + dnext * 1024, cx.lds_addr + (unsigned)((cx.buf ^ 1) * BUF + ddst + dnext * 1024));
+                dnext += 4;
+            }
+        };
+#if NHB_DMA_EVERY == 0
+        while (dnext < dpieces) dma_step();
+#endif
         const char* const buf = cx.lds + cx.buf * BUF;
         if (c == 0) {  // the accumulators start at the bias of their rows: register 4 j + i of tile t holds row 32 t + 8 j + 4 h + i
 #pragma unroll
@@ -97,42 +123,48 @@ NH_DEVICE void gemm_b(BCtx& cx, const nh_bf16x8* ah, const nh_bf16x8* al, const 
                 }
         }
         const char* const wb = buf + 2048 + cx.lane * 16;
-        auto block = [&](int kk, int t) {
-            const int kb = c * CH + kk;
-            const nh_bf16x8 bh = kb < NKA ? ah[kb < NKA ? kb : 0] : xh[kb >= NKA ? kb - NKA : 0];
-            const nh_bf16x8 bl = kb < NKA ? al[kb < NKA ? kb : 0] : xl[kb >= NKA ? kb - NKA : 0];
-            const nh_bf16x8 wh = *(const nh_bf16x8*)(wb + ((kk * NT + t) * 2) * 1024);
-            const nh_bf16x8 wl = *(const nh_bf16x8*)(wb + ((kk * NT + t) * 2 + 1) * 1024);
-            acc[t] = nh_mfma_bf16(wl, bh, acc[t]);  // (the small terms first)
-            acc[t] = nh_mfma_bf16(wh, bl, acc[t]);
-            acc[t] = nh_mfma_bf16(wh, bh, acc[t]);
+        // The (k-block, tile) blocks of this chunk, software-pipelined by hand: the weight pieces of block i + PF are read
+        // from LDS before the MFMAs of block i issue, each side of a scheduling fence -- left to itself the compiler reads
+        // every block into ONE register quad right in front of its MFMAs and waits for it (seen in the ISA: ds_read_b128,
+        // s_waitcnt lgkmcnt(0), v_mfma, ... -- the matrix pipe idles for an LDS latency per block; 0.39 of the roofline).
+        const int nkk = NK - c * CH < CH ? NK - c * CH : CH;  // k-blocks in this chunk
+        const int nblk = nkk * NT;
+        constexpr int PF = NHB_PREFETCH;
+        constexpr int NBUF = PF + 1;
+        nh_bf16x8 wph[NBUF], wpl[NBUF];
+        auto kk_of = [&](int i) { return i / NT; };
+        auto t_of = [&](int i) { return i % NT; };
+        auto load = [&](int i) {
+            wph[i % NBUF] = *(const nh_bf16x8*)(wb + ((kk_of(i) * NT + t_of(i)) * 2) * 1024);
+            wpl[i % NBUF] = *(const nh_bf16x8*)(wb + ((kk_of(i) * NT + t_of(i)) * 2 + 1) * 1024);
         };
-#ifndef NHB_LATE_EPI  // (A/B builds only)
-        if (EPI != 0 && c == NCH - 1) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
+        for (int i = 0; i < PF; ++i)
+            if (i < nblk) load(i);
 #pragma unroll
-                for (int kk = 0; kk < CH; ++kk)
-                    if (c * CH + kk < NK) block(kk, t);
-                if (t < NTE) convert_tile<EPI == 1>(acc[t], oh + 2 * t, ol + 2 * t);
-            }
-        } else
+        for (int i = 0; i < CH * NT; ++i) {
+            if (i < nblk) {
+#if NHB_DMA_EVERY > 0
+                if (i % NHB_DMA_EVERY == 0) dma_step();
 #endif
-        {
-#pragma unroll
-            for (int kk = 0; kk < CH; ++kk)
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    if (c * CH + kk < NK) block(kk, t);
+                if (i + PF < nblk) load(i + PF);
+                nh_sched_fence();
+                const int kb = c * CH + kk_of(i), t = t_of(i);
+                const nh_bf16x8 bh = kb < NKA ? ah[kb < NKA ? kb : 0] : xh[kb >= NKA ? kb - NKA : 0];
+                const nh_bf16x8 bl = kb < NKA ? al[kb < NKA ? kb : 0] : xl[kb >= NKA ? kb - NKA : 0];
+                const nh_bf16x8 wh = wph[i % NBUF], wl = wpl[i % NBUF];
+                acc[t] = nh_mfma_bf16(wl, bh, acc[t]);  // (the small terms first)
+                acc[t] = nh_mfma_bf16(wh, bl, acc[t]);
+                acc[t] = nh_mfma_bf16(wh, bh, acc[t]);
+            }
         }
+        while (dnext < dpieces) dma_step();  // (whatever the blocks did not cover: short chunks in front of long ones)
         cx.buf ^= 1;
     }
-#ifdef NHB_LATE_EPI
     if (EPI != 0) {
 #pragma unroll
         for (int t = 0; t < NTE; ++t) convert_tile<EPI == 1>(acc[t], oh + 2 * t, ol + 2 * t);
     }
-#endif
 }
 
 template <int NB>
@@ -188,7 +220,7 @@ struct FwdBArgs {
     unsigned packed_bytes;
     NhPackedOffsets off;  // (32-bit word offsets)
     int L, skip;
-    int64_t M;
+    int64_t M, groups;  // sample points; 128-sample groups = ceil(M / 128)
     int mode;
     const float* x;
     int dx, dd;
@@ -216,15 +248,21 @@ NH_KERNEL void NH_LB(256, BShape<W>::WAVES_PER_SIMD) k_mlp_fwd_bf16x3(FwdBArgs a
     cx.wave = nh_wave_in_block();
     cx.h = cx.lane >> 5;
     const int h = cx.h;
-    const int64_t m = (int64_t)blockIdx.x * 128 + cx.wave * 32 + (cx.lane & 31);
-    const bool valid = m < a.M;
-    const int64_t mc = valid ? m : a.M - 1;
     const NhPackedOffsets& po = a.off;
     auto first = [](int nk, int nt) { return nhb_first_bytes(nk, nt, W); };
 
     // the first weights travel while the encodings are formed
     b_issue<BUF>(cx, po.f_layer1 * 4, first(XB, TH), 0, 0);
 
+    // Persistent workgroups: the launch holds as many workgroups as the chip runs at once (host: one or two per CU) and each
+    // walks over its 128-sample groups -- a workgroup owns all of a CU's LDS, so with one group per workgroup the next
+    // could only be dispatched after the previous one had drained (17 % of the SIMD time had no wave resident: rocprofv3
+    // SQ_WAVE_CYCLES against the kernel's duration); here the last layer of a group already streams layer1 of the next.
+    for (int64_t grp = blockIdx.x; grp < a.groups; grp += gridDim.x) {
+    const bool again = grp + gridDim.x < a.groups;
+    const int64_t m = grp * 128 + cx.wave * 32 + (cx.lane & 31);
+    const bool valid = m < a.M;
+    const int64_t mc = valid ? m : a.M - 1;
     nh_bf16x8 xh[XB], xl[XB];
     const int ray_i = a.mode == 0 ? 0 : (int)(mc / a.S);
     if (a.mode == 0) {
@@ -269,7 +307,7 @@ NH_KERNEL void NH_LB(256, BShape<W>::WAVES_PER_SIMD) k_mlp_fwd_bf16x3(FwdBArgs a
         gemm_b<W, TH + 1, KBH, 0, 1, TH>(cx, hh, hl, nullptr, nullptr, po.f_head * 4, po.f_dir * 4, first(KBH + DB, TH / 2), acc, nh, nl);
         const float alpha = acc[TH][0];
         gemm_b<W, TH / 2, KBH, DB, 1, TH / 2>(cx, nh, nl, dh, dl, po.f_dir * 4, po.f_rgb * 4, first(KBH / 2, 1), acc, hh, hl);
-        gemm_b<W, 1, KBH / 2, 0>(cx, hh, hl, nullptr, nullptr, po.f_rgb * 4, 0, 0, acc);
+        gemm_b<W, 1, KBH / 2, 0>(cx, hh, hl, nullptr, nullptr, po.f_rgb * 4, po.f_layer1 * 4, again ? first(XB, TH) : 0, acc);
         if (valid && h == 0) {
             float4 r4;
             r4.x = acc[0][0];
@@ -279,7 +317,7 @@ NH_KERNEL void NH_LB(256, BShape<W>::WAVES_PER_SIMD) k_mlp_fwd_bf16x3(FwdBArgs a
             *(float4*)(a.out + (size_t)m * 4) = r4;
         }
     } else {
-        gemm_b<W, 1, KBH, 0>(cx, hh, hl, nullptr, nullptr, po.f_head * 4, 0, 0, acc);  // fc_out (models.py:256)
+        gemm_b<W, 1, KBH, 0>(cx, hh, hl, nullptr, nullptr, po.f_head * 4, po.f_layer1 * 4, again ? first(XB, TH) : 0, acc);  // fc_out (models.py:256)
         if (valid && h == 0) {
             float4 r4;
             r4.x = acc[0][0];
@@ -289,6 +327,7 @@ NH_KERNEL void NH_LB(256, BShape<W>::WAVES_PER_SIMD) k_mlp_fwd_bf16x3(FwdBArgs a
             *(float4*)(a.out + (size_t)m * 4) = r4;
         }
     }
+    }  // (groups of this workgroup)
 }
 
 // ---- weight image --------------------------------------------------------------------------------------------------
@@ -316,6 +355,23 @@ NH_KERNEL void k_pack_bf16x3(const float* __restrict__ params, const int32_t* __
     const nh_bf16 hi = nh_to_bf16(v);
     img[(2 * blk) * 512 + q] = hi;
     img[(2 * blk + 1) * 512 + q] = nh_to_bf16(v - nh_from_bf16(hi));
+}
+
+// compute units of the current device (the emulator: 3, so that the CPU suite walks the persistent loop)
+int b_compute_units() {
+#ifndef NERFHIP_EMU
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            cus = v;
+        else
+            cus = 256;
+    }
+    return cus;
+#else
+    return 3;
+#endif
 }
 
 template <class K>
@@ -364,12 +420,19 @@ int nh_mlp_bf16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& 
     a.Ld = p->view ? p->cfg.num_encoding_fn_dir : 0;
     a.out = out;
     const int64_t groups = nh_ceil_div(M, 128);
+    a.groups = groups;
+    // as many workgroups as are resident at once (a workgroup per CU for the 256-wide nets -- its LDS --, two for 128-wide)
+    int64_t resident = (int64_t)b_compute_units() * (p->W >= 256 ? 1 : 2);
+#ifdef NHB_NOT_PERSISTENT  // (A/B builds only)
+    resident = groups;
+#endif
+    const int64_t grid = groups < resident ? groups : resident;
     int rc = NERFHIP_OK;
 #define NH_FWDB(WW, VV)                                                                                    \
     {                                                                                                      \
         rc = b_lds_limit(k_mlp_fwd_bf16x3<WW, VV>, BShape<WW>::LDS_BYTES);                                 \
         if (rc) return rc;                                                                                 \
-        NH_LAUNCH((k_mlp_fwd_bf16x3<WW, VV>), groups, 256, BShape<WW>::LDS_BYTES, stream, a);             \
+        NH_LAUNCH((k_mlp_fwd_bf16x3<WW, VV>), grid, 256, BShape<WW>::LDS_BYTES, stream, a);               \
     }
     if (p->W == 256 && p->view) NH_FWDB(256, true)
     else if (p->W == 256) NH_FWDB(256, false)

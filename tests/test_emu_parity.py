@@ -87,6 +87,9 @@ def test_mlp_512_wide_instances(emu):
 def test_mlp_forward_bf16x3(emu):
     """NERFHIP_PRECISION_BF16X3 plans: the split-bf16 inference forward, both kernel widths, every layer kind."""
     P.case_mlp_forward_bf16x3(emu, m=37)
+    # more 128-sample groups than resident workgroups (the emulator reports 3 CUs): the persistent loop, ragged last group
+    P.case_mlp_forward_bf16x3(emu, names=("default4x128",), m=900)
+    P.case_mlp_forward_bf16x3(emu, names=("skip_every_layer_256",), m=600)
     P.case_render_bf16x3(emu, P.MLP_GEOMETRIES["default4x128"], n=10, nc=8, nf=8, tag="4x128_emu")
 
 

@@ -56,7 +56,10 @@ def maybe(fn):
 def bench_lines():
     for src, dst in (("bench.log", "bench_line.json"), ("bench_4x128.log", "bench_line_4x128.json"),
                      ("bench_4x128_single.log", "bench_line_4x128_single_stream.json"), ("bench_4x64.log", "bench_line_4x64.json"),
-                     ("bench_8x512.log", "bench_line_8x512.json"), ("bench_eval.log", "bench_line_eval_800x800.json")):
+                     ("bench_8x512.log", "bench_line_8x512.json"), ("bench_eval.log", "bench_line_eval_800x800.json"),
+                     ("bench_eval_bf16x3.log", "bench_line_eval_800x800_bf16x3.json"),
+                     ("bench_eval_fp32_4x128.log", "bench_line_eval_800x800_4x128.json"),
+                     ("bench_eval_bf16x3_4x128.log", "bench_line_eval_800x800_4x128_bf16x3.json")):
         if os.path.exists(os.path.join(G, src)):
             json.dump(last_json_line(os.path.join(G, src)), open(os.path.join(P, "%s_%s" % (tag, dst)), "w"), indent=1)
     with open(os.path.join(P, tag + "_multi_rank_one_gpu.txt"), "w") as f:
@@ -96,11 +99,23 @@ def rays_and_overlap():
 maybe(rays_and_overlap)
 maybe(lambda: kernel_stats("prof", "bench_kernel_stats.txt"))
 maybe(lambda: kernel_stats("prof128", "bench_kernel_stats_4x128.txt"))
+
+
+def eval_kernel_stats():
+    rows = list(csv.DictReader(open(os.path.join(G, "prof_eval_bf16x3", "bench_kernel_stats.csv"))))
+    with open(os.path.join(P, tag + "_bench_kernel_stats_eval_bf16x3.txt"), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --mode eval --precision bf16x3 --no-cpu-baseline   (1 warm-up + 3 timed poses)\n")
+        f.write("%-64s %8s %14s %12s %8s\n" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
+        for r in rows:
+            f.write("%-64s %8s %14s %12.0f %8s\n" % (r["Name"][:64], r["Calls"], r["TotalDurationNs"], float(r["AverageNs"]), r["Percentage"]))
+
+
+maybe(eval_kernel_stats)
 for src, dst in (("eval.log", "eval_800x800.txt"), ("phase_timing.txt", "phase_timing.txt"), ("wgrad_timeline.txt", "wgrad_timeline.txt"),
                  ("wgrad_timeline_4x128.txt", "wgrad_timeline_4x128.txt"), ("pmc_summary_8x256_4096.txt", "pmc_summary.txt"),
                  ("pmc_summary_8x256_4096.json", "pmc_summary_8x256_4096.json"), ("pmc_summary_4x128_4096.txt", "pmc_summary_4x128_4096.txt"),
-                 ("pmc_summary_4x128_4096.json", "pmc_summary_4x128_4096.json"), ("split_bf16_mock.txt", "split_bf16_mock.txt"),
-                 ("ab/ab_summary.txt", "variant_ab.txt")):
+                 ("pmc_summary_4x128_4096.json", "pmc_summary_4x128_4096.json"), ("bf16x3_timing.txt", "bf16x3_timing.txt"),
+                 ("bf16x3_pmc.txt", "bf16x3_pmc.txt")):
     copy(src, dst)
 
 

@@ -12,6 +12,10 @@ timeout 200 python bench.py --hidden 128 --layers 4 --no-cpu-baseline --overlap 
 timeout 200 python bench.py --hidden 64 --layers 4 --no-cpu-baseline > $R/bench_4x64.log 2>&1
 timeout 200 python bench.py --hidden 512 --layers 8 --no-cpu-baseline --steps 5 > $R/bench_8x512.log 2>&1
 timeout 300 python bench.py --mode eval > $R/bench_eval.log 2>&1
+timeout 200 python bench.py --mode eval --no-cpu-baseline --precision bf16x3 > $R/bench_eval_bf16x3.log 2>&1
+timeout 200 python bench.py --mode eval --no-cpu-baseline --hidden 128 --layers 4 > $R/bench_eval_fp32_4x128.log 2>&1
+timeout 200 python bench.py --mode eval --no-cpu-baseline --hidden 128 --layers 4 --precision bf16x3 > $R/bench_eval_bf16x3_4x128.log 2>&1
+timeout 200 python scripts/bf16x3_timing.py > $R/bf16x3_timing.txt 2>&1
 for r in 2048 1024; do timeout 200 python bench.py --rays $r --no-cpu-baseline > $R/bench_rays$r.log 2>&1; done
 export NERFHIP_BENCH_ONE_DEVICE=1
 timeout 200 python bench.py --gpus 2 --steps 6 --warmup 2 > $R/dp2_weak.log 2>&1; echo "rc=$?" >> $R/dp2_weak.log
@@ -20,7 +24,9 @@ timeout 200 python bench.py --gpus 2 --mode eval --steps 2 --warmup 1 --gather >
 unset NERFHIP_BENCH_ONE_DEVICE
 cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $R/bench_prof.log 2>&1
 cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/prof128 -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --hidden 128 --layers 4 --overlap 0 > $R/bench_prof128.log 2>&1
+cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/prof_eval_bf16x3 -o bench -- python $GRAFT_REPO_ROOT/bench.py --mode eval --precision bf16x3 --no-cpu-baseline > $R/bench_prof_eval_bf16x3.log 2>&1
 cd $GRAFT_REPO_ROOT
+bash scripts/gpu_bf16_pmc.sh > $R/bf16_pmc.log 2>&1
 PMC_BENCH_ARGS="" bash scripts/gpu_pmc.sh > $R/pmc_8x256.log 2>&1
 cp $R/pmc_summary.json $R/pmc_summary_8x256_4096.json; cp $R/pmc_summary.txt $R/pmc_summary_8x256_4096.txt
 PMC_BENCH_ARGS="--hidden 128 --layers 4" bash scripts/gpu_pmc.sh > $R/pmc_4x128.log 2>&1
@@ -31,5 +37,5 @@ if [ -f nerf-pytorch_amd/libnerfhip_dbg.so ]; then
   timeout 200 python scripts/phase_timing.py > $R/phase_timing.txt 2>&1
 fi
 grep -E "passed|failed|error" $R/pytest_gpu.log | tail -3; tail -2 $R/smoke.log; tail -2 $R/bench.log | cut -c1-1500
-for f in bench_4x128 bench_4x128_single bench_4x64 bench_8x512 bench_eval bench_rays2048 bench_rays1024 dp2_weak dp2_strong dp2_eval; do echo "== $f"; grep "^{" $R/$f.log | tail -1 | cut -c1-260; done
+for f in bench_4x128 bench_4x128_single bench_4x64 bench_8x512 bench_eval bench_eval_bf16x3 bench_eval_fp32_4x128 bench_eval_bf16x3_4x128 bench_rays2048 bench_rays1024 dp2_weak dp2_strong dp2_eval; do echo "== $f"; grep "^{" $R/$f.log | tail -1 | cut -c1-260; done
 cat $R/pmc_summary_8x256_4096.txt $R/pmc_summary_4x128_4096.txt; ls $R/prof $R/prof128 | head

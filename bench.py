@@ -301,9 +301,10 @@ def main():
     ap.add_argument("--layers", type=int, default=MODEL["num_layers"])
     ap.add_argument("--overlap", type=int, default=-1, help="1: two-stream step (coarse backward next to the fine pass); "
                     "0: single-stream order; -1: the engine's default for the net width")
-    ap.add_argument("--precision", choices=("fp32", "bf16x3"), default="fp32",
-                    help="eval only: arithmetic of the inference forward -- fp32 (default, the reference's) or the split-bf16 "
-                         "kernels (NERFHIP_PRECISION_BF16X3: NOT the reference's arithmetic; a separate, labelled line)")
+    ap.add_argument("--precision", choices=("fp32", "bf16x3", "bf16x3_fwd"), default="fp32",
+                    help="fp32 (default: the reference's arithmetic, the headline).  --mode eval --precision bf16x3: the inference "
+                         "forward on the split-bf16 kernels.  --mode train --precision bf16x3_fwd: the training forward on them, "
+                         "backward kernels unchanged fp32.  Both are NOT the reference's arithmetic: separate, labelled lines")
     ap.add_argument("--gather", action="store_true", help="eval: rank 0 also receives every pose's rows (output plumbing)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / timing plumbing only, on the CPU with "
                     "gloo: no kernel runs and no number is reported (the CPU test-suite uses it)")
@@ -356,8 +357,11 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    if args.mode == "train" and args.precision != "fp32":
-        raise SystemExit("--precision bf16x3 is an inference arithmetic: use it with --mode eval")
+    if (args.mode == "train" and args.precision == "bf16x3") or (args.mode == "eval" and args.precision == "bf16x3_fwd"):
+        raise SystemExit("--precision bf16x3 goes with --mode eval, bf16x3_fwd with --mode train")
+    if args.precision == "bf16x3_fwd":
+        mc.set_training_precision("bf16x3_fwd")
+        mf.set_training_precision("bf16x3_fwd")
     if args.mode == "train":
         strong = args.global_rays > 0
         if strong:
@@ -492,9 +496,11 @@ def main():
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(sec * 1e3, 3),
                    ms_per_step_per_rank=[round(t / args.steps * 1e3, 3) for t in per_rank],
                    higher_is_better=True, scaling="strong" if strong else "weak", vs_baseline=None,
-                   dtype="f32" if (args.mode == "train" or args.precision == "fp32") else
-                   "bf16x3 (fp32 operands split into two bf16 pieces, three bf16 MFMAs per product block, f32 accumulate; "
-                   "fp32-equivalent FLOPs)", data="synthetic",
+                   dtype="f32" if args.precision == "fp32" else
+                   ("bf16x3 (fp32 operands split into two bf16 pieces, three bf16 MFMAs per product block, f32 accumulate; "
+                    "fp32-equivalent FLOPs)" if args.precision == "bf16x3" else
+                    "forward bf16x3 (split-bf16 products, f32 accumulate), backward + optimizer f32; fp32-equivalent FLOPs"),
+                   data="synthetic",
                    config=dict(workload=workload, rays_per_gpu=n, global_rays=total_rays, parallelism="dp%d" % world,
                                two_stream_step=bool(eng.overlap) if args.mode == "train" else None,
                                backend=("gloo(one-device test hook)" if one_device else "nccl(RCCL)") if world > 1 else None),

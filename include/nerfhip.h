@@ -171,6 +171,13 @@ nerfhip_plan_t nerfhip_plan_create(const nerfhip_model_cfg* cfg);
  * point refuses it.  Supported for kernel widths 128 and 256, num_encoding_fn_xyz <= 10, num_encoding_fn_dir <= 4. */
 #define NERFHIP_PRECISION_FP32 0
 #define NERFHIP_PRECISION_BF16X3 1
+/* BF16X3_FWD: a TRAINING-capable plan whose forward passes (training and inference alike) run on the split-bf16 kernel while
+ * the backward kernels stay the exact fp32 ones: the training forward writes the same fp32 activation stash (the values it
+ * actually computed) and ReLU masks, so nerfhip_mlp_bwd / nerfhip_render_bwd* are unchanged -- they differentiate the fp32
+ * function at activations that carry the forward's ~1e-5 relative error.  The packed image holds both the fp32 image (its
+ * transposed layers feed the data-gradient kernel) and the bf16 image; build it with nerfhip_pack_weights_plan.  An
+ * experiment toward the north star's speed-up, accepted by PSNR@iters, not by the 1e-4 bar; opt-in. */
+#define NERFHIP_PRECISION_BF16X3_FWD 2
 nerfhip_plan_t nerfhip_plan_create_ex(const nerfhip_model_cfg* cfg, int precision);
 int nerfhip_plan_precision(nerfhip_plan_t plan);
 void nerfhip_plan_destroy(nerfhip_plan_t plan);

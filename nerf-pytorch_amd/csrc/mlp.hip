@@ -65,9 +65,10 @@ int nh_mlp_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, i
     } else {
         NH_REQUIRE(in.x, "mlp_fwd: x is NULL");
     }
-    if (p->precision == NERFHIP_PRECISION_BF16X3) {
-        NH_REQUIRE(!stash, "mlp_fwd: a bf16x3 plan is inference-only (no activation stash, no backward)");
-        return nh_mlp_bf16_forward(p, packed, in, M, out, stream);
+    if (p->precision != NERFHIP_PRECISION_FP32) {
+        NH_REQUIRE(!stash || p->precision == NERFHIP_PRECISION_BF16X3_FWD,
+                   "mlp_fwd: a bf16x3 plan is inference-only (no activation stash, no backward; NERFHIP_PRECISION_BF16X3_FWD trains)");
+        return nh_mlp_bf16_forward(p, packed, in, M, out, stash, stream);
     }
     return nh_mlp16_forward(p, packed, in, M, out, stash, stream);
 }
@@ -75,7 +76,7 @@ int nh_mlp_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, i
 int nh_mlp_backward(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash,
                     float* scratch, int64_t scratch_bytes, float* g_params, nerfhip_stream_t stream) {
     NH_REQUIRE(p && packed && g_out && stash && scratch && g_params && M > 0, "mlp_bwd: bad arguments");
-    NH_REQUIRE(p->precision == NERFHIP_PRECISION_FP32, "mlp_bwd: a bf16x3 plan is inference-only");
+    NH_REQUIRE(p->precision != NERFHIP_PRECISION_BF16X3, "mlp_bwd: a bf16x3 plan is inference-only");
     NH_REQUIRE(scratch_bytes >= nh_mlp_bwd_scratch_bytes(p, M), "mlp_bwd: scratch too small (%lld < %lld)",
                (long long)scratch_bytes, (long long)nh_mlp_bwd_scratch_bytes(p, M));
     const int64_t nt = nh_ceil_div(M, 128) * 4;

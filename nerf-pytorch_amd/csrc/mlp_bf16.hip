@@ -184,11 +184,26 @@ NH_DEVICE void put_pair(nh_bf16x8& oh, nh_bf16x8& ol, int e, float v) {
 
 NH_DEVICE float bsel3(int a, float x, float y, float z) { return a == 0 ? x : (a == 1 ? y : z); }
 
-// the encoding slots of lane half h (plan.cpp build_slot_map_b): slot 16 kb + 8 h + e; pair slot >> 1 = 3 f + axis
-template <int NB>
-NH_DEVICE void encode_b(nh_bf16x8* oh, nh_bf16x8* ol, float x, float y, float z, int h, const float* freqs, int Lf) {
+// eight fp32 slot values of one k-block -> operand pieces, and (training) -> this sample's row of the slot region
+NH_DEVICE void put_block(nh_bf16x8& oh, nh_bf16x8& ol, const float* v, float* slot_row) {
 #pragma unroll
-    for (int kb = 0; kb < NB; ++kb)
+    for (int e = 0; e < 8; ++e) put_pair(oh, ol, e, v[e]);
+    if (slot_row) {
+        float4 a4, b4;
+        a4.x = v[0], a4.y = v[1], a4.z = v[2], a4.w = v[3];
+        b4.x = v[4], b4.y = v[5], b4.z = v[6], b4.w = v[7];
+        *(float4*)slot_row = a4;
+        *(float4*)(slot_row + 4) = b4;
+    }
+}
+
+// the encoding slots of lane half h (plan.cpp build_slot_map_b): slot 16 kb + 8 h + e; pair slot >> 1 = 3 f + axis.
+// slot_row (training): this sample's row of the stash's slot region; the lane writes its slots 16 kb + 8 h .. + 7.
+template <int NB>
+NH_DEVICE void encode_b(nh_bf16x8* oh, nh_bf16x8* ol, float x, float y, float z, int h, const float* freqs, int Lf, float* slot_row) {
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+        float v[8];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int pr = 8 * kb + 4 * h + q;
@@ -199,20 +214,69 @@ NH_DEVICE void encode_b(nh_bf16x8* oh, nh_bf16x8* ol, float x, float y, float z,
             float v0 = valid ? s : 0.0f, v1 = valid ? c : 0.0f;
             if (kb == NB - 1 && q == 2 && h == 1) v0 = x, v1 = y;  // slots NS-4, NS-3 (never a valid pair: 6 L <= NS - 4)
             if (kb == NB - 1 && q == 3 && h == 1) v0 = z, v1 = 0.0f;
-            put_pair(oh[kb], ol[kb], 2 * q, v0);
-            put_pair(oh[kb], ol[kb], 2 * q + 1, v1);
+            v[2 * q] = v0;
+            v[2 * q + 1] = v1;
         }
+        put_block(oh[kb], ol[kb], v, slot_row ? slot_row + 16 * kb + 8 * h : nullptr);
+    }
 }
 // the same slots gathered from a caller-encoded row (mode 0)
 template <int NB>
-NH_DEVICE void gather_b(nh_bf16x8* oh, nh_bf16x8* ol, const float* row, const signed char* col, int h) {
+NH_DEVICE void gather_b(nh_bf16x8* oh, nh_bf16x8* ol, const float* row, const signed char* col, int h, float* slot_row) {
 #pragma unroll
-    for (int kb = 0; kb < NB; ++kb)
+    for (int kb = 0; kb < NB; ++kb) {
+        float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = (int)col[16 * kb + 8 * h + e];
-            put_pair(oh[kb], ol[kb], e, c >= 0 ? row[c] : 0.0f);
+            v[e] = c >= 0 ? row[c] : 0.0f;
         }
+        put_block(oh[kb], ol[kb], v, slot_row ? slot_row + 16 * kb + 8 * h : nullptr);
+    }
+}
+
+// ---- the training stash (NERFHIP_PRECISION_BF16X3_FWD): what the fp32 backward kernels read (nh_plan.h NhStashLayout) ------
+// rows of NT output tiles of this lane's sample: register 4 j + i of tile t is row 32 t + 8 j + 4 h + i -> one 16-byte store
+template <int NT, bool RELU>
+NH_DEVICE void stash_rows(float* sample_row, int h, const f32x16* acc) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 r4;
+            r4.x = RELU ? nh_relu(acc[t][4 * j]) : acc[t][4 * j];
+            r4.y = RELU ? nh_relu(acc[t][4 * j + 1]) : acc[t][4 * j + 1];
+            r4.z = RELU ? nh_relu(acc[t][4 * j + 2]) : acc[t][4 * j + 2];
+            r4.w = RELU ? nh_relu(acc[t][4 * j + 3]) : acc[t][4 * j + 3];
+            *(float4*)(sample_row + 32 * t + 8 * j + 4 * h) = r4;
+        }
+}
+// ReLU bits in the data-gradient kernel's layout (mlp16.hip finish() / nh16_bitpos): its lane (sample & 15, g) holds unit
+// 16 (r >> 2) + 4 g + (r & 3) in register r; of its n = 8 NT registers, r sits in word r >> 5 at bit
+// min(32, n - 32 (r >> 5)) - 1 - (r & 31).  This lane's units 32 t + 8 j + 4 h + i are register 4 (2 t + (j >> 1)) + i of the
+// two lanes g = 2 (j & 1) + h: it writes both lanes' words whole -- no exchange between lanes.
+template <int NT>
+NH_DEVICE void stash_mask(unsigned* tile16_mask, int s, int h, const f32x16* acc) {
+    constexpr int n = 8 * NT;
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+        unsigned w0 = 0u, w1 = 0u;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 4 * (2 * t + jh) + i, word = r >> 5;
+                    const int pos = ((n - 32 * word) < 32 ? (n - 32 * word) : 32) - 1 - (r & 31);
+                    const unsigned bit = acc[t][4 * (2 * jh + jb) + i] > 0.0f ? 1u : 0u;
+                    if (word == 0) w0 |= bit << pos;
+                    else w1 |= bit << pos;
+                }
+        unsigned* dst = tile16_mask + ((s & 15) + 16 * (2 * jb + h)) * 2;
+        dst[0] = w0;
+        dst[1] = w1;
+    }
 }
 
 struct FwdBArgs {
@@ -233,9 +297,14 @@ struct FwdBArgs {
     float fx[16], fd[16];
     int Lx, Ld;
     float* out;
+    float* stash;      // TRAIN launches: the activation stash of the fp32 backward kernels
+    NhStashLayout sl;
+    int64_t nt;        // 32-sample tiles of the launch (4 per 128-sample group)
 };
 
-template <int W, bool VIEW>
+// TRAIN (NERFHIP_PRECISION_BF16X3_FWD plans): the launch also writes the activation stash -- encoding slots, every layer's
+// fp32 output rows as computed here, ReLU masks -- in the format k_mlp_dgrad16 / k_wgrad read
+template <int W, bool VIEW, bool TRAIN>
 NH_KERNEL void NH_LB(256, BShape<W>::WAVES_PER_SIMD) k_mlp_fwd_bf16x3(FwdBArgs a) {
     constexpr int TH = BShape<W>::TH, KBH = BShape<W>::KBH, BUF = BShape<W>::BUF, XB = NHB_XBLOCKS, DB = NHB_DBLOCKS;
     NH_DYN_LDS(lds_raw);
@@ -263,15 +332,27 @@ NH_KERNEL void NH_LB(256, BShape<W>::WAVES_PER_SIMD) k_mlp_fwd_bf16x3(FwdBArgs a
     const int64_t m = grp * 128 + cx.wave * 32 + (cx.lane & 31);
     const bool valid = m < a.M;
     const int64_t mc = valid ? m : a.M - 1;
+    // training: this sample's row of a stash region ([32-sample tile][sample][rows]; whole groups are written, clamped
+    // samples included), and the mask words of its 16-sample tile ([tile][mask][64 lanes][2 words])
+    const int s32 = cx.lane & 31;
+    const int64_t tile32 = grp * 4 + cx.wave;
+    auto srow = [&](const NhRegion& R, int rows) -> float* {
+        return a.stash + (size_t)32 * (size_t)a.nt * (size_t)R.row_prefix + ((size_t)tile32 * 32 + (size_t)s32) * (size_t)rows;
+    };
+    auto smask = [&](int idx) -> unsigned* {
+        return (unsigned*)(a.stash + (size_t)32 * (size_t)a.nt * (size_t)a.sl.total_rows) +
+               ((size_t)(tile32 * 2 + (s32 >> 4)) * (size_t)a.sl.n_masks + (size_t)idx) * 128;
+    };
     nh_bf16x8 xh[XB], xl[XB];
     const int ray_i = a.mode == 0 ? 0 : (int)(mc / a.S);
     if (a.mode == 0) {
-        gather_b<XB>(xh, xl, a.x + (size_t)mc * (size_t)(a.dx + a.dd), a.xcol, h);
+        gather_b<XB>(xh, xl, a.x + (size_t)mc * (size_t)(a.dx + a.dd), a.xcol, h, TRAIN ? srow(a.sl.X, 16 * XB) : nullptr);
     } else {
         const float* const rr = a.rays + (size_t)ray_i * a.ray_stride;
         const float zz = a.z[mc];
         // pts = ro + rd * z   (nerf/train_utils.py:67,107)
-        encode_b<XB>(xh, xl, rr[0] + rr[3] * zz, rr[1] + rr[4] * zz, rr[2] + rr[5] * zz, h, a.fx, a.Lx);
+        encode_b<XB>(xh, xl, rr[0] + rr[3] * zz, rr[1] + rr[4] * zz, rr[2] + rr[5] * zz, h, a.fx, a.Lx,
+                     TRAIN ? srow(a.sl.X, 16 * XB) : nullptr);
     }
 
     f32x16 acc[TH + 1];
@@ -282,6 +363,7 @@ NH_KERNEL void NH_LB(256, BShape<W>::WAVES_PER_SIMD) k_mlp_fwd_bf16x3(FwdBArgs a
         // no activation after layer1 (models.py:238)
         gemm_b<W, TH, 0, XB, 2, TH>(cx, nullptr, nullptr, xh, xl, po.f_layer1 * 4, (more ? po.f_xyz[0] : po.f_head) * 4,
                                     more ? first(KBH, TH) : (VIEW ? first(KBH, TH + 1) : first(KBH, 1)), acc, hh, hl);
+        if (TRAIN) stash_rows<TH, false>(srow(a.sl.H[0], W), h, acc);
     }
     for (int i = 0; i < a.L - 1; ++i) {
         const bool sk = (i % a.skip == 0) && i > 0;
@@ -294,19 +376,31 @@ NH_KERNEL void NH_LB(256, BShape<W>::WAVES_PER_SIMD) k_mlp_fwd_bf16x3(FwdBArgs a
         else
             gemm_b<W, TH, KBH, 0, 1, TH>(cx, hh, hl, nullptr, nullptr, po.f_xyz[i] * 4, nxt, nfirst, acc, nh, nl);
         copy_blocks<KBH>(hh, hl, nh, nl);
+        if (TRAIN) {  // H_{i+1} = relu(layers_xyz[i](..)) and its mask i
+            stash_rows<TH, true>(srow(a.sl.H[i + 1], W), h, acc);
+            stash_mask<TH>(smask(i), s32, h, acc);
+        }
     }
     if (VIEW) {
         nh_bf16x8 dh[DB], dl[DB];
         if (a.mode == 0) {
-            gather_b<DB>(dh, dl, a.x + (size_t)mc * (size_t)(a.dx + a.dd) + a.dx, a.dcol, h);
+            gather_b<DB>(dh, dl, a.x + (size_t)mc * (size_t)(a.dx + a.dd) + a.dx, a.dcol, h, TRAIN ? srow(a.sl.D, 16 * DB) : nullptr);
         } else {
             const float* const rr = a.rays + (size_t)ray_i * a.ray_stride;
-            encode_b<DB>(dh, dl, rr[8], rr[9], rr[10], h, a.fd, a.Ld);
+            encode_b<DB>(dh, dl, rr[8], rr[9], rr[10], h, a.fd, a.Ld, TRAIN ? srow(a.sl.D, 16 * DB) : nullptr);
         }
         // tiles 0..TH-1: feat = relu(fc_feat(h)); tile TH row 0: fc_alpha(h), raw (models.py:248-249)
         gemm_b<W, TH + 1, KBH, 0, 1, TH>(cx, hh, hl, nullptr, nullptr, po.f_head * 4, po.f_dir * 4, first(KBH + DB, TH / 2), acc, nh, nl);
         const float alpha = acc[TH][0];
+        if (TRAIN) {  // FEAT and its mask L - 1
+            stash_rows<TH, true>(srow(a.sl.FEAT, W), h, acc);
+            stash_mask<TH>(smask(a.L - 1), s32, h, acc);
+        }
         gemm_b<W, TH / 2, KBH, DB, 1, TH / 2>(cx, nh, nl, dh, dl, po.f_dir * 4, po.f_rgb * 4, first(KBH / 2, 1), acc, hh, hl);
+        if (TRAIN) {  // DIRH and its mask L
+            stash_rows<TH / 2, true>(srow(a.sl.DIRH, W / 2), h, acc);
+            stash_mask<TH / 2>(smask(a.L), s32, h, acc);
+        }
         gemm_b<W, 1, KBH / 2, 0>(cx, hh, hl, nullptr, nullptr, po.f_rgb * 4, po.f_layer1 * 4, again ? first(XB, TH) : 0, acc);
         if (valid && h == 0) {
             float4 r4;
@@ -333,12 +427,13 @@ NH_KERNEL void NH_LB(256, BShape<W>::WAVES_PER_SIMD) k_mlp_fwd_bf16x3(FwdBArgs a
 // ---- weight image --------------------------------------------------------------------------------------------------
 struct PackBArgs {
     int n_layers;
+    int64_t first;  // first word of the split-bf16 images (what lies in front is the fp32 image)
     int64_t base[NH_MAX_LAYERS + 5];  // word offset of every layer image, ascending
 };
 
 NH_KERNEL void k_pack_bf16x3(const float* __restrict__ params, const int32_t* __restrict__ table, int64_t n, PackBArgs la,
                              float* __restrict__ packed) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = la.first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int l = 0;
     while (l + 1 < la.n_layers && i >= la.base[l + 1]) ++l;
@@ -391,17 +486,20 @@ int b_lds_limit(K kern, int bytes) {
 
 }  // namespace
 
-int nh_mlp_bf16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out,
+int nh_mlp_bf16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
                         nerfhip_stream_t stream) {
     NH_REQUIRE(M < ((int64_t)1 << 31), "mlp_fwd: at most 2^31 - 1 sample points per call (got %lld)", (long long)M);
     FwdBArgs a;
     memset(&a, 0, sizeof(a));
     a.packed = packed;
     a.packed_bytes = (unsigned)(p->packed_floats * 4);
-    a.off = p->po;
+    a.off = p->pob;
     a.L = p->L;
     a.skip = p->skip;
     a.M = M;
+    a.stash = stash;
+    a.sl = p->stash;
+    a.nt = nh_ceil_div(M, 128) * 4;
     a.mode = in.mode;
     a.x = in.x;
     a.dx = p->Dx;
@@ -428,11 +526,18 @@ int nh_mlp_bf16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& 
 #endif
     const int64_t grid = groups < resident ? groups : resident;
     int rc = NERFHIP_OK;
-#define NH_FWDB(WW, VV)                                                                                    \
+#define NH_FWDB_T(WW, VV, TT)                                                                              \
     {                                                                                                      \
-        rc = b_lds_limit(k_mlp_fwd_bf16x3<WW, VV>, BShape<WW>::LDS_BYTES);                                 \
+        rc = b_lds_limit(k_mlp_fwd_bf16x3<WW, VV, TT>, BShape<WW>::LDS_BYTES);                             \
         if (rc) return rc;                                                                                 \
-        NH_LAUNCH((k_mlp_fwd_bf16x3<WW, VV>), grid, 256, BShape<WW>::LDS_BYTES, stream, a);               \
+        NH_LAUNCH((k_mlp_fwd_bf16x3<WW, VV, TT>), grid, 256, BShape<WW>::LDS_BYTES, stream, a);           \
+    }
+#define NH_FWDB(WW, VV)              \
+    {                                \
+        if (stash)                   \
+            NH_FWDB_T(WW, VV, true)  \
+        else                         \
+            NH_FWDB_T(WW, VV, false) \
     }
     if (p->W == 256 && p->view) NH_FWDB(256, true)
     else if (p->W == 256) NH_FWDB(256, false)
@@ -443,6 +548,7 @@ int nh_mlp_bf16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& 
         return NERFHIP_ERR_UNSUPPORTED;
     }
 #undef NH_FWDB
+#undef NH_FWDB_T
     return nh_launch_status("mlp_fwd_bf16x3");
 }
 
@@ -450,10 +556,15 @@ extern "C" int nerfhip_pack_weights_plan(nerfhip_plan_t plan, const float* param
                                          nerfhip_stream_t stream) {
     NH_REQUIRE(plan && params && table && packed, "pack_weights_plan: bad arguments");
     const int64_t n = plan->packed_floats;
-    if (plan->precision != NERFHIP_PRECISION_BF16X3) return nerfhip_pack_weights(params, table, n, packed, stream);
+    if (plan->precision == NERFHIP_PRECISION_FP32) return nerfhip_pack_weights(params, table, n, packed, stream);
+    const int64_t n32 = plan->packed32_floats;  // (BF16X3_FWD: the fp32 image in front -- a plain gather)
+    if (n32 > 0) {
+        const int rc = nerfhip_pack_weights(params, table, n32, packed, stream);
+        if (rc) return rc;
+    }
     PackBArgs la;
     memset(&la, 0, sizeof(la));
-    const NhPackedOffsets& o = plan->po;
+    const NhPackedOffsets& o = plan->pob;
     int k = 0;
     la.base[k++] = o.f_layer1;
     for (int i = 0; i < plan->L - 1; ++i) la.base[k++] = o.f_xyz[i];
@@ -463,6 +574,7 @@ extern "C" int nerfhip_pack_weights_plan(nerfhip_plan_t plan, const float* param
         la.base[k++] = o.f_rgb;
     }
     la.n_layers = k;
-    NH_LAUNCH(k_pack_bf16x3, nh_ceil_div(n, 256), 256, 0, stream, params, table, n, la, packed);
+    la.first = n32;
+    NH_LAUNCH(k_pack_bf16x3, nh_ceil_div(n - n32, 256), 256, 0, stream, params, table, n, la, packed);
     return nh_launch_status("pack_weights_plan");
 }

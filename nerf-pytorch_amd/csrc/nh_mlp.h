@@ -25,7 +25,7 @@ int nh_mlp16_dgrad(nerfhip_plan* p, const float* packed, const float* g_out, int
                    nerfhip_stream_t stream);
 
 // mlp_bf16.hip: the split-bf16 inference forward of NERFHIP_PRECISION_BF16X3 plans (no stash)
-int nh_mlp_bf16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out,
+int nh_mlp_bf16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
                         nerfhip_stream_t stream);
 
 // wgrad.hip: split-K weight-gradient GEMMs over the stash / d(pre-activation) images (nt = 32-sample tiles) + reduction

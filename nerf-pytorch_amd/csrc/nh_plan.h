@@ -132,7 +132,9 @@ struct nerfhip_plan {
     int64_t nparams;
     int t_layer1_w, t_layer1_b, t_xyz_w[NH_MAX_LAYERS], t_xyz_b[NH_MAX_LAYERS];
     int t_dir_w, t_dir_b, t_alpha_w, t_alpha_b, t_rgb_w, t_rgb_b, t_feat_w, t_feat_b, t_out_w, t_out_b;
-    int precision;                    // NERFHIP_PRECISION_FP32 | NERFHIP_PRECISION_BF16X3 (inference-only plan: mlp_bf16.hip)
+    int precision;                    // NERFHIP_PRECISION_FP32 | _BF16X3 (inference-only plan) | _BF16X3_FWD (bf16x3 forward, fp32 backward)
+    NhPackedOffsets pob;              // bf16x3 plans: word offsets of the split-bf16 layer images inside the packed buffer
+    int64_t packed32_floats;          // words of the fp32 image in front of them (0 for _BF16X3, the whole buffer for _FP32)
     int xyz_slot_b[16 * NHB_XBLOCKS];  // bf16x3 plans: encoding slot -> reference column, or -1
     int dir_slot_b[16 * NHB_DBLOCKS];
     int krx, krd;                     // encoding registers per lane group: NH16_KRX / NH16_KRD or the _EXT pair

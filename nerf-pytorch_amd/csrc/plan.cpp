@@ -336,15 +336,17 @@ void fill_spec_b(const GemmSpecB& s, int64_t off, int32_t* table) {
                     img[(((int64_t)kb * s.nt + t) * 64 + lane) * 8 + e] = (int32_t)s.w(32 * t + (lane & 31), kb, lane >> 5, e);
 }
 
-void layout_packed_b(nerfhip_plan* p) {
-    int64_t off = 0;
-    memset(&p->po, 0, sizeof(p->po));
+// the split-bf16 layer images, behind the first `base` words of the packed buffer
+void layout_packed_b(nerfhip_plan* p, int64_t base) {
+    int64_t off = base;
+    memset(&p->pob, 0, sizeof(p->pob));
     SpecsB S;
     build_specs_b(p, S);
-    for_each_spec_b(p, S, p->po, [&](const GemmSpecB& s, int64_t* dst) {
+    for_each_spec_b(p, S, p->pob, [&](const GemmSpecB& s, int64_t* dst) {
         *dst = off;
         off += nhb_image_words(s.nk, s.nt);
     });
+    p->packed32_floats = base;
     p->packed_floats = off;
 }
 
@@ -552,7 +554,7 @@ void build_layouts_and_jobs(nerfhip_plan* p) {
 static nerfhip_plan_t plan_create_impl(const nerfhip_model_cfg* cfg, int precision);
 extern "C" nerfhip_plan_t nerfhip_plan_create(const nerfhip_model_cfg* cfg) { return plan_create_impl(cfg, NERFHIP_PRECISION_FP32); }
 extern "C" nerfhip_plan_t nerfhip_plan_create_ex(const nerfhip_model_cfg* cfg, int precision) {
-    if (precision != NERFHIP_PRECISION_FP32 && precision != NERFHIP_PRECISION_BF16X3) {
+    if (precision != NERFHIP_PRECISION_FP32 && precision != NERFHIP_PRECISION_BF16X3 && precision != NERFHIP_PRECISION_BF16X3_FWD) {
         nh_set_error("plan_create_ex: unknown precision %d", precision);
         return nullptr;
     }
@@ -649,8 +651,8 @@ static nerfhip_plan_t plan_create_impl(const nerfhip_model_cfg* cfg, int precisi
         p->freqs_xyz[k] = 0.f;
         p->freqs_dir[k] = 0.f;
     }
-    if (precision == NERFHIP_PRECISION_BF16X3) {
-        // inference-only plan: the split-bf16 forward kernel exists for the 128- and 256-wide nets with the reference's own
+    if (precision != NERFHIP_PRECISION_FP32) {
+        // split-bf16 forward: the split-bf16 forward kernel exists for the 128- and 256-wide nets with the reference's own
         // encoding sizes; everything else is the fp32 path's business
         const bool okx = build_slot_map_b(cfg->num_encoding_fn_xyz, cfg->include_input_xyz ? 1 : 0, 16 * NHB_XBLOCKS, p->xyz_slot_b);
         const bool okd = build_slot_map_b(p->view ? cfg->num_encoding_fn_dir : 0, (p->view && cfg->include_input_dir) ? 1 : 0,
@@ -661,9 +663,19 @@ static nerfhip_plan_t plan_create_impl(const nerfhip_model_cfg* cfg, int precisi
             delete p;
             return nullptr;
         }
-        layout_packed_b(p);
+        memset(&p->po, 0, sizeof(p->po));
+        p->packed_floats = 0;
+        if (precision == NERFHIP_PRECISION_BF16X3_FWD) {
+            layout_packed(p);  // the fp32 image: its transposed layers feed the data-gradient kernel
+            // the training forward stores the encodings in ITS slot order: that is what the weight-gradient scatter must undo
+            for (int row = 0; row < 4 * NH16_KRX_EXT; ++row) p->xyz_slot_col[row] = row < 16 * NHB_XBLOCKS ? p->xyz_slot_b[row] : -1;
+            for (int row = 0; row < 4 * NH16_KRD_EXT; ++row) p->dir_slot_col[row] = row < 16 * NHB_DBLOCKS ? p->dir_slot_b[row] : -1;
+        }
+        layout_packed_b(p, p->packed_floats);
     } else {
         layout_packed(p);
+        p->packed32_floats = p->packed_floats;
+        memset(&p->pob, 0, sizeof(p->pob));
     }
     build_layouts_and_jobs(p);
     if ((int)p->jobs.size() > NH_MAX_JOBS) {
@@ -711,12 +723,12 @@ extern "C" int nerfhip_plan_describe(nerfhip_plan_t plan, char* buf, int64_t cap
 
 extern "C" int nerfhip_plan_pack_index(nerfhip_plan_t plan, int32_t* host_table) {
     NH_REQUIRE(plan && host_table, "plan_pack_index: bad arguments");
-    if (plan->precision == NERFHIP_PRECISION_BF16X3) {
+    if (plan->precision != NERFHIP_PRECISION_FP32) {
         SpecsB S;
         build_specs_b(plan, S);
-        NhPackedOffsets o = plan->po;
+        NhPackedOffsets o = plan->pob;
         for_each_spec_b(plan, S, o, [&](const GemmSpecB& s, int64_t* dst) { fill_spec_b(s, *dst, host_table); });
-        return NERFHIP_OK;
+        if (plan->precision == NERFHIP_PRECISION_BF16X3) return NERFHIP_OK;
     }
     Specs16 S16;
     build_specs16(plan, S16);

@@ -328,7 +328,7 @@ def case_mlp_forward(b, names=None, m=70):
         b.lib.plan_destroy(plan)
 
 
-BF16X3 = 1  # NERFHIP_PRECISION_BF16X3
+BF16X3, BF16X3_FWD = 1, 2  # NERFHIP_PRECISION_BF16X3, NERFHIP_PRECISION_BF16X3_FWD
 BF16X3_GEOMETRIES = ("default4x128", "northstar8x256", "fern8x128_skip3_L6", "novw4x128", "two_layer_L4_L2", "one_layer",
                      "one_layer_novw_256", "skip_every_layer_256", "noinput_linear", "odd5x99_skip2", "wide3x200_skip1",
                      "novw2x130")
@@ -374,10 +374,15 @@ def case_mlp_golden(b):
         b.lib.plan_destroy(plan)
 
 
-def case_mlp_backward(b, names=None, m=150):
+def case_mlp_backward(b, names=None, m=150, precision=0):
+    """precision = BF16X3_FWD: the training forward on the split-bf16 kernel (its stash: slots in ITS order, fp32 rows as it
+    computed them, ReLU masks in the data-gradient kernel's lane layout), the backward kernels unchanged.  The gradient is
+    then the fp32 gradient at activations carrying ~1e-5 relative error: bounds 20x the fp32 path's, rows whose ReLU
+    decisions are closer than 1e-4 (relative) to zero dropped (a third of them: hundreds of units per row)."""
+    margin, tol = (1e-6, 2e-5) if not precision else (1e-4, 4e-4)
     for name in names or ("default4x128", "deep8x128_skip4", "fern8x128_skip3_L6", "novw4x128"):
         cfg = MLP_GEOMETRIES[name]
-        plan, params, flat, packed = mlp_setup(b, cfg, seed=41)
+        plan, params, flat, packed = mlp_setup(b, cfg, seed=41, precision=precision)
         dx, dd = O.model_dims(cfg)
         gen = rng(42)
         x = torch.randn(m, dx + dd, generator=gen)
@@ -385,9 +390,9 @@ def case_mlp_backward(b, names=None, m=150):
         # rows with a ReLU input within 1e-6 (relative) of zero are dropped: their branch is decided by fp32 round-off, the
         # kernel's k-ordered sums and torch's GEMM may disagree, and ONE such unit moves the gradient by 1e-2 of max|g|
         # (seen on MI355X and on the emulator alike: sample 136 of seed 42 for the 3x512 net, pre-activation 3.7e-9)
-        keep = O.mlp_relu_margin(params, x, cfg) > 1e-6
+        keep = O.mlp_relu_margin(params, x, cfg) > margin
         x, go = x[keep].contiguous(), go[keep].contiguous()
-        assert x.shape[0] >= 0.9 * m, (x.shape[0], m)
+        assert x.shape[0] >= (0.9 if not precision else 0.4) * m, (x.shape[0], m)
         p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
         (O.mlp_forward(p, x, cfg) * go).sum().backward()
         got_y, stash = b.mlp_fwd(plan, packed, x.numpy(), want_stash=True)
@@ -396,7 +401,7 @@ def case_mlp_backward(b, names=None, m=150):
         for k, v in p.items():
             ref = v.grad.numpy()
             scale = float(np.abs(ref).max()) + 1e-12
-            close(grads[k], ref, 2e-5 * scale + 1e-7, 2e-4, what="mlp bwd %s %s" % (name, k))
+            close(grads[k], ref, tol * scale + 1e-7, 10 * tol, what="mlp bwd %s %s" % (name, k))
         b.lib.plan_destroy(plan)
 
 
@@ -498,11 +503,12 @@ def case_e2e_northstar_golden(b):
 
 
 def case_render_vs_oracle(b, cfg, n, nc, nf, seed=5, white=False, noise=0.3, with_grads=False, tol=1e-4,
-                          grad_tol=(1e-3, 5e-3), tag=""):
-    """Fused render against the oracle on random-init nets of an arbitrary geometry (e.g. the 8x256 north star)."""
+                          grad_tol=(1e-3, 5e-3), tag="", precision=0):
+    """Fused render against the oracle on random-init nets of an arbitrary geometry (e.g. the 8x256 north star).
+    precision = BF16X3_FWD: both nets' forwards on the split-bf16 kernel (coarse maps then carry its ~1e-5, not fp32 round-off)."""
     gen = rng(seed)
-    pc, par_c, _, packed_c = mlp_setup(b, cfg, seed=seed + 1)
-    pf, par_f, _, packed_f = mlp_setup(b, cfg, seed=seed + 2)
+    pc, par_c, _, packed_c = mlp_setup(b, cfg, seed=seed + 1, precision=precision)
+    pf, par_f, _, packed_f = mlp_setup(b, cfg, seed=seed + 2, precision=precision)
     ro = torch.tensor([0.2, -0.1, 4.0]).expand(n, 3) + 0.05 * torch.randn(n, 3, generator=gen)
     rd = torch.randn(n, 3, generator=gen) * 0.3
     rd[:, 2] = -1.0
@@ -521,7 +527,7 @@ def case_render_vs_oracle(b, cfg, n, nc, nf, seed=5, white=False, noise=0.3, wit
     # weights (measured on MI355X, 8x256 random init, 256 rays: HIP-vs-CPU rgb_fine 1.5e-5 / acc_fine 2.9e-5, while
     # PyTorch-ROCm-vs-CPU is 2.7e-5 / 5.3e-5; profiles/r01_error_floor.txt) -- rgb keeps the 1e-4 north-star bar.
     for k in ("rgb_coarse", "acc_coarse", "depth_coarse"):
-        close(out[k], want[k].detach().numpy(), 1e-5, what="render %s" % k)
+        close(out[k], want[k].detach().numpy(), 1e-5 if not precision else 1e-4, what="render %s" % k)
     close(out["rgb_fine"], want["rgb_fine"].detach().numpy(), tol, what="render rgb_fine")
     close(out["acc_fine"], want["acc_fine"].detach().numpy(), 5 * tol, what="render acc_fine")
     close(out["depth_fine"], want["depth_fine"].detach().numpy(), 20 * tol, what="render depth_fine")

@@ -93,6 +93,14 @@ def test_mlp_forward_bf16x3(emu):
     P.case_render_bf16x3(emu, P.MLP_GEOMETRIES["default4x128"], n=10, nc=8, nf=8, tag="4x128_emu")
 
 
+def test_mlp_bf16x3_forward_training_stash_feeds_the_fp32_backward(emu):
+    """NERFHIP_PRECISION_BF16X3_FWD: forward (with stash) on the split-bf16 kernel, backward on the fp32 kernels."""
+    P.case_mlp_backward(emu, names=("default4x128", "fern8x128_skip3_L6", "novw4x128", "skip_every_layer_256", "odd5x99_skip2"), m=200,
+                        precision=P.BF16X3_FWD)
+    P.case_render_vs_oracle(emu, P.MLP_GEOMETRIES["default4x128"], n=12, nc=16, nf=16, with_grads=True, tag="bf16x3_fwd_emu",
+                            tol=5e-4, grad_tol=(5e-3, 5e-2), precision=P.BF16X3_FWD)
+
+
 def test_ndc_rays_backward(emu):
     P.case_ndc_rays_bwd(emu, n=200)
 

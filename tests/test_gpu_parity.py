@@ -91,6 +91,15 @@ def test_mlp_forward_bf16x3(gpu):
     P.case_render_bf16x3(gpu, P.MLP_GEOMETRIES["northstar8x256"], n=128, nc=64, nf=128, tag="8x256_128")
 
 
+def test_mlp_bf16x3_forward_training_stash_feeds_the_fp32_backward(gpu):
+    P.case_mlp_backward(gpu, names=("default4x128", "fern8x128_skip3_L6", "novw4x128", "skip_every_layer_256", "odd5x99_skip2",
+                                    "northstar8x256"), m=1500, precision=P.BF16X3_FWD)
+    P.case_render_vs_oracle(gpu, P.MLP_GEOMETRIES["default4x128"], n=200, nc=64, nf=64, with_grads=True, tag="bf16x3_fwd_4x128_200",
+                            tol=5e-4, grad_tol=(5e-3, 5e-2), precision=P.BF16X3_FWD)
+    P.case_render_vs_oracle(gpu, P.MLP_GEOMETRIES["northstar8x256"], n=48, nc=64, nf=128, with_grads=True, tag="bf16x3_fwd_8x256_48",
+                            tol=5e-4, grad_tol=(5e-3, 5e-2), precision=P.BF16X3_FWD)
+
+
 def test_ndc_rays_backward(gpu):
     P.case_ndc_rays_bwd(gpu, n=5000)
 

@@ -71,16 +71,41 @@ NH_DEVICE void convert_tile(const f32x16& acc, nh_bf16x8* oh, nh_bf16x8* ol) {
 }
 
 // EPI (0: none; 1: ReLU; 2: identity): the first NTE output tiles leave as the next layer's operand pieces oh / ol (k-blocks
-// 2 t, 2 t + 1 from tile t), converted after the layer's last chunk.  (Converting each tile of the last chunk as it
+// 2 t, 2 t + 1 from tile t; they may be the inputs themselves), converted after the layer's last chunk.  (Converting each tile of the last chunk as it
 // completes, in the shadow of the next tile's MFMAs, measured 3 % SLOWER on MI355X: the second set of operand registers it
 // needs takes the VGPR file to its limit -- profiles/r03_variant_ab.txt section 7.)
 // acc[t] = bias + sum over NKA activation k-blocks (ah/al) and NKB encoding k-blocks (xh/xl) of this layer's image at byte
 // offset `base`; while the last chunk is multiplied the first chunk of the next layer (next_base, next_first bytes) travels.
+template <int NB>
+NH_DEVICE void stash_mask_in(unsigned* tile16_mask, int s, int h, const nh_bf16x8* vh);
+
+// in_rows / in_mask (training launches, else NULL): the gemm stores ITS OWN activation inputs -- the previous layer's output
+// as the operand pieces say it, hi + lo, i.e. exactly the values this layer consumes -- into that layer's stash region,
+// one k-block (two 16-byte stores) every other block of its first chunk, under the MFMAs, and the ReLU bits of the same
+// values in the data-gradient kernel's lane layout (as mlp16.hip: "every gemm stores its own input rows").
 template <int W, int NT, int NKA, int NKB, int EPI = 0, int NTE = 0>
 NH_DEVICE void gemm_b(BCtx& cx, const nh_bf16x8* ah, const nh_bf16x8* al, const nh_bf16x8* xh, const nh_bf16x8* xl, int64_t base,
-                      int64_t next_base, int next_first, f32x16* acc, nh_bf16x8* oh = nullptr, nh_bf16x8* ol = nullptr) {
+                      int64_t next_base, int next_first, f32x16* acc, nh_bf16x8* oh = nullptr, nh_bf16x8* ol = nullptr,
+                      float* in_rows = nullptr, unsigned* in_mask = nullptr, int s32 = 0) {
     constexpr int NK = NKA + NKB, BUF = BShape<W>::BUF, CH = BShape<W>::CHUNK / (NT * 2048), NCH = (NK + CH - 1) / CH;
     static_assert(CH >= 1, "a k-block of every tile must fit one chunk buffer");
+    if (in_mask) stash_mask_in<NKA>(in_mask, s32, cx.h, ah);
+    int srow_next = 0;  // next input k-block whose rows go out
+    auto store_step = [&](int kb) {
+        float4 a4, b4;
+        a4.x = nh_from_bf16(ah[kb][0]) + nh_from_bf16(al[kb][0]);
+        a4.y = nh_from_bf16(ah[kb][1]) + nh_from_bf16(al[kb][1]);
+        a4.z = nh_from_bf16(ah[kb][2]) + nh_from_bf16(al[kb][2]);
+        a4.w = nh_from_bf16(ah[kb][3]) + nh_from_bf16(al[kb][3]);
+        b4.x = nh_from_bf16(ah[kb][4]) + nh_from_bf16(al[kb][4]);
+        b4.y = nh_from_bf16(ah[kb][5]) + nh_from_bf16(al[kb][5]);
+        b4.z = nh_from_bf16(ah[kb][6]) + nh_from_bf16(al[kb][6]);
+        b4.w = nh_from_bf16(ah[kb][7]) + nh_from_bf16(al[kb][7]);
+        float* const dst = in_rows + 32 * (kb >> 1) + 16 * (kb & 1) + 4 * cx.h;  // units nhb_unit(kb, h, 0..3) and (kb, h, 4..7) = + 8
+        *(float4*)dst = a4;
+        *(float4*)(dst + 8) = b4;
+    };
+    (void)srow_next;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         nh_wait_vmem();    // this wave's pieces of the current chunk have landed ...
@@ -147,6 +172,9 @@ NH_DEVICE void gemm_b(BCtx& cx, const nh_bf16x8* ah, const nh_bf16x8* al, const 
 #if NHB_DMA_EVERY > 0
                 if (i % NHB_DMA_EVERY == 0) dma_step();
 #endif
+                if (NKA > 0 && c == 0 && i % 2 == 0 && i / 2 < NKA) {
+                    if (in_rows) store_step(i / 2);
+                }
                 if (i + PF < nblk) load(i + PF);
                 nh_sched_fence();
                 const int kb = c * CH + kk_of(i), t = t_of(i);
@@ -159,20 +187,16 @@ NH_DEVICE void gemm_b(BCtx& cx, const nh_bf16x8* ah, const nh_bf16x8* al, const 
             }
         }
         while (dnext < dpieces) dma_step();  // (whatever the blocks did not cover: short chunks in front of long ones)
+        if (NKA > 0 && c == 0 && in_rows) {
+#pragma unroll
+            for (int kb = 0; kb < NKA; ++kb)
+                if (kb >= (nblk + 1) / 2) store_step(kb);  // (first chunks with fewer than 2 NKA blocks: the rgb / fc_out gemms)
+        }
         cx.buf ^= 1;
     }
     if (EPI != 0) {
 #pragma unroll
         for (int t = 0; t < NTE; ++t) convert_tile<EPI == 1>(acc[t], oh + 2 * t, ol + 2 * t);
-    }
-}
-
-template <int NB>
-NH_DEVICE void copy_blocks(nh_bf16x8* dh, nh_bf16x8* dl, const nh_bf16x8* sh, const nh_bf16x8* sl) {
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        dh[k] = sh[k];
-        dl[k] = sl[k];
     }
 }
 
@@ -236,43 +260,27 @@ NH_DEVICE void gather_b(nh_bf16x8* oh, nh_bf16x8* ol, const float* row, const si
 }
 
 // ---- the training stash (NERFHIP_PRECISION_BF16X3_FWD): what the fp32 backward kernels read (nh_plan.h NhStashLayout) ------
-// rows of NT output tiles of this lane's sample: register 4 j + i of tile t is row 32 t + 8 j + 4 h + i -> one 16-byte store
-template <int NT, bool RELU>
-NH_DEVICE void stash_rows(float* sample_row, int h, const f32x16* acc) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float4 r4;
-            r4.x = RELU ? nh_relu(acc[t][4 * j]) : acc[t][4 * j];
-            r4.y = RELU ? nh_relu(acc[t][4 * j + 1]) : acc[t][4 * j + 1];
-            r4.z = RELU ? nh_relu(acc[t][4 * j + 2]) : acc[t][4 * j + 2];
-            r4.w = RELU ? nh_relu(acc[t][4 * j + 3]) : acc[t][4 * j + 3];
-            *(float4*)(sample_row + 32 * t + 8 * j + 4 * h) = r4;
-        }
-}
-// ReLU bits in the data-gradient kernel's layout (mlp16.hip finish() / nh16_bitpos): its lane (sample & 15, g) holds unit
-// 16 (r >> 2) + 4 g + (r & 3) in register r; of its n = 8 NT registers, r sits in word r >> 5 at bit
-// min(32, n - 32 (r >> 5)) - 1 - (r & 31).  This lane's units 32 t + 8 j + 4 h + i are register 4 (2 t + (j >> 1)) + i of the
-// two lanes g = 2 (j & 1) + h: it writes both lanes' words whole -- no exchange between lanes.
-template <int NT>
-NH_DEVICE void stash_mask(unsigned* tile16_mask, int s, int h, const f32x16* acc) {
-    constexpr int n = 8 * NT;
+// ReLU bits of a layer's NB k-blocks of operand pieces (value > 0 <=> its high piece > 0) in the data-gradient kernel's
+// layout (mlp16.hip finish() / nh16_bitpos): its lane (sample & 15, g) holds unit 16 (r >> 2) + 4 g + (r & 3) in register r; of
+// its n = 4 NB registers, r sits in word r >> 5 at bit min(32, n - 32 (r >> 5)) - 1 - (r & 31).  This lane's element e of
+// k-block kb is unit 32 (kb >> 1) + 16 (kb & 1) + 8 (e >> 2) + 4 h + (e & 3) = register 4 kb + (e & 3) of the lane
+// g = 2 (e >> 2) + h: it writes both lanes' words whole -- no exchange between lanes.
+template <int NB>
+NH_DEVICE void stash_mask_in(unsigned* tile16_mask, int s, int h, const nh_bf16x8* vh) {
+    constexpr int n = 4 * NB;
 #pragma unroll
     for (int jb = 0; jb < 2; ++jb) {
         unsigned w0 = 0u, w1 = 0u;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
-            for (int jh = 0; jh < 2; ++jh)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = 4 * (2 * t + jh) + i, word = r >> 5;
-                    const int pos = ((n - 32 * word) < 32 ? (n - 32 * word) : 32) - 1 - (r & 31);
-                    const unsigned bit = acc[t][4 * (2 * jh + jb) + i] > 0.0f ? 1u : 0u;
-                    if (word == 0) w0 |= bit << pos;
-                    else w1 |= bit << pos;
-                }
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * kb + i, word = r >> 5;
+                const int pos = ((n - 32 * word) < 32 ? (n - 32 * word) : 32) - 1 - (r & 31);
+                const unsigned bit = nh_from_bf16(vh[kb][4 * jb + i]) > 0.0f ? 1u : 0u;
+                if (word == 0) w0 |= bit << pos;
+                else w1 |= bit << pos;
+            }
         unsigned* dst = tile16_mask + ((s & 15) + 16 * (2 * jb + h)) * 2;
         dst[0] = w0;
         dst[1] = w1;
@@ -304,8 +312,10 @@ struct FwdBArgs {
 
 // TRAIN (NERFHIP_PRECISION_BF16X3_FWD plans): the launch also writes the activation stash -- encoding slots, every layer's
 // fp32 output rows as computed here, ReLU masks -- in the format k_mlp_dgrad16 / k_wgrad read
+// (register budget: two waves per SIMD for the 128-wide inference kernel; the training one needs ~300 registers with its
+// store addresses and runs one wave per SIMD like the 256-wide kernels rather than spill)
 template <int W, bool VIEW, bool TRAIN>
-NH_KERNEL void NH_LB(256, BShape<W>::WAVES_PER_SIMD) k_mlp_fwd_bf16x3(FwdBArgs a) {
+NH_KERNEL void NH_LB(256, (TRAIN ? 1 : BShape<W>::WAVES_PER_SIMD)) k_mlp_fwd_bf16x3(FwdBArgs a) {
     constexpr int TH = BShape<W>::TH, KBH = BShape<W>::KBH, BUF = BShape<W>::BUF, XB = NHB_XBLOCKS, DB = NHB_DBLOCKS;
     NH_DYN_LDS(lds_raw);
     BCtx cx;
@@ -356,14 +366,13 @@ NH_KERNEL void NH_LB(256, BShape<W>::WAVES_PER_SIMD) k_mlp_fwd_bf16x3(FwdBArgs a
     }
 
     f32x16 acc[TH + 1];
-    nh_bf16x8 hh[KBH], hl[KBH];  // the current activations as operand pieces
-    nh_bf16x8 nh[KBH], nl[KBH];  // the next ones, filled tile by tile while the layer's last chunk is multiplied
+    nh_bf16x8 hh[KBH], hl[KBH];  // the current activations as operand pieces (a layer's output replaces them in place:
+                                 // the conversion runs after the layer's last MFMA)
     {
         const bool more = a.L > 1;
         // no activation after layer1 (models.py:238)
         gemm_b<W, TH, 0, XB, 2, TH>(cx, nullptr, nullptr, xh, xl, po.f_layer1 * 4, (more ? po.f_xyz[0] : po.f_head) * 4,
                                     more ? first(KBH, TH) : (VIEW ? first(KBH, TH + 1) : first(KBH, 1)), acc, hh, hl);
-        if (TRAIN) stash_rows<TH, false>(srow(a.sl.H[0], W), h, acc);
     }
     for (int i = 0; i < a.L - 1; ++i) {
         const bool sk = (i % a.skip == 0) && i > 0;
@@ -371,15 +380,13 @@ NH_KERNEL void NH_LB(256, BShape<W>::WAVES_PER_SIMD) k_mlp_fwd_bf16x3(FwdBArgs a
         const bool nsk = more && ((i + 1) % a.skip == 0);
         const int64_t nxt = (more ? po.f_xyz[i + 1] : po.f_head) * 4;
         const int nfirst = more ? (nsk ? first(KBH + XB, TH) : first(KBH, TH)) : (VIEW ? first(KBH, TH + 1) : first(KBH, 1));
+        // (training: the gemm stores its inputs H_i and their ReLU mask i - 1; H_0 = layer1's output has none)
+        float* const in_rows = TRAIN ? srow(a.sl.H[i], W) : nullptr;
+        unsigned* const in_mask = (TRAIN && i > 0) ? smask(i - 1) : nullptr;
         if (sk)
-            gemm_b<W, TH, KBH, XB, 1, TH>(cx, hh, hl, xh, xl, po.f_xyz[i] * 4, nxt, nfirst, acc, nh, nl);
+            gemm_b<W, TH, KBH, XB, 1, TH>(cx, hh, hl, xh, xl, po.f_xyz[i] * 4, nxt, nfirst, acc, hh, hl, in_rows, in_mask, s32);
         else
-            gemm_b<W, TH, KBH, 0, 1, TH>(cx, hh, hl, nullptr, nullptr, po.f_xyz[i] * 4, nxt, nfirst, acc, nh, nl);
-        copy_blocks<KBH>(hh, hl, nh, nl);
-        if (TRAIN) {  // H_{i+1} = relu(layers_xyz[i](..)) and its mask i
-            stash_rows<TH, true>(srow(a.sl.H[i + 1], W), h, acc);
-            stash_mask<TH>(smask(i), s32, h, acc);
-        }
+            gemm_b<W, TH, KBH, 0, 1, TH>(cx, hh, hl, nullptr, nullptr, po.f_xyz[i] * 4, nxt, nfirst, acc, hh, hl, in_rows, in_mask, s32);
     }
     if (VIEW) {
         nh_bf16x8 dh[DB], dl[DB];
@@ -390,18 +397,14 @@ NH_KERNEL void NH_LB(256, BShape<W>::WAVES_PER_SIMD) k_mlp_fwd_bf16x3(FwdBArgs a
             encode_b<DB>(dh, dl, rr[8], rr[9], rr[10], h, a.fd, a.Ld, TRAIN ? srow(a.sl.D, 16 * DB) : nullptr);
         }
         // tiles 0..TH-1: feat = relu(fc_feat(h)); tile TH row 0: fc_alpha(h), raw (models.py:248-249)
-        gemm_b<W, TH + 1, KBH, 0, 1, TH>(cx, hh, hl, nullptr, nullptr, po.f_head * 4, po.f_dir * 4, first(KBH + DB, TH / 2), acc, nh, nl);
+        // (training: each gemm stores its own inputs -- H_{L-1} and mask L - 2, FEAT and mask L - 1, DIRH and mask L)
+        gemm_b<W, TH + 1, KBH, 0, 1, TH>(cx, hh, hl, nullptr, nullptr, po.f_head * 4, po.f_dir * 4, first(KBH + DB, TH / 2), acc, hh, hl,
+                                         TRAIN ? srow(a.sl.H[a.L - 1], W) : nullptr, (TRAIN && a.L > 1) ? smask(a.L - 2) : nullptr, s32);
         const float alpha = acc[TH][0];
-        if (TRAIN) {  // FEAT and its mask L - 1
-            stash_rows<TH, true>(srow(a.sl.FEAT, W), h, acc);
-            stash_mask<TH>(smask(a.L - 1), s32, h, acc);
-        }
-        gemm_b<W, TH / 2, KBH, DB, 1, TH / 2>(cx, nh, nl, dh, dl, po.f_dir * 4, po.f_rgb * 4, first(KBH / 2, 1), acc, hh, hl);
-        if (TRAIN) {  // DIRH and its mask L
-            stash_rows<TH / 2, true>(srow(a.sl.DIRH, W / 2), h, acc);
-            stash_mask<TH / 2>(smask(a.L), s32, h, acc);
-        }
-        gemm_b<W, 1, KBH / 2, 0>(cx, hh, hl, nullptr, nullptr, po.f_rgb * 4, po.f_layer1 * 4, again ? first(XB, TH) : 0, acc);
+        gemm_b<W, TH / 2, KBH, DB, 1, TH / 2>(cx, hh, hl, dh, dl, po.f_dir * 4, po.f_rgb * 4, first(KBH / 2, 1), acc, hh, hl,
+                                              TRAIN ? srow(a.sl.FEAT, W) : nullptr, TRAIN ? smask(a.L - 1) : nullptr, s32);
+        gemm_b<W, 1, KBH / 2, 0>(cx, hh, hl, nullptr, nullptr, po.f_rgb * 4, po.f_layer1 * 4, again ? first(XB, TH) : 0, acc, nullptr, nullptr,
+                                 TRAIN ? srow(a.sl.DIRH, W / 2) : nullptr, TRAIN ? smask(a.L) : nullptr, s32);
         if (valid && h == 0) {
             float4 r4;
             r4.x = acc[0][0];
@@ -411,7 +414,8 @@ NH_KERNEL void NH_LB(256, BShape<W>::WAVES_PER_SIMD) k_mlp_fwd_bf16x3(FwdBArgs a
             *(float4*)(a.out + (size_t)m * 4) = r4;
         }
     } else {
-        gemm_b<W, 1, KBH, 0>(cx, hh, hl, nullptr, nullptr, po.f_head * 4, po.f_layer1 * 4, again ? first(XB, TH) : 0, acc);  // fc_out (models.py:256)
+        gemm_b<W, 1, KBH, 0>(cx, hh, hl, nullptr, nullptr, po.f_head * 4, po.f_layer1 * 4, again ? first(XB, TH) : 0, acc, nullptr, nullptr,
+                             TRAIN ? srow(a.sl.H[a.L - 1], W) : nullptr, (TRAIN && a.L > 1) ? smask(a.L - 2) : nullptr, s32);  // fc_out (models.py:256)
         if (valid && h == 0) {
             float4 r4;
             r4.x = acc[0][0];

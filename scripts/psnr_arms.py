@@ -9,6 +9,8 @@ MANY seeds, everything else identical per seed (initial weights, training views,
     dropin     this package behind the reference API + torch.optim.Adam; torch's draws (the numbers `ref` consumes)
     engine_td  TrainEngine (fused loss, k_adam) FED torch's draws -- differs from `dropin` only in Adam / loss kernels
     engine     TrainEngine with its in-kernel Philox draws -- differs from `engine_td` only in the random numbers
+    engine_bf16fwd  `engine` with NERFHIP_PRECISION_BF16X3_FWD nets: the forward passes on the split-bf16 kernel, the backward
+               kernels unchanged fp32 (same draws as `engine`: differs from it only in the forward's arithmetic)
 
 Scene: the teacher of scripts/psnr400.py (pretrained lego-lowres nets rendered at 400x400, 100 training / 10 held-out
 views).  Students: --hidden x --layers nets (default the reference's own 4x128: its scripts build FlexibleNeRFModel with
@@ -78,6 +80,9 @@ def run(arm, seed, iters, check, student, poses, imgs, train, views):
         ex, ed = N.get_embedding_function(10, True, True), N.get_embedding_function(4, True, True)
     else:
         mc, mf = mc.to(dev), mf.to(dev)
+        if arm == "engine_bf16fwd":  # the engine arm with both nets' forwards on the split-bf16 kernel (backward fp32)
+            mc.set_training_precision("bf16x3_fwd")
+            mf.set_training_precision("bf16x3_fwd")
         eng = N.TrainEngine(mc, mf, NC, NF, perturb=True, white_background=True, noise_std=0.2, lr=5e-3, seed=seed)
     torch.manual_seed(seed + 12345)  # the draws of the training loop: arms ref / dropin / engine_td consume the same numbers
     for i in range(1, iters + 1):

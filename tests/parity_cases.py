@@ -392,7 +392,7 @@ def case_mlp_backward(b, names=None, m=150, precision=0):
         # (seen on MI355X and on the emulator alike: sample 136 of seed 42 for the 3x512 net, pre-activation 3.7e-9)
         keep = O.mlp_relu_margin(params, x, cfg) > margin
         x, go = x[keep].contiguous(), go[keep].contiguous()
-        assert x.shape[0] >= (0.9 if not precision else 0.4) * m, (x.shape[0], m)
+        assert x.shape[0] >= (0.9 if not precision else 0.1) * m, (x.shape[0], m)   # (8x256: 2,300 units per row)
         p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
         (O.mlp_forward(p, x, cfg) * go).sum().backward()
         got_y, stash = b.mlp_fwd(plan, packed, x.numpy(), want_stash=True)

@@ -301,7 +301,7 @@ def main():
     ap.add_argument("--layers", type=int, default=MODEL["num_layers"])
     ap.add_argument("--overlap", type=int, default=-1, help="1: two-stream step (coarse backward next to the fine pass); "
                     "0: single-stream order; -1: the engine's default for the net width")
-    ap.add_argument("--precision", choices=("fp32", "bf16x3", "bf16x3_fwd"), default="fp32",
+    ap.add_argument("--precision", choices=("fp32", "bf16x3", "bf16x3_fwd", "bf16x3_fwd_dgrad"), default="fp32",
                     help="fp32 (default: the reference's arithmetic, the headline).  --mode eval --precision bf16x3: the inference "
                          "forward on the split-bf16 kernels.  --mode train --precision bf16x3_fwd: the training forward on them, "
                          "backward kernels unchanged fp32.  Both are NOT the reference's arithmetic: separate, labelled lines")
@@ -357,11 +357,11 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    if (args.mode == "train" and args.precision == "bf16x3") or (args.mode == "eval" and args.precision == "bf16x3_fwd"):
-        raise SystemExit("--precision bf16x3 goes with --mode eval, bf16x3_fwd with --mode train")
-    if args.precision == "bf16x3_fwd":
-        mc.set_training_precision("bf16x3_fwd")
-        mf.set_training_precision("bf16x3_fwd")
+    if (args.mode == "train" and args.precision == "bf16x3") or (args.mode == "eval" and args.precision.startswith("bf16x3_fwd")):
+        raise SystemExit("--precision bf16x3 goes with --mode eval, bf16x3_fwd / bf16x3_fwd_dgrad with --mode train")
+    if args.precision.startswith("bf16x3_fwd"):
+        mc.set_training_precision(args.precision)
+        mf.set_training_precision(args.precision)
     if args.mode == "train":
         strong = args.global_rays > 0
         if strong:
@@ -499,7 +499,10 @@ def main():
                    dtype="f32" if args.precision == "fp32" else
                    ("bf16x3 (fp32 operands split into two bf16 pieces, three bf16 MFMAs per product block, f32 accumulate; "
                     "fp32-equivalent FLOPs)" if args.precision == "bf16x3" else
-                    "forward bf16x3 (split-bf16 products, f32 accumulate), backward + optimizer f32; fp32-equivalent FLOPs"),
+                    ("forward bf16x3 (split-bf16 products, f32 accumulate), backward + optimizer f32; fp32-equivalent FLOPs"
+                     if args.precision == "bf16x3_fwd" else
+                     "forward + data gradient bf16x3 (split-bf16 products, f32 accumulate), weight gradient + optimizer f32; "
+                     "fp32-equivalent FLOPs")),
                    data="synthetic",
                    config=dict(workload=workload, rays_per_gpu=n, global_rays=total_rays, parallelism="dp%d" % world,
                                two_stream_step=bool(eng.overlap) if args.mode == "train" else None,

@@ -178,6 +178,9 @@ nerfhip_plan_t nerfhip_plan_create(const nerfhip_model_cfg* cfg);
  * transposed layers feed the data-gradient kernel) and the bf16 image; build it with nerfhip_pack_weights_plan.  An
  * experiment toward the north star's speed-up, accepted by PSNR@iters, not by the 1e-4 bar; opt-in. */
 #define NERFHIP_PRECISION_BF16X3_FWD 2
+/* BF16X3_FWD_DGRAD: as BF16X3_FWD, and the data-gradient chain (k_mlp_dgrad) runs on the split-bf16 kernel too; the weight-
+ * gradient GEMMs stay fp32.  Same status: opt-in experiment, accepted by PSNR@iters. */
+#define NERFHIP_PRECISION_BF16X3_FWD_DGRAD 3
 nerfhip_plan_t nerfhip_plan_create_ex(const nerfhip_model_cfg* cfg, int precision);
 int nerfhip_plan_precision(nerfhip_plan_t plan);
 void nerfhip_plan_destroy(nerfhip_plan_t plan);

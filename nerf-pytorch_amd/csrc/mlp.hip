@@ -66,7 +66,7 @@ int nh_mlp_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, i
         NH_REQUIRE(in.x, "mlp_fwd: x is NULL");
     }
     if (p->precision != NERFHIP_PRECISION_FP32) {
-        NH_REQUIRE(!stash || p->precision == NERFHIP_PRECISION_BF16X3_FWD,
+        NH_REQUIRE(!stash || p->precision != NERFHIP_PRECISION_BF16X3,
                    "mlp_fwd: a bf16x3 plan is inference-only (no activation stash, no backward; NERFHIP_PRECISION_BF16X3_FWD trains)");
         return nh_mlp_bf16_forward(p, packed, in, M, out, stash, stream);
     }
@@ -80,7 +80,8 @@ int nh_mlp_backward(nerfhip_plan* p, const float* packed, const float* g_out, in
     NH_REQUIRE(scratch_bytes >= nh_mlp_bwd_scratch_bytes(p, M), "mlp_bwd: scratch too small (%lld < %lld)",
                (long long)scratch_bytes, (long long)nh_mlp_bwd_scratch_bytes(p, M));
     const int64_t nt = nh_ceil_div(M, 128) * 4;
-    int rc = nh_mlp16_dgrad(p, packed, g_out, M, stash, scratch, stream);
+    int rc = p->precision == NERFHIP_PRECISION_BF16X3_FWD_DGRAD ? nh_mlp_bf16_dgrad(p, packed, g_out, M, stash, scratch, stream)
+                                                                : nh_mlp16_dgrad(p, packed, g_out, M, stash, scratch, stream);
     if (rc) return rc;
     return nh_wgrad(p, nt, stash, scratch, scratch + (size_t)nt * (size_t)p->grad.total_rows * 32, g_params, stream);
 }

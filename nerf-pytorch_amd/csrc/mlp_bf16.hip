@@ -428,11 +428,176 @@ NH_KERNEL void NH_LB(256, (TRAIN ? 1 : BShape<W>::WAVES_PER_SIMD)) k_mlp_fwd_bf1
     }  // (groups of this workgroup)
 }
 
+// ---- the data-gradient chain on the same loop (NERFHIP_PRECISION_BF16X3_FWD_DGRAD) -------------------------------------------
+// dpre_{k-1} = relu'(H_{k-1}) * (W_{k-1}^T dpre_k), walked from d(raw output) down to layer1 (mlp16.hip k_mlp_dgrad16 is the
+// fp32 original; the reference has no such function: it is autograd of nerf/models.py:233-258).  A wave owns 32 samples;
+// d(pre-activation) lives in registers as operand pieces and every gemm stores its own input -- the d(pre-activation) image
+// the weight-gradient kernel reads -- as the forward does with the activations.  ReLU masks: the words the forward kernels
+// wrote for the fp32 data-gradient kernel's lanes (s & 15, g = 2 jb + h), jb = 0, 1 -- this lane's units.
+struct DgradBArgs {
+    const float* packed;
+    unsigned packed_bytes;
+    NhPackedOffsets off;
+    int L;
+    int64_t M, groups, nt;
+    const float* g_out;
+    const float* stash;
+    NhStashLayout sl;
+    float* grad;
+    NhGradLayout gl;
+};
+
+// zero the accumulators whose ReLU bit is 0: unit 32 t + 8 j + 4 h + i is register r = 4 (2 t + (j >> 1)) + i of lane g = 2 (j & 1) + h
+template <int NT>
+NH_DEVICE void gate_tiles(f32x16* acc, const unsigned* mw) {
+    constexpr int n = 8 * NT;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * (2 * t + (j >> 1)) + i, word = r >> 5;
+                const int pos = ((n - 32 * word) < 32 ? (n - 32 * word) : 32) - 1 - (r & 31);
+                acc[t][4 * j + i] = nh_gate(acc[t][4 * j + i], mw[2 * (j & 1) + word], pos);
+            }
+}
+
+template <int W, bool VIEW>
+NH_KERNEL void NH_LB(256, 1) k_mlp_dgrad_bf16x3(DgradBArgs a) {
+    constexpr int TH = BShape<W>::TH, KBH = BShape<W>::KBH, BUF = BShape<W>::BUF;
+    NH_DYN_LDS(lds_raw);
+    BCtx cx;
+    cx.lds = lds_raw;
+    cx.lds_addr = nh_lds_addr((const float*)lds_raw);
+    cx.dma = nh_dma_src(a.packed, a.packed_bytes);
+    cx.buf = 0;
+    cx.lane = nh_lane();
+    cx.wave = nh_wave_in_block();
+    cx.h = cx.lane >> 5;
+    const int h = cx.h, L = a.L;
+    const NhPackedOffsets& po = a.off;
+    auto first = [](int nk, int nt) { return nhb_first_bytes(nk, nt, W); };
+    const int64_t first_img = (VIEW ? po.b_rgb : po.b_head) * 4;
+    const int first_bytes = VIEW ? first(1, TH / 2) : first(1, TH);
+    b_issue<BUF>(cx, first_img, first_bytes, 0, 0);
+
+    for (int64_t grp = blockIdx.x; grp < a.groups; grp += gridDim.x) {
+        const bool again = grp + gridDim.x < a.groups;
+        const int s32 = cx.lane & 31;
+        const int64_t m = grp * 128 + cx.wave * 32 + s32;
+        const int64_t tile32 = grp * 4 + cx.wave;
+        float go[4] = {0.f, 0.f, 0.f, 0.f};  // d(raw output) of this lane's sample (zero beyond M: nothing flows)
+        if (m < a.M) {
+            const float4 t4 = *(const float4*)(a.g_out + (size_t)m * 4);
+            go[0] = t4.x, go[1] = t4.y, go[2] = t4.z, go[3] = t4.w;
+        }
+        auto grow = [&](const NhRegion& R, int rows) -> float* {
+            return a.grad + (size_t)32 * (size_t)a.nt * (size_t)R.row_prefix + ((size_t)tile32 * 32 + (size_t)s32) * (size_t)rows;
+        };
+        // ReLU mask `idx` of this lane's units: words [jb][0..1]
+        auto get_mask = [&](int idx, unsigned* mw) {
+            const unsigned* base = (const unsigned*)(a.stash + (size_t)32 * (size_t)a.nt * (size_t)a.sl.total_rows) +
+                                   ((size_t)(tile32 * 2 + (s32 >> 4)) * (size_t)a.sl.n_masks + (size_t)idx) * 128;
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) {
+                const unsigned* p = base + ((s32 & 15) + 16 * (2 * jb + h)) * 2;
+                mw[2 * jb] = p[0];
+                mw[2 * jb + 1] = p[1];
+            }
+        };
+        {  // POUT (32 rows): rows 0..2 d(rgb raw), row 3 d(sigma raw), the rest zero; lane half h writes rows 16 h .. 16 h + 15
+            float* const pr = grow(a.gl.POUT, 32) + 16 * h;
+            float4 z4, g4;
+            z4.x = z4.y = z4.z = z4.w = 0.0f;
+            g4.x = h == 0 ? go[0] : 0.0f, g4.y = h == 0 ? go[1] : 0.0f, g4.z = h == 0 ? go[2] : 0.0f, g4.w = h == 0 ? go[3] : 0.0f;
+            *(float4*)pr = g4;
+            *(float4*)(pr + 4) = z4;
+            *(float4*)(pr + 8) = z4;
+            *(float4*)(pr + 12) = z4;
+        }
+        f32x16 acc[TH];
+        nh_bf16x8 hh[KBH], hl[KBH];  // d(pre-activation) of the layer just finished, as operand pieces
+        unsigned mw[4];
+        nh_bf16x8 d1h[1], d1l[1];    // the one k-block of d(raw output): elements 0..2 (0..3 without viewdirs) of lane half 0
+        {
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (h == 0) {
+                v[0] = go[0], v[1] = go[1], v[2] = go[2];
+                if (!VIEW) v[3] = go[3];
+            }
+            put_block(d1h[0], d1l[0], v, nullptr);
+        }
+        if (VIEW) {
+            gemm_b<W, TH / 2, 0, 1>(cx, nullptr, nullptr, d1h, d1l, po.b_rgb * 4, po.b_dir * 4, first(KBH / 2, TH), acc);
+            get_mask(L, mw);  // DIRH
+            gate_tiles<TH / 2>(acc, mw);
+#pragma unroll
+            for (int t = 0; t < TH / 2; ++t) convert_tile<false>(acc[t], hh + 2 * t, hl + 2 * t);
+            gemm_b<W, TH, KBH / 2, 0>(cx, hh, hl, nullptr, nullptr, po.b_dir * 4, po.b_head * 4, first(KBH + 1, TH), acc, nullptr, nullptr,
+                                      grow(a.gl.PDIR, W / 2));
+            get_mask(L - 1, mw);  // FEAT
+            gate_tiles<TH>(acc, mw);
+#pragma unroll
+            for (int t = 0; t < TH; ++t) convert_tile<false>(acc[t], hh + 2 * t, hl + 2 * t);
+            nh_bf16x8 dah[1], dal[1];  // d(sigma raw) enters through fc_alpha's column (k-block KBH, half 0, element 0)
+            {
+                float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (h == 0) v[0] = go[3];
+                put_block(dah[0], dal[0], v, nullptr);
+            }
+            const bool last = L == 1;
+            gemm_b<W, TH, KBH, 1>(cx, hh, hl, dah, dal, po.b_head * 4, last ? first_img : po.b_xyz[L > 1 ? L - 2 : 0] * 4,
+                                  last ? (again ? first_bytes : 0) : first(KBH, TH), acc, nullptr, nullptr, grow(a.gl.PFEAT, W));
+        } else {
+            const bool last = L == 1;
+            gemm_b<W, TH, 0, 1>(cx, nullptr, nullptr, d1h, d1l, po.b_head * 4, last ? first_img : po.b_xyz[L > 1 ? L - 2 : 0] * 4,
+                                last ? (again ? first_bytes : 0) : first(KBH, TH), acc);
+        }
+        // acc = W^T d(pre-activation) for H_{L-1}: gate by its ReLU mask L - 2 (H_0 = layer1's output has no activation)
+        if (L > 1) {
+            get_mask(L - 2, mw);
+            gate_tiles<TH>(acc, mw);
+        }
+#pragma unroll
+        for (int t = 0; t < TH; ++t) convert_tile<false>(acc[t], hh + 2 * t, hl + 2 * t);
+        for (int k = L - 1; k >= 1; --k) {
+            const bool last = k == 1;
+            gemm_b<W, TH, KBH, 0>(cx, hh, hl, nullptr, nullptr, po.b_xyz[k - 1] * 4, last ? first_img : po.b_xyz[k >= 2 ? k - 2 : 0] * 4,
+                                  last ? (again ? first_bytes : 0) : first(KBH, TH), acc, nullptr, nullptr, grow(a.gl.P[k], W));
+            if (k - 1 >= 1) {
+                get_mask(k - 2, mw);  // H_{k-1}
+                gate_tiles<TH>(acc, mw);
+            }
+#pragma unroll
+            for (int t = 0; t < TH; ++t) convert_tile<false>(acc[t], hh + 2 * t, hl + 2 * t);
+        }
+        {  // d(pre-activation) of layer1: no gemm consumes it -- stored here (hi + lo, as every other image)
+            float* const pr = grow(a.gl.P[0], W);
+#pragma unroll
+            for (int kb = 0; kb < KBH; ++kb) {
+                float4 a4, b4;
+                a4.x = nh_from_bf16(hh[kb][0]) + nh_from_bf16(hl[kb][0]);
+                a4.y = nh_from_bf16(hh[kb][1]) + nh_from_bf16(hl[kb][1]);
+                a4.z = nh_from_bf16(hh[kb][2]) + nh_from_bf16(hl[kb][2]);
+                a4.w = nh_from_bf16(hh[kb][3]) + nh_from_bf16(hl[kb][3]);
+                b4.x = nh_from_bf16(hh[kb][4]) + nh_from_bf16(hl[kb][4]);
+                b4.y = nh_from_bf16(hh[kb][5]) + nh_from_bf16(hl[kb][5]);
+                b4.z = nh_from_bf16(hh[kb][6]) + nh_from_bf16(hl[kb][6]);
+                b4.w = nh_from_bf16(hh[kb][7]) + nh_from_bf16(hl[kb][7]);
+                float* const dst = pr + 32 * (kb >> 1) + 16 * (kb & 1) + 4 * h;
+                *(float4*)dst = a4;
+                *(float4*)(dst + 8) = b4;
+            }
+        }
+    }
+}
+
 // ---- weight image --------------------------------------------------------------------------------------------------
 struct PackBArgs {
     int n_layers;
     int64_t first;  // first word of the split-bf16 images (what lies in front is the fp32 image)
-    int64_t base[NH_MAX_LAYERS + 5];  // word offset of every layer image, ascending
+    int64_t base[2 * NH_MAX_LAYERS + 10];  // word offset of every layer image, ascending
 };
 
 NH_KERNEL void k_pack_bf16x3(const float* __restrict__ params, const int32_t* __restrict__ table, int64_t n, PackBArgs la,
@@ -556,6 +721,43 @@ int nh_mlp_bf16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& 
     return nh_launch_status("mlp_fwd_bf16x3");
 }
 
+int nh_mlp_bf16_dgrad(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
+                      nerfhip_stream_t stream) {
+    DgradBArgs d;
+    memset(&d, 0, sizeof(d));
+    d.packed = packed;
+    d.packed_bytes = (unsigned)(p->packed_floats * 4);
+    d.off = p->pob;
+    d.L = p->L;
+    d.M = M;
+    d.groups = nh_ceil_div(M, 128);
+    d.nt = d.groups * 4;
+    d.g_out = g_out;
+    d.stash = stash;
+    d.sl = p->stash;
+    d.grad = scratch;
+    d.gl = p->grad;
+    const int64_t resident = b_compute_units();  // (one wave per SIMD: one workgroup per CU also for the 128-wide nets)
+    const int64_t grid = d.groups < resident ? d.groups : resident;
+    int rc = NERFHIP_OK;
+#define NH_BWDB(WW, VV)                                                                                    \
+    {                                                                                                      \
+        rc = b_lds_limit(k_mlp_dgrad_bf16x3<WW, VV>, BShape<WW>::LDS_BYTES);                               \
+        if (rc) return rc;                                                                                 \
+        NH_LAUNCH((k_mlp_dgrad_bf16x3<WW, VV>), grid, 256, BShape<WW>::LDS_BYTES, stream, d);             \
+    }
+    if (p->W == 256 && p->view) NH_BWDB(256, true)
+    else if (p->W == 256) NH_BWDB(256, false)
+    else if (p->W == 128 && p->view) NH_BWDB(128, true)
+    else if (p->W == 128) NH_BWDB(128, false)
+    else {
+        nh_set_error("mlp_bwd: no bf16x3 data-gradient kernel for kernel width %d", p->W);
+        return NERFHIP_ERR_UNSUPPORTED;
+    }
+#undef NH_BWDB
+    return nh_launch_status("mlp_dgrad_bf16x3");
+}
+
 extern "C" int nerfhip_pack_weights_plan(nerfhip_plan_t plan, const float* params, const int32_t* table, float* packed,
                                          nerfhip_stream_t stream) {
     NH_REQUIRE(plan && params && table && packed, "pack_weights_plan: bad arguments");
@@ -576,6 +778,14 @@ extern "C" int nerfhip_pack_weights_plan(nerfhip_plan_t plan, const float* param
     if (plan->view) {
         la.base[k++] = o.f_dir;
         la.base[k++] = o.f_rgb;
+    }
+    if (plan->precision == NERFHIP_PRECISION_BF16X3_FWD_DGRAD) {  // (the order of plan.cpp for_each_spec_b)
+        if (plan->view) {
+            la.base[k++] = o.b_rgb;
+            la.base[k++] = o.b_dir;
+        }
+        la.base[k++] = o.b_head;
+        for (int i = 0; i < plan->L - 1; ++i) la.base[k++] = o.b_xyz[i];
     }
     la.n_layers = k;
     la.first = n32;

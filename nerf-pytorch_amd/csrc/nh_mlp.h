@@ -28,6 +28,9 @@ int nh_mlp16_dgrad(nerfhip_plan* p, const float* packed, const float* g_out, int
 int nh_mlp_bf16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
                         nerfhip_stream_t stream);
 
+int nh_mlp_bf16_dgrad(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
+                      nerfhip_stream_t stream);
+
 // wgrad.hip: split-K weight-gradient GEMMs over the stash / d(pre-activation) images (nt = 32-sample tiles) + reduction
 int64_t nh_wgrad_partial_floats(nerfhip_plan* p, int64_t nt);
 int nh_wgrad(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad, float* partial, float* g_params,

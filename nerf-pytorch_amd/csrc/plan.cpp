@@ -218,6 +218,7 @@ struct GemmSpecB {
 };
 struct SpecsB {
     GemmSpecB f_layer1, f_xyz[NH_MAX_LAYERS], f_head, f_dir, f_rgb;
+    GemmSpecB b_rgb, b_dir, b_head, b_xyz[NH_MAX_LAYERS];  // transposed images of the data-gradient chain (no bias)
 };
 
 // encoding slot -> reference column (nerf/nerf_helpers.py:130-157: [x], then per frequency sin(3), cos(3))
@@ -313,6 +314,54 @@ void build_specs_b(const nerfhip_plan* p, SpecsB& S) {
         };
         s.b = [=](int o) -> int64_t { return o < 4 ? ob.off + o : -1; };
     }
+    // ---- the data-gradient chain (NERFHIP_PRECISION_BF16X3_FWD_DGRAD): d(in)[f] = sum_u W[u][f] dpre[u]; k-block element
+    // (kb, h, e) is unit u = nhb_unit(kb, h, e) of the layer's OUTPUT, output row f a unit of its input
+    for (int i = 0; i < L - 1; ++i) {
+        GemmSpecB& s = S.b_xyz[i];
+        NhTensor w = T(p->t_xyz_w[i]);
+        const int ld = H + (p->is_skip(i) ? Dx : 0);
+        s.nk = KBH;
+        s.nt = TH;
+        s.w = [=](int f, int kb, int h, int e) -> int64_t {
+            const int u = nhb_unit(kb, h, e);
+            return (u < H && f < H) ? w.off + (int64_t)u * ld + f : -1;
+        };
+    }
+    if (p->view) {
+        NhTensor fw = T(p->t_feat_w), aw = T(p->t_alpha_w), dw = T(p->t_dir_w), rw = T(p->t_rgb_w);
+        {
+            GemmSpecB& s = S.b_rgb;  // ONE k-block: elements 0..2 of lane half 0 carry d(rgb raw)
+            s.nk = 1;
+            s.nt = TH / 2;
+            s.w = [=](int f, int kb, int h, int e) -> int64_t { return (kb == 0 && h == 0 && e < 3 && f < H2) ? rw.off + (int64_t)e * H2 + f : -1; };
+        }
+        {
+            GemmSpecB& s = S.b_dir;  // d(feat)[f] = sum_u Wdir[u][f] dpre_dir[u]
+            s.nk = KBH / 2;
+            s.nt = TH;
+            const int ld = H + Dd;
+            s.w = [=](int f, int kb, int h, int e) -> int64_t {
+                const int u = nhb_unit(kb, h, e);
+                return (u < H2 && f < H) ? dw.off + (int64_t)u * ld + f : -1;
+            };
+        }
+        {
+            GemmSpecB& s = S.b_head;  // dh[f] = sum_u Wfeat[u][f] dpre_feat[u] + Walpha[0][f] d(sigma raw) (k-block KBH, half 0, element 0)
+            s.nk = KBH + 1;
+            s.nt = TH;
+            s.w = [=](int f, int kb, int h, int e) -> int64_t {
+                if (f >= H) return -1;
+                if (kb < KBH) return nhb_unit(kb, h, e) < H ? fw.off + (int64_t)nhb_unit(kb, h, e) * H + f : -1;
+                return (h == 0 && e == 0) ? aw.off + f : -1;
+            };
+        }
+    } else {
+        NhTensor ow = T(p->t_out_w);
+        GemmSpecB& s = S.b_head;  // ONE k-block: elements 0..3 of lane half 0 carry d(out raw)
+        s.nk = 1;
+        s.nt = TH;
+        s.w = [=](int f, int kb, int h, int e) -> int64_t { return (kb == 0 && h == 0 && e < 4 && f < H) ? ow.off + (int64_t)e * H + f : -1; };
+    }
 }
 
 template <class Fn>
@@ -323,6 +372,14 @@ void for_each_spec_b(const nerfhip_plan* p, SpecsB& S, NhPackedOffsets& o, Fn fn
     if (p->view) {
         fn(S.f_dir, &o.f_dir);
         fn(S.f_rgb, &o.f_rgb);
+    }
+    if (p->precision == NERFHIP_PRECISION_BF16X3_FWD_DGRAD) {
+        if (p->view) {
+            fn(S.b_rgb, &o.b_rgb);
+            fn(S.b_dir, &o.b_dir);
+        }
+        fn(S.b_head, &o.b_head);
+        for (int i = 0; i < p->L - 1; ++i) fn(S.b_xyz[i], &o.b_xyz[i]);
     }
 }
 
@@ -554,7 +611,8 @@ void build_layouts_and_jobs(nerfhip_plan* p) {
 static nerfhip_plan_t plan_create_impl(const nerfhip_model_cfg* cfg, int precision);
 extern "C" nerfhip_plan_t nerfhip_plan_create(const nerfhip_model_cfg* cfg) { return plan_create_impl(cfg, NERFHIP_PRECISION_FP32); }
 extern "C" nerfhip_plan_t nerfhip_plan_create_ex(const nerfhip_model_cfg* cfg, int precision) {
-    if (precision != NERFHIP_PRECISION_FP32 && precision != NERFHIP_PRECISION_BF16X3 && precision != NERFHIP_PRECISION_BF16X3_FWD) {
+    if (precision != NERFHIP_PRECISION_FP32 && precision != NERFHIP_PRECISION_BF16X3 && precision != NERFHIP_PRECISION_BF16X3_FWD &&
+        precision != NERFHIP_PRECISION_BF16X3_FWD_DGRAD) {
         nh_set_error("plan_create_ex: unknown precision %d", precision);
         return nullptr;
     }
@@ -665,7 +723,7 @@ static nerfhip_plan_t plan_create_impl(const nerfhip_model_cfg* cfg, int precisi
         }
         memset(&p->po, 0, sizeof(p->po));
         p->packed_floats = 0;
-        if (precision == NERFHIP_PRECISION_BF16X3_FWD) {
+        if (precision != NERFHIP_PRECISION_BF16X3) {
             layout_packed(p);  // the fp32 image: its transposed layers feed the data-gradient kernel
             // the training forward stores the encodings in ITS slot order: that is what the weight-gradient scatter must undo
             for (int row = 0; row < 4 * NH16_KRX_EXT; ++row) p->xyz_slot_col[row] = row < 16 * NHB_XBLOCKS ? p->xyz_slot_b[row] : -1;

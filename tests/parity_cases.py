@@ -328,7 +328,7 @@ def case_mlp_forward(b, names=None, m=70):
         b.lib.plan_destroy(plan)
 
 
-BF16X3, BF16X3_FWD = 1, 2  # NERFHIP_PRECISION_BF16X3, NERFHIP_PRECISION_BF16X3_FWD
+BF16X3, BF16X3_FWD, BF16X3_FWD_DGRAD = 1, 2, 3  # NERFHIP_PRECISION_*
 BF16X3_GEOMETRIES = ("default4x128", "northstar8x256", "fern8x128_skip3_L6", "novw4x128", "two_layer_L4_L2", "one_layer",
                      "one_layer_novw_256", "skip_every_layer_256", "noinput_linear", "odd5x99_skip2", "wide3x200_skip1",
                      "novw2x130")
@@ -405,20 +405,26 @@ def case_mlp_backward(b, names=None, m=150, precision=0):
         b.lib.plan_destroy(plan)
 
 
-def case_mlp_input_grad(b, names=None, m=150):
+def case_mlp_input_grad(b, names=None, m=150, precision=0):
     """d(loss)/d(x) of FlexibleNeRFModel.forward vs the oracle's autograd (x enters layer1, the skip layers, layers_dir)."""
     for name in names or ("default4x128", "fern8x128_skip3_L6", "novw4x128", "odd5x99_skip2"):
         cfg = MLP_GEOMETRIES[name]
-        plan, params, flat, packed = mlp_setup(b, cfg, seed=43)
+        plan, params, flat, packed = mlp_setup(b, cfg, seed=43, precision=precision)
         dx, dd = O.model_dims(cfg)
         gen = rng(44)
-        x = torch.randn(m, dx + dd, generator=gen).requires_grad_(True)
+        x = torch.randn(m, dx + dd, generator=gen)
         go = torch.randn(m, 4, generator=gen)
+        if precision:  # (split-bf16 kernels: rows whose ReLU decisions hang on less than their ~1e-5 are not comparable)
+            keep = O.mlp_relu_margin(params, x, cfg) > 1e-4
+            x, go = x[keep].contiguous(), go[keep].contiguous()
+            m = x.shape[0]
+        x = x.requires_grad_(True)
         (O.mlp_forward(params, x, cfg) * go).sum().backward()
         ref = x.grad.numpy()
         _, stash = b.mlp_fwd(plan, packed, x.detach().numpy(), want_stash=True)
         _, gx = b.mlp_bwd(plan, packed, go.numpy(), stash, flat_for_input_grad=flat)
-        close(gx, ref, 2e-5 * float(np.abs(ref).max()) + 1e-7, 2e-4, what="mlp input grad " + name)
+        tol = 2e-5 if not precision else 4e-4
+        close(gx, ref, tol * float(np.abs(ref).max()) + 1e-7, 10 * tol, what="mlp input grad " + name)
         b.lib.plan_destroy(plan)
 
 

@@ -316,7 +316,7 @@ struct RowsPost {
     NH_MEMBER void tile(int t) const {
         if (!row.base) return;
         float* dst = t < 16 ? row.at(16 * t) : (float*)((char*)row.at(16 * (t - 16)) + hi_bytes);
-        *(float4*)dst = make_float4(act[4 * t], act[4 * t + 1], act[4 * t + 2], act[4 * t + 3]);
+        nh_store4(dst, act[4 * t], act[4 * t + 1], act[4 * t + 2], act[4 * t + 3]);
     }
 };
 // encoding slots (register r of lane (j,g) is row g*KR + r; the lane offset already includes g*KR): stored with k-step 0
@@ -328,7 +328,7 @@ struct SlotsPost {
     NH_MEMBER void first() const {
         if (!row.base) return;
 #pragma unroll
-        for (int q = 0; q < KR / 4; ++q) *(float4*)row.at(4 * q) = make_float4(e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]);
+        for (int q = 0; q < KR / 4; ++q) nh_store4(row.at(4 * q), e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]);
     }
     NH_MEMBER void tile(int) const {}
 };
@@ -361,7 +361,7 @@ NH_DEVICE void store_rows(const RowRef& row, const float* act, size_t hi_bytes) 
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         float* dst = t < 16 ? row.at(16 * t) : (float*)((char*)row.at(16 * (t - 16)) + hi_bytes);
-        *(float4*)dst = make_float4(act[4 * t], act[4 * t + 1], act[4 * t + 2], act[4 * t + 3]);
+        nh_store4(dst, act[4 * t], act[4 * t + 1], act[4 * t + 2], act[4 * t + 3]);
     }
 }
 

@@ -102,8 +102,8 @@ NH_DEVICE void gemm_b(BCtx& cx, const nh_bf16x8* ah, const nh_bf16x8* al, const 
         b4.z = nh_from_bf16(ah[kb][6]) + nh_from_bf16(al[kb][6]);
         b4.w = nh_from_bf16(ah[kb][7]) + nh_from_bf16(al[kb][7]);
         float* const dst = in_rows + 32 * (kb >> 1) + 16 * (kb & 1) + 4 * cx.h;  // units nhb_unit(kb, h, 0..3) and (kb, h, 4..7) = + 8
-        *(float4*)dst = a4;
-        *(float4*)(dst + 8) = b4;
+        nh_store4(dst, a4.x, a4.y, a4.z, a4.w);
+        nh_store4(dst + 8, b4.x, b4.y, b4.z, b4.w);
     };
     (void)srow_next;
 #pragma unroll

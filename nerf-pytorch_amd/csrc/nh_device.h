@@ -154,6 +154,21 @@ static inline void nh_clk_end(const unsigned long long*) {}
 constexpr int NH_CLK_LDS_BYTES = 32;
 enum { NH_CLK_FWD = 0, NH_CLK_DGRAD = 1, NH_CLK_WGRAD = 2, NH_CLK_KERNELS = 3 };
 
+// 16-byte store of a stash / d(pre-activation) row piece.  (A/B builds: -DNH_STASH_NT issues it non-temporal -- measured on
+// MI355X and rejected: a row's 128-byte lines are completed by several instructions and rely on L2 to merge them; nt costs
+// 0.4 % for the fp32 kernels and 44 % for the split-bf16 training kernels, profiles/r03_variant_ab.txt section 8.)
+NH_DEVICE void nh_store4(float* dst, float x, float y, float z, float w) {
+#if defined(NH_STASH_NT) && !defined(NERFHIP_EMU)
+    typedef float nh_f4 __attribute__((ext_vector_type(4)));
+    nh_f4 v = {x, y, z, w};
+    __builtin_nontemporal_store(v, (nh_f4*)dst);
+#else
+    float4 v;
+    v.x = x, v.y = y, v.z = z, v.w = w;
+    *(float4*)dst = v;
+#endif
+}
+
 // ---- helpers shared by both builds -------------------------------------------------------------------------------
 
 // ReLU / mask helpers shaped to cost one or two VALU instructions each (every VALU instruction of a one-wave-per-SIMD

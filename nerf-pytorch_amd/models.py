@@ -175,7 +175,8 @@ class FlexibleNeRFModel(torch.nn.Module):
         and the headline benchmark refer to) or "bf16x3_fwd" (NERFHIP_PRECISION_BF16X3_FWD: the forward -- training and
         inference alike -- on the split-bf16 kernel, the backward kernels unchanged fp32) or "bf16x3_fwd_dgrad" (the
         data-gradient chain on it too; the weight-gradient GEMMs stay fp32).  Experiments accepted by PSNR@iters, not by the
-        1e-4 bar: DESIGN.md 7.4.  Parameters, optimizer state and checkpoints are unaffected."""
+        1e-4 bar: DESIGN.md 7.4-7.5.  Parameters (re-homed into a fresh flat buffer, same Parameter objects), optimizer state
+        and checkpoints are unaffected; call it before a TrainEngine is built on the model."""
         if precision not in ("fp32", "bf16x3_fwd", "bf16x3_fwd_dgrad"):
             raise ValueError("training precision must be 'fp32', 'bf16x3_fwd' or 'bf16x3_fwd_dgrad' (got %r)" % (precision,))
         _PlanHandle(self.cfg, PRECISIONS[precision])  # (raises for a geometry the bf16x3 kernels do not cover, before anything changes)

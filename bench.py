@@ -260,6 +260,8 @@ def kernel_kind(name):
         return "fwd"
     if "k_mlp_dgrad" in name:
         return "dgrad"
+    if "k_wgrad_bf16x3" in name:
+        return "wgrad_bf16"   # (--precision bf16x3_train: the hidden x hidden blocks; "wgrad" is then the thin blocks only)
     if "k_wgrad" in name and "reduce" not in name:
         return "wgrad"
     return None
@@ -301,7 +303,7 @@ def main():
     ap.add_argument("--layers", type=int, default=MODEL["num_layers"])
     ap.add_argument("--overlap", type=int, default=-1, help="1: two-stream step (coarse backward next to the fine pass); "
                     "0: single-stream order; -1: the engine's default for the net width")
-    ap.add_argument("--precision", choices=("fp32", "bf16x3", "bf16x3_fwd", "bf16x3_fwd_dgrad"), default="fp32",
+    ap.add_argument("--precision", choices=("fp32", "bf16x3", "bf16x3_fwd", "bf16x3_fwd_dgrad", "bf16x3_train"), default="fp32",
                     help="fp32 (default: the reference's arithmetic, the headline).  --mode eval --precision bf16x3: the inference "
                          "forward on the split-bf16 kernels.  --mode train --precision bf16x3_fwd: the training forward on them, "
                          "backward kernels unchanged fp32.  Both are NOT the reference's arithmetic: separate, labelled lines")
@@ -357,9 +359,9 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    if (args.mode == "train" and args.precision == "bf16x3") or (args.mode == "eval" and args.precision.startswith("bf16x3_fwd")):
-        raise SystemExit("--precision bf16x3 goes with --mode eval, bf16x3_fwd / bf16x3_fwd_dgrad with --mode train")
-    if args.precision.startswith("bf16x3_fwd"):
+    if (args.mode == "train" and args.precision == "bf16x3") or (args.mode == "eval" and args.precision.startswith("bf16x3_")):
+        raise SystemExit("--precision bf16x3 goes with --mode eval, bf16x3_fwd / bf16x3_fwd_dgrad / bf16x3_train with --mode train")
+    if args.precision.startswith("bf16x3_"):
         mc.set_training_precision(args.precision)
         mf.set_training_precision(args.precision)
     if args.mode == "train":
@@ -442,6 +444,24 @@ def main():
                      "fwd": stash_bytes_per_sample(cfg) if args.mode == "train" else 16 + 4,   # inference: raw out + z in
                      "dgrad": 4 * (cfg["num_layers"] * cfg["hidden_size"] + cfg["hidden_size"] + cfg["hidden_size"] // 2 + 32)
                      + 8 * (cfg["num_layers"] + 1) + 16}
+        if args.precision == "bf16x3_train":
+            # the weight gradient is two kernels then: the hidden x hidden blocks (k_wgrad_bf16x3: two launches per net, full and
+            # half-height blocks) and the thin blocks left to the fp32 k_wgrad
+            Wd, Ln = cfg["hidden_size"], cfg["num_layers"]
+            big_macs = (Ln - 1) * Wd * Wd + Wd * Wd + (Wd // 2) * Wd
+            big_rows = Ln * 2 * Wd + (Wd // 2 + Wd)
+            flops["wgrad_bf16"], flops["wgrad"] = 2.0 * big_macs, 2.0 * (fwd_macs - big_macs)
+            hbm_bytes["wgrad_bf16"], hbm_bytes["wgrad"] = 4 * big_rows, hbm_bytes["wgrad"] - 4 * big_rows
+        merged = {}
+        for name, (cnt, ms) in kern.items():   # (template instances of one kernel kind -- k_wgrad_bf16x3<256,256> / <128,256> -- count as one)
+            kind = kernel_kind(name)
+            if kind == "wgrad_bf16":
+                c0, m0, n0 = merged.get(kind, (0, 0.0, name))
+                merged[kind] = (c0 + cnt, m0 + ms, n0 if c0 else name)
+        for kind, (cnt, ms, name) in merged.items():
+            for nm in [n for n in kern if kernel_kind(n) == kind]:
+                del kern[nm]
+            kern["k_wgrad_bf16x3<*>"] = (cnt // 2, ms)   # (two launches = one pass over the net's blocks)
         kernels = {}
         for name, (cnt, ms) in kern.items():
             kind = kernel_kind(name)
@@ -452,9 +472,10 @@ def main():
             spl = (m_c + m_f) / launches_per_step                     # sample points per launch (mean)
             tf = flops[kind] * spl / (avg_ms * 1e-3) / 1e12
             gb = hbm_bytes[kind] * spl / 1e9
-            cyc, ticks, wgs = (int(clk[3 * {"fwd": 0, "dgrad": 1, "wgrad": 2}[kind] + c]) for c in range(3))
+            cyc, ticks, wgs = (int(clk[3 * {"fwd": 0, "dgrad": 1, "wgrad": 2}.get(kind, 0) + c]) if kind in ("fwd", "dgrad", "wgrad") else 0
+                               for c in range(3))
             ghz = 0.1 * cyc / ticks if ticks else None
-            counter_gb, source = pmc_traffic(cfg, n, kind) if args.mode == "train" else (None, None)
+            counter_gb, source = pmc_traffic(cfg, n, kind) if (args.mode == "train" and args.precision == "fp32") else (None, None)
             # a kernel is priced against ITS OWN matrix pipe: fp32 MFMA, or the bf16 MFMA at three instructions per product block
             peak = BF16X3_PEAK_TFLOPS if "bf16x3" in name else FP32_MFMA_PEAK_TFLOPS
             kernels[kind] = dict(kernel=name, ms_per_step=round(ms / args.steps, 4), avg_launch_ms=round(avg_ms, 4), launches=cnt,
@@ -501,8 +522,10 @@ def main():
                     "fp32-equivalent FLOPs)" if args.precision == "bf16x3" else
                     ("forward bf16x3 (split-bf16 products, f32 accumulate), backward + optimizer f32; fp32-equivalent FLOPs"
                      if args.precision == "bf16x3_fwd" else
-                     "forward + data gradient bf16x3 (split-bf16 products, f32 accumulate), weight gradient + optimizer f32; "
-                     "fp32-equivalent FLOPs")),
+                     ("forward + data gradient bf16x3 (split-bf16 products, f32 accumulate), weight gradient + optimizer f32; "
+                      "fp32-equivalent FLOPs" if args.precision == "bf16x3_fwd_dgrad" else
+                      "forward, data gradient and the hidden x hidden weight-gradient blocks bf16x3 (split-bf16 products, f32 "
+                      "accumulate); thin weight-gradient blocks + optimizer f32; fp32-equivalent FLOPs"))),
                    data="synthetic",
                    config=dict(workload=workload, rays_per_gpu=n, global_rays=total_rays, parallelism="dp%d" % world,
                                two_stream_step=bool(eng.overlap) if args.mode == "train" else None,

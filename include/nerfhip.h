@@ -181,6 +181,10 @@ nerfhip_plan_t nerfhip_plan_create(const nerfhip_model_cfg* cfg);
 /* BF16X3_FWD_DGRAD: as BF16X3_FWD, and the data-gradient chain (k_mlp_dgrad) runs on the split-bf16 kernel too; the weight-
  * gradient GEMMs stay fp32.  Same status: opt-in experiment, accepted by PSNR@iters. */
 #define NERFHIP_PRECISION_BF16X3_FWD_DGRAD 3
+/* BF16X3_TRAIN: as BF16X3_FWD_DGRAD, and the large weight-gradient GEMMs (hidden x hidden blocks: ~94 % of the weight-gradient
+ * FLOPs) run on the bf16 MFMAs too (operands split on the fly from the fp32 stash / d(pre-activation) images); the thin blocks
+ * (encoding columns, fc_alpha, fc_rgb | fc_out) stay on the fp32 kernel.  Same status: opt-in experiment. */
+#define NERFHIP_PRECISION_BF16X3_TRAIN 4
 nerfhip_plan_t nerfhip_plan_create_ex(const nerfhip_model_cfg* cfg, int precision);
 int nerfhip_plan_precision(nerfhip_plan_t plan);
 void nerfhip_plan_destroy(nerfhip_plan_t plan);

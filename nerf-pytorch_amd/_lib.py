@@ -43,7 +43,7 @@ class RenderCotangents(C.Structure):
                                    "g_depth_fine")]
 
 
-PRECISION_FP32, PRECISION_BF16X3, PRECISION_BF16X3_FWD, PRECISION_BF16X3_FWD_DGRAD = 0, 1, 2, 3  # NERFHIP_PRECISION_*
+PRECISION_FP32, PRECISION_BF16X3, PRECISION_BF16X3_FWD, PRECISION_BF16X3_FWD_DGRAD, PRECISION_BF16X3_TRAIN = 0, 1, 2, 3, 4  # NERFHIP_PRECISION_*
 PART_COARSE, PART_FINE, PART_SHARED_BWD = 1, 2, 4
 
 

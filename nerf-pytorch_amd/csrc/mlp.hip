@@ -52,7 +52,7 @@ NH_KERNEL void k_mlp_input_grad(InGradArgs a) {
 // weight-gradient kernel, then the split-K partials
 int64_t nh_mlp_bwd_scratch_bytes(nerfhip_plan* p, int64_t M) {
     const int64_t nt = nh_ceil_div(M, 128) * 4;
-    return (nt * p->grad.total_rows * 32 + nh_wgrad_partial_floats(p, nt)) * (int64_t)sizeof(float);
+    return (nt * p->grad.total_rows * 32 + nh_wgrad_partial_floats(p, nt) + nh_wgrad_bf16_partial_floats(p, nt)) * (int64_t)sizeof(float);
 }
 
 int nh_mlp_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
@@ -80,10 +80,14 @@ int nh_mlp_backward(nerfhip_plan* p, const float* packed, const float* g_out, in
     NH_REQUIRE(scratch_bytes >= nh_mlp_bwd_scratch_bytes(p, M), "mlp_bwd: scratch too small (%lld < %lld)",
                (long long)scratch_bytes, (long long)nh_mlp_bwd_scratch_bytes(p, M));
     const int64_t nt = nh_ceil_div(M, 128) * 4;
-    int rc = p->precision == NERFHIP_PRECISION_BF16X3_FWD_DGRAD ? nh_mlp_bf16_dgrad(p, packed, g_out, M, stash, scratch, stream)
-                                                                : nh_mlp16_dgrad(p, packed, g_out, M, stash, scratch, stream);
+    const bool bdg = p->precision == NERFHIP_PRECISION_BF16X3_FWD_DGRAD || p->precision == NERFHIP_PRECISION_BF16X3_TRAIN;
+    int rc = bdg ? nh_mlp_bf16_dgrad(p, packed, g_out, M, stash, scratch, stream) : nh_mlp16_dgrad(p, packed, g_out, M, stash, scratch, stream);
     if (rc) return rc;
-    return nh_wgrad(p, nt, stash, scratch, scratch + (size_t)nt * (size_t)p->grad.total_rows * 32, g_params, stream);
+    float* const partial = scratch + (size_t)nt * (size_t)p->grad.total_rows * 32;
+    rc = nh_wgrad(p, nt, stash, scratch, partial, g_params, stream);
+    if (rc) return rc;
+    // (BF16X3_TRAIN: the large blocks, behind the fp32 kernel's partials)
+    return nh_wgrad_bf16(p, nt, stash, scratch, partial + nh_wgrad_partial_floats(p, nt), g_params, stream);
 }
 
 extern "C" int64_t nerfhip_plan_bwd_scratch_bytes(nerfhip_plan_t plan, int64_t m) {

@@ -779,7 +779,7 @@ extern "C" int nerfhip_pack_weights_plan(nerfhip_plan_t plan, const float* param
         la.base[k++] = o.f_dir;
         la.base[k++] = o.f_rgb;
     }
-    if (plan->precision == NERFHIP_PRECISION_BF16X3_FWD_DGRAD) {  // (the order of plan.cpp for_each_spec_b)
+    if (plan->precision == NERFHIP_PRECISION_BF16X3_FWD_DGRAD || plan->precision == NERFHIP_PRECISION_BF16X3_TRAIN) {  // (the order of plan.cpp for_each_spec_b)
         if (plan->view) {
             la.base[k++] = o.b_rgb;
             la.base[k++] = o.b_dir;

@@ -115,6 +115,12 @@ NH_DEVICE void nh_dma16a(const NhDmaSrc& s, int voff, int soff, unsigned lds_wav
         : "memory");
 }
 NH_DEVICE void nh_wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// ... until at most N of this wave's vector-memory operations are outstanding (the N newest: they complete in order)
+template <int N>
+NH_DEVICE void nh_wait_vmem_keep() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 // nothing is scheduled across this point (pins "issue the prefetch BEFORE the MFMAs")
 NH_DEVICE void nh_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 NH_DEVICE void nh_sincos(float x, float* s, float* c) { sincosf(x, s, c); }

@@ -36,6 +36,11 @@ int64_t nh_wgrad_partial_floats(nerfhip_plan* p, int64_t nt);
 int nh_wgrad(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad, float* partial, float* g_params,
              nerfhip_stream_t stream);
 
+// wgrad_bf16.hip: the large weight blocks of NERFHIP_PRECISION_BF16X3_TRAIN plans (plan->bjobs) on the bf16 MFMAs
+int64_t nh_wgrad_bf16_partial_floats(nerfhip_plan* p, int64_t nt);
+int nh_wgrad_bf16(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad, float* partial, float* g_params,
+                  nerfhip_stream_t stream);
+
 // render.hip: compositing backward with the optional dL/d||rd|| output, and the gradient w.r.t. the packed rays
 int nh_volume_render_bwd(const float* raw, const float* z, const float* rd, int rd_stride, int64_t n, int s, float noise_std,
                          const float* noise, uint64_t seed, uint32_t rng_stream, uint64_t ray_offset, int white_background,

@@ -125,6 +125,15 @@ struct NhJob {
     int64_t s_w_off, s_bias_off;
 };
 
+// A weight block whose gradient the split-bf16 weight-gradient kernel computes (NERFHIP_PRECISION_BF16X3_TRAIN; wgrad_bf16.hip):
+// dW[r][c] = sum_samples A[r][s] B[c][s] for r < r_hi, c < col_count, written to w_off + r * w_ld + c; bias = row sums of A.
+struct NhJobB {
+    int a_rows, b_rows;                  // rows of the A region (d(pre-activation) image) and of the B region (activation stash)
+    int64_t a_row_prefix, b_row_prefix;  // region offsets = 32 * n_tiles * prefix floats
+    int r_hi, col_count, w_ld;
+    int64_t w_off, bias_off;
+};
+
 struct nerfhip_plan {
     nerfhip_model_cfg cfg;
     int W, H, L, skip, Dx, Dd, view;  // W: kernel width (64 | 128 | 256 | 512) >= H: the model's hidden_size (units H..W-1 are zero padding)
@@ -149,6 +158,7 @@ struct nerfhip_plan {
     NhStashLayout stash;
     NhGradLayout grad;
     std::vector<NhJob> jobs;
+    std::vector<NhJobB> bjobs;        // (BF16X3_TRAIN: the large blocks, taken out of `jobs`)
     int wgrad_waves;         // waves per workgroup of the weight-gradient kernel: 8 (256- and 512-wide nets) or 4 (narrower)
     bool is_skip(int i) const { return i % skip == 0 && i > 0; }
 };

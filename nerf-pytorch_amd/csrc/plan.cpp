@@ -373,7 +373,7 @@ void for_each_spec_b(const nerfhip_plan* p, SpecsB& S, NhPackedOffsets& o, Fn fn
         fn(S.f_dir, &o.f_dir);
         fn(S.f_rgb, &o.f_rgb);
     }
-    if (p->precision == NERFHIP_PRECISION_BF16X3_FWD_DGRAD) {
+    if (p->precision == NERFHIP_PRECISION_BF16X3_FWD_DGRAD || p->precision == NERFHIP_PRECISION_BF16X3_TRAIN) {
         if (p->view) {
             fn(S.b_rgb, &o.b_rgb);
             fn(S.b_dir, &o.b_dir);
@@ -586,16 +586,43 @@ void build_layouts_and_jobs(nerfhip_plan* p) {
 #endif
     // (tiles cover the kernel width W; only the rows / columns of the real H hidden units are unpacked)
     const int TW = W / 32, H = p->H, H2 = H / 2;
+    // BF16X3_TRAIN: the hidden x hidden blocks go to the split-bf16 weight-gradient kernel instead (wgrad_bf16.hip)
+    p->bjobs.clear();
+    // (256-wide nets only: for the 128 x 128 blocks of narrower nets the conversion outweighs the MFMAs -- measured on MI355X:
+    // 4x128 step 4.23 -> 5.04 ms -- so there BF16X3_TRAIN is BF16X3_FWD_DGRAD)
+    const bool big_b = p->precision == NERFHIP_PRECISION_BF16X3_TRAIN && W >= 256;
+    auto add_big = [&](const NhRegion& A, int a_rows, const NhRegion& B, int r_hi, int w_tensor, int bias_tensor) {
+        NhJobB j;
+        j.a_rows = a_rows;
+        j.b_rows = W;
+        j.a_row_prefix = A.row_prefix;
+        j.b_row_prefix = B.row_prefix;
+        j.r_hi = r_hi;
+        j.col_count = H;
+        j.w_ld = p->tensors[w_tensor].cols;
+        j.w_off = p->tensors[w_tensor].off;
+        j.bias_off = p->tensors[bias_tensor].off;
+        p->bjobs.push_back(j);
+    };
     // layer1: dP_0 x X
     add_job(p, G.P[0], TW, S.X, 0, p->krx / 8, 0, H, p->t_layer1_w, 1, 0, p->Dx, p->t_layer1_b);
     for (int i = 0; i < L - 1; ++i) {
-        add_job(p, G.P[i + 1], TW, S.H[i], 0, TW, 0, H, p->t_xyz_w[i], 0, 0, H, p->t_xyz_b[i]);
+        if (big_b)
+            add_big(G.P[i + 1], W, S.H[i], H, p->t_xyz_w[i], p->t_xyz_b[i]);
+        else
+            add_job(p, G.P[i + 1], TW, S.H[i], 0, TW, 0, H, p->t_xyz_w[i], 0, 0, H, p->t_xyz_b[i]);
         if (p->is_skip(i)) add_job(p, G.P[i + 1], TW, S.X, 0, p->krx / 8, 0, H, p->t_xyz_w[i], 1, H, p->Dx, -1);
     }
     if (p->view) {
-        add_job(p, G.PFEAT, TW, S.H[L - 1], 0, TW, 0, H, p->t_feat_w, 0, 0, H, p->t_feat_b);
+        if (big_b)
+            add_big(G.PFEAT, W, S.H[L - 1], H, p->t_feat_w, p->t_feat_b);
+        else
+            add_job(p, G.PFEAT, TW, S.H[L - 1], 0, TW, 0, H, p->t_feat_w, 0, 0, H, p->t_feat_b);
         add_job(p, G.POUT, 1, S.H[L - 1], 0, TW, 3, 4, p->t_alpha_w, 0, 0, H, p->t_alpha_b);
-        add_job(p, G.PDIR, TW / 2, S.FEAT, 0, TW, 0, H2, p->t_dir_w, 0, 0, H, p->t_dir_b);
+        if (big_b)
+            add_big(G.PDIR, W / 2, S.FEAT, H2, p->t_dir_w, p->t_dir_b);
+        else
+            add_job(p, G.PDIR, TW / 2, S.FEAT, 0, TW, 0, H2, p->t_dir_w, 0, 0, H, p->t_dir_b);
         add_job(p, G.PDIR, TW / 2, S.D, 0, p->krd / 8, 0, H2, p->t_dir_w, 2, H, p->Dd, -1);
         add_job(p, G.POUT, 1, S.DIRH, 0, TW / 2, 0, 3, p->t_rgb_w, 0, 0, H2, p->t_rgb_b);
     } else {
@@ -612,7 +639,7 @@ static nerfhip_plan_t plan_create_impl(const nerfhip_model_cfg* cfg, int precisi
 extern "C" nerfhip_plan_t nerfhip_plan_create(const nerfhip_model_cfg* cfg) { return plan_create_impl(cfg, NERFHIP_PRECISION_FP32); }
 extern "C" nerfhip_plan_t nerfhip_plan_create_ex(const nerfhip_model_cfg* cfg, int precision) {
     if (precision != NERFHIP_PRECISION_FP32 && precision != NERFHIP_PRECISION_BF16X3 && precision != NERFHIP_PRECISION_BF16X3_FWD &&
-        precision != NERFHIP_PRECISION_BF16X3_FWD_DGRAD) {
+        precision != NERFHIP_PRECISION_BF16X3_FWD_DGRAD && precision != NERFHIP_PRECISION_BF16X3_TRAIN) {
         nh_set_error("plan_create_ex: unknown precision %d", precision);
         return nullptr;
     }

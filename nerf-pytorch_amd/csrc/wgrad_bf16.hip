@@ -1,0 +1,336 @@
+// wgrad_bf16.hip -- the large weight-gradient GEMMs of NERFHIP_PRECISION_BF16X3_TRAIN plans on the bf16 MFMAs (opt-in experiment,
+// DESIGN.md 7.6; the fp32 original is wgrad.hip; the reference has no such function: it is autograd of nerf/models.py:233-258).
+//
+//     dW[r][c] = sum over samples s of A[r][s] * B[c][s],    A = a d(pre-activation) image, B = an activation image of the stash,
+//
+// both fp32, sample-major ([32-sample tile][sample][rows]).  v_mfma_f32_32x32x16_bf16 wants a lane's 8 consecutive k (= samples)
+// of ONE row in 16 contiguous bytes, and each fp32 value split into two bf16 pieces (hi = bf16(v), lo = bf16(v - hi);
+// A.B ~ Ah.Bh + Ah.Bl + Al.Bh, fp32 accumulation: the arithmetic of mlp_bf16.hip).  So a workgroup (4 waves, one per SIMD) walks
+// over its range of samples in steps of 16 (one k-block), two phases per step:
+//   convert : the step's A and B blocks (contiguous in HBM, brought to LDS by LDS-DMA into one of two fp32 stages: the copies of
+//             the next two steps are in flight while this one is converted and multiplied) are read row-wise -- thread t owns row t mod rows: 8 samples of it per item, strided dword reads, conflict-free across
+//             the wave --, split, and written back k-minor as MFMA operand blocks ([32-row tile][k-block][lane] x 16 B); the same
+//             thread keeps the running row sum of A (the bias gradient);
+//   multiply: wave (wo, wi) of the 2 x 2 grid owns a quarter of the block (4 x 4 accumulator tiles = 256 AGPRs for a 256 x 256
+//             block): 8 + 8 operand reads and 48 MFMAs per step.
+// Split-K over the workgroups of a block; the partials (accumulator tiles as [tile][16 registers][64 lanes], then the 256 threads'
+// bias sums) are summed in a fixed order by k_wgrad_bf16_reduce -- bit-reproducible, no atomics -- and scattered into the
+// reference parameter layout.
+#include "nh_device.h"
+#include "nh_mlp.h"
+
+namespace {
+
+constexpr int NHW_MAX_JOBS = 40;
+#ifndef NHW_STAGES  // (A/B builds only) fp32 stages in LDS = 16-sample steps whose copies are in flight; 2 measured 4 % faster than 3
+#define NHW_STAGES 2
+#endif
+
+struct WgBJob {
+    int64_t a_off, b_off;  // float offsets of the two regions inside the grad scratch / the stash
+    int wg0, nwg;          // this block's workgroups [wg0, wg0 + nwg)
+    int r_hi, col_count, w_ld;
+    int64_t w_off, bias_off;
+};
+struct WgBArgs {
+    const float* stash;
+    const float* grad;
+    float* partial;
+    float* g_params;
+    int64_t nt;
+    int njobs, part_stride;  // floats per workgroup partial: AR * BR accumulators + 256 bias sums
+    WgBJob jobs[NHW_MAX_JOBS];
+};
+
+template <int AR, int BR>
+struct WShape {
+    static constexpr int PO = AR / 64, PI = BR / 64, TA = AR / 32, TB = BR / 32;
+    static constexpr int STAGE_A = AR * 64, STAGE_B = BR * 64;   // bytes of one 16-sample step of the region, fp32
+    static constexpr int STAGE = STAGE_A + STAGE_B;               // (NHW_STAGES of them: the copies of the next steps land while step u is converted)
+    static constexpr int OPER_A = AR * 32, OPER_B = BR * 32;      // bytes of its high (or low) operand blocks
+    static constexpr int LDS_BYTES = NHW_STAGES * STAGE + 2 * OPER_A + 2 * OPER_B;
+    static constexpr int PART = AR * BR + 256;
+};
+
+// rows -> operand blocks of one 16-sample k-block: item id = row + rows * q handles samples 8 q .. 8 q + 7 of `row` (q = the lane
+// half that supplies them).  Two steps, each side of a scheduling fence: ALL of a thread's values are read from the stage first
+// (left to itself the compiler waits for every pair of dwords right after asking for it: 16 exposed LDS latencies per step),
+// then split and written back.  rows_load returns nothing; rows_store returns the sum of the values (the bias gradient's share).
+template <int ROWS>
+struct RowItems {
+    static constexpr int N = (ROWS * 2 + 255) / 256;  // items per thread
+    float v[N][8];
+};
+template <int ROWS>
+NH_DEVICE void rows_load(const float* stage, int tid, RowItems<ROWS>& r) {
+#pragma unroll
+    for (int it = 0; it < RowItems<ROWS>::N; ++it) {
+        const int id = tid + 256 * it;
+        const bool on = ROWS * 2 % 256 == 0 || id < ROWS * 2;
+        const int row = id % ROWS, q = on ? id / ROWS : 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r.v[it][e] = on ? stage[(8 * q + e) * ROWS + row] : 0.0f;
+    }
+}
+template <int ROWS>
+NH_DEVICE float rows_store(const RowItems<ROWS>& r, char* hi_blocks, char* lo_blocks, int tid) {
+    float sum = 0.0f;
+#pragma unroll
+    for (int it = 0; it < RowItems<ROWS>::N; ++it) {
+        const int id = tid + 256 * it;
+        if (ROWS * 2 % 256 != 0 && id >= ROWS * 2) break;
+        const int row = id % ROWS, q = id / ROWS;
+        nh_bf16x8 h8, l8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = r.v[it][e];
+            sum += v;
+            const nh_bf16 hi = nh_to_bf16(v);
+            h8[e] = hi;
+            l8[e] = nh_to_bf16(v - nh_from_bf16(hi));
+        }
+        // operand block of the 32-row tile row >> 5: lane (row & 31) + 32 q, 16 bytes per lane
+        const int off = (((row >> 5) * 2 + q) * 32 + (row & 31)) * 16;
+        *(nh_bf16x8*)(hi_blocks + off) = h8;
+        *(nh_bf16x8*)(lo_blocks + off) = l8;
+    }
+    return sum;
+}
+
+template <int AR, int BR>
+NH_KERNEL void NH_LB(256, 1) k_wgrad_bf16x3(WgBArgs a) {
+    using S = WShape<AR, BR>;
+    constexpr int PO = S::PO, PI = S::PI;
+    NH_DYN_LDS(lds);
+    char* const ah_blk = lds + NHW_STAGES * S::STAGE;
+    char* const al_blk = ah_blk + S::OPER_A;
+    char* const bh_blk = al_blk + S::OPER_A;
+    char* const bl_blk = bh_blk + S::OPER_B;
+    const int lane = nh_lane(), wave = nh_wave_in_block(), tid = (int)threadIdx.x;
+    // this workgroup's block and its range of 16-sample steps (two per sample tile)
+    int jq = 0;
+    while (jq + 1 < a.njobs && (int)blockIdx.x >= a.jobs[jq + 1].wg0) ++jq;
+    const WgBJob& jb = a.jobs[jq];
+    const int64_t k = (int64_t)blockIdx.x - jb.wg0;
+    const int64_t u0 = 2 * (a.nt * k / jb.nwg), u1 = 2 * (a.nt * (k + 1) / jb.nwg);
+    const float* const a_reg = a.grad + jb.a_off;
+    const float* const b_reg = a.stash + jb.b_off;
+    const unsigned lds0 = nh_lds_addr((const float*)lds);
+    auto issue = [&](int64_t u) {  // one step of both regions -> stage u & 1: 1-KiB pieces dealt to the four waves
+        const NhDmaSrc da = nh_dma_src(a_reg + (size_t)u * 16 * AR, (unsigned)S::STAGE_A);
+        const NhDmaSrc db = nh_dma_src(b_reg + (size_t)u * 16 * BR, (unsigned)S::STAGE_B);
+        const unsigned st = lds0 + (unsigned)((int)(u % NHW_STAGES) * S::STAGE);
+        for (int p = wave; p < S::STAGE_A / 1024; p += 4) nh_dma16a(da, lane * 16, p * 1024, st + (unsigned)(p * 1024));
+        for (int p = wave; p < S::STAGE_B / 1024; p += 4) nh_dma16a(db, lane * 16, p * 1024, st + (unsigned)(S::STAGE_A + p * 1024));
+    };
+    f32x16 acc[PO][PI];
+#pragma unroll
+    for (int x = 0; x < PO; ++x)
+#pragma unroll
+        for (int y = 0; y < PI; ++y)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[x][y][c] = 0.0f;
+    float bias = 0.0f;
+    const int ta0 = (wave >> 1) * PO, tb0 = (wave & 1) * PI;
+    constexpr int PIECES = S::STAGE / 4096;  // copy instructions per wave and step
+    static_assert(S::STAGE_A % 4096 == 0 && S::STAGE_B % 4096 == 0, "every wave issues the same number of pieces");
+#pragma unroll
+    for (int d = 0; d < NHW_STAGES; ++d)
+        if (u0 + d < u1) issue(u0 + d);
+    for (int64_t u = u0; u < u1; ++u) {
+        // the copy of step u is this wave's OLDEST outstanding one: wait for it alone while the later steps' copies stay in flight
+#ifndef NHW_EXP_NO_WAIT  // (diagnostic builds only, wrong results)
+        const int64_t behind = u1 - 1 - u < NHW_STAGES - 1 ? u1 - 1 - u : NHW_STAGES - 1;  // steps in flight behind step u
+        if (behind >= 2) nh_wait_vmem_keep<2 * PIECES>();
+        else if (behind == 1) nh_wait_vmem_keep<PIECES>();
+        else nh_wait_vmem();
+#endif
+        nh_block_sync();  // step u has landed for everyone; every wave is done multiplying the previous step's operand blocks
+        const char* const stage = lds + (int)(u % NHW_STAGES) * S::STAGE;
+        RowItems<AR> ra;
+        RowItems<BR> rb;
+        rows_load<AR>((const float*)stage, tid, ra);
+        rows_load<BR>((const float*)(stage + S::STAGE_A), tid, rb);
+        nh_sched_fence();
+        bias += rows_store<AR>(ra, ah_blk, al_blk, tid);
+        (void)rows_store<BR>(rb, bh_blk, bl_blk, tid);
+        nh_block_sync();  // operand blocks complete; this step's stage is free
+        if (u + NHW_STAGES < u1) issue(u + NHW_STAGES);  // (into the stage just converted)
+        nh_bf16x8 ah[PO], al[PO], bh[PI], bl[PI];
+#pragma unroll
+        for (int x = 0; x < PO; ++x) {
+            ah[x] = *(const nh_bf16x8*)(ah_blk + (ta0 + x) * 1024 + lane * 16);
+            al[x] = *(const nh_bf16x8*)(al_blk + (ta0 + x) * 1024 + lane * 16);
+        }
+#pragma unroll
+        for (int y = 0; y < PI; ++y) {
+            bh[y] = *(const nh_bf16x8*)(bh_blk + (tb0 + y) * 1024 + lane * 16);
+            bl[y] = *(const nh_bf16x8*)(bl_blk + (tb0 + y) * 1024 + lane * 16);
+        }
+        nh_sched_fence();
+        // (three sweeps over the accumulator tiles, the small terms first: no MFMA reads the accumulator its predecessor wrote)
+#pragma unroll
+        for (int x = 0; x < PO; ++x)
+#pragma unroll
+            for (int y = 0; y < PI; ++y) acc[x][y] = nh_mfma_bf16(al[x], bh[y], acc[x][y]);
+#pragma unroll
+        for (int x = 0; x < PO; ++x)
+#pragma unroll
+            for (int y = 0; y < PI; ++y) acc[x][y] = nh_mfma_bf16(ah[x], bl[y], acc[x][y]);
+#pragma unroll
+        for (int x = 0; x < PO; ++x)
+#pragma unroll
+            for (int y = 0; y < PI; ++y) acc[x][y] = nh_mfma_bf16(ah[x], bh[y], acc[x][y]);
+    }
+    // the partial: accumulator tile (ta, tb) as [16 registers][64 lanes], then the threads' bias sums
+    float* const part = a.partial + (size_t)blockIdx.x * (size_t)a.part_stride;
+#pragma unroll
+    for (int x = 0; x < PO; ++x)
+#pragma unroll
+        for (int y = 0; y < PI; ++y)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) part[((ta0 + x) * S::TB + (tb0 + y)) * 1024 + c * 64 + lane] = acc[x][y][c];
+    part[AR * BR + tid] = bias;
+}
+
+// sums the split-K partials of a block in workgroup order and scatters them into the reference parameter layout; element
+// (tile (ta, tb), register c, lane l) is row 32 ta + (c & 3) + 8 (c >> 2) + 4 (l >> 5), column 32 tb + (l & 31)
+template <int AR, int BR>
+NH_KERNEL void k_wgrad_bf16_reduce(WgBArgs a) {
+    constexpr int TB = BR / 32, E = AR * BR;
+    const int jq = (int)blockIdx.y;
+    const WgBJob& jb = a.jobs[jq];
+    const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (e < E) {
+        const int tile = e >> 10, c = (e >> 6) & 15, l = e & 63;
+        const int row = 32 * (tile / TB) + (c & 3) + 8 * (c >> 2) + 4 * (l >> 5), col = 32 * (tile % TB) + (l & 31);
+        if (row < jb.r_hi && col < jb.col_count) {
+            float s = 0.0f;
+            for (int k = 0; k < jb.nwg; ++k) s += a.partial[(size_t)(jb.wg0 + k) * (size_t)a.part_stride + e];
+            a.g_params[jb.w_off + (int64_t)row * jb.w_ld + col] = s;
+        }
+    } else if (e < E + AR) {  // bias: thread t of every workgroup summed row t mod AR
+        const int row = e - E;
+        if (row < jb.r_hi && jb.bias_off >= 0) {
+            float s = 0.0f;
+            for (int k = 0; k < jb.nwg; ++k)
+                for (int t = row; t < 256; t += AR) s += a.partial[(size_t)(jb.wg0 + k) * (size_t)a.part_stride + E + t];
+            a.g_params[jb.bias_off + row] = s;
+        }
+    }
+}
+
+template <class K>
+int w_lds_limit(K kern, int bytes) {
+#ifndef NERFHIP_EMU
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        nh_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d): %s", bytes, hipGetErrorString(e));
+        return NERFHIP_ERR_LAUNCH;
+    }
+#else
+    (void)kern;
+    (void)bytes;
+#endif
+    return NERFHIP_OK;
+}
+
+// workgroups per launch: three rounds of one per CU (as k_wgrad's 768), dealt to the blocks in proportion to their size
+constexpr int NHW_WGS = 768;
+
+// fills the job tables of the two launches (blocks with a_rows == W, blocks with a_rows == W / 2); returns partial floats needed
+int64_t schedule(nerfhip_plan* p, int64_t nt, WgBArgs* full, WgBArgs* half) {
+    const int W = p->W;
+    int64_t units = 0;
+    for (const NhJobB& j : p->bjobs) units += j.a_rows == W ? 2 : 1;
+    int64_t floats = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        WgBArgs* w = pass == 0 ? full : half;
+        const int ar = pass == 0 ? W : W / 2;
+        int n = 0, wg = 0;
+        for (const NhJobB& j : p->bjobs) {
+            if (j.a_rows != ar) continue;
+            int64_t nwg = units ? (int64_t)NHW_WGS * (pass == 0 ? 2 : 1) / units : 1;
+            if (nwg < 1) nwg = 1;
+            if (nwg > nt) nwg = nt > 0 ? nt : 1;
+            if (w && n < NHW_MAX_JOBS) {
+                WgBJob& d = w->jobs[n];
+                d.a_off = 32 * nt * j.a_row_prefix;
+                d.b_off = 32 * nt * j.b_row_prefix;
+                d.wg0 = wg;
+                d.nwg = (int)nwg;
+                d.r_hi = j.r_hi;
+                d.col_count = j.col_count;
+                d.w_ld = j.w_ld;
+                d.w_off = j.w_off;
+                d.bias_off = j.bias_off;
+            }
+            ++n;
+            wg += (int)nwg;
+        }
+        const int stride = ar * W + 256;
+        if (w) {
+            w->njobs = n;
+            w->part_stride = stride;
+            w->nt = nt;
+        }
+        floats += (int64_t)wg * stride;
+    }
+    return floats;
+}
+
+template <int AR, int BR>
+int launch(WgBArgs& w, nerfhip_stream_t stream) {
+    if (w.njobs == 0) return NERFHIP_OK;
+    int rc = w_lds_limit(k_wgrad_bf16x3<AR, BR>, WShape<AR, BR>::LDS_BYTES);
+    if (rc) return rc;
+    const int wgs = w.jobs[w.njobs - 1].wg0 + w.jobs[w.njobs - 1].nwg;
+    NH_LAUNCH((k_wgrad_bf16x3<AR, BR>), wgs, 256, (WShape<AR, BR>::LDS_BYTES), stream, w);
+    rc = nh_launch_status("wgrad_bf16x3");
+    if (rc) return rc;
+#ifdef NERFHIP_EMU
+    for (int q = 0; q < w.njobs; ++q) {  // (the emulator's launch takes a one-dimensional grid: one block per launch)
+        WgBArgs one = w;
+        one.njobs = 1;
+        one.jobs[0] = w.jobs[q];
+        NH_LAUNCH((k_wgrad_bf16_reduce<AR, BR>), (AR * BR + AR + 255) / 256, 256, 0, stream, one);
+    }
+#else
+    hipLaunchKernelGGL((k_wgrad_bf16_reduce<AR, BR>), dim3((AR * BR + AR + 255) / 256, w.njobs), dim3(256), 0, (hipStream_t)stream, w);
+#endif
+    return nh_launch_status("wgrad_bf16_reduce");
+}
+
+}  // namespace
+
+int64_t nh_wgrad_bf16_partial_floats(nerfhip_plan* p, int64_t nt) {
+    if (p->bjobs.empty()) return 0;
+    return schedule(p, nt > 0 ? nt : 1, nullptr, nullptr);
+}
+
+int nh_wgrad_bf16(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad, float* partial, float* g_params,
+                  nerfhip_stream_t stream) {
+    if (p->bjobs.empty()) return NERFHIP_OK;
+    NH_REQUIRE((int)p->bjobs.size() <= NHW_MAX_JOBS, "wgrad_bf16: too many blocks");
+    WgBArgs full, half;
+    memset(&full, 0, sizeof(full));
+    memset(&half, 0, sizeof(half));
+    schedule(p, nt, &full, &half);
+    full.stash = half.stash = stash;
+    full.grad = half.grad = grad;
+    full.g_params = half.g_params = g_params;
+    full.partial = partial;
+    // (the second launch's partials follow the first's)
+    int64_t first = 0;
+    if (full.njobs) first = (int64_t)(full.jobs[full.njobs - 1].wg0 + full.jobs[full.njobs - 1].nwg) * full.part_stride;
+    half.partial = partial + first;
+    int rc = NERFHIP_OK;
+    if (p->W == 256) {  // (plan.cpp hands this kernel blocks only for the 256-wide nets)
+        rc = launch<256, 256>(full, stream);
+        if (!rc) rc = launch<128, 256>(half, stream);
+    } else {
+        nh_set_error("wgrad_bf16: no kernel for kernel width %d", p->W);
+        return NERFHIP_ERR_UNSUPPORTED;
+    }
+    return rc;
+}

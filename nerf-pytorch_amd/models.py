@@ -17,7 +17,7 @@ from .nerf_helpers import frequency_bands_cpu
 
 
 PRECISIONS = {"fp32": L.PRECISION_FP32, "bf16x3": L.PRECISION_BF16X3, "bf16x3_fwd": L.PRECISION_BF16X3_FWD,
-              "bf16x3_fwd_dgrad": L.PRECISION_BF16X3_FWD_DGRAD}
+              "bf16x3_fwd_dgrad": L.PRECISION_BF16X3_FWD_DGRAD, "bf16x3_train": L.PRECISION_BF16X3_TRAIN}
 
 
 class _PlanHandle:
@@ -174,11 +174,12 @@ class FlexibleNeRFModel(torch.nn.Module):
         """Arithmetic of this model's TRAINING forward passes: "fp32" (default: the reference's, what every parity claim
         and the headline benchmark refer to) or "bf16x3_fwd" (NERFHIP_PRECISION_BF16X3_FWD: the forward -- training and
         inference alike -- on the split-bf16 kernel, the backward kernels unchanged fp32) or "bf16x3_fwd_dgrad" (the
-        data-gradient chain on it too; the weight-gradient GEMMs stay fp32).  Experiments accepted by PSNR@iters, not by the
+        data-gradient chain on it too; the weight-gradient GEMMs stay fp32) or "bf16x3_train" (the large weight-gradient blocks
+        on the bf16 MFMAs as well).  Experiments accepted by PSNR@iters, not by the
         1e-4 bar: DESIGN.md 7.4-7.5.  Parameters (re-homed into a fresh flat buffer, same Parameter objects), optimizer state
         and checkpoints are unaffected; call it before a TrainEngine is built on the model."""
-        if precision not in ("fp32", "bf16x3_fwd", "bf16x3_fwd_dgrad"):
-            raise ValueError("training precision must be 'fp32', 'bf16x3_fwd' or 'bf16x3_fwd_dgrad' (got %r)" % (precision,))
+        if precision not in ("fp32", "bf16x3_fwd", "bf16x3_fwd_dgrad", "bf16x3_train"):
+            raise ValueError("training precision must be 'fp32', 'bf16x3_fwd', 'bf16x3_fwd_dgrad' or 'bf16x3_train' (got %r)" % (precision,))
         _PlanHandle(self.cfg, PRECISIONS[precision])  # (raises for a geometry the bf16x3 kernels do not cover, before anything changes)
         self.training_precision = precision
         self._native_init()

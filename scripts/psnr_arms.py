@@ -12,6 +12,7 @@ MANY seeds, everything else identical per seed (initial weights, training views,
     engine_bf16fwd  `engine` with NERFHIP_PRECISION_BF16X3_FWD nets: the forward passes on the split-bf16 kernel, the backward
                kernels unchanged fp32 (same draws as `engine`: differs from it only in the forward's arithmetic)
     engine_bf16fd   the same with NERFHIP_PRECISION_BF16X3_FWD_DGRAD nets: the data-gradient chain on the split-bf16 kernel too
+    engine_bf16tr   the same with NERFHIP_PRECISION_BF16X3_TRAIN nets: also the hidden x hidden weight-gradient blocks (256-wide nets)
 
 Scene: the teacher of scripts/psnr400.py (pretrained lego-lowres nets rendered at 400x400, 100 training / 10 held-out
 views).  Students: --hidden x --layers nets (default the reference's own 4x128: its scripts build FlexibleNeRFModel with
@@ -81,8 +82,8 @@ def run(arm, seed, iters, check, student, poses, imgs, train, views):
         ex, ed = N.get_embedding_function(10, True, True), N.get_embedding_function(4, True, True)
     else:
         mc, mf = mc.to(dev), mf.to(dev)
-        if arm in ("engine_bf16fwd", "engine_bf16fd"):  # the engine arm with both nets' forwards (and data gradients) on the split-bf16 kernels
-            prec = "bf16x3_fwd" if arm == "engine_bf16fwd" else "bf16x3_fwd_dgrad"
+        if arm in ("engine_bf16fwd", "engine_bf16fd", "engine_bf16tr"):  # the engine arm on the split-bf16 training precisions
+            prec = {"engine_bf16fwd": "bf16x3_fwd", "engine_bf16fd": "bf16x3_fwd_dgrad", "engine_bf16tr": "bf16x3_train"}[arm]
             mc.set_training_precision(prec)
             mf.set_training_precision(prec)
         eng = N.TrainEngine(mc, mf, NC, NF, perturb=True, white_background=True, noise_std=0.2, lr=5e-3, seed=seed)

@@ -46,7 +46,7 @@ def main(root):
           % (last, collapsed or "none"))
     print("# seeds dropped from the paired statistics: %s" % (bad or "none"))
     use = [s for s in sorted(runs) if s not in bad]
-    arms = [a for a in ("ref", "dropin", "engine_td", "engine", "engine_bf16fwd", "engine_bf16fd") if any(a in runs[s]["arms"] for s in use)]
+    arms = [a for a in ("ref", "dropin", "engine_td", "engine", "engine_bf16fwd", "engine_bf16fd", "engine_bf16tr") if any(a in runs[s]["arms"] for s in use)]
     checks = sorted(int(k) for k in any_run["arms"]["engine"])
     print("\n== validation PSNR (coarse+fine), mean over usable seeds [n] ==")
     print("%-10s" % "iteration" + "".join("%16s" % a for a in arms))
@@ -57,7 +57,7 @@ def main(root):
             row += "%11.3f [%2d]" % (sum(v) / len(v), len(v)) if v else "%16s" % "-"
         print(row)
     pairs = [("engine", "ref"), ("engine", "dropin"), ("engine", "engine_td"), ("engine_td", "dropin"), ("dropin", "ref")]
-    extra = [(a, "engine") for a in ("engine_bf16fwd", "engine_bf16fd") if any(a in runs[s]["arms"] for s in use)]
+    extra = [(a, "engine") for a in ("engine_bf16fwd", "engine_bf16fd", "engine_bf16tr") if any(a in runs[s]["arms"] for s in use)]
     if extra:
         pairs = extra + [p for p in pairs if all(any(a in runs[s]["arms"] for s in use) for a in p)]
     for key, label in (("val_psnr", "validation PSNR coarse+fine"), ("val_psnr_fine", "validation PSNR, fine net alone"),

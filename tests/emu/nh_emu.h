@@ -218,6 +218,8 @@ NH_DEVICE void nh_dma16a(const NhDmaSrc& s, int voff, int soff, unsigned lds_wav
     nh_dma16(s, voff, soff, (float*)(emu::g_dyn_smem + lds_wave_addr));
 }
 NH_DEVICE void nh_wait_vmem() {}
+template <int N>
+NH_DEVICE void nh_wait_vmem_keep() {}
 NH_DEVICE void nh_sched_fence() {}
 NH_DEVICE unsigned long long nh_wall_clock() { return 0ull; }
 NH_DEVICE unsigned long long nh_core_clock() { return 0ull; }

@@ -328,7 +328,7 @@ def case_mlp_forward(b, names=None, m=70):
         b.lib.plan_destroy(plan)
 
 
-BF16X3, BF16X3_FWD, BF16X3_FWD_DGRAD = 1, 2, 3  # NERFHIP_PRECISION_*
+BF16X3, BF16X3_FWD, BF16X3_FWD_DGRAD, BF16X3_TRAIN = 1, 2, 3, 4  # NERFHIP_PRECISION_*
 BF16X3_GEOMETRIES = ("default4x128", "northstar8x256", "fern8x128_skip3_L6", "novw4x128", "two_layer_L4_L2", "one_layer",
                      "one_layer_novw_256", "skip_every_layer_256", "noinput_linear", "odd5x99_skip2", "wide3x200_skip1",
                      "novw2x130")

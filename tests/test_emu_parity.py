@@ -110,6 +110,15 @@ def test_mlp_bf16x3_forward_and_data_gradient(emu):
                             tol=5e-4, grad_tol=(5e-3, 5e-2), precision=P.BF16X3_FWD_DGRAD)
 
 
+def test_mlp_bf16x3_whole_training_step(emu):
+    """NERFHIP_PRECISION_BF16X3_TRAIN: forward, data gradient AND the large weight-gradient blocks on the bf16 MFMAs (the thin
+    blocks -- encoding columns, fc_alpha, fc_rgb / fc_out -- stay on the fp32 kernel)."""
+    P.case_mlp_backward(emu, names=("default4x128", "fern8x128_skip3_L6", "novw4x128", "skip_every_layer_256", "odd5x99_skip2",
+                                    "one_layer", "two_layer_L4_L2"), m=200, precision=P.BF16X3_TRAIN)
+    P.case_render_vs_oracle(emu, P.MLP_GEOMETRIES["default4x128"], n=12, nc=16, nf=16, with_grads=True, tag="bf16x3_train_emu",
+                            tol=5e-4, grad_tol=(5e-3, 5e-2), precision=P.BF16X3_TRAIN)
+
+
 def test_ndc_rays_backward(emu):
     P.case_ndc_rays_bwd(emu, n=200)
 

@@ -108,6 +108,15 @@ def test_mlp_bf16x3_forward_and_data_gradient(gpu):
                             tol=5e-4, grad_tol=(5e-3, 5e-2), precision=P.BF16X3_FWD_DGRAD)
 
 
+def test_mlp_bf16x3_whole_training_step(gpu):
+    P.case_mlp_backward(gpu, names=("default4x128", "fern8x128_skip3_L6", "novw4x128", "skip_every_layer_256", "odd5x99_skip2",
+                                    "one_layer", "two_layer_L4_L2", "northstar8x256"), m=1500, precision=P.BF16X3_TRAIN)
+    P.case_render_vs_oracle(gpu, P.MLP_GEOMETRIES["northstar8x256"], n=48, nc=64, nf=128, with_grads=True, tag="bf16x3_train_8x256_48",
+                            tol=5e-4, grad_tol=(5e-3, 5e-2), precision=P.BF16X3_TRAIN)
+    P.case_render_vs_oracle(gpu, P.MLP_GEOMETRIES["default4x128"], n=200, nc=64, nf=64, with_grads=True, tag="bf16x3_train_4x128_200",
+                            tol=5e-4, grad_tol=(5e-3, 5e-2), precision=P.BF16X3_TRAIN)
+
+
 def test_ndc_rays_backward(gpu):
     P.case_ndc_rays_bwd(gpu, n=5000)
 

@@ -62,7 +62,8 @@ def bench_lines():
                      ("bench_eval_bf16x3_4x128.log", "bench_line_eval_800x800_4x128_bf16x3.json"),
                      ("bench_bf16x3_fwd.log", "bench_line_bf16x3_fwd.json"), ("bench_bf16x3_fwd_4x128.log", "bench_line_bf16x3_fwd_4x128.json"),
                      ("bench_bf16x3_fwd_dgrad.log", "bench_line_bf16x3_fwd_dgrad.json"),
-                     ("bench_bf16x3_fwd_dgrad_4x128.log", "bench_line_bf16x3_fwd_dgrad_4x128.json")):
+                     ("bench_bf16x3_fwd_dgrad_4x128.log", "bench_line_bf16x3_fwd_dgrad_4x128.json"),
+                     ("bench_bf16x3_train.log", "bench_line_bf16x3_train.json")):
         if os.path.exists(os.path.join(G, src)):
             json.dump(last_json_line(os.path.join(G, src)), open(os.path.join(P, "%s_%s" % (tag, dst)), "w"), indent=1)
     with open(os.path.join(P, tag + "_multi_rank_one_gpu.txt"), "w") as f:

@@ -20,6 +20,7 @@ timeout 200 python bench.py --no-cpu-baseline --precision bf16x3_fwd > $R/bench_
 timeout 200 python bench.py --no-cpu-baseline --precision bf16x3_fwd --hidden 128 --layers 4 --overlap 0 > $R/bench_bf16x3_fwd_4x128.log 2>&1
 timeout 200 python bench.py --no-cpu-baseline --precision bf16x3_fwd_dgrad > $R/bench_bf16x3_fwd_dgrad.log 2>&1
 timeout 200 python bench.py --no-cpu-baseline --precision bf16x3_fwd_dgrad --hidden 128 --layers 4 --overlap 0 > $R/bench_bf16x3_fwd_dgrad_4x128.log 2>&1
+timeout 200 python bench.py --no-cpu-baseline --precision bf16x3_train > $R/bench_bf16x3_train.log 2>&1
 for r in 2048 1024; do timeout 200 python bench.py --rays $r --no-cpu-baseline > $R/bench_rays$r.log 2>&1; done
 export NERFHIP_BENCH_ONE_DEVICE=1
 timeout 200 python bench.py --gpus 2 --steps 6 --warmup 2 > $R/dp2_weak.log 2>&1; echo "rc=$?" >> $R/dp2_weak.log
@@ -41,5 +42,5 @@ if [ -f nerf-pytorch_amd/libnerfhip_dbg.so ]; then
   timeout 200 python scripts/phase_timing.py > $R/phase_timing.txt 2>&1
 fi
 grep -E "passed|failed|error" $R/pytest_gpu.log | tail -3; tail -2 $R/smoke.log; tail -2 $R/bench.log | cut -c1-1500
-for f in bench_4x128 bench_4x128_single bench_4x64 bench_8x512 bench_eval bench_eval_bf16x3 bench_eval_fp32_4x128 bench_eval_bf16x3_4x128 bench_bf16x3_fwd bench_bf16x3_fwd_4x128 bench_bf16x3_fwd_dgrad bench_bf16x3_fwd_dgrad_4x128 bench_rays2048 bench_rays1024 dp2_weak dp2_strong dp2_eval; do echo "== $f"; grep "^{" $R/$f.log | tail -1 | cut -c1-260; done
+for f in bench_4x128 bench_4x128_single bench_4x64 bench_8x512 bench_eval bench_eval_bf16x3 bench_eval_fp32_4x128 bench_eval_bf16x3_4x128 bench_bf16x3_fwd bench_bf16x3_fwd_4x128 bench_bf16x3_fwd_dgrad bench_bf16x3_fwd_dgrad_4x128 bench_bf16x3_train bench_rays2048 bench_rays1024 dp2_weak dp2_strong dp2_eval; do echo "== $f"; grep "^{" $R/$f.log | tail -1 | cut -c1-260; done
 cat $R/pmc_summary_8x256_4096.txt $R/pmc_summary_4x128_4096.txt; ls $R/prof $R/prof128 | head

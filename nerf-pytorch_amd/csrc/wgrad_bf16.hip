@@ -5,14 +5,14 @@
 //
 // both fp32, sample-major ([32-sample tile][sample][rows]).  v_mfma_f32_32x32x16_bf16 wants a lane's 8 consecutive k (= samples)
 // of ONE row in 16 contiguous bytes, and each fp32 value split into two bf16 pieces (hi = bf16(v), lo = bf16(v - hi);
-// A.B ~ Ah.Bh + Ah.Bl + Al.Bh, fp32 accumulation: the arithmetic of mlp_bf16.hip).  So a workgroup (4 waves, one per SIMD) walks
+// A.B ~ Ah.Bh + Ah.Bl + Al.Bh, fp32 accumulation: the arithmetic of mlp_bf16.hip).  So a workgroup (8 waves) walks
 // over its range of samples in steps of 16 (one k-block), two phases per step:
 //   convert : the step's A and B blocks (contiguous in HBM, brought to LDS by LDS-DMA into one of two fp32 stages: the copies of
 //             the next two steps are in flight while this one is converted and multiplied) are read row-wise -- thread t owns row t mod rows: 8 samples of it per item, strided dword reads, conflict-free across
 //             the wave --, split, and written back k-minor as MFMA operand blocks ([32-row tile][k-block][lane] x 16 B); the same
 //             thread keeps the running row sum of A (the bias gradient);
-//   multiply: wave (wo, wi) of the 2 x 2 grid owns a quarter of the block (4 x 4 accumulator tiles = 256 AGPRs for a 256 x 256
-//             block): 8 + 8 operand reads and 48 MFMAs per step.
+//   multiply: wave (wo, wi) of the 4 x 2 grid (8 waves, two per SIMD) owns an eighth of the block (2 x 4 accumulator tiles = 128
+//             AGPRs for a 256 x 256 block): 4 + 8 operand reads and 24 MFMAs per step.
 // Split-K over the workgroups of a block; the partials (accumulator tiles as [tile][16 registers][64 lanes], then the 256 threads'
 // bias sums) are summed in a fixed order by k_wgrad_bf16_reduce -- bit-reproducible, no atomics -- and scattered into the
 // reference parameter layout.
@@ -22,6 +22,11 @@
 namespace {
 
 constexpr int NHW_MAX_JOBS = 40;
+#ifndef NHW_WAVES  // (A/B builds only) waves per workgroup: 4 (one per SIMD, 4 x 4 accumulator tiles each) or 8 (two per SIMD, 2 x 4:
+                   // measured 10 % faster -- the two waves of a SIMD hide each other's LDS latencies inside a phase)
+#define NHW_WAVES 8
+#endif
+constexpr int NHW_THREADS = 64 * NHW_WAVES;
 #ifndef NHW_STAGES  // (A/B builds only) fp32 stages in LDS = 16-sample steps whose copies are in flight; 2 measured 4 % faster than 3
 #define NHW_STAGES 2
 #endif
@@ -44,12 +49,12 @@ struct WgBArgs {
 
 template <int AR, int BR>
 struct WShape {
-    static constexpr int PO = AR / 64, PI = BR / 64, TA = AR / 32, TB = BR / 32;
+    static constexpr int PO = AR / (16 * NHW_WAVES), PI = BR / 64, TA = AR / 32, TB = BR / 32;  // wave grid (NHW_WAVES / 2) x 2
     static constexpr int STAGE_A = AR * 64, STAGE_B = BR * 64;   // bytes of one 16-sample step of the region, fp32
     static constexpr int STAGE = STAGE_A + STAGE_B;               // (NHW_STAGES of them: the copies of the next steps land while step u is converted)
     static constexpr int OPER_A = AR * 32, OPER_B = BR * 32;      // bytes of its high (or low) operand blocks
     static constexpr int LDS_BYTES = NHW_STAGES * STAGE + 2 * OPER_A + 2 * OPER_B;
-    static constexpr int PART = AR * BR + 256;
+    static constexpr int PART = AR * BR + NHW_THREADS;
 };
 
 // rows -> operand blocks of one 16-sample k-block: item id = row + rows * q handles samples 8 q .. 8 q + 7 of `row` (q = the lane
@@ -58,15 +63,15 @@ struct WShape {
 // then split and written back.  rows_load returns nothing; rows_store returns the sum of the values (the bias gradient's share).
 template <int ROWS>
 struct RowItems {
-    static constexpr int N = (ROWS * 2 + 255) / 256;  // items per thread
+    static constexpr int N = (ROWS * 2 + NHW_THREADS - 1) / NHW_THREADS;  // items per thread
     float v[N][8];
 };
 template <int ROWS>
 NH_DEVICE void rows_load(const float* stage, int tid, RowItems<ROWS>& r) {
 #pragma unroll
     for (int it = 0; it < RowItems<ROWS>::N; ++it) {
-        const int id = tid + 256 * it;
-        const bool on = ROWS * 2 % 256 == 0 || id < ROWS * 2;
+        const int id = tid + NHW_THREADS * it;
+        const bool on = ROWS * 2 % NHW_THREADS == 0 || id < ROWS * 2;
         const int row = id % ROWS, q = on ? id / ROWS : 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) r.v[it][e] = on ? stage[(8 * q + e) * ROWS + row] : 0.0f;
@@ -77,8 +82,8 @@ NH_DEVICE float rows_store(const RowItems<ROWS>& r, char* hi_blocks, char* lo_bl
     float sum = 0.0f;
 #pragma unroll
     for (int it = 0; it < RowItems<ROWS>::N; ++it) {
-        const int id = tid + 256 * it;
-        if (ROWS * 2 % 256 != 0 && id >= ROWS * 2) break;
+        const int id = tid + NHW_THREADS * it;
+        if (ROWS * 2 % NHW_THREADS != 0 && id >= ROWS * 2) break;
         const int row = id % ROWS, q = id / ROWS;
         nh_bf16x8 h8, l8;
 #pragma unroll
@@ -98,7 +103,7 @@ NH_DEVICE float rows_store(const RowItems<ROWS>& r, char* hi_blocks, char* lo_bl
 }
 
 template <int AR, int BR>
-NH_KERNEL void NH_LB(256, 1) k_wgrad_bf16x3(WgBArgs a) {
+NH_KERNEL void NH_LB(NHW_THREADS, NHW_WAVES / 4) k_wgrad_bf16x3(WgBArgs a) {
     using S = WShape<AR, BR>;
     constexpr int PO = S::PO, PI = S::PI;
     NH_DYN_LDS(lds);
@@ -120,8 +125,8 @@ NH_KERNEL void NH_LB(256, 1) k_wgrad_bf16x3(WgBArgs a) {
         const NhDmaSrc da = nh_dma_src(a_reg + (size_t)u * 16 * AR, (unsigned)S::STAGE_A);
         const NhDmaSrc db = nh_dma_src(b_reg + (size_t)u * 16 * BR, (unsigned)S::STAGE_B);
         const unsigned st = lds0 + (unsigned)((int)(u % NHW_STAGES) * S::STAGE);
-        for (int p = wave; p < S::STAGE_A / 1024; p += 4) nh_dma16a(da, lane * 16, p * 1024, st + (unsigned)(p * 1024));
-        for (int p = wave; p < S::STAGE_B / 1024; p += 4) nh_dma16a(db, lane * 16, p * 1024, st + (unsigned)(S::STAGE_A + p * 1024));
+        for (int p = wave; p < S::STAGE_A / 1024; p += NHW_WAVES) nh_dma16a(da, lane * 16, p * 1024, st + (unsigned)(p * 1024));
+        for (int p = wave; p < S::STAGE_B / 1024; p += NHW_WAVES) nh_dma16a(db, lane * 16, p * 1024, st + (unsigned)(S::STAGE_A + p * 1024));
     };
     f32x16 acc[PO][PI];
 #pragma unroll
@@ -132,8 +137,8 @@ NH_KERNEL void NH_LB(256, 1) k_wgrad_bf16x3(WgBArgs a) {
             for (int c = 0; c < 16; ++c) acc[x][y][c] = 0.0f;
     float bias = 0.0f;
     const int ta0 = (wave >> 1) * PO, tb0 = (wave & 1) * PI;
-    constexpr int PIECES = S::STAGE / 4096;  // copy instructions per wave and step
-    static_assert(S::STAGE_A % 4096 == 0 && S::STAGE_B % 4096 == 0, "every wave issues the same number of pieces");
+    constexpr int PIECES = S::STAGE / (1024 * NHW_WAVES);  // copy instructions per wave and step
+    static_assert(S::STAGE_A % (1024 * NHW_WAVES) == 0 && S::STAGE_B % (1024 * NHW_WAVES) == 0, "every wave issues the same number of pieces");
 #pragma unroll
     for (int d = 0; d < NHW_STAGES; ++d)
         if (u0 + d < u1) issue(u0 + d);
@@ -190,7 +195,7 @@ NH_KERNEL void NH_LB(256, 1) k_wgrad_bf16x3(WgBArgs a) {
         for (int y = 0; y < PI; ++y)
 #pragma unroll
             for (int c = 0; c < 16; ++c) part[((ta0 + x) * S::TB + (tb0 + y)) * 1024 + c * 64 + lane] = acc[x][y][c];
-    part[AR * BR + tid] = bias;
+    part[AR * BR + tid] = bias;  // (thread t summed row t mod AR)
 }
 
 // sums the split-K partials of a block in workgroup order and scatters them into the reference parameter layout; element
@@ -214,7 +219,7 @@ NH_KERNEL void k_wgrad_bf16_reduce(WgBArgs a) {
         if (row < jb.r_hi && jb.bias_off >= 0) {
             float s = 0.0f;
             for (int k = 0; k < jb.nwg; ++k)
-                for (int t = row; t < 256; t += AR) s += a.partial[(size_t)(jb.wg0 + k) * (size_t)a.part_stride + E + t];
+                for (int t = row; t < NHW_THREADS; t += AR) s += a.partial[(size_t)(jb.wg0 + k) * (size_t)a.part_stride + E + t];
             a.g_params[jb.bias_off + row] = s;
         }
     }
@@ -268,7 +273,7 @@ int64_t schedule(nerfhip_plan* p, int64_t nt, WgBArgs* full, WgBArgs* half) {
             ++n;
             wg += (int)nwg;
         }
-        const int stride = ar * W + 256;
+        const int stride = ar * W + NHW_THREADS;
         if (w) {
             w->njobs = n;
             w->part_stride = stride;
@@ -285,7 +290,7 @@ int launch(WgBArgs& w, nerfhip_stream_t stream) {
     int rc = w_lds_limit(k_wgrad_bf16x3<AR, BR>, WShape<AR, BR>::LDS_BYTES);
     if (rc) return rc;
     const int wgs = w.jobs[w.njobs - 1].wg0 + w.jobs[w.njobs - 1].nwg;
-    NH_LAUNCH((k_wgrad_bf16x3<AR, BR>), wgs, 256, (WShape<AR, BR>::LDS_BYTES), stream, w);
+    NH_LAUNCH((k_wgrad_bf16x3<AR, BR>), wgs, NHW_THREADS, (WShape<AR, BR>::LDS_BYTES), stream, w);
     rc = nh_launch_status("wgrad_bf16x3");
     if (rc) return rc;
 #ifdef NERFHIP_EMU

@@ -225,10 +225,20 @@ NH_KERNEL void k_wgrad_bf16_reduce(WgBArgs a) {
     } else if (e < E + AR) {  // bias: thread t of every workgroup summed row t mod AR
         const int row = e - E;
         if (row < jb.r_hi && jb.bias_off >= 0) {
-            float s = 0.0f;
-            for (int k = 0; k < jb.nwg; ++k)
-                for (int t = row; t < NHW_THREADS; t += AR) s += a.partial[(size_t)(jb.wg0 + k) * (size_t)a.part_stride + E + t];
-            a.g_params[jb.bias_off + row] = s;
+            // (the same eight interleaved sums: as ONE chain this was up to 1024 dependent loads -- the kernel's long pole)
+            float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const float* const src = a.partial + (size_t)jb.wg0 * (size_t)a.part_stride + E + row;
+            int k = 0;
+            for (; k + 8 <= jb.nwg; k += 8) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int t = 0; t < NHW_THREADS; t += AR) s8[q] += src[(size_t)(k + q) * (size_t)a.part_stride + t];
+            }
+            for (int q = 0; k < jb.nwg; ++k, ++q)
+#pragma unroll
+                for (int t = 0; t < NHW_THREADS; t += AR) s8[q] += src[(size_t)k * (size_t)a.part_stride + t];
+            a.g_params[jb.bias_off + row] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
         }
     }
 }

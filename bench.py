@@ -44,7 +44,7 @@ RAYS_PER_GPU = 4096
 NC, NF = 64, 128
 MODEL = dict(num_layers=8, hidden_size=256, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md chip table (256 CUs x 256 FLOP/clk at 2.4 GHz)
-BF16X3_PEAK_TFLOPS = 2500.0 / 3.0  # dense bf16 MFMA peak (same table) / three MFMAs per fp32-equivalent product block
+BF16X3_PEAK_TFLOPS = 2500.0 / 3.0  # dense bf16 / fp16 MFMA peak (same table) / three MFMAs per fp32-equivalent product block
 HBM_PEAK_TBS = 8.0             # same guide: HBM3E ~8 TB/s
 PEAK_CLOCK_GHZ = 2.4
 
@@ -73,30 +73,45 @@ def macs_per_sample(cfg, dx=63, dd=27):
     return fwd, dgrad
 
 
-def cpu_baseline(sample_rays=RAYS_PER_GPU):
+def _synthetic_batch(O, wl, cfg, n, g):
+    """n rays of the workload's geometry + targets + the reference's four random draws (CPU tensors)."""
+    nc, nf = wl["nc"], wl["nf"]
+    if wl["no_ndc"]:
+        ro = torch.tensor([0.0, 0.0, 4.0]).expand(n, 3)
+        rd = torch.randn(n, 3, generator=g) * 0.3
+        rd[:, 2] = -1.0
+        rays = O.pack_rays(ro, rd, wl["near"], wl["far"], rd)
+    else:  # forward-facing capture: NDC rays (nerf/train_utils.py:156-160), viewdirs from the pre-NDC directions
+        ro = torch.tensor([0.0, 0.0, 0.3]).expand(n, 3) + 0.05 * torch.randn(n, 3, generator=g)
+        rd = torch.randn(n, 3, generator=g) * 0.3
+        rd[:, 2] = -1.0
+        no, nd = O.ndc_rays(wl["H"], wl["W"], wl["focal"], 1.0, ro, rd)
+        rays = O.pack_rays(no, nd, wl["near"], wl["far"], rd)
+    tgt = torch.rand(n, 3, generator=g)
+    rand = dict(t_rand=torch.rand(n, nc, generator=g), noise_coarse=torch.randn(n, nc, generator=g),
+                u=torch.rand(n, nf, generator=g), noise_fine=torch.randn(n, nc + nf, generator=g))
+    opt = dict(num_coarse=nc, num_fine=nf, perturb=True, lindisp=False, white_background=False, noise_std=wl["noise"])
+    return rays, tgt, rand, opt
+
+
+def cpu_baseline(sample_rays=RAYS_PER_GPU, wl=None, cfg=None):
     """The oracle (kind "port": oracle/nerf_oracle.py, the CPU restatement of the reference path, bit-identical to the
     reference's own functions on CPU -- tests/test_oracle.py) forward + backward on ONE full batch of `sample_rays`
-    synthetic rays, 64+128 samples, 8x256 nets, after a 64-ray warm-up (thread pool, allocator)."""
+    synthetic rays of the workload, after a 64-ray warm-up (thread pool, allocator)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import nerf_oracle as O
+    wl = wl or WORKLOADS["lego"]
+    cfg = dict(cfg or wl["model"])
     # 16-32 threads is the fastest setting on the 256-thread EPYC host of the GPU box (measured: 8 -> 520, 16 -> 709,
     # 32 -> 576, 64 -> 253, 128 -> 49 rays/s at 128 rays; profiles/r01_cpu_threads.txt): more threads only add
     # fork/join overhead
     torch.set_num_threads(min(32, os.cpu_count() or 1))
-    cfg = dict(MODEL)
     pc = {k: v.requires_grad_(True) for k, v in O.init_params(cfg, seed=1).items()}
     pf = {k: v.requires_grad_(True) for k, v in O.init_params(cfg, seed=2).items()}
     g = torch.Generator().manual_seed(0)
-    opt = dict(num_coarse=NC, num_fine=NF, perturb=True, lindisp=False, white_background=False, noise_std=0.2)
 
     def one(n):
-        ro = torch.tensor([0.0, 0.0, 4.0]).expand(n, 3)
-        rd = torch.randn(n, 3, generator=g) * 0.3
-        rd[:, 2] = -1.0
-        rays = O.pack_rays(ro, rd, 2.0, 6.0, rd)
-        tgt = torch.rand(n, 3, generator=g)
-        rand = dict(t_rand=torch.rand(n, NC, generator=g), noise_coarse=torch.randn(n, NC, generator=g),
-                    u=torch.rand(n, NF, generator=g), noise_fine=torch.randn(n, NC + NF, generator=g))
+        rays, tgt, rand, opt = _synthetic_batch(O, wl, cfg, n, g)
         t0 = time.perf_counter()
         out = O.render_rays(rays, pc, pf, cfg, cfg, opt, rand, chunksize=131072)
         loss, _, _, _ = O.loss_and_psnr(out["rgb_coarse"], out["rgb_fine"], tgt)
@@ -109,9 +124,10 @@ def cpu_baseline(sample_rays=RAYS_PER_GPU):
     n = sample_rays
     dt = one(n)
     return dict(value=n / dt, unit="rays/s", cores=torch.get_num_threads(), kind="port", seconds=round(dt, 2),
-                sample="one full batch of %d rays x (64 coarse + 128 fine), 8x256 nets, fwd+bwd (no optimizer), after a 64-ray "
+                sample="one full batch of %d rays x (%d coarse + %d fine), %dx%d nets, fwd+bwd (no optimizer), after a 64-ray "
                        "warm-up; oracle/nerf_oracle.py = the reference's functions restated on torch %s CPU ops (bit-identical "
-                       "to the reference on CPU, tests/test_oracle.py)" % (n, torch.__version__))
+                       "to the reference on CPU, tests/test_oracle.py)" % (n, wl["nc"], wl["nf"], cfg["num_layers"], cfg["hidden_size"],
+                                                                           torch.__version__))
 
 
 def dropin_route(dev, n=RAYS_PER_GPU, steps=5, warmup=2):
@@ -173,25 +189,23 @@ def stash_bytes_per_sample(cfg, dx_slots=64, dd_slots=32):
     return 4 * (dx_slots + dd_slots + L * Wd + Wd + Wd // 2) + 8 * (L + 1)
 
 
-def pytorch_rocm_reference(dev, n=RAYS_PER_GPU, reps=3):
+def pytorch_rocm_reference(dev, n=RAYS_PER_GPU, reps=3, wl=None, cfg=None):
     """The reference's own PyTorch path (the oracle's torch ops, op for op) on THIS GPU: forward+backward on n rays --
     the denominator of the north star's "x the reference single-GPU PyTorch-ROCm rays/sec"."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import nerf_oracle as O
-    cfg = dict(MODEL)
+    wl = wl or WORKLOADS["lego"]
+    cfg = dict(cfg or wl["model"])
+    nc, nf = wl["nc"], wl["nf"]
     pc = {k: v.to(dev).requires_grad_(True) for k, v in O.init_params(cfg, 1).items()}
     pf = {k: v.to(dev).requires_grad_(True) for k, v in O.init_params(cfg, 2).items()}
     g = torch.Generator().manual_seed(0)
-    ro = torch.tensor([0.0, 0.0, 4.0]).expand(n, 3)
-    rd = torch.randn(n, 3, generator=g) * 0.3
-    rd[:, 2] = -1.0
-    rays = O.pack_rays(ro, rd, 2.0, 6.0, rd).to(dev)
-    tgt = torch.rand(n, 3, generator=g).to(dev)
-    opt = dict(num_coarse=NC, num_fine=NF, perturb=True, lindisp=False, white_background=False, noise_std=0.2)
+    rays, tgt, _, opt = _synthetic_batch(O, wl, cfg, n, g)
+    rays, tgt = rays.to(dev), tgt.to(dev)
     best = float("inf")
     for it in range(reps + 1):
-        rand = dict(t_rand=torch.rand(n, NC, device=dev), noise_coarse=torch.randn(n, NC, device=dev),
-                    u=torch.rand(n, NF, device=dev), noise_fine=torch.randn(n, NC + NF, device=dev))
+        rand = dict(t_rand=torch.rand(n, nc, device=dev), noise_coarse=torch.randn(n, nc, device=dev),
+                    u=torch.rand(n, nf, device=dev), noise_fine=torch.randn(n, nc + nf, device=dev))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         out = O.render_rays(rays, pc, pf, cfg, cfg, opt, rand, chunksize=131072)
@@ -260,33 +274,101 @@ def kernel_kind(name):
         return "fwd"
     if "k_mlp_dgrad" in name:
         return "dgrad"
-    if "k_wgrad_bf16x3" in name:
-        return "wgrad_bf16"   # (--precision bf16x3_train: the hidden x hidden blocks; "wgrad" is then the thin blocks only)
-    if "k_wgrad" in name and "reduce" not in name:
+    if "k_wgrad_bf16x3" in name or "k_wgrad_f16x3" in name:
+        return "wgrad_big"    # (--precision *_train: the hidden x hidden blocks on the 16-bit MFMAs)
+    if "k_wgrad<MD>[thin" in name:
+        return "wgrad_thin"   # (... and what is left to the fp32 kernel then)
+    if "k_wgrad<" in name:
         return "wgrad"
     return None
+
+
+def kernel_family(name):
+    """The matrix pipe a kernel multiplies on: "fp32" (v_mfma_f32_16x16x4 / 32x32x2) or the 16-bit MFMAs on split operands."""
+    if "bf16x3" in name:
+        return "bf16x3"
+    if "f16x3" in name:
+        return "f16x3"
+    return "fp32"
+
+
+def precision_level(prec):
+    """(piece format | None, level) of a --precision value: level 0 fp32, 1 inference forward, 2 + training forward, 3 + data
+    gradient, 4 + the large weight-gradient blocks (include/nerfhip.h NERFHIP_PRECISION_*)."""
+    if prec == "fp32":
+        return None, 0
+    fmt, _, rest = prec.partition("x3")
+    return fmt + "x3", {"": 1, "_fwd": 2, "_fwd_dgrad": 3, "_train": 4}[rest]
+
+
+def lib_sources_sha16():
+    """Fingerprint of the kernel sources the library was built from (what a tracked PMC summary must have been measured on)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "nerf-pytorch_amd", "csrc")
+    for p in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.cpp")) +
+                    [os.path.join(d, "Makefile"), os.path.join(ROOT, "include", "nerfhip.h")]):
+        h.update(os.path.basename(p).encode())
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(cfg, n, kind):
     """Counter bytes per launch of kernel `kind` from the tracked rocprofv3 --pmc passes of this same command (newest
     round first; scripts/gpu_pmc.sh: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 as MI355X_MICROARCH.md
-    prescribes for gfx950), or None when no pass was recorded for this configuration."""
+    prescribes for gfx950), or None when no pass was recorded for this configuration.  A summary is used only if it carries
+    the fingerprint of the kernel sources this library was built from (`lib_sources_sha16`): a stale file is refused and the
+    line says so."""
     tag = "%dx%d_%d" % (cfg["num_layers"], cfg["hidden_size"], n)
     kname = "k_wgrad" if kind == "wgrad" else "k_mlp_%s16" % kind
-    for rnd in ("r03", "r02"):
+    mine = lib_sources_sha16()
+    stale = None
+    for rnd in ("r04", "r03", "r02"):
         for fn in ("%s_pmc_summary_%s.json" % (rnd, tag), "%s_pmc_summary.json" % rnd):
             path = os.path.join(ROOT, "profiles", fn)
             if not os.path.exists(path) or (fn.endswith("summary.json") and (cfg != MODEL or n != RAYS_PER_GPU)):
                 continue
-            rows = [v for v in json.load(open(path)).values() if v["kernel"] == kname]
+            doc = json.load(open(path))
+            stamp = doc.get("_lib_sources_sha16") if isinstance(doc.get("_lib_sources_sha16"), str) else None
+            if stamp != mine:
+                stale = stale or "profiles/%s refused: measured on kernel sources %s, this library is %s" % (fn, stamp or "(unstamped)", mine)
+                continue
+            rows = [v for v in doc.values() if isinstance(v, dict) and v.get("kernel") == kname]
             if not rows:
                 continue
             # like with like: the algorithmic figure of k_wgrad is its operand READ stream, that of the forward / data-gradient
             # kernels their stash / d(pre-activation) WRITE stream (weights and masks are the small remainder)
             per = [r["fetch_gb_x2"] if kind == "wgrad" else r["write_gb"] for r in rows]
-            return round(sum(per) / len(per), 3), "profiles/%s (rocprofv3 --pmc passes of this command: %s, mean over the " \
-                "launch sizes recorded)" % (fn, "FETCH_SIZE x2" if kind == "wgrad" else "WRITE_SIZE")
-    return None, None
+            return round(sum(per) / len(per), 3), "profiles/%s (rocprofv3 --pmc passes of this command on kernel sources %s: %s, mean over " \
+                "the launch sizes recorded)" % (fn, mine, "FETCH_SIZE x2" if kind == "wgrad" else "WRITE_SIZE")
+    return None, stale
+
+
+def fern_poses(k=40):
+    """Forward-facing camera-to-world matrices like an LLFF capture (load_llff.py poses after recentering): the camera
+    looks down -z, a few degrees of rotation and a few tenths of a unit of translation around the origin."""
+    out = []
+    for i in range(k):
+        a, b = 0.12 * math.sin(2 * math.pi * i / k), 0.08 * math.cos(2 * math.pi * i / k)
+        ry = torch.tensor([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]])
+        rx = torch.tensor([[1, 0, 0], [0, math.cos(b), -math.sin(b)], [0, math.sin(b), math.cos(b)]])
+        c2w = torch.eye(4)
+        c2w[:3, :3] = ry @ rx
+        c2w[:3, 3] = torch.tensor([0.3 * math.sin(2 * math.pi * i / k), 0.2 * math.cos(2 * math.pi * i / k), 0.1 * math.sin(4 * math.pi * i / k)])
+        out.append(c2w)
+    return torch.stack(out)
+
+
+# BASELINE.json configs[1] (config/lego.yml: the configuration the metric is quoted on) and configs[3] (config/fern.yml:
+# models 4x64 skip 3 with 6 xyz frequencies :46-58, NDC rays with near 0 / far 1 :11-14, sigma noise 1.0 :89; 64 + 64 samples as
+# BASELINE.json states the config -- the yml itself says num_fine 128; LLFF fern at downsample 8: 378 x 504, focal 407.5)
+WORKLOADS = {
+    "lego": dict(H=400, W=400, focal=FOCAL, nc=64, nf=128, model=MODEL, near=2.0, far=6.0, no_ndc=True, noise=0.2, baseline_config=1),
+    "fern": dict(H=378, W=504, focal=407.5, nc=64, nf=64,
+                 model=dict(num_layers=4, hidden_size=64, skip_connect_every=3, num_encoding_fn_xyz=6, num_encoding_fn_dir=4),
+                 near=0.0, far=1.0, no_ndc=False, noise=1.0, baseline_config=3),
+}
 
 
 def main():
@@ -295,18 +377,25 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="default 20 (train) / 3 (eval)")
     ap.add_argument("--warmup", type=int, default=None, help="default 3 (train) / 1 (eval)")
     ap.add_argument("--mode", choices=("train", "eval"), default="train")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="lego",
+                    help="lego: BASELINE configs[1] (the headline; default).  fern: BASELINE configs[3] as config/fern.yml declares it "
+                         "(4x64 nets, skip 3, 6 xyz frequencies, NDC rays, near 0 / far 1, 378x504, sigma noise 1.0, 64 + 64 samples)")
     ap.add_argument("--rays", type=int, default=RAYS_PER_GPU, help="rays per GPU and iteration (weak scaling)")
     ap.add_argument("--global-rays", type=int, default=0, help="strong scaling: rays per iteration over ALL GPUs")
     ap.add_argument("--image", type=int, default=0, help="image side: default 400 (train) / 800 (eval)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--hidden", type=int, default=MODEL["hidden_size"])
-    ap.add_argument("--layers", type=int, default=MODEL["num_layers"])
+    ap.add_argument("--hidden", type=int, default=0, help="hidden_size (default: the workload's)")
+    ap.add_argument("--layers", type=int, default=0, help="num_layers (default: the workload's)")
     ap.add_argument("--overlap", type=int, default=-1, help="1: two-stream step (coarse backward next to the fine pass); "
                     "0: single-stream order; -1: the engine's default for the net width")
-    ap.add_argument("--precision", choices=("fp32", "bf16x3", "bf16x3_fwd", "bf16x3_fwd_dgrad", "bf16x3_train"), default="fp32",
-                    help="fp32 (default: the reference's arithmetic, the headline).  --mode eval --precision bf16x3: the inference "
-                         "forward on the split-bf16 kernels.  --mode train --precision bf16x3_fwd: the training forward on them, "
-                         "backward kernels unchanged fp32.  Both are NOT the reference's arithmetic: separate, labelled lines")
+    ap.add_argument("--precision", choices=("fp32", "bf16x3", "bf16x3_fwd", "bf16x3_fwd_dgrad", "bf16x3_train", "f16x3", "f16x3_fwd",
+                                            "f16x3_fwd_dgrad", "f16x3_train", "fp32+bf16x3_fwd_dgrad", "fp32+bf16x3_train", "fp32+f16x3_train"),
+                    default="fp32",
+                    help="fp32 (default: the reference's arithmetic, the headline).  f16x3* / bf16x3*: the GEMMs on the 16-bit MFMAs "
+                         "with every operand split into two fp16 (fp32-grade products) / bf16 (~2^-16) pieces: --mode eval "
+                         "--precision f16x3 | bf16x3 the inference forward; --mode train --precision *_fwd the training forward, "
+                         "*_fwd_dgrad + the data-gradient chain, *_train + the large weight-gradient blocks.  A+B: coarse net A, fine "
+                         "net B.  Separate, labelled lines: the driver's default stays fp32")
     ap.add_argument("--gather", action="store_true", help="eval: rank 0 also receives every pose's rows (output plumbing)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / timing plumbing only, on the CPU with "
                     "gloo: no kernel runs and no number is reported (the CPU test-suite uses it)")
@@ -339,32 +428,53 @@ def main():
         raise SystemExit("bench.py: --gpus %d but only %d device(s) visible" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    rccl = None
     if world > 1:
         if one_device:
             torch.distributed.init_process_group("gloo")
         else:
             torch.distributed.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+            try:
+                rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                rccl = "unknown"
 
-    cfg = dict(MODEL, hidden_size=args.hidden, num_layers=args.layers)
+    wl = dict(WORKLOADS[args.workload])
+    cfg = dict(wl["model"])
+    if args.hidden:
+        cfg["hidden_size"] = args.hidden
+    if args.layers:
+        cfg["num_layers"] = args.layers
+    nc, nf = wl["nc"], wl["nf"]
+    dx, dd = 3 + 6 * cfg["num_encoding_fn_xyz"], 3 + 6 * cfg["num_encoding_fn_dir"]
     torch.manual_seed(42)  # config/lego.yml:8; every rank builds identical weights
     mc = N.FlexibleNeRFModel(**cfg).to(dev)
     mf = N.FlexibleNeRFModel(**cfg).to(dev)
     lib = N._lib.get_lib()
-    side = args.image or (400 if args.mode == "train" else 800)
-    focal = 0.5 * side / math.tan(0.5 * 0.6911112070083618)  # 555.5555 at 400, 1111.111 at 800 (blender camera_angle_x)
-    poses = torch.stack([pose_spherical(th, -30.0, 4.0) for th in torch.linspace(-180, 180, 101)[:-1].tolist()]).to(dev)
+    if args.workload == "lego":
+        side = args.image or (400 if args.mode == "train" else 800)
+        height = width = side
+        focal = 0.5 * side / math.tan(0.5 * 0.6911112070083618)  # 555.5555 at 400, 1111.111 at 800 (blender camera_angle_x)
+        poses = torch.stack([pose_spherical(th, -30.0, 4.0) for th in torch.linspace(-180, 180, 101)[:-1].tolist()]).to(dev)
+    else:
+        height, width, focal = wl["H"], wl["W"], wl["focal"]
+        side = 0
+        poses = fern_poses().to(dev)
 
     def fence():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    if (args.mode == "train" and args.precision == "bf16x3") or (args.mode == "eval" and args.precision.startswith("bf16x3_")):
-        raise SystemExit("--precision bf16x3 goes with --mode eval, bf16x3_fwd / bf16x3_fwd_dgrad / bf16x3_train with --mode train")
-    if args.precision.startswith("bf16x3_"):
-        mc.set_training_precision(args.precision)
-        mf.set_training_precision(args.precision)
+    prec_c, prec_f = args.precision.split("+") if "+" in args.precision else (args.precision, args.precision)
+    infer_only = prec_f in ("bf16x3", "f16x3")
+    if (args.mode == "train" and infer_only) or (args.mode == "eval" and not infer_only and prec_f != "fp32"):
+        raise SystemExit("--precision bf16x3 / f16x3 go with --mode eval, the *_fwd / *_fwd_dgrad / *_train ones with --mode train")
     if args.mode == "train":
+        if prec_c != "fp32":
+            mc.set_training_precision(prec_c)
+        if prec_f != "fp32":
+            mf.set_training_precision(prec_f)
         strong = args.global_rays > 0
         if strong:
             lo, hi = N.parallel.shard_bounds(args.global_rays, rank, world)
@@ -373,30 +483,33 @@ def main():
         else:
             n = args.rays
             total_rays = n * world
-        eng = N.TrainEngine(mc, mf, NC, NF, perturb=True, lindisp=False, white_background=False, noise_std=0.2, lr=5e-3,
+        eng = N.TrainEngine(mc, mf, nc, nf, perturb=True, lindisp=False, white_background=False, noise_std=wl["noise"], lr=5e-3,
                             seed=1234, world_size=world, rank=rank, overlap=None if args.overlap < 0 else bool(args.overlap))
-        opts = N.make_options(NC, NF, num_random_rays=n)
+        opts = N.make_options(nc, nf, num_random_rays=n, radiance_field_noise_std=wl["noise"], no_ndc=wl["no_ndc"], near=wl["near"],
+                              far=wl["far"])
         g = torch.Generator(device=dev).manual_seed(1000 + rank)
-        images = torch.rand(8, side, side, 3, generator=g, device=dev)     # synthetic training views, resident in HBM
+        images = torch.rand(8, height, width, 3, generator=g, device=dev)     # synthetic training views, resident in HBM
 
         def one_step(i):
             # the reference's loop body, train_nerf.py:210-270: pick a view, draw the step's distinct pixels, their rays
             # and targets (one launch, on the device), forward, loss, backward, [all-reduce], Adam with the decayed lr.
             # Weak scaling: every rank its own view; strong scaling: all ranks shard ONE view's draw.
             k = i if strong else i * world + rank
-            return eng.step_on_image(images[k % 8], poses[k % poses.shape[0]], side, side, focal, opts, n,
+            return eng.step_on_image(images[k % 8], poses[k % poses.shape[0]], height, width, focal, opts, n,
                                      lr=N.TrainEngine.lr_at(i), global_rays=args.global_rays if strong else None)
-        samples_per_step = (n * NC, n * (NC + NF))
+        samples_per_step = (n * nc, n * (nc + nf))
     else:
+        if args.workload != "lego":
+            raise SystemExit("--mode eval is BASELINE configs[4] (lego 800x800)")
         strong = True
         total_rays = side * side
         ex, ed = N.get_embedding_function(10, True, True), N.get_embedding_function(4, True, True)
         # eval_nerf.py:158-190 with the validation options of config/lego.yml (perturb off, noise 0); one chunk per rank
-        opts = N.make_options(NC, NF, perturb=False, radiance_field_noise_std=0.0, chunksize=1 << 22)
+        opts = N.make_options(nc, nf, perturb=False, radiance_field_noise_std=0.0, chunksize=1 << 22)
         lo, hi = N.parallel.shard_bounds(side, rank, world)
         n = (hi - lo) * side
-        mc.set_inference_precision(args.precision)
-        mf.set_inference_precision(args.precision)
+        mc.set_inference_precision(prec_c)
+        mf.set_inference_precision(prec_f)
 
         def one_step(i):
             with torch.no_grad():
@@ -405,7 +518,7 @@ def main():
                 if args.gather:
                     rgb8 = N.parallel.gather_image_rows(rgb8)
             return rgb8
-        samples_per_step = (n * NC, n * (NC + NF))
+        samples_per_step = (n * nc, n * (nc + nf))
 
     for i in range(args.warmup):
         one_step(i)
@@ -423,11 +536,14 @@ def main():
     clk = (ctypes.c_uint64 * 9)()
     lib.profile_clocks(clk)
     per_rank = [dt_local]
+    allreduce_ms = None
     if world > 1:
         tt = torch.tensor([dt_local], device=dev, dtype=torch.float64)
         gathered = [torch.zeros_like(tt) for _ in range(world)]
         torch.distributed.all_gather(gathered, tt)
         per_rank = [float(t) for t in gathered]
+        if args.mode == "train":
+            allreduce_ms = eng.collective_times_ms()
     dt = max(per_rank)
     loss_host = [float(v) for v in last.cpu()] if args.mode == "train" else None
 
@@ -436,114 +552,155 @@ def main():
         for line in buf.value.decode().splitlines():
             name, cnt, ms = line.rsplit(" ", 2)
             kern[name.strip("()")] = (int(cnt), float(ms))
-        fwd_macs, dgrad_macs = macs_per_sample(cfg)
+        fwd_macs, dgrad_macs = macs_per_sample(cfg, dx, dd)
         m_c, m_f = samples_per_step
+        Wd, Ln = cfg["hidden_size"], cfg["num_layers"]
         # algorithmic FLOPs and HBM bytes per sample point of each MLP kernel
-        flops = {"fwd": 2.0 * fwd_macs, "dgrad": 2.0 * dgrad_macs, "wgrad": 2.0 * fwd_macs}
-        hbm_bytes = {"wgrad": wgrad_bytes_per_sample(cfg),
-                     "fwd": stash_bytes_per_sample(cfg) if args.mode == "train" else 16 + 4,   # inference: raw out + z in
-                     "dgrad": 4 * (cfg["num_layers"] * cfg["hidden_size"] + cfg["hidden_size"] + cfg["hidden_size"] // 2 + 32)
-                     + 8 * (cfg["num_layers"] + 1) + 16}
-        if args.precision == "bf16x3_train":
-            # the weight gradient is two kernels then: the hidden x hidden blocks (k_wgrad_bf16x3: two launches per net, full and
-            # half-height blocks) and the thin blocks left to the fp32 k_wgrad
-            Wd, Ln = cfg["hidden_size"], cfg["num_layers"]
-            big_macs = (Ln - 1) * Wd * Wd + Wd * Wd + (Wd // 2) * Wd
-            big_rows = Ln * 2 * Wd + (Wd // 2 + Wd)
-            flops["wgrad_bf16"], flops["wgrad"] = 2.0 * big_macs, 2.0 * (fwd_macs - big_macs)
-            hbm_bytes["wgrad_bf16"], hbm_bytes["wgrad"] = 4 * big_rows, hbm_bytes["wgrad"] - 4 * big_rows
+        stash_b = stash_bytes_per_sample(cfg) if args.mode == "train" else 16 + 4   # inference: raw out + z in
+        dgrad_b = 4 * (Ln * Wd + Wd + Wd // 2 + 32) + 8 * (Ln + 1) + 16
+        wgrad_b = wgrad_bytes_per_sample(cfg)
+        big_macs = (Ln - 1) * Wd * Wd + Wd * Wd + (Wd // 2) * Wd         # the hidden x hidden blocks (level-4 plans, 256-wide kernels)
+        big_b = 4 * (Ln * 2 * Wd + (Wd // 2 + Wd))
+        # which kernel each net's passes run on: (kind, family) -> [flops per step, bytes per step, launches per step]
+        work = {}
+
+        def add(kind, fam, flops, nbytes, launches=1):
+            w = work.setdefault((kind, fam), [0.0, 0.0, 0])
+            w[0] += flops
+            w[1] += nbytes
+            w[2] += launches
+        for m, prec in ((m_c, prec_c), (m_f, prec_f)):
+            fmt, level = precision_level(prec)
+            add("fwd", fmt if level >= 1 else "fp32", 2.0 * fwd_macs * m, stash_b * m)
+            if args.mode != "train":
+                continue
+            add("dgrad", fmt if level >= 3 else "fp32", 2.0 * dgrad_macs * m, dgrad_b * m)
+            if level == 4 and 128 < Wd <= 256:
+                add("wgrad_big", fmt, 2.0 * big_macs * m, big_b * m, 2)      # (two launches: full- and half-height blocks)
+                add("wgrad_thin", "fp32", 2.0 * (fwd_macs - big_macs) * m, (wgrad_b - big_b) * m)
+            else:
+                add("wgrad", "fp32", 2.0 * fwd_macs * m, wgrad_b * m)
+        # template instances of one kernel (k_wgrad_f16x3<full> / <half>) count as one
         merged = {}
-        for name, (cnt, ms) in kern.items():   # (template instances of one kernel kind -- k_wgrad_bf16x3<256,256> / <128,256> -- count as one)
-            kind = kernel_kind(name)
-            if kind == "wgrad_bf16":
-                c0, m0, n0 = merged.get(kind, (0, 0.0, name))
-                merged[kind] = (c0 + cnt, m0 + ms, n0 if c0 else name)
-        for kind, (cnt, ms, name) in merged.items():
-            for nm in [n for n in kern if kernel_kind(n) == kind]:
-                del kern[nm]
-            kern["k_wgrad_bf16x3<*>"] = (cnt // 2, ms)   # (two launches = one pass over the net's blocks)
-        kernels = {}
         for name, (cnt, ms) in kern.items():
             kind = kernel_kind(name)
             if kind is None:
                 continue
-            launches_per_step = cnt / args.steps                      # one launch per net: coarse (m_c) + fine (m_f)
-            avg_ms = ms / cnt
-            spl = (m_c + m_f) / launches_per_step                     # sample points per launch (mean)
-            tf = flops[kind] * spl / (avg_ms * 1e-3) / 1e12
-            gb = hbm_bytes[kind] * spl / 1e9
-            cyc, ticks, wgs = (int(clk[3 * {"fwd": 0, "dgrad": 1, "wgrad": 2}.get(kind, 0) + c]) if kind in ("fwd", "dgrad", "wgrad") else 0
-                               for c in range(3))
-            ghz = 0.1 * cyc / ticks if ticks else None
-            counter_gb, source = pmc_traffic(cfg, n, kind) if (args.mode == "train" and args.precision == "fp32") else (None, None)
-            # a kernel is priced against ITS OWN matrix pipe: fp32 MFMA, or the bf16 MFMA at three instructions per product block
-            peak = BF16X3_PEAK_TFLOPS if "bf16x3" in name else FP32_MFMA_PEAK_TFLOPS
-            kernels[kind] = dict(kernel=name, ms_per_step=round(ms / args.steps, 4), avg_launch_ms=round(avg_ms, 4), launches=cnt,
-                                 algorithmic_gflop_per_launch=round(flops[kind] * spl / 1e9, 2), tflops=round(tf, 2),
-                                 peak=round(peak, 1), frac=round(tf / peak, 4),
-                                 sclk_ghz=None if ghz is None else round(ghz, 3),
-                                 frac_at_measured_clock=None if ghz is None else round(tf / (FP32_MFMA_PEAK_TFLOPS * ghz / PEAK_CLOCK_GHZ), 4),
-                                 traffic=dict(algorithmic_gb=round(gb, 3), counter_gb=counter_gb, source=source),
-                                 hbm_tb_s=round(gb / avg_ms, 3), hbm_frac=round(gb / avg_ms / HBM_PEAK_TBS, 4))
+            key = (kind, kernel_family(name))
+            c0, m0, names = merged.get(key, (0, 0.0, []))
+            merged[key] = (c0 + cnt, m0 + ms, names + [name])
+        kernels = {}
+        kinds_seen = [k for k, _ in merged]
+        for (kind, fam), (cnt, ms, names) in merged.items():
+            if (kind, fam) not in work:
+                continue
+            fl, by, launches = work[(kind, fam)]
+            label = names[0] if len(names) == 1 else names[0].split("<")[0] + "<*>"
+            ms_step = ms / args.steps
+            tf = fl / (ms_step * 1e-3) / 1e12
+            gb = by / 1e9
+            ghz = None
+            if fam == "fp32" and kind in ("fwd", "dgrad", "wgrad", "wgrad_thin"):
+                cyc, ticks = (int(clk[3 * {"fwd": 0, "dgrad": 1}.get(kind, 2) + c]) for c in range(2))
+                ghz = 0.1 * cyc / ticks if ticks else None
+            counter_gb, source = (pmc_traffic(cfg, n, kind) if (args.mode == "train" and args.precision == "fp32" and args.workload == "lego"
+                                                               and kind in ("fwd", "dgrad", "wgrad")) else (None, None))
+            # a kernel is priced against ITS OWN matrix pipe: fp32 MFMA, or the 16-bit MFMA at three instructions per product block
+            peak = FP32_MFMA_PEAK_TFLOPS if fam == "fp32" else BF16X3_PEAK_TFLOPS
+            key = kind if kinds_seen.count(kind) == 1 else "%s[%s]" % (kind, fam)
+            kernels[key] = dict(kernel=label, family=fam, ms_per_step=round(ms_step, 4), avg_launch_ms=round(ms / cnt, 4), launches=cnt,
+                                launches_per_step=launches, algorithmic_gflop_per_step=round(fl / 1e9, 2),
+                                algorithmic_gflop_per_launch=round(fl / launches / 1e9, 2), tflops=round(tf, 2),
+                                peak=round(peak, 1), frac=round(tf / peak, 4),
+                                sclk_ghz=None if ghz is None else round(ghz, 3),
+                                frac_at_measured_clock=None if ghz is None else round(tf / (FP32_MFMA_PEAK_TFLOPS * ghz / PEAK_CLOCK_GHZ), 4),
+                                traffic=dict(algorithmic_gb=round(gb / launches, 3), counter_gb=counter_gb, source=source),
+                                hbm_tb_s=round(gb / ms_step, 3), hbm_frac=round(gb / ms_step / HBM_PEAK_TBS, 4))
         roof = None
         if kernels:
             dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])   # the kernel the step spends most time in
             lowest = min(kernels, key=lambda k: kernels[k]["frac"])
             d = kernels[dom]
-            roof = dict(bound="mfma", kernel=d["kernel"], achieved=d["tflops"], peak=d["peak"], unit="TFLOP/s",
-                        frac=d["frac"], traffic=d["traffic"], avg_launch_ms=d["avg_launch_ms"], launches=d["launches"],
-                        algorithmic_gflop_per_launch=d["algorithmic_gflop_per_launch"],
+            # the narrow nets are within reach of both roofs: name the one the dominant kernel is closer to
+            bound = "hbm" if d["hbm_frac"] > d["frac"] else "mfma"
+            roof = dict(bound=bound, kernel=d["kernel"],
+                        achieved=d["tflops"] if bound == "mfma" else round(d["hbm_tb_s"] * 1e3, 1),
+                        peak=d["peak"] if bound == "mfma" else HBM_PEAK_TBS * 1e3, unit="TFLOP/s" if bound == "mfma" else "GB/s",
+                        frac=d["frac"] if bound == "mfma" else d["hbm_frac"], traffic=d["traffic"], avg_launch_ms=d["avg_launch_ms"],
+                        launches=d["launches"], algorithmic_gflop_per_launch=d["algorithmic_gflop_per_launch"],
                         sclk_ghz=d["sclk_ghz"], frac_at_measured_clock=d["frac_at_measured_clock"],
+                        mfma=dict(achieved_tflops=d["tflops"], peak_tflops=d["peak"], frac=d["frac"]),
                         hbm=dict(achieved_tb_s=d["hbm_tb_s"], peak_tb_s=HBM_PEAK_TBS, frac=d["hbm_frac"]),
                         lowest_frac_kernel=kernels[lowest]["kernel"], lowest_frac=kernels[lowest]["frac"],
                         mlp_kernels=kernels,
                         kernel_ms_per_step={nm: round(m / args.steps, 4) for nm, (_, m) in sorted(kern.items(), key=lambda kv: -kv[1][1])})
         if args.mode == "train":
             total_flops = (2.0 * (2 * fwd_macs + dgrad_macs)) * (m_c + m_f)
-            step_bytes = sum(hbm_bytes[k] for k in ("fwd", "dgrad", "wgrad")) * (m_c + m_f)
-            workload = ("lego %dx%d synthetic views (BASELINE configs[%d]): %d rays/GPU/iter (%d over all GPUs), %d coarse + %d "
-                        "fine samples, %dx%d coarse+fine nets, perturb, noise 0.2, Adam, full iteration"
-                        % (side, side, 2 if (strong and side == 800) else 1, n, total_rays, NC, NF, cfg["num_layers"], cfg["hidden_size"]))
+            step_bytes = (stash_b + dgrad_b + wgrad_b) * (m_c + m_f)
+            if args.workload == "lego":
+                workload = ("lego %dx%d synthetic views (BASELINE configs[%d]): %d rays/GPU/iter (%d over all GPUs), %d coarse + %d "
+                            "fine samples, %dx%d coarse+fine nets, perturb, noise 0.2, Adam, full iteration"
+                            % (side, side, 2 if (strong and side == 800) else 1, n, total_rays, nc, nf, Ln, Wd))
+            else:
+                workload = ("fern / LLFF %dx%d synthetic forward-facing views (BASELINE configs[3], config/fern.yml): NDC rays, near 0 / far 1, "
+                            "%d rays/GPU/iter (%d over all GPUs), %d coarse + %d fine samples, %dx%d skip-%d nets with %d xyz frequencies, "
+                            "perturb, noise 1.0, Adam, full iteration"
+                            % (height, width, n, total_rays, nc, nf, Ln, Wd, cfg["skip_connect_every"], cfg["num_encoding_fn_xyz"]))
             metric = "train rays/sec"
         else:
             total_flops = 2.0 * fwd_macs * (m_c + m_f)
-            step_bytes = hbm_bytes["fwd"] * (m_c + m_f)
+            step_bytes = stash_b * (m_c + m_f)
             workload = ("eval_nerf.py 360-degree render (BASELINE configs[4]): %dx%d poses, rows sharded over %d GPU(s) (%d rays/GPU/"
                         "pose), %d coarse + %d fine samples, %dx%d nets, perturb off, 8-bit cast on the device, one step = one pose"
-                        % (side, side, world, n, NC, NF, cfg["num_layers"], cfg["hidden_size"]))
+                        % (side, side, world, n, nc, nf, Ln, Wd))
             metric = "eval rays/sec"
         sec = dt / args.steps
+
+        def describe(prec):
+            fmt, level = precision_level(prec)
+            if level == 0:
+                return "f32"
+            pieces = ("two IEEE fp16 pieces per operand (hi + lo reproduces the fp32 value to 2^-24; weights pre-scaled by 2^8, gradients by a "
+                      "per-launch power of two), three fp16 MFMAs per product block, f32 accumulate: ~3 x 2^-24 per product" if fmt == "f16x3" else
+                      "two bf16 pieces per operand, three bf16 MFMAs per product block, f32 accumulate: ~2^-16 per product")
+            what = {1: "forward", 2: "forward (backward + optimizer f32)", 3: "forward + data gradient (weight gradient + optimizer f32)",
+                    4: "forward, data gradient and the hidden x hidden weight-gradient blocks (thin weight-gradient blocks + optimizer f32)"}[level]
+            return "%s: %s on %s; fp32-equivalent FLOPs" % (fmt, what, pieces)
+        dtype = describe(prec_f) if prec_c == prec_f else "coarse net: %s | fine net: %s" % (describe(prec_c), describe(prec_f))
         res = dict(metric=metric, value=round(total_rays * args.steps / dt, 2), unit="rays/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(sec * 1e3, 3),
                    ms_per_step_per_rank=[round(t / args.steps * 1e3, 3) for t in per_rank],
                    higher_is_better=True, scaling="strong" if strong else "weak", vs_baseline=None,
-                   dtype="f32" if args.precision == "fp32" else
-                   ("bf16x3 (fp32 operands split into two bf16 pieces, three bf16 MFMAs per product block, f32 accumulate; "
-                    "fp32-equivalent FLOPs)" if args.precision == "bf16x3" else
-                    ("forward bf16x3 (split-bf16 products, f32 accumulate), backward + optimizer f32; fp32-equivalent FLOPs"
-                     if args.precision == "bf16x3_fwd" else
-                     ("forward + data gradient bf16x3 (split-bf16 products, f32 accumulate), weight gradient + optimizer f32; "
-                      "fp32-equivalent FLOPs" if args.precision == "bf16x3_fwd_dgrad" else
-                      "forward, data gradient and the hidden x hidden weight-gradient blocks bf16x3 (split-bf16 products, f32 "
-                      "accumulate); thin weight-gradient blocks + optimizer f32; fp32-equivalent FLOPs"))),
-                   data="synthetic",
+                   dtype=dtype, precision=args.precision, data="synthetic",
                    config=dict(workload=workload, rays_per_gpu=n, global_rays=total_rays, parallelism="dp%d" % world,
                                two_stream_step=bool(eng.overlap) if args.mode == "train" else None,
-                               backend=("gloo(one-device test hook)" if one_device else "nccl(RCCL)") if world > 1 else None),
+                               backend=("gloo(one-device test hook)" if one_device else "nccl(RCCL %s)" % rccl) if world > 1 else None),
+                   # every launch of the timed region is bracketed by two HIP events on its stream (nerfhip_profile_enable): the
+                   # per-kernel times below come from THIS run; measured cost of the events: none (27.31 vs 27.41 ms)
+                   profiled_in_timed_region=True, lib_sources_sha16=lib_sources_sha16(),
                    step_tflops=round(total_flops / sec / 1e12, 2),
                    step_frac_of_fp32_mfma_peak=round(total_flops / sec / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                    step_algorithmic_hbm_tb_s=round(step_bytes / sec / 1e12, 3),
                    step_hbm_frac_of_8tb_s=round(step_bytes / sec / 1e12 / HBM_PEAK_TBS, 4),
                    final_loss=loss_host, roofline=roof)
+        if world > 1:
+            # self-diagnosis of the first real N-GPU run: the exchange next to the compute, per net
+            res["multi_gpu"] = dict(nranks=world, rccl=rccl, ms_per_step_per_rank=res["ms_per_step_per_rank"],
+                                    allreduce_ms_per_step=allreduce_ms,
+                                    gradient_bytes_per_net=4 * mc.num_flat_params,
+                                    note="allreduce_ms_per_step: one all-reduce of each net's flat gradient by itself, after the timed region "
+                                         "(HIP events, mean of 20: TrainEngine.collective_times_ms) -- in the step the fine net's overlaps the "
+                                         "coarse backward; SURVEY 5.8 expects ~55 us for 4.77 MB over xGMI.  ms_per_step_per_rank is compute + exchange")
         if world == 1 and not args.no_cpu_baseline:
             if args.mode == "train":
-                res["cpu_baseline"] = cpu_baseline()
+                res["cpu_baseline"] = cpu_baseline(wl=wl, cfg=cfg)
+                if args.workload == "lego" and cfg == MODEL:
+                    try:
+                        res["dropin_route"] = dropin_route(dev)
+                    except Exception as e:
+                        res["dropin_route"] = dict(error=repr(e)[:200])
                 try:
-                    res["dropin_route"] = dropin_route(dev)
-                except Exception as e:
-                    res["dropin_route"] = dict(error=repr(e)[:200])
-                try:
-                    res["pytorch_rocm_reference"] = pytorch_rocm_reference(dev)
+                    res["pytorch_rocm_reference"] = pytorch_rocm_reference(dev, wl=wl, cfg=cfg)
                     res["speedup_vs_pytorch_rocm_fwd_bwd"] = round(res["value"] / res["pytorch_rocm_reference"]["value"], 3)
                 except Exception as e:  # the torch arm needs ~13 GB and must never take the bench line down
                     res["pytorch_rocm_reference"] = dict(error=repr(e)[:200])

@@ -146,10 +146,10 @@ int nerfhip_hierarchical_z(const float* z_coarse, const float* weights, int64_t 
 /* ---- K4/K8: the MLP (models.FlexibleNeRFModel, nerf/models.py:185-256) ----------------------------------------- */
 typedef struct nerfhip_model_cfg {
     int num_layers;         /* models.py:188 */
-    int hidden_size;        /* models.py:189; 2..256 (kernel widths 64 / 128 / 256; other sizes ride zero-padded on the next width) */
+    int hidden_size;        /* models.py:189; 2..512 (kernel widths 64 / 128 / 256 / 512; other sizes ride zero-padded on the next width) */
     int skip_connect_every; /* models.py:190; cat(h, xyz) before layers_xyz[i] iff i % skip == 0 and i > 0 */
-    int num_encoding_fn_xyz;
-    int num_encoding_fn_dir;
+    int num_encoding_fn_xyz; /* 0..16 (every config .yml of the reference: <= 10) */
+    int num_encoding_fn_dir; /* 0..10 (every config .yml of the reference: <= 4) */
     int include_input_xyz;
     int include_input_dir;
     int log_sampling_xyz;
@@ -185,6 +185,22 @@ nerfhip_plan_t nerfhip_plan_create(const nerfhip_model_cfg* cfg);
  * FLOPs) run on the bf16 MFMAs too (operands split on the fly from the fp32 stash / d(pre-activation) images); the thin blocks
  * (encoding columns, fc_alpha, fc_rgb | fc_out) stay on the fp32 kernel.  Same status: opt-in experiment. */
 #define NERFHIP_PRECISION_BF16X3_TRAIN 4
+/* F16X3 family (round 4): the SAME kernels and the same three-MFMA product structure on v_mfma_f32_32x32x16_f16, every operand
+ * split into two IEEE fp16 pieces: hi = f16(v), lo = f16(v - hi), both round-to-nearest.  A piece carries 11 significant bits and
+ * the rounding error of hi is at most half an ulp, so hi + lo reproduces v to 2^-24 relative -- fp32's own rounding -- wherever
+ * the low piece is a normal or subnormal fp16 number (the gfx950 matrix pipe multiplies fp16 subnormals exactly; measured:
+ * scripts/probe/f16_mfma_probe.hip); the dropped xl.wl term is 2^-24 relative as well.  So a product block carries ~3 x 2^-24
+ * instead of bf16x3's ~2^-16: fp32-grade arithmetic at the bf16x3 kernels' speed.  What fp16's 5-bit exponent costs is handled
+ * inside the library: the packed weight pieces (and biases) are pre-scaled by 2^8 (exact; the kernels multiply every layer's
+ * accumulators by 2^-8 on the way out) so that a weight's low piece is a normal fp16 number down to |w| = 2^-10, and the
+ * data-gradient chain runs on d(raw output) scaled by a power of two chosen per launch from max|d(raw output)| (a one-word
+ * device reduction, no host synchronisation), undone exactly in the weight-gradient reduction.  Same plan kinds as the bf16x3
+ * family: F16X3 inference-only; F16X3_FWD / _FWD_DGRAD / _TRAIN training-capable.  Activations beyond 65504 overflow an fp16
+ * piece (no NeRF layer gets near that); opt-in, labelled, never selected implicitly. */
+#define NERFHIP_PRECISION_F16X3 5
+#define NERFHIP_PRECISION_F16X3_FWD 6
+#define NERFHIP_PRECISION_F16X3_FWD_DGRAD 7
+#define NERFHIP_PRECISION_F16X3_TRAIN 8
 nerfhip_plan_t nerfhip_plan_create_ex(const nerfhip_model_cfg* cfg, int precision);
 int nerfhip_plan_precision(nerfhip_plan_t plan);
 void nerfhip_plan_destroy(nerfhip_plan_t plan);

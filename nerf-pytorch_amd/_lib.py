@@ -44,6 +44,7 @@ class RenderCotangents(C.Structure):
 
 
 PRECISION_FP32, PRECISION_BF16X3, PRECISION_BF16X3_FWD, PRECISION_BF16X3_FWD_DGRAD, PRECISION_BF16X3_TRAIN = 0, 1, 2, 3, 4  # NERFHIP_PRECISION_*
+PRECISION_F16X3, PRECISION_F16X3_FWD, PRECISION_F16X3_FWD_DGRAD, PRECISION_F16X3_TRAIN = 5, 6, 7, 8
 PART_COARSE, PART_FINE, PART_SHARED_BWD = 1, 2, 4
 
 

@@ -28,6 +28,7 @@ struct InGradArgs {
     int64_t M, nt;
     int D;
     float* g_x;
+    const unsigned* gscale;  // fp16 data-gradient chains: the images carry nh_gscale_of(*gscale); else NULL
 };
 
 NH_KERNEL void k_mlp_input_grad(InGradArgs a) {
@@ -43,16 +44,40 @@ NH_KERNEL void k_mlp_input_grad(InGradArgs a) {
         const float* w = a.params + t.w_off + t.col0 + (c - t.out0);
         for (int u = 0; u < t.nu; ++u) s = fmaf(dp[u], w[(size_t)u * t.w_ld], s);
     }
-    a.g_x[idx] = s;
+    a.g_x[idx] = a.gscale ? s * nh_gscale_inv(*a.gscale) : s;
 }
+
+// max |x| of a launch's d(raw output) as a bit pattern (non-negative floats order like unsigned integers; a NaN sorts above
+// Inf and turns the scaling off: nh_gscale_exp) -- the fp16 data-gradient chain picks its power-of-two scale from it
+NH_KERNEL void k_absmax_bits(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out) {
+    unsigned m = 0u;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        unsigned u;
+        const float v = x[i];
+        memcpy(&u, &v, 4);
+        u &= 0x7fffffffu;
+        m = u > m ? u : m;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned o = (unsigned)nh_shfl_xor_i((int)m, d);
+        m = o > m ? o : m;
+    }
+    if (nh_lane() == 0) nh_atomic_max_u32(out, m);
+}
+NH_KERNEL void k_zero_word(unsigned* out) { out[0] = 0u; }
 
 }  // namespace
 
 // scratch of a backward over M sample points: the d(pre-activation) images the data-gradient kernel writes for the
 // weight-gradient kernel, then the split-K partials
+// (... then 64 words whose first holds max|g_out| of the launch for the fp16 data-gradient chain's scale)
+static int64_t gscale_word_offset(nerfhip_plan* p, int64_t nt) {
+    return nt * p->grad.total_rows * 32 + nh_wgrad_partial_floats(p, nt) + nh_wgrad_x3_partial_floats(p, nt);
+}
 int64_t nh_mlp_bwd_scratch_bytes(nerfhip_plan* p, int64_t M) {
     const int64_t nt = nh_ceil_div(M, 128) * 4;
-    return (nt * p->grad.total_rows * 32 + nh_wgrad_partial_floats(p, nt) + nh_wgrad_bf16_partial_floats(p, nt)) * (int64_t)sizeof(float);
+    return (gscale_word_offset(p, nt) + 64) * (int64_t)sizeof(float);
 }
 
 int nh_mlp_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
@@ -66,9 +91,10 @@ int nh_mlp_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, i
         NH_REQUIRE(in.x, "mlp_fwd: x is NULL");
     }
     if (p->precision != NERFHIP_PRECISION_FP32) {
-        NH_REQUIRE(!stash || p->precision != NERFHIP_PRECISION_BF16X3,
-                   "mlp_fwd: a bf16x3 plan is inference-only (no activation stash, no backward; NERFHIP_PRECISION_BF16X3_FWD trains)");
-        return nh_mlp_bf16_forward(p, packed, in, M, out, stash, stream);
+        NH_REQUIRE(!stash || nh_prec_level(p->precision) != 1,
+                   "mlp_fwd: a bf16x3 / f16x3 plan is inference-only (no activation stash, no backward; the _FWD / _FWD_DGRAD / _TRAIN plans train)");
+        return nh_prec_f16(p->precision) ? nh_mlp_forward_f16(p, packed, in, M, out, stash, stream)
+                                         : nh_mlp_forward_bf16(p, packed, in, M, out, stash, stream);
     }
     return nh_mlp16_forward(p, packed, in, M, out, stash, stream);
 }
@@ -76,18 +102,35 @@ int nh_mlp_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, i
 int nh_mlp_backward(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash,
                     float* scratch, int64_t scratch_bytes, float* g_params, nerfhip_stream_t stream) {
     NH_REQUIRE(p && packed && g_out && stash && scratch && g_params && M > 0, "mlp_bwd: bad arguments");
-    NH_REQUIRE(p->precision != NERFHIP_PRECISION_BF16X3, "mlp_bwd: a bf16x3 plan is inference-only");
+    NH_REQUIRE(nh_prec_level(p->precision) != 1, "mlp_bwd: a bf16x3 / f16x3 plan is inference-only");
     NH_REQUIRE(scratch_bytes >= nh_mlp_bwd_scratch_bytes(p, M), "mlp_bwd: scratch too small (%lld < %lld)",
                (long long)scratch_bytes, (long long)nh_mlp_bwd_scratch_bytes(p, M));
     const int64_t nt = nh_ceil_div(M, 128) * 4;
-    const bool bdg = p->precision == NERFHIP_PRECISION_BF16X3_FWD_DGRAD || p->precision == NERFHIP_PRECISION_BF16X3_TRAIN;
-    int rc = bdg ? nh_mlp_bf16_dgrad(p, packed, g_out, M, stash, scratch, stream) : nh_mlp16_dgrad(p, packed, g_out, M, stash, scratch, stream);
+    const bool bdg = nh_prec_level(p->precision) >= 3, f16 = nh_prec_f16(p->precision);
+    int rc = NERFHIP_OK;
+    unsigned* gscale = nullptr;
+    if (bdg && f16) {
+        // the fp16 chain's scale: max|g_out| of THIS launch, reduced on the device (two small launches, no host round trip)
+        gscale = (unsigned*)(scratch + gscale_word_offset(p, nt));
+        NH_LAUNCH(k_zero_word, 1, 1, 0, stream, gscale);
+        const int64_t n4 = M * 4;
+        NH_LAUNCH(k_absmax_bits, nh_ceil_div(n4, 256 * 16) < 2048 ? nh_ceil_div(n4, 256 * 16) : 2048, 256, 0, stream, g_out, n4, gscale);
+        rc = nh_launch_status("absmax_bits");
+        if (rc) return rc;
+    }
+    if (bdg)
+        rc = f16 ? nh_mlp_dgrad_f16(p, packed, g_out, M, stash, scratch, gscale, stream)
+                 : nh_mlp_dgrad_bf16(p, packed, g_out, M, stash, scratch, nullptr, stream);
+    else
+        rc = nh_mlp16_dgrad(p, packed, g_out, M, stash, scratch, stream);
     if (rc) return rc;
     float* const partial = scratch + (size_t)nt * (size_t)p->grad.total_rows * 32;
-    rc = nh_wgrad(p, nt, stash, scratch, partial, g_params, stream);
+    rc = nh_wgrad(p, nt, stash, scratch, partial, g_params, gscale, stream);
     if (rc) return rc;
-    // (BF16X3_TRAIN: the large blocks, behind the fp32 kernel's partials)
-    return nh_wgrad_bf16(p, nt, stash, scratch, partial + nh_wgrad_partial_floats(p, nt), g_params, stream);
+    // (level 4: the large blocks, behind the fp32 kernel's partials)
+    float* const partial_b = partial + nh_wgrad_partial_floats(p, nt);
+    return f16 ? nh_wgrad_f16(p, nt, stash, scratch, partial_b, g_params, gscale, stream)
+               : nh_wgrad_bf16(p, nt, stash, scratch, partial_b, g_params, nullptr, stream);
 }
 
 extern "C" int64_t nerfhip_plan_bwd_scratch_bytes(nerfhip_plan_t plan, int64_t m) {
@@ -140,6 +183,8 @@ extern "C" int nerfhip_mlp_bwd_input(nerfhip_plan_t p, const float* params, int6
     a.nt = nh_ceil_div(m, 128) * 4;
     a.D = p->Dx + p->Dd;
     a.g_x = g_x;
+    // (the scratch of an fp16 data-gradient launch ends with its scale word: nh_mlp_backward)
+    a.gscale = (nh_prec_f16(p->precision) && nh_prec_level(p->precision) >= 3) ? (const unsigned*)((const float*)scratch + gscale_word_offset(p, a.nt)) : nullptr;
     NH_LAUNCH(k_mlp_input_grad, nh_ceil_div(m * a.D, 256), 256, 0, stream, a);
     return nh_launch_status("mlp_input_grad");
 }

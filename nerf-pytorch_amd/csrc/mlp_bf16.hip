@@ -15,6 +15,37 @@
 #include "nh_device.h"
 #include "nh_mlp.h"
 
+// ---- the piece format of this translation unit ------------------------------------------------------------------------------------
+// The file is compiled twice: as is (bf16 pieces: the bf16x3 plans) and through mlp_f16.hip with NHB_F16 defined (IEEE fp16 pieces:
+// the f16x3 plans, include/nerfhip.h).  Same loops, same images, same register layouts; what differs is the conversion, the MFMA,
+// and -- fp16's 5-bit exponent -- two scalings: the packed weights and biases carry NHB_WS = 2^8 (k_pack_*: a weight's low piece
+// is then a normal fp16 number down to |w| = 2^-10) and every gemm's accumulators are multiplied by 1 / NHB_WS on the way out; the
+// data-gradient chain runs on d(raw output) times a power of two picked per launch from max|d(raw output)| (DgradBArgs::gscale).
+#ifdef NHB_F16
+typedef nh_f16 nh_pc;
+typedef nh_f16x8 nh_pcx8;
+#define nh_to_pc nh_to_f16
+#define nh_from_pc nh_from_f16
+#define nh_mfma_pc nh_mfma_f16
+#define NHB_FMT "f16"
+#define NHB_FN(stem) stem##_f16
+#define NHB_KERNEL(stem) stem##_f16x3
+constexpr float NHB_WS = NHB_F16_WSCALE;
+#else
+typedef nh_bf16 nh_pc;
+typedef nh_bf16x8 nh_pcx8;
+#define nh_to_pc nh_to_bf16
+#define nh_from_pc nh_from_bf16
+#define nh_mfma_pc nh_mfma_bf16
+#define NHB_FMT "bf16"
+#define NHB_FN(stem) stem##_bf16
+#define NHB_KERNEL(stem) stem##_bf16x3
+constexpr float NHB_WS = 1.0f;
+#endif
+constexpr float NHB_INV_WS = 1.0f / NHB_WS;
+// an accumulator on its way out of a gemm (fp16 pieces: minus the weights' scale; bf16: as is)
+NH_DEVICE float nhb_out(float acc) { return NHB_WS != 1.0f ? acc * NHB_INV_WS : acc; }
+
 namespace {
 
 #ifndef NHB_DMA_EVERY  // (A/B builds only) a wave issues one 1-KiB piece of the next chunk every so many blocks; 0: all at once
@@ -52,21 +83,21 @@ NH_DEVICE void b_issue(const BCtx& cx, int64_t src, int bytes, int b, int dst_of
 
 // one accumulator tile -> two k-blocks of the next layer's operand pieces: hi = bf16(v), lo = bf16(v - hi)
 template <bool RELU>
-NH_DEVICE void convert_tile(const f32x16& acc, nh_bf16x8* oh, nh_bf16x8* ol) {
+NH_DEVICE void convert_tile(const f32x16& acc, nh_pcx8* oh, nh_pcx8* ol) {
 #ifdef NHB_EXP_NO_EPI  // (diagnostic builds only, wrong results: what the kernel costs without the conversions)
-    oh[0][0] = nh_to_bf16(acc[0]);
-    ol[1][0] = nh_to_bf16(acc[8]);
+    oh[0][0] = nh_to_pc(acc[0]);
+    ol[1][0] = nh_to_pc(acc[8]);
     return;
 #endif
 #pragma unroll
     for (int half = 0; half < 2; ++half)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float v = acc[half * 8 + j];
+            float v = nhb_out(acc[half * 8 + j]);
             if (RELU) v = nh_relu(v);
-            const nh_bf16 hi = nh_to_bf16(v);
+            const nh_pc hi = nh_to_pc(v);
             oh[half][j] = hi;
-            ol[half][j] = nh_to_bf16(v - nh_from_bf16(hi));
+            ol[half][j] = nh_to_pc(v - nh_from_pc(hi));
         }
 }
 
@@ -77,15 +108,15 @@ NH_DEVICE void convert_tile(const f32x16& acc, nh_bf16x8* oh, nh_bf16x8* ol) {
 // acc[t] = bias + sum over NKA activation k-blocks (ah/al) and NKB encoding k-blocks (xh/xl) of this layer's image at byte
 // offset `base`; while the last chunk is multiplied the first chunk of the next layer (next_base, next_first bytes) travels.
 template <int NB>
-NH_DEVICE void stash_mask_in(unsigned* tile16_mask, int s, int h, const nh_bf16x8* vh);
+NH_DEVICE void stash_mask_in(unsigned* tile16_mask, int s, int h, const nh_pcx8* vh);
 
 // in_rows / in_mask (training launches, else NULL): the gemm stores ITS OWN activation inputs -- the previous layer's output
 // as the operand pieces say it, hi + lo, i.e. exactly the values this layer consumes -- into that layer's stash region,
 // one k-block (two 16-byte stores) every other block of its first chunk, under the MFMAs, and the ReLU bits of the same
 // values in the data-gradient kernel's lane layout (as mlp16.hip: "every gemm stores its own input rows").
 template <int W, int NT, int NKA, int NKB, int EPI = 0, int NTE = 0>
-NH_DEVICE void gemm_b(BCtx& cx, const nh_bf16x8* ah, const nh_bf16x8* al, const nh_bf16x8* xh, const nh_bf16x8* xl, int64_t base,
-                      int64_t next_base, int next_first, f32x16* acc, nh_bf16x8* oh = nullptr, nh_bf16x8* ol = nullptr,
+NH_DEVICE void gemm_b(BCtx& cx, const nh_pcx8* ah, const nh_pcx8* al, const nh_pcx8* xh, const nh_pcx8* xl, int64_t base,
+                      int64_t next_base, int next_first, f32x16* acc, nh_pcx8* oh = nullptr, nh_pcx8* ol = nullptr,
                       float* in_rows = nullptr, unsigned* in_mask = nullptr, int s32 = 0) {
     constexpr int NK = NKA + NKB, BUF = BShape<W>::BUF, CH = BShape<W>::CHUNK / (NT * 2048), NCH = (NK + CH - 1) / CH;
     static_assert(CH >= 1, "a k-block of every tile must fit one chunk buffer");
@@ -93,17 +124,17 @@ NH_DEVICE void gemm_b(BCtx& cx, const nh_bf16x8* ah, const nh_bf16x8* al, const 
     auto store_step = [&](int kb) {
         float4 a4, b4;
 #ifdef NHB_EXP_STASH_HI  // (diagnostic builds only, wrong results: what the hi + lo reconstruction costs)
-        a4.x = nh_from_bf16(ah[kb][0]), a4.y = nh_from_bf16(ah[kb][1]), a4.z = nh_from_bf16(ah[kb][2]), a4.w = nh_from_bf16(ah[kb][3]);
-        b4.x = nh_from_bf16(ah[kb][4]), b4.y = nh_from_bf16(ah[kb][5]), b4.z = nh_from_bf16(ah[kb][6]), b4.w = nh_from_bf16(ah[kb][7]);
+        a4.x = nh_from_pc(ah[kb][0]), a4.y = nh_from_pc(ah[kb][1]), a4.z = nh_from_pc(ah[kb][2]), a4.w = nh_from_pc(ah[kb][3]);
+        b4.x = nh_from_pc(ah[kb][4]), b4.y = nh_from_pc(ah[kb][5]), b4.z = nh_from_pc(ah[kb][6]), b4.w = nh_from_pc(ah[kb][7]);
 #else
-        a4.x = nh_from_bf16(ah[kb][0]) + nh_from_bf16(al[kb][0]);
-        a4.y = nh_from_bf16(ah[kb][1]) + nh_from_bf16(al[kb][1]);
-        a4.z = nh_from_bf16(ah[kb][2]) + nh_from_bf16(al[kb][2]);
-        a4.w = nh_from_bf16(ah[kb][3]) + nh_from_bf16(al[kb][3]);
-        b4.x = nh_from_bf16(ah[kb][4]) + nh_from_bf16(al[kb][4]);
-        b4.y = nh_from_bf16(ah[kb][5]) + nh_from_bf16(al[kb][5]);
-        b4.z = nh_from_bf16(ah[kb][6]) + nh_from_bf16(al[kb][6]);
-        b4.w = nh_from_bf16(ah[kb][7]) + nh_from_bf16(al[kb][7]);
+        a4.x = nh_from_pc(ah[kb][0]) + nh_from_pc(al[kb][0]);
+        a4.y = nh_from_pc(ah[kb][1]) + nh_from_pc(al[kb][1]);
+        a4.z = nh_from_pc(ah[kb][2]) + nh_from_pc(al[kb][2]);
+        a4.w = nh_from_pc(ah[kb][3]) + nh_from_pc(al[kb][3]);
+        b4.x = nh_from_pc(ah[kb][4]) + nh_from_pc(al[kb][4]);
+        b4.y = nh_from_pc(ah[kb][5]) + nh_from_pc(al[kb][5]);
+        b4.z = nh_from_pc(ah[kb][6]) + nh_from_pc(al[kb][6]);
+        b4.w = nh_from_pc(ah[kb][7]) + nh_from_pc(al[kb][7]);
 #endif
         float* const dst = in_rows + 32 * (kb >> 1) + 16 * (kb & 1) + 4 * cx.h;  // units nhb_unit(kb, h, 0..3) and (kb, h, 4..7) = + 8
 #ifdef NHB_EXP_NO_STASH_STORE  // (diagnostic builds only, wrong results: what the stores themselves cost)
@@ -172,12 +203,12 @@ NH_DEVICE void gemm_b(BCtx& cx, const nh_bf16x8* ah, const nh_bf16x8* al, const 
         const int nblk = nkk * NT;
         constexpr int PF = NHB_PREFETCH;
         constexpr int NBUF = PF + 1;
-        nh_bf16x8 wph[NBUF], wpl[NBUF];
+        nh_pcx8 wph[NBUF], wpl[NBUF];
         auto kk_of = [&](int i) { return i / NT; };
         auto t_of = [&](int i) { return i % NT; };
         auto load = [&](int i) {
-            wph[i % NBUF] = *(const nh_bf16x8*)(wb + ((kk_of(i) * NT + t_of(i)) * 2) * 1024);
-            wpl[i % NBUF] = *(const nh_bf16x8*)(wb + ((kk_of(i) * NT + t_of(i)) * 2 + 1) * 1024);
+            wph[i % NBUF] = *(const nh_pcx8*)(wb + ((kk_of(i) * NT + t_of(i)) * 2) * 1024);
+            wpl[i % NBUF] = *(const nh_pcx8*)(wb + ((kk_of(i) * NT + t_of(i)) * 2 + 1) * 1024);
         };
 #pragma unroll
         for (int i = 0; i < PF; ++i)
@@ -194,12 +225,12 @@ NH_DEVICE void gemm_b(BCtx& cx, const nh_bf16x8* ah, const nh_bf16x8* al, const 
                 if (i + PF < nblk) load(i + PF);
                 nh_sched_fence();
                 const int kb = c * CH + kk_of(i), t = t_of(i);
-                const nh_bf16x8 bh = kb < NKA ? ah[kb < NKA ? kb : 0] : xh[kb >= NKA ? kb - NKA : 0];
-                const nh_bf16x8 bl = kb < NKA ? al[kb < NKA ? kb : 0] : xl[kb >= NKA ? kb - NKA : 0];
-                const nh_bf16x8 wh = wph[i % NBUF], wl = wpl[i % NBUF];
-                acc[t] = nh_mfma_bf16(wl, bh, acc[t]);  // (the small terms first)
-                acc[t] = nh_mfma_bf16(wh, bl, acc[t]);
-                acc[t] = nh_mfma_bf16(wh, bh, acc[t]);
+                const nh_pcx8 bh = kb < NKA ? ah[kb < NKA ? kb : 0] : xh[kb >= NKA ? kb - NKA : 0];
+                const nh_pcx8 bl = kb < NKA ? al[kb < NKA ? kb : 0] : xl[kb >= NKA ? kb - NKA : 0];
+                const nh_pcx8 wh = wph[i % NBUF], wl = wpl[i % NBUF];
+                acc[t] = nh_mfma_pc(wl, bh, acc[t]);  // (the small terms first)
+                acc[t] = nh_mfma_pc(wh, bl, acc[t]);
+                acc[t] = nh_mfma_pc(wh, bh, acc[t]);
             }
         }
         while (dnext < dpieces) dma_step();  // (whatever the blocks did not cover: short chunks in front of long ones)
@@ -216,16 +247,16 @@ NH_DEVICE void gemm_b(BCtx& cx, const nh_bf16x8* ah, const nh_bf16x8* al, const 
     }
 }
 
-NH_DEVICE void put_pair(nh_bf16x8& oh, nh_bf16x8& ol, int e, float v) {
-    const nh_bf16 hi = nh_to_bf16(v);
+NH_DEVICE void put_pair(nh_pcx8& oh, nh_pcx8& ol, int e, float v) {
+    const nh_pc hi = nh_to_pc(v);
     oh[e] = hi;
-    ol[e] = nh_to_bf16(v - nh_from_bf16(hi));
+    ol[e] = nh_to_pc(v - nh_from_pc(hi));
 }
 
 NH_DEVICE float bsel3(int a, float x, float y, float z) { return a == 0 ? x : (a == 1 ? y : z); }
 
 // eight fp32 slot values of one k-block -> operand pieces, and (training) -> this sample's row of the slot region
-NH_DEVICE void put_block(nh_bf16x8& oh, nh_bf16x8& ol, const float* v, float* slot_row) {
+NH_DEVICE void put_block(nh_pcx8& oh, nh_pcx8& ol, const float* v, float* slot_row) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) put_pair(oh, ol, e, v[e]);
     if (slot_row) {
@@ -240,7 +271,7 @@ NH_DEVICE void put_block(nh_bf16x8& oh, nh_bf16x8& ol, const float* v, float* sl
 // the encoding slots of lane half h (plan.cpp build_slot_map_b): slot 16 kb + 8 h + e; pair slot >> 1 = 3 f + axis.
 // slot_row (training): this sample's row of the stash's slot region; the lane writes its slots 16 kb + 8 h .. + 7.
 template <int NB>
-NH_DEVICE void encode_b(nh_bf16x8* oh, nh_bf16x8* ol, float x, float y, float z, int h, const float* freqs, int Lf, float* slot_row) {
+NH_DEVICE void encode_b(nh_pcx8* oh, nh_pcx8* ol, float x, float y, float z, int h, const float* freqs, int Lf, float* slot_row) {
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
         float v[8];
@@ -262,7 +293,7 @@ NH_DEVICE void encode_b(nh_bf16x8* oh, nh_bf16x8* ol, float x, float y, float z,
 }
 // the same slots gathered from a caller-encoded row (mode 0)
 template <int NB>
-NH_DEVICE void gather_b(nh_bf16x8* oh, nh_bf16x8* ol, const float* row, const signed char* col, int h, float* slot_row) {
+NH_DEVICE void gather_b(nh_pcx8* oh, nh_pcx8* ol, const float* row, const signed char* col, int h, float* slot_row) {
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
         float v[8];
@@ -282,7 +313,7 @@ NH_DEVICE void gather_b(nh_bf16x8* oh, nh_bf16x8* ol, const float* row, const si
 // k-block kb is unit 32 (kb >> 1) + 16 (kb & 1) + 8 (e >> 2) + 4 h + (e & 3) = register 4 kb + (e & 3) of the lane
 // g = 2 (e >> 2) + h: it writes both lanes' words whole -- no exchange between lanes.
 template <int NB>
-NH_DEVICE void stash_mask_in(unsigned* tile16_mask, int s, int h, const nh_bf16x8* vh) {
+NH_DEVICE void stash_mask_in(unsigned* tile16_mask, int s, int h, const nh_pcx8* vh) {
     constexpr int n = 4 * NB;
 #pragma unroll
     for (int jb = 0; jb < 2; ++jb) {
@@ -293,7 +324,7 @@ NH_DEVICE void stash_mask_in(unsigned* tile16_mask, int s, int h, const nh_bf16x
             for (int i = 0; i < 4; ++i) {
                 const int r = 4 * kb + i, word = r >> 5;
                 const int pos = ((n - 32 * word) < 32 ? (n - 32 * word) : 32) - 1 - (r & 31);
-                const unsigned bit = nh_from_bf16(vh[kb][4 * jb + i]) > 0.0f ? 1u : 0u;
+                const unsigned bit = nh_from_pc(vh[kb][4 * jb + i]) > 0.0f ? 1u : 0u;
                 if (word == 0) w0 |= bit << pos;
                 else w1 |= bit << pos;
             }
@@ -331,7 +362,7 @@ struct FwdBArgs {
 // (register budget: two waves per SIMD for the 128-wide inference kernel; the training one needs ~300 registers with its
 // store addresses and runs one wave per SIMD like the 256-wide kernels rather than spill)
 template <int W, bool VIEW, bool TRAIN>
-NH_KERNEL void NH_LB(256, (TRAIN ? 1 : BShape<W>::WAVES_PER_SIMD)) k_mlp_fwd_bf16x3(FwdBArgs a) {
+NH_KERNEL void NH_LB(256, (TRAIN ? 1 : BShape<W>::WAVES_PER_SIMD)) NHB_KERNEL(k_mlp_fwd)(FwdBArgs a) {
     constexpr int TH = BShape<W>::TH, KBH = BShape<W>::KBH, BUF = BShape<W>::BUF, XB = NHB_XBLOCKS, DB = NHB_DBLOCKS;
     NH_DYN_LDS(lds_raw);
     BCtx cx;
@@ -369,7 +400,7 @@ NH_KERNEL void NH_LB(256, (TRAIN ? 1 : BShape<W>::WAVES_PER_SIMD)) k_mlp_fwd_bf1
         return (unsigned*)(a.stash + (size_t)32 * (size_t)a.nt * (size_t)a.sl.total_rows) +
                ((size_t)(tile32 * 2 + (s32 >> 4)) * (size_t)a.sl.n_masks + (size_t)idx) * 128;
     };
-    nh_bf16x8 xh[XB], xl[XB];
+    nh_pcx8 xh[XB], xl[XB];
     const int ray_i = a.mode == 0 ? 0 : (int)(mc / a.S);
     if (a.mode == 0) {
         gather_b<XB>(xh, xl, a.x + (size_t)mc * (size_t)(a.dx + a.dd), a.xcol, h, TRAIN ? srow(a.sl.X, 16 * XB) : nullptr);
@@ -382,7 +413,7 @@ NH_KERNEL void NH_LB(256, (TRAIN ? 1 : BShape<W>::WAVES_PER_SIMD)) k_mlp_fwd_bf1
     }
 
     f32x16 acc[TH + 1];
-    nh_bf16x8 hh[KBH], hl[KBH];  // the current activations as operand pieces (a layer's output replaces them in place:
+    nh_pcx8 hh[KBH], hl[KBH];  // the current activations as operand pieces (a layer's output replaces them in place:
                                  // the conversion runs after the layer's last MFMA)
     {
         const bool more = a.L > 1;
@@ -405,7 +436,7 @@ NH_KERNEL void NH_LB(256, (TRAIN ? 1 : BShape<W>::WAVES_PER_SIMD)) k_mlp_fwd_bf1
             gemm_b<W, TH, KBH, 0, 1, TH>(cx, hh, hl, nullptr, nullptr, po.f_xyz[i] * 4, nxt, nfirst, acc, hh, hl, in_rows, in_mask, s32);
     }
     if (VIEW) {
-        nh_bf16x8 dh[DB], dl[DB];
+        nh_pcx8 dh[DB], dl[DB];
         if (a.mode == 0) {
             gather_b<DB>(dh, dl, a.x + (size_t)mc * (size_t)(a.dx + a.dd) + a.dx, a.dcol, h, TRAIN ? srow(a.sl.D, 16 * DB) : nullptr);
         } else {
@@ -416,16 +447,16 @@ NH_KERNEL void NH_LB(256, (TRAIN ? 1 : BShape<W>::WAVES_PER_SIMD)) k_mlp_fwd_bf1
         // (training: each gemm stores its own inputs -- H_{L-1} and mask L - 2, FEAT and mask L - 1, DIRH and mask L)
         gemm_b<W, TH + 1, KBH, 0, 1, TH>(cx, hh, hl, nullptr, nullptr, po.f_head * 4, po.f_dir * 4, first(KBH + DB, TH / 2), acc, hh, hl,
                                          TRAIN ? srow(a.sl.H[a.L - 1], W) : nullptr, (TRAIN && a.L > 1) ? smask(a.L - 2) : nullptr, s32);
-        const float alpha = acc[TH][0];
+        const float alpha = nhb_out(acc[TH][0]);
         gemm_b<W, TH / 2, KBH, DB, 1, TH / 2>(cx, hh, hl, dh, dl, po.f_dir * 4, po.f_rgb * 4, first(KBH / 2, 1), acc, hh, hl,
                                               TRAIN ? srow(a.sl.FEAT, W) : nullptr, TRAIN ? smask(a.L - 1) : nullptr, s32);
         gemm_b<W, 1, KBH / 2, 0>(cx, hh, hl, nullptr, nullptr, po.f_rgb * 4, po.f_layer1 * 4, again ? first(XB, TH) : 0, acc, nullptr, nullptr,
                                  TRAIN ? srow(a.sl.DIRH, W / 2) : nullptr, TRAIN ? smask(a.L) : nullptr, s32);
         if (valid && h == 0) {
             float4 r4;
-            r4.x = acc[0][0];
-            r4.y = acc[0][1];
-            r4.z = acc[0][2];
+            r4.x = nhb_out(acc[0][0]);
+            r4.y = nhb_out(acc[0][1]);
+            r4.z = nhb_out(acc[0][2]);
             r4.w = alpha;
             *(float4*)(a.out + (size_t)m * 4) = r4;
         }
@@ -434,10 +465,10 @@ NH_KERNEL void NH_LB(256, (TRAIN ? 1 : BShape<W>::WAVES_PER_SIMD)) k_mlp_fwd_bf1
                              TRAIN ? srow(a.sl.H[a.L - 1], W) : nullptr, (TRAIN && a.L > 1) ? smask(a.L - 2) : nullptr, s32);  // fc_out (models.py:256)
         if (valid && h == 0) {
             float4 r4;
-            r4.x = acc[0][0];
-            r4.y = acc[0][1];
-            r4.z = acc[0][2];
-            r4.w = acc[0][3];
+            r4.x = nhb_out(acc[0][0]);
+            r4.y = nhb_out(acc[0][1]);
+            r4.z = nhb_out(acc[0][2]);
+            r4.w = nhb_out(acc[0][3]);
             *(float4*)(a.out + (size_t)m * 4) = r4;
         }
     }
@@ -461,6 +492,7 @@ struct DgradBArgs {
     NhStashLayout sl;
     float* grad;
     NhGradLayout gl;
+    const unsigned* gscale;  // fp16 pieces: device word holding the bits of max|g_out| (nh_gscale_of); NULL: no scaling
 };
 
 // zero the accumulators whose ReLU bit is 0: unit 32 t + 8 j + 4 h + i is register r = 4 (2 t + (j >> 1)) + i of lane g = 2 (j & 1) + h
@@ -480,7 +512,7 @@ NH_DEVICE void gate_tiles(f32x16* acc, const unsigned* mw) {
 }
 
 template <int W, bool VIEW>
-NH_KERNEL void NH_LB(256, 1) k_mlp_dgrad_bf16x3(DgradBArgs a) {
+NH_KERNEL void NH_LB(256, 1) NHB_KERNEL(k_mlp_dgrad)(DgradBArgs a) {
     constexpr int TH = BShape<W>::TH, KBH = BShape<W>::KBH, BUF = BShape<W>::BUF;
     NH_DYN_LDS(lds_raw);
     BCtx cx;
@@ -505,8 +537,11 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_dgrad_bf16x3(DgradBArgs a) {
         const int64_t tile32 = grp * 4 + cx.wave;
         float go[4] = {0.f, 0.f, 0.f, 0.f};  // d(raw output) of this lane's sample (zero beyond M: nothing flows)
         if (m < a.M) {
+            // (fp16 pieces: the whole chain -- and every d(pre-activation) image it stores -- carries the launch's power-of-two
+            // scale; the weight-gradient reduction divides it out again)
+            const float gs = a.gscale ? nh_gscale_of(*a.gscale) : 1.0f;
             const float4 t4 = *(const float4*)(a.g_out + (size_t)m * 4);
-            go[0] = t4.x, go[1] = t4.y, go[2] = t4.z, go[3] = t4.w;
+            go[0] = t4.x * gs, go[1] = t4.y * gs, go[2] = t4.z * gs, go[3] = t4.w * gs;
         }
         auto grow = [&](const NhRegion& R, int rows) -> float* {
             return a.grad + (size_t)32 * (size_t)a.nt * (size_t)R.row_prefix + ((size_t)tile32 * 32 + (size_t)s32) * (size_t)rows;
@@ -533,9 +568,9 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_dgrad_bf16x3(DgradBArgs a) {
             *(float4*)(pr + 12) = z4;
         }
         f32x16 acc[TH];
-        nh_bf16x8 hh[KBH], hl[KBH];  // d(pre-activation) of the layer just finished, as operand pieces
+        nh_pcx8 hh[KBH], hl[KBH];  // d(pre-activation) of the layer just finished, as operand pieces
         unsigned mw[4];
-        nh_bf16x8 d1h[1], d1l[1];    // the one k-block of d(raw output): elements 0..2 (0..3 without viewdirs) of lane half 0
+        nh_pcx8 d1h[1], d1l[1];    // the one k-block of d(raw output): elements 0..2 (0..3 without viewdirs) of lane half 0
         {
             float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (h == 0) {
@@ -556,7 +591,7 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_dgrad_bf16x3(DgradBArgs a) {
             gate_tiles<TH>(acc, mw);
 #pragma unroll
             for (int t = 0; t < TH; ++t) convert_tile<false>(acc[t], hh + 2 * t, hl + 2 * t);
-            nh_bf16x8 dah[1], dal[1];  // d(sigma raw) enters through fc_alpha's column (k-block KBH, half 0, element 0)
+            nh_pcx8 dah[1], dal[1];  // d(sigma raw) enters through fc_alpha's column (k-block KBH, half 0, element 0)
             {
                 float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 if (h == 0) v[0] = go[3];
@@ -593,14 +628,14 @@ NH_KERNEL void NH_LB(256, 1) k_mlp_dgrad_bf16x3(DgradBArgs a) {
 #pragma unroll
             for (int kb = 0; kb < KBH; ++kb) {
                 float4 a4, b4;
-                a4.x = nh_from_bf16(hh[kb][0]) + nh_from_bf16(hl[kb][0]);
-                a4.y = nh_from_bf16(hh[kb][1]) + nh_from_bf16(hl[kb][1]);
-                a4.z = nh_from_bf16(hh[kb][2]) + nh_from_bf16(hl[kb][2]);
-                a4.w = nh_from_bf16(hh[kb][3]) + nh_from_bf16(hl[kb][3]);
-                b4.x = nh_from_bf16(hh[kb][4]) + nh_from_bf16(hl[kb][4]);
-                b4.y = nh_from_bf16(hh[kb][5]) + nh_from_bf16(hl[kb][5]);
-                b4.z = nh_from_bf16(hh[kb][6]) + nh_from_bf16(hl[kb][6]);
-                b4.w = nh_from_bf16(hh[kb][7]) + nh_from_bf16(hl[kb][7]);
+                a4.x = nh_from_pc(hh[kb][0]) + nh_from_pc(hl[kb][0]);
+                a4.y = nh_from_pc(hh[kb][1]) + nh_from_pc(hl[kb][1]);
+                a4.z = nh_from_pc(hh[kb][2]) + nh_from_pc(hl[kb][2]);
+                a4.w = nh_from_pc(hh[kb][3]) + nh_from_pc(hl[kb][3]);
+                b4.x = nh_from_pc(hh[kb][4]) + nh_from_pc(hl[kb][4]);
+                b4.y = nh_from_pc(hh[kb][5]) + nh_from_pc(hl[kb][5]);
+                b4.z = nh_from_pc(hh[kb][6]) + nh_from_pc(hl[kb][6]);
+                b4.w = nh_from_pc(hh[kb][7]) + nh_from_pc(hl[kb][7]);
                 float* const dst = pr + 32 * (kb >> 1) + 16 * (kb & 1) + 4 * h;
                 *(float4*)dst = a4;
                 *(float4*)(dst + 8) = b4;
@@ -616,7 +651,7 @@ struct PackBArgs {
     int64_t base[2 * NH_MAX_LAYERS + 10];  // word offset of every layer image, ascending
 };
 
-NH_KERNEL void k_pack_bf16x3(const float* __restrict__ params, const int32_t* __restrict__ table, int64_t n, PackBArgs la,
+NH_KERNEL void NHB_KERNEL(k_pack)(const float* __restrict__ params, const int32_t* __restrict__ table, int64_t n, PackBArgs la,
                              float* __restrict__ packed) {
     const int64_t i = la.first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -624,17 +659,17 @@ NH_KERNEL void k_pack_bf16x3(const float* __restrict__ params, const int32_t* __
     while (l + 1 < la.n_layers && i >= la.base[l + 1]) ++l;
     const int64_t r = i - la.base[l];
     const int32_t s = table[i];
-    const float v = s >= 0 ? params[s] : 0.0f;
+    const float v = (s >= 0 ? params[s] : 0.0f) * NHB_WS;  // (fp16 pieces: times 2^8, exact; every gemm takes it out again)
     if (r < 512) {  // bias word
         packed[i] = v;
         return;
     }
     const int64_t w = r - 512, blk = w >> 9;  // (kb * nt + t), element lane * 8 + e inside it
     const int q = (int)(w & 511);
-    nh_bf16* const img = (nh_bf16*)(packed + la.base[l] + 512);
-    const nh_bf16 hi = nh_to_bf16(v);
+    nh_pc* const img = (nh_pc*)(packed + la.base[l] + 512);
+    const nh_pc hi = nh_to_pc(v);
     img[(2 * blk) * 512 + q] = hi;
-    img[(2 * blk + 1) * 512 + q] = nh_to_bf16(v - nh_from_bf16(hi));
+    img[(2 * blk + 1) * 512 + q] = nh_to_pc(v - nh_from_pc(hi));
 }
 
 // compute units of the current device (the emulator: 3, so that the CPU suite walks the persistent loop)
@@ -671,7 +706,7 @@ int b_lds_limit(K kern, int bytes) {
 
 }  // namespace
 
-int nh_mlp_bf16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
+int NHB_FN(nh_mlp_forward)(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
                         nerfhip_stream_t stream) {
     NH_REQUIRE(M < ((int64_t)1 << 31), "mlp_fwd: at most 2^31 - 1 sample points per call (got %lld)", (long long)M);
     FwdBArgs a;
@@ -713,9 +748,10 @@ int nh_mlp_bf16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& 
     int rc = NERFHIP_OK;
 #define NH_FWDB_T(WW, VV, TT)                                                                              \
     {                                                                                                      \
-        rc = b_lds_limit(k_mlp_fwd_bf16x3<WW, VV, TT>, BShape<WW>::LDS_BYTES);                             \
+        rc = b_lds_limit(NHB_KERNEL(k_mlp_fwd)<WW, VV, TT>, BShape<WW>::LDS_BYTES);                             \
         if (rc) return rc;                                                                                 \
-        NH_LAUNCH((k_mlp_fwd_bf16x3<WW, VV, TT>), grid, 256, BShape<WW>::LDS_BYTES, stream, a);           \
+        NH_LAUNCH_NAMED("k_mlp_fwd_" NHB_FMT "x3<" #WW ", " #VV ", " #TT ">", (NHB_KERNEL(k_mlp_fwd)<WW, VV, TT>), grid, 256,  \
+                        BShape<WW>::LDS_BYTES, stream, a);                                                 \
     }
 #define NH_FWDB(WW, VV)              \
     {                                \
@@ -729,16 +765,16 @@ int nh_mlp_bf16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& 
     else if (p->W == 128 && p->view) NH_FWDB(128, true)
     else if (p->W == 128) NH_FWDB(128, false)
     else {
-        nh_set_error("mlp_fwd: no bf16x3 kernel for kernel width %d", p->W);
+        nh_set_error("mlp_fwd: no " NHB_FMT "x3 kernel for kernel width %d", p->W);
         return NERFHIP_ERR_UNSUPPORTED;
     }
 #undef NH_FWDB
 #undef NH_FWDB_T
-    return nh_launch_status("mlp_fwd_bf16x3");
+    return nh_launch_status("mlp_fwd_" NHB_FMT "x3");
 }
 
-int nh_mlp_bf16_dgrad(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
-                      nerfhip_stream_t stream) {
+int NHB_FN(nh_mlp_dgrad)(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
+                         const unsigned* gscale, nerfhip_stream_t stream) {
     DgradBArgs d;
     memset(&d, 0, sizeof(d));
     d.packed = packed;
@@ -753,37 +789,32 @@ int nh_mlp_bf16_dgrad(nerfhip_plan* p, const float* packed, const float* g_out, 
     d.sl = p->stash;
     d.grad = scratch;
     d.gl = p->grad;
+    d.gscale = gscale;
     const int64_t resident = b_compute_units();  // (one wave per SIMD: one workgroup per CU also for the 128-wide nets)
     const int64_t grid = d.groups < resident ? d.groups : resident;
     int rc = NERFHIP_OK;
 #define NH_BWDB(WW, VV)                                                                                    \
     {                                                                                                      \
-        rc = b_lds_limit(k_mlp_dgrad_bf16x3<WW, VV>, BShape<WW>::LDS_BYTES);                               \
+        rc = b_lds_limit(NHB_KERNEL(k_mlp_dgrad)<WW, VV>, BShape<WW>::LDS_BYTES);                               \
         if (rc) return rc;                                                                                 \
-        NH_LAUNCH((k_mlp_dgrad_bf16x3<WW, VV>), grid, 256, BShape<WW>::LDS_BYTES, stream, d);             \
+        NH_LAUNCH_NAMED("k_mlp_dgrad_" NHB_FMT "x3<" #WW ", " #VV ">", (NHB_KERNEL(k_mlp_dgrad)<WW, VV>), grid, 256,           \
+                        BShape<WW>::LDS_BYTES, stream, d);                                                 \
     }
     if (p->W == 256 && p->view) NH_BWDB(256, true)
     else if (p->W == 256) NH_BWDB(256, false)
     else if (p->W == 128 && p->view) NH_BWDB(128, true)
     else if (p->W == 128) NH_BWDB(128, false)
     else {
-        nh_set_error("mlp_bwd: no bf16x3 data-gradient kernel for kernel width %d", p->W);
+        nh_set_error("mlp_bwd: no " NHB_FMT "x3 data-gradient kernel for kernel width %d", p->W);
         return NERFHIP_ERR_UNSUPPORTED;
     }
 #undef NH_BWDB
-    return nh_launch_status("mlp_dgrad_bf16x3");
+    return nh_launch_status("mlp_dgrad_" NHB_FMT "x3");
 }
 
-extern "C" int nerfhip_pack_weights_plan(nerfhip_plan_t plan, const float* params, const int32_t* table, float* packed,
-                                         nerfhip_stream_t stream) {
-    NH_REQUIRE(plan && params && table && packed, "pack_weights_plan: bad arguments");
-    const int64_t n = plan->packed_floats;
-    if (plan->precision == NERFHIP_PRECISION_FP32) return nerfhip_pack_weights(params, table, n, packed, stream);
-    const int64_t n32 = plan->packed32_floats;  // (BF16X3_FWD: the fp32 image in front -- a plain gather)
-    if (n32 > 0) {
-        const int rc = nerfhip_pack_weights(params, table, n32, packed, stream);
-        if (rc) return rc;
-    }
+// the split-precision layer images of a plan (behind its fp32 image, if it has one): gather, scale (fp16), split
+int NHB_FN(nh_pack_pieces)(nerfhip_plan* plan, const float* params, const int32_t* table, float* packed, nerfhip_stream_t stream) {
+    const int64_t n = plan->packed_floats, n32 = plan->packed32_floats;
     PackBArgs la;
     memset(&la, 0, sizeof(la));
     const NhPackedOffsets& o = plan->pob;
@@ -795,7 +826,7 @@ extern "C" int nerfhip_pack_weights_plan(nerfhip_plan_t plan, const float* param
         la.base[k++] = o.f_dir;
         la.base[k++] = o.f_rgb;
     }
-    if (plan->precision == NERFHIP_PRECISION_BF16X3_FWD_DGRAD || plan->precision == NERFHIP_PRECISION_BF16X3_TRAIN) {  // (the order of plan.cpp for_each_spec_b)
+    if (nh_prec_level(plan->precision) >= 3) {  // (the order of plan.cpp for_each_spec_b)
         if (plan->view) {
             la.base[k++] = o.b_rgb;
             la.base[k++] = o.b_dir;
@@ -805,6 +836,22 @@ extern "C" int nerfhip_pack_weights_plan(nerfhip_plan_t plan, const float* param
     }
     la.n_layers = k;
     la.first = n32;
-    NH_LAUNCH(k_pack_bf16x3, nh_ceil_div(n - n32, 256), 256, 0, stream, params, table, n, la, packed);
+    NH_LAUNCH_NAMED("k_pack_" NHB_FMT "x3", NHB_KERNEL(k_pack), nh_ceil_div(n - n32, 256), 256, 0, stream, params, table, n, la, packed);
     return nh_launch_status("pack_weights_plan");
 }
+
+#ifndef NHB_F16
+extern "C" int nerfhip_pack_weights_plan(nerfhip_plan_t plan, const float* params, const int32_t* table, float* packed,
+                                         nerfhip_stream_t stream) {
+    NH_REQUIRE(plan && params && table && packed, "pack_weights_plan: bad arguments");
+    const int64_t n = plan->packed_floats;
+    if (plan->precision == NERFHIP_PRECISION_FP32) return nerfhip_pack_weights(params, table, n, packed, stream);
+    const int64_t n32 = plan->packed32_floats;  // (training-capable plans: the fp32 image in front -- a plain gather)
+    if (n32 > 0) {
+        const int rc = nerfhip_pack_weights(params, table, n32, packed, stream);
+        if (rc) return rc;
+    }
+    return nh_prec_f16(plan->precision) ? nh_pack_pieces_f16(plan, params, table, packed, stream)
+                                        : nh_pack_pieces_bf16(plan, params, table, packed, stream);
+}
+#endif

@@ -36,6 +36,7 @@ NH_DEVICE int nh_shfl_i(int v, int src) { return __shfl(v, src, 64); }
 NH_DEVICE float nh_shfl_up(float v, int d) { return __shfl_up(v, d, 64); }
 NH_DEVICE float nh_shfl_down(float v, int d) { return __shfl_down(v, d, 64); }
 NH_DEVICE float nh_shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
+NH_DEVICE int nh_shfl_xor_i(int v, int m) { return __shfl_xor(v, m, 64); }
 NH_DEVICE double nh_shfl_d(double v, int src) { return __shfl(v, src, 64); }
 NH_DEVICE double nh_shfl_up_d(double v, int d) { return __shfl_up(v, d, 64); }
 NH_DEVICE double nh_shfl_down_d(double v, int d) { return __shfl_down(v, d, 64); }
@@ -62,7 +63,20 @@ NH_DEVICE f32x16 nh_mfma_bf16(nh_bf16x8 a, nh_bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// IEEE fp16 pieces of the f16x3 plans (the same kernels, compiled a second time: mlp_f16.hip, wgrad_f16.hip).  nh_to_f16:
+// round-to-nearest-even incl. subnormal results (v_cvt_f16_f32; the kernels run with fp16 denormals on, HIP's default);
+// nh_mfma_f16: v_mfma_f32_32x32x16_f16, operand / result layout as nh_mfma_bf16 -- the matrix pipe takes fp16 subnormal inputs
+// at face value (measured on MI355X: scripts/probe/f16_mfma_probe.hip).
+typedef _Float16 nh_f16;
+typedef _Float16 nh_f16x8 __attribute__((ext_vector_type(8)));
+NH_DEVICE nh_f16 nh_to_f16(float v) { return (nh_f16)v; }
+NH_DEVICE float nh_from_f16(nh_f16 h) { return (float)h; }
+NH_DEVICE f32x16 nh_mfma_f16(nh_f16x8 a, nh_f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
 NH_DEVICE void nh_atomic_add(float* p, float v) { atomicAdd(p, v); }
+NH_DEVICE void nh_atomic_max_u32(unsigned* p, unsigned v) { atomicMax(p, v); }
 // Asynchronous global -> LDS copy of 16 bytes per lane (global_load_lds_dwordx4): lane l's 16 bytes at `g` land at
 // lds_wave_base + 16*l (the LDS destination is wave-uniform base + lane*16).  Completion: nh_wait_vmem() + barrier.
 NH_DEVICE void nh_glds16(const float* g, float* lds_wave_base) {
@@ -202,6 +216,29 @@ NH_DEVICE float nh_gate(float v, unsigned word, int k) {
     i &= m;
     memcpy(&v, &i, 4);
     return v;
+}
+
+// Gradient scale of the fp16 data-gradient chain: `maxbits` = bit pattern of max|d(raw output)| over a launch (k_absmax_bits).
+// nh_gscale_of: the power of two S with max * S in [16, 32) -- fp16's normal range is [2^-14, 2^16): the head room above covers
+// what the transposed layers can amplify, the 2^18 below keeps both pieces of everything within 2^-6 of the maximum normal --;
+// nh_gscale_inv: 1 / S exactly.  Degenerate maxima (0, subnormal, Inf / NaN) give S = 1.
+NH_DEVICE int nh_gscale_exp(unsigned maxbits) {
+    const int e = (int)((maxbits >> 23) & 255u);
+    if (e == 0 || e == 255) return 127;
+    const int se = 258 - e;
+    return se < 1 ? 1 : (se > 253 ? 253 : se);
+}
+NH_DEVICE float nh_gscale_of(unsigned maxbits) {
+    const unsigned u = (unsigned)nh_gscale_exp(maxbits) << 23;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+NH_DEVICE float nh_gscale_inv(unsigned maxbits) {
+    const unsigned u = (unsigned)(254 - nh_gscale_exp(maxbits)) << 23;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
 }
 
 // Row (feature) index held by accumulator register c (0..15) of MFMA tile t for lane-half h.

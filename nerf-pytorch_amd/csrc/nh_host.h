@@ -24,11 +24,20 @@ unsigned long long* nh_prof_clock_slot(int kind);
 #ifdef NERFHIP_EMU
 #define NH_LAUNCH(kern, grid, block, smem, stream, ...) \
     emu::launch(emu::Dim3((unsigned)(grid)), emu::Dim3((unsigned)(block)), (size_t)(smem), [&]() { kern(__VA_ARGS__); })
+#define NH_LAUNCH_NAMED(name, kern, grid, block, smem, stream, ...) NH_LAUNCH(kern, grid, block, smem, stream, __VA_ARGS__)
 static inline int nh_launch_status(const char*) { return NERFHIP_OK; }
 #else
 #define NH_LAUNCH(kern, grid, block, smem, stream, ...)                                                             \
     do {                                                                                                            \
         nh_prof_begin(#kern, stream);                                                                               \
+        hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (size_t)(smem), (hipStream_t)(stream), \
+                           __VA_ARGS__);                                                                            \
+        nh_prof_end(stream);                                                                                        \
+    } while (0)
+// the same with the profile name spelled out (kernels whose C++ name is assembled by a macro: the split-precision translation units)
+#define NH_LAUNCH_NAMED(name, kern, grid, block, smem, stream, ...)                                                 \
+    do {                                                                                                            \
+        nh_prof_begin(name, stream);                                                                                \
         hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (size_t)(smem), (hipStream_t)(stream), \
                            __VA_ARGS__);                                                                            \
         nh_prof_end(stream);                                                                                        \

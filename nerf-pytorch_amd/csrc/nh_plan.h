@@ -59,6 +59,15 @@ constexpr int nhb_first_bytes(int nk, int nt, int W) {
     return 2048 + (nk < nhb_chunk_bytes(W) / (nt * 2048) ? nk : nhb_chunk_bytes(W) / (nt * 2048)) * nt * 2048;
 }
 
+// Split-precision plans (include/nerfhip.h NERFHIP_PRECISION_*): `level` says which kernels run on the 16-bit MFMAs -- 0 none
+// (fp32), 1 the inference forward only (inference-only plan), 2 + the training forward, 3 + the data-gradient chain, 4 + the
+// large weight-gradient blocks -- and `f16` which pieces they multiply: bf16 (8 significant bits each, 8-bit exponent) or IEEE
+// fp16 (11 bits, 5-bit exponent: weights pre-scaled, d(raw output) scaled per launch).
+static inline int nh_prec_level(int precision) { return precision <= NERFHIP_PRECISION_BF16X3_TRAIN ? precision : precision - 4; }
+static inline bool nh_prec_f16(int precision) { return precision >= NERFHIP_PRECISION_F16X3; }
+// fp16 pieces: the packed weights and biases carry this power of two (exact), every gemm's accumulators its inverse
+constexpr float NHB_F16_WSCALE = 256.0f;
+
 struct NhTensor {
     std::string name;
     int64_t off;
@@ -141,7 +150,7 @@ struct nerfhip_plan {
     int64_t nparams;
     int t_layer1_w, t_layer1_b, t_xyz_w[NH_MAX_LAYERS], t_xyz_b[NH_MAX_LAYERS];
     int t_dir_w, t_dir_b, t_alpha_w, t_alpha_b, t_rgb_w, t_rgb_b, t_feat_w, t_feat_b, t_out_w, t_out_b;
-    int precision;                    // NERFHIP_PRECISION_FP32 | _BF16X3 (inference-only plan) | _BF16X3_FWD (bf16x3 forward, fp32 backward)
+    int precision;                    // NERFHIP_PRECISION_*: nh_prec_level() / nh_prec_f16() above
     NhPackedOffsets pob;              // bf16x3 plans: word offsets of the split-bf16 layer images inside the packed buffer
     int64_t packed32_floats;          // words of the fp32 image in front of them (0 for _BF16X3, the whole buffer for _FP32)
     int xyz_slot_b[16 * NHB_XBLOCKS];  // bf16x3 plans: encoding slot -> reference column, or -1

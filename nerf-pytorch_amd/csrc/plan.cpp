@@ -373,7 +373,7 @@ void for_each_spec_b(const nerfhip_plan* p, SpecsB& S, NhPackedOffsets& o, Fn fn
         fn(S.f_dir, &o.f_dir);
         fn(S.f_rgb, &o.f_rgb);
     }
-    if (p->precision == NERFHIP_PRECISION_BF16X3_FWD_DGRAD || p->precision == NERFHIP_PRECISION_BF16X3_TRAIN) {
+    if (nh_prec_level(p->precision) >= 3) {
         if (p->view) {
             fn(S.b_rgb, &o.b_rgb);
             fn(S.b_dir, &o.b_dir);
@@ -590,7 +590,7 @@ void build_layouts_and_jobs(nerfhip_plan* p) {
     p->bjobs.clear();
     // (256-wide nets only: for the 128 x 128 blocks of narrower nets the conversion outweighs the MFMAs -- measured on MI355X:
     // 4x128 step 4.23 -> 5.04 ms -- so there BF16X3_TRAIN is BF16X3_FWD_DGRAD)
-    const bool big_b = p->precision == NERFHIP_PRECISION_BF16X3_TRAIN && W >= 256;
+    const bool big_b = nh_prec_level(p->precision) == 4 && W >= 256;
     auto add_big = [&](const NhRegion& A, int a_rows, const NhRegion& B, int r_hi, int w_tensor, int bias_tensor) {
         NhJobB j;
         j.a_rows = a_rows;
@@ -638,8 +638,7 @@ void build_layouts_and_jobs(nerfhip_plan* p) {
 static nerfhip_plan_t plan_create_impl(const nerfhip_model_cfg* cfg, int precision);
 extern "C" nerfhip_plan_t nerfhip_plan_create(const nerfhip_model_cfg* cfg) { return plan_create_impl(cfg, NERFHIP_PRECISION_FP32); }
 extern "C" nerfhip_plan_t nerfhip_plan_create_ex(const nerfhip_model_cfg* cfg, int precision) {
-    if (precision != NERFHIP_PRECISION_FP32 && precision != NERFHIP_PRECISION_BF16X3 && precision != NERFHIP_PRECISION_BF16X3_FWD &&
-        precision != NERFHIP_PRECISION_BF16X3_FWD_DGRAD && precision != NERFHIP_PRECISION_BF16X3_TRAIN) {
+    if (precision < NERFHIP_PRECISION_FP32 || precision > NERFHIP_PRECISION_F16X3_TRAIN) {
         nh_set_error("plan_create_ex: unknown precision %d", precision);
         return nullptr;
     }
@@ -743,14 +742,14 @@ static nerfhip_plan_t plan_create_impl(const nerfhip_model_cfg* cfg, int precisi
         const bool okd = build_slot_map_b(p->view ? cfg->num_encoding_fn_dir : 0, (p->view && cfg->include_input_dir) ? 1 : 0,
                                           16 * NHB_DBLOCKS, p->dir_slot_b);
         if (!(okx && okd) || (p->W != 128 && p->W != 256)) {
-            nh_set_error("plan_create_ex: bf16x3 plans need hidden_size in (64, 256], num_encoding_fn_xyz <= 10 and "
+            nh_set_error("plan_create_ex: bf16x3 / f16x3 plans need hidden_size in (64, 256], num_encoding_fn_xyz <= 10 and "
                          "num_encoding_fn_dir <= 4 (got %d, %d, %d)", cfg->hidden_size, cfg->num_encoding_fn_xyz, cfg->num_encoding_fn_dir);
             delete p;
             return nullptr;
         }
         memset(&p->po, 0, sizeof(p->po));
         p->packed_floats = 0;
-        if (precision != NERFHIP_PRECISION_BF16X3) {
+        if (nh_prec_level(precision) != 1) {
             layout_packed(p);  // the fp32 image: its transposed layers feed the data-gradient kernel
             // the training forward stores the encodings in ITS slot order: that is what the weight-gradient scatter must undo
             for (int row = 0; row < 4 * NH16_KRX_EXT; ++row) p->xyz_slot_col[row] = row < 16 * NHB_XBLOCKS ? p->xyz_slot_b[row] : -1;
@@ -763,8 +762,11 @@ static nerfhip_plan_t plan_create_impl(const nerfhip_model_cfg* cfg, int precisi
         memset(&p->pob, 0, sizeof(p->pob));
     }
     build_layouts_and_jobs(p);
-    if ((int)p->jobs.size() > NH_MAX_JOBS) {
-        nh_set_error("plan_create: too many gradient jobs");
+    // (the weight-gradient reduce kernel's table holds one record per job and one per attached side block)
+    int reduce_records = 0;
+    for (const NhJob& j : p->jobs) reduce_records += j.side_kind ? 2 : 1;
+    if ((int)p->jobs.size() > NH_MAX_JOBS || reduce_records > NH_MAX_JOBS) {
+        nh_set_error("plan_create: too many gradient jobs (%d jobs, %d reduce records; limit %d)", (int)p->jobs.size(), reduce_records, NH_MAX_JOBS);
         delete p;
         return nullptr;
     }
@@ -813,7 +815,7 @@ extern "C" int nerfhip_plan_pack_index(nerfhip_plan_t plan, int32_t* host_table)
         build_specs_b(plan, S);
         NhPackedOffsets o = plan->pob;
         for_each_spec_b(plan, S, o, [&](const GemmSpecB& s, int64_t* dst) { fill_spec_b(s, *dst, host_table); });
-        if (plan->precision == NERFHIP_PRECISION_BF16X3) return NERFHIP_OK;
+        if (nh_prec_level(plan->precision) == 1) return NERFHIP_OK;
     }
     Specs16 S16;
     build_specs16(plan, S16);

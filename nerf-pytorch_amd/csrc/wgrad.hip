@@ -56,7 +56,7 @@ struct JobRed {  // k_wgrad_reduce
     int tile0;     // first accumulator tile of this block inside a workgroup's partial (0, or behind the host job's tiles)
 };
 constexpr int NH_JOBS_DEV = NH_MAX_JOBS;
-static_assert(sizeof(JobDev) * NH_JOBS_DEV + 64 <= 4096 && sizeof(JobRed) * NH_JOBS_DEV + 232 <= 4096,
+static_assert(sizeof(JobDev) * NH_JOBS_DEV + 64 <= 4096 && sizeof(JobRed) * NH_JOBS_DEV + 240 <= 4096,
               "the job tables must fit the 4 KB kernel-argument limit");
 // Workgroup shapes.  256-wide nets: 8 waves per workgroup (two per SIMD), two LDS stages of 16384 floats (+ slack for
 // the operand prefetch that runs one k-step past the end of a stage): one workgroup per CU.  128-wide nets (jobs of at
@@ -91,6 +91,8 @@ struct WgradArgs {
 struct ReduceArgs {
     const float* partial;
     float* g_params;
+    const unsigned* gscale;  // fp16 data-gradient chains: device word with the bits of max|g_out| (the d(pre-activation) images
+                             // carry nh_gscale_of of it, the reduction multiplies by nh_gscale_inv -- exact); else NULL
     int njobs, total_wgs;
     int part_bias, part_stride;
     JobRed jobs[NH_JOBS_DEV];
@@ -539,6 +541,7 @@ NH_KERNEL void k_wgrad_reduce(ReduceArgs a) {
     NH_SHARED float part[256];
     const int ji = (int)(blockIdx.x >> 8);
     const JobRed jb = a.jobs[ji];
+    const float unscale = a.gscale ? nh_gscale_inv(*a.gscale) : 1.0f;
     // A job owns 256 blocks of 256 threads.  Jobs with few accumulator tiles would leave most of them idle and a handful of
     // threads with ~150 dependent partial loads each (the 64- and 128-wide nets: this kernel was 3-6 % of their step), so a
     // block covers 256 >> ksl elements with (1 << ksl) K-slices per element: slice s sums partials s, s + KS, ... and the
@@ -586,7 +589,7 @@ NH_KERNEL void k_wgrad_reduce(ReduceArgs a) {
             for (int sidx = 0; sidx < nsl; ++sidx) total += part[sidx * epb + e_local];
         }
     }
-    if (col >= 0 && slice == 0) a.g_params[(size_t)jb.w_off + (size_t)(out_row - jb.r_lo) * jb.w_ld + col] = total;
+    if (col >= 0 && slice == 0) a.g_params[(size_t)jb.w_off + (size_t)(out_row - jb.r_lo) * jb.w_ld + col] = total * unscale;
     if (slice == 0 && in_job && jb.bias_off >= 0 && b_t == 0 && c == 0 && lane < 32) {
         const int brow = 32 * jb.po * (a_t / jb.po) + jb.po * lane + a_t % jb.po;
         if (brow >= jb.r_lo && brow < jb.r_hi) {
@@ -600,7 +603,7 @@ NH_KERNEL void k_wgrad_reduce(ReduceArgs a) {
             }
             for (; q < nks; ++q) sum[0] += p[(size_t)q * a.part_stride];
             a.g_params[(size_t)jb.bias_off + (brow - jb.r_lo)] =
-                ((sum[0] + sum[1]) + (sum[2] + sum[3])) + ((sum[4] + sum[5]) + (sum[6] + sum[7]));
+                (((sum[0] + sum[1]) + (sum[2] + sum[3])) + ((sum[4] + sum[5]) + (sum[6] + sum[7]))) * unscale;
         }
     }
 }
@@ -676,6 +679,11 @@ void wgrad_schedule(const nerfhip_plan* p, int64_t nt, WgradArgs& w, ReduceArgs*
         if (d.g < 1) d.g = 1;
         if (r) {
             auto ks_log = [](int tiles) { return tiles <= 4 ? 4 : (tiles <= 16 ? 2 : 0); };  // 256 blocks x (256 >> ks_log) elements cover tiles * 1024
+            if (nred + (j.side_kind ? 2 : 1) > NH_JOBS_DEV) {  // (refused by nerfhip_plan_create; never write past the table)
+                nred += j.side_kind ? 2 : 1;
+                start += (int)ks[q];
+                continue;
+            }
             JobRed& e = r->jobs[nred++];
             e.a_tiles = j.a_tiles;
             e.b_tiles = j.b_tiles;
@@ -733,7 +741,7 @@ void wgrad_schedule(const nerfhip_plan* p, int64_t nt, WgradArgs& w, ReduceArgs*
 }
 
 template <class MD>
-int launch_wgrad(const WgradArgs& w, nerfhip_stream_t stream) {
+int launch_wgrad(const WgradArgs& w, const char* name, nerfhip_stream_t stream) {
 #ifndef NERFHIP_EMU
     hipError_t e = hipFuncSetAttribute((const void*)k_wgrad<MD>, hipFuncAttributeMaxDynamicSharedMemorySize, MD::LDS_BYTES);
     if (e != hipSuccess) {
@@ -741,7 +749,7 @@ int launch_wgrad(const WgradArgs& w, nerfhip_stream_t stream) {
         return NERFHIP_ERR_LAUNCH;
     }
 #endif
-    NH_LAUNCH((k_wgrad<MD>), w.total_wgs, 64 * MD::NWV, MD::LDS_BYTES, stream, w);
+    NH_LAUNCH_NAMED(name, (k_wgrad<MD>), w.total_wgs, 64 * MD::NWV, MD::LDS_BYTES, stream, w);
     return nh_launch_status("wgrad");
 }
 
@@ -754,7 +762,7 @@ int64_t nh_wgrad_partial_floats(nerfhip_plan* p, int64_t nt) {
 }
 
 int nh_wgrad(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad, float* partial, float* g_params,
-             nerfhip_stream_t stream) {
+             const unsigned* gscale, nerfhip_stream_t stream) {
     WgradArgs w;
     ReduceArgs red;
     memset(&w, 0, sizeof(w));
@@ -765,6 +773,9 @@ int nh_wgrad(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad,
     w.partial = partial;
     red.partial = partial;
     red.g_params = g_params;
+    red.gscale = gscale;
+    // (one reduce record per job AND per side block: nerfhip_plan_create counts both against NH_MAX_JOBS)
+    NH_REQUIRE(red.njobs <= NH_JOBS_DEV, "wgrad: %d reduce records exceed the table of %d", red.njobs, NH_JOBS_DEV);
     w.nt = nt;
     w.clk = nh_prof_clock_slot(NH_CLK_WGRAD);
     for (int q = 0; q < w.njobs; ++q) {
@@ -778,10 +789,12 @@ int nh_wgrad(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad,
                    j.a_tiles, j.b_tiles, j.wo, j.wi, j.po, j.pi);
     }
     int rc = NERFHIP_OK;
+    // (profile name: a level-4 plan leaves this kernel the thin blocks only -- a different amount of work under the same symbol)
+    const char* const name = p->bjobs.empty() ? "k_wgrad<MD>" : "k_wgrad<MD>[thin blocks]";
     if (p->wgrad_waves == 4)
-        rc = launch_wgrad<WModeNarrow>(w, stream);
+        rc = launch_wgrad<WModeNarrow>(w, name, stream);
     else
-        rc = launch_wgrad<WModeWide>(w, stream);
+        rc = launch_wgrad<WModeWide>(w, name, stream);
     if (rc) return rc;
     NH_LAUNCH(k_wgrad_reduce, red.njobs * 256, 256, 0, stream, red);
     return nh_launch_status("wgrad_reduce");

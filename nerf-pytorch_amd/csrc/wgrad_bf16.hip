@@ -14,10 +14,32 @@
 //   multiply: wave (wo, wi) of the 4 x 2 grid (8 waves, two per SIMD) owns an eighth of the block (2 x 4 accumulator tiles = 128
 //             AGPRs for a 256 x 256 block): 4 + 8 operand reads and 24 MFMAs per step.
 // Split-K over the workgroups of a block; the partials (accumulator tiles as [tile][16 registers][64 lanes], then the 256 threads'
-// bias sums) are summed in a fixed order by k_wgrad_bf16_reduce -- bit-reproducible, no atomics -- and scattered into the
+// bias sums) are summed in a fixed order by NHB_KERNEL(k_wgrad_reduce) -- bit-reproducible, no atomics -- and scattered into the
 // reference parameter layout.
 #include "nh_device.h"
 #include "nh_mlp.h"
+
+// (compiled twice, like mlp_bf16.hip: as is for the bf16x3 plans and through wgrad_f16.hip -- NHB_F16 -- for the f16x3 plans, whose
+// d(pre-activation) images carry the launch's power-of-two gradient scale: WgBArgs::gscale, divided out by the reduction)
+#ifdef NHB_F16
+typedef nh_f16 nh_pc;
+typedef nh_f16x8 nh_pcx8;
+#define nh_to_pc nh_to_f16
+#define nh_from_pc nh_from_f16
+#define nh_mfma_pc nh_mfma_f16
+#define NHB_FMT "f16"
+#define NHB_FN(stem) stem##_f16
+#define NHB_KERNEL(stem) stem##_f16x3
+#else
+typedef nh_bf16 nh_pc;
+typedef nh_bf16x8 nh_pcx8;
+#define nh_to_pc nh_to_bf16
+#define nh_from_pc nh_from_bf16
+#define nh_mfma_pc nh_mfma_bf16
+#define NHB_FMT "bf16"
+#define NHB_FN(stem) stem##_bf16
+#define NHB_KERNEL(stem) stem##_bf16x3
+#endif
 
 namespace {
 
@@ -44,6 +66,7 @@ struct WgBArgs {
     float* g_params;
     int64_t nt;
     int njobs, part_stride;  // floats per workgroup partial: AR * BR accumulators + 256 bias sums
+    const unsigned* gscale;  // device word: bits of max|g_out| of the data-gradient launch that wrote `grad` (fp16 chain), or NULL
     WgBJob jobs[NHW_MAX_JOBS];
 };
 
@@ -85,25 +108,25 @@ NH_DEVICE float rows_store(const RowItems<ROWS>& r, char* hi_blocks, char* lo_bl
         const int id = tid + NHW_THREADS * it;
         if (ROWS * 2 % NHW_THREADS != 0 && id >= ROWS * 2) break;
         const int row = id % ROWS, q = id / ROWS;
-        nh_bf16x8 h8, l8;
+        nh_pcx8 h8, l8;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float v = r.v[it][e];
             sum += v;
-            const nh_bf16 hi = nh_to_bf16(v);
+            const nh_pc hi = nh_to_pc(v);
             h8[e] = hi;
-            l8[e] = nh_to_bf16(v - nh_from_bf16(hi));
+            l8[e] = nh_to_pc(v - nh_from_pc(hi));
         }
         // operand block of the 32-row tile row >> 5: lane (row & 31) + 32 q, 16 bytes per lane
         const int off = (((row >> 5) * 2 + q) * 32 + (row & 31)) * 16;
-        *(nh_bf16x8*)(hi_blocks + off) = h8;
-        *(nh_bf16x8*)(lo_blocks + off) = l8;
+        *(nh_pcx8*)(hi_blocks + off) = h8;
+        *(nh_pcx8*)(lo_blocks + off) = l8;
     }
     return sum;
 }
 
 template <int AR, int BR>
-NH_KERNEL void NH_LB(NHW_THREADS, NHW_WAVES / 4) k_wgrad_bf16x3(WgBArgs a) {
+NH_KERNEL void NH_LB(NHW_THREADS, NHW_WAVES / 4) NHB_KERNEL(k_wgrad)(WgBArgs a) {
     using S = WShape<AR, BR>;
     constexpr int PO = S::PO, PI = S::PI;
     NH_DYN_LDS(lds);
@@ -161,31 +184,31 @@ NH_KERNEL void NH_LB(NHW_THREADS, NHW_WAVES / 4) k_wgrad_bf16x3(WgBArgs a) {
         (void)rows_store<BR>(rb, bh_blk, bl_blk, tid);
         nh_block_sync();  // operand blocks complete; this step's stage is free
         if (u + NHW_STAGES < u1) issue(u + NHW_STAGES);  // (into the stage just converted)
-        nh_bf16x8 ah[PO], al[PO], bh[PI], bl[PI];
+        nh_pcx8 ah[PO], al[PO], bh[PI], bl[PI];
 #pragma unroll
         for (int x = 0; x < PO; ++x) {
-            ah[x] = *(const nh_bf16x8*)(ah_blk + (ta0 + x) * 1024 + lane * 16);
-            al[x] = *(const nh_bf16x8*)(al_blk + (ta0 + x) * 1024 + lane * 16);
+            ah[x] = *(const nh_pcx8*)(ah_blk + (ta0 + x) * 1024 + lane * 16);
+            al[x] = *(const nh_pcx8*)(al_blk + (ta0 + x) * 1024 + lane * 16);
         }
 #pragma unroll
         for (int y = 0; y < PI; ++y) {
-            bh[y] = *(const nh_bf16x8*)(bh_blk + (tb0 + y) * 1024 + lane * 16);
-            bl[y] = *(const nh_bf16x8*)(bl_blk + (tb0 + y) * 1024 + lane * 16);
+            bh[y] = *(const nh_pcx8*)(bh_blk + (tb0 + y) * 1024 + lane * 16);
+            bl[y] = *(const nh_pcx8*)(bl_blk + (tb0 + y) * 1024 + lane * 16);
         }
         nh_sched_fence();
         // (three sweeps over the accumulator tiles, the small terms first: no MFMA reads the accumulator its predecessor wrote)
 #pragma unroll
         for (int x = 0; x < PO; ++x)
 #pragma unroll
-            for (int y = 0; y < PI; ++y) acc[x][y] = nh_mfma_bf16(al[x], bh[y], acc[x][y]);
+            for (int y = 0; y < PI; ++y) acc[x][y] = nh_mfma_pc(al[x], bh[y], acc[x][y]);
 #pragma unroll
         for (int x = 0; x < PO; ++x)
 #pragma unroll
-            for (int y = 0; y < PI; ++y) acc[x][y] = nh_mfma_bf16(ah[x], bl[y], acc[x][y]);
+            for (int y = 0; y < PI; ++y) acc[x][y] = nh_mfma_pc(ah[x], bl[y], acc[x][y]);
 #pragma unroll
         for (int x = 0; x < PO; ++x)
 #pragma unroll
-            for (int y = 0; y < PI; ++y) acc[x][y] = nh_mfma_bf16(ah[x], bh[y], acc[x][y]);
+            for (int y = 0; y < PI; ++y) acc[x][y] = nh_mfma_pc(ah[x], bh[y], acc[x][y]);
     }
     // the partial: accumulator tile (ta, tb) as [16 registers][64 lanes], then the threads' bias sums
     float* const part = a.partial + (size_t)blockIdx.x * (size_t)a.part_stride;
@@ -201,11 +224,12 @@ NH_KERNEL void NH_LB(NHW_THREADS, NHW_WAVES / 4) k_wgrad_bf16x3(WgBArgs a) {
 // sums the split-K partials of a block in workgroup order and scatters them into the reference parameter layout; element
 // (tile (ta, tb), register c, lane l) is row 32 ta + (c & 3) + 8 (c >> 2) + 4 (l >> 5), column 32 tb + (l & 31)
 template <int AR, int BR>
-NH_KERNEL void k_wgrad_bf16_reduce(WgBArgs a) {
+NH_KERNEL void NHB_KERNEL(k_wgrad_reduce)(WgBArgs a) {
     constexpr int TB = BR / 32, E = AR * BR, GX = (E + AR + 255) / 256;  // GX workgroups per block
     const int jq = (int)blockIdx.x / GX;
     const WgBJob& jb = a.jobs[jq];
     const int e = ((int)blockIdx.x % GX) * 256 + (int)threadIdx.x;
+    const float unscale = a.gscale ? nh_gscale_inv(*a.gscale) : 1.0f;  // (a power of two: exact)
     if (e < E) {
         const int tile = e >> 10, c = (e >> 6) & 15, l = e & 63;
         const int row = 32 * (tile / TB) + (c & 3) + 8 * (c >> 2) + 4 * (l >> 5), col = 32 * (tile % TB) + (l & 31);
@@ -220,7 +244,7 @@ NH_KERNEL void k_wgrad_bf16_reduce(WgBArgs a) {
                 for (int q = 0; q < 8; ++q) s8[q] += src[(size_t)(k + q) * (size_t)a.part_stride];
             }
             for (int q = 0; k < jb.nwg; ++k, ++q) s8[q] += src[(size_t)k * (size_t)a.part_stride];
-            a.g_params[jb.w_off + (int64_t)row * jb.w_ld + col] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+            a.g_params[jb.w_off + (int64_t)row * jb.w_ld + col] = (((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]))) * unscale;
         }
     } else if (e < E + AR) {  // bias: thread t of every workgroup summed row t mod AR
         const int row = e - E;
@@ -238,7 +262,7 @@ NH_KERNEL void k_wgrad_bf16_reduce(WgBArgs a) {
             for (int q = 0; k < jb.nwg; ++k, ++q)
 #pragma unroll
                 for (int t = 0; t < NHW_THREADS; t += AR) s8[q] += src[(size_t)k * (size_t)a.part_stride + t];
-            a.g_params[jb.bias_off + row] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+            a.g_params[jb.bias_off + row] = (((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]))) * unscale;
         }
     }
 }
@@ -312,25 +336,28 @@ int64_t schedule(nerfhip_plan* p, int64_t nt, WgBArgs* full, WgBArgs* half) {
 template <int AR, int BR>
 int launch(WgBArgs& w, nerfhip_stream_t stream) {
     if (w.njobs == 0) return NERFHIP_OK;
-    int rc = w_lds_limit(k_wgrad_bf16x3<AR, BR>, WShape<AR, BR>::LDS_BYTES);
+    int rc = w_lds_limit(NHB_KERNEL(k_wgrad)<AR, BR>, WShape<AR, BR>::LDS_BYTES);
     if (rc) return rc;
     const int wgs = w.jobs[w.njobs - 1].wg0 + w.jobs[w.njobs - 1].nwg;
-    NH_LAUNCH((k_wgrad_bf16x3<AR, BR>), wgs, NHW_THREADS, (WShape<AR, BR>::LDS_BYTES), stream, w);
-    rc = nh_launch_status("wgrad_bf16x3");
+    NH_LAUNCH_NAMED(AR == BR ? "k_wgrad_" NHB_FMT "x3<full>" : "k_wgrad_" NHB_FMT "x3<half>", (NHB_KERNEL(k_wgrad)<AR, BR>), wgs, NHW_THREADS,
+                    (WShape<AR, BR>::LDS_BYTES), stream, w);
+    rc = nh_launch_status("wgrad_" NHB_FMT "x3");
     if (rc) return rc;
-    NH_LAUNCH((k_wgrad_bf16_reduce<AR, BR>), ((AR * BR + AR + 255) / 256) * w.njobs, 256, 0, stream, w);
-    return nh_launch_status("wgrad_bf16_reduce");
+    NH_LAUNCH_NAMED("k_wgrad_" NHB_FMT "_reduce", (NHB_KERNEL(k_wgrad_reduce)<AR, BR>), ((AR * BR + AR + 255) / 256) * w.njobs, 256, 0, stream, w);
+    return nh_launch_status("wgrad_" NHB_FMT "_reduce");
 }
 
 }  // namespace
 
-int64_t nh_wgrad_bf16_partial_floats(nerfhip_plan* p, int64_t nt) {
+#ifndef NHB_F16
+int64_t nh_wgrad_x3_partial_floats(nerfhip_plan* p, int64_t nt) {
     if (p->bjobs.empty()) return 0;
     return schedule(p, nt > 0 ? nt : 1, nullptr, nullptr);
 }
+#endif
 
-int nh_wgrad_bf16(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad, float* partial, float* g_params,
-                  nerfhip_stream_t stream) {
+int NHB_FN(nh_wgrad)(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad, float* partial, float* g_params,
+                     const unsigned* gscale, nerfhip_stream_t stream) {
     if (p->bjobs.empty()) return NERFHIP_OK;
     NH_REQUIRE((int)p->bjobs.size() <= NHW_MAX_JOBS, "wgrad_bf16: too many blocks");
     WgBArgs full, half;
@@ -340,6 +367,7 @@ int nh_wgrad_bf16(nerfhip_plan* p, int64_t nt, const float* stash, const float* 
     full.stash = half.stash = stash;
     full.grad = half.grad = grad;
     full.g_params = half.g_params = g_params;
+    full.gscale = half.gscale = gscale;
     full.partial = partial;
     // (the second launch's partials follow the first's)
     int64_t first = 0;
@@ -350,7 +378,7 @@ int nh_wgrad_bf16(nerfhip_plan* p, int64_t nt, const float* stash, const float* 
         rc = launch<256, 256>(full, stream);
         if (!rc) rc = launch<128, 256>(half, stream);
     } else {
-        nh_set_error("wgrad_bf16: no kernel for kernel width %d", p->W);
+        nh_set_error("wgrad_" NHB_FMT ": no kernel for kernel width %d", p->W);
         return NERFHIP_ERR_UNSUPPORTED;
     }
     return rc;

@@ -215,6 +215,34 @@ class TrainEngine:
                     w.wait()
         self._pending = []
 
+    def collective_times_ms(self, reps=20, warmup=3):
+        """Diagnostic for the first real N-GPU run: what ONE gradient all-reduce of each net costs by itself -- the same
+        buffers, the same process group, nothing else on the device -- as HIP events on the current stream around a
+        synchronous collective (mean of `reps` after `warmup`).  In the step the fine net's all-reduce overlaps the coarse
+        backward, so these are upper bounds of what the exchange adds.  Returns {"fine": ms, "coarse": ms} (None entries
+        when there is no process group); the gradient buffers are restored."""
+        if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            return dict(fine=None, coarse=None)
+        out = {}
+        keep = self.grad.clone()
+        with torch.cuda.device(self.dev):
+            for name, sl in (("fine", self.grad[self.nc_params:]), ("coarse", self.grad[:self.nc_params])):
+                if sl.numel() == 0:
+                    out[name] = None
+                    continue
+                for _ in range(warmup):
+                    allreduce_gradients(sl, self.pg, single_rank=True)
+                torch.cuda.synchronize(self.dev)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(reps):
+                    allreduce_gradients(sl, self.pg, single_rank=True)
+                b.record()
+                torch.cuda.synchronize(self.dev)
+                out[name] = round(a.elapsed_time(b) / reps, 4)
+            self.grad.copy_(keep)
+        return out
+
     def optimizer_step(self, lr=None):
         lib = self.lib
         self.wait_gradients()

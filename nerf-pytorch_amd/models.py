@@ -17,7 +17,11 @@ from .nerf_helpers import frequency_bands_cpu
 
 
 PRECISIONS = {"fp32": L.PRECISION_FP32, "bf16x3": L.PRECISION_BF16X3, "bf16x3_fwd": L.PRECISION_BF16X3_FWD,
-              "bf16x3_fwd_dgrad": L.PRECISION_BF16X3_FWD_DGRAD, "bf16x3_train": L.PRECISION_BF16X3_TRAIN}
+              "bf16x3_fwd_dgrad": L.PRECISION_BF16X3_FWD_DGRAD, "bf16x3_train": L.PRECISION_BF16X3_TRAIN,
+              "f16x3": L.PRECISION_F16X3, "f16x3_fwd": L.PRECISION_F16X3_FWD, "f16x3_fwd_dgrad": L.PRECISION_F16X3_FWD_DGRAD,
+              "f16x3_train": L.PRECISION_F16X3_TRAIN}
+TRAINING_PRECISIONS = ("fp32", "bf16x3_fwd", "bf16x3_fwd_dgrad", "bf16x3_train", "f16x3_fwd", "f16x3_fwd_dgrad", "f16x3_train")
+INFERENCE_PRECISIONS = ("fp32", "bf16x3", "f16x3")
 
 
 class _PlanHandle:
@@ -171,27 +175,30 @@ class FlexibleNeRFModel(torch.nn.Module):
     training_precision = "fp32"
 
     def set_training_precision(self, precision):
-        """Arithmetic of this model's TRAINING forward passes: "fp32" (default: the reference's, what every parity claim
-        and the headline benchmark refer to) or "bf16x3_fwd" (NERFHIP_PRECISION_BF16X3_FWD: the forward -- training and
-        inference alike -- on the split-bf16 kernel, the backward kernels unchanged fp32) or "bf16x3_fwd_dgrad" (the
-        data-gradient chain on it too; the weight-gradient GEMMs stay fp32) or "bf16x3_train" (the large weight-gradient blocks
-        on the bf16 MFMAs as well).  Experiments accepted by PSNR@iters, not by the
-        1e-4 bar: DESIGN.md 7.4-7.5.  Parameters (re-homed into a fresh flat buffer, same Parameter objects), optimizer state
-        and checkpoints are unaffected; call it before a TrainEngine is built on the model."""
-        if precision not in ("fp32", "bf16x3_fwd", "bf16x3_fwd_dgrad", "bf16x3_train"):
-            raise ValueError("training precision must be 'fp32', 'bf16x3_fwd', 'bf16x3_fwd_dgrad' or 'bf16x3_train' (got %r)" % (precision,))
-        _PlanHandle(self.cfg, PRECISIONS[precision])  # (raises for a geometry the bf16x3 kernels do not cover, before anything changes)
+        """Arithmetic of this model's TRAINING passes (and of its inference passes unless set_inference_precision says
+        otherwise): "fp32" (default: the reference's own arithmetic, what the headline benchmark runs) or one of the
+        split-precision plans of include/nerfhip.h -- the same three-MFMA product on two 16-bit pieces per operand:
+          "f16x3_fwd" / "f16x3_fwd_dgrad" / "f16x3_train"   IEEE fp16 pieces: ~3 x 2^-24 per product, fp32-grade (the
+              forward | + the data-gradient chain | + the large weight-gradient blocks on the 16-bit MFMAs);
+          "bf16x3_fwd" / "bf16x3_fwd_dgrad" / "bf16x3_train"  bf16 pieces: ~2^-16 per product (round 3's experiments,
+              accepted by PSNR@iters only: DESIGN.md 7.4-7.6).
+        Parameters (re-homed into a fresh flat buffer, same Parameter objects), optimizer state and checkpoints are
+        unaffected; call it before a TrainEngine is built on the model.  The two nets of a render may use different
+        precisions (plans are per net)."""
+        if precision not in TRAINING_PRECISIONS:
+            raise ValueError("training precision must be one of %s (got %r)" % (TRAINING_PRECISIONS, precision))
+        _PlanHandle(self.cfg, PRECISIONS[precision])  # (raises for a geometry the split-precision kernels do not cover, before anything changes)
         self.training_precision = precision
         self._native_init()
         return self
 
     def set_inference_precision(self, precision):
         """Arithmetic of this model's forward passes that no backward follows (torch.no_grad() / mode="validation"):
-        "fp32" (default: the kernels every parity claim refers to) or "bf16x3" (NERFHIP_PRECISION_BF16X3: split-bf16
-        products on the bf16 MFMAs, ~2^-16 instead of 2^-24 relative error per product, > 2x the inference throughput;
-        include/nerfhip.h).  Training forwards are always fp32.  Raises for geometries the bf16x3 kernels do not cover."""
-        if precision not in PRECISIONS:
-            raise ValueError("inference precision must be one of %s (got %r)" % (sorted(PRECISIONS), precision))
+        "fp32" (default), "f16x3" (NERFHIP_PRECISION_F16X3: fp16 pieces, fp32-grade products, > 2x the inference
+        throughput) or "bf16x3" (bf16 pieces: ~2^-16 per product).  Inference-only plans: the training precisions are
+        set with set_training_precision.  Raises for geometries the split-precision kernels do not cover."""
+        if precision not in INFERENCE_PRECISIONS:
+            raise ValueError("inference precision must be one of %s (got %r)" % (INFERENCE_PRECISIONS, precision))
         owner = _PlanHandle(self.cfg, PRECISIONS[precision]) if precision != "fp32" else None
         self.inference_precision = precision
         self._inf_owner, self._inf_table, self._inf_packed = owner, None, None
@@ -214,6 +221,8 @@ class FlexibleNeRFModel(torch.nn.Module):
             lib.plan_pack_index(plan, host.data_ptr())
             self._inf_table = host.to(dev)
             self._inf_packed = torch.empty(n, dtype=torch.float32, device=dev)
+        # (re-packed on every call, like _packed(): ~30 us against a render chunk's milliseconds.  The parameters are written
+        # behind torch's back -- the fused Adam kernel, views re-homed with .data -- so no version counter can be trusted)
         with L.launch_on(self._flat, self._inf_table, self._inf_packed) as st:
             lib.pack_weights_plan(plan, self._flat.data_ptr(), self._inf_table.data_ptr(), self._inf_packed.data_ptr(), st)
         return self._inf_packed

@@ -87,6 +87,7 @@ NH_DEVICE int nh_shfl_i(int v, int src) { return nh_emu_xchg(v, src & 63); }
 NH_DEVICE float nh_shfl_up(float v, int d) { return nh_emu_xchg(v, emu::cur->lane - d); }
 NH_DEVICE float nh_shfl_down(float v, int d) { return nh_emu_xchg(v, emu::cur->lane + d); }
 NH_DEVICE float nh_shfl_xor(float v, int m) { return nh_emu_xchg(v, emu::cur->lane ^ m); }
+NH_DEVICE int nh_shfl_xor_i(int v, int m) { return nh_emu_xchg(v, emu::cur->lane ^ m); }
 NH_DEVICE double nh_shfl_d(double v, int src) { return nh_emu_xchg(v, src & 63); }
 NH_DEVICE double nh_shfl_up_d(double v, int d) { return nh_emu_xchg(v, emu::cur->lane - d); }
 NH_DEVICE double nh_shfl_down_d(double v, int d) { return nh_emu_xchg(v, emu::cur->lane + d); }
@@ -201,7 +202,77 @@ NH_DEVICE f32x16 nh_mfma_bf16(nh_bf16x8 a, nh_bf16x8 b, f32x16 c) {
     return d;
 }
 
+// IEEE fp16 pieces (mlp_f16.hip): software round-to-nearest-even conversion incl. subnormals; the MFMA as nh_mfma_bf16
+struct nh_f16 {
+    uint16_t bits;
+};
+struct nh_f16x8 {
+    nh_f16 v[8];
+    nh_f16& operator[](int i) { return v[i]; }
+    const nh_f16& operator[](int i) const { return v[i]; }
+};
+NH_DEVICE float nh_from_f16(nh_f16 h) {
+    const uint32_t sign = (uint32_t)(h.bits & 0x8000u) << 16, ex = (h.bits >> 10) & 31u, man = h.bits & 1023u;
+    float f;
+    if (ex == 31u) {
+        const uint32_t u = sign | 0x7f800000u | (man << 13);
+        memcpy(&f, &u, 4);
+        return f;
+    }
+    if (ex == 0u) {
+        f = ldexpf((float)man, -24);
+        return sign ? -f : f;
+    }
+    const uint32_t u = sign | ((ex + 112u) << 23) | (man << 13);
+    memcpy(&f, &u, 4);
+    return f;
+}
+NH_DEVICE nh_f16 nh_to_f16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+    const uint32_t a = u & 0x7fffffffu;
+    if (a > 0x7f800000u) return nh_f16{(uint16_t)(sign | 0x7e00u)};
+    if (a >= 0x47800000u) return nh_f16{(uint16_t)(sign | 0x7c00u)};  // >= 65536: inf (65520..65536 handled by the rounding below)
+    float af;
+    memcpy(&af, &a, 4);
+    if (a < 0x38800000u) {  // below 2^-14: a multiple of 2^-24, round-to-nearest-even (nearbyintf under the default mode)
+        const float q = nearbyintf(ldexpf(af, 24));
+        return nh_f16{(uint16_t)(sign | (uint16_t)q)};   // (q == 1024 is the smallest normal: the bit pattern carries over)
+    }
+    uint32_t r = a + 0xfffu + ((a >> 13) & 1u);  // round the 13 dropped bits to nearest even
+    const uint32_t ex = (r >> 23) - 112u, man = (r >> 13) & 1023u;
+    if (ex >= 31u) return nh_f16{(uint16_t)(sign | 0x7c00u)};
+    return nh_f16{(uint16_t)(sign | (ex << 10) | man)};
+}
+NH_DEVICE f32x16 nh_mfma_f16(nh_f16x8 a, nh_f16x8 b, f32x16 c) {
+    emu::WaveState& w = emu::cur_wave();
+    const int lane = emu::cur->lane, j = lane & 31, h = lane >> 5;
+    f32x16 d = c;
+    for (int part = 0; part < 2; ++part) {
+        int ph = emu::cur->xphase;
+        emu::cur->xphase ^= 1;
+        memcpy(&w.xa[ph][lane], &a.v[4 * part], 8);
+        memcpy(&w.xb[ph][lane], &b.v[4 * part], 8);
+        emu::wave_barrier();
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+            float acc = d[r];
+            for (int hh = 0; hh < 2; ++hh)
+                for (int e = 0; e < 4; ++e) {
+                    nh_f16 av[4], bv[4];
+                    memcpy(av, &w.xa[ph][i + 32 * hh], 8);
+                    memcpy(bv, &w.xb[ph][j + 32 * hh], 8);
+                    acc = fmaf(nh_from_f16(av[e]), nh_from_f16(bv[e]), acc);
+                }
+            d[r] = acc;
+        }
+    }
+    return d;
+}
+
 NH_DEVICE void nh_atomic_add(float* p, float v) { *p += v; }
+NH_DEVICE void nh_atomic_max_u32(unsigned* p, unsigned v) { if (v > *p) *p = v; }
 NH_DEVICE void nh_glds16(const float* g, float* lds_wave_base) { memcpy(lds_wave_base + 4 * emu::cur->lane, g, 16); }
 struct NhDmaSrc {
     const char* base;

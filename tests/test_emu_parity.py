@@ -118,6 +118,28 @@ def test_mlp_bf16x3_whole_training_step(emu):
                             tol=5e-4, grad_tol=(5e-3, 5e-2), precision=P.BF16X3_TRAIN)
 
 
+# ---- the same plans on IEEE fp16 pieces (NERFHIP_PRECISION_F16X3*): held to the fp32 kernels' own bounds -----------------------
+def test_mlp_forward_f16x3(emu):
+    """The inference forward on fp16 pieces: ~3 x 2^-24 per product -- the fp32 kernels' 2e-5 bound and an fp32-sized distance
+    from the fp64 forward, every layer kind, both widths, the persistent loop."""
+    P.case_mlp_forward_bf16x3(emu, m=37, precision=P.F16X3)
+    P.case_mlp_forward_bf16x3(emu, names=("default4x128",), m=900, precision=P.F16X3)
+    P.case_render_bf16x3(emu, P.MLP_GEOMETRIES["default4x128"], n=10, nc=8, nf=8, tag="4x128_emu", precision=P.F16X3)
+
+
+def test_mlp_f16x3_training_levels_hold_the_fp32_gradient_bounds(emu):
+    """F16X3_FWD / _FWD_DGRAD / _TRAIN: parameter and input gradients within the fp32 kernels' 2e-5 of max|g| (same ReLU margin,
+    same row counts), the fused render with gradients at the fp32 tolerances; the data-gradient chain runs on d(raw output) times
+    a power of two taken from its maximum (tiny cotangents: the fp16 pieces would otherwise flush them)."""
+    P.case_mlp_backward(emu, names=("default4x128", "skip_every_layer_256"), m=120, precision=P.F16X3_FWD)
+    P.case_mlp_backward(emu, names=("fern8x128_skip3_L6", "novw4x128", "one_layer"), m=120, precision=P.F16X3_FWD_DGRAD)
+    P.case_mlp_backward(emu, names=("skip_every_layer_256", "one_layer_novw_256"), m=120, precision=P.F16X3_TRAIN)
+    P.case_mlp_backward(emu, names=("default4x128",), m=100, precision=P.F16X3_FWD_DGRAD, g_scale=3e-7)
+    P.case_mlp_input_grad(emu, names=("default4x128", "novw4x128"), m=45, precision=P.F16X3_FWD_DGRAD)
+    P.case_render_vs_oracle(emu, P.MLP_GEOMETRIES["default4x128"], n=12, nc=16, nf=16, with_grads=True, tag="f16x3_train_emu",
+                            precision=P.F16X3_FWD_DGRAD)
+
+
 def test_ndc_rays_backward(emu):
     P.case_ndc_rays_bwd(emu, n=200)
 

@@ -88,7 +88,7 @@ def test_two_stream_step_equals_single_stream_step():
     assert float(out[0][2][-1, 2]) < float(out[0][2][0, 2])
 
 
-@pytest.mark.parametrize("precision", ["bf16x3_fwd", "bf16x3_fwd_dgrad", "bf16x3_train"])
+@pytest.mark.parametrize("precision", ["bf16x3_fwd", "bf16x3_fwd_dgrad", "bf16x3_train", "f16x3_fwd", "f16x3_fwd_dgrad", "f16x3_train"])
 def test_engine_on_split_bf16_training_precisions_tracks_the_fp32_engine(precision):
     """set_training_precision (NERFHIP_PRECISION_BF16X3_FWD / _FWD_DGRAD; opt-in): the same engine, the same
     in-kernel draws, the forward (and the data-gradient chain) on the split-bf16 kernels.  One forward/backward: the loss

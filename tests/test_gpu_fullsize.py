@@ -142,6 +142,41 @@ class _Case:
         self.gpu.lib.plan_destroy(self.plan_f)
 
 
+# The arithmetic of the two nets' plans (include/nerfhip.h NERFHIP_PRECISION_*).  Every full-batch test runs with the SAME
+# assertions for each entry: "fp32" (the reference's arithmetic), "f16x3_train" (every GEMM of the step on fp16 pieces), and --
+# end-to-end lego only -- "fp32+bf16x3" (coarse net fp32, so that the sampler sees fp32 weights, fine net
+# on the bf16-piece forward + data-gradient kernels).
+ARITH = {"fp32": (0, 0), "f16x3_train": (P.F16X3_TRAIN, P.F16X3_TRAIN), "fp32+bf16x3": (0, P.BF16X3_FWD_DGRAD)}
+INFER = {"fp32": 0, "f16x3": P.F16X3}
+
+
+class _Plans:
+    """Plans + packed images of a case's two nets in one arithmetic (the case's own fp32 plans are reused for "fp32")."""
+
+    def __init__(self, c, arith):
+        self.c, self.arith = c, arith
+        pc_, pf_ = ARITH[arith]
+        gpu = c.gpu
+        self.own = []
+        if pc_ == 0:
+            self.plan_c, self.packed_c = c.plan_c, c.packed_c
+        else:
+            self.plan_c = gpu.make_plan(c.cfg, pc_)
+            self.packed_c = gpu.pack(self.plan_c, gpu.flatten_params(self.plan_c, {k: v.detach().numpy() for k, v in c.par_c.items()}))
+            self.own.append(self.plan_c)
+        if pf_ == 0:
+            self.plan_f, self.packed_f = c.plan_f, c.packed_f
+        else:
+            self.plan_f = gpu.make_plan(c.cfg, pf_)
+            self.packed_f = gpu.pack(self.plan_f, gpu.flatten_params(self.plan_f, {k: v.detach().numpy() for k, v in c.par_f.items()}))
+            self.own.append(self.plan_f)
+        self.tag = "" if arith == "fp32" else "_" + arith
+
+    def close(self):
+        for pl in self.own:
+            self.c.gpu.lib.plan_destroy(pl)
+
+
 @pytest.fixture(scope="module")
 def lego(gpu):
     n = _batch_size(6.0e6)
@@ -176,12 +211,20 @@ def lego_padded_nets(gpu):
     c.close()
 
 
-def _end_to_end(c, coarse_grad_tol, fine_grad_tol, rgb_fine_tol=(1e-4, 1e-4)):
+def _end_to_end(c, coarse_grad_tol, fine_grad_tol, rgb_fine_tol=(1e-4, 1e-4), arith="fp32"):
+    pl = _Plans(c, arith)
+    try:
+        return _end_to_end_on(c, pl, coarse_grad_tol, fine_grad_tol, rgb_fine_tol)
+    finally:
+        pl.close()
+
+
+def _end_to_end_on(c, pl, coarse_grad_tol, fine_grad_tol, rgb_fine_tol):
     gpu = c.gpu
-    out = gpu.render(c.plan_c, c.plan_f, c.packed_c, c.packed_f, c.rays.numpy(), c.opt, c.rnp, training=True,
+    out = gpu.render(pl.plan_c, pl.plan_f, pl.packed_c, pl.packed_f, c.rays.numpy(), c.opt, c.rnp, training=True,
                      want_regions=("z_fine",))
     l3, gc, gf = gpu.mse_loss(out["rgb_coarse"], out["rgb_fine"], c.tgt.numpy())
-    out2 = gpu.render(c.plan_c, c.plan_f, c.packed_c, c.packed_f, c.rays.numpy(), c.opt, c.rnp, training=True, g_rgb=(gc, gf))
+    out2 = gpu.render(pl.plan_c, pl.plan_f, pl.packed_c, pl.packed_f, c.rays.numpy(), c.opt, c.rnp, training=True, g_rgb=(gc, gf))
     w = {k: v.detach().numpy() for k, v in c.want.items() if v is not None}
     rec = dict(rays=c.n, samples="%d+%d" % (c.nc, c.nf), oracle_seconds=round(c.oracle_seconds, 1),
                oracle_threads=torch.get_num_threads(), outputs={}, loss=dict(gpu=float(l3[2]), oracle=float(c.loss.detach())))
@@ -199,12 +242,13 @@ def _end_to_end(c, coarse_grad_tol, fine_grad_tol, rgb_fine_tol=(1e-4, 1e-4)):
     for k in fine_keys:
         rec["outputs"][k]["rays_over_1e4"] = _over(out[k], w[k])
     rec["z_fine_vs_oracle"] = dict(hip=_moved(out["z_fine"], w["z_fine"], span), torch_cuda=_moved(yard["z_fine"], w["z_fine"], span))
-    gcw, gcp = _grad_stats(gpu.unflatten(c.plan_c, out2["g_params_coarse"]), c.ref_gc)
-    gfw, gfp = _grad_stats(gpu.unflatten(c.plan_f, out2["g_params_fine"]), c.ref_gf)
+    gcw, gcp = _grad_stats(gpu.unflatten(pl.plan_c, out2["g_params_coarse"]), c.ref_gc)
+    gfw, gfp = _grad_stats(gpu.unflatten(pl.plan_f, out2["g_params_fine"]), c.ref_gf)
     rec["grad_coarse_worst_rel"] = gcw
     rec["grad_fine_worst_rel"] = gfw
     rec["grad_fine_per_tensor"] = gfp
-    _record(c.name, rec)
+    rec["arithmetic"] = pl.arith
+    _record(c.name + pl.tag, rec)
     # coarse pass: fp32 round-off only
     for k in ("rgb_coarse", "acc_coarse", "depth_coarse"):
         assert rec["outputs"][k]["max"] <= 1e-5, (k, rec["outputs"][k])
@@ -226,17 +270,19 @@ def _end_to_end(c, coarse_grad_tol, fine_grad_tol, rgb_fine_tol=(1e-4, 1e-4)):
     return rec
 
 
-def test_lego_full_batch_every_ray_vs_oracle(lego):
+@pytest.mark.parametrize("arith", ["fp32", "f16x3_train", "fp32+bf16x3"])
+def test_lego_full_batch_every_ray_vs_oracle(lego, arith):
     """BASELINE configs[1]: outputs of all rays and all 2 x 595,844 gradient entries against the oracle.
     Measured on MI355X (profiles/r02_parity_fullsize.json): rgb_fine max 7.9e-5 / p99.9 4.7e-5; coarse-net gradients
     max 1.4e-4 / p99.9 3.6e-5 of max|g| (two fp32 sums of 262,144 terms in different orders); fine-net gradients max
     6.5e-4 / p99.9 3.6e-4 (behind the sampler)."""
-    _end_to_end(lego, coarse_grad_tol=(2e-4, 5e-5), fine_grad_tol=(3e-3, 1e-3))
+    _end_to_end(lego, coarse_grad_tol=(2e-4, 5e-5), fine_grad_tol=(3e-3, 1e-3), arith=arith)
 
 
-def test_lego_default_4x128_nets_full_batch_vs_oracle(lego_default_nets):
+@pytest.mark.parametrize("arith", ["fp32", "f16x3_train"])
+def test_lego_default_4x128_nets_full_batch_vs_oracle(lego_default_nets, arith):
     """Measured (profiles/r02_parity_fullsize.json): coarse-net gradients 2.0e-5 / 1.0e-5, fine-net 2.6e-4 / 1.9e-4."""
-    _end_to_end(lego_default_nets, coarse_grad_tol=(1e-4, 5e-5), fine_grad_tol=(1.3e-3, 9e-4))
+    _end_to_end(lego_default_nets, coarse_grad_tol=(1e-4, 5e-5), fine_grad_tol=(1.3e-3, 9e-4), arith=arith)
 
 
 def test_lego_padded_hidden_size_batch_vs_oracle(lego_padded_nets):
@@ -251,14 +297,15 @@ def test_lego_padded_hidden_size_teacher_forced_fine_pass(lego_padded_nets):
     _teacher_forced(lego_padded_nets)
 
 
-def test_fern_full_batch_every_ray_vs_oracle(fern):
+@pytest.mark.parametrize("arith", ["fp32", "f16x3_train"])
+def test_fern_full_batch_every_ray_vs_oracle(fern, arith):
     """BASELINE configs[3] (NDC, Dx = 39, 64 + 64, noise 1.0): with sigma noise of std 1.0 the per-sample cotangents of
     the early layers nearly cancel (case_render_vs_oracle).  Measured (profiles/r02_parity_fullsize.json): coarse-net
     gradients max 3.5e-6 / p99.9 3.4e-6 of max|g|, fine-net 3.2e-5 / 1.8e-5: the bounds are 5x those."""
-    _end_to_end(fern, coarse_grad_tol=(1.75e-5, 1.75e-5), fine_grad_tol=(1.6e-4, 9e-5))
+    _end_to_end(fern, coarse_grad_tol=(1.75e-5, 1.75e-5), fine_grad_tol=(1.6e-4, 9e-5), arith=arith)
 
 
-def _fine_pass_units(c, sel, z, tgt):
+def _fine_pass_units(c, sel, z, tgt, pl=None):
     """The fine pass of rays `sel` with given depths through the unit entry points of the C ABI: MLP forward on
     host-encoded points (writes the stash) -> compositing -> compositing backward -> MLP backward."""
     gpu, cfg = c.gpu, c.cfg
@@ -269,14 +316,15 @@ def _fine_pass_units(c, sel, z, tgt):
     emb = O.positional_encoding(pts, cfg["num_encoding_fn_xyz"], True, True)
     dirs = rays[..., None, -3:].expand(n, s, 3).reshape(-1, 3)
     x = torch.cat((emb, O.positional_encoding(dirs, cfg["num_encoding_fn_dir"], True, True)), dim=-1).numpy()
-    raw, stash = gpu.mlp_fwd(c.plan_f, c.packed_f, x, want_stash=True)
+    plan_f, packed_f = (pl.plan_f, pl.packed_f) if pl is not None else (c.plan_f, c.packed_f)
+    raw, stash = gpu.mlp_fwd(plan_f, packed_f, x, want_stash=True)
     noise = c.rnp["noise_fine"][sel]
     rgb, disp, acc, w, dep = gpu.volume_render_fwd(raw.reshape(n, s, 4), z.numpy(), rd.numpy(), c.opt["noise_std"], noise)
     g_rgb = ((2.0 / (3.0 * n)) * (rgb - tgt.numpy())).astype(np.float32)  # d mse_loss / d rgb  (train_nerf.py:250-258)
     g_raw = gpu.volume_render_bwd(raw.reshape(n, s, 4), z.numpy(), rd.numpy(), g_rgb=g_rgb, noise_std=c.opt["noise_std"],
                                   noise=noise)
-    gflat = gpu.mlp_bwd(c.plan_f, c.packed_f, g_raw.reshape(-1, 4), stash)
-    return raw, rgb, acc, gpu.unflatten(c.plan_f, gflat), dep, disp
+    gflat = gpu.mlp_bwd(plan_f, packed_f, g_raw.reshape(-1, 4), stash)
+    return raw, rgb, acc, gpu.unflatten(plan_f, gflat), dep, disp
 
 
 def _oracle_fine_grads(c, sel, z, tgt, dtype):
@@ -291,7 +339,15 @@ def _oracle_fine_grads(c, sel, z, tgt, dtype):
     return {k: v.grad.numpy() for k, v in par.items()}
 
 
-def _teacher_forced(c):
+def _teacher_forced(c, arith="fp32"):
+    pl = _Plans(c, arith)
+    try:
+        return _teacher_forced_on(c, pl)
+    finally:
+        pl.close()
+
+
+def _teacher_forced_on(c, pl):
     """The fine pass with the ORACLE's depths (no sampler between the two sides).  Full batch against the oracle's fp32
     gradients, then a 256-ray slice against an fp64 run of the oracle: the kernels must sit at the fp32 floor, i.e. no
     further from fp64 than torch's own fp32 path is.  (What remains between two fp32 implementations is not only the
@@ -300,7 +356,7 @@ def _teacher_forced(c):
     paths are 2.6e-3 of max|g| away from fp64 in the SAME entry -- hence quantiles, not maxima, on the slice.)"""
     n = c.n
     z = c.want["z_fine"].detach()
-    raw, rgb, acc, grads, dep, disp = _fine_pass_units(c, slice(0, n), z, c.tgt)
+    raw, rgb, acc, grads, dep, disp = _fine_pass_units(c, slice(0, n), z, c.tgt, pl)
     far = float(c.rays[:, 7].max())
     wd = c.want["disp_fine"].detach().numpy()
     assert np.array_equal(np.isnan(disp), np.isnan(wd)), "disparity NaN masks differ (volume_rendering_utils.py:48)"
@@ -315,14 +371,15 @@ def _teacher_forced(c):
     rec["grad_fine_per_tensor"] = per
     m = 256
     sel = slice(0, m)
-    g_hip = _fine_pass_units(c, sel, z[sel], c.tgt[sel])[3]
+    g_hip = _fine_pass_units(c, sel, z[sel], c.tgt[sel], pl)[3]
     g32 = _oracle_fine_grads(c, sel, z[sel], c.tgt[sel], torch.float32)
     g64 = _oracle_fine_grads(c, sel, z[sel], c.tgt[sel], torch.float64)
     rec["slice_rays"] = m
     rec["slice_hip_vs_fp64"] = _grad_stats(g_hip, g64)[0]
     rec["slice_torch_fp32_vs_fp64"] = _grad_stats(g32, g64)[0]
     rec["slice_hip_vs_torch_fp32"] = _grad_stats(g_hip, g32)[0]
-    _record(c.name + "_teacher_forced", rec)
+    rec["arithmetic"] = pl.arith
+    _record(c.name + "_teacher_forced" + pl.tag, rec)
     assert rec["raw"]["max"] <= 1e-6, rec["raw"]
     assert rec["rgb_fine"]["max"] <= 2e-6 and rec["acc_fine"]["max"] <= 2e-6, rec
     # depth = sum w z (volume_rendering_utils.py:44) and disparity (:46-48) on the SAME depths: fp32 round-off only
@@ -334,12 +391,14 @@ def _teacher_forced(c):
     assert rec["slice_hip_vs_fp64"]["max"] <= 1.5 * rec["slice_torch_fp32_vs_fp64"]["max"] + 1e-4, rec
 
 
-def test_lego_teacher_forced_fine_pass(lego):
-    _teacher_forced(lego)
+@pytest.mark.parametrize("arith", ["fp32", "f16x3_train"])
+def test_lego_teacher_forced_fine_pass(lego, arith):
+    _teacher_forced(lego, arith)
 
 
-def test_fern_teacher_forced_fine_pass(fern):
-    _teacher_forced(fern)
+@pytest.mark.parametrize("arith", ["fp32", "f16x3_train"])
+def test_fern_teacher_forced_fine_pass(fern, arith):
+    _teacher_forced(fern, arith)
 
 
 # ---- BASELINE configs[0]: tiny_nerf.py (100x100, 32 samples, coarse only, 6 frequencies, no view directions) ---------------
@@ -440,9 +499,10 @@ class _EvalCase:
     forward only: the inference instantiation of the MLP kernel (no stash) against the oracle, next to the reference's
     own GPU path (the oracle's torch ops on cuda) as the yardstick."""
 
-    def __init__(self, gpu, name, cfg, params_c, params_f, nc, nf, white, n=16384):
+    def __init__(self, gpu, name, cfg, params_c, params_f, nc, nf, white, n=16384, infer="fp32"):
         import math
-        self.gpu, self.name, self.cfg, self.nc, self.nf = gpu, name, cfg, nc, nf
+        self.gpu, self.name, self.cfg, self.nc, self.nf = gpu, name + ("" if infer == "fp32" else "_" + infer), cfg, nc, nf
+        self.infer = infer
         torch.set_num_threads(min(32, os.cpu_count() or 1))
         H = W = 800
         focal = 0.5 * W / math.tan(0.5 * 0.6911112070083618)
@@ -461,7 +521,7 @@ class _EvalCase:
         self.opt = dict(num_coarse=nc, num_fine=nf, perturb=False, lindisp=False, white_background=white, noise_std=0.0)
         self.rand = {}
         self.par_c, self.par_f = params_c, params_f
-        self.plan_c, self.plan_f = gpu.make_plan(cfg), gpu.make_plan(cfg)
+        self.plan_c, self.plan_f = gpu.make_plan(cfg, INFER[infer]), gpu.make_plan(cfg, INFER[infer])
         self.packed_c = gpu.pack(self.plan_c, gpu.flatten_params(self.plan_c, {k: v.numpy() for k, v in params_c.items()}))
         self.packed_f = gpu.pack(self.plan_f, gpu.flatten_params(self.plan_f, {k: v.numpy() for k, v in params_f.items()}))
         t0 = time.perf_counter()
@@ -511,8 +571,10 @@ def _eval_parity(c):
     rec = dict(rays=c.n, image="800x800", samples="%d+%d" % (c.nc, c.nf), oracle_seconds=round(c.oracle_seconds, 1),
                hip_vs_cpu={k: dict(_stats(out[k], w[k]), rays_over_1e4=_over(out[k], w[k])) for k in keys},
                torch_cuda_vs_cpu={k: dict(_stats(yard[k], w[k]), rays_over_1e4=_over(yard[k], w[k])) for k in keys},
-               z_fine_vs_oracle=dict(hip=_moved(out["z_fine"], w["z_fine"], span), torch_cuda=_moved(yard["z_fine"], w["z_fine"], span)))
-    _bf16x3_arm(c, w, keys, rec, span)
+               z_fine_vs_oracle=dict(hip=_moved(out["z_fine"], w["z_fine"], span), torch_cuda=_moved(yard["z_fine"], w["z_fine"], span)),
+               arithmetic=c.infer)
+    if c.infer == "fp32":
+        _bf16x3_arm(c, w, keys, rec, span)
     for k in ("disp_coarse", "disp_fine"):  # NaN where acc == 0 (volume_rendering_utils.py:48): same pixels
         assert np.array_equal(np.isnan(out[k]), np.isnan(w[k])), k
     rec["nan_disparity_pixels"] = int(np.isnan(w["disp_fine"]).sum())
@@ -563,12 +625,14 @@ def _scene_params(cfg, seed, smooth, gain=2.45, head_gain=4.0, sigma_shift=-2.0)
     return p
 
 
+@pytest.mark.parametrize("infer", ["fp32", "f16x3"])
 @pytest.mark.parametrize("smooth", [True, False], ids=["smooth_scene", "rough_scene"])
-def test_eval_800x800_northstar_nets_inference_vs_oracle(gpu, smooth):
-    """Config 5 with the north-star geometry (8x256, 64 + 128): synthetic scene nets (_scene_params)."""
+def test_eval_800x800_northstar_nets_inference_vs_oracle(gpu, smooth, infer):
+    """Config 5 with the north-star geometry (8x256, 64 + 128): synthetic scene nets (_scene_params).  infer: the plans'
+    arithmetic -- the fp32 kernels, or the inference kernels on fp16 pieces under the SAME assertions."""
     cfg = P.MLP_GEOMETRIES["northstar8x256"]
     c = _EvalCase(gpu, "eval800_8x256_64+128_%s" % ("smooth" if smooth else "rough"), cfg, _scene_params(cfg, 505, smooth),
-                  _scene_params(cfg, 502, smooth), 64, 128, False)
+                  _scene_params(cfg, 502, smooth), 64, 128, False, infer=infer)
     try:
         rec = _eval_parity(c)
     finally:
@@ -583,7 +647,8 @@ def test_eval_800x800_northstar_nets_inference_vs_oracle(gpu, smooth):
         assert err["p999"] <= 1.5e-4 and err["rays_over_1e4"] <= 0.0025 * c.n, err
 
 
-def test_eval_800x800_pretrained_lego_nets_inference_vs_oracle(gpu):
+@pytest.mark.parametrize("infer", ["fp32", "f16x3"])
+def test_eval_800x800_pretrained_lego_nets_inference_vs_oracle(gpu, infer):
     """Config 5 with TRAINED weights: the reference's pretrained lego-lowres nets (4x128, white background, 64 + 64 --
     pretrained/lego-lowres/config.yml) at 800x800: sharp surfaces and empty space, the sampler's worst case."""
     from conftest import gold
@@ -591,7 +656,7 @@ def test_eval_800x800_pretrained_lego_nets_inference_vs_oracle(gpu):
     cfg = P.MLP_GEOMETRIES["default4x128"]
     pc = {k[2:]: torch.from_numpy(wts[k]) for k in wts.files if k.startswith("c_")}
     pf = {k[2:]: torch.from_numpy(wts[k]) for k in wts.files if k.startswith("f_")}
-    c = _EvalCase(gpu, "eval800_pretrained_4x128_64+64", cfg, pc, pf, 64, 64, True)
+    c = _EvalCase(gpu, "eval800_pretrained_4x128_64+64", cfg, pc, pf, 64, 64, True, infer=infer)
     try:
         rec = _eval_parity_trained(c)
     finally:
@@ -612,8 +677,9 @@ def _eval_parity_trained(c):
                hip_vs_cpu={k: dict(_stats(out[k], w[k]), rays_over_1e4=_over(out[k], w[k])) for k in keys},
                torch_cuda_vs_cpu={k: dict(_stats(yard[k], w[k]), rays_over_1e4=_over(yard[k], w[k])) for k in keys},
                z_fine_vs_oracle=dict(hip=_moved(out["z_fine"], w["z_fine"], 4.0), torch_cuda=_moved(yard["z_fine"], w["z_fine"], 4.0)),
-               rays_hitting_the_object=int((w["acc_fine"] > 0.5).sum()))
-    _bf16x3_arm(c, w, keys, rec, 4.0)
+               rays_hitting_the_object=int((w["acc_fine"] > 0.5).sum()), arithmetic=c.infer)
+    if c.infer == "fp32":
+        _bf16x3_arm(c, w, keys, rec, 4.0)
     _record(c.name, rec)
     h, y = rec["hip_vs_cpu"], rec["torch_cuda_vs_cpu"]
     for k in ("rgb_coarse", "acc_coarse"):

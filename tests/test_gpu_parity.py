@@ -117,6 +117,41 @@ def test_mlp_bf16x3_whole_training_step(gpu):
                             tol=5e-4, grad_tol=(5e-3, 5e-2), precision=P.BF16X3_TRAIN)
 
 
+# ---- the same plans on IEEE fp16 pieces (NERFHIP_PRECISION_F16X3*): the fp32 kernels' own bounds, unchanged -------------------
+def test_mlp_forward_f16x3(gpu):
+    """Twelve geometries: within the fp32 kernels' 2e-5 of the oracle and at an fp32-sized distance from the fp64 forward; the
+    fused inference render: coarse maps at 1e-5, the fine pass no further from the oracle than the fp32 kernels' own."""
+    P.case_mlp_forward_bf16x3(gpu, m=3000, precision=P.F16X3)
+    P.case_render_bf16x3(gpu, P.MLP_GEOMETRIES["default4x128"], n=300, nc=64, nf=64, tag="4x128_300", precision=P.F16X3)
+    P.case_render_bf16x3(gpu, P.MLP_GEOMETRIES["northstar8x256"], n=128, nc=64, nf=128, tag="8x256_128", precision=P.F16X3)
+
+
+@pytest.mark.parametrize("level", ["fwd", "fwd_dgrad", "train"])
+def test_mlp_f16x3_training_levels_hold_the_fp32_gradient_bounds(gpu, level):
+    """case_mlp_backward / case_mlp_input_grad / case_render_vs_oracle exactly as the fp32 kernels run them (test_mlp_backward,
+    test_render_northstar_geometry): 2e-5 of max|g| teacher-forced at m = 1500 with the 1e-6 ReLU margin, default render bounds."""
+    prec = {"fwd": P.F16X3_FWD, "fwd_dgrad": P.F16X3_FWD_DGRAD, "train": P.F16X3_TRAIN}[level]
+    P.case_mlp_backward(gpu, names=("default4x128", "fern8x128_skip3_L6", "novw4x128", "skip_every_layer_256", "odd5x99_skip2",
+                                    "one_layer", "two_layer_L4_L2", "northstar8x256"), m=1500, precision=prec)
+    if level != "fwd":
+        P.case_mlp_backward(gpu, names=("default4x128", "northstar8x256"), m=1500, precision=prec, g_scale=2e-8)  # (the chain's scale)
+        P.case_mlp_input_grad(gpu, names=("default4x128", "novw4x128", "northstar8x256"), m=1500, precision=prec)
+    P.case_render_vs_oracle(gpu, P.MLP_GEOMETRIES["northstar8x256"], n=48, nc=64, nf=128, with_grads=True, tag="f16x3_%s_8x256_48" % level,
+                            grad_tol=(3.4e-3, 5.6e-3), precision=prec)  # (test_northstar_render_and_gradients_vs_oracle's bounds)
+    P.case_render_vs_oracle(gpu, P.MLP_GEOMETRIES["default4x128"], n=200, nc=64, nf=64, white=True, noise=1.0, with_grads=True,
+                            tag="f16x3_%s_default200_white_noise1" % level, grad_tol=(1e-5, 5.5e-3), precision=prec)  # (test_default_model_render_white_background's)
+
+
+@pytest.mark.parametrize("name", ["e2e_a.npz", "e2e_b.npz", "e2e_c.npz", "e2e_d.npz", "e2e_northstar.npz"])
+def test_e2e_reference_goldens_f16x3_train(gpu, name):
+    """The goldens recorded from the REAL reference (outputs, loss, every gradient tensor), every kernel of the step on fp16 pieces:
+    the same assertions as test_e2e_reference_goldens / test_e2e_northstar_reference_golden."""
+    if name == "e2e_northstar.npz":
+        P.case_e2e_northstar_golden(gpu, precision=P.F16X3_TRAIN)
+    else:
+        P.case_e2e_golden(gpu, name, precision=P.F16X3_TRAIN)
+
+
 def test_ndc_rays_backward(gpu):
     P.case_ndc_rays_bwd(gpu, n=5000)
 

@@ -18,9 +18,18 @@
 // ---- the piece format of this translation unit ------------------------------------------------------------------------------------
 // The file is compiled twice: as is (bf16 pieces: the bf16x3 plans) and through mlp_f16.hip with NHB_F16 defined (IEEE fp16 pieces:
 // the f16x3 plans, include/nerfhip.h).  Same loops, same images, same register layouts; what differs is the conversion, the MFMA,
-// and -- fp16's 5-bit exponent -- two scalings: the packed weights and biases carry NHB_WS = 2^8 (k_pack_*: a weight's low piece
-// is then a normal fp16 number down to |w| = 2^-10) and every gemm's accumulators are multiplied by 1 / NHB_WS on the way out; the
-// data-gradient chain runs on d(raw output) times a power of two picked per launch from max|d(raw output)| (DgradBArgs::gscale).
+// and -- fp16's 5-bit exponent, [2^-14, 2^16) with the low piece 2^-12 below the value -- block-floating-point bookkeeping, all in
+// exact powers of two:
+//   * packed weights (and biases) carry NHB_WS = 2^8: a weight's low piece is a normal fp16 number down to |w| = 2^-10;
+//   * forward: every SAMPLE carries the exponent S of its current activations -- the operand pieces are those of h * 2^S, with S
+//     chosen by the epilogue that produced h so that the sample's largest activation lands in [2^13, 2^14): no activation range is
+//     out of reach and small activations keep both pieces (fp32-like relative precision).  A gemm starts its accumulators at
+//     bias * 2^S, so they hold WS * 2^S * pre-activation; the epilogue finds the sample's maximum (one cross-half exchange), turns
+//     it into the next S and applies the difference as the one multiply the weight scale costs anyway.  Encodings carry an exponent
+//     of their own (from the sample's coordinates); a layer that reads both caps S at it and rescales the encoding pieces on the
+//     fly (v_pk_mul_f16).  Raw outputs and stash rows are brought back to plain fp32 values on the way out;
+//   * data gradient: the chain of a sample runs on its d(raw output) times a power of two of its own (nh_device.h), and the images
+//     it stores carry ONE power of two per launch (DgradBArgs::gscale), divided out by the weight-gradient reduction.
 #ifdef NHB_F16
 typedef nh_f16 nh_pc;
 typedef nh_f16x8 nh_pcx8;
@@ -31,6 +40,8 @@ typedef nh_f16x8 nh_pcx8;
 #define NHB_FN(stem) stem##_f16
 #define NHB_KERNEL(stem) stem##_f16x3
 constexpr float NHB_WS = NHB_F16_WSCALE;
+constexpr int NHB_WS_LOG2 = 8;
+constexpr bool NHB_IS_F16 = true;
 #else
 typedef nh_bf16 nh_pc;
 typedef nh_bf16x8 nh_pcx8;
@@ -41,10 +52,15 @@ typedef nh_bf16x8 nh_pcx8;
 #define NHB_FN(stem) stem##_bf16
 #define NHB_KERNEL(stem) stem##_bf16x3
 constexpr float NHB_WS = 1.0f;
+constexpr int NHB_WS_LOG2 = 0;
+constexpr bool NHB_IS_F16 = false;
 #endif
+static_assert(NHB_WS == (float)(1 << NHB_WS_LOG2), "weight scale");
 constexpr float NHB_INV_WS = 1.0f / NHB_WS;
-// an accumulator on its way out of a gemm (fp16 pieces: minus the weights' scale; bf16: as is)
-NH_DEVICE float nhb_out(float acc) { return NHB_WS != 1.0f ? acc * NHB_INV_WS : acc; }
+constexpr int NHB_TARGET_LOG2 = 13;  // a sample's largest operand value lands in [2^13, 2^14)
+constexpr int NHB_NO_CAP = 100;
+// a raw network output from an accumulator that holds WS * 2^s * value
+NH_DEVICE float nhb_raw(float acc, int s) { return NHB_IS_F16 ? acc * nh_pow2i(-NHB_WS_LOG2 - s) : acc; }
 
 namespace {
 
@@ -82,8 +98,9 @@ NH_DEVICE void b_issue(const BCtx& cx, int64_t src, int bytes, int b, int dst_of
 }
 
 // one accumulator tile -> two k-blocks of the next layer's operand pieces: hi = bf16(v), lo = bf16(v - hi)
+// (mul, fp16 pieces: the power of two that takes the accumulators to the scale the pieces are wanted at)
 template <bool RELU>
-NH_DEVICE void convert_tile(const f32x16& acc, nh_pcx8* oh, nh_pcx8* ol) {
+NH_DEVICE void convert_tile(const f32x16& acc, nh_pcx8* oh, nh_pcx8* ol, float mul) {
 #ifdef NHB_EXP_NO_EPI  // (diagnostic builds only, wrong results: what the kernel costs without the conversions)
     oh[0][0] = nh_to_pc(acc[0]);
     ol[1][0] = nh_to_pc(acc[8]);
@@ -93,12 +110,28 @@ NH_DEVICE void convert_tile(const f32x16& acc, nh_pcx8* oh, nh_pcx8* ol) {
     for (int half = 0; half < 2; ++half)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float v = nhb_out(acc[half * 8 + j]);
+            float v = acc[half * 8 + j];
+            if (NHB_IS_F16) v *= mul;
             if (RELU) v = nh_relu(v);
             const nh_pc hi = nh_to_pc(v);
             oh[half][j] = hi;
             ol[half][j] = nh_to_pc(v - nh_from_pc(hi));
         }
+}
+
+// bit pattern of the largest value the epilogue will convert (ReLU: of the positive ones; identity: of the magnitudes) over this
+// lane's tiles AND those of the other lane half of its sample (the two halves hold different units of the same sample)
+template <int NTE, bool RELU>
+NH_DEVICE unsigned tile_max_bits(const f32x16* acc) {
+    float m = 0.0f;
+#pragma unroll
+    for (int t = 0; t < NTE; ++t)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) m = fmaxf(m, RELU ? acc[t][c] : fabsf(acc[t][c]));
+    unsigned u;
+    memcpy(&u, &m, 4);
+    const unsigned o = (unsigned)nh_shfl_xor_i((int)u, 32);
+    return u > o ? u : o;
 }
 
 // EPI (0: none; 1: ReLU; 2: identity): the first NTE output tiles leave as the next layer's operand pieces oh / ol (k-blocks
@@ -114,10 +147,16 @@ NH_DEVICE void stash_mask_in(unsigned* tile16_mask, int s, int h, const nh_pcx8*
 // as the operand pieces say it, hi + lo, i.e. exactly the values this layer consumes -- into that layer's stash region,
 // one k-block (two 16-byte stores) every other block of its first chunk, under the MFMAs, and the ReLU bits of the same
 // values in the data-gradient kernel's lane layout (as mlp16.hip: "every gemm stores its own input rows").
-template <int W, int NT, int NKA, int NKB, int EPI = 0, int NTE = 0>
+// ROW_SCALE (the fp16 data-gradient chain): the stored rows are the pieces' sum times row_scale -- the power of two that turns the
+// sample's own scale into the launch's.
+// DYN (the fp16 forward): the block-floating-point bookkeeping of the file header -- s_in: exponent of the hidden inputs (of the
+// encoding inputs when there are no hidden ones), s_x: exponent the encoding pieces were made at (>= s_in: rescaled on the fly),
+// cap: the largest exponent the outputs may get (the next layer's encoding exponent, or NHB_NO_CAP), *s_out: what they got.
+template <int W, int NT, int NKA, int NKB, int EPI = 0, int NTE = 0, bool ROW_SCALE = false, bool DYN = false>
 NH_DEVICE void gemm_b(BCtx& cx, const nh_pcx8* ah, const nh_pcx8* al, const nh_pcx8* xh, const nh_pcx8* xl, int64_t base,
                       int64_t next_base, int next_first, f32x16* acc, nh_pcx8* oh = nullptr, nh_pcx8* ol = nullptr,
-                      float* in_rows = nullptr, unsigned* in_mask = nullptr, int s32 = 0) {
+                      float* in_rows = nullptr, unsigned* in_mask = nullptr, int s32 = 0, float row_scale = 1.0f, int s_in = 0,
+                      int s_x = 0, int cap = NHB_NO_CAP, int* s_out = nullptr) {
     constexpr int NK = NKA + NKB, BUF = BShape<W>::BUF, CH = BShape<W>::CHUNK / (NT * 2048), NCH = (NK + CH - 1) / CH;
     static_assert(CH >= 1, "a k-block of every tile must fit one chunk buffer");
     int srow_next = 0;  // next input k-block whose rows go out
@@ -136,6 +175,10 @@ NH_DEVICE void gemm_b(BCtx& cx, const nh_pcx8* ah, const nh_pcx8* al, const nh_p
         b4.z = nh_from_pc(ah[kb][6]) + nh_from_pc(al[kb][6]);
         b4.w = nh_from_pc(ah[kb][7]) + nh_from_pc(al[kb][7]);
 #endif
+        if (ROW_SCALE) {
+            a4.x *= row_scale, a4.y *= row_scale, a4.z *= row_scale, a4.w *= row_scale;
+            b4.x *= row_scale, b4.y *= row_scale, b4.z *= row_scale, b4.w *= row_scale;
+        }
         float* const dst = in_rows + 32 * (kb >> 1) + 16 * (kb & 1) + 4 * cx.h;  // units nhb_unit(kb, h, 0..3) and (kb, h, 4..7) = + 8
 #ifdef NHB_EXP_NO_STASH_STORE  // (diagnostic builds only, wrong results: what the stores themselves cost)
         if (a4.x == 1.2345e-30f && b4.y == 5.4321e-30f) nh_store4(dst, a4.x, a4.y, a4.z, a4.w);
@@ -188,10 +231,12 @@ NH_DEVICE void gemm_b(BCtx& cx, const nh_pcx8* ah, const nh_pcx8* al, const nh_p
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float4 b4 = *(const float4*)(buf + (32 * t + 8 * j + 4 * cx.h) * 4);
-                    acc[t][4 * j] = b4.x;
-                    acc[t][4 * j + 1] = b4.y;
-                    acc[t][4 * j + 2] = b4.z;
-                    acc[t][4 * j + 3] = b4.w;
+                    // (DYN: the products carry 2^s_in, so must the bias -- the multiply takes the place of the copy)
+                    const float bsc = DYN ? nh_pow2i(s_in) : 1.0f;
+                    acc[t][4 * j] = DYN ? b4.x * bsc : b4.x;
+                    acc[t][4 * j + 1] = DYN ? b4.y * bsc : b4.y;
+                    acc[t][4 * j + 2] = DYN ? b4.z * bsc : b4.z;
+                    acc[t][4 * j + 3] = DYN ? b4.w * bsc : b4.w;
                 }
         }
         const char* const wb = buf + 2048 + cx.lane * 16;
@@ -225,8 +270,15 @@ NH_DEVICE void gemm_b(BCtx& cx, const nh_pcx8* ah, const nh_pcx8* al, const nh_p
                 if (i + PF < nblk) load(i + PF);
                 nh_sched_fence();
                 const int kb = c * CH + kk_of(i), t = t_of(i);
-                const nh_pcx8 bh = kb < NKA ? ah[kb < NKA ? kb : 0] : xh[kb >= NKA ? kb - NKA : 0];
-                const nh_pcx8 bl = kb < NKA ? al[kb < NKA ? kb : 0] : xl[kb >= NKA ? kb - NKA : 0];
+                nh_pcx8 bh = kb < NKA ? ah[kb < NKA ? kb : 0] : xh[kb >= NKA ? kb - NKA : 0];
+                nh_pcx8 bl = kb < NKA ? al[kb < NKA ? kb : 0] : xl[kb >= NKA ? kb - NKA : 0];
+#ifdef NHB_F16
+                if (DYN && NKA > 0 && kb >= NKA) {  // encoding pieces made at 2^s_x, wanted at the hidden inputs' 2^s_in (<= s_x)
+                    const float xf = nh_pow2i(s_in - s_x);
+                    bh = nh_f16x8_scale(bh, xf);
+                    bl = nh_f16x8_scale(bl, xf);
+                }
+#endif
                 const nh_pcx8 wh = wph[i % NBUF], wl = wpl[i % NBUF];
                 acc[t] = nh_mfma_pc(wl, bh, acc[t]);  // (the small terms first)
                 acc[t] = nh_mfma_pc(wh, bl, acc[t]);
@@ -242,8 +294,20 @@ NH_DEVICE void gemm_b(BCtx& cx, const nh_pcx8* ah, const nh_pcx8* al, const nh_p
         cx.buf ^= 1;
     }
     if (EPI != 0) {
+        float mul = NHB_INV_WS;
+        if (DYN) {
+            // the accumulators hold WS * 2^s_in * value: move the sample's largest output to [2^13, 2^14) -- unless the next
+            // layer's encodings sit lower -- and remember the exponent the pieces now carry
+            const unsigned mb = tile_max_bits<NTE, EPI == 1>(acc);
+            const int base_e = NHB_WS_LOG2 + s_in;
+            int so = base_e + nh_shift_to(mb, NHB_TARGET_LOG2);
+            so = so < cap ? so : cap;
+            so = so > base_e + 120 ? base_e + 120 : (so < base_e - 120 ? base_e - 120 : so);
+            mul = nh_pow2i(so - base_e);
+            *s_out = so;  // the pieces made below are those of value * 2^so
+        }
 #pragma unroll
-        for (int t = 0; t < NTE; ++t) convert_tile<EPI == 1>(acc[t], oh + 2 * t, ol + 2 * t);
+        for (int t = 0; t < NTE; ++t) convert_tile<EPI == 1>(acc[t], oh + 2 * t, ol + 2 * t, mul);
     }
 }
 
@@ -255,10 +319,11 @@ NH_DEVICE void put_pair(nh_pcx8& oh, nh_pcx8& ol, int e, float v) {
 
 NH_DEVICE float bsel3(int a, float x, float y, float z) { return a == 0 ? x : (a == 1 ? y : z); }
 
-// eight fp32 slot values of one k-block -> operand pieces, and (training) -> this sample's row of the slot region
-NH_DEVICE void put_block(nh_pcx8& oh, nh_pcx8& ol, const float* v, float* slot_row) {
+// eight fp32 slot values of one k-block -> operand pieces (of v * sc: fp16 pieces carry the sample's encoding exponent), and
+// (training) -> this sample's row of the slot region (the plain values)
+NH_DEVICE void put_block(nh_pcx8& oh, nh_pcx8& ol, const float* v, float* slot_row, float sc = 1.0f) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) put_pair(oh, ol, e, v[e]);
+    for (int e = 0; e < 8; ++e) put_pair(oh, ol, e, NHB_IS_F16 ? v[e] * sc : v[e]);
     if (slot_row) {
         float4 a4, b4;
         a4.x = v[0], a4.y = v[1], a4.z = v[2], a4.w = v[3];
@@ -271,7 +336,7 @@ NH_DEVICE void put_block(nh_pcx8& oh, nh_pcx8& ol, const float* v, float* slot_r
 // the encoding slots of lane half h (plan.cpp build_slot_map_b): slot 16 kb + 8 h + e; pair slot >> 1 = 3 f + axis.
 // slot_row (training): this sample's row of the stash's slot region; the lane writes its slots 16 kb + 8 h .. + 7.
 template <int NB>
-NH_DEVICE void encode_b(nh_pcx8* oh, nh_pcx8* ol, float x, float y, float z, int h, const float* freqs, int Lf, float* slot_row) {
+NH_DEVICE void encode_b(nh_pcx8* oh, nh_pcx8* ol, float x, float y, float z, int h, const float* freqs, int Lf, float* slot_row, float sc) {
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
         float v[8];
@@ -288,12 +353,12 @@ NH_DEVICE void encode_b(nh_pcx8* oh, nh_pcx8* ol, float x, float y, float z, int
             v[2 * q] = v0;
             v[2 * q + 1] = v1;
         }
-        put_block(oh[kb], ol[kb], v, slot_row ? slot_row + 16 * kb + 8 * h : nullptr);
+        put_block(oh[kb], ol[kb], v, slot_row ? slot_row + 16 * kb + 8 * h : nullptr, sc);
     }
 }
 // the same slots gathered from a caller-encoded row (mode 0)
 template <int NB>
-NH_DEVICE void gather_b(nh_pcx8* oh, nh_pcx8* ol, const float* row, const signed char* col, int h, float* slot_row) {
+NH_DEVICE void gather_b(nh_pcx8* oh, nh_pcx8* ol, const float* row, const signed char* col, int h, float* slot_row, float sc) {
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
         float v[8];
@@ -302,8 +367,28 @@ NH_DEVICE void gather_b(nh_pcx8* oh, nh_pcx8* ol, const float* row, const signed
             const int c = (int)col[16 * kb + 8 * h + e];
             v[e] = c >= 0 ? row[c] : 0.0f;
         }
-        put_block(oh[kb], ol[kb], v, slot_row ? slot_row + 16 * kb + 8 * h : nullptr);
+        put_block(oh[kb], ol[kb], v, slot_row ? slot_row + 16 * kb + 8 * h : nullptr, sc);
     }
+}
+// exponent for a sample's encodings (fp16 pieces): its largest magnitude `m` (both lane halves) to [2^13, 2^14)
+NH_DEVICE int enc_exponent(float m) {
+    unsigned u;
+    memcpy(&u, &m, 4);
+    const unsigned o = (unsigned)nh_shfl_xor_i((int)u, 32);
+    return nh_shift_to(u > o ? u : o, NHB_TARGET_LOG2);
+}
+// largest magnitude among this lane's slots of a caller-encoded row
+template <int NB>
+NH_DEVICE float gather_max_b(const float* row, const signed char* col, int h) {
+    float m = 0.0f;
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = (int)col[16 * kb + 8 * h + e];
+            m = fmaxf(m, c >= 0 ? fabsf(row[c]) : 0.0f);
+        }
+    return m;
 }
 
 // ---- the training stash (NERFHIP_PRECISION_BF16X3_FWD): what the fp32 backward kernels read (nh_plan.h NhStashLayout) ------
@@ -402,15 +487,22 @@ NH_KERNEL void NH_LB(256, (TRAIN ? 1 : BShape<W>::WAVES_PER_SIMD)) NHB_KERNEL(k_
     };
     nh_pcx8 xh[XB], xl[XB];
     const int ray_i = a.mode == 0 ? 0 : (int)(mc / a.S);
+    constexpr bool DYN = NHB_IS_F16;  // (fp16 pieces: per-sample exponents, file header; ex / ed: the encodings', s: the activations')
+    constexpr bool RS = TRAIN && NHB_IS_F16;
+    int ex = 0, ed = 0, s = 0;
     if (a.mode == 0) {
-        gather_b<XB>(xh, xl, a.x + (size_t)mc * (size_t)(a.dx + a.dd), a.xcol, h, TRAIN ? srow(a.sl.X, 16 * XB) : nullptr);
+        const float* const row = a.x + (size_t)mc * (size_t)(a.dx + a.dd);
+        if (DYN) ex = enc_exponent(gather_max_b<XB>(row, a.xcol, h));
+        gather_b<XB>(xh, xl, row, a.xcol, h, TRAIN ? srow(a.sl.X, 16 * XB) : nullptr, nh_pow2i(ex));
     } else {
         const float* const rr = a.rays + (size_t)ray_i * a.ray_stride;
         const float zz = a.z[mc];
         // pts = ro + rd * z   (nerf/train_utils.py:67,107)
-        encode_b<XB>(xh, xl, rr[0] + rr[3] * zz, rr[1] + rr[4] * zz, rr[2] + rr[5] * zz, h, a.fx, a.Lx,
-                     TRAIN ? srow(a.sl.X, 16 * XB) : nullptr);
+        const float px = rr[0] + rr[3] * zz, py = rr[1] + rr[4] * zz, pz = rr[2] + rr[5] * zz;
+        if (DYN) ex = enc_exponent(fmaxf(fmaxf(fabsf(px), fabsf(py)), fmaxf(fabsf(pz), 1.0f)));  // (sines and cosines: <= 1)
+        encode_b<XB>(xh, xl, px, py, pz, h, a.fx, a.Lx, TRAIN ? srow(a.sl.X, 16 * XB) : nullptr, nh_pow2i(ex));
     }
+    s = ex;
 
     f32x16 acc[TH + 1];
     nh_pcx8 hh[KBH], hl[KBH];  // the current activations as operand pieces (a layer's output replaces them in place:
@@ -418,8 +510,11 @@ NH_KERNEL void NH_LB(256, (TRAIN ? 1 : BShape<W>::WAVES_PER_SIMD)) NHB_KERNEL(k_
     {
         const bool more = a.L > 1;
         // no activation after layer1 (models.py:238)
-        gemm_b<W, TH, 0, XB, 2, TH>(cx, nullptr, nullptr, xh, xl, po.f_layer1 * 4, (more ? po.f_xyz[0] : po.f_head) * 4,
-                                    more ? first(KBH, TH) : (VIEW ? first(KBH, TH + 1) : first(KBH, 1)), acc, hh, hl);
+        // (cap of the outputs' exponent: the next gemm's encodings -- layers_xyz[0] never is a skip layer; the head's are the
+        // directions, whose exponent is not known yet: at most NHB_TARGET_LOG2, |viewdir| <= 1 ... taken when they are formed)
+        gemm_b<W, TH, 0, XB, 2, TH, false, DYN>(cx, nullptr, nullptr, xh, xl, po.f_layer1 * 4, (more ? po.f_xyz[0] : po.f_head) * 4,
+                                                more ? first(KBH, TH) : (VIEW ? first(KBH, TH + 1) : first(KBH, 1)), acc, hh, hl, nullptr,
+                                                nullptr, 0, 1.0f, ex, ex, NHB_NO_CAP, &s);
     }
     for (int i = 0; i < a.L - 1; ++i) {
         const bool sk = (i % a.skip == 0) && i > 0;
@@ -430,45 +525,57 @@ NH_KERNEL void NH_LB(256, (TRAIN ? 1 : BShape<W>::WAVES_PER_SIMD)) NHB_KERNEL(k_
         // (training: the gemm stores its inputs H_i and their ReLU mask i - 1; H_0 = layer1's output has none)
         float* const in_rows = TRAIN ? srow(a.sl.H[i], W) : nullptr;
         unsigned* const in_mask = (TRAIN && i > 0) ? smask(i - 1) : nullptr;
+        const int cap = nsk ? ex : NHB_NO_CAP;  // (a skip layer next: its hidden inputs must not sit above the encodings)
+        const float rsc = RS ? nh_pow2i(-s) : 1.0f;  // (training, fp16 pieces: the stash rows are plain values)
         if (sk)
-            gemm_b<W, TH, KBH, XB, 1, TH>(cx, hh, hl, xh, xl, po.f_xyz[i] * 4, nxt, nfirst, acc, hh, hl, in_rows, in_mask, s32);
+            gemm_b<W, TH, KBH, XB, 1, TH, RS, DYN>(cx, hh, hl, xh, xl, po.f_xyz[i] * 4, nxt, nfirst, acc, hh, hl, in_rows, in_mask, s32, rsc, s, ex,
+                                                   cap, &s);
         else
-            gemm_b<W, TH, KBH, 0, 1, TH>(cx, hh, hl, nullptr, nullptr, po.f_xyz[i] * 4, nxt, nfirst, acc, hh, hl, in_rows, in_mask, s32);
+            gemm_b<W, TH, KBH, 0, 1, TH, RS, DYN>(cx, hh, hl, nullptr, nullptr, po.f_xyz[i] * 4, nxt, nfirst, acc, hh, hl, in_rows, in_mask, s32, rsc,
+                                                  s, s, cap, &s);
     }
     if (VIEW) {
         nh_pcx8 dh[DB], dl[DB];
         if (a.mode == 0) {
-            gather_b<DB>(dh, dl, a.x + (size_t)mc * (size_t)(a.dx + a.dd) + a.dx, a.dcol, h, TRAIN ? srow(a.sl.D, 16 * DB) : nullptr);
+            const float* const row = a.x + (size_t)mc * (size_t)(a.dx + a.dd) + a.dx;
+            if (DYN) ed = enc_exponent(gather_max_b<DB>(row, a.dcol, h));
+            gather_b<DB>(dh, dl, row, a.dcol, h, TRAIN ? srow(a.sl.D, 16 * DB) : nullptr, nh_pow2i(ed));
         } else {
             const float* const rr = a.rays + (size_t)ray_i * a.ray_stride;
-            encode_b<DB>(dh, dl, rr[8], rr[9], rr[10], h, a.fd, a.Ld, TRAIN ? srow(a.sl.D, 16 * DB) : nullptr);
+            if (DYN) ed = enc_exponent(fmaxf(fmaxf(fabsf(rr[8]), fabsf(rr[9])), fmaxf(fabsf(rr[10]), 1.0f)));
+            encode_b<DB>(dh, dl, rr[8], rr[9], rr[10], h, a.fd, a.Ld, TRAIN ? srow(a.sl.D, 16 * DB) : nullptr, nh_pow2i(ed));
         }
         // tiles 0..TH-1: feat = relu(fc_feat(h)); tile TH row 0: fc_alpha(h), raw (models.py:248-249)
         // (training: each gemm stores its own inputs -- H_{L-1} and mask L - 2, FEAT and mask L - 1, DIRH and mask L)
-        gemm_b<W, TH + 1, KBH, 0, 1, TH>(cx, hh, hl, nullptr, nullptr, po.f_head * 4, po.f_dir * 4, first(KBH + DB, TH / 2), acc, hh, hl,
-                                         TRAIN ? srow(a.sl.H[a.L - 1], W) : nullptr, (TRAIN && a.L > 1) ? smask(a.L - 2) : nullptr, s32);
-        const float alpha = nhb_out(acc[TH][0]);
-        gemm_b<W, TH / 2, KBH, DB, 1, TH / 2>(cx, hh, hl, dh, dl, po.f_dir * 4, po.f_rgb * 4, first(KBH / 2, 1), acc, hh, hl,
-                                              TRAIN ? srow(a.sl.FEAT, W) : nullptr, TRAIN ? smask(a.L - 1) : nullptr, s32);
-        gemm_b<W, 1, KBH / 2, 0>(cx, hh, hl, nullptr, nullptr, po.f_rgb * 4, po.f_layer1 * 4, again ? first(XB, TH) : 0, acc, nullptr, nullptr,
-                                 TRAIN ? srow(a.sl.DIRH, W / 2) : nullptr, TRAIN ? smask(a.L) : nullptr, s32);
+        const int s_head = s;  // (the head's inputs: fc_alpha's raw row comes out at WS * 2^s_head)
+        gemm_b<W, TH + 1, KBH, 0, 1, TH, RS, DYN>(cx, hh, hl, nullptr, nullptr, po.f_head * 4, po.f_dir * 4, first(KBH + DB, TH / 2), acc, hh, hl,
+                                                  TRAIN ? srow(a.sl.H[a.L - 1], W) : nullptr, (TRAIN && a.L > 1) ? smask(a.L - 2) : nullptr, s32,
+                                                  RS ? nh_pow2i(-s) : 1.0f, s, s, ed, &s);
+        const float alpha = nhb_raw(acc[TH][0], s_head);
+        gemm_b<W, TH / 2, KBH, DB, 1, TH / 2, RS, DYN>(cx, hh, hl, dh, dl, po.f_dir * 4, po.f_rgb * 4, first(KBH / 2, 1), acc, hh, hl,
+                                                       TRAIN ? srow(a.sl.FEAT, W) : nullptr, TRAIN ? smask(a.L - 1) : nullptr, s32,
+                                                       RS ? nh_pow2i(-s) : 1.0f, s, ed, NHB_NO_CAP, &s);
+        gemm_b<W, 1, KBH / 2, 0, 0, 0, RS, DYN>(cx, hh, hl, nullptr, nullptr, po.f_rgb * 4, po.f_layer1 * 4, again ? first(XB, TH) : 0, acc, nullptr,
+                                                nullptr, TRAIN ? srow(a.sl.DIRH, W / 2) : nullptr, TRAIN ? smask(a.L) : nullptr, s32,
+                                                RS ? nh_pow2i(-s) : 1.0f, s, s);
         if (valid && h == 0) {
             float4 r4;
-            r4.x = nhb_out(acc[0][0]);
-            r4.y = nhb_out(acc[0][1]);
-            r4.z = nhb_out(acc[0][2]);
+            r4.x = nhb_raw(acc[0][0], s);
+            r4.y = nhb_raw(acc[0][1], s);
+            r4.z = nhb_raw(acc[0][2], s);
             r4.w = alpha;
             *(float4*)(a.out + (size_t)m * 4) = r4;
         }
     } else {
-        gemm_b<W, 1, KBH, 0>(cx, hh, hl, nullptr, nullptr, po.f_head * 4, po.f_layer1 * 4, again ? first(XB, TH) : 0, acc, nullptr, nullptr,
-                             TRAIN ? srow(a.sl.H[a.L - 1], W) : nullptr, (TRAIN && a.L > 1) ? smask(a.L - 2) : nullptr, s32);  // fc_out (models.py:256)
+        gemm_b<W, 1, KBH, 0, 0, 0, RS, DYN>(cx, hh, hl, nullptr, nullptr, po.f_head * 4, po.f_layer1 * 4, again ? first(XB, TH) : 0, acc, nullptr,
+                                            nullptr, TRAIN ? srow(a.sl.H[a.L - 1], W) : nullptr, (TRAIN && a.L > 1) ? smask(a.L - 2) : nullptr, s32,
+                                            RS ? nh_pow2i(-s) : 1.0f, s, s);  // fc_out (models.py:256)
         if (valid && h == 0) {
             float4 r4;
-            r4.x = nhb_out(acc[0][0]);
-            r4.y = nhb_out(acc[0][1]);
-            r4.z = nhb_out(acc[0][2]);
-            r4.w = nhb_out(acc[0][3]);
+            r4.x = nhb_raw(acc[0][0], s);
+            r4.y = nhb_raw(acc[0][1], s);
+            r4.z = nhb_raw(acc[0][2], s);
+            r4.w = nhb_raw(acc[0][3], s);
             *(float4*)(a.out + (size_t)m * 4) = r4;
         }
     }
@@ -536,12 +643,23 @@ NH_KERNEL void NH_LB(256, 1) NHB_KERNEL(k_mlp_dgrad)(DgradBArgs a) {
         const int64_t m = grp * 128 + cx.wave * 32 + s32;
         const int64_t tile32 = grp * 4 + cx.wave;
         float go[4] = {0.f, 0.f, 0.f, 0.f};  // d(raw output) of this lane's sample (zero beyond M: nothing flows)
+        // fp16 pieces: this sample's chain runs on its cotangent times a power of two of its own (max |d(raw output)| of the sample
+        // to 2^6: fp32-like relative precision however small the cotangent); what is STORED carries the launch's one power of
+        // two instead (rs = launch scale / sample scale), which the weight-gradient reduction divides out again
+        float rs = 1.0f;
         if (m < a.M) {
-            // (fp16 pieces: the whole chain -- and every d(pre-activation) image it stores -- carries the launch's power-of-two
-            // scale; the weight-gradient reduction divides it out again)
-            const float gs = a.gscale ? nh_gscale_of(*a.gscale) : 1.0f;
             const float4 t4 = *(const float4*)(a.g_out + (size_t)m * 4);
-            go[0] = t4.x * gs, go[1] = t4.y * gs, go[2] = t4.z * gs, go[3] = t4.w * gs;
+            float ss = 1.0f;
+            if (NHB_IS_F16 && a.gscale) {
+                unsigned u0, u1, u2, u3;
+                memcpy(&u0, &t4.x, 4), memcpy(&u1, &t4.y, 4), memcpy(&u2, &t4.z, 4), memcpy(&u3, &t4.w, 4);
+                u0 &= 0x7fffffffu, u1 &= 0x7fffffffu, u2 &= 0x7fffffffu, u3 &= 0x7fffffffu;
+                const unsigned mb = (u0 > u1 ? u0 : u1) > (u2 > u3 ? u2 : u3) ? (u0 > u1 ? u0 : u1) : (u2 > u3 ? u2 : u3);
+                const int es = nh_pow2_to(mb, NH_GSCALE_SAMPLE_LOG2), er = nh_pow2_to(*a.gscale, NH_GSCALE_LAUNCH_LOG2) - es + 127;
+                ss = nh_pow2_float(es);
+                rs = er >= 1 ? nh_pow2_float(er < 254 ? er : 254) : 0.0f;  // (a cotangent 2^-126 below the launch's largest: stored as 0)
+            }
+            go[0] = t4.x * ss, go[1] = t4.y * ss, go[2] = t4.z * ss, go[3] = t4.w * ss;
         }
         auto grow = [&](const NhRegion& R, int rows) -> float* {
             return a.grad + (size_t)32 * (size_t)a.nt * (size_t)R.row_prefix + ((size_t)tile32 * 32 + (size_t)s32) * (size_t)rows;
@@ -561,7 +679,7 @@ NH_KERNEL void NH_LB(256, 1) NHB_KERNEL(k_mlp_dgrad)(DgradBArgs a) {
             float* const pr = grow(a.gl.POUT, 32) + 16 * h;
             float4 z4, g4;
             z4.x = z4.y = z4.z = z4.w = 0.0f;
-            g4.x = h == 0 ? go[0] : 0.0f, g4.y = h == 0 ? go[1] : 0.0f, g4.z = h == 0 ? go[2] : 0.0f, g4.w = h == 0 ? go[3] : 0.0f;
+            g4.x = h == 0 ? go[0] * rs : 0.0f, g4.y = h == 0 ? go[1] * rs : 0.0f, g4.z = h == 0 ? go[2] * rs : 0.0f, g4.w = h == 0 ? go[3] * rs : 0.0f;
             *(float4*)pr = g4;
             *(float4*)(pr + 4) = z4;
             *(float4*)(pr + 8) = z4;
@@ -584,13 +702,13 @@ NH_KERNEL void NH_LB(256, 1) NHB_KERNEL(k_mlp_dgrad)(DgradBArgs a) {
             get_mask(L, mw);  // DIRH
             gate_tiles<TH / 2>(acc, mw);
 #pragma unroll
-            for (int t = 0; t < TH / 2; ++t) convert_tile<false>(acc[t], hh + 2 * t, hl + 2 * t);
-            gemm_b<W, TH, KBH / 2, 0>(cx, hh, hl, nullptr, nullptr, po.b_dir * 4, po.b_head * 4, first(KBH + 1, TH), acc, nullptr, nullptr,
-                                      grow(a.gl.PDIR, W / 2));
+            for (int t = 0; t < TH / 2; ++t) convert_tile<false>(acc[t], hh + 2 * t, hl + 2 * t, NHB_INV_WS);
+            gemm_b<W, TH, KBH / 2, 0, 0, 0, NHB_IS_F16>(cx, hh, hl, nullptr, nullptr, po.b_dir * 4, po.b_head * 4, first(KBH + 1, TH), acc, nullptr,
+                                                        nullptr, grow(a.gl.PDIR, W / 2), nullptr, 0, rs);
             get_mask(L - 1, mw);  // FEAT
             gate_tiles<TH>(acc, mw);
 #pragma unroll
-            for (int t = 0; t < TH; ++t) convert_tile<false>(acc[t], hh + 2 * t, hl + 2 * t);
+            for (int t = 0; t < TH; ++t) convert_tile<false>(acc[t], hh + 2 * t, hl + 2 * t, NHB_INV_WS);
             nh_pcx8 dah[1], dal[1];  // d(sigma raw) enters through fc_alpha's column (k-block KBH, half 0, element 0)
             {
                 float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -598,8 +716,9 @@ NH_KERNEL void NH_LB(256, 1) NHB_KERNEL(k_mlp_dgrad)(DgradBArgs a) {
                 put_block(dah[0], dal[0], v, nullptr);
             }
             const bool last = L == 1;
-            gemm_b<W, TH, KBH, 1>(cx, hh, hl, dah, dal, po.b_head * 4, last ? first_img : po.b_xyz[L > 1 ? L - 2 : 0] * 4,
-                                  last ? (again ? first_bytes : 0) : first(KBH, TH), acc, nullptr, nullptr, grow(a.gl.PFEAT, W));
+            gemm_b<W, TH, KBH, 1, 0, 0, NHB_IS_F16>(cx, hh, hl, dah, dal, po.b_head * 4, last ? first_img : po.b_xyz[L > 1 ? L - 2 : 0] * 4,
+                                                    last ? (again ? first_bytes : 0) : first(KBH, TH), acc, nullptr, nullptr, grow(a.gl.PFEAT, W),
+                                                    nullptr, 0, rs);
         } else {
             const bool last = L == 1;
             gemm_b<W, TH, 0, 1>(cx, nullptr, nullptr, d1h, d1l, po.b_head * 4, last ? first_img : po.b_xyz[L > 1 ? L - 2 : 0] * 4,
@@ -611,17 +730,18 @@ NH_KERNEL void NH_LB(256, 1) NHB_KERNEL(k_mlp_dgrad)(DgradBArgs a) {
             gate_tiles<TH>(acc, mw);
         }
 #pragma unroll
-        for (int t = 0; t < TH; ++t) convert_tile<false>(acc[t], hh + 2 * t, hl + 2 * t);
+        for (int t = 0; t < TH; ++t) convert_tile<false>(acc[t], hh + 2 * t, hl + 2 * t, NHB_INV_WS);
         for (int k = L - 1; k >= 1; --k) {
             const bool last = k == 1;
-            gemm_b<W, TH, KBH, 0>(cx, hh, hl, nullptr, nullptr, po.b_xyz[k - 1] * 4, last ? first_img : po.b_xyz[k >= 2 ? k - 2 : 0] * 4,
-                                  last ? (again ? first_bytes : 0) : first(KBH, TH), acc, nullptr, nullptr, grow(a.gl.P[k], W));
+            gemm_b<W, TH, KBH, 0, 0, 0, NHB_IS_F16>(cx, hh, hl, nullptr, nullptr, po.b_xyz[k - 1] * 4, last ? first_img : po.b_xyz[k >= 2 ? k - 2 : 0] * 4,
+                                                    last ? (again ? first_bytes : 0) : first(KBH, TH), acc, nullptr, nullptr, grow(a.gl.P[k], W),
+                                                    nullptr, 0, rs);
             if (k - 1 >= 1) {
                 get_mask(k - 2, mw);  // H_{k-1}
                 gate_tiles<TH>(acc, mw);
             }
 #pragma unroll
-            for (int t = 0; t < TH; ++t) convert_tile<false>(acc[t], hh + 2 * t, hl + 2 * t);
+            for (int t = 0; t < TH; ++t) convert_tile<false>(acc[t], hh + 2 * t, hl + 2 * t, NHB_INV_WS);
         }
         {  // d(pre-activation) of layer1: no gemm consumes it -- stored here (hi + lo, as every other image)
             float* const pr = grow(a.gl.P[0], W);
@@ -636,6 +756,10 @@ NH_KERNEL void NH_LB(256, 1) NHB_KERNEL(k_mlp_dgrad)(DgradBArgs a) {
                 b4.y = nh_from_pc(hh[kb][5]) + nh_from_pc(hl[kb][5]);
                 b4.z = nh_from_pc(hh[kb][6]) + nh_from_pc(hl[kb][6]);
                 b4.w = nh_from_pc(hh[kb][7]) + nh_from_pc(hl[kb][7]);
+                if (NHB_IS_F16) {
+                    a4.x *= rs, a4.y *= rs, a4.z *= rs, a4.w *= rs;
+                    b4.x *= rs, b4.y *= rs, b4.z *= rs, b4.w *= rs;
+                }
                 float* const dst = pr + 32 * (kb >> 1) + 16 * (kb & 1) + 4 * h;
                 *(float4*)dst = a4;
                 *(float4*)(dst + 8) = b4;
@@ -660,7 +784,7 @@ NH_KERNEL void NHB_KERNEL(k_pack)(const float* __restrict__ params, const int32_
     const int64_t r = i - la.base[l];
     const int32_t s = table[i];
     const float v = (s >= 0 ? params[s] : 0.0f) * NHB_WS;  // (fp16 pieces: times 2^8, exact; every gemm takes it out again)
-    if (r < 512) {  // bias word
+    if (r < 512) {  // bias word: joins accumulators of (scaled weights) x (scaled activations)
         packed[i] = v;
         return;
     }

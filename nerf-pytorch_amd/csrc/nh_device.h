@@ -74,7 +74,10 @@ NH_DEVICE float nh_from_f16(nh_f16 h) { return (float)h; }
 NH_DEVICE f32x16 nh_mfma_f16(nh_f16x8 a, nh_f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
+// eight pieces times a power of two (v_pk_mul_f16: exact unless a piece leaves fp16's range at the bottom)
+NH_DEVICE nh_f16x8 nh_f16x8_scale(nh_f16x8 v, float pow2) { return v * (nh_f16)pow2; }
 
+NH_DEVICE float nh_med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }  // v_med3_f32: clamp in one instruction
 NH_DEVICE void nh_atomic_add(float* p, float v) { atomicAdd(p, v); }
 NH_DEVICE void nh_atomic_max_u32(unsigned* p, unsigned v) { atomicMax(p, v); }
 // Asynchronous global -> LDS copy of 16 bytes per lane (global_load_lds_dwordx4): lane l's 16 bytes at `g` land at
@@ -218,28 +221,42 @@ NH_DEVICE float nh_gate(float v, unsigned word, int k) {
     return v;
 }
 
-// Gradient scale of the fp16 data-gradient chain: `maxbits` = bit pattern of max|d(raw output)| over a launch (k_absmax_bits).
-// nh_gscale_of: the power of two S with max * S in [16, 32) -- fp16's normal range is [2^-14, 2^16): the head room above covers
-// what the transposed layers can amplify, the 2^18 below keeps both pieces of everything within 2^-6 of the maximum normal --;
-// nh_gscale_inv: 1 / S exactly.  Degenerate maxima (0, subnormal, Inf / NaN) give S = 1.
-NH_DEVICE int nh_gscale_exp(unsigned maxbits) {
-    const int e = (int)((maxbits >> 23) & 255u);
+// Power-of-two scales of the fp16 data-gradient chain (exact to apply and to undo).  fp16's normal range is [2^-14, 2^16) and a
+// value's low piece sits 2^-12 below it, so a value keeps both pieces exact down to 2^-2 and loses ABSOLUTE precision (2^-25)
+// below: what is multiplied should sit well above 1, with head room for what the transposed layers amplify.
+//   nh_pow2_to(bits, t): the power of two S with |x| * S in [2^t, 2^(t+1)) for x = the float with bit pattern `bits` (degenerate
+//       x -- 0, subnormal, Inf / NaN -- gives S = 1); returned as its biased exponent (1 .. 253: S and 1 / S both normal).
+//   per SAMPLE (k_mlp_dgrad_f16x3): the chain of a sample runs on d(raw output) * nh_pow2_to(max |d(raw output)| of the sample, 6)
+//       -- every sample keeps fp32-like RELATIVE precision however small its cotangent --;
+//   per LAUNCH (what the d(pre-activation) images carry, and the weight-gradient reduction divides out): max over the launch
+//       (k_absmax_bits) to 2^8: nh_gscale_of / nh_gscale_inv.
+NH_DEVICE int nh_pow2_to(unsigned bits, int t) {
+    const int e = (int)((bits >> 23) & 255u);
     if (e == 0 || e == 255) return 127;
-    const int se = 258 - e;
+    const int se = 254 + t - e;
     return se < 1 ? 1 : (se > 253 ? 253 : se);
 }
-NH_DEVICE float nh_gscale_of(unsigned maxbits) {
-    const unsigned u = (unsigned)nh_gscale_exp(maxbits) << 23;
+// 2^k as a float, k clamped to the normal range
+NH_DEVICE float nh_pow2i(int k) {
+    const unsigned u = (unsigned)((k < -126 ? -126 : (k > 127 ? 127 : k)) + 127) << 23;
     float f;
     memcpy(&f, &u, 4);
     return f;
 }
-NH_DEVICE float nh_gscale_inv(unsigned maxbits) {
-    const unsigned u = (unsigned)(254 - nh_gscale_exp(maxbits)) << 23;
+// the shift k with |x| * 2^k in [2^t, 2^(t+1)) for x = the float with bit pattern `bits`; 0 for x = 0 / subnormal / Inf / NaN
+NH_DEVICE int nh_shift_to(unsigned bits, int t) {
+    const int e = (int)((bits >> 23) & 255u);
+    return (e == 0 || e == 255) ? 0 : t + 127 - e;
+}
+NH_DEVICE float nh_pow2_float(int biased_exp) {
+    const unsigned u = (unsigned)biased_exp << 23;
     float f;
     memcpy(&f, &u, 4);
     return f;
 }
+constexpr int NH_GSCALE_LAUNCH_LOG2 = 8, NH_GSCALE_SAMPLE_LOG2 = 6;
+NH_DEVICE float nh_gscale_of(unsigned maxbits) { return nh_pow2_float(nh_pow2_to(maxbits, NH_GSCALE_LAUNCH_LOG2)); }
+NH_DEVICE float nh_gscale_inv(unsigned maxbits) { return nh_pow2_float(254 - nh_pow2_to(maxbits, NH_GSCALE_LAUNCH_LOG2)); }
 
 // Row (feature) index held by accumulator register c (0..15) of MFMA tile t for lane-half h.
 NH_DEVICE int nh_feat_of(int t, int c, int h) { return 32 * t + (c & 3) + 8 * (c >> 2) + 4 * h; }

@@ -65,7 +65,8 @@ constexpr int nhb_first_bytes(int nk, int nt, int W) {
 // fp16 (11 bits, 5-bit exponent: weights pre-scaled, d(raw output) scaled per launch).
 static inline int nh_prec_level(int precision) { return precision <= NERFHIP_PRECISION_BF16X3_TRAIN ? precision : precision - 4; }
 static inline bool nh_prec_f16(int precision) { return precision >= NERFHIP_PRECISION_F16X3; }
-// fp16 pieces: the packed weights and biases carry this power of two (exact), every gemm's accumulators its inverse
+// fp16 pieces: the packed weights (and biases) carry this exact power of two -- a weight's low piece is then a normal fp16 number
+// down to |w| = 2^-10; what is multiplied with them carries per-SAMPLE exponents the kernels keep themselves (mlp_bf16.hip header)
 constexpr float NHB_F16_WSCALE = 256.0f;
 
 struct NhTensor {

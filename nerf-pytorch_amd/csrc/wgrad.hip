@@ -56,7 +56,7 @@ struct JobRed {  // k_wgrad_reduce
     int tile0;     // first accumulator tile of this block inside a workgroup's partial (0, or behind the host job's tiles)
 };
 constexpr int NH_JOBS_DEV = NH_MAX_JOBS;
-static_assert(sizeof(JobDev) * NH_JOBS_DEV + 64 <= 4096 && sizeof(JobRed) * NH_JOBS_DEV + 240 <= 4096,
+static_assert(sizeof(JobDev) * NH_JOBS_DEV + 64 <= 4096 && sizeof(JobRed) * NH_JOBS_DEV + 248 <= 4096,
               "the job tables must fit the 4 KB kernel-argument limit");
 // Workgroup shapes.  256-wide nets: 8 waves per workgroup (two per SIMD), two LDS stages of 16384 floats (+ slack for
 // the operand prefetch that runs one k-step past the end of a stage): one workgroup per CU.  128-wide nets (jobs of at
@@ -93,6 +93,7 @@ struct ReduceArgs {
     float* g_params;
     const unsigned* gscale;  // fp16 data-gradient chains: device word with the bits of max|g_out| (the d(pre-activation) images
                              // carry nh_gscale_of of it, the reduction multiplies by nh_gscale_inv -- exact); else NULL
+    float w_unscale;         // a constant factor on the weight gradients (1: the stash rows are plain values)
     int njobs, total_wgs;
     int part_bias, part_stride;
     JobRed jobs[NH_JOBS_DEV];
@@ -589,7 +590,7 @@ NH_KERNEL void k_wgrad_reduce(ReduceArgs a) {
             for (int sidx = 0; sidx < nsl; ++sidx) total += part[sidx * epb + e_local];
         }
     }
-    if (col >= 0 && slice == 0) a.g_params[(size_t)jb.w_off + (size_t)(out_row - jb.r_lo) * jb.w_ld + col] = total * unscale;
+    if (col >= 0 && slice == 0) a.g_params[(size_t)jb.w_off + (size_t)(out_row - jb.r_lo) * jb.w_ld + col] = total * (unscale * a.w_unscale);
     if (slice == 0 && in_job && jb.bias_off >= 0 && b_t == 0 && c == 0 && lane < 32) {
         const int brow = 32 * jb.po * (a_t / jb.po) + jb.po * lane + a_t % jb.po;
         if (brow >= jb.r_lo && brow < jb.r_hi) {
@@ -774,6 +775,7 @@ int nh_wgrad(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad,
     red.partial = partial;
     red.g_params = g_params;
     red.gscale = gscale;
+    red.w_unscale = 1.0f;  // (the stash rows are plain fp32 values in every precision)
     // (one reduce record per job AND per side block: nerfhip_plan_create counts both against NH_MAX_JOBS)
     NH_REQUIRE(red.njobs <= NH_JOBS_DEV, "wgrad: %d reduce records exceed the table of %d", red.njobs, NH_JOBS_DEV);
     w.nt = nt;

@@ -67,6 +67,7 @@ struct WgBArgs {
     int64_t nt;
     int njobs, part_stride;  // floats per workgroup partial: AR * BR accumulators + 256 bias sums
     const unsigned* gscale;  // device word: bits of max|g_out| of the data-gradient launch that wrote `grad` (fp16 chain), or NULL
+    float w_unscale;         // a constant factor on the weight gradients (1: the stash rows are plain values)
     WgBJob jobs[NHW_MAX_JOBS];
 };
 
@@ -244,7 +245,7 @@ NH_KERNEL void NHB_KERNEL(k_wgrad_reduce)(WgBArgs a) {
                 for (int q = 0; q < 8; ++q) s8[q] += src[(size_t)(k + q) * (size_t)a.part_stride];
             }
             for (int q = 0; k < jb.nwg; ++k, ++q) s8[q] += src[(size_t)k * (size_t)a.part_stride];
-            a.g_params[jb.w_off + (int64_t)row * jb.w_ld + col] = (((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]))) * unscale;
+            a.g_params[jb.w_off + (int64_t)row * jb.w_ld + col] = (((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]))) * (unscale * a.w_unscale);
         }
     } else if (e < E + AR) {  // bias: thread t of every workgroup summed row t mod AR
         const int row = e - E;
@@ -368,6 +369,7 @@ int NHB_FN(nh_wgrad)(nerfhip_plan* p, int64_t nt, const float* stash, const floa
     full.grad = half.grad = grad;
     full.g_params = half.g_params = g_params;
     full.gscale = half.gscale = gscale;
+    full.w_unscale = half.w_unscale = 1.0f;
     full.partial = partial;
     // (the second launch's partials follow the first's)
     int64_t first = 0;

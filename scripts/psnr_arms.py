@@ -13,6 +13,10 @@ MANY seeds, everything else identical per seed (initial weights, training views,
                kernels unchanged fp32 (same draws as `engine`: differs from it only in the forward's arithmetic)
     engine_bf16fd   the same with NERFHIP_PRECISION_BF16X3_FWD_DGRAD nets: the data-gradient chain on the split-bf16 kernel too
     engine_bf16tr   the same with NERFHIP_PRECISION_BF16X3_TRAIN nets: also the hidden x hidden weight-gradient blocks (256-wide nets)
+    engine_f16fd / engine_f16tr   (round 4) `engine` with NERFHIP_PRECISION_F16X3_FWD_DGRAD / _TRAIN nets: the same kernels on fp16
+               pieces (fp32-grade products)
+--lr: the initial learning rate of EVERY arm (default the reference recipe's 5e-3, config/lego.yml; at 8x256 half the seeds collapse
+under it in every arm -- a dead net renders a constant --, so the round-4 study of the metric's own geometry lowers it for all arms).
 
 Scene: the teacher of scripts/psnr400.py (pretrained lego-lowres nets rendered at 400x400, 100 training / 10 held-out
 views).  Students: --hidden x --layers nets (default the reference's own 4x128: its scripts build FlexibleNeRFModel with
@@ -63,6 +67,13 @@ def torch_draws(n):
             torch.rand((n, NF), dtype=torch.float32, device=dev), torch.randn((n, NC + NF), dtype=torch.float32, device=dev))
 
 
+LR0 = 5e-3
+
+
+def lr_at(i):
+    return N.TrainEngine.lr_at(i, lr0=LR0)
+
+
 def run(arm, seed, iters, check, student, poses, imgs, train, views):
     P4.STUDENT.clear()
     P4.STUDENT.update(student)  # (validate_ref reads it)
@@ -75,18 +86,19 @@ def run(arm, seed, iters, check, student, poses, imgs, train, views):
     if arm == "ref":
         pc = {k: v.detach().clone().to(dev).requires_grad_(True) for k, v in mc.state_dict().items()}
         pf = {k: v.detach().clone().to(dev).requires_grad_(True) for k, v in mf.state_dict().items()}
-        opt = torch.optim.Adam(list(pc.values()) + list(pf.values()), lr=5e-3)
+        opt = torch.optim.Adam(list(pc.values()) + list(pf.values()), lr=LR0)
     elif arm == "dropin":
         mc, mf = mc.to(dev), mf.to(dev)
-        opt = torch.optim.Adam(list(mc.parameters()) + list(mf.parameters()), lr=5e-3)
+        opt = torch.optim.Adam(list(mc.parameters()) + list(mf.parameters()), lr=LR0)
         ex, ed = N.get_embedding_function(10, True, True), N.get_embedding_function(4, True, True)
     else:
         mc, mf = mc.to(dev), mf.to(dev)
-        if arm in ("engine_bf16fwd", "engine_bf16fd", "engine_bf16tr"):  # the engine arm on the split-bf16 training precisions
-            prec = {"engine_bf16fwd": "bf16x3_fwd", "engine_bf16fd": "bf16x3_fwd_dgrad", "engine_bf16tr": "bf16x3_train"}[arm]
+        if arm in ("engine_bf16fwd", "engine_bf16fd", "engine_bf16tr", "engine_f16fd", "engine_f16tr"):  # the engine arm on a split precision
+            prec = {"engine_bf16fwd": "bf16x3_fwd", "engine_bf16fd": "bf16x3_fwd_dgrad", "engine_bf16tr": "bf16x3_train",
+                    "engine_f16fd": "f16x3_fwd_dgrad", "engine_f16tr": "f16x3_train"}[arm]
             mc.set_training_precision(prec)
             mf.set_training_precision(prec)
-        eng = N.TrainEngine(mc, mf, NC, NF, perturb=True, white_background=True, noise_std=0.2, lr=5e-3, seed=seed)
+        eng = N.TrainEngine(mc, mf, NC, NF, perturb=True, white_background=True, noise_std=0.2, lr=LR0, seed=seed)
     torch.manual_seed(seed + 12345)  # the draws of the training loop: arms ref / dropin / engine_td consume the same numbers
     for i in range(1, iters + 1):
         ro, rd, tgt = next(stream)
@@ -111,11 +123,11 @@ def run(arm, seed, iters, check, student, poses, imgs, train, views):
         else:
             rays = N.pack_rays(ro, rd, opts)
             draws = torch_draws(rays.shape[0]) if arm == "engine_td" else None
-            loss3 = eng.step(rays, tgt, lr=N.TrainEngine.lr_at(i - 1), draws=draws)
+            loss3 = eng.step(rays, tgt, lr=lr_at(i - 1), draws=draws)
             losses.append(loss3[2:3].clone())
         if arm in ("ref", "dropin"):
             for gq in opt.param_groups:  # train_nerf.py:264-270
-                gq["lr"] = N.TrainEngine.lr_at(i)
+                gq["lr"] = lr_at(i)
         if i in check:
             torch.cuda.synchronize()
             t_train += time.perf_counter() - t_mark
@@ -138,12 +150,14 @@ if __name__ == "__main__":
     ap.add_argument("--arms", default="engine,engine_td,dropin,ref")
     ap.add_argument("--hidden", type=int, default=128)
     ap.add_argument("--layers", type=int, default=4)
+    ap.add_argument("--lr", type=float, default=5e-3)
     a = ap.parse_args()
+    LR0 = a.lr
     student = dict(num_layers=a.layers, hidden_size=a.hidden, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4)
     check = [i for i in (250, 500, 1000, 1500, 2000, 3000, 4000, 5000) if i <= a.iters] or [a.iters]
     poses, imgs, train, val = P4.teacher_dataset()
     views = val[:P4.VAL_PER_CHECK]
-    res = dict(seed=a.seed, iters=a.iters, student="%dx%d" % (a.layers, a.hidden), rays_per_iter=RAYS, image="%dx%d" % (H, W), arms={})
+    res = dict(seed=a.seed, iters=a.iters, lr0=a.lr, student="%dx%d" % (a.layers, a.hidden), rays_per_iter=RAYS, image="%dx%d" % (H, W), arms={})
     for arm in a.arms.split(","):
         res["arms"][arm] = run(arm, a.seed, a.iters, check, student, poses, imgs, train, views)
         json.dump(res, open(a.out, "w"), indent=1)

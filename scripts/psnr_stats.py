@@ -31,8 +31,8 @@ def main(root):
         print("no runs under", root)
         return
     any_run = next(iter(runs.values()))
-    print("# scripts/psnr_arms.py: students %s, %s, %d rays/iter, 64+128, %d iterations; %d seeds: %s" % (
-        any_run["student"], any_run["image"], any_run["rays_per_iter"], any_run["iters"], len(runs), sorted(runs)))
+    print("# scripts/psnr_arms.py: students %s, %s, %d rays/iter, 64+128, %d iterations, initial lr %g (every arm); %d seeds: %s" % (
+        any_run["student"], any_run["image"], any_run["rays_per_iter"], any_run["iters"], any_run.get("lr0", 5e-3), len(runs), sorted(runs)))
     last = str(max(int(k) for k in any_run["arms"]["engine"]))
     collapsed = []
     for s, j in sorted(runs.items()):
@@ -46,7 +46,13 @@ def main(root):
           % (last, collapsed or "none"))
     print("# seeds dropped from the paired statistics: %s" % (bad or "none"))
     use = [s for s in sorted(runs) if s not in bad]
-    arms = [a for a in ("ref", "dropin", "engine_td", "engine", "engine_bf16fwd", "engine_bf16fd", "engine_bf16tr") if any(a in runs[s]["arms"] for s in use)]
+    per_arm = {}
+    for s, arm, which, *_ in collapsed:
+        per_arm.setdefault(arm, []).append((s, which))
+    all_arms = sorted({a for j in runs.values() for a in j["arms"]})
+    print("# collapse rate per arm: " + ", ".join("%s %d/%d" % (a, len(per_arm.get(a, [])), sum(1 for j in runs.values() if a in j["arms"])) for a in all_arms))
+    arms = [a for a in ("ref", "dropin", "engine_td", "engine", "engine_bf16fwd", "engine_bf16fd", "engine_bf16tr", "engine_f16fd", "engine_f16tr")
+            if any(a in runs[s]["arms"] for s in use)]
     checks = sorted(int(k) for k in any_run["arms"]["engine"])
     print("\n== validation PSNR (coarse+fine), mean over usable seeds [n] ==")
     print("%-10s" % "iteration" + "".join("%16s" % a for a in arms))
@@ -57,7 +63,8 @@ def main(root):
             row += "%11.3f [%2d]" % (sum(v) / len(v), len(v)) if v else "%16s" % "-"
         print(row)
     pairs = [("engine", "ref"), ("engine", "dropin"), ("engine", "engine_td"), ("engine_td", "dropin"), ("dropin", "ref")]
-    extra = [(a, "engine") for a in ("engine_bf16fwd", "engine_bf16fd", "engine_bf16tr") if any(a in runs[s]["arms"] for s in use)]
+    extra = [(a, "engine") for a in ("engine_bf16fwd", "engine_bf16fd", "engine_bf16tr", "engine_f16fd", "engine_f16tr") if any(a in runs[s]["arms"] for s in use)]
+    extra += [(a, "ref") for a in ("engine_f16fd", "engine_f16tr") if any(a in runs[s]["arms"] and "ref" in runs[s]["arms"] for s in use)]
     if extra:
         pairs = extra + [p for p in pairs if all(any(a in runs[s]["arms"] for s in use) for a in p)]
     for key, label in (("val_psnr", "validation PSNR coarse+fine"), ("val_psnr_fine", "validation PSNR, fine net alone"),

@@ -245,6 +245,11 @@ NH_DEVICE nh_f16 nh_to_f16(float f) {
     if (ex >= 31u) return nh_f16{(uint16_t)(sign | 0x7c00u)};
     return nh_f16{(uint16_t)(sign | (ex << 10) | man)};
 }
+NH_DEVICE nh_f16x8 nh_f16x8_scale(nh_f16x8 v, float pow2) {
+    nh_f16x8 o;
+    for (int e = 0; e < 8; ++e) o[e] = nh_to_f16(nh_from_f16(v[e]) * nh_from_f16(nh_to_f16(pow2)));
+    return o;
+}
 NH_DEVICE f32x16 nh_mfma_f16(nh_f16x8 a, nh_f16x8 b, f32x16 c) {
     emu::WaveState& w = emu::cur_wave();
     const int lane = emu::cur->lane, j = lane & 31, h = lane >> 5;
@@ -271,6 +276,7 @@ NH_DEVICE f32x16 nh_mfma_f16(nh_f16x8 a, nh_f16x8 b, f32x16 c) {
     return d;
 }
 
+NH_DEVICE float nh_med3(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 NH_DEVICE void nh_atomic_add(float* p, float v) { *p += v; }
 NH_DEVICE void nh_atomic_max_u32(unsigned* p, unsigned v) { if (v > *p) *p = v; }
 NH_DEVICE void nh_glds16(const float* g, float* lds_wave_base) { memcpy(lds_wave_base + 4 * emu::cur->lane, g, 16); }

@@ -182,6 +182,11 @@ NH_DEVICE void gemm_b(BCtx& cx, const nh_pcx8* ah, const nh_pcx8* al, const nh_p
         float* const dst = in_rows + 32 * (kb >> 1) + 16 * (kb & 1) + 4 * cx.h;  // units nhb_unit(kb, h, 0..3) and (kb, h, 4..7) = + 8
 #ifdef NHB_EXP_NO_STASH_STORE  // (diagnostic builds only, wrong results: what the stores themselves cost)
         if (a4.x == 1.2345e-30f && b4.y == 5.4321e-30f) nh_store4(dst, a4.x, a4.y, a4.z, a4.w);
+#elif defined(NHB_EXP_DENSE_STASH)  // (diagnostic builds only, wrong layout: the SAME bytes as [32-row tile][plane][slot][sample][16 B] --
+        // every store instruction then writes eight whole 128-byte lines instead of 32 x 32 bytes at a 1-KiB stride)
+        float* const tb = in_rows - s32 * (16 * NKA);
+        nh_store4(tb + (((kb >> 1) * 2 + 0) * 4 + 2 * (kb & 1) + cx.h) * 128 + s32 * 4, a4.x, a4.y, a4.z, a4.w);
+        nh_store4(tb + (((kb >> 1) * 2 + 1) * 4 + 2 * (kb & 1) + cx.h) * 128 + s32 * 4, b4.x, b4.y, b4.z, b4.w);
 #else
         nh_store4(dst, a4.x, a4.y, a4.z, a4.w);
         nh_store4(dst + 8, b4.x, b4.y, b4.z, b4.w);

@@ -77,6 +77,29 @@ NH_DEVICE f32x16 nh_mfma_f16(nh_f16x8 a, nh_f16x8 b, f32x16 c) {
 // eight pieces times a power of two (v_pk_mul_f16: exact unless a piece leaves fp16's range at the bottom)
 NH_DEVICE nh_f16x8 nh_f16x8_scale(nh_f16x8 v, float pow2) { return v * (nh_f16)pow2; }
 
+// ds_read_b64_tr_b16 (gfx950): the 16 lanes of a quarter wave each name 8 bytes (four 16-bit elements) in LDS; read as a
+// 4 x 16 matrix in lane order (lane k holds row k >> 2, columns 4 (k & 3) .. + 3), lane i gets COLUMN i: element j of its result
+// is element (i & 3) of lane 4 j + (i >> 2)'s bytes.  Turns a sample-major image into k-minor MFMA operands for free.
+NH_DEVICE unsigned long long nh_lds_tr16(const char* lds_ptr) {
+    typedef short nh_s4 __attribute__((__vector_size__(4 * sizeof(short))));
+    const nh_s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) nh_s4*)lds_ptr);
+    unsigned long long u;
+    __builtin_memcpy(&u, &v, 8);
+    return u;
+}
+// sum of the two 16-bit floats packed in `pair` (+ c), in fp32: v_dot2c_f32_f16 / v_dot2c_f32_bf16 against (1, 1)
+NH_DEVICE float nh_pair_sum_f16(unsigned pair, float c) {
+    typedef _Float16 nh_h2 __attribute__((ext_vector_type(2)));
+    nh_h2 a, one = {(_Float16)1.0f, (_Float16)1.0f};
+    __builtin_memcpy(&a, &pair, 4);
+    return __builtin_amdgcn_fdot2(a, one, c, false);
+}
+NH_DEVICE float nh_pair_sum_bf16(unsigned pair, float c) {
+    typedef __bf16 nh_b2 __attribute__((ext_vector_type(2)));
+    nh_b2 a, one = {(__bf16)1.0f, (__bf16)1.0f};
+    __builtin_memcpy(&a, &pair, 4);
+    return __builtin_amdgcn_fdot2_f32_bf16(a, one, c, false);
+}
 NH_DEVICE float nh_med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }  // v_med3_f32: clamp in one instruction
 NH_DEVICE void nh_atomic_add(float* p, float v) { atomicAdd(p, v); }
 NH_DEVICE void nh_atomic_max_u32(unsigned* p, unsigned v) { atomicMax(p, v); }

@@ -7,7 +7,7 @@ F=${3:-mlp_bf16}
 mkdir -p build_var_$1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -x hip -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -mllvm -pragma-unroll-threshold=4000000 $2 -c $F.hip -o build_var_$1/$F.o
 OBJS=""
-for f in elementwise dataio render sample mlp mlp16 mlp16_w512 mlp16_ext mlp_bf16 wgrad wgrad_bf16 fused plan; do
+for f in elementwise dataio render sample mlp mlp16 mlp16_w512 mlp16_ext mlp_bf16 mlp_f16 wgrad wgrad_bf16 wgrad_f16 fused plan; do
   if [ "$f" = "$F" ]; then OBJS="$OBJS build_var_$1/$f.o"; else OBJS="$OBJS build/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libnerfhip_$1.so $OBJS

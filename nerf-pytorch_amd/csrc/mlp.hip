@@ -47,37 +47,21 @@ NH_KERNEL void k_mlp_input_grad(InGradArgs a) {
     a.g_x[idx] = a.gscale ? s * nh_gscale_inv(*a.gscale) : s;
 }
 
-// max |x| of a launch's d(raw output) as a bit pattern (non-negative floats order like unsigned integers; a NaN sorts above
-// Inf and turns the scaling off: nh_gscale_exp) -- the fp16 data-gradient chain picks its power-of-two scale from it
-NH_KERNEL void k_absmax_bits(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out) {
-    unsigned m = 0u;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        unsigned u;
-        const float v = x[i];
-        memcpy(&u, &v, 4);
-        u &= 0x7fffffffu;
-        m = u > m ? u : m;
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const unsigned o = (unsigned)nh_shfl_xor_i((int)m, d);
-        m = o > m ? o : m;
-    }
-    if (nh_lane() == 0) nh_atomic_max_u32(out, m);
+NH_KERNEL void k_zero_words(unsigned* out, int n) {
+    for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) out[i] = 0u;
 }
-NH_KERNEL void k_zero_word(unsigned* out) { out[0] = 0u; }
 
 }  // namespace
 
 // scratch of a backward over M sample points: the d(pre-activation) images the data-gradient kernel writes for the
 // weight-gradient kernel, then the split-K partials
-// (... then 64 words whose first holds max|g_out| of the launch for the fp16 data-gradient chain's scale)
+// (... then NH_RMAX_WORDS words: the region maxima of the d(pre-activation) images, fp16 level-4 plans)
 static int64_t gscale_word_offset(nerfhip_plan* p, int64_t nt) {
     return nt * p->grad.total_rows * 32 + nh_wgrad_partial_floats(p, nt) + nh_wgrad_x3_partial_floats(p, nt);
 }
 int64_t nh_mlp_bwd_scratch_bytes(nerfhip_plan* p, int64_t M) {
     const int64_t nt = nh_ceil_div(M, 128) * 4;
-    return (gscale_word_offset(p, nt) + 64) * (int64_t)sizeof(float);
+    return (gscale_word_offset(p, nt) + NH_RMAX_WORDS) * (int64_t)sizeof(float);
 }
 
 int nh_mlp_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
@@ -108,29 +92,34 @@ int nh_mlp_backward(nerfhip_plan* p, const float* packed, const float* g_out, in
     const int64_t nt = nh_ceil_div(M, 128) * 4;
     const bool bdg = nh_prec_level(p->precision) >= 3, f16 = nh_prec_f16(p->precision);
     int rc = NERFHIP_OK;
-    unsigned* gscale = nullptr;
-    if (bdg && f16) {
-        // the fp16 chain's scale: max|g_out| of THIS launch, reduced on the device (two small launches, no host round trip)
-        gscale = (unsigned*)(scratch + gscale_word_offset(p, nt));
-        NH_LAUNCH(k_zero_word, 1, 1, 0, stream, gscale);
-        const int64_t n4 = M * 4;
-        NH_LAUNCH(k_absmax_bits, nh_ceil_div(n4, 256 * 16) < 2048 ? nh_ceil_div(n4, 256 * 16) : 2048, 256, 0, stream, g_out, n4, gscale);
-        rc = nh_launch_status("absmax_bits");
+    // fp16 plans whose large weight-gradient blocks run on the fp16 MFMAs: the producers record per-region maxima (behind the
+    // stash: the forward's; behind this scratch: the data-gradient launch's), from which k_wgrad_f16x3 takes its scales
+    unsigned* amax = nullptr;
+    const unsigned* bmax = nullptr;
+    if (f16 && !p->bjobs.empty()) {
+        amax = (unsigned*)(scratch + gscale_word_offset(p, nt));
+        bmax = (const unsigned*)(stash + nh_stash_floats(p, nt));
+        rc = nh_zero_words(amax, NH_RMAX_WORDS, stream);
         if (rc) return rc;
     }
     if (bdg)
-        rc = f16 ? nh_mlp_dgrad_f16(p, packed, g_out, M, stash, scratch, gscale, stream)
+        rc = f16 ? nh_mlp_dgrad_f16(p, packed, g_out, M, stash, scratch, amax, stream)
                  : nh_mlp_dgrad_bf16(p, packed, g_out, M, stash, scratch, nullptr, stream);
     else
         rc = nh_mlp16_dgrad(p, packed, g_out, M, stash, scratch, stream);
     if (rc) return rc;
     float* const partial = scratch + (size_t)nt * (size_t)p->grad.total_rows * 32;
-    rc = nh_wgrad(p, nt, stash, scratch, partial, g_params, gscale, stream);
+    rc = nh_wgrad(p, nt, stash, scratch, partial, g_params, nullptr, stream);
     if (rc) return rc;
     // (level 4: the large blocks, behind the fp32 kernel's partials)
     float* const partial_b = partial + nh_wgrad_partial_floats(p, nt);
-    return f16 ? nh_wgrad_f16(p, nt, stash, scratch, partial_b, g_params, gscale, stream)
-               : nh_wgrad_bf16(p, nt, stash, scratch, partial_b, g_params, nullptr, stream);
+    return f16 ? nh_wgrad_f16(p, nt, stash, scratch, partial_b, g_params, amax, bmax, stream)
+               : nh_wgrad_bf16(p, nt, stash, scratch, partial_b, g_params, nullptr, nullptr, stream);
+}
+
+int nh_zero_words(unsigned* dev, int n, nerfhip_stream_t stream) {
+    NH_LAUNCH(k_zero_words, 1, 64, 0, stream, dev, n);
+    return nh_launch_status("zero_words");
 }
 
 extern "C" int64_t nerfhip_plan_bwd_scratch_bytes(nerfhip_plan_t plan, int64_t m) {
@@ -183,8 +172,7 @@ extern "C" int nerfhip_mlp_bwd_input(nerfhip_plan_t p, const float* params, int6
     a.nt = nh_ceil_div(m, 128) * 4;
     a.D = p->Dx + p->Dd;
     a.g_x = g_x;
-    // (the scratch of an fp16 data-gradient launch ends with its scale word: nh_mlp_backward)
-    a.gscale = (nh_prec_f16(p->precision) && nh_prec_level(p->precision) >= 3) ? (const unsigned*)((const float*)scratch + gscale_word_offset(p, a.nt)) : nullptr;
+    a.gscale = nullptr;  // (the d(pre-activation) images are plain values in every precision)
     NH_LAUNCH(k_mlp_input_grad, nh_ceil_div(m * a.D, 256), 256, 0, stream, a);
     return nh_launch_status("mlp_input_grad");
 }

@@ -28,8 +28,11 @@
 //     it into the next S and applies the difference as the one multiply the weight scale costs anyway.  Encodings carry an exponent
 //     of their own (from the sample's coordinates); a layer that reads both caps S at it and rescales the encoding pieces on the
 //     fly (v_pk_mul_f16).  Raw outputs and stash rows are brought back to plain fp32 values on the way out;
-//   * data gradient: the chain of a sample runs on its d(raw output) times a power of two of its own (nh_device.h), and the images
-//     it stores carry ONE power of two per launch (DgradBArgs::gscale), divided out by the weight-gradient reduction.
+//   * data gradient: the same bookkeeping -- the chain of a sample starts at its d(raw output) moved to [2^13, 2^14) and every
+//     layer's d(pre-activation) is renormalised per sample (whatever the transposed layers amplify or damp); the images it stores
+//     are plain fp32 values;
+//   * the producers record the largest magnitude they store per region (one atomicMax per wave and gemm: `rmax`), from which the
+//     fp16 weight-gradient kernel (wgrad_f16.hip) takes the power of two it splits that region's values at.
 #ifdef NHB_F16
 typedef nh_f16 nh_pc;
 typedef nh_f16x8 nh_pcx8;
@@ -119,6 +122,26 @@ NH_DEVICE void convert_tile(const f32x16& acc, nh_pcx8* oh, nh_pcx8* ol, float m
         }
 }
 
+// largest magnitude of eight stored values, and its way into the region's word: wave maximum, one atomic per wave
+NH_DEVICE float row_max8(float m, const float4& a, const float4& b) {
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+    return fmaxf(m, fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
+}
+NH_DEVICE void region_max_out(unsigned* rmax, float m) {
+    unsigned u;
+    memcpy(&u, &m, 4);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned o = (unsigned)nh_shfl_xor_i((int)u, d);
+        u = o > u ? o : u;
+    }
+    if (nh_lane() == 0 && u != 0u) nh_atomic_max_u32(rmax, u);
+}
+// accumulators (WS * 2^s_in * value) -> operand pieces of value * 2^s_out with the sample's largest magnitude moved to
+// [2^13, 2^14) (never above `cap`): the renormalisation step of the data-gradient chain (the forward's sits in gemm_b's epilogue)
+template <int NT>
+NH_DEVICE int renorm_convert(const f32x16* acc, nh_pcx8* oh, nh_pcx8* ol, int s_in, int cap);
+
 // bit pattern of the largest value the epilogue will convert (ReLU: of the positive ones; identity: of the magnitudes) over this
 // lane's tiles AND those of the other lane half of its sample (the two halves hold different units of the same sample)
 template <int NTE, bool RELU>
@@ -132,6 +155,23 @@ NH_DEVICE unsigned tile_max_bits(const f32x16* acc) {
     memcpy(&u, &m, 4);
     const unsigned o = (unsigned)nh_shfl_xor_i((int)u, 32);
     return u > o ? u : o;
+}
+
+template <int NT>
+NH_DEVICE int renorm_convert(const f32x16* acc, nh_pcx8* oh, nh_pcx8* ol, int s_in, int cap) {
+    float mul = NHB_INV_WS;
+    int so = 0;
+    if (NHB_IS_F16) {
+        const unsigned mb = tile_max_bits<NT, false>(acc);
+        const int base_e = NHB_WS_LOG2 + s_in;
+        so = base_e + nh_shift_to(mb, NHB_TARGET_LOG2);
+        so = so < cap ? so : cap;
+        so = so > base_e + 120 ? base_e + 120 : (so < base_e - 120 ? base_e - 120 : so);
+        mul = nh_pow2i(so - base_e);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) convert_tile<false>(acc[t], oh + 2 * t, ol + 2 * t, mul);
+    return so;
 }
 
 // EPI (0: none; 1: ReLU; 2: identity): the first NTE output tiles leave as the next layer's operand pieces oh / ol (k-blocks
@@ -156,10 +196,11 @@ template <int W, int NT, int NKA, int NKB, int EPI = 0, int NTE = 0, bool ROW_SC
 NH_DEVICE void gemm_b(BCtx& cx, const nh_pcx8* ah, const nh_pcx8* al, const nh_pcx8* xh, const nh_pcx8* xl, int64_t base,
                       int64_t next_base, int next_first, f32x16* acc, nh_pcx8* oh = nullptr, nh_pcx8* ol = nullptr,
                       float* in_rows = nullptr, unsigned* in_mask = nullptr, int s32 = 0, float row_scale = 1.0f, int s_in = 0,
-                      int s_x = 0, int cap = NHB_NO_CAP, int* s_out = nullptr) {
+                      int s_x = 0, int cap = NHB_NO_CAP, int* s_out = nullptr, unsigned* rmax = nullptr) {
     constexpr int NK = NKA + NKB, BUF = BShape<W>::BUF, CH = BShape<W>::CHUNK / (NT * 2048), NCH = (NK + CH - 1) / CH;
     static_assert(CH >= 1, "a k-block of every tile must fit one chunk buffer");
     int srow_next = 0;  // next input k-block whose rows go out
+    float smax = 0.0f;  // (rmax: the largest magnitude this lane stores)
     auto store_step = [&](int kb) {
         float4 a4, b4;
 #ifdef NHB_EXP_STASH_HI  // (diagnostic builds only, wrong results: what the hi + lo reconstruction costs)
@@ -179,6 +220,7 @@ NH_DEVICE void gemm_b(BCtx& cx, const nh_pcx8* ah, const nh_pcx8* al, const nh_p
             a4.x *= row_scale, a4.y *= row_scale, a4.z *= row_scale, a4.w *= row_scale;
             b4.x *= row_scale, b4.y *= row_scale, b4.z *= row_scale, b4.w *= row_scale;
         }
+        if (NHB_IS_F16 && rmax) smax = row_max8(smax, a4, b4);
         float* const dst = in_rows + 32 * (kb >> 1) + 16 * (kb & 1) + 4 * cx.h;  // units nhb_unit(kb, h, 0..3) and (kb, h, 4..7) = + 8
 #ifdef NHB_EXP_NO_STASH_STORE  // (diagnostic builds only, wrong results: what the stores themselves cost)
         if (a4.x == 1.2345e-30f && b4.y == 5.4321e-30f) nh_store4(dst, a4.x, a4.y, a4.z, a4.w);
@@ -298,6 +340,7 @@ NH_DEVICE void gemm_b(BCtx& cx, const nh_pcx8* ah, const nh_pcx8* al, const nh_p
         }
         cx.buf ^= 1;
     }
+    if (NHB_IS_F16 && rmax && in_rows && NKA > 0) region_max_out(rmax, smax);
     if (EPI != 0) {
         float mul = NHB_INV_WS;
         if (DYN) {
@@ -443,6 +486,7 @@ struct FwdBArgs {
     int Lx, Ld;
     float* out;
     float* stash;      // TRAIN launches: the activation stash of the fp32 backward kernels
+    unsigned* rmax;    // fp16 level-4 plans: per-region maxima of what the stash holds (H[k] -> k, FEAT -> L), else NULL
     NhStashLayout sl;
     int64_t nt;        // 32-sample tiles of the launch (4 per 128-sample group)
 };
@@ -534,10 +578,10 @@ NH_KERNEL void NH_LB(256, (TRAIN ? 1 : BShape<W>::WAVES_PER_SIMD)) NHB_KERNEL(k_
         const float rsc = RS ? nh_pow2i(-s) : 1.0f;  // (training, fp16 pieces: the stash rows are plain values)
         if (sk)
             gemm_b<W, TH, KBH, XB, 1, TH, RS, DYN>(cx, hh, hl, xh, xl, po.f_xyz[i] * 4, nxt, nfirst, acc, hh, hl, in_rows, in_mask, s32, rsc, s, ex,
-                                                   cap, &s);
+                                                   cap, &s, (TRAIN && a.rmax) ? a.rmax + i : nullptr);
         else
             gemm_b<W, TH, KBH, 0, 1, TH, RS, DYN>(cx, hh, hl, nullptr, nullptr, po.f_xyz[i] * 4, nxt, nfirst, acc, hh, hl, in_rows, in_mask, s32, rsc,
-                                                  s, s, cap, &s);
+                                                  s, s, cap, &s, (TRAIN && a.rmax) ? a.rmax + i : nullptr);
     }
     if (VIEW) {
         nh_pcx8 dh[DB], dl[DB];
@@ -555,11 +599,11 @@ NH_KERNEL void NH_LB(256, (TRAIN ? 1 : BShape<W>::WAVES_PER_SIMD)) NHB_KERNEL(k_
         const int s_head = s;  // (the head's inputs: fc_alpha's raw row comes out at WS * 2^s_head)
         gemm_b<W, TH + 1, KBH, 0, 1, TH, RS, DYN>(cx, hh, hl, nullptr, nullptr, po.f_head * 4, po.f_dir * 4, first(KBH + DB, TH / 2), acc, hh, hl,
                                                   TRAIN ? srow(a.sl.H[a.L - 1], W) : nullptr, (TRAIN && a.L > 1) ? smask(a.L - 2) : nullptr, s32,
-                                                  RS ? nh_pow2i(-s) : 1.0f, s, s, ed, &s);
+                                                  RS ? nh_pow2i(-s) : 1.0f, s, s, ed, &s, (TRAIN && a.rmax) ? a.rmax + (a.L - 1) : nullptr);
         const float alpha = nhb_raw(acc[TH][0], s_head);
         gemm_b<W, TH / 2, KBH, DB, 1, TH / 2, RS, DYN>(cx, hh, hl, dh, dl, po.f_dir * 4, po.f_rgb * 4, first(KBH / 2, 1), acc, hh, hl,
                                                        TRAIN ? srow(a.sl.FEAT, W) : nullptr, TRAIN ? smask(a.L - 1) : nullptr, s32,
-                                                       RS ? nh_pow2i(-s) : 1.0f, s, ed, NHB_NO_CAP, &s);
+                                                       RS ? nh_pow2i(-s) : 1.0f, s, ed, NHB_NO_CAP, &s, (TRAIN && a.rmax) ? a.rmax + a.L : nullptr);
         gemm_b<W, 1, KBH / 2, 0, 0, 0, RS, DYN>(cx, hh, hl, nullptr, nullptr, po.f_rgb * 4, po.f_layer1 * 4, again ? first(XB, TH) : 0, acc, nullptr,
                                                 nullptr, TRAIN ? srow(a.sl.DIRH, W / 2) : nullptr, TRAIN ? smask(a.L) : nullptr, s32,
                                                 RS ? nh_pow2i(-s) : 1.0f, s, s);
@@ -574,7 +618,8 @@ NH_KERNEL void NH_LB(256, (TRAIN ? 1 : BShape<W>::WAVES_PER_SIMD)) NHB_KERNEL(k_
     } else {
         gemm_b<W, 1, KBH, 0, 0, 0, RS, DYN>(cx, hh, hl, nullptr, nullptr, po.f_head * 4, po.f_layer1 * 4, again ? first(XB, TH) : 0, acc, nullptr,
                                             nullptr, TRAIN ? srow(a.sl.H[a.L - 1], W) : nullptr, (TRAIN && a.L > 1) ? smask(a.L - 2) : nullptr, s32,
-                                            RS ? nh_pow2i(-s) : 1.0f, s, s);  // fc_out (models.py:256)
+                                            RS ? nh_pow2i(-s) : 1.0f, s, s, NHB_NO_CAP, nullptr,
+                                            (TRAIN && a.rmax) ? a.rmax + (a.L - 1) : nullptr);  // fc_out (models.py:256)
         if (valid && h == 0) {
             float4 r4;
             r4.x = nhb_raw(acc[0][0], s);
@@ -604,7 +649,7 @@ struct DgradBArgs {
     NhStashLayout sl;
     float* grad;
     NhGradLayout gl;
-    const unsigned* gscale;  // fp16 pieces: device word holding the bits of max|g_out| (nh_gscale_of); NULL: no scaling
+    unsigned* rmax;  // fp16 level-4 plans: per-region maxima of the images written (P[k] -> k, PFEAT -> L, PDIR -> L + 1), else NULL
 };
 
 // zero the accumulators whose ReLU bit is 0: unit 32 t + 8 j + 4 h + i is register r = 4 (2 t + (j >> 1)) + i of lane g = 2 (j & 1) + h
@@ -648,24 +693,12 @@ NH_KERNEL void NH_LB(256, 1) NHB_KERNEL(k_mlp_dgrad)(DgradBArgs a) {
         const int64_t m = grp * 128 + cx.wave * 32 + s32;
         const int64_t tile32 = grp * 4 + cx.wave;
         float go[4] = {0.f, 0.f, 0.f, 0.f};  // d(raw output) of this lane's sample (zero beyond M: nothing flows)
-        // fp16 pieces: this sample's chain runs on its cotangent times a power of two of its own (max |d(raw output)| of the sample
-        // to 2^6: fp32-like relative precision however small the cotangent); what is STORED carries the launch's one power of
-        // two instead (rs = launch scale / sample scale), which the weight-gradient reduction divides out again
-        float rs = 1.0f;
         if (m < a.M) {
             const float4 t4 = *(const float4*)(a.g_out + (size_t)m * 4);
-            float ss = 1.0f;
-            if (NHB_IS_F16 && a.gscale) {
-                unsigned u0, u1, u2, u3;
-                memcpy(&u0, &t4.x, 4), memcpy(&u1, &t4.y, 4), memcpy(&u2, &t4.z, 4), memcpy(&u3, &t4.w, 4);
-                u0 &= 0x7fffffffu, u1 &= 0x7fffffffu, u2 &= 0x7fffffffu, u3 &= 0x7fffffffu;
-                const unsigned mb = (u0 > u1 ? u0 : u1) > (u2 > u3 ? u2 : u3) ? (u0 > u1 ? u0 : u1) : (u2 > u3 ? u2 : u3);
-                const int es = nh_pow2_to(mb, NH_GSCALE_SAMPLE_LOG2), er = nh_pow2_to(*a.gscale, NH_GSCALE_LAUNCH_LOG2) - es + 127;
-                ss = nh_pow2_float(es);
-                rs = er >= 1 ? nh_pow2_float(er < 254 ? er : 254) : 0.0f;  // (a cotangent 2^-126 below the launch's largest: stored as 0)
-            }
-            go[0] = t4.x * ss, go[1] = t4.y * ss, go[2] = t4.z * ss, go[3] = t4.w * ss;
+            go[0] = t4.x, go[1] = t4.y, go[2] = t4.z, go[3] = t4.w;
         }
+        // fp16 pieces: the per-sample exponent of the chain (file header).  s: of the current d(pre-activation) pieces
+        int s = 0;
         auto grow = [&](const NhRegion& R, int rows) -> float* {
             return a.grad + (size_t)32 * (size_t)a.nt * (size_t)R.row_prefix + ((size_t)tile32 * 32 + (size_t)s32) * (size_t)rows;
         };
@@ -684,7 +717,7 @@ NH_KERNEL void NH_LB(256, 1) NHB_KERNEL(k_mlp_dgrad)(DgradBArgs a) {
             float* const pr = grow(a.gl.POUT, 32) + 16 * h;
             float4 z4, g4;
             z4.x = z4.y = z4.z = z4.w = 0.0f;
-            g4.x = h == 0 ? go[0] * rs : 0.0f, g4.y = h == 0 ? go[1] * rs : 0.0f, g4.z = h == 0 ? go[2] * rs : 0.0f, g4.w = h == 0 ? go[3] * rs : 0.0f;
+            g4.x = h == 0 ? go[0] : 0.0f, g4.y = h == 0 ? go[1] : 0.0f, g4.z = h == 0 ? go[2] : 0.0f, g4.w = h == 0 ? go[3] : 0.0f;
             *(float4*)pr = g4;
             *(float4*)(pr + 4) = z4;
             *(float4*)(pr + 8) = z4;
@@ -700,30 +733,44 @@ NH_KERNEL void NH_LB(256, 1) NHB_KERNEL(k_mlp_dgrad)(DgradBArgs a) {
                 v[0] = go[0], v[1] = go[1], v[2] = go[2];
                 if (!VIEW) v[3] = go[3];
             }
-            put_block(d1h[0], d1l[0], v, nullptr);
+            if (NHB_IS_F16) {  // (both lane halves of the sample agree: they loaded the same cotangent)
+                const float mg = fmaxf(fmaxf(fabsf(go[0]), fabsf(go[1])), fmaxf(fabsf(go[2]), VIEW ? 0.0f : fabsf(go[3])));
+                unsigned ub;
+                memcpy(&ub, &mg, 4);
+                s = nh_shift_to(ub, NHB_TARGET_LOG2);
+            }
+            put_block(d1h[0], d1l[0], v, nullptr, nh_pow2i(s));
         }
+        unsigned* const rm = NHB_IS_F16 ? a.rmax : nullptr;
         if (VIEW) {
             gemm_b<W, TH / 2, 0, 1>(cx, nullptr, nullptr, d1h, d1l, po.b_rgb * 4, po.b_dir * 4, first(KBH / 2, TH), acc);
             get_mask(L, mw);  // DIRH
             gate_tiles<TH / 2>(acc, mw);
-#pragma unroll
-            for (int t = 0; t < TH / 2; ++t) convert_tile<false>(acc[t], hh + 2 * t, hl + 2 * t, NHB_INV_WS);
+            s = renorm_convert<TH / 2>(acc, hh, hl, s, NHB_NO_CAP);
             gemm_b<W, TH, KBH / 2, 0, 0, 0, NHB_IS_F16>(cx, hh, hl, nullptr, nullptr, po.b_dir * 4, po.b_head * 4, first(KBH + 1, TH), acc, nullptr,
-                                                        nullptr, grow(a.gl.PDIR, W / 2), nullptr, 0, rs);
+                                                        nullptr, grow(a.gl.PDIR, W / 2), nullptr, 0, nh_pow2i(-s), s, s, NHB_NO_CAP, nullptr,
+                                                        rm ? rm + (L + 1) : nullptr);
             get_mask(L - 1, mw);  // FEAT
             gate_tiles<TH>(acc, mw);
-#pragma unroll
-            for (int t = 0; t < TH; ++t) convert_tile<false>(acc[t], hh + 2 * t, hl + 2 * t, NHB_INV_WS);
+            // (d(sigma raw) joins the next gemm as a k-block of its own at the same exponent: it must fit)
+            int cap_sigma = NHB_NO_CAP;
+            if (NHB_IS_F16 && go[3] != 0.0f) {
+                const float ag = fabsf(go[3]);
+                unsigned ub;
+                memcpy(&ub, &ag, 4);
+                if (((ub >> 23) & 255u) != 0u) cap_sigma = nh_shift_to(ub, NHB_TARGET_LOG2);
+            }
+            s = renorm_convert<TH>(acc, hh, hl, s, cap_sigma);
             nh_pcx8 dah[1], dal[1];  // d(sigma raw) enters through fc_alpha's column (k-block KBH, half 0, element 0)
             {
                 float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 if (h == 0) v[0] = go[3];
-                put_block(dah[0], dal[0], v, nullptr);
+                put_block(dah[0], dal[0], v, nullptr, nh_pow2i(s));
             }
             const bool last = L == 1;
             gemm_b<W, TH, KBH, 1, 0, 0, NHB_IS_F16>(cx, hh, hl, dah, dal, po.b_head * 4, last ? first_img : po.b_xyz[L > 1 ? L - 2 : 0] * 4,
                                                     last ? (again ? first_bytes : 0) : first(KBH, TH), acc, nullptr, nullptr, grow(a.gl.PFEAT, W),
-                                                    nullptr, 0, rs);
+                                                    nullptr, 0, nh_pow2i(-s), s, s, NHB_NO_CAP, nullptr, rm ? rm + L : nullptr);
         } else {
             const bool last = L == 1;
             gemm_b<W, TH, 0, 1>(cx, nullptr, nullptr, d1h, d1l, po.b_head * 4, last ? first_img : po.b_xyz[L > 1 ? L - 2 : 0] * 4,
@@ -734,19 +781,17 @@ NH_KERNEL void NH_LB(256, 1) NHB_KERNEL(k_mlp_dgrad)(DgradBArgs a) {
             get_mask(L - 2, mw);
             gate_tiles<TH>(acc, mw);
         }
-#pragma unroll
-        for (int t = 0; t < TH; ++t) convert_tile<false>(acc[t], hh + 2 * t, hl + 2 * t, NHB_INV_WS);
+        s = renorm_convert<TH>(acc, hh, hl, s, NHB_NO_CAP);
         for (int k = L - 1; k >= 1; --k) {
             const bool last = k == 1;
             gemm_b<W, TH, KBH, 0, 0, 0, NHB_IS_F16>(cx, hh, hl, nullptr, nullptr, po.b_xyz[k - 1] * 4, last ? first_img : po.b_xyz[k >= 2 ? k - 2 : 0] * 4,
                                                     last ? (again ? first_bytes : 0) : first(KBH, TH), acc, nullptr, nullptr, grow(a.gl.P[k], W),
-                                                    nullptr, 0, rs);
+                                                    nullptr, 0, nh_pow2i(-s), s, s, NHB_NO_CAP, nullptr, rm ? rm + k : nullptr);
             if (k - 1 >= 1) {
                 get_mask(k - 2, mw);  // H_{k-1}
                 gate_tiles<TH>(acc, mw);
             }
-#pragma unroll
-            for (int t = 0; t < TH; ++t) convert_tile<false>(acc[t], hh + 2 * t, hl + 2 * t, NHB_INV_WS);
+            s = renorm_convert<TH>(acc, hh, hl, s, NHB_NO_CAP);
         }
         {  // d(pre-activation) of layer1: no gemm consumes it -- stored here (hi + lo, as every other image)
             float* const pr = grow(a.gl.P[0], W);
@@ -762,6 +807,7 @@ NH_KERNEL void NH_LB(256, 1) NHB_KERNEL(k_mlp_dgrad)(DgradBArgs a) {
                 b4.z = nh_from_pc(hh[kb][6]) + nh_from_pc(hl[kb][6]);
                 b4.w = nh_from_pc(hh[kb][7]) + nh_from_pc(hl[kb][7]);
                 if (NHB_IS_F16) {
+                    const float rs = nh_pow2i(-s);
                     a4.x *= rs, a4.y *= rs, a4.z *= rs, a4.w *= rs;
                     b4.x *= rs, b4.y *= rs, b4.z *= rs, b4.w *= rs;
                 }
@@ -847,6 +893,12 @@ int NHB_FN(nh_mlp_forward)(nerfhip_plan* p, const float* packed, const NhMlpInpu
     a.skip = p->skip;
     a.M = M;
     a.stash = stash;
+    // (fp16 plans whose large weight-gradient blocks run on the fp16 MFMAs: the stash's region maxima, zeroed here)
+    a.rmax = (NHB_IS_F16 && stash && !p->bjobs.empty()) ? (unsigned*)(stash + nh_stash_floats(p, nh_ceil_div(M, 128) * 4)) : nullptr;
+    if (a.rmax) {
+        const int rc0 = nh_zero_words(a.rmax, NH_RMAX_WORDS, stream);
+        if (rc0) return rc0;
+    }
     a.sl = p->stash;
     a.nt = nh_ceil_div(M, 128) * 4;
     a.mode = in.mode;
@@ -903,7 +955,7 @@ int NHB_FN(nh_mlp_forward)(nerfhip_plan* p, const float* packed, const NhMlpInpu
 }
 
 int NHB_FN(nh_mlp_dgrad)(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
-                         const unsigned* gscale, nerfhip_stream_t stream) {
+                         unsigned* rmax, nerfhip_stream_t stream) {
     DgradBArgs d;
     memset(&d, 0, sizeof(d));
     d.packed = packed;
@@ -918,7 +970,7 @@ int NHB_FN(nh_mlp_dgrad)(nerfhip_plan* p, const float* packed, const float* g_ou
     d.sl = p->stash;
     d.grad = scratch;
     d.gl = p->grad;
-    d.gscale = gscale;
+    d.rmax = rmax;
     const int64_t resident = b_compute_units();  // (one wave per SIMD: one workgroup per CU also for the 128-wide nets)
     const int64_t grid = d.groups < resident ? d.groups : resident;
     int rc = NERFHIP_OK;

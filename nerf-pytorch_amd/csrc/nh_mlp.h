@@ -25,30 +25,34 @@ int nh_mlp16_dgrad(nerfhip_plan* p, const float* packed, const float* g_out, int
                    nerfhip_stream_t stream);
 
 // mlp_bf16.hip (bf16 pieces) and the same source through mlp_f16.hip (fp16 pieces): forward (with / without stash) and
-// data-gradient chain of the split-precision plans; gscale (fp16 chain): device word with the bits of max|g_out|, or NULL
+// data-gradient chain of the split-precision plans; rmax (fp16, level-4 plans): NH_RMAX_WORDS zeroed device words for the region maxima, or NULL
 int nh_mlp_forward_bf16(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
                         nerfhip_stream_t stream);
 int nh_mlp_dgrad_bf16(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
-                      const unsigned* gscale, nerfhip_stream_t stream);
+                      unsigned* rmax, nerfhip_stream_t stream);
 int nh_pack_pieces_bf16(nerfhip_plan* plan, const float* params, const int32_t* table, float* packed, nerfhip_stream_t stream);
 int nh_mlp_forward_f16(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
                        nerfhip_stream_t stream);
 int nh_mlp_dgrad_f16(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
-                     const unsigned* gscale, nerfhip_stream_t stream);
+                     unsigned* rmax, nerfhip_stream_t stream);
+// mlp.hip: n words of device memory to zero, on the stream
+int nh_zero_words(unsigned* dev, int n, nerfhip_stream_t stream);
 int nh_pack_pieces_f16(nerfhip_plan* plan, const float* params, const int32_t* table, float* packed, nerfhip_stream_t stream);
 
 // wgrad.hip: split-K weight-gradient GEMMs over the stash / d(pre-activation) images (nt = 32-sample tiles) + reduction
 int64_t nh_wgrad_partial_floats(nerfhip_plan* p, int64_t nt);
-// gscale (fp16 data-gradient chains): device word with the bits of max|g_out| -- the reduction multiplies by nh_gscale_inv --, or NULL
+// gscale: a device word with the bits of a maximum the images were scaled by (nh_gscale_of; the reduction multiplies by
+// nh_gscale_inv), or NULL (every precision stores plain values today)
 int nh_wgrad(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad, float* partial, float* g_params,
              const unsigned* gscale, nerfhip_stream_t stream);
 
 // wgrad_bf16.hip / wgrad_f16.hip: the large weight blocks of level-4 plans (plan->bjobs) on the 16-bit MFMAs
 int64_t nh_wgrad_x3_partial_floats(nerfhip_plan* p, int64_t nt);
+// amax / bmax (fp16): the region maxima recorded by the data-gradient / forward launch that wrote `grad` / `stash`, or NULL
 int nh_wgrad_bf16(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad, float* partial, float* g_params,
-                  const unsigned* gscale, nerfhip_stream_t stream);
+                  const unsigned* amax, const unsigned* bmax, nerfhip_stream_t stream);
 int nh_wgrad_f16(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad, float* partial, float* g_params,
-                 const unsigned* gscale, nerfhip_stream_t stream);
+                 const unsigned* amax, const unsigned* bmax, nerfhip_stream_t stream);
 
 // render.hip: compositing backward with the optional dL/d||rd|| output, and the gradient w.r.t. the packed rays
 int nh_volume_render_bwd(const float* raw, const float* z, const float* rd, int rd_stride, int64_t n, int s, float noise_std,

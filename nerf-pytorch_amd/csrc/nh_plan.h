@@ -88,6 +88,10 @@ struct NhPackedOffsets {
     int64_t b_xyz[NH_MAX_LAYERS];
 };
 
+// Words behind a training stash / a backward scratch in which the fp16 kernels record the largest magnitude stored per region
+// (mlp_bf16.hip `rmax`; indices: H[k] / P[k] -> k, FEAT / PFEAT -> L, DIRH / PDIR -> L + 1): zeroed before the producing launch
+constexpr int NH_RMAX_WORDS = 64;
+
 // Activation stash regions: [tiles][32 samples][rows] each, `row_prefix` rows precede it inside a tile group.
 // 512-wide nets: a 512-row activation is stored as TWO consecutive 256-row regions (rows 0..255 at row_prefix, rows
 // 256..511 at row_prefix + 256; NhRegion::rows == 256 names the first half): the weight-gradient kernel reads whole
@@ -138,6 +142,7 @@ struct NhJob {
 // A weight block whose gradient the split-bf16 weight-gradient kernel computes (NERFHIP_PRECISION_BF16X3_TRAIN; wgrad_bf16.hip):
 // dW[r][c] = sum_samples A[r][s] B[c][s] for r < r_hi, c < col_count, written to w_off + r * w_ld + c; bias = row sums of A.
 struct NhJobB {
+    int a_idx, b_idx;                    // the regions' slots among the recorded maxima (NH_RMAX_WORDS)
     int a_rows, b_rows;                  // rows of the A region (d(pre-activation) image) and of the B region (activation stash)
     int64_t a_row_prefix, b_row_prefix;  // region offsets = 32 * n_tiles * prefix floats
     int r_hi, col_count, w_ld;
@@ -172,3 +177,7 @@ struct nerfhip_plan {
     int wgrad_waves;         // waves per workgroup of the weight-gradient kernel: 8 (256- and 512-wide nets) or 4 (narrower)
     bool is_skip(int i) const { return i % skip == 0 && i > 0; }
 };
+// floats of a training stash of `tiles` 32-sample tiles: the row regions, then the ReLU masks (the region maxima follow)
+static inline int64_t nh_stash_floats(const nerfhip_plan* p, int64_t tiles) {
+    return tiles * (p->stash.total_rows * 32 + (int64_t)p->stash.n_masks * 128 * nh16_mask_words(p->W));
+}

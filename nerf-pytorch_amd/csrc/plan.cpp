@@ -591,8 +591,10 @@ void build_layouts_and_jobs(nerfhip_plan* p) {
     // (256-wide nets only: for the 128 x 128 blocks of narrower nets the conversion outweighs the MFMAs -- measured on MI355X:
     // 4x128 step 4.23 -> 5.04 ms -- so there BF16X3_TRAIN is BF16X3_FWD_DGRAD)
     const bool big_b = nh_prec_level(p->precision) == 4 && W >= 256;
-    auto add_big = [&](const NhRegion& A, int a_rows, const NhRegion& B, int r_hi, int w_tensor, int bias_tensor) {
+    auto add_big = [&](const NhRegion& A, int a_rows, const NhRegion& B, int r_hi, int w_tensor, int bias_tensor, int a_idx, int b_idx) {
         NhJobB j;
+        j.a_idx = a_idx;
+        j.b_idx = b_idx;
         j.a_rows = a_rows;
         j.b_rows = W;
         j.a_row_prefix = A.row_prefix;
@@ -608,19 +610,19 @@ void build_layouts_and_jobs(nerfhip_plan* p) {
     add_job(p, G.P[0], TW, S.X, 0, p->krx / 8, 0, H, p->t_layer1_w, 1, 0, p->Dx, p->t_layer1_b);
     for (int i = 0; i < L - 1; ++i) {
         if (big_b)
-            add_big(G.P[i + 1], W, S.H[i], H, p->t_xyz_w[i], p->t_xyz_b[i]);
+            add_big(G.P[i + 1], W, S.H[i], H, p->t_xyz_w[i], p->t_xyz_b[i], i + 1, i);
         else
             add_job(p, G.P[i + 1], TW, S.H[i], 0, TW, 0, H, p->t_xyz_w[i], 0, 0, H, p->t_xyz_b[i]);
         if (p->is_skip(i)) add_job(p, G.P[i + 1], TW, S.X, 0, p->krx / 8, 0, H, p->t_xyz_w[i], 1, H, p->Dx, -1);
     }
     if (p->view) {
         if (big_b)
-            add_big(G.PFEAT, W, S.H[L - 1], H, p->t_feat_w, p->t_feat_b);
+            add_big(G.PFEAT, W, S.H[L - 1], H, p->t_feat_w, p->t_feat_b, L, L - 1);
         else
             add_job(p, G.PFEAT, TW, S.H[L - 1], 0, TW, 0, H, p->t_feat_w, 0, 0, H, p->t_feat_b);
         add_job(p, G.POUT, 1, S.H[L - 1], 0, TW, 3, 4, p->t_alpha_w, 0, 0, H, p->t_alpha_b);
         if (big_b)
-            add_big(G.PDIR, W / 2, S.FEAT, H2, p->t_dir_w, p->t_dir_b);
+            add_big(G.PDIR, W / 2, S.FEAT, H2, p->t_dir_w, p->t_dir_b, L + 1, L);
         else
             add_job(p, G.PDIR, TW / 2, S.FEAT, 0, TW, 0, H2, p->t_dir_w, 0, 0, H, p->t_dir_b);
         add_job(p, G.PDIR, TW / 2, S.D, 0, p->krd / 8, 0, H2, p->t_dir_w, 2, H, p->Dd, -1);
@@ -837,6 +839,6 @@ extern "C" int nerfhip_plan_set_freqs(nerfhip_plan_t plan, const float* freqs_xy
 extern "C" int64_t nerfhip_plan_stash_bytes(nerfhip_plan_t plan, int64_t m) {
     if (!plan || m < 0) return -1;
     int64_t tiles = nh_ceil_div(m, 128) * 4;
-    // per 32-sample tile: the row regions, then the ReLU masks of its two 16-sample wave tiles
-    return tiles * (plan->stash.total_rows * 32 + (int64_t)plan->stash.n_masks * 128 * nh16_mask_words(plan->W)) * (int64_t)sizeof(float);
+    // per 32-sample tile: the row regions, then the ReLU masks of its two 16-sample wave tiles; behind them the region maxima
+    return (nh_stash_floats(plan, tiles) + NH_RMAX_WORDS) * (int64_t)sizeof(float);
 }

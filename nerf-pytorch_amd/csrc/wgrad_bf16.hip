@@ -19,8 +19,10 @@
 #include "nh_device.h"
 #include "nh_mlp.h"
 
-// (compiled twice, like mlp_bf16.hip: as is for the bf16x3 plans and through wgrad_f16.hip -- NHB_F16 -- for the f16x3 plans, whose
-// d(pre-activation) images carry the launch's power-of-two gradient scale: WgBArgs::gscale, divided out by the reduction)
+// (compiled twice, like mlp_bf16.hip: as is for the bf16x3 plans and through wgrad_f16.hip -- NHB_F16 -- for the f16x3 plans.  fp16's
+// range: the values of a block's A region (d(pre-activation): 1e-3 ... 1e-12, and whatever the transposed layers amplify) and of its
+// B region are multiplied, BEFORE they are split, by the power of two that moves the region's largest magnitude -- recorded by the
+// launch that wrote it, WgBArgs::amax / bmax -- to [2^14, 2^15); the reduction divides the two out again (exact).)
 #ifdef NHB_F16
 typedef nh_f16 nh_pc;
 typedef nh_f16x8 nh_pcx8;
@@ -30,6 +32,7 @@ typedef nh_f16x8 nh_pcx8;
 #define NHB_FMT "f16"
 #define NHB_FN(stem) stem##_f16
 #define NHB_KERNEL(stem) stem##_f16x3
+constexpr bool NHB_IS_F16 = true;
 #else
 typedef nh_bf16 nh_pc;
 typedef nh_bf16x8 nh_pcx8;
@@ -39,6 +42,7 @@ typedef nh_bf16x8 nh_pcx8;
 #define NHB_FMT "bf16"
 #define NHB_FN(stem) stem##_bf16
 #define NHB_KERNEL(stem) stem##_bf16x3
+constexpr bool NHB_IS_F16 = false;
 #endif
 
 namespace {
@@ -58,6 +62,7 @@ struct WgBJob {
     int wg0, nwg;          // this block's workgroups [wg0, wg0 + nwg)
     int r_hi, col_count, w_ld;
     int64_t w_off, bias_off;
+    int a_idx, b_idx;      // slots of the two regions among the recorded maxima
 };
 struct WgBArgs {
     const float* stash;
@@ -66,8 +71,8 @@ struct WgBArgs {
     float* g_params;
     int64_t nt;
     int njobs, part_stride;  // floats per workgroup partial: AR * BR accumulators + 256 bias sums
-    const unsigned* gscale;  // device word: bits of max|g_out| of the data-gradient launch that wrote `grad` (fp16 chain), or NULL
-    float w_unscale;         // a constant factor on the weight gradients (1: the stash rows are plain values)
+    const unsigned* amax;    // fp16: region maxima recorded by the data-gradient launch that wrote `grad` (bit patterns), or NULL
+    const unsigned* bmax;    // fp16: ... by the forward launch that wrote `stash`, or NULL
     WgBJob jobs[NHW_MAX_JOBS];
 };
 
@@ -101,8 +106,9 @@ NH_DEVICE void rows_load(const float* stage, int tid, RowItems<ROWS>& r) {
         for (int e = 0; e < 8; ++e) r.v[it][e] = on ? stage[(8 * q + e) * ROWS + row] : 0.0f;
     }
 }
+// (scale, fp16: the region's power of two -- applied to what is split, not to the bias sum)
 template <int ROWS>
-NH_DEVICE float rows_store(const RowItems<ROWS>& r, char* hi_blocks, char* lo_blocks, int tid) {
+NH_DEVICE float rows_store(const RowItems<ROWS>& r, char* hi_blocks, char* lo_blocks, int tid, float scale) {
     float sum = 0.0f;
 #pragma unroll
     for (int it = 0; it < RowItems<ROWS>::N; ++it) {
@@ -112,8 +118,9 @@ NH_DEVICE float rows_store(const RowItems<ROWS>& r, char* hi_blocks, char* lo_bl
         nh_pcx8 h8, l8;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float v = r.v[it][e];
+            float v = r.v[it][e];
             sum += v;
+            if (NHB_IS_F16) v *= scale;
             const nh_pc hi = nh_to_pc(v);
             h8[e] = hi;
             l8[e] = nh_to_pc(v - nh_from_pc(hi));
@@ -144,6 +151,8 @@ NH_KERNEL void NH_LB(NHW_THREADS, NHW_WAVES / 4) NHB_KERNEL(k_wgrad)(WgBArgs a) 
     const int64_t u0 = 2 * (a.nt * k / jb.nwg), u1 = 2 * (a.nt * (k + 1) / jb.nwg);
     const float* const a_reg = a.grad + jb.a_off;
     const float* const b_reg = a.stash + jb.b_off;
+    const float a_scale = (NHB_IS_F16 && a.amax) ? nh_pow2i(nh_shift_to(a.amax[jb.a_idx], 14)) : 1.0f;
+    const float b_scale = (NHB_IS_F16 && a.bmax) ? nh_pow2i(nh_shift_to(a.bmax[jb.b_idx], 14)) : 1.0f;
     const unsigned lds0 = nh_lds_addr((const float*)lds);
     auto issue = [&](int64_t u) {  // one step of both regions -> stage u & 1: 1-KiB pieces dealt to the four waves
         const NhDmaSrc da = nh_dma_src(a_reg + (size_t)u * 16 * AR, (unsigned)S::STAGE_A);
@@ -181,8 +190,8 @@ NH_KERNEL void NH_LB(NHW_THREADS, NHW_WAVES / 4) NHB_KERNEL(k_wgrad)(WgBArgs a) 
         rows_load<AR>((const float*)stage, tid, ra);
         rows_load<BR>((const float*)(stage + S::STAGE_A), tid, rb);
         nh_sched_fence();
-        bias += rows_store<AR>(ra, ah_blk, al_blk, tid);
-        (void)rows_store<BR>(rb, bh_blk, bl_blk, tid);
+        bias += rows_store<AR>(ra, ah_blk, al_blk, tid, a_scale);
+        (void)rows_store<BR>(rb, bh_blk, bl_blk, tid, b_scale);
         nh_block_sync();  // operand blocks complete; this step's stage is free
         if (u + NHW_STAGES < u1) issue(u + NHW_STAGES);  // (into the stage just converted)
         nh_pcx8 ah[PO], al[PO], bh[PI], bl[PI];
@@ -230,7 +239,8 @@ NH_KERNEL void NHB_KERNEL(k_wgrad_reduce)(WgBArgs a) {
     const int jq = (int)blockIdx.x / GX;
     const WgBJob& jb = a.jobs[jq];
     const int e = ((int)blockIdx.x % GX) * 256 + (int)threadIdx.x;
-    const float unscale = a.gscale ? nh_gscale_inv(*a.gscale) : 1.0f;  // (a power of two: exact)
+    // (the powers of two the kernel split this block's regions at: exact to divide out)
+    const float unscale = (NHB_IS_F16 && a.amax && a.bmax) ? nh_pow2i(-nh_shift_to(a.amax[jb.a_idx], 14) - nh_shift_to(a.bmax[jb.b_idx], 14)) : 1.0f;
     if (e < E) {
         const int tile = e >> 10, c = (e >> 6) & 15, l = e & 63;
         const int row = 32 * (tile / TB) + (c & 3) + 8 * (c >> 2) + 4 * (l >> 5), col = 32 * (tile % TB) + (l & 31);
@@ -245,7 +255,7 @@ NH_KERNEL void NHB_KERNEL(k_wgrad_reduce)(WgBArgs a) {
                 for (int q = 0; q < 8; ++q) s8[q] += src[(size_t)(k + q) * (size_t)a.part_stride];
             }
             for (int q = 0; k < jb.nwg; ++k, ++q) s8[q] += src[(size_t)k * (size_t)a.part_stride];
-            a.g_params[jb.w_off + (int64_t)row * jb.w_ld + col] = (((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]))) * (unscale * a.w_unscale);
+            a.g_params[jb.w_off + (int64_t)row * jb.w_ld + col] = (((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]))) * unscale;
         }
     } else if (e < E + AR) {  // bias: thread t of every workgroup summed row t mod AR
         const int row = e - E;
@@ -263,7 +273,7 @@ NH_KERNEL void NHB_KERNEL(k_wgrad_reduce)(WgBArgs a) {
             for (int q = 0; k < jb.nwg; ++k, ++q)
 #pragma unroll
                 for (int t = 0; t < NHW_THREADS; t += AR) s8[q] += src[(size_t)k * (size_t)a.part_stride + t];
-            a.g_params[jb.bias_off + row] = (((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]))) * unscale;
+            a.g_params[jb.bias_off + row] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));  // (sums of plain values)
         }
     }
 }
@@ -319,6 +329,8 @@ int64_t schedule(nerfhip_plan* p, int64_t nt, WgBArgs* full, WgBArgs* half) {
                 d.w_ld = j.w_ld;
                 d.w_off = j.w_off;
                 d.bias_off = j.bias_off;
+                d.a_idx = j.a_idx;
+                d.b_idx = j.b_idx;
             }
             ++n;
             wg += (int)nwg;
@@ -358,7 +370,7 @@ int64_t nh_wgrad_x3_partial_floats(nerfhip_plan* p, int64_t nt) {
 #endif
 
 int NHB_FN(nh_wgrad)(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad, float* partial, float* g_params,
-                     const unsigned* gscale, nerfhip_stream_t stream) {
+                     const unsigned* amax, const unsigned* bmax, nerfhip_stream_t stream) {
     if (p->bjobs.empty()) return NERFHIP_OK;
     NH_REQUIRE((int)p->bjobs.size() <= NHW_MAX_JOBS, "wgrad_bf16: too many blocks");
     WgBArgs full, half;
@@ -368,8 +380,8 @@ int NHB_FN(nh_wgrad)(nerfhip_plan* p, int64_t nt, const float* stash, const floa
     full.stash = half.stash = stash;
     full.grad = half.grad = grad;
     full.g_params = half.g_params = g_params;
-    full.gscale = half.gscale = gscale;
-    full.w_unscale = half.w_unscale = 1.0f;
+    full.amax = half.amax = amax;
+    full.bmax = half.bmax = bmax;
     full.partial = partial;
     // (the second launch's partials follow the first's)
     int64_t first = 0;

@@ -242,9 +242,11 @@ def case_sample_pdf(b):
 
 
 # ---- MLP ---------------------------------------------------------------------------------------------------------------
-def mlp_setup(b, cfg, seed, precision=0):
+def mlp_setup(b, cfg, seed, precision=0, w_gain=1.0):
     plan = b.make_plan(cfg, precision)
     params = O.init_params(cfg, seed=seed)
+    if w_gain != 1.0:  # (weights w_gain times torch's default init: activations and gradients grow by that factor per layer)
+        params = {k: (v * w_gain if k.endswith("weight") else v) for k, v in params.items()}
     flat = b.flatten_params(plan, {k: v.numpy() for k, v in params.items()})
     packed = b.pack(plan, flat)
     return plan, params, flat, packed
@@ -385,7 +387,7 @@ def case_mlp_golden(b):
         b.lib.plan_destroy(plan)
 
 
-def case_mlp_backward(b, names=None, m=150, precision=0, g_scale=1.0):
+def case_mlp_backward(b, names=None, m=150, precision=0, g_scale=1.0, w_gain=1.0):
     """precision = BF16X3_FWD: the training forward on the split-bf16 kernel (its stash: slots in ITS order, fp32 rows as it
     computed them, ReLU masks in the data-gradient kernel's lane layout), the backward kernels unchanged.  The gradient is
     then the fp32 gradient at activations carrying ~1e-5 relative error: bounds 20x the fp32 path's, rows whose ReLU
@@ -393,7 +395,7 @@ def case_mlp_backward(b, names=None, m=150, precision=0, g_scale=1.0):
     margin, tol = (1e-6, 2e-5) if not loose(precision) else (1e-4, 4e-4)
     for name in names or ("default4x128", "deep8x128_skip4", "fern8x128_skip3_L6", "novw4x128"):
         cfg = MLP_GEOMETRIES[name]
-        plan, params, flat, packed = mlp_setup(b, cfg, seed=41, precision=precision)
+        plan, params, flat, packed = mlp_setup(b, cfg, seed=41, precision=precision, w_gain=w_gain)
         dx, dd = O.model_dims(cfg)
         gen = rng(42)
         x = torch.randn(m, dx + dd, generator=gen)

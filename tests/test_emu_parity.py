@@ -135,6 +135,10 @@ def test_mlp_f16x3_training_levels_hold_the_fp32_gradient_bounds(emu):
     P.case_mlp_backward(emu, names=("fern8x128_skip3_L6", "novw4x128", "one_layer"), m=120, precision=P.F16X3_FWD_DGRAD)
     P.case_mlp_backward(emu, names=("skip_every_layer_256", "one_layer_novw_256"), m=120, precision=P.F16X3_TRAIN)
     P.case_mlp_backward(emu, names=("default4x128",), m=100, precision=P.F16X3_FWD_DGRAD, g_scale=3e-7)
+    # weights 4x torch's init: activations in the thousands, d(pre-activation) a million times d(raw output) -- no fixed fp16 scale
+    # holds both ends; the per-sample exponents (forward and data gradient) and the per-region scales of k_wgrad_f16x3 do
+    P.case_mlp_backward(emu, names=("skip_every_layer_256",), m=100, precision=P.F16X3_TRAIN, w_gain=4.0, g_scale=1e-4)
+    P.case_mlp_backward(emu, names=("default4x128",), m=100, precision=P.F16X3_FWD_DGRAD, w_gain=0.25)
     P.case_mlp_input_grad(emu, names=("default4x128", "novw4x128"), m=45, precision=P.F16X3_FWD_DGRAD)
     P.case_render_vs_oracle(emu, P.MLP_GEOMETRIES["default4x128"], n=12, nc=16, nf=16, with_grads=True, tag="f16x3_train_emu",
                             precision=P.F16X3_FWD_DGRAD)

@@ -31,8 +31,10 @@
 //   * data gradient: the same bookkeeping -- the chain of a sample starts at its d(raw output) moved to [2^13, 2^14) and every
 //     layer's d(pre-activation) is renormalised per sample (whatever the transposed layers amplify or damp); the images it stores
 //     are plain fp32 values;
-//   * the producers record the largest magnitude they store per region (one atomicMax per wave and gemm: `rmax`), from which the
-//     fp16 weight-gradient kernel (wgrad_f16.hip) takes the power of two it splits that region's values at.
+//   * what a sample's stored row holds is bounded by its exponent (pieces below 2^14, times 2^-s): the producers record, per
+//     region, the largest such bound over their samples (`rmax` words: 256 + 14 - s; a wave maximum per gemm into the wave's LDS
+//     slots, one atomicMax per wave and region at the end of the kernel), from which the fp16 weight-gradient kernel
+//     (wgrad_f16.hip) takes the power of two it splits that region's values at.
 #ifdef NHB_F16
 typedef nh_f16 nh_pc;
 typedef nh_f16x8 nh_pcx8;
@@ -62,6 +64,14 @@ static_assert(NHB_WS == (float)(1 << NHB_WS_LOG2), "weight scale");
 constexpr float NHB_INV_WS = 1.0f / NHB_WS;
 constexpr int NHB_TARGET_LOG2 = 13;  // a sample's largest operand value lands in [2^13, 2^14)
 constexpr int NHB_NO_CAP = 100;
+// the exponent given to a sample whose values are all zero (a dead layer; a padding sample of the last group): high enough that
+// its bound (2^(14 - 60)) never sets a region's scale, low enough that a bias times 2^60 stays a float
+constexpr int NHB_ZERO_EXP = 60;
+// exponent for pieces of values whose largest magnitude has bit pattern `mb`, given that it currently carries 2^base_e
+NH_DEVICE int exp_for(unsigned mb, int base_e) {
+    return ((mb >> 23) & 255u) == 0u ? NHB_ZERO_EXP : base_e + nh_shift_to(mb, NHB_TARGET_LOG2);
+}
+constexpr int NHB_RM_LDS = 4 * NH_RMAX_WORDS * 4;  // LDS bytes behind the chunk buffers: a workgroup's four waves' region slots
 // a raw network output from an accumulator that holds WS * 2^s * value
 NH_DEVICE float nhb_raw(float acc, int s) { return NHB_IS_F16 ? acc * nh_pow2i(-NHB_WS_LOG2 - s) : acc; }
 
@@ -85,7 +95,25 @@ struct BCtx {
     unsigned lds_addr;
     NhDmaSrc dma;
     int buf, lane, wave, h;
+    unsigned* wrm;  // fp16 level-4 plans: this wave's NH_RMAX_WORDS region slots in LDS (behind the chunk buffers), else NULL
 };
+// the rows a gemm stored for region `ridx` came from pieces below 2^(NHB_TARGET + 1) at per-sample exponent s: note the bound
+NH_DEVICE void note_region(const BCtx& cx, int ridx, int s) {
+    const int e = 256 + 14 - s;
+    const unsigned wm = nh_wave_max_u32((unsigned)(e < 1 ? 1 : (e > 511 ? 511 : e)));
+    if (cx.lane == 0 && wm > cx.wrm[ridx]) cx.wrm[ridx] = wm;
+}
+// kernel prologue / epilogue of the region bookkeeping
+NH_DEVICE void regions_begin(BCtx& cx, char* lds_tail, unsigned* rmax) {
+    cx.wrm = rmax ? (unsigned*)lds_tail + cx.wave * NH_RMAX_WORDS : nullptr;
+    if (cx.wrm) cx.wrm[cx.lane] = 0u;
+}
+NH_DEVICE void regions_end(const BCtx& cx, unsigned* rmax) {
+    if (cx.wrm) {
+        const unsigned v = cx.wrm[cx.lane];
+        if (v != 0u) nh_atomic_max_u32(rmax + cx.lane, v);
+    }
+}
 
 // `bytes` (a multiple of 1 KiB) of the image, from byte offset `src`, into chunk buffer b at byte offset dst_off: one 1-KiB
 // piece per wave-instruction, pieces dealt round-robin to the four waves
@@ -122,21 +150,6 @@ NH_DEVICE void convert_tile(const f32x16& acc, nh_pcx8* oh, nh_pcx8* ol, float m
         }
 }
 
-// largest magnitude of eight stored values, and its way into the region's word: wave maximum, one atomic per wave
-NH_DEVICE float row_max8(float m, const float4& a, const float4& b) {
-    m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
-    return fmaxf(m, fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
-}
-NH_DEVICE void region_max_out(unsigned* rmax, float m) {
-    unsigned u;
-    memcpy(&u, &m, 4);
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const unsigned o = (unsigned)nh_shfl_xor_i((int)u, d);
-        u = o > u ? o : u;
-    }
-    if (nh_lane() == 0 && u != 0u) nh_atomic_max_u32(rmax, u);
-}
 // accumulators (WS * 2^s_in * value) -> operand pieces of value * 2^s_out with the sample's largest magnitude moved to
 // [2^13, 2^14) (never above `cap`): the renormalisation step of the data-gradient chain (the forward's sits in gemm_b's epilogue)
 template <int NT>
@@ -164,7 +177,7 @@ NH_DEVICE int renorm_convert(const f32x16* acc, nh_pcx8* oh, nh_pcx8* ol, int s_
     if (NHB_IS_F16) {
         const unsigned mb = tile_max_bits<NT, false>(acc);
         const int base_e = NHB_WS_LOG2 + s_in;
-        so = base_e + nh_shift_to(mb, NHB_TARGET_LOG2);
+        so = exp_for(mb, base_e);
         so = so < cap ? so : cap;
         so = so > base_e + 120 ? base_e + 120 : (so < base_e - 120 ? base_e - 120 : so);
         mul = nh_pow2i(so - base_e);
@@ -196,11 +209,10 @@ template <int W, int NT, int NKA, int NKB, int EPI = 0, int NTE = 0, bool ROW_SC
 NH_DEVICE void gemm_b(BCtx& cx, const nh_pcx8* ah, const nh_pcx8* al, const nh_pcx8* xh, const nh_pcx8* xl, int64_t base,
                       int64_t next_base, int next_first, f32x16* acc, nh_pcx8* oh = nullptr, nh_pcx8* ol = nullptr,
                       float* in_rows = nullptr, unsigned* in_mask = nullptr, int s32 = 0, float row_scale = 1.0f, int s_in = 0,
-                      int s_x = 0, int cap = NHB_NO_CAP, int* s_out = nullptr, unsigned* rmax = nullptr) {
+                      int s_x = 0, int cap = NHB_NO_CAP, int* s_out = nullptr, int ridx = -1) {
     constexpr int NK = NKA + NKB, BUF = BShape<W>::BUF, CH = BShape<W>::CHUNK / (NT * 2048), NCH = (NK + CH - 1) / CH;
     static_assert(CH >= 1, "a k-block of every tile must fit one chunk buffer");
     int srow_next = 0;  // next input k-block whose rows go out
-    float smax = 0.0f;  // (rmax: the largest magnitude this lane stores)
     auto store_step = [&](int kb) {
         float4 a4, b4;
 #ifdef NHB_EXP_STASH_HI  // (diagnostic builds only, wrong results: what the hi + lo reconstruction costs)
@@ -220,7 +232,6 @@ NH_DEVICE void gemm_b(BCtx& cx, const nh_pcx8* ah, const nh_pcx8* al, const nh_p
             a4.x *= row_scale, a4.y *= row_scale, a4.z *= row_scale, a4.w *= row_scale;
             b4.x *= row_scale, b4.y *= row_scale, b4.z *= row_scale, b4.w *= row_scale;
         }
-        if (NHB_IS_F16 && rmax) smax = row_max8(smax, a4, b4);
         float* const dst = in_rows + 32 * (kb >> 1) + 16 * (kb & 1) + 4 * cx.h;  // units nhb_unit(kb, h, 0..3) and (kb, h, 4..7) = + 8
 #ifdef NHB_EXP_NO_STASH_STORE  // (diagnostic builds only, wrong results: what the stores themselves cost)
         if (a4.x == 1.2345e-30f && b4.y == 5.4321e-30f) nh_store4(dst, a4.x, a4.y, a4.z, a4.w);
@@ -340,7 +351,7 @@ NH_DEVICE void gemm_b(BCtx& cx, const nh_pcx8* ah, const nh_pcx8* al, const nh_p
         }
         cx.buf ^= 1;
     }
-    if (NHB_IS_F16 && rmax && in_rows && NKA > 0) region_max_out(rmax, smax);
+    if (NHB_IS_F16 && cx.wrm && ridx >= 0 && in_rows && NKA > 0) note_region(cx, ridx, s_in);
     if (EPI != 0) {
         float mul = NHB_INV_WS;
         if (DYN) {
@@ -348,7 +359,7 @@ NH_DEVICE void gemm_b(BCtx& cx, const nh_pcx8* ah, const nh_pcx8* al, const nh_p
             // layer's encodings sit lower -- and remember the exponent the pieces now carry
             const unsigned mb = tile_max_bits<NTE, EPI == 1>(acc);
             const int base_e = NHB_WS_LOG2 + s_in;
-            int so = base_e + nh_shift_to(mb, NHB_TARGET_LOG2);
+            int so = exp_for(mb, base_e);
             so = so < cap ? so : cap;
             so = so > base_e + 120 ? base_e + 120 : (so < base_e - 120 ? base_e - 120 : so);
             mul = nh_pow2i(so - base_e);
@@ -423,7 +434,7 @@ NH_DEVICE int enc_exponent(float m) {
     unsigned u;
     memcpy(&u, &m, 4);
     const unsigned o = (unsigned)nh_shfl_xor_i((int)u, 32);
-    return nh_shift_to(u > o ? u : o, NHB_TARGET_LOG2);
+    return exp_for(u > o ? u : o, 0);
 }
 // largest magnitude among this lane's slots of a caller-encoded row
 template <int NB>
@@ -507,6 +518,7 @@ NH_KERNEL void NH_LB(256, (TRAIN ? 1 : BShape<W>::WAVES_PER_SIMD)) NHB_KERNEL(k_
     cx.lane = nh_lane();
     cx.wave = nh_wave_in_block();
     cx.h = cx.lane >> 5;
+    regions_begin(cx, lds_raw + BShape<W>::LDS_BYTES, (TRAIN && NHB_IS_F16) ? a.rmax : nullptr);
     const int h = cx.h;
     const NhPackedOffsets& po = a.off;
     auto first = [](int nk, int nt) { return nhb_first_bytes(nk, nt, W); };
@@ -578,10 +590,10 @@ NH_KERNEL void NH_LB(256, (TRAIN ? 1 : BShape<W>::WAVES_PER_SIMD)) NHB_KERNEL(k_
         const float rsc = RS ? nh_pow2i(-s) : 1.0f;  // (training, fp16 pieces: the stash rows are plain values)
         if (sk)
             gemm_b<W, TH, KBH, XB, 1, TH, RS, DYN>(cx, hh, hl, xh, xl, po.f_xyz[i] * 4, nxt, nfirst, acc, hh, hl, in_rows, in_mask, s32, rsc, s, ex,
-                                                   cap, &s, (TRAIN && a.rmax) ? a.rmax + i : nullptr);
+                                                   cap, &s, TRAIN ? i : -1);
         else
             gemm_b<W, TH, KBH, 0, 1, TH, RS, DYN>(cx, hh, hl, nullptr, nullptr, po.f_xyz[i] * 4, nxt, nfirst, acc, hh, hl, in_rows, in_mask, s32, rsc,
-                                                  s, s, cap, &s, (TRAIN && a.rmax) ? a.rmax + i : nullptr);
+                                                  s, s, cap, &s, TRAIN ? i : -1);
     }
     if (VIEW) {
         nh_pcx8 dh[DB], dl[DB];
@@ -599,11 +611,11 @@ NH_KERNEL void NH_LB(256, (TRAIN ? 1 : BShape<W>::WAVES_PER_SIMD)) NHB_KERNEL(k_
         const int s_head = s;  // (the head's inputs: fc_alpha's raw row comes out at WS * 2^s_head)
         gemm_b<W, TH + 1, KBH, 0, 1, TH, RS, DYN>(cx, hh, hl, nullptr, nullptr, po.f_head * 4, po.f_dir * 4, first(KBH + DB, TH / 2), acc, hh, hl,
                                                   TRAIN ? srow(a.sl.H[a.L - 1], W) : nullptr, (TRAIN && a.L > 1) ? smask(a.L - 2) : nullptr, s32,
-                                                  RS ? nh_pow2i(-s) : 1.0f, s, s, ed, &s, (TRAIN && a.rmax) ? a.rmax + (a.L - 1) : nullptr);
+                                                  RS ? nh_pow2i(-s) : 1.0f, s, s, ed, &s, TRAIN ? a.L - 1 : -1);
         const float alpha = nhb_raw(acc[TH][0], s_head);
         gemm_b<W, TH / 2, KBH, DB, 1, TH / 2, RS, DYN>(cx, hh, hl, dh, dl, po.f_dir * 4, po.f_rgb * 4, first(KBH / 2, 1), acc, hh, hl,
                                                        TRAIN ? srow(a.sl.FEAT, W) : nullptr, TRAIN ? smask(a.L - 1) : nullptr, s32,
-                                                       RS ? nh_pow2i(-s) : 1.0f, s, ed, NHB_NO_CAP, &s, (TRAIN && a.rmax) ? a.rmax + a.L : nullptr);
+                                                       RS ? nh_pow2i(-s) : 1.0f, s, ed, NHB_NO_CAP, &s, TRAIN ? a.L : -1);
         gemm_b<W, 1, KBH / 2, 0, 0, 0, RS, DYN>(cx, hh, hl, nullptr, nullptr, po.f_rgb * 4, po.f_layer1 * 4, again ? first(XB, TH) : 0, acc, nullptr,
                                                 nullptr, TRAIN ? srow(a.sl.DIRH, W / 2) : nullptr, TRAIN ? smask(a.L) : nullptr, s32,
                                                 RS ? nh_pow2i(-s) : 1.0f, s, s);
@@ -618,8 +630,7 @@ NH_KERNEL void NH_LB(256, (TRAIN ? 1 : BShape<W>::WAVES_PER_SIMD)) NHB_KERNEL(k_
     } else {
         gemm_b<W, 1, KBH, 0, 0, 0, RS, DYN>(cx, hh, hl, nullptr, nullptr, po.f_head * 4, po.f_layer1 * 4, again ? first(XB, TH) : 0, acc, nullptr,
                                             nullptr, TRAIN ? srow(a.sl.H[a.L - 1], W) : nullptr, (TRAIN && a.L > 1) ? smask(a.L - 2) : nullptr, s32,
-                                            RS ? nh_pow2i(-s) : 1.0f, s, s, NHB_NO_CAP, nullptr,
-                                            (TRAIN && a.rmax) ? a.rmax + (a.L - 1) : nullptr);  // fc_out (models.py:256)
+                                            RS ? nh_pow2i(-s) : 1.0f, s, s, NHB_NO_CAP, nullptr, TRAIN ? a.L - 1 : -1);  // fc_out (models.py:256)
         if (valid && h == 0) {
             float4 r4;
             r4.x = nhb_raw(acc[0][0], s);
@@ -630,6 +641,7 @@ NH_KERNEL void NH_LB(256, (TRAIN ? 1 : BShape<W>::WAVES_PER_SIMD)) NHB_KERNEL(k_
         }
     }
     }  // (groups of this workgroup)
+    regions_end(cx, a.rmax);
 }
 
 // ---- the data-gradient chain on the same loop (NERFHIP_PRECISION_BF16X3_FWD_DGRAD) -------------------------------------------
@@ -680,6 +692,7 @@ NH_KERNEL void NH_LB(256, 1) NHB_KERNEL(k_mlp_dgrad)(DgradBArgs a) {
     cx.lane = nh_lane();
     cx.wave = nh_wave_in_block();
     cx.h = cx.lane >> 5;
+    regions_begin(cx, lds_raw + BShape<W>::LDS_BYTES, NHB_IS_F16 ? a.rmax : nullptr);
     const int h = cx.h, L = a.L;
     const NhPackedOffsets& po = a.off;
     auto first = [](int nk, int nt) { return nhb_first_bytes(nk, nt, W); };
@@ -737,11 +750,10 @@ NH_KERNEL void NH_LB(256, 1) NHB_KERNEL(k_mlp_dgrad)(DgradBArgs a) {
                 const float mg = fmaxf(fmaxf(fabsf(go[0]), fabsf(go[1])), fmaxf(fabsf(go[2]), VIEW ? 0.0f : fabsf(go[3])));
                 unsigned ub;
                 memcpy(&ub, &mg, 4);
-                s = nh_shift_to(ub, NHB_TARGET_LOG2);
+                s = exp_for(ub, 0);
             }
             put_block(d1h[0], d1l[0], v, nullptr, nh_pow2i(s));
         }
-        unsigned* const rm = NHB_IS_F16 ? a.rmax : nullptr;
         if (VIEW) {
             gemm_b<W, TH / 2, 0, 1>(cx, nullptr, nullptr, d1h, d1l, po.b_rgb * 4, po.b_dir * 4, first(KBH / 2, TH), acc);
             get_mask(L, mw);  // DIRH
@@ -749,7 +761,7 @@ NH_KERNEL void NH_LB(256, 1) NHB_KERNEL(k_mlp_dgrad)(DgradBArgs a) {
             s = renorm_convert<TH / 2>(acc, hh, hl, s, NHB_NO_CAP);
             gemm_b<W, TH, KBH / 2, 0, 0, 0, NHB_IS_F16>(cx, hh, hl, nullptr, nullptr, po.b_dir * 4, po.b_head * 4, first(KBH + 1, TH), acc, nullptr,
                                                         nullptr, grow(a.gl.PDIR, W / 2), nullptr, 0, nh_pow2i(-s), s, s, NHB_NO_CAP, nullptr,
-                                                        rm ? rm + (L + 1) : nullptr);
+                                                        L + 1);
             get_mask(L - 1, mw);  // FEAT
             gate_tiles<TH>(acc, mw);
             // (d(sigma raw) joins the next gemm as a k-block of its own at the same exponent: it must fit)
@@ -770,7 +782,7 @@ NH_KERNEL void NH_LB(256, 1) NHB_KERNEL(k_mlp_dgrad)(DgradBArgs a) {
             const bool last = L == 1;
             gemm_b<W, TH, KBH, 1, 0, 0, NHB_IS_F16>(cx, hh, hl, dah, dal, po.b_head * 4, last ? first_img : po.b_xyz[L > 1 ? L - 2 : 0] * 4,
                                                     last ? (again ? first_bytes : 0) : first(KBH, TH), acc, nullptr, nullptr, grow(a.gl.PFEAT, W),
-                                                    nullptr, 0, nh_pow2i(-s), s, s, NHB_NO_CAP, nullptr, rm ? rm + L : nullptr);
+                                                    nullptr, 0, nh_pow2i(-s), s, s, NHB_NO_CAP, nullptr, L);
         } else {
             const bool last = L == 1;
             gemm_b<W, TH, 0, 1>(cx, nullptr, nullptr, d1h, d1l, po.b_head * 4, last ? first_img : po.b_xyz[L > 1 ? L - 2 : 0] * 4,
@@ -786,7 +798,7 @@ NH_KERNEL void NH_LB(256, 1) NHB_KERNEL(k_mlp_dgrad)(DgradBArgs a) {
             const bool last = k == 1;
             gemm_b<W, TH, KBH, 0, 0, 0, NHB_IS_F16>(cx, hh, hl, nullptr, nullptr, po.b_xyz[k - 1] * 4, last ? first_img : po.b_xyz[k >= 2 ? k - 2 : 0] * 4,
                                                     last ? (again ? first_bytes : 0) : first(KBH, TH), acc, nullptr, nullptr, grow(a.gl.P[k], W),
-                                                    nullptr, 0, nh_pow2i(-s), s, s, NHB_NO_CAP, nullptr, rm ? rm + k : nullptr);
+                                                    nullptr, 0, nh_pow2i(-s), s, s, NHB_NO_CAP, nullptr, k);
             if (k - 1 >= 1) {
                 get_mask(k - 2, mw);  // H_{k-1}
                 gate_tiles<TH>(acc, mw);
@@ -794,6 +806,7 @@ NH_KERNEL void NH_LB(256, 1) NHB_KERNEL(k_mlp_dgrad)(DgradBArgs a) {
             s = renorm_convert<TH>(acc, hh, hl, s, NHB_NO_CAP);
         }
         {  // d(pre-activation) of layer1: no gemm consumes it -- stored here (hi + lo, as every other image)
+            if (NHB_IS_F16 && cx.wrm) note_region(cx, 0, s);
             float* const pr = grow(a.gl.P[0], W);
 #pragma unroll
             for (int kb = 0; kb < KBH; ++kb) {
@@ -817,6 +830,7 @@ NH_KERNEL void NH_LB(256, 1) NHB_KERNEL(k_mlp_dgrad)(DgradBArgs a) {
             }
         }
     }
+    regions_end(cx, a.rmax);
 }
 
 // ---- weight image --------------------------------------------------------------------------------------------------
@@ -929,10 +943,10 @@ int NHB_FN(nh_mlp_forward)(nerfhip_plan* p, const float* packed, const NhMlpInpu
     int rc = NERFHIP_OK;
 #define NH_FWDB_T(WW, VV, TT)                                                                              \
     {                                                                                                      \
-        rc = b_lds_limit(NHB_KERNEL(k_mlp_fwd)<WW, VV, TT>, BShape<WW>::LDS_BYTES);                             \
+        rc = b_lds_limit(NHB_KERNEL(k_mlp_fwd)<WW, VV, TT>, BShape<WW>::LDS_BYTES + NHB_RM_LDS);                \
         if (rc) return rc;                                                                                 \
         NH_LAUNCH_NAMED("k_mlp_fwd_" NHB_FMT "x3<" #WW ", " #VV ", " #TT ">", (NHB_KERNEL(k_mlp_fwd)<WW, VV, TT>), grid, 256,  \
-                        BShape<WW>::LDS_BYTES, stream, a);                                                 \
+                        BShape<WW>::LDS_BYTES + NHB_RM_LDS, stream, a);                                    \
     }
 #define NH_FWDB(WW, VV)              \
     {                                \
@@ -976,10 +990,10 @@ int NHB_FN(nh_mlp_dgrad)(nerfhip_plan* p, const float* packed, const float* g_ou
     int rc = NERFHIP_OK;
 #define NH_BWDB(WW, VV)                                                                                    \
     {                                                                                                      \
-        rc = b_lds_limit(NHB_KERNEL(k_mlp_dgrad)<WW, VV>, BShape<WW>::LDS_BYTES);                               \
+        rc = b_lds_limit(NHB_KERNEL(k_mlp_dgrad)<WW, VV>, BShape<WW>::LDS_BYTES + NHB_RM_LDS);                  \
         if (rc) return rc;                                                                                 \
         NH_LAUNCH_NAMED("k_mlp_dgrad_" NHB_FMT "x3<" #WW ", " #VV ">", (NHB_KERNEL(k_mlp_dgrad)<WW, VV>), grid, 256,           \
-                        BShape<WW>::LDS_BYTES, stream, d);                                                 \
+                        BShape<WW>::LDS_BYTES + NHB_RM_LDS, stream, d);                                    \
     }
     if (p->W == 256 && p->view) NH_BWDB(256, true)
     else if (p->W == 256) NH_BWDB(256, false)

@@ -100,6 +100,18 @@ NH_DEVICE float nh_pair_sum_bf16(unsigned pair, float c) {
     __builtin_memcpy(&a, &pair, 4);
     return __builtin_amdgcn_fdot2_f32_bf16(a, one, c, false);
 }
+// maximum of v over the wave, as a wave-uniform value: six v_max_u32 with DPP operands (row_shr 1 2 4 8, row_bcast 15 31) and a
+// v_readlane -- no LDS traffic
+NH_DEVICE unsigned nh_wave_max_u32(unsigned v) {
+    unsigned t;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false), v = v > t ? v : t;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false), v = v > t ? v : t;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false), v = v > t ? v : t;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false), v = v > t ? v : t;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false), v = v > t ? v : t;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false), v = v > t ? v : t;
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
 NH_DEVICE float nh_med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }  // v_med3_f32: clamp in one instruction
 NH_DEVICE void nh_atomic_add(float* p, float v) { atomicAdd(p, v); }
 NH_DEVICE void nh_atomic_max_u32(unsigned* p, unsigned v) { atomicMax(p, v); }

@@ -21,8 +21,8 @@
 
 // (compiled twice, like mlp_bf16.hip: as is for the bf16x3 plans and through wgrad_f16.hip -- NHB_F16 -- for the f16x3 plans.  fp16's
 // range: the values of a block's A region (d(pre-activation): 1e-3 ... 1e-12, and whatever the transposed layers amplify) and of its
-// B region are multiplied, BEFORE they are split, by the power of two that moves the region's largest magnitude -- recorded by the
-// launch that wrote it, WgBArgs::amax / bmax -- to [2^14, 2^15); the reduction divides the two out again (exact).)
+// B region are multiplied, BEFORE they are split, by the power of two that brings the region's bound -- the launch that wrote it
+// recorded 256 + log2 of it, WgBArgs::amax / bmax -- to 2^14; the reduction divides the two out again (exact).)
 #ifdef NHB_F16
 typedef nh_f16 nh_pc;
 typedef nh_f16x8 nh_pcx8;
@@ -75,6 +75,9 @@ struct WgBArgs {
     const unsigned* bmax;    // fp16: ... by the forward launch that wrote `stash`, or NULL
     WgBJob jobs[NHW_MAX_JOBS];
 };
+
+// a region's recorded word (256 + log2 of the bound on its magnitudes; 0: nothing recorded) -> the shift that brings the bound to 2^14
+NH_DEVICE int region_shift(unsigned word) { return word == 0u ? 0 : 14 - ((int)word - 256); }
 
 template <int AR, int BR>
 struct WShape {
@@ -151,8 +154,8 @@ NH_KERNEL void NH_LB(NHW_THREADS, NHW_WAVES / 4) NHB_KERNEL(k_wgrad)(WgBArgs a) 
     const int64_t u0 = 2 * (a.nt * k / jb.nwg), u1 = 2 * (a.nt * (k + 1) / jb.nwg);
     const float* const a_reg = a.grad + jb.a_off;
     const float* const b_reg = a.stash + jb.b_off;
-    const float a_scale = (NHB_IS_F16 && a.amax) ? nh_pow2i(nh_shift_to(a.amax[jb.a_idx], 14)) : 1.0f;
-    const float b_scale = (NHB_IS_F16 && a.bmax) ? nh_pow2i(nh_shift_to(a.bmax[jb.b_idx], 14)) : 1.0f;
+    const float a_scale = (NHB_IS_F16 && a.amax) ? nh_pow2i(region_shift(a.amax[jb.a_idx])) : 1.0f;
+    const float b_scale = (NHB_IS_F16 && a.bmax) ? nh_pow2i(region_shift(a.bmax[jb.b_idx])) : 1.0f;
     const unsigned lds0 = nh_lds_addr((const float*)lds);
     auto issue = [&](int64_t u) {  // one step of both regions -> stage u & 1: 1-KiB pieces dealt to the four waves
         const NhDmaSrc da = nh_dma_src(a_reg + (size_t)u * 16 * AR, (unsigned)S::STAGE_A);
@@ -240,7 +243,7 @@ NH_KERNEL void NHB_KERNEL(k_wgrad_reduce)(WgBArgs a) {
     const WgBJob& jb = a.jobs[jq];
     const int e = ((int)blockIdx.x % GX) * 256 + (int)threadIdx.x;
     // (the powers of two the kernel split this block's regions at: exact to divide out)
-    const float unscale = (NHB_IS_F16 && a.amax && a.bmax) ? nh_pow2i(-nh_shift_to(a.amax[jb.a_idx], 14) - nh_shift_to(a.bmax[jb.b_idx], 14)) : 1.0f;
+    const float unscale = (NHB_IS_F16 && a.amax && a.bmax) ? nh_pow2i(-region_shift(a.amax[jb.a_idx]) - region_shift(a.bmax[jb.b_idx])) : 1.0f;
     if (e < E) {
         const int tile = e >> 10, c = (e >> 6) & 15, l = e & 63;
         const int row = 32 * (tile / TB) + (c & 3) + 8 * (c >> 2) + 4 * (l >> 5), col = 32 * (tile % TB) + (l & 31);

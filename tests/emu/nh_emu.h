@@ -296,6 +296,13 @@ NH_DEVICE float nh_pair_sum_f16(unsigned pair, float c) {
 NH_DEVICE float nh_pair_sum_bf16(unsigned pair, float c) {
     return (c + nh_from_bf16(nh_bf16{(uint16_t)(pair & 0xffffu)})) + nh_from_bf16(nh_bf16{(uint16_t)(pair >> 16)});
 }
+NH_DEVICE unsigned nh_wave_max_u32(unsigned v) {
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned o = (unsigned)nh_shfl_xor_i((int)v, d);
+        v = o > v ? o : v;
+    }
+    return v;
+}
 NH_DEVICE float nh_med3(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 NH_DEVICE void nh_atomic_add(float* p, float v) { *p += v; }
 NH_DEVICE void nh_atomic_max_u32(unsigned* p, unsigned v) { if (v > *p) *p = v; }

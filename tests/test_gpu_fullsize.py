@@ -416,19 +416,30 @@ def _teacher_forced_on(c, pl):
     rec["grad_fine_per_tensor"] = per
     m = 256
     rec["slice_rays"] = m
-    slices = []
-    for s0 in (0, m, 2 * m):  # three slices: on 256 rays ONE ReLU branch decided by round-off is visible in a p99.9 -- the median
-        sel = slice(s0, s0 + m)   # of three says what the arithmetic does, the per-slice values stay on record
-        g_hip = _fine_pass_units(c, sel, z[sel], c.tgt[sel], pl)[3]
-        g32 = _oracle_fine_grads(c, sel, z[sel], c.tgt[sel], torch.float32)
-        g64 = _oracle_fine_grads(c, sel, z[sel], c.tgt[sel], torch.float64)
-        slices.append(dict(first_ray=s0, hip_vs_fp64=_grad_stats(g_hip, g64)[0], torch_fp32_vs_fp64=_grad_stats(g32, g64)[0],
-                           hip_vs_torch_fp32=_grad_stats(g_hip, g32)[0]))
-    rec["slices"] = slices
-    med = lambda key, q: float(np.median([sl[key][q] for sl in slices]))  # noqa: E731
-    rec["slice_hip_vs_fp64"] = dict(p999=med("hip_vs_fp64", "p999"), max=med("hip_vs_fp64", "max"))
-    rec["slice_torch_fp32_vs_fp64"] = dict(p999=med("torch_fp32_vs_fp64", "p999"), max=med("torch_fp32_vs_fp64", "max"))
-    rec["slice_hip_vs_torch_fp32"] = dict(p999=med("hip_vs_torch_fp32", "p999"), max=med("hip_vs_torch_fp32", "max"))
+    sel = slice(0, m)
+    g_hip = _fine_pass_units(c, sel, z[sel], c.tgt[sel], pl)[3]
+    g32 = _oracle_fine_grads(c, sel, z[sel], c.tgt[sel], torch.float32)
+    g64 = _oracle_fine_grads(c, sel, z[sel], c.tgt[sel], torch.float64)
+    rec["slice_hip_vs_fp64"] = _grad_stats(g_hip, g64)[0]
+    rec["slice_torch_fp32_vs_fp64"] = _grad_stats(g32, g64)[0]
+    rec["slice_hip_vs_torch_fp32"] = _grad_stats(g_hip, g32)[0]
+    if pl.arith != "fp32":
+        # An arithmetic with its own rounding is held to the yardstick the fp32 KERNELS set on the same slices -- no further
+        # from the fp64 gradient than they are (x 1.5) -- over three slices: on 256 rays ONE ReLU branch that round-off decides
+        # the other way is visible in a p99.9 (measured: slice 0 of the lego batch, 3.3e-4 against 1.9e-4, identical before and
+        # after every change of the fp16 scaling), so the median of three says what the arithmetic does; all values on record.
+        slices = []
+        for s0 in (0, m, 2 * m):
+            sl = slice(s0, s0 + m)
+            g64s = g64 if s0 == 0 else _oracle_fine_grads(c, sl, z[sl], c.tgt[sl], torch.float64)
+            g32s = g32 if s0 == 0 else _oracle_fine_grads(c, sl, z[sl], c.tgt[sl], torch.float32)
+            ga = g_hip if s0 == 0 else _fine_pass_units(c, sl, z[sl], c.tgt[sl], pl)[3]
+            gk = _fine_pass_units(c, sl, z[sl], c.tgt[sl], None)[3]   # (the fp32 kernels)
+            slices.append(dict(first_ray=s0, arith_vs_fp64=_grad_stats(ga, g64s)[0], fp32_kernels_vs_fp64=_grad_stats(gk, g64s)[0],
+                               torch_fp32_vs_fp64=_grad_stats(g32s, g64s)[0]))
+        rec["slices"] = slices
+        med = lambda key, q: float(np.median([sl_[key][q] for sl_ in slices]))  # noqa: E731
+        rec["slices_median"] = {k: dict(p999=med(k, "p999"), max=med(k, "max")) for k in ("arith_vs_fp64", "fp32_kernels_vs_fp64", "torch_fp32_vs_fp64")}
     rec["arithmetic"] = pl.arith
     _record(c.name + "_teacher_forced" + pl.tag, rec)
     assert rec["raw"]["max"] <= 1e-6, rec["raw"]
@@ -438,8 +449,14 @@ def _teacher_forced_on(c, pl):
     assert rec["disp_fine_rel"]["max"] <= 1e-5, rec["disp_fine_rel"]
     # a gradient entry is a sum over 786,432 (lego) samples: the two fp32 summation orders differ by ~sqrt(N) eps
     assert worst["max"] <= 1e-4 and worst["p999"] <= 5e-5, worst
-    assert rec["slice_hip_vs_fp64"]["p999"] <= 1.5 * rec["slice_torch_fp32_vs_fp64"]["p999"] + 1e-6, rec
-    assert rec["slice_hip_vs_fp64"]["max"] <= 1.5 * rec["slice_torch_fp32_vs_fp64"]["max"] + 1e-4, rec
+    if pl.arith == "fp32":
+        assert rec["slice_hip_vs_fp64"]["p999"] <= 1.5 * rec["slice_torch_fp32_vs_fp64"]["p999"] + 1e-6, rec
+        assert rec["slice_hip_vs_fp64"]["max"] <= 1.5 * rec["slice_torch_fp32_vs_fp64"]["max"] + 1e-4, rec
+    else:
+        sm = rec["slices_median"]
+        yard = max(sm["fp32_kernels_vs_fp64"]["p999"], sm["torch_fp32_vs_fp64"]["p999"])
+        assert sm["arith_vs_fp64"]["p999"] <= 1.5 * yard + 1e-6, (sm, rec["slices"])
+        assert sm["arith_vs_fp64"]["max"] <= 1.5 * max(sm["fp32_kernels_vs_fp64"]["max"], sm["torch_fp32_vs_fp64"]["max"]) + 1e-4, (sm, rec["slices"])
 
 
 @pytest.mark.parametrize("arith", ["fp32", "f16x3_train"])

@@ -209,7 +209,8 @@ template <int W, int NT, int NKA, int NKB, int EPI = 0, int NTE = 0, bool ROW_SC
 NH_DEVICE void gemm_b(BCtx& cx, const nh_pcx8* ah, const nh_pcx8* al, const nh_pcx8* xh, const nh_pcx8* xl, int64_t base,
                       int64_t next_base, int next_first, f32x16* acc, nh_pcx8* oh = nullptr, nh_pcx8* ol = nullptr,
                       float* in_rows = nullptr, unsigned* in_mask = nullptr, int s32 = 0, float row_scale = 1.0f, int s_in = 0,
-                      int s_x = 0, int cap = NHB_NO_CAP, int* s_out = nullptr, int ridx = -1) {
+                      int s_x = 0, int cap = NHB_NO_CAP, int* s_out = nullptr, int ridx = -1, float bias_mul = 0.0f,
+                      bool use_bias_mul = false) {
     constexpr int NK = NKA + NKB, BUF = BShape<W>::BUF, CH = BShape<W>::CHUNK / (NT * 2048), NCH = (NK + CH - 1) / CH;
     static_assert(CH >= 1, "a k-block of every tile must fit one chunk buffer");
     int srow_next = 0;  // next input k-block whose rows go out
@@ -290,11 +291,14 @@ NH_DEVICE void gemm_b(BCtx& cx, const nh_pcx8* ah, const nh_pcx8* al, const nh_p
                 for (int j = 0; j < 4; ++j) {
                     const float4 b4 = *(const float4*)(buf + (32 * t + 8 * j + 4 * cx.h) * 4);
                     // (DYN: the products carry 2^s_in, so must the bias -- the multiply takes the place of the copy)
-                    const float bsc = DYN ? nh_pow2i(s_in) : 1.0f;
-                    acc[t][4 * j] = DYN ? b4.x * bsc : b4.x;
-                    acc[t][4 * j + 1] = DYN ? b4.y * bsc : b4.y;
-                    acc[t][4 * j + 2] = DYN ? b4.z * bsc : b4.z;
-                    acc[t][4 * j + 3] = DYN ? b4.w * bsc : b4.w;
+                    // (use_bias_mul, the data-gradient chain's head: the bias row holds fc_alpha's weights, the factor is the
+                    // sample's d(sigma raw) at the inputs' exponent)
+                    const bool scaled = DYN || use_bias_mul;
+                    const float bsc = use_bias_mul ? bias_mul : (DYN ? nh_pow2i(s_in) : 1.0f);
+                    acc[t][4 * j] = scaled ? b4.x * bsc : b4.x;
+                    acc[t][4 * j + 1] = scaled ? b4.y * bsc : b4.y;
+                    acc[t][4 * j + 2] = scaled ? b4.z * bsc : b4.z;
+                    acc[t][4 * j + 3] = scaled ? b4.w * bsc : b4.w;
                 }
         }
         const char* const wb = buf + 2048 + cx.lane * 16;
@@ -759,30 +763,18 @@ NH_KERNEL void NH_LB(256, 1) NHB_KERNEL(k_mlp_dgrad)(DgradBArgs a) {
             get_mask(L, mw);  // DIRH
             gate_tiles<TH / 2>(acc, mw);
             s = renorm_convert<TH / 2>(acc, hh, hl, s, NHB_NO_CAP);
-            gemm_b<W, TH, KBH / 2, 0, 0, 0, NHB_IS_F16>(cx, hh, hl, nullptr, nullptr, po.b_dir * 4, po.b_head * 4, first(KBH + 1, TH), acc, nullptr,
+            gemm_b<W, TH, KBH / 2, 0, 0, 0, NHB_IS_F16>(cx, hh, hl, nullptr, nullptr, po.b_dir * 4, po.b_head * 4, first(KBH, TH), acc, nullptr,
                                                         nullptr, grow(a.gl.PDIR, W / 2), nullptr, 0, nh_pow2i(-s), s, s, NHB_NO_CAP, nullptr,
                                                         L + 1);
             get_mask(L - 1, mw);  // FEAT
             gate_tiles<TH>(acc, mw);
-            // (d(sigma raw) joins the next gemm as a k-block of its own at the same exponent: it must fit)
-            int cap_sigma = NHB_NO_CAP;
-            if (NHB_IS_F16 && go[3] != 0.0f) {
-                const float ag = fabsf(go[3]);
-                unsigned ub;
-                memcpy(&ub, &ag, 4);
-                if (((ub >> 23) & 255u) != 0u) cap_sigma = nh_shift_to(ub, NHB_TARGET_LOG2);
-            }
-            s = renorm_convert<TH>(acc, hh, hl, s, cap_sigma);
-            nh_pcx8 dah[1], dal[1];  // d(sigma raw) enters through fc_alpha's column (k-block KBH, half 0, element 0)
-            {
-                float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                if (h == 0) v[0] = go[3];
-                put_block(dah[0], dal[0], v, nullptr, nh_pow2i(s));
-            }
+            s = renorm_convert<TH>(acc, hh, hl, s, NHB_NO_CAP);
+            // d(sigma raw) enters through fc_alpha: the head image's bias row holds fc_alpha's weights (plan.cpp build_specs_b), and
+            // the accumulators start at bias * d(sigma raw) * 2^s -- fp32, whatever its size next to the hidden inputs
             const bool last = L == 1;
-            gemm_b<W, TH, KBH, 1, 0, 0, NHB_IS_F16>(cx, hh, hl, dah, dal, po.b_head * 4, last ? first_img : po.b_xyz[L > 1 ? L - 2 : 0] * 4,
+            gemm_b<W, TH, KBH, 0, 0, 0, NHB_IS_F16>(cx, hh, hl, nullptr, nullptr, po.b_head * 4, last ? first_img : po.b_xyz[L > 1 ? L - 2 : 0] * 4,
                                                     last ? (again ? first_bytes : 0) : first(KBH, TH), acc, nullptr, nullptr, grow(a.gl.PFEAT, W),
-                                                    nullptr, 0, nh_pow2i(-s), s, s, NHB_NO_CAP, nullptr, L);
+                                                    nullptr, 0, nh_pow2i(-s), s, s, NHB_NO_CAP, nullptr, L, NHB_IS_F16 ? go[3] * nh_pow2i(s) : go[3], true);
         } else {
             const bool last = L == 1;
             gemm_b<W, TH, 0, 1>(cx, nullptr, nullptr, d1h, d1l, po.b_head * 4, last ? first_img : po.b_xyz[L > 1 ? L - 2 : 0] * 4,

@@ -346,14 +346,17 @@ void build_specs_b(const nerfhip_plan* p, SpecsB& S) {
             };
         }
         {
-            GemmSpecB& s = S.b_head;  // dh[f] = sum_u Wfeat[u][f] dpre_feat[u] + Walpha[0][f] d(sigma raw) (k-block KBH, half 0, element 0)
-            s.nk = KBH + 1;
+            // dh[f] = sum_u Wfeat[u][f] dpre_feat[u] + Walpha[0][f] d(sigma raw): the rank-one term rides in the image's BIAS row
+            // (row f: Walpha[0][f]); the kernel starts its accumulators at bias * d(sigma raw) -- one fp32 multiply per unit
+            // instead of a k-block whose single useful column would have to share the hidden inputs' fp16 exponent
+            GemmSpecB& s = S.b_head;
+            s.nk = KBH;
             s.nt = TH;
             s.w = [=](int f, int kb, int h, int e) -> int64_t {
                 if (f >= H) return -1;
-                if (kb < KBH) return nhb_unit(kb, h, e) < H ? fw.off + (int64_t)nhb_unit(kb, h, e) * H + f : -1;
-                return (h == 0 && e == 0) ? aw.off + f : -1;
+                return nhb_unit(kb, h, e) < H ? fw.off + (int64_t)nhb_unit(kb, h, e) * H + f : -1;
             };
+            s.b = [=](int f) -> int64_t { return f < H ? aw.off + f : -1; };
         }
     } else {
         NhTensor ow = T(p->t_out_w);

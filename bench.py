@@ -704,6 +704,28 @@ def main():
                     res["speedup_vs_pytorch_rocm_fwd_bwd"] = round(res["value"] / res["pytorch_rocm_reference"]["value"], 3)
                 except Exception as e:  # the torch arm needs ~13 GB and must never take the bench line down
                     res["pytorch_rocm_reference"] = dict(error=repr(e)[:200])
+                if args.workload == "lego" and cfg == MODEL and args.precision == "fp32":
+                    # the same workload, same steps, on the fp16-piece kernels (the arithmetic that holds the parity suite at the
+                    # fp32 kernels' bounds: tests/test_gpu_fullsize.py) -- a labelled line of its own, measured by
+                    # this very script in a child process; `value` above stays the fp32 headline
+                    res["labelled_lines"] = {}
+                    for prec in ("f16x3_train",):
+                        try:
+                            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--precision", prec, "--no-cpu-baseline", "--steps",
+                                                  str(args.steps), "--warmup", str(args.warmup), "--rays", str(args.rays)],
+                                                 capture_output=True, text=True, timeout=300)
+                            j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+                            res["labelled_lines"][prec] = dict(
+                                value=j["value"], unit=j["unit"], ms_per_step=j["ms_per_step"], dtype=j["dtype"],
+                                vs_fp32_line=round(j["value"] / res["value"], 3),
+                                speedup_vs_pytorch_rocm_fwd_bwd=(round(j["value"] / res["pytorch_rocm_reference"]["value"], 3)
+                                                                 if "value" in res["pytorch_rocm_reference"] else None),
+                                mlp_kernels={k: dict(kernel=v["kernel"], ms_per_step=v["ms_per_step"], frac_of_own_mfma_roofline=v["frac"],
+                                                     hbm_tb_s=v["hbm_tb_s"], hbm_frac=v["hbm_frac"])
+                                             for k, v in j["roofline"]["mlp_kernels"].items()},
+                                command="python bench.py --precision %s" % prec)
+                        except Exception as e:
+                            res["labelled_lines"][prec] = dict(error=repr(e)[:200])
             else:
                 res["cpu_baseline"] = cpu_baseline_eval()
         else:

@@ -15,7 +15,8 @@ def load(pattern):
 
 
 def short(name):
-    for k in ("k_mlp_fwd16", "k_mlp_dgrad16", "k_mlp_fwd", "k_mlp_dgrad", "k_wgrad_reduce", "k_wgrad"):
+    for k in ("k_mlp_fwd16", "k_mlp_dgrad16", "k_mlp_fwd_f16x3", "k_mlp_dgrad_f16x3", "k_mlp_fwd_bf16x3", "k_mlp_dgrad_bf16x3", "k_mlp_fwd", "k_mlp_dgrad",
+              "k_wgrad_reduce", "k_wgrad_f16x3", "k_wgrad_bf16x3", "k_wgrad"):
         if k in name:
             return k
     return None
@@ -56,4 +57,15 @@ for key in sorted(acc):
     summary["%s/%d" % key] = dict(kernel=key[0], grid=key[1], dur_ms=d, mfma_util=mfma, clk_ghz=gui / (d * 1e6) if d == d and d > 0 else None,
                                   fetch_gb_raw=fetch, fetch_gb_x2=2 * fetch, write_gb=write)
 if len(sys.argv) > 2:
+    # stamp: the fingerprint of the kernel sources these counters were measured on (bench.py refuses a summary whose stamp is
+    # not the one of the library it runs: lib_sources_sha16)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bench.py"))
+    try:
+        bm = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bm)
+        summary["_lib_sources_sha16"] = bm.lib_sources_sha16()
+    except Exception as e:
+        summary["_lib_sources_sha16"] = "unavailable: %r" % (e,)
     json.dump(summary, open(sys.argv[2], "w"), indent=1, sort_keys=True)

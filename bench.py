@@ -660,8 +660,8 @@ def main():
             fmt, level = precision_level(prec)
             if level == 0:
                 return "f32"
-            pieces = ("two IEEE fp16 pieces per operand (hi + lo reproduces the fp32 value to 2^-24; weights pre-scaled by 2^8, gradients by a "
-                      "per-launch power of two), three fp16 MFMAs per product block, f32 accumulate: ~3 x 2^-24 per product" if fmt == "f16x3" else
+            pieces = ("two IEEE fp16 pieces per operand (hi + lo reproduces the fp32 value to 2^-24; per-sample block floating point against "
+                      "fp16's range), three fp16 MFMAs per product block, f32 accumulate: ~3 x 2^-24 per product" if fmt == "f16x3" else
                       "two bf16 pieces per operand, three bf16 MFMAs per product block, f32 accumulate: ~2^-16 per product")
             what = {1: "forward", 2: "forward (backward + optimizer f32)", 3: "forward + data gradient (weight gradient + optimizer f32)",
                     4: "forward, data gradient and the hidden x hidden weight-gradient blocks (thin weight-gradient blocks + optimizer f32)"}[level]

@@ -37,12 +37,15 @@ def _grad_stats(got, ref):
     """Per parameter tensor: |got - ref| relative to max|ref| of the tensor; returns the worst tensor's max and p99.9."""
     worst = dict(max=0.0, p999=0.0, tensor="")
     per = {}
+    every = []
     for k, r in ref.items():
         scale = float(np.abs(r).max()) + 1e-30
         e = (np.abs(np.asarray(got[k], np.float64) - np.asarray(r, np.float64)) / scale).reshape(-1)
+        every.append(e)
         per[k] = dict(max=float(e.max()), p999=float(np.quantile(e, 0.999)))
         if per[k]["max"] > worst["max"]:
             worst = dict(max=per[k]["max"], p999=per[k]["p999"], tensor=k)
+    worst["p50_all"] = float(np.median(np.concatenate(every)))  # (the median over ALL entries: blind to a ReLU branch that flipped)
     return worst, per
 
 
@@ -426,10 +429,11 @@ def _teacher_forced_on(c, pl):
     if pl.arith != "fp32":
         # An arithmetic with its own rounding is held to the yardstick the fp32 implementations (these kernels, torch) set on
         # the same slices, over THREE slices: on 256 rays one ReLU branch that round-off decides the other way is visible in a
-        # p99.9, and every implementation has such slices of its own (measured on the fern batch: fp16 pieces 8.2e-5 / 6.0e-5 /
-        # 3.7e-7, fp32 kernels 8.2e-5 / 5.3e-7 / 8.9e-6, torch 8.3e-5 / 3.5e-6 / 1.6e-6 -- each flips somewhere, none twice in the
-        # same place).  Asserted: the best slice (no flip: what the arithmetic itself does) and the worst slice (how large a
-        # flip gets) are both within 1.5x of the fp32 implementations'; all values on record.
+        # p99.9, and every implementation has such slices of its own (measured on the fern batch, p99.9: fp16 pieces 8.2e-5 /
+        # 6.0e-5 / 3.7e-7, fp32 kernels 8.2e-5 / 5.3e-7 / 8.9e-6, torch 8.3e-5 / 3.5e-6 / 1.6e-6 -- each flips somewhere, none
+        # twice in the same place; on the 8x256 lego batch every slice carries flips).  Asserted, all values on record:
+        # (i) on EVERY slice the median over all gradient entries -- what the arithmetic itself does, blind to a flipped
+        # branch -- within 1.5x of the fp32 implementations'; (ii) the worst slice -- how large a flip gets -- within 1.5x of theirs.
         slices = []
         for s0 in (0, m, 2 * m):
             sl = slice(s0, s0 + m)
@@ -456,11 +460,13 @@ def _teacher_forced_on(c, pl):
         assert rec["slice_hip_vs_fp64"]["p999"] <= 1.5 * rec["slice_torch_fp32_vs_fp64"]["p999"] + 1e-6, rec
         assert rec["slice_hip_vs_fp64"]["max"] <= 1.5 * rec["slice_torch_fp32_vs_fp64"]["max"] + 1e-4, rec
     else:
-        for which in ("slices_best", "slices_worst"):
-            sm = rec[which]
-            yard = max(sm["fp32_kernels_vs_fp64"]["p999"], sm["torch_fp32_vs_fp64"]["p999"])
-            assert sm["arith_vs_fp64"]["p999"] <= 1.5 * yard + 1e-6, (which, sm, rec["slices"])
-            assert sm["arith_vs_fp64"]["max"] <= 1.5 * max(sm["fp32_kernels_vs_fp64"]["max"], sm["torch_fp32_vs_fp64"]["max"]) + 1e-6, (which, sm, rec["slices"])
+        for sl_ in rec["slices"]:
+            yard50 = max(sl_["fp32_kernels_vs_fp64"]["p50_all"], sl_["torch_fp32_vs_fp64"]["p50_all"])
+            assert sl_["arith_vs_fp64"]["p50_all"] <= 1.5 * yard50 + 1e-9, sl_
+        sm = rec["slices_worst"]
+        yard = max(sm["fp32_kernels_vs_fp64"]["p999"], sm["torch_fp32_vs_fp64"]["p999"])
+        assert sm["arith_vs_fp64"]["p999"] <= 1.5 * yard + 1e-6, (sm, rec["slices"])
+        assert sm["arith_vs_fp64"]["max"] <= 1.5 * max(sm["fp32_kernels_vs_fp64"]["max"], sm["torch_fp32_vs_fp64"]["max"]) + 1e-6, (sm, rec["slices"])
 
 
 @pytest.mark.parametrize("arith", ["fp32", "f16x3_train"])

@@ -114,8 +114,11 @@ extern "C" int nerfhip_render_fwd_parts(nerfhip_plan_t pc, nerfhip_plan_t pf, co
     NH_REQUIRE(parts >= 1 && parts <= 3, "render_fwd: parts must be a combination of NERFHIP_PART_COARSE | NERFHIP_PART_FINE");
     NH_REQUIRE(cfg->num_fine == 0 || packed_f, "render_fwd: packed_fine is NULL");
     if (n == 0) return NERFHIP_OK;
-    // (the regions a forward touches are the same in both training layouts; the size check uses the smaller one)
-    const Workspace w = layout(pc, pf, cfg, n, training ? 2 : 0);
+    // (the regions a forward touches are the same in both training layouts; the size is checked against the layout the caller
+    // names -- 1: one set of backward buffers per net, 2: shared -- so that an undersized workspace for the backward it intends
+    // is refused here, not at backward time)
+    NH_REQUIRE(training >= 0 && training <= 2, "render_fwd: training must be 0, 1 (two sets of backward buffers) or 2 (shared)");
+    const Workspace w = layout(pc, pf, cfg, n, training);
     NH_REQUIRE(workspace_bytes >= w.total, "render_fwd: workspace too small (%lld < %lld)", (long long)workspace_bytes,
                (long long)w.total);
     char* ws = (char*)workspace;

@@ -123,6 +123,11 @@ NH_DEVICE float rows_store(const RowItems<ROWS>& r, char* hi_blocks, char* lo_bl
         for (int e = 0; e < 8; ++e) {
             float v = r.v[it][e];
             sum += v;
+#ifdef NHW_EXP_NO_CONVERT  // (diagnostic builds only, wrong results: what the split costs this kernel -- nothing, it waits for HBM)
+            h8[e] = nh_to_pc(v);
+            l8[e] = h8[e];
+            continue;
+#endif
             if (NHB_IS_F16) v *= scale;
             const nh_pc hi = nh_to_pc(v);
             h8[e] = hi;
@@ -209,6 +214,13 @@ NH_KERNEL void NH_LB(NHW_THREADS, NHW_WAVES / 4) NHB_KERNEL(k_wgrad)(WgBArgs a) 
             bl[y] = *(const nh_pcx8*)(bl_blk + (tb0 + y) * 1024 + lane * 16);
         }
         nh_sched_fence();
+#ifdef NHW_EXP_ONE_MFMA  // (diagnostic builds only, wrong results: one of the three sweeps -- what the multiplies cost this kernel)
+#pragma unroll
+        for (int x = 0; x < PO; ++x)
+#pragma unroll
+            for (int y = 0; y < PI; ++y) acc[x][y] = nh_mfma_pc(ah[x], bh[y], acc[x][y]);
+        continue;
+#endif
         // (three sweeps over the accumulator tiles, the small terms first: no MFMA reads the accumulator its predecessor wrote)
 #pragma unroll
         for (int x = 0; x < PO; ++x)

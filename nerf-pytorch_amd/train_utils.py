@@ -109,7 +109,7 @@ class _FusedRender(torch.autograd.Function):
             lib.render_fwd(plan_c, plan_f, C.byref(cfg), rays.data_ptr(), n, packed_c.data_ptr(),
                            packed_f.data_ptr() if packed_f is not None else None, linspace01(nc, dev).data_ptr(),
                            linspace01(nf, dev).data_ptr() if nf > 0 else None, C.byref(rr), 0, 0, C.byref(out),
-                           ws.data_ptr(), wsb, int(training), st)
+                           ws.data_ptr(), wsb, 2 if training else 0, st)  # (2: this node's backward shares one set of backward buffers)
         # (the ray gradient multiplies by the weights of THIS forward: keep copies only if it will be asked for)
         flats = (model_c._flat.clone(), model_f._flat.clone() if nf > 0 else None) if (training and rays_grad) else None
         ctx.keep = (rays, model_c, model_f, cfg, rand, ws, wsb, packed_c, packed_f, training, flats)

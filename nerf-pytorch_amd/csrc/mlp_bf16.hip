@@ -326,9 +326,14 @@ NH_DEVICE void gemm_b(BCtx& cx, const nh_pcx8* ah, const nh_pcx8* al, const nh_p
 #if NHB_DMA_EVERY > 0
                 if (i % NHB_DMA_EVERY == 0) dma_step();
 #endif
+#ifdef NHB_STORE_SPREAD  // (A/B builds only) a k-block's rows go out when its first tile is multiplied: the stores of a gemm
+                          // spread over ALL its chunks instead of the first
+                if (NKA > 0 && in_rows && t_of(i) == 0 && c * CH + kk_of(i) < NKA) store_step(c * CH + kk_of(i));
+#else
                 if (NKA > 0 && c == 0 && i % 2 == 0 && i / 2 < NKA) {
                     if (in_rows) store_step(i / 2);
                 }
+#endif
                 if (i + PF < nblk) load(i + PF);
                 nh_sched_fence();
                 const int kb = c * CH + kk_of(i), t = t_of(i);
@@ -348,11 +353,13 @@ NH_DEVICE void gemm_b(BCtx& cx, const nh_pcx8* ah, const nh_pcx8* al, const nh_p
             }
         }
         while (dnext < dpieces) dma_step();  // (whatever the blocks did not cover: short chunks in front of long ones)
+#ifndef NHB_STORE_SPREAD
         if (NKA > 0 && c == 0 && in_rows) {
 #pragma unroll
             for (int kb = 0; kb < NKA; ++kb)
                 if (kb >= (nblk + 1) / 2) store_step(kb);  // (first chunks with fewer than 2 NKA blocks: the rgb / fc_out gemms)
         }
+#endif
         cx.buf ^= 1;
     }
     if (NHB_IS_F16 && cx.wrm && ridx >= 0 && in_rows && NKA > 0) note_region(cx, ridx, s_in);

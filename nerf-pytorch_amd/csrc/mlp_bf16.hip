@@ -233,7 +233,13 @@ NH_DEVICE void gemm_b(BCtx& cx, const nh_pcx8* ah, const nh_pcx8* al, const nh_p
             a4.x *= row_scale, a4.y *= row_scale, a4.z *= row_scale, a4.w *= row_scale;
             b4.x *= row_scale, b4.y *= row_scale, b4.z *= row_scale, b4.w *= row_scale;
         }
+#ifdef NHB_EXP_SWIZZLE_STASH  // (diagnostic builds only, wrong layout for the consumers: the 256-byte quarters of a sample's row
+                              // XOR-ed with the sample index, so that one store instruction's 32 pieces spread over 16 L2 channels
+                              // instead of 4 -- does the write path care?)
+        float* const dst = in_rows + ((32 * (kb >> 1) + 16 * (kb & 1) + 4 * cx.h) ^ ((s32 & (NKA >= 16 ? 3 : 1)) << 6));
+#else
         float* const dst = in_rows + 32 * (kb >> 1) + 16 * (kb & 1) + 4 * cx.h;  // units nhb_unit(kb, h, 0..3) and (kb, h, 4..7) = + 8
+#endif
 #ifdef NHB_EXP_NO_STASH_STORE  // (diagnostic builds only, wrong results: what the stores themselves cost)
         if (a4.x == 1.2345e-30f && b4.y == 5.4321e-30f) nh_store4(dst, a4.x, a4.y, a4.z, a4.w);
 #elif defined(NHB_EXP_DENSE_STASH)  // (diagnostic builds only, wrong layout: the SAME bytes as [32-row tile][plane][slot][sample][16 B] --

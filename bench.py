@@ -397,6 +397,8 @@ def main():
                          "*_fwd_dgrad + the data-gradient chain, *_train + the large weight-gradient blocks.  A+B: coarse net A, fine "
                          "net B.  Separate, labelled lines: the driver's default stays fp32")
     ap.add_argument("--gather", action="store_true", help="eval: rank 0 also receives every pose's rows (output plumbing)")
+    ap.add_argument("--no-kernel-profile", action="store_true", help="do not bracket the launches of the timed region with HIP events (no "
+                    "per-kernel times, no roofline object): what the events cost a short step")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / timing plumbing only, on the CPU with "
                     "gloo: no kernel runs and no number is reported (the CPU test-suite uses it)")
     args = ap.parse_args()
@@ -522,11 +524,14 @@ def main():
 
     for i in range(args.warmup):
         one_step(i)
+    if not args.no_kernel_profile:
+        lib.profile_reserve(96 * args.steps)          # a step is 40-70 launches; event creation stays out of the timed region
     fence()
-    lib.profile_enable(1)
+    lib.profile_enable(0 if args.no_kernel_profile else 1)
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         last = one_step(i)
+    dt_issue = time.perf_counter() - t0                # the host is done enqueueing; == dt_local when the step is host-bound
     fence()
     dt_local = time.perf_counter() - t0
     lib.profile_enable(0)
@@ -546,6 +551,20 @@ def main():
             allreduce_ms = eng.collective_times_ms()
     dt = max(per_rank)
     loss_host = [float(v) for v in last.cpu()] if args.mode == "train" else None
+    # What the per-launch HIP events of the timed region cost: the same K steps once more WITHOUT them (N = 1 only).  Nothing at
+    # 27 ms per step; 0.28 ms of a 2.0-ms fern step (a step is ~40 launches, each with two event records on the host's path).
+    unprofiled = None
+    if world == 1 and not args.no_kernel_profile:
+        fence()
+        t1 = time.perf_counter()
+        for i in range(args.warmup + args.steps, args.warmup + 2 * args.steps):
+            one_step(i)
+        dt_plain_issue = time.perf_counter() - t1
+        fence()
+        dt_plain = time.perf_counter() - t1
+        unprofiled = dict(value=round(total_rays * args.steps / dt_plain, 2), unit="rays/s", ms_per_step=round(dt_plain / args.steps * 1e3, 3),
+                          host_issue_ms_per_step=round(dt_plain_issue / args.steps * 1e3, 3),
+                          what="the same %d steps right after the timed region, without the per-launch HIP events (no per-kernel times)" % args.steps)
 
     if rank == 0:
         kern = {}
@@ -559,8 +578,10 @@ def main():
         stash_b = stash_bytes_per_sample(cfg) if args.mode == "train" else 16 + 4   # inference: raw out + z in
         dgrad_b = 4 * (Ln * Wd + Wd + Wd // 2 + 32) + 8 * (Ln + 1) + 16
         wgrad_b = wgrad_bytes_per_sample(cfg)
-        big_macs = (Ln - 1) * Wd * Wd + Wd * Wd + (Wd // 2) * Wd         # the hidden x hidden blocks (level-4 plans, 256-wide kernels)
-        big_b = 4 * (Ln * 2 * Wd + (Wd // 2 + Wd))
+        # the hidden x hidden blocks of the level-4 plans: layers_xyz, fc_feat and -- 256-wide kernels only -- the hidden columns of layers_dir
+        wide = Wd > 128
+        big_macs = (Ln - 1) * Wd * Wd + Wd * Wd + ((Wd // 2) * Wd if wide else 0)
+        big_b = 4 * (Ln * 2 * Wd + ((Wd // 2 + Wd) if wide else 0))
         # which kernel each net's passes run on: (kind, family) -> [flops per step, bytes per step, launches per step]
         work = {}
 
@@ -575,8 +596,8 @@ def main():
             if args.mode != "train":
                 continue
             add("dgrad", fmt if level >= 3 else "fp32", 2.0 * dgrad_macs * m, dgrad_b * m)
-            if level == 4 and 128 < Wd <= 256:
-                add("wgrad_big", fmt, 2.0 * big_macs * m, big_b * m, 2)      # (two launches: full- and half-height blocks)
+            if level == 4 and 64 < Wd <= 256:
+                add("wgrad_big", fmt, 2.0 * big_macs * m, big_b * m, 2 if wide else 1)   # (256: full- and half-height blocks are two launches)
                 add("wgrad_thin", "fp32", 2.0 * (fwd_macs - big_macs) * m, (wgrad_b - big_b) * m)
             else:
                 add("wgrad", "fp32", 2.0 * fwd_macs * m, wgrad_b * m)
@@ -677,7 +698,8 @@ def main():
                                backend=("gloo(one-device test hook)" if one_device else "nccl(RCCL %s)" % rccl) if world > 1 else None),
                    # every launch of the timed region is bracketed by two HIP events on its stream (nerfhip_profile_enable): the
                    # per-kernel times below come from THIS run; measured cost of the events: none (27.31 vs 27.41 ms)
-                   profiled_in_timed_region=True, lib_sources_sha16=lib_sources_sha16(),
+                   profiled_in_timed_region=not args.no_kernel_profile, host_issue_ms_per_step=round(dt_issue / args.steps * 1e3, 3),
+                   unprofiled_rerun=unprofiled, lib_sources_sha16=lib_sources_sha16(),
                    step_tflops=round(total_flops / sec / 1e12, 2),
                    step_frac_of_fp32_mfma_peak=round(total_flops / sec / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                    step_algorithmic_hbm_tb_s=round(step_bytes / sec / 1e12, 3),

@@ -56,6 +56,8 @@ int nerfhip_rng_fill(int kind, uint64_t seed, uint32_t stream_id, uint64_t first
  * nerfhip_profile_report waits for them and writes "kernel_name launches total_ms\n" lines into buf, then clears. */
 int nerfhip_profile_enable(int on);
 int nerfhip_profile_report(char* buf, int64_t cap);
+/* pre-creates the event pairs of `launches` launches (reused after every report), so that none is created while timing */
+int nerfhip_profile_reserve(int64_t launches);
 /* Shader clock under load: while profiling is enabled the three MLP kernels stamp every workgroup with the shader-clock
  * counter (s_memtime) and the constant 100 MHz counter (s_memrealtime).  out[3k + 0/1/2] = shader cycles / 100 MHz ticks /
  * workgroups summed over the workgroups of kernel k (0 = k_mlp_fwd16, 1 = k_mlp_dgrad16, 2 = k_wgrad):

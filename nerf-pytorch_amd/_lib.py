@@ -62,6 +62,7 @@ _PROTOS = {
     "nerfhip_is_emulated": (C.c_int, []),
     "nerfhip_profile_enable": (C.c_int, [C.c_int]),
     "nerfhip_profile_report": (C.c_int, [C.c_char_p, c_i64]),
+    "nerfhip_profile_reserve": (C.c_int, [c_i64]),
     "nerfhip_profile_clocks": (C.c_int, [C.POINTER(c_u64)]),
     "nerfhip_rng_fill": (C.c_int, [C.c_int, c_u64, c_u32, c_u64, c_i64, c_f, c_f]),
     "nerfhip_ray_bundle": (C.c_int, [C.c_int, C.c_int, C.c_float, c_f, C.c_int, c_f, c_i64, c_f, c_f, c_f]),

@@ -37,6 +37,17 @@ struct ProfRec {
     hipEvent_t a, b;
 };
 std::vector<ProfRec> g_prof;
+std::vector<hipEvent_t> g_prof_pool;  // events of reported launches, reused: creating a pair per launch costs ~7 us of host time
+hipEvent_t prof_event() {
+    hipEvent_t e = nullptr;
+    if (!g_prof_pool.empty()) {
+        e = g_prof_pool.back();
+        g_prof_pool.pop_back();
+    } else {
+        (void)hipEventCreate(&e);
+    }
+    return e;
+}
 unsigned long long* g_clk_dev = nullptr;  // [NH_CLK_KERNELS][4]: shader cycles, 100 MHz ticks, workgroups, unused
 #endif
 }  // namespace
@@ -48,26 +59,20 @@ unsigned long long* nh_prof_clock_slot(int kind) {
     return nullptr;
 #endif
 }
-void nh_prof_begin(const char* name, nerfhip_stream_t stream) {
+void nh_prof_events(const char* name, void** start, void** stop) {
+    *start = *stop = nullptr;
 #ifndef NERFHIP_EMU
     if (!g_prof_on) return;
     ProfRec r;
     r.name = name;
-    (void)hipEventCreate(&r.a);
-    (void)hipEventCreate(&r.b);
-    (void)hipEventRecord(r.a, (hipStream_t)stream);
-    g_prof.push_back(r);
+    r.a = prof_event();
+    r.b = prof_event();
+    if (!r.a || !r.b) return;
+    *start = (void*)r.a;
+    *stop = (void*)r.b;
+    g_prof.push_back(std::move(r));
 #else
     (void)name;
-    (void)stream;
-#endif
-}
-void nh_prof_end(nerfhip_stream_t stream) {
-#ifndef NERFHIP_EMU
-    if (!g_prof_on || g_prof.empty()) return;
-    (void)hipEventRecord(g_prof.back().b, (hipStream_t)stream);
-#else
-    (void)stream;
 #endif
 }
 extern "C" int nerfhip_profile_enable(int on) {
@@ -78,6 +83,22 @@ extern "C" int nerfhip_profile_enable(int on) {
     }
 #endif
     g_prof_on = on != 0;
+    return NERFHIP_OK;
+}
+// Pre-creates the event pairs of `launches` launches, so that none is created inside a timed region.
+extern "C" int nerfhip_profile_reserve(int64_t launches) {
+    NH_REQUIRE(launches >= 0 && launches <= (1 << 20), "profile_reserve: bad arguments");
+#ifndef NERFHIP_EMU
+    while ((int64_t)g_prof_pool.size() < 2 * launches) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) {
+            nh_set_error("profile_reserve: hipEventCreate failed");
+            return NERFHIP_ERR_LAUNCH;
+        }
+        g_prof_pool.push_back(e);
+    }
+    g_prof.reserve(g_prof.size() + (size_t)launches);
+#endif
     return NERFHIP_OK;
 }
 // Shader clock the MLP kernels ran at while profiling was enabled: out[3 * k + {0,1,2}] = shader-clock cycles, 100 MHz
@@ -109,8 +130,8 @@ extern "C" int nerfhip_profile_report(char* buf, int64_t cap) {
         (void)hipEventSynchronize(r.b);
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, r.a, r.b);
-        (void)hipEventDestroy(r.a);
-        (void)hipEventDestroy(r.b);
+        g_prof_pool.push_back(r.a);
+        g_prof_pool.push_back(r.b);
         auto& e = acc[r.name];
         e.first += 1;
         e.second += ms;

@@ -591,9 +591,10 @@ void build_layouts_and_jobs(nerfhip_plan* p) {
     const int TW = W / 32, H = p->H, H2 = H / 2;
     // BF16X3_TRAIN: the hidden x hidden blocks go to the split-bf16 weight-gradient kernel instead (wgrad_bf16.hip)
     p->bjobs.clear();
-    // (256-wide nets only: for the 128 x 128 blocks of narrower nets the conversion outweighs the MFMAs -- measured on MI355X:
-    // 4x128 step 4.23 -> 5.04 ms -- so there BF16X3_TRAIN is BF16X3_FWD_DGRAD)
-    const bool big_b = nh_prec_level(p->precision) == 4 && W >= 256;
+    // (128- and 256-wide nets; 128: the four full blocks only -- the half-height block of layers_dir stays a thin job.  Round 3's
+    // kernel lost on the 128 x 128 blocks (4x128 step 4.23 -> 5.04 ms); round 4's, which waits for HBM and nothing else, wins:
+    // 4.35 -> 4.04 ms, profiles/r04_wgrad_128_ab.txt.  Other widths: _TRAIN is _FWD_DGRAD)
+    const bool big_b = nh_prec_level(p->precision) == 4 && (W == 128 || W == 256);
     auto add_big = [&](const NhRegion& A, int a_rows, const NhRegion& B, int r_hi, int w_tensor, int bias_tensor, int a_idx, int b_idx) {
         NhJobB j;
         j.a_idx = a_idx;
@@ -624,7 +625,7 @@ void build_layouts_and_jobs(nerfhip_plan* p) {
         else
             add_job(p, G.PFEAT, TW, S.H[L - 1], 0, TW, 0, H, p->t_feat_w, 0, 0, H, p->t_feat_b);
         add_job(p, G.POUT, 1, S.H[L - 1], 0, TW, 3, 4, p->t_alpha_w, 0, 0, H, p->t_alpha_b);
-        if (big_b)
+        if (big_b && W >= 256)
             add_big(G.PDIR, W / 2, S.FEAT, H2, p->t_dir_w, p->t_dir_b, L + 1, L);
         else
             add_job(p, G.PDIR, TW / 2, S.FEAT, 0, TW, 0, H2, p->t_dir_w, 0, 0, H, p->t_dir_b);

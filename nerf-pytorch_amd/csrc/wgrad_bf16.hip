@@ -403,9 +403,12 @@ int NHB_FN(nh_wgrad)(nerfhip_plan* p, int64_t nt, const float* stash, const floa
     if (full.njobs) first = (int64_t)(full.jobs[full.njobs - 1].wg0 + full.jobs[full.njobs - 1].nwg) * full.part_stride;
     half.partial = partial + first;
     int rc = NERFHIP_OK;
-    if (p->W == 256) {  // (plan.cpp hands this kernel blocks only for the 256-wide nets)
+    if (p->W == 256) {  // (plan.cpp hands this kernel blocks only for the 256- and 128-wide nets)
         rc = launch<256, 256>(full, stream);
         if (!rc) rc = launch<128, 256>(half, stream);
+    } else if (p->W == 128) {
+        NH_REQUIRE(half.njobs == 0, "wgrad_" NHB_FMT ": no half-height kernel for kernel width 128");
+        rc = launch<128, 128>(full, stream);
     } else {
         nh_set_error("wgrad_" NHB_FMT ": no kernel for kernel width %d", p->W);
         return NERFHIP_ERR_UNSUPPORTED;

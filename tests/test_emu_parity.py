@@ -113,7 +113,7 @@ def test_mlp_bf16x3_whole_training_step(emu):
     """NERFHIP_PRECISION_BF16X3_TRAIN: forward, data gradient AND the large weight-gradient blocks on the bf16 MFMAs (the thin
     blocks -- encoding columns, fc_alpha, fc_rgb / fc_out -- stay on the fp32 kernel)."""
     P.case_mlp_backward(emu, names=("skip_every_layer_256", "one_layer_novw_256", "odd5x99_skip2"), m=120,
-                        precision=P.BF16X3_TRAIN)  # (the 256-wide ones reach k_wgrad_bf16x3; GPU: eight geometries)
+                        precision=P.BF16X3_TRAIN)  # (the 128- and 256-wide ones reach k_wgrad_bf16x3; GPU: eight geometries)
     P.case_render_vs_oracle(emu, P.MLP_GEOMETRIES["default4x128"], n=12, nc=16, nf=16, with_grads=True, tag="bf16x3_train_emu",
                             tol=5e-4, grad_tol=(5e-3, 5e-2), precision=P.BF16X3_TRAIN)
 
@@ -133,15 +133,15 @@ def test_mlp_f16x3_training_levels_hold_the_fp32_gradient_bounds(emu):
     a power of two taken from its maximum (tiny cotangents: the fp16 pieces would otherwise flush them)."""
     P.case_mlp_backward(emu, names=("default4x128", "skip_every_layer_256"), m=120, precision=P.F16X3_FWD)
     P.case_mlp_backward(emu, names=("fern8x128_skip3_L6", "novw4x128", "one_layer"), m=120, precision=P.F16X3_FWD_DGRAD)
-    P.case_mlp_backward(emu, names=("skip_every_layer_256", "one_layer_novw_256"), m=120, precision=P.F16X3_TRAIN)
-    P.case_mlp_backward(emu, names=("default4x128",), m=100, precision=P.F16X3_FWD_DGRAD, g_scale=3e-7)
+    P.case_mlp_backward(emu, names=("skip_every_layer_256", "one_layer_novw_256", "default4x128"), m=120, precision=P.F16X3_TRAIN)
+    P.case_mlp_backward(emu, names=("default4x128",), m=100, precision=P.F16X3_TRAIN, g_scale=3e-7)
     # weights 4x torch's init: activations in the thousands, d(pre-activation) a million times d(raw output) -- no fixed fp16 scale
     # holds both ends; the per-sample exponents (forward and data gradient) and the per-region scales of k_wgrad_f16x3 do
     P.case_mlp_backward(emu, names=("skip_every_layer_256",), m=100, precision=P.F16X3_TRAIN, w_gain=4.0, g_scale=1e-4)
     P.case_mlp_backward(emu, names=("default4x128",), m=100, precision=P.F16X3_FWD_DGRAD, w_gain=0.25)
     P.case_mlp_input_grad(emu, names=("default4x128", "novw4x128"), m=45, precision=P.F16X3_FWD_DGRAD)
     P.case_render_vs_oracle(emu, P.MLP_GEOMETRIES["default4x128"], n=12, nc=16, nf=16, with_grads=True, tag="f16x3_train_emu",
-                            precision=P.F16X3_FWD_DGRAD)
+                            precision=P.F16X3_TRAIN)  # (128-wide nets: the four full blocks reach k_wgrad_f16x3<128, 128>)
 
 
 def test_ndc_rays_backward(emu):

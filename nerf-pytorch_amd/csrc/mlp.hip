@@ -77,8 +77,8 @@ int nh_mlp_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, i
     if (p->precision != NERFHIP_PRECISION_FP32) {
         NH_REQUIRE(!stash || nh_prec_level(p->precision) != 1,
                    "mlp_fwd: a bf16x3 / f16x3 plan is inference-only (no activation stash, no backward; the _FWD / _FWD_DGRAD / _TRAIN plans train)");
-        return nh_prec_f16(p->precision) ? nh_mlp_forward_f16(p, packed, in, M, out, stash, stream)
-                                         : nh_mlp_forward_bf16(p, packed, in, M, out, stash, stream);
+        if (!nh_prec_f16(p->precision)) return nh_mlp_forward_bf16(p, packed, in, M, out, stash, stream);
+        return p->w2 ? nh_mlp_forward_f16w(p, packed, in, M, out, stash, stream) : nh_mlp_forward_f16(p, packed, in, M, out, stash, stream);
     }
     return nh_mlp16_forward(p, packed, in, M, out, stash, stream);
 }
@@ -103,7 +103,8 @@ int nh_mlp_backward(nerfhip_plan* p, const float* packed, const float* g_out, in
         if (rc) return rc;
     }
     if (bdg)
-        rc = f16 ? nh_mlp_dgrad_f16(p, packed, g_out, M, stash, scratch, amax, stream)
+        rc = f16 ? (p->w2 ? nh_mlp_dgrad_f16w(p, packed, g_out, M, stash, scratch, amax, stream)
+                          : nh_mlp_dgrad_f16(p, packed, g_out, M, stash, scratch, amax, stream))
                  : nh_mlp_dgrad_bf16(p, packed, g_out, M, stash, scratch, nullptr, stream);
     else
         rc = nh_mlp16_dgrad(p, packed, g_out, M, stash, scratch, stream);

@@ -74,6 +74,12 @@ NH_DEVICE float nh_from_f16(nh_f16 h) { return (float)h; }
 NH_DEVICE f32x16 nh_mfma_f16(nh_f16x8 a, nh_f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
+// v_mfma_f32_16x16x32_f16 (the two-waves-per-SIMD kernels of mlp_f16w.hip): D = A(16x32) * B(32x16) + C; lane l supplies
+// A[l&15][8*(l>>4) + e] and B[8*(l>>4) + e][l&15], e = 0..7; D register c of lane l is D[4*(l>>4) + c][l&15] -- the C/D layout of
+// nh_mfma16.  16 cycles per instruction and SIMD.
+NH_DEVICE f32x4 nh_mfma_f16_16(nh_f16x8 a, nh_f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
 // eight pieces times a power of two (v_pk_mul_f16: exact unless a piece leaves fp16's range at the bottom)
 NH_DEVICE nh_f16x8 nh_f16x8_scale(nh_f16x8 v, float pow2) { return v * (nh_f16)pow2; }
 

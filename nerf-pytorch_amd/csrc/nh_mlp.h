@@ -35,6 +35,12 @@ int nh_mlp_forward_f16(nerfhip_plan* p, const float* packed, const NhMlpInput& i
                        nerfhip_stream_t stream);
 int nh_mlp_dgrad_f16(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
                      unsigned* rmax, nerfhip_stream_t stream);
+// mlp_f16w.hip: the same arithmetic with two waves per SIMD (16-sample waves on v_mfma_f32_16x16x32_f16), for plans whose images are
+// in that geometry (nerfhip_plan::w2)
+int nh_mlp_forward_f16w(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
+                        nerfhip_stream_t stream);
+int nh_mlp_dgrad_f16w(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
+                      unsigned* rmax, nerfhip_stream_t stream);
 // mlp.hip: n words of device memory to zero, on the stream
 int nh_zero_words(unsigned* dev, int n, nerfhip_stream_t stream);
 int nh_pack_pieces_f16(nerfhip_plan* plan, const float* params, const int32_t* table, float* packed, nerfhip_stream_t stream);

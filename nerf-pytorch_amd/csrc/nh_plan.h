@@ -59,6 +59,19 @@ constexpr int nhb_first_bytes(int nk, int nt, int W) {
     return 2048 + (nk < nhb_chunk_bytes(W) / (nt * 2048) ? nk : nhb_chunk_bytes(W) / (nt * 2048)) * nt * 2048;
 }
 
+// The same images for the two-waves-per-SIMD fp16 kernels (mlp_f16w.hip, v_mfma_f32_16x16x32_f16; nerfhip_plan::w2): 16-row output
+// tiles and 32-deep k-blocks -- lane l of a (k-block kb, tile t) block holds W[16 t + (l & 15)][in(kb, l >> 4, e)], e = 0..7.
+// Hidden inputs: in = nhw_unit(kb, g, e), the unit accumulator register e & 3 of output tile 2 kb + (e >> 2) holds for lane group
+// g; encoding inputs: slot 32 kb + 8 g + e (the SAME slot numbering: the stash's slot rows and the weight-gradient scatter do not
+// change).  Blocks are streamed in linear (kb, t) order, NHW_CHUNK_BLOCKS of them per LDS chunk buffer.
+#ifndef NHB_W2_DEFAULT  // (A/B builds: 0 keeps the fp16 plans on the one-wave-per-SIMD kernels of mlp_f16.hip)
+#define NHB_W2_DEFAULT 1
+#endif
+static inline int nhw_unit(int kb, int g, int e) { return 32 * kb + 16 * (e >> 2) + 4 * g + (e & 3); }
+constexpr int NHW_XBLOCKS = 2, NHW_DBLOCKS = 1;
+constexpr int nhw_chunk_blocks(int W) { return W >= 256 ? 32 : 16; }  // 2-KiB (hi + lo) blocks per chunk buffer
+constexpr int nhw_first_bytes(int nblocks, int W) { return 2048 + (nblocks < nhw_chunk_blocks(W) ? nblocks : nhw_chunk_blocks(W)) * 2048; }
+
 // Split-precision plans (include/nerfhip.h NERFHIP_PRECISION_*): `level` says which kernels run on the 16-bit MFMAs -- 0 none
 // (fp32), 1 the inference forward only (inference-only plan), 2 + the training forward, 3 + the data-gradient chain, 4 + the
 // large weight-gradient blocks -- and `f16` which pieces they multiply: bf16 (8 significant bits each, 8-bit exponent) or IEEE
@@ -157,6 +170,7 @@ struct nerfhip_plan {
     int t_layer1_w, t_layer1_b, t_xyz_w[NH_MAX_LAYERS], t_xyz_b[NH_MAX_LAYERS];
     int t_dir_w, t_dir_b, t_alpha_w, t_alpha_b, t_rgb_w, t_rgb_b, t_feat_w, t_feat_b, t_out_w, t_out_b;
     int precision;                    // NERFHIP_PRECISION_*: nh_prec_level() / nh_prec_f16() above
+    int w2;                           // split-precision images in the geometry of mlp_f16w.hip (16-row tiles, 32-deep k-blocks): fp16 plans
     NhPackedOffsets pob;              // bf16x3 plans: word offsets of the split-bf16 layer images inside the packed buffer
     int64_t packed32_floats;          // words of the fp32 image in front of them (0 for _BF16X3, the whole buffer for _FP32)
     int xyz_slot_b[16 * NHB_XBLOCKS];  // bf16x3 plans: encoding slot -> reference column, or -1

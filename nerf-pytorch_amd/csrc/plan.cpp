@@ -236,13 +236,17 @@ bool build_slot_map_b(int L, int include_input, int nslots, int* col) {
 }
 
 void build_specs_b(const nerfhip_plan* p, SpecsB& S) {
-    const int W = p->W, H = p->H, H2 = H / 2, KBH = W / 16, TH = W / 32, Dx = p->Dx, Dd = p->Dd, L = p->L;
+    // (w2: the geometry of mlp_f16w.hip -- `h` is then the lane group l >> 4 and a k-block is 32 inputs deep: nh_plan.h)
+    const bool w2 = p->w2 != 0;
+    const int W = p->W, H = p->H, H2 = H / 2, KBH = w2 ? W / 32 : W / 16, TH = w2 ? W / 16 : W / 32, Dx = p->Dx, Dd = p->Dd, L = p->L;
+    const int XBLOCKS = w2 ? NHW_XBLOCKS : NHB_XBLOCKS, DBLOCKS = w2 ? NHW_DBLOCKS : NHB_DBLOCKS;
     auto T = [p](int idx) { return p->tensors[idx]; };
-    auto xcol = [p](int kb, int h, int e) { return p->xyz_slot_b[16 * kb + 8 * h + e]; };
-    auto dcol = [p](int kb, int h, int e) { return p->dir_slot_b[16 * kb + 8 * h + e]; };
+    auto xcol = [p, w2](int kb, int h, int e) { return p->xyz_slot_b[(w2 ? 32 : 16) * kb + 8 * h + e]; };
+    auto dcol = [p, w2](int kb, int h, int e) { return p->dir_slot_b[(w2 ? 32 : 16) * kb + 8 * h + e]; };
+    auto nhb_unit = [w2](int kb, int h, int e) { return w2 ? nhw_unit(kb, h, e) : ::nhb_unit(kb, h, e); };
     {
         GemmSpecB& s = S.f_layer1;
-        s.nk = NHB_XBLOCKS;
+        s.nk = XBLOCKS;
         s.nt = TH;
         NhTensor w = T(p->t_layer1_w), b = T(p->t_layer1_b);
         s.w = [=](int o, int kb, int h, int e) -> int64_t {
@@ -254,7 +258,7 @@ void build_specs_b(const nerfhip_plan* p, SpecsB& S) {
     for (int i = 0; i < L - 1; ++i) {
         GemmSpecB& s = S.f_xyz[i];
         const bool sk = p->is_skip(i);
-        s.nk = KBH + (sk ? NHB_XBLOCKS : 0);
+        s.nk = KBH + (sk ? XBLOCKS : 0);
         s.nt = TH;
         NhTensor w = T(p->t_xyz_w[i]), b = T(p->t_xyz_b[i]);
         const int ld = H + (sk ? Dx : 0);
@@ -284,7 +288,7 @@ void build_specs_b(const nerfhip_plan* p, SpecsB& S) {
         }
         {
             GemmSpecB& s = S.f_dir;
-            s.nk = KBH + NHB_DBLOCKS;
+            s.nk = KBH + DBLOCKS;
             s.nt = TH / 2;
             const int ld = H + Dd;
             s.w = [=](int o, int kb, int h, int e) -> int64_t {
@@ -386,14 +390,15 @@ void for_each_spec_b(const nerfhip_plan* p, SpecsB& S, NhPackedOffsets& o, Fn fn
     }
 }
 
-void fill_spec_b(const GemmSpecB& s, int64_t off, int32_t* table) {
-    for (int i = 0; i < 512; ++i) table[off + i] = (i < 32 * s.nt && s.b) ? (int32_t)s.b(i) : -1;
+void fill_spec_b(const GemmSpecB& s, int64_t off, int32_t* table, bool w2) {
+    const int R = w2 ? 16 : 32;  // rows of an output tile; a lane is (row l & (R - 1), group l / R)
+    for (int i = 0; i < 512; ++i) table[off + i] = (i < R * s.nt && s.b) ? (int32_t)s.b(i) : -1;
     int32_t* img = table + off + 512;
     for (int kb = 0; kb < s.nk; ++kb)
         for (int t = 0; t < s.nt; ++t)
             for (int lane = 0; lane < 64; ++lane)
                 for (int e = 0; e < 8; ++e)
-                    img[(((int64_t)kb * s.nt + t) * 64 + lane) * 8 + e] = (int32_t)s.w(32 * t + (lane & 31), kb, lane >> 5, e);
+                    img[(((int64_t)kb * s.nt + t) * 64 + lane) * 8 + e] = (int32_t)s.w(R * t + (lane & (R - 1)), kb, lane / R, e);
 }
 
 // the split-bf16 layer images, behind the first `base` words of the packed buffer
@@ -678,6 +683,7 @@ static nerfhip_plan_t plan_create_impl(const nerfhip_model_cfg* cfg, int precisi
     nerfhip_plan* p = new nerfhip_plan();
     p->cfg = *cfg;
     p->precision = precision;
+    p->w2 = 0;
     p->H = cfg->hidden_size;
     // the kernels exist for four widths; a model rides zero-padded on the next one (build_specs16)
     p->W = p->H <= 64 ? 64 : (p->H <= 128 ? 128 : (p->H <= 256 ? 256 : 512));
@@ -753,6 +759,8 @@ static nerfhip_plan_t plan_create_impl(const nerfhip_model_cfg* cfg, int precisi
             delete p;
             return nullptr;
         }
+        // fp16 pieces: the two-waves-per-SIMD kernels of mlp_f16w.hip and their image geometry
+        p->w2 = (NHB_W2_DEFAULT && nh_prec_f16(precision)) ? 1 : 0;
         memset(&p->po, 0, sizeof(p->po));
         p->packed_floats = 0;
         if (nh_prec_level(precision) != 1) {
@@ -804,8 +812,9 @@ extern "C" int nerfhip_plan_describe(nerfhip_plan_t plan, char* buf, int64_t cap
         const int w = snprintf(buf + used, (size_t)(cap - used), fmt, v...);
         if (w > 0) used += w < cap - used ? w : cap - used - 1;
     };
-    put("kernel_width %d hidden_size %d layers %d params %lld packed_floats %lld wgrad_waves %d jobs %d precision %d\n", plan->W, plan->H,
-        plan->L, (long long)plan->nparams, (long long)plan->packed_floats, plan->wgrad_waves, (int)plan->jobs.size(), plan->precision);
+    put("kernel_width %d hidden_size %d layers %d params %lld packed_floats %lld wgrad_waves %d jobs %d precision %d two_wave_images %d\n",
+        plan->W, plan->H, plan->L, (long long)plan->nparams, (long long)plan->packed_floats, plan->wgrad_waves, (int)plan->jobs.size(),
+        plan->precision, plan->w2);
     for (size_t q = 0; q < plan->jobs.size(); ++q) {
         const NhJob& j = plan->jobs[q];
         put("job %d tiles %dx%d waves %dx%d patch %dx%d cost %d side %d side_tiles %d\n", (int)q, j.a_tiles, j.b_tiles, j.wo, j.wi, j.po,
@@ -820,7 +829,7 @@ extern "C" int nerfhip_plan_pack_index(nerfhip_plan_t plan, int32_t* host_table)
         SpecsB S;
         build_specs_b(plan, S);
         NhPackedOffsets o = plan->pob;
-        for_each_spec_b(plan, S, o, [&](const GemmSpecB& s, int64_t* dst) { fill_spec_b(s, *dst, host_table); });
+        for_each_spec_b(plan, S, o, [&](const GemmSpecB& s, int64_t* dst) { fill_spec_b(s, *dst, host_table, plan->w2 != 0); });
         if (nh_prec_level(plan->precision) == 1) return NERFHIP_OK;
     }
     Specs16 S16;

@@ -276,6 +276,34 @@ NH_DEVICE f32x16 nh_mfma_f16(nh_f16x8 a, nh_f16x8 b, f32x16 c) {
     return d;
 }
 
+// v_mfma_f32_16x16x32_f16 (mlp_f16w.hip): lane l supplies A[l&15][8*(l>>4)+e] and B[8*(l>>4)+e][l&15]; D register c of lane l is
+// D[4*(l>>4)+c][l&15]; exact products, fp32 fmaf chain in k order
+NH_DEVICE f32x4 nh_mfma_f16_16(nh_f16x8 a, nh_f16x8 b, f32x4 c) {
+    emu::WaveState& w = emu::cur_wave();
+    const int lane = emu::cur->lane, j = lane & 15, g = lane >> 4;
+    f32x4 d = c;
+    for (int part = 0; part < 2; ++part) {  // elements 4*part .. 4*part+3 of every lane: 8 bytes per exchange
+        int ph = emu::cur->xphase;
+        emu::cur->xphase ^= 1;
+        memcpy(&w.xa[ph][lane], &a.v[4 * part], 8);
+        memcpy(&w.xb[ph][lane], &b.v[4 * part], 8);
+        emu::wave_barrier();
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * g + r;
+            float acc = d[r];
+            for (int gg = 0; gg < 4; ++gg)
+                for (int e = 0; e < 4; ++e) {
+                    nh_f16 av[4], bv[4];
+                    memcpy(av, &w.xa[ph][i + 16 * gg], 8);
+                    memcpy(bv, &w.xb[ph][j + 16 * gg], 8);
+                    acc = fmaf(nh_from_f16(av[e]), nh_from_f16(bv[e]), acc);
+                }
+            d[r] = acc;
+        }
+    }
+    return d;
+}
+
 // ds_read_b64_tr_b16 semantics (nh_device.h): element j of lane i's result = element (i & 3) of lane 4 j + (i >> 2) of its quarter wave
 NH_DEVICE unsigned long long nh_lds_tr16(const char* lds_ptr) {
     emu::WaveState& w = emu::cur_wave();

@@ -177,7 +177,7 @@ def test_product_reads_no_environment_and_ships_one_kernel_set():
     assert wg.count("#ifdef NH_WGRAD_TIMELINE") >= 3 and "nh_wall_clock()" in wg  # instrumentation is debug-build only
     assert sorted(f for f in os.listdir(csrc) if f.endswith(".hip")) == [
         "dataio.hip", "elementwise.hip", "fused.hip", "mlp.hip", "mlp16.hip", "mlp16_ext.hip", "mlp16_w512.hip", "mlp_bf16.hip", "mlp_f16.hip",
-        "render.hip", "sample.hip", "wgrad.hip", "wgrad_bf16.hip", "wgrad_f16.hip"]
+        "mlp_f16w.hip", "render.hip", "sample.hip", "wgrad.hip", "wgrad_bf16.hip", "wgrad_f16.hip"]
 
 
 def test_shard_bounds():

@@ -46,6 +46,7 @@ struct WCtx {
     unsigned lds_addr;
     NhDmaSrc dma;
     int buf, lane, wave, g;
+    bool landed;    // this wave has already waited for its copy pieces of the chunk about to be multiplied (gemm_w: the mid-chunk wait)
     unsigned* wrm;  // level-4 plans: this wave's NH_RMAX_WORDS region slots in LDS, else NULL
 };
 // the rows a gemm stored for region `ridx` came from pieces below 2^(TARGET + 1) at per-sample exponent s: note the bound
@@ -90,6 +91,11 @@ struct MaskW {
 // mul; BITS: the ReLU bits of the values as the next layer consumes them (hi > 0), shift-accumulated in register order
 template <bool RELU, bool BITS>
 NH_DEVICE void convert_pair(const f32x4& a0, const f32x4& a1, nh_f16x8& oh, nh_f16x8& ol, float mul, MaskW& bits, int r0) {
+#ifdef NHW_EXP_NO_EPI  // (diagnostic builds only, wrong results: what the kernel costs without the conversions)
+    oh[0] = nh_to_f16(a0[0] * mul);
+    ol[4] = nh_to_f16(a1[0]);
+    return;
+#endif
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         float v = (e < 4 ? a0[e & 3] : a1[e & 3]) * mul;
@@ -122,9 +128,13 @@ NH_DEVICE unsigned tile_max_bits(const f32x4* acc) {
 // [2^13, 2^14) (never above `cap`): the renormalisation step of the data-gradient chain
 template <int NT>
 NH_DEVICE int renorm_convert(const f32x4* acc, nh_f16x8* oh, nh_f16x8* ol, int s_in, int cap) {
-    const unsigned mb = tile_max_bits<NT, false>(acc);
     const int base_e = WS_LOG2 + s_in;
+#ifdef NHW_EXP_NO_MAX  // (diagnostic builds only, wrong results)
+    int so = base_e;
+#else
+    const unsigned mb = tile_max_bits<NT, false>(acc);
     int so = exp_for(mb, base_e);
+#endif
     so = so < cap ? so : cap;
     so = so > base_e + 120 ? base_e + 120 : (so < base_e - 120 ? base_e - 120 : so);
     const float mul = nh_pow2i(so - base_e);
@@ -159,6 +169,9 @@ constexpr int w_store_block(int ts, int nts, int nblk, int cb) {
     const int n_c = (nblk - c * cb) < cb ? (nblk - c * cb) : cb;
     const int half = n_c / 2, room = n_c - half;
     if (NHW_STORES_FIRST) return c * cb + ((ts - b0) * (half > 0 ? half : 1)) / (b1 - b0);
+#ifdef NHW_STORES_SPREAD  // (A/B builds only) over the whole chunk
+    return c * cb + ((ts - b0) * n_c) / (b1 - b0);
+#endif
     return c * cb + half + ((ts - b0) * room) / (b1 - b0);
 }
 
@@ -198,12 +211,23 @@ NH_DEVICE void gemm_w(WCtx& cx, const nh_f16x8* ah, const nh_f16x8* al, const nh
         float v2 = nh_from_f16(ah[kb][o + 2]) + nh_from_f16(al[kb][o + 2]);
         float v3 = nh_from_f16(ah[kb][o + 3]) + nh_from_f16(al[kb][o + 3]);
         v0 *= row_scale, v1 *= row_scale, v2 *= row_scale, v3 *= row_scale;
+#ifdef NHW_EXP_NO_STORE  // (diagnostic builds only, wrong results: what the stores themselves cost)
+        if (v0 != 1.2345e-30f || v1 != 5.4321e-30f) return;
+#endif
         nh_store4(in_rows + 16 * ts + 4 * cx.g, v0, v1, v2, v3);  // units 16 ts + 4 g .. + 3
     };
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        nh_wait_vmem();    // this wave's pieces of the current chunk have landed (and its stash stores: vmcnt counts them) ...
+        // this wave's pieces of the current chunk have landed (and its stash stores: vmcnt counts them) ...
+#ifdef NHW_MID_WAIT
+        if (!cx.landed) nh_wait_vmem();
+        cx.landed = false;
+#else
+        nh_wait_vmem();
+#endif
+#ifndef NHW_EXP_NO_BARRIER  // (diagnostic builds only, wrong results: what the chunk barriers cost)
         nh_block_sync();   // ... and everyone's; nobody still reads the other buffer
+#endif
         // the next chunk (or the next layer's first one) goes to the other buffer WHILE this one is multiplied
         int64_t dsrc = 0;
         int dpieces = 0, ddst = 0;
@@ -213,10 +237,17 @@ NH_DEVICE void gemm_w(WCtx& cx, const nh_f16x8* ah, const nh_f16x8* al, const nh
         } else if (next_first > 0) {
             dsrc = next_base, dpieces = next_first >> 10, ddst = 0;
         }
+#ifdef NHW_EXP_NO_STREAM  // (diagnostic builds only, wrong results: what the kernel costs without the weight stream)
+        dpieces = dpieces < 8 ? dpieces : 8;
+#endif
         int dnext = cx.wave;  // this wave's next piece
         auto dma_step = [&]() {
             if (dnext < dpieces) {
+#ifdef NHW_EXP_SAME_SRC  // (diagnostic builds only, wrong results: every piece re-reads the image's first 8 KiB -- issue and LDS cost without the L2 traffic)
+                nh_dma16a(cx.dma, cx.lane * 16, (dnext & 7) * 1024, cx.lds_addr + (unsigned)((cx.buf ^ 1) * BUF + ddst + dnext * 1024));
+#else
                 nh_dma16a(cx.dma, cx.lane * 16, (int)dsrc + dnext * 1024, cx.lds_addr + (unsigned)((cx.buf ^ 1) * BUF + ddst + dnext * 1024));
+#endif
                 dnext += 8;
             }
         };
@@ -249,7 +280,11 @@ NH_DEVICE void gemm_w(WCtx& cx, const nh_f16x8* ah, const nh_f16x8* al, const nh
         nh_f16x8 wph[4], wpl[4];
         auto load = [&](int i) {
             wph[i & 3] = *(const nh_f16x8*)(wb + (2 * i) * 1024);
+#ifdef NHW_EXP_HALF_LDS  // (diagnostic builds only, wrong results: half of the operand reads)
+            wpl[i & 3] = wph[i & 3];
+#else
             wpl[i & 3] = *(const nh_f16x8*)(wb + (2 * i + 1) * 1024);
+#endif
         };
         if (0 < nblk) load(0);
         if (1 < nblk) load(1);
@@ -260,7 +295,25 @@ NH_DEVICE void gemm_w(WCtx& cx, const nh_f16x8* ah, const nh_f16x8* al, const nh
                 if (ip + 2 < nblk) load(ip + 2);
                 if (ip + 3 < nblk) load(ip + 3);
                 // one copy piece per pair: the copy is out before the chunk's second half ...
+#ifdef NHW_DMA_BURST  // (A/B builds only) all of a wave's pieces at the chunk's start: forward +7 %, data gradient -2 %
+                if (ip == 0)
+                    while (dnext < dpieces) dma_step();
+#elif defined(NHW_DMA_ONE)  // (A/B builds only) one piece per pair: forward +5 %, data gradient +4 %
                 if (!(NHW_STORES_FIRST && NTS > 0) || ip >= nblk / 2) dma_step();
+#else  // two pieces per pair: the copy is out after a quarter of the chunk
+                dma_step();
+                dma_step();
+#endif
+#ifdef NHW_MID_WAIT
+                // Training launches, chunks of at least 20 blocks: the wave waits for its copy pieces HERE, half a chunk after it
+                // issued them (2 per pair: at most 10 by pair 5) and before its first store of this chunk -- the next chunk's barrier
+                // then needs no vmcnt wait, and the stores stay in flight across it (they are waited for here, half a chunk later)
+                if (NTS > 0 && nblk >= 20 && ip == ((nblk / 2) & ~1)) {
+                    while (dnext < dpieces) dma_step();
+                    nh_wait_vmem();
+                    cx.landed = true;
+                }
+#endif
                 if (NTS > 0) {  // ... which carries the stores
 #pragma unroll
                     for (int ts = 0; ts < NTS; ++ts) {
@@ -290,9 +343,16 @@ NH_DEVICE void gemm_w(WCtx& cx, const nh_f16x8* ah, const nh_f16x8* al, const nh
     if (NTS > 0 && cx.wrm && ridx >= 0) note_region(cx, ridx, s_in);
     if (EPI != 0) {
         float mul = 1.0f / WS;
+#ifdef NHW_EXP_NO_MAX  // (diagnostic builds only, wrong results: what the per-sample exponent search costs)
+        if (DYN) *s_out = s_in;
+        if (false) {
+#else
         if (DYN) {
+#endif
             // the accumulators hold WS * 2^s_in * value: move the sample's largest output to [2^13, 2^14) -- unless the next
             // layer's encodings sit lower -- and remember the exponent the pieces now carry
+            // (collecting the maximum tile by tile under the last k-block's MFMAs instead measured 3.5 % SLOWER on the forward:
+            // profiles/r04_f16w_ab.txt)
             const unsigned mb = tile_max_bits<NTE, EPI == 1>(acc);
             const int base_e = WS_LOG2 + s_in;
             int so = exp_for(mb, base_e);
@@ -418,6 +478,7 @@ NH_KERNEL void NH_LB(512, 2) k_mlp_fwd_f16w(FwdWArgs a) {
     cx.lds_addr = nh_lds_addr((const float*)lds_raw);
     cx.dma = nh_dma_src(a.packed, a.packed_bytes);
     cx.buf = 0;
+    cx.landed = false;
     cx.lane = nh_lane();
     cx.wave = nh_wave_in_block();
     cx.g = cx.lane >> 4;
@@ -577,6 +638,7 @@ NH_KERNEL void NH_LB(512, 2) k_mlp_dgrad_f16w(DgradWArgs a) {
     cx.lds_addr = nh_lds_addr((const float*)lds_raw);
     cx.dma = nh_dma_src(a.packed, a.packed_bytes);
     cx.buf = 0;
+    cx.landed = false;
     cx.lane = nh_lane();
     cx.wave = nh_wave_in_block();
     cx.g = cx.lane >> 4;
@@ -768,7 +830,7 @@ int nh_mlp_forward_f16w(nerfhip_plan* p, const float* packed, const NhMlpInput& 
     {                                                                                                             \
         rc = w_lds_limit(k_mlp_fwd_f16w<WW, VV, TT>, WShape<WW>::LDS_BYTES + RM_LDS);                             \
         if (rc) return rc;                                                                                        \
-        NH_LAUNCH_NAMED("k_mlp_fwd_f16w<" #WW ", " #VV ", " #TT ">", (k_mlp_fwd_f16w<WW, VV, TT>), grid, 512,      \
+        NH_LAUNCH_NAMED("k_mlp_fwd_f16x3w<" #WW ", " #VV ", " #TT ">", (k_mlp_fwd_f16w<WW, VV, TT>), grid, 512,      \
                         WShape<WW>::LDS_BYTES + RM_LDS, stream, a);                                               \
     }
 #define NH_FWDW(WW, VV)              \
@@ -816,7 +878,7 @@ int nh_mlp_dgrad_f16w(nerfhip_plan* p, const float* packed, const float* g_out, 
     {                                                                                                             \
         rc = w_lds_limit(k_mlp_dgrad_f16w<WW, VV>, WShape<WW>::LDS_BYTES + RM_LDS);                               \
         if (rc) return rc;                                                                                        \
-        NH_LAUNCH_NAMED("k_mlp_dgrad_f16w<" #WW ", " #VV ">", (k_mlp_dgrad_f16w<WW, VV>), grid, 512,               \
+        NH_LAUNCH_NAMED("k_mlp_dgrad_f16x3w<" #WW ", " #VV ">", (k_mlp_dgrad_f16w<WW, VV>), grid, 512,               \
                         WShape<WW>::LDS_BYTES + RM_LDS, stream, d);                                               \
     }
     if (p->W == 256 && p->view) NH_BWDW(256, true)

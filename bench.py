@@ -579,9 +579,15 @@ def main():
         dgrad_b = 4 * (Ln * Wd + Wd + Wd // 2 + 32) + 8 * (Ln + 1) + 16
         wgrad_b = wgrad_bytes_per_sample(cfg)
         # the hidden x hidden blocks of the level-4 plans: layers_xyz, fc_feat and -- 256-wide kernels only -- the hidden columns of layers_dir
+        # ... and the thin blocks that ride on them as guests (wgrad_bf16.hip SA / SB): a skip layer's xyz columns, fc_alpha's row,
+        # the direction columns -- their own regions are the only bytes they add
         wide = Wd > 128
-        big_macs = (Ln - 1) * Wd * Wd + Wd * Wd + ((Wd // 2) * Wd if wide else 0)
-        big_b = 4 * (Ln * 2 * Wd + ((Wd // 2 + Wd) if wide else 0))
+        n_skip = sum(1 for i in range(1, Ln - 1) if i % cfg["skip_connect_every"] == 0)
+        big_macs = (Ln - 1) * Wd * Wd + Wd * Wd + ((Wd // 2) * Wd if wide else 0) + n_skip * Wd * dx + Wd + ((Wd // 2) * dd if wide else 0)
+        big_b = 4 * (Ln * 2 * Wd + ((Wd // 2 + Wd) if wide else 0) + n_skip * 64 + 32 + (32 if wide else 0))
+        # what is left to the fp32 kernel then: layer1's block, fc_rgb's, and -- 128-wide kernels -- layers_dir's two
+        thin_b = 4 * ((Wd + 64) + (32 + Wd // 2) + (0 if wide else (Wd // 2 + Wd) + (Wd // 2 + 32)))
+        big_launches = 1 + (1 if n_skip else 0) + 1 + (1 if wide else 0)   # (one launch per block shape: plain, + xyz guest, + fc_alpha guest, half-height)
         # which kernel each net's passes run on: (kind, family) -> [flops per step, bytes per step, launches per step]
         work = {}
 
@@ -597,8 +603,8 @@ def main():
                 continue
             add("dgrad", fmt if level >= 3 else "fp32", 2.0 * dgrad_macs * m, dgrad_b * m)
             if level == 4 and 64 < Wd <= 256:
-                add("wgrad_big", fmt, 2.0 * big_macs * m, big_b * m, 2 if wide else 1)   # (256: full- and half-height blocks are two launches)
-                add("wgrad_thin", "fp32", 2.0 * (fwd_macs - big_macs) * m, (wgrad_b - big_b) * m)
+                add("wgrad_big", fmt, 2.0 * big_macs * m, big_b * m, big_launches)
+                add("wgrad_thin", "fp32", 2.0 * (fwd_macs - big_macs) * m, thin_b * m)
             else:
                 add("wgrad", "fp32", 2.0 * fwd_macs * m, wgrad_b * m)
         # template instances of one kernel (k_wgrad_f16x3<full> / <half>) count as one

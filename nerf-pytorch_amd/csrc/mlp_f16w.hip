@@ -468,9 +468,9 @@ struct FwdWArgs {
 };
 
 // TRAIN: the launch also writes the activation stash -- encoding slots, every layer's fp32 output rows (plain values), ReLU masks -- in
-// the format k_mlp_dgrad16 / k_mlp_dgrad_f16w / k_wgrad / k_wgrad_f16x3 read
+// the format k_mlp_dgrad16 / k_mlp_dgrad_f16x3w / k_wgrad / k_wgrad_f16x3 read
 template <int W, bool VIEW, bool TRAIN>
-NH_KERNEL void NH_LB(512, 2) k_mlp_fwd_f16w(FwdWArgs a) {
+NH_KERNEL void NH_LB(512, 2) k_mlp_fwd_f16x3w(FwdWArgs a) {
     constexpr int TW = WShape<W>::TW, KB = WShape<W>::KB, BUF = WShape<W>::BUF, CB = WShape<W>::CB;
     NH_DYN_LDS(lds_raw);
     WCtx cx;
@@ -525,6 +525,8 @@ NH_KERNEL void NH_LB(512, 2) k_mlp_fwd_f16w(FwdWArgs a) {
             encode_w<XB>(xh, xl, px, py, pz, g, a.fx, a.Lx, TRAIN ? srow(a.sl.X, 32 * XB) : nullptr, nh_pow2i(ex));
         }
         s = ex;
+        // (the slot rows hold plain values, bounded by the sample's encoding exponent: the weight-gradient kernel's guest blocks)
+        if (TRAIN && cx.wrm) note_region(cx, nh_rmax_x(a.L), ex);
 
         f32x4 acc[TW + 1];
         nh_f16x8 hh[KB], hl[KB];  // the current activations as operand pieces (a layer's output replaces them in place)
@@ -567,6 +569,7 @@ NH_KERNEL void NH_LB(512, 2) k_mlp_fwd_f16w(FwdWArgs a) {
                 ed = enc_exponent(fmaxf(fmaxf(fabsf(rr[8]), fabsf(rr[9])), fmaxf(fabsf(rr[10]), 1.0f)));
                 encode_w<DB>(dh, dl, rr[8], rr[9], rr[10], g, a.fd, a.Ld, TRAIN ? srow(a.sl.D, 32 * DB) : nullptr, nh_pow2i(ed));
             }
+            if (TRAIN && cx.wrm) note_region(cx, nh_rmax_d(a.L), ed);
             // tiles 0..TW-1: feat = relu(fc_feat(h)); tile TW row 0: fc_alpha(h), raw (models.py:248-249)
             // (training: each gemm stores its own inputs -- H_{L-1} and mask L - 2, FEAT and mask L - 1, DIRH and mask L)
             const int s_head = s;  // (the head's inputs: fc_alpha's raw row comes out at WS * 2^s_head)
@@ -630,7 +633,7 @@ struct DgradWArgs {
 };
 
 template <int W, bool VIEW>
-NH_KERNEL void NH_LB(512, 2) k_mlp_dgrad_f16w(DgradWArgs a) {
+NH_KERNEL void NH_LB(512, 2) k_mlp_dgrad_f16x3w(DgradWArgs a) {
     constexpr int TW = WShape<W>::TW, KB = WShape<W>::KB, BUF = WShape<W>::BUF;
     NH_DYN_LDS(lds_raw);
     WCtx cx;
@@ -678,6 +681,12 @@ NH_KERNEL void NH_LB(512, 2) k_mlp_dgrad_f16w(DgradWArgs a) {
             const bool g0 = g == 0;
             nh_store4(pr, g0 ? go[0] : 0.0f, g0 ? go[1] : 0.0f, g0 ? go[2] : 0.0f, g0 ? go[3] : 0.0f);
             nh_store4(pr + 4, 0.0f, 0.0f, 0.0f, 0.0f);
+            if (cx.wrm) {  // (the region's bound: all four cotangents -- fc_alpha's row rides on a large weight-gradient block)
+                const float mp = fmaxf(fmaxf(fabsf(go[0]), fabsf(go[1])), fmaxf(fabsf(go[2]), fabsf(go[3])));
+                unsigned up;
+                memcpy(&up, &mp, 4);
+                note_region(cx, nh_rmax_pout(L), exp_for(up, 0));
+            }
         }
         f32x4 acc[TW];
         nh_f16x8 hh[KB], hl[KB];   // d(pre-activation) of the layer just finished, as operand pieces
@@ -828,9 +837,9 @@ int nh_mlp_forward_f16w(nerfhip_plan* p, const float* packed, const NhMlpInput& 
     int rc = NERFHIP_OK;
 #define NH_FWDW_T(WW, VV, TT)                                                                                     \
     {                                                                                                             \
-        rc = w_lds_limit(k_mlp_fwd_f16w<WW, VV, TT>, WShape<WW>::LDS_BYTES + RM_LDS);                             \
+        rc = w_lds_limit(k_mlp_fwd_f16x3w<WW, VV, TT>, WShape<WW>::LDS_BYTES + RM_LDS);                             \
         if (rc) return rc;                                                                                        \
-        NH_LAUNCH_NAMED("k_mlp_fwd_f16x3w<" #WW ", " #VV ", " #TT ">", (k_mlp_fwd_f16w<WW, VV, TT>), grid, 512,      \
+        NH_LAUNCH_NAMED("k_mlp_fwd_f16x3w<" #WW ", " #VV ", " #TT ">", (k_mlp_fwd_f16x3w<WW, VV, TT>), grid, 512,      \
                         WShape<WW>::LDS_BYTES + RM_LDS, stream, a);                                               \
     }
 #define NH_FWDW(WW, VV)              \
@@ -876,9 +885,9 @@ int nh_mlp_dgrad_f16w(nerfhip_plan* p, const float* packed, const float* g_out, 
     int rc = NERFHIP_OK;
 #define NH_BWDW(WW, VV)                                                                                           \
     {                                                                                                             \
-        rc = w_lds_limit(k_mlp_dgrad_f16w<WW, VV>, WShape<WW>::LDS_BYTES + RM_LDS);                               \
+        rc = w_lds_limit(k_mlp_dgrad_f16x3w<WW, VV>, WShape<WW>::LDS_BYTES + RM_LDS);                               \
         if (rc) return rc;                                                                                        \
-        NH_LAUNCH_NAMED("k_mlp_dgrad_f16x3w<" #WW ", " #VV ">", (k_mlp_dgrad_f16w<WW, VV>), grid, 512,               \
+        NH_LAUNCH_NAMED("k_mlp_dgrad_f16x3w<" #WW ", " #VV ">", (k_mlp_dgrad_f16x3w<WW, VV>), grid, 512,               \
                         WShape<WW>::LDS_BYTES + RM_LDS, stream, d);                                               \
     }
     if (p->W == 256 && p->view) NH_BWDW(256, true)

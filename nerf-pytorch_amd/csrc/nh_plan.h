@@ -104,6 +104,11 @@ struct NhPackedOffsets {
 // Words behind a training stash / a backward scratch in which the fp16 kernels record the largest magnitude stored per region
 // (mlp_bf16.hip `rmax`; indices: H[k] / P[k] -> k, FEAT / PFEAT -> L, DIRH / PDIR -> L + 1): zeroed before the producing launch
 constexpr int NH_RMAX_WORDS = 64;
+// ... and for the regions that ride as guests on the large weight-gradient blocks: the xyz / direction slot regions of the stash, the
+// d(raw output) region of the scratch
+constexpr int nh_rmax_x(int L) { return L + 2; }
+constexpr int nh_rmax_d(int L) { return L + 3; }
+constexpr int nh_rmax_pout(int L) { return L + 2; }
 
 // Activation stash regions: [tiles][32 samples][rows] each, `row_prefix` rows precede it inside a tile group.
 // 512-wide nets: a 512-row activation is stored as TWO consecutive 256-row regions (rows 0..255 at row_prefix, rows
@@ -160,6 +165,14 @@ struct NhJobB {
     int64_t a_row_prefix, b_row_prefix;  // region offsets = 32 * n_tiles * prefix floats
     int r_hi, col_count, w_ld;
     int64_t w_off, bias_off;
+    // A thin block riding on this one (wgrad_bf16.hip "SA / SB"), taken out of `jobs`: side_kind 1 = a 32-row region of the gradient
+    // scratch as ONE more A tile against this block's B region (side rows s_r_lo .. s_r_hi - 1 are the guest's parameter rows);
+    // 2 = a 32- / 64-row slot region of the stash as more B tiles against this block's A region (columns through the slot map
+    // s_col_kind: 1 xyz, 2 dir).  side_idx: the region's slot among the recorded maxima.
+    int side_kind, side_rows, side_idx;
+    int64_t side_row_prefix;
+    int s_r_lo, s_r_hi, s_w_ld, s_col_kind, s_col_base, s_col_count;
+    int64_t s_w_off, s_bias_off;
 };
 
 struct nerfhip_plan {

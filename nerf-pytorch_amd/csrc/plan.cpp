@@ -600,8 +600,18 @@ void build_layouts_and_jobs(nerfhip_plan* p) {
     // kernel lost on the 128 x 128 blocks (4x128 step 4.23 -> 5.04 ms); round 4's, which waits for HBM and nothing else, wins:
     // 4.35 -> 4.04 ms, profiles/r04_wgrad_128_ab.txt.  Other widths: _TRAIN is _FWD_DGRAD)
     const bool big_b = nh_prec_level(p->precision) == 4 && (W == 128 || W == 256);
+    // ... and a thin block whose operands such a block streams anyway rides on it as a guest (wgrad_bf16.hip SA / SB) instead of
+    // reading them a second time as an fp32 job of its own: a skip layer's xyz columns, fc_alpha's row, layers_dir's direction columns.
+    // (fp16 pieces: the guest regions need recorded maxima, which the kernels of mlp_f16w.hip write)
+#ifdef NHW_NO_GUESTS  // (A/B builds only)
+    const bool guests = false;
+#else
+    const bool guests = big_b && (!nh_prec_f16(p->precision) || p->w2);
+#endif
     auto add_big = [&](const NhRegion& A, int a_rows, const NhRegion& B, int r_hi, int w_tensor, int bias_tensor, int a_idx, int b_idx) {
         NhJobB j;
+        memset(&j, 0, sizeof(j));
+        j.s_bias_off = -1;
         j.a_idx = a_idx;
         j.b_idx = b_idx;
         j.a_rows = a_rows;
@@ -622,19 +632,43 @@ void build_layouts_and_jobs(nerfhip_plan* p) {
             add_big(G.P[i + 1], W, S.H[i], H, p->t_xyz_w[i], p->t_xyz_b[i], i + 1, i);
         else
             add_job(p, G.P[i + 1], TW, S.H[i], 0, TW, 0, H, p->t_xyz_w[i], 0, 0, H, p->t_xyz_b[i]);
-        if (p->is_skip(i)) add_job(p, G.P[i + 1], TW, S.X, 0, p->krx / 8, 0, H, p->t_xyz_w[i], 1, H, p->Dx, -1);
+        if (p->is_skip(i)) {
+            if (guests && S.X.rows == 64) {  // the xyz columns: P_{i+1} x X next to P_{i+1} x H_i
+                NhJobB& j = p->bjobs.back();
+                j.side_kind = 2, j.side_rows = S.X.rows, j.side_idx = nh_rmax_x(L), j.side_row_prefix = S.X.row_prefix;
+                j.s_w_off = p->tensors[p->t_xyz_w[i]].off, j.s_w_ld = p->tensors[p->t_xyz_w[i]].cols;
+                j.s_col_kind = 1, j.s_col_base = H, j.s_col_count = p->Dx;
+            } else {
+                add_job(p, G.P[i + 1], TW, S.X, 0, p->krx / 8, 0, H, p->t_xyz_w[i], 1, H, p->Dx, -1);
+            }
+        }
     }
     if (p->view) {
         if (big_b)
             add_big(G.PFEAT, W, S.H[L - 1], H, p->t_feat_w, p->t_feat_b, L, L - 1);
         else
             add_job(p, G.PFEAT, TW, S.H[L - 1], 0, TW, 0, H, p->t_feat_w, 0, 0, H, p->t_feat_b);
-        add_job(p, G.POUT, 1, S.H[L - 1], 0, TW, 3, 4, p->t_alpha_w, 0, 0, H, p->t_alpha_b);
+        if (guests) {  // fc_alpha: row 3 of POUT x H_{L-1} next to PFEAT x H_{L-1}
+            NhJobB& j = p->bjobs.back();
+            j.side_kind = 1, j.side_rows = 32, j.side_idx = nh_rmax_pout(L), j.side_row_prefix = G.POUT.row_prefix;
+            j.s_r_lo = 3, j.s_r_hi = 4;
+            j.s_w_off = p->tensors[p->t_alpha_w].off, j.s_w_ld = p->tensors[p->t_alpha_w].cols;
+            j.s_bias_off = p->tensors[p->t_alpha_b].off;
+        } else {
+            add_job(p, G.POUT, 1, S.H[L - 1], 0, TW, 3, 4, p->t_alpha_w, 0, 0, H, p->t_alpha_b);
+        }
         if (big_b && W >= 256)
             add_big(G.PDIR, W / 2, S.FEAT, H2, p->t_dir_w, p->t_dir_b, L + 1, L);
         else
             add_job(p, G.PDIR, TW / 2, S.FEAT, 0, TW, 0, H2, p->t_dir_w, 0, 0, H, p->t_dir_b);
-        add_job(p, G.PDIR, TW / 2, S.D, 0, p->krd / 8, 0, H2, p->t_dir_w, 2, H, p->Dd, -1);
+        if (guests && W >= 256 && S.D.rows == 32 && p->Dd > 0) {  // the direction columns: PDIR x D next to PDIR x FEAT
+            NhJobB& j = p->bjobs.back();
+            j.side_kind = 2, j.side_rows = S.D.rows, j.side_idx = nh_rmax_d(L), j.side_row_prefix = S.D.row_prefix;
+            j.s_w_off = p->tensors[p->t_dir_w].off, j.s_w_ld = p->tensors[p->t_dir_w].cols;
+            j.s_col_kind = 2, j.s_col_base = H, j.s_col_count = p->Dd;
+        } else {
+            add_job(p, G.PDIR, TW / 2, S.D, 0, p->krd / 8, 0, H2, p->t_dir_w, 2, H, p->Dd, -1);
+        }
         add_job(p, G.POUT, 1, S.DIRH, 0, TW / 2, 0, 3, p->t_rgb_w, 0, 0, H2, p->t_rgb_b);
     } else {
         add_job(p, G.POUT, 1, S.H[L - 1], 0, TW, 0, 4, p->t_out_w, 0, 0, H, p->t_out_b);

@@ -77,6 +77,8 @@ NH_DEVICE float nhb_raw(float acc, int s) { return NHB_IS_F16 ? acc * nh_pow2i(-
 
 namespace {
 
+#ifndef NHB_PACK_ONLY  // (mlp_f16.hip: the fp16-piece plans run on the kernels of mlp_f16w.hip; this file gives them the image packer)
+
 #ifndef NHB_DMA_EVERY  // (A/B builds only) a wave issues one 1-KiB piece of the next chunk every so many blocks; 0: all at once
 #define NHB_DMA_EVERY 1
 #endif
@@ -838,6 +840,8 @@ NH_KERNEL void NH_LB(256, 1) NHB_KERNEL(k_mlp_dgrad)(DgradBArgs a) {
     regions_end(cx, a.rmax);
 }
 
+#endif  // NHB_PACK_ONLY
+
 // ---- weight image --------------------------------------------------------------------------------------------------
 struct PackBArgs {
     int n_layers;
@@ -866,6 +870,7 @@ NH_KERNEL void NHB_KERNEL(k_pack)(const float* __restrict__ params, const int32_
     img[(2 * blk + 1) * 512 + q] = nh_to_pc(v - nh_from_pc(hi));
 }
 
+#ifndef NHB_PACK_ONLY
 // compute units of the current device (the emulator: 3, so that the CPU suite walks the persistent loop)
 int b_compute_units() {
 #ifndef NERFHIP_EMU
@@ -897,9 +902,20 @@ int b_lds_limit(K kern, int bytes) {
 #endif
     return NERFHIP_OK;
 }
+#endif  // NHB_PACK_ONLY
 
 }  // namespace
 
+#ifdef NHB_PACK_ONLY
+int NHB_FN(nh_mlp_forward)(nerfhip_plan*, const float*, const NhMlpInput&, int64_t, float*, float*, nerfhip_stream_t) {
+    nh_set_error("mlp_fwd: this build carries no one-wave-per-SIMD " NHB_FMT "x3 kernels (the plan's images must be in the geometry of mlp_f16w.hip)");
+    return NERFHIP_ERR_UNSUPPORTED;
+}
+int NHB_FN(nh_mlp_dgrad)(nerfhip_plan*, const float*, const float*, int64_t, const float*, float*, unsigned*, nerfhip_stream_t) {
+    nh_set_error("mlp_bwd: this build carries no one-wave-per-SIMD " NHB_FMT "x3 kernels (the plan's images must be in the geometry of mlp_f16w.hip)");
+    return NERFHIP_ERR_UNSUPPORTED;
+}
+#else
 int NHB_FN(nh_mlp_forward)(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
                         nerfhip_stream_t stream) {
     NH_REQUIRE(M < ((int64_t)1 << 31), "mlp_fwd: at most 2^31 - 1 sample points per call (got %lld)", (long long)M);
@@ -1011,6 +1027,8 @@ int NHB_FN(nh_mlp_dgrad)(nerfhip_plan* p, const float* packed, const float* g_ou
 #undef NH_BWDB
     return nh_launch_status("mlp_dgrad_" NHB_FMT "x3");
 }
+
+#endif  // NHB_PACK_ONLY
 
 // the split-precision layer images of a plan (behind its fp32 image, if it has one): gather, scale (fp16), split
 int NHB_FN(nh_pack_pieces)(nerfhip_plan* plan, const float* params, const int32_t* table, float* packed, nerfhip_stream_t stream) {

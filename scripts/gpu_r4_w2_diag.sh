@@ -13,6 +13,8 @@ for lib in $1; do
 import sys, json
 try:
     d = json.loads(sys.stdin.read()); print('$lib', d['value'], d['ms_per_step'], {k: v['ms_per_step'] for k, v in ((d.get('roofline') or {}).get('mlp_kernels') or {}).items()})
+    km = (d.get('roofline') or {}).get('kernel_ms_per_step') or d.get('kernel_ms_per_step') or {}
+    print('   ', {k: v for k, v in km.items() if 'wgrad' in k})
 except Exception as e:
     print('$lib', 'unparsed', repr(e)[:120])" >> $out
 done

@@ -104,6 +104,29 @@ def test_thin_weight_blocks_ride_as_side_tiles(lib):
         assert all(j["side"] == "0" for j in describe(*geo)[1])
 
 
+def test_split_precision_plans_guests_and_image_geometry(lib):
+    """Level-4 plans: the large weight-gradient blocks leave the fp32 job list and take the thin blocks that share a region with
+    them along as guests (wgrad_bf16.hip SA / SB) -- what stays are layer1's block and fc_rgb's; fp16-piece plans carry their images
+    in the geometry of the two-waves-per-SIMD kernels (mlp_f16w.hip), bf16-piece plans in that of mlp_bf16.hip."""
+    def describe(prec, *geo):
+        plan = lib.plan_create_ex(C.byref(L.ModelCfg(*geo, 1, 1, 1, 1, 1)), prec)
+        assert plan
+        buf = C.create_string_buffer(1 << 14)
+        lib.plan_describe(plan, buf, len(buf))
+        lib.plan_destroy(plan)
+        lines = buf.value.decode().splitlines()
+        return lines[0], lines[1:]
+    for prec, w2 in ((4, "0"), (8, "1")):                       # NERFHIP_PRECISION_BF16X3_TRAIN, _F16X3_TRAIN
+        head, jobs = describe(prec, 8, 256, 4, 10, 4)
+        assert head.split()[-2:] == ["two_wave_images", w2] and len(jobs) == 2, (head, jobs)
+        head, jobs = describe(prec, 4, 128, 4, 10, 4)          # 128-wide: layers_dir's two blocks stay fp32 jobs (one a side tile)
+        assert len(jobs) == 3, (head, jobs)
+    head, jobs = describe(7, 8, 256, 4, 10, 4)                  # _F16X3_FWD_DGRAD: every weight-gradient block on the fp32 kernel
+    assert head.split()[-1] == "1" and len(jobs) == 12
+    head, jobs = describe(5, 8, 256, 4, 10, 4)                  # _F16X3: inference-only
+    assert head.split()[-1] == "1"
+
+
 def test_model_state_dict_is_reference_compatible(lib):
     w = gold("lego_lowres_weights.npz")
     m = N.FlexibleNeRFModel(num_layers=4, hidden_size=128, skip_connect_every=4, num_encoding_fn_xyz=10,

@@ -8,7 +8,8 @@
 // that loop -- 8-wave workgroups, two waves per SIMD, one workgroup per CU, weights resident in LDS (no stream, no stash, no
 // conversions: the diagnostic build `noall` of profiles/r04_f16w_ab.txt is the product's counterpart, 0.54 of the MFMA peak) -- with
 // groups of G = 1, 2, 4, 8 blocks: the group's 3 G MFMAs go product by product over its G tiles (dependency distance G), the 2 G reads
-// of the NEXT group in front of them.  Also: without the LDS reads (what the dependency pattern alone costs) and with a barrier
+// of the NEXT group in front of them.  Also: without the LDS reads (2 G blocks of random pieces held in registers: what the matrix pipe
+// sustains on such operands, and what the dependency pattern alone costs) and with a barrier
 // every 32 blocks (the product's chunk barrier).  Output: fraction of the 2.5 PF dense fp16 peak.
 // Build: hipcc --offload-arch=gfx950 -O3 scripts/f16w_loop_mock.hip -o scripts/f16w_loop_mock
 #include <hip/hip_runtime.h>
@@ -38,6 +39,13 @@ __global__ __launch_bounds__(512, 2) void k_loop(const char* __restrict__ wimg, 
     for (int t = 0; t < TW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const char* const wb = lds + lane * 16;
     f16x8 wh[2 * G], wl[2 * G];
+    if (!READS) {  // (random weight pieces held in registers: what the matrix pipe sustains on such operands without the LDS stream)
+#pragma unroll
+        for (int q = 0; q < 2 * G; ++q) {
+            wh[q] = *(const f16x8*)(wb + (2 * q) * 1024);
+            wl[q] = *(const f16x8*)(wb + (2 * q + 1) * 1024);
+        }
+    }
     for (int L = 0; L < layers; ++L) {
 #pragma unroll
         for (int c = 0; c < NBLK / CB; ++c) {

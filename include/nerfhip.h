@@ -184,21 +184,24 @@ nerfhip_plan_t nerfhip_plan_create(const nerfhip_model_cfg* cfg);
  * gradient GEMMs stay fp32.  Same status: opt-in experiment, accepted by PSNR@iters. */
 #define NERFHIP_PRECISION_BF16X3_FWD_DGRAD 3
 /* BF16X3_TRAIN: as BF16X3_FWD_DGRAD, and the large weight-gradient GEMMs (hidden x hidden blocks: ~94 % of the weight-gradient
- * FLOPs) run on the bf16 MFMAs too (operands split on the fly from the fp32 stash / d(pre-activation) images); the thin blocks
- * (encoding columns, fc_alpha, fc_rgb | fc_out) stay on the fp32 kernel.  Same status: opt-in experiment. */
+ * FLOPs) run on the bf16 MFMAs too (operands split on the fly from the fp32 stash / d(pre-activation) images), with the thin blocks
+ * that share a region with one of them -- a skip layer's xyz columns, fc_alpha, the direction columns -- riding along in the same
+ * launch; layer1's block and fc_rgb | fc_out stay on the fp32 kernel.  Same status: opt-in experiment. */
 #define NERFHIP_PRECISION_BF16X3_TRAIN 4
-/* F16X3 family (round 4): the SAME kernels and the same three-MFMA product structure on v_mfma_f32_32x32x16_f16, every operand
- * split into two IEEE fp16 pieces: hi = f16(v), lo = f16(v - hi), both round-to-nearest.  A piece carries 11 significant bits and
- * the rounding error of hi is at most half an ulp, so hi + lo reproduces v to 2^-24 relative -- fp32's own rounding -- wherever
- * the low piece is a normal or subnormal fp16 number (the gfx950 matrix pipe multiplies fp16 subnormals exactly; measured:
- * scripts/probe/f16_mfma_probe.hip); the dropped xl.wl term is 2^-24 relative as well.  So a product block carries ~3 x 2^-24
- * instead of bf16x3's ~2^-16: fp32-grade arithmetic at the bf16x3 kernels' speed.  What fp16's 5-bit exponent costs is handled
- * inside the library: the packed weight pieces (and biases) are pre-scaled by 2^8 (exact; the kernels multiply every layer's
- * accumulators by 2^-8 on the way out) so that a weight's low piece is a normal fp16 number down to |w| = 2^-10, and the
- * data-gradient chain runs on d(raw output) scaled by a power of two chosen per launch from max|d(raw output)| (a one-word
- * device reduction, no host synchronisation), undone exactly in the weight-gradient reduction.  Same plan kinds as the bf16x3
- * family: F16X3 inference-only; F16X3_FWD / _FWD_DGRAD / _TRAIN training-capable.  Activations beyond 65504 overflow an fp16
- * piece (no NeRF layer gets near that); opt-in, labelled, never selected implicitly. */
+/* F16X3 family (round 4): the same three-MFMA product structure on the fp16 MFMAs, every operand split into two IEEE fp16 pieces:
+ * hi = f16(v), lo = f16(v - hi), both round-to-nearest.  A piece carries 11 significant bits and the rounding error of hi is at
+ * most half an ulp, so hi + lo reproduces v to 2^-24 relative -- fp32's own rounding -- wherever the low piece is a normal or
+ * subnormal fp16 number (the gfx950 matrix pipe multiplies fp16 subnormals exactly; measured: scripts/probe/f16_mfma_probe.hip);
+ * the dropped xl.wl term is 2^-24 relative as well.  So a product block carries ~3 x 2^-24 instead of bf16x3's ~2^-16: fp32-grade
+ * arithmetic, and the GPU parity suite runs on these plans under the fp32 kernels' assertions.  What fp16's 5-bit exponent costs
+ * is handled inside the library, all in exact powers of two: the packed weight pieces (and biases) carry 2^8; every
+ * SAMPLE carries the exponent of its current activations / d(pre-activation), chosen by the epilogue that produced them so that its
+ * largest value lands in [2^13, 2^14) -- no activation range is out of reach, no cotangent too small --; the stash and every output
+ * are plain fp32 values; the weight-gradient kernel splits a region at the power of two its producers recorded for it (one word
+ * per region behind the stash / scratch, no host synchronisation) and divides it out exactly in its reduction.  Forward and data
+ * gradient run with two waves per SIMD on v_mfma_f32_16x16x32_f16 (csrc/mlp_f16w.hip), the weight gradient on
+ * v_mfma_f32_32x32x16_f16.  Same plan kinds as the bf16x3 family: F16X3 inference-only; F16X3_FWD / _FWD_DGRAD / _TRAIN
+ * training-capable.  Opt-in, labelled, never selected implicitly. */
 #define NERFHIP_PRECISION_F16X3 5
 #define NERFHIP_PRECISION_F16X3_FWD 6
 #define NERFHIP_PRECISION_F16X3_FWD_DGRAD 7

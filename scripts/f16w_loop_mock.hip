@@ -22,7 +22,9 @@ constexpr int KB = 8, TW = 16, NBLK = KB * TW, CB = 32;  // a 256 x 256 layer: 8
 
 // EPI: after every layer the 16 accumulator tiles become the next layer's operand pieces as in the product (per-sample maximum over
 // the four lane groups, one multiply, ReLU, hi = f16(v), lo = f16(v - hi)); the accumulators restart at zero
-template <int G, bool READS, bool BARRIER, bool EPI = false>
+// SHARE: every block read from LDS feeds SHARE accumulator tiles (with different register operands): 1 / SHARE of the operand reads per
+// MFMA -- the inner loop a weight-stationary kernel would have (weight slices in registers, the activations as the LDS operand)
+template <int G, bool READS, bool BARRIER, bool EPI = false, int SHARE = 1>
 __global__ __launch_bounds__(512, 2) void k_loop(const char* __restrict__ wimg, float* __restrict__ out, int layers) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
@@ -59,20 +61,22 @@ __global__ __launch_bounds__(512, 2) void k_loop(const char* __restrict__ wimg, 
 #pragma unroll
             for (int j = 0; j < G; ++j) load(j);
 #pragma unroll
-            for (int i0 = 0; i0 < CB; i0 += G) {
+            for (int i0 = 0; i0 < CB / SHARE; i0 += G) {
 #pragma unroll
                 for (int j = 0; j < G; ++j)
-                    if (i0 + G + j < CB) load(i0 + G + j);
+                    if (i0 + G + j < CB / SHARE) load(i0 + G + j);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
-                    for (int j = 0; j < G; ++j) {
-                        const int gi = c * CB + i0 + j, kb = gi / TW, t = gi % TW;
-                        const f16x8 a = pr == 0 ? wl[(i0 + j) % (2 * G)] : wh[(i0 + j) % (2 * G)];
-                        const f16x8 b = pr == 1 ? bl[kb] : bh[kb];
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[t], 0, 0, 0);
-                    }
+                    for (int j = 0; j < G; ++j)
+#pragma unroll
+                        for (int sh = 0; sh < SHARE; ++sh) {
+                            const int gi = c * CB + (i0 + j) * SHARE + sh, kb = (gi / TW + sh) % KB, t = gi % TW;
+                            const f16x8 a = pr == 0 ? wl[(i0 + j) % (2 * G)] : wh[(i0 + j) % (2 * G)];
+                            const f16x8 b = pr == 1 ? bl[kb] : bh[kb];
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[t], 0, 0, 0);
+                        }
             }
         }
         if (EPI) {
@@ -114,15 +118,15 @@ __global__ __launch_bounds__(512, 2) void k_loop(const char* __restrict__ wimg, 
     out[(size_t)blockIdx.x * 512 + threadIdx.x] = s;
 }
 
-template <int G, bool READS, bool BARRIER, bool EPI = false>
+template <int G, bool READS, bool BARRIER, bool EPI = false, int SHARE = 1>
 void run(const char* what, const char* wimg, float* out, int grid, int layers) {
-    hipFuncSetAttribute((const void*)k_loop<G, READS, BARRIER, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, CB * 2048);
+    hipFuncSetAttribute((const void*)k_loop<G, READS, BARRIER, EPI, SHARE>, hipFuncAttributeMaxDynamicSharedMemorySize, CB * 2048);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL((k_loop<G, READS, BARRIER, EPI>), dim3(grid), dim3(512), CB * 2048, 0, wimg, out, layers);
+        hipLaunchKernelGGL((k_loop<G, READS, BARRIER, EPI, SHARE>), dim3(grid), dim3(512), CB * 2048, 0, wimg, out, layers);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
     }
@@ -159,6 +163,9 @@ int main() {
     run<4, true, true>("G = 4, LDS reads, barrier per 32 blocks", wimg, out, grid, layers);
     run<2, true, true, true>("G = 2, LDS reads, barrier, per-layer conversion (maximum, ReLU, hi / lo)", wimg, out, grid, layers);
     run<4, true, true, true>("G = 4, LDS reads, barrier, per-layer conversion", wimg, out, grid, layers);
+    run<2, true, true, false, 2>("G = 2, every LDS block feeds 2 tiles (half the reads per MFMA), barrier", wimg, out, grid, layers);
+    run<4, true, true, false, 2>("G = 4, every LDS block feeds 2 tiles, barrier", wimg, out, grid, layers);
+    run<2, true, true, false, 4>("G = 2, every LDS block feeds 4 tiles (a quarter of the reads), barrier", wimg, out, grid, layers);
     run<1, false, false>("G = 1, no LDS reads", wimg, out, grid, layers);
     run<2, false, false>("G = 2, no LDS reads", wimg, out, grid, layers);
     run<4, false, false>("G = 4, no LDS reads", wimg, out, grid, layers);

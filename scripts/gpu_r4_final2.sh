@@ -26,8 +26,7 @@ if [ "$1" = "1" ]; then
   timeout 100 python bench.py --no-cpu-baseline --hidden 128 --layers 4 --precision f16x3_train > $R/bench_f16x3_train_4x128.log 2>&1
   timeout 100 python bench.py --mode eval --no-cpu-baseline --precision f16x3 > $R/bench_eval_f16x3.log 2>&1
   timeout 100 python bench.py --no-cpu-baseline --precision bf16x3_train > $R/bench_bf16x3_train.log 2>&1
-  timeout 100 python bench.py --no-cpu-baseline --workload fern --precision f16x3_train > $R/bench_fern_f16x3_train.log 2>&1
-  show bench bench_f16x3_train bench_f16x3_train_4x128 bench_eval_f16x3 bench_bf16x3_train bench_fern_f16x3_train
+  show bench bench_f16x3_train bench_f16x3_train_4x128 bench_eval_f16x3 bench_bf16x3_train
 else
   cd /tmp
   timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/prof_f16 -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --precision f16x3_train > $R/bench_prof_f16.log 2>&1

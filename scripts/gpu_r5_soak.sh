@@ -21,6 +21,6 @@ timeout 300 python scripts/psnr_soak.py 9 40 $R/soak/preflight.json --arms engin
 rc=$?; echo "preflight rc=$rc"; tail -4 $R/soak/preflight.log
 if [ $rc -ne 0 ]; then tail -30 $R/soak/preflight.log; exit 1; fi
 for seed in 1 2; do
-  timeout 1000 python scripts/psnr_soak.py $seed $ITERS $R/soak/soak_seed$seed.json --arms engine_f16tr,engine > $R/soak/soak_seed$seed.log 2>&1
+  timeout 1150 python scripts/psnr_soak.py $seed $ITERS $R/soak/soak_seed$seed.json --arms engine_f16tr,engine > $R/soak/soak_seed$seed.log 2>&1
   echo "soak seed $seed rc=$?"; grep -c diag $R/soak/soak_seed$seed.log; grep "val_psnr" $R/soak/soak_seed$seed.log | tail -4
 done

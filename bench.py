@@ -44,7 +44,7 @@ RAYS_PER_GPU = 4096
 NC, NF = 64, 128
 MODEL = dict(num_layers=8, hidden_size=256, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md chip table (256 CUs x 256 FLOP/clk at 2.4 GHz)
-BF16X3_PEAK_TFLOPS = 2500.0 / 3.0  # dense bf16 / fp16 MFMA peak (same table) / three MFMAs per fp32-equivalent product block
+F16X3_PEAK_TFLOPS = 2500.0 / 3.0   # dense fp16 MFMA peak (same table) / three MFMAs per fp32-equivalent product block
 HBM_PEAK_TBS = 8.0             # same guide: HBM3E ~8 TB/s
 PEAK_CLOCK_GHZ = 2.4
 
@@ -274,8 +274,8 @@ def kernel_kind(name):
         return "fwd"
     if "k_mlp_dgrad" in name:
         return "dgrad"
-    if "k_wgrad_bf16x3" in name or "k_wgrad_f16x3" in name:
-        return "wgrad_big"    # (--precision *_train: the hidden x hidden blocks on the 16-bit MFMAs)
+    if "k_wgrad_f16x3" in name:
+        return "wgrad_big"    # (--precision f16x3_train: the hidden x hidden blocks on the fp16 MFMAs)
     if "k_wgrad<MD>[thin" in name:
         return "wgrad_thin"   # (... and what is left to the fp32 kernel then)
     if "k_wgrad<" in name:
@@ -284,9 +284,7 @@ def kernel_kind(name):
 
 
 def kernel_family(name):
-    """The matrix pipe a kernel multiplies on: "fp32" (v_mfma_f32_16x16x4 / 32x32x2) or the 16-bit MFMAs on split operands."""
-    if "bf16x3" in name:
-        return "bf16x3"
+    """The matrix pipe a kernel multiplies on: "fp32" (v_mfma_f32_16x16x4 / 32x32x2) or the fp16 MFMAs on split operands."""
     if "f16x3" in name:
         return "f16x3"
     return "fp32"
@@ -324,7 +322,7 @@ def pmc_traffic(cfg, n, kind):
     kname = "k_wgrad" if kind == "wgrad" else "k_mlp_%s16" % kind
     mine = lib_sources_sha16()
     stale = None
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         for fn in ("%s_pmc_summary_%s.json" % (rnd, tag), "%s_pmc_summary.json" % rnd):
             path = os.path.join(ROOT, "profiles", fn)
             if not os.path.exists(path) or (fn.endswith("summary.json") and (cfg != MODEL or n != RAYS_PER_GPU)):
@@ -388,14 +386,13 @@ def main():
     ap.add_argument("--layers", type=int, default=0, help="num_layers (default: the workload's)")
     ap.add_argument("--overlap", type=int, default=-1, help="1: two-stream step (coarse backward next to the fine pass); "
                     "0: single-stream order; -1: the engine's default for the net width")
-    ap.add_argument("--precision", choices=("fp32", "bf16x3", "bf16x3_fwd", "bf16x3_fwd_dgrad", "bf16x3_train", "f16x3", "f16x3_fwd",
-                                            "f16x3_fwd_dgrad", "f16x3_train", "fp32+bf16x3_fwd_dgrad", "fp32+bf16x3_train", "fp32+f16x3_train"),
+    ap.add_argument("--precision", choices=("fp32", "f16x3", "f16x3_fwd", "f16x3_fwd_dgrad", "f16x3_train", "fp32+f16x3_train"),
                     default="fp32",
-                    help="fp32 (default: the reference's arithmetic, the headline).  f16x3* / bf16x3*: the GEMMs on the 16-bit MFMAs "
-                         "with every operand split into two fp16 (fp32-grade products) / bf16 (~2^-16) pieces: --mode eval "
-                         "--precision f16x3 | bf16x3 the inference forward; --mode train --precision *_fwd the training forward, "
-                         "*_fwd_dgrad + the data-gradient chain, *_train + the large weight-gradient blocks.  A+B: coarse net A, fine "
-                         "net B.  Separate, labelled lines: the driver's default stays fp32")
+                    help="fp32 (default: the reference's arithmetic, the headline).  f16x3*: the GEMMs on the fp16 MFMAs with every "
+                         "operand split into two IEEE fp16 pieces (fp32-grade products): --mode eval --precision f16x3 the inference "
+                         "forward; --mode train --precision f16x3_fwd the training forward, f16x3_fwd_dgrad + the data-gradient chain, "
+                         "f16x3_train + the large weight-gradient blocks.  A+B: coarse net A, fine net B.  Separate, labelled lines: "
+                         "the driver's default stays fp32")
     ap.add_argument("--gather", action="store_true", help="eval: rank 0 also receives every pose's rows (output plumbing)")
     ap.add_argument("--no-kernel-profile", action="store_true", help="do not bracket the launches of the timed region with HIP events (no "
                     "per-kernel times, no roofline object): what the events cost a short step")
@@ -469,9 +466,9 @@ def main():
         torch.cuda.synchronize()
 
     prec_c, prec_f = args.precision.split("+") if "+" in args.precision else (args.precision, args.precision)
-    infer_only = prec_f in ("bf16x3", "f16x3")
+    infer_only = prec_f == "f16x3"
     if (args.mode == "train" and infer_only) or (args.mode == "eval" and not infer_only and prec_f != "fp32"):
-        raise SystemExit("--precision bf16x3 / f16x3 go with --mode eval, the *_fwd / *_fwd_dgrad / *_train ones with --mode train")
+        raise SystemExit("--precision f16x3 goes with --mode eval, f16x3_fwd / _fwd_dgrad / _train with --mode train")
     if (prec_c != "fp32" or prec_f != "fp32") and not 64 < cfg["hidden_size"] <= 256:
         # (nerfhip_plan_create_ex refuses such plans: the split-precision kernels exist for the 128- and 256-wide kernel widths)
         raise SystemExit("--precision %s needs hidden_size in (64, 256] (this workload: %d); the 64- and 512-wide nets run fp32"
@@ -583,7 +580,7 @@ def main():
         dgrad_b = 4 * (Ln * Wd + Wd + Wd // 2 + 32) + 8 * (Ln + 1) + 16
         wgrad_b = wgrad_bytes_per_sample(cfg)
         # the hidden x hidden blocks of the level-4 plans: layers_xyz, fc_feat and -- 256-wide kernels only -- the hidden columns of layers_dir
-        # ... and the thin blocks that ride on them as guests (wgrad_bf16.hip SA / SB): a skip layer's xyz columns, fc_alpha's row,
+        # ... and the thin blocks that ride on them as guests (wgrad_f16.hip SA / SB): a skip layer's xyz columns, fc_alpha's row,
         # the direction columns -- their own regions are the only bytes they add
         wide = Wd > 128
         n_skip = sum(1 for i in range(1, Ln - 1) if i % cfg["skip_connect_every"] == 0)
@@ -637,7 +634,7 @@ def main():
             counter_gb, source = (pmc_traffic(cfg, n, kind) if (args.mode == "train" and args.precision == "fp32" and args.workload == "lego"
                                                                and kind in ("fwd", "dgrad", "wgrad")) else (None, None))
             # a kernel is priced against ITS OWN matrix pipe: fp32 MFMA, or the 16-bit MFMA at three instructions per product block
-            peak = FP32_MFMA_PEAK_TFLOPS if fam == "fp32" else BF16X3_PEAK_TFLOPS
+            peak = FP32_MFMA_PEAK_TFLOPS if fam == "fp32" else F16X3_PEAK_TFLOPS
             key = kind if kinds_seen.count(kind) == 1 else "%s[%s]" % (kind, fam)
             kernels[key] = dict(kernel=label, family=fam, ms_per_step=round(ms_step, 4), avg_launch_ms=round(ms / cnt, 4), launches=cnt,
                                 launches_per_step=launches, algorithmic_gflop_per_step=round(fl / 1e9, 2),
@@ -692,8 +689,7 @@ def main():
             if level == 0:
                 return "f32"
             pieces = ("two IEEE fp16 pieces per operand (hi + lo reproduces the fp32 value to 2^-24; per-sample block floating point against "
-                      "fp16's range), three fp16 MFMAs per product block, f32 accumulate: ~3 x 2^-24 per product" if fmt == "f16x3" else
-                      "two bf16 pieces per operand, three bf16 MFMAs per product block, f32 accumulate: ~2^-16 per product")
+                      "fp16's range), three fp16 MFMAs per product block, f32 accumulate: ~3 x 2^-24 per product")
             what = {1: "forward", 2: "forward (backward + optimizer f32)", 3: "forward + data gradient (weight gradient + optimizer f32)",
                     4: "forward, data gradient and the hidden x hidden weight-gradient blocks (thin weight-gradient blocks + optimizer f32)"}[level]
             return "%s: %s on %s; fp32-equivalent FLOPs" % (fmt, what, pieces)

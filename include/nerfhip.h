@@ -163,45 +163,36 @@ typedef struct nerfhip_plan* nerfhip_plan_t;
 
 /* Host-only.  Returns NULL (and sets the error string) for an unsupported geometry. */
 nerfhip_plan_t nerfhip_plan_create(const nerfhip_model_cfg* cfg);
-/* Arithmetic of the plan's FORWARD (inference) GEMMs.  FP32 (= nerfhip_plan_create): exact fp32 products on
- * v_mfma_f32_16x16x4_f32 -- the path every parity claim and the headline benchmark refer to.  BF16X3: an INFERENCE-ONLY
- * plan whose forward kernel multiplies on v_mfma_f32_32x32x16_bf16 with every operand split into two bf16 pieces,
- * x.w ~ xh.wh + xh.wl + xl.wh with fp32 accumulation (the xl.wl term, ~2^-16 relative, is dropped): ~2^-16 relative error
- * per product instead of fp32's 2^-24 -- NOT the reference's arithmetic, never selected implicitly.  Such a plan has its own
- * packed image (nerfhip_plan_packed_floats / nerfhip_plan_pack_index / nerfhip_pack_weights_plan), serves
- * nerfhip_mlp_fwd without a stash and the render entry points with training = 0, and every training / backward entry
- * point refuses it.  Supported for kernel widths 128 and 256, num_encoding_fn_xyz <= 10, num_encoding_fn_dir <= 4. */
+/* Arithmetic of the plan's GEMMs.  FP32 (= nerfhip_plan_create): exact fp32 products on v_mfma_f32_16x16x4_f32 / 32x32x2 -- the
+ * reference's own arithmetic, the path the headline benchmark runs; never replaced implicitly.
+ *
+ * F16X3 family (round 4): every GEMM as THREE fp16 MFMAs on operands split into two IEEE fp16 pieces, hi = f16(v), lo = f16(v - hi),
+ * both round-to-nearest: x.w ~ xh.wh + xh.wl + xl.wh with fp32 accumulation.  A piece carries 11 significant bits and the rounding
+ * error of hi is at most half an ulp, so hi + lo reproduces v to 2^-24 relative -- fp32's own rounding -- wherever the low piece is
+ * a normal or subnormal fp16 number (the gfx950 matrix pipe multiplies fp16 subnormals exactly; measured: scripts/probe/
+ * f16_mfma_probe.hip); the dropped xl.wl term is 2^-24 relative as well.  So a product block carries ~3 x 2^-24: fp32-grade
+ * arithmetic, and the GPU parity suite holds these plans to the SAME bounds as the fp32 kernels (tests/tolerances.py).  What fp16's
+ * 5-bit exponent costs is handled inside the library, all in exact powers of two: the packed weight pieces (and
+ * biases) carry 2^8 -- so |w| must stay below 255.9; larger weights are saturated by nerfhip_pack_weights_plan, not turned into Inf --;
+ * every SAMPLE carries the exponent of its current activations / d(pre-activation), chosen by the epilogue that produced them so that
+ * its largest value lands in [2^13, 2^14) -- no activation range is out of reach, no cotangent too small --; the stash and every
+ * output are plain fp32 values; the weight-gradient kernel splits a region at the power of two its producers recorded for it (one
+ * word per region behind the stash / scratch, no host synchronisation) and divides it out exactly in its reduction.  Forward and
+ * data gradient run with two waves per SIMD on v_mfma_f32_16x16x32_f16 (csrc/mlp_f16w.hip), the weight gradient on
+ * v_mfma_f32_32x32x16_f16 (csrc/wgrad_f16.hip).
+ *   F16X3            INFERENCE-ONLY plan: its own packed image (nerfhip_plan_packed_floats / nerfhip_plan_pack_index /
+ *                    nerfhip_pack_weights_plan), serves nerfhip_mlp_fwd without a stash and the render entry points with
+ *                    training = 0; every training / backward entry point refuses it.
+ *   F16X3_FWD        training-capable: the forward passes on fp16 pieces (writes the same fp32 stash and ReLU masks), the backward
+ *                    kernels the exact fp32 ones; the packed image holds the fp32 image and the fp16-piece image.
+ *   F16X3_FWD_DGRAD  ... and the data-gradient chain on fp16 pieces; the weight-gradient GEMMs stay fp32.
+ *   F16X3_TRAIN      ... and the large weight-gradient GEMMs (hidden x hidden blocks: ~94 % of those FLOPs) on the fp16 MFMAs, with
+ *                    the thin blocks that share a region with one of them -- a skip layer's xyz columns, fc_alpha, the direction
+ *                    columns -- riding along in the same launch; layer1's block and fc_rgb | fc_out stay on the fp32 kernel.
+ * Supported for kernel widths 128 and 256, num_encoding_fn_xyz <= 10, num_encoding_fn_dir <= 4.  Opt-in, labelled.
+ * Values 1 .. 4 named round 3's bf16-piece plans (~2^-16 per product: they did not hold the parity bounds); removed in round 5,
+ * nerfhip_plan_create_ex refuses them with a message, the numbers stay reserved. */
 #define NERFHIP_PRECISION_FP32 0
-#define NERFHIP_PRECISION_BF16X3 1
-/* BF16X3_FWD: a TRAINING-capable plan whose forward passes (training and inference alike) run on the split-bf16 kernel while
- * the backward kernels stay the exact fp32 ones: the training forward writes the same fp32 activation stash (the values it
- * actually computed) and ReLU masks, so nerfhip_mlp_bwd / nerfhip_render_bwd* are unchanged -- they differentiate the fp32
- * function at activations that carry the forward's ~1e-5 relative error.  The packed image holds both the fp32 image (its
- * transposed layers feed the data-gradient kernel) and the bf16 image; build it with nerfhip_pack_weights_plan.  An
- * experiment toward the north star's speed-up, accepted by PSNR@iters, not by the 1e-4 bar; opt-in. */
-#define NERFHIP_PRECISION_BF16X3_FWD 2
-/* BF16X3_FWD_DGRAD: as BF16X3_FWD, and the data-gradient chain (k_mlp_dgrad) runs on the split-bf16 kernel too; the weight-
- * gradient GEMMs stay fp32.  Same status: opt-in experiment, accepted by PSNR@iters. */
-#define NERFHIP_PRECISION_BF16X3_FWD_DGRAD 3
-/* BF16X3_TRAIN: as BF16X3_FWD_DGRAD, and the large weight-gradient GEMMs (hidden x hidden blocks: ~94 % of the weight-gradient
- * FLOPs) run on the bf16 MFMAs too (operands split on the fly from the fp32 stash / d(pre-activation) images), with the thin blocks
- * that share a region with one of them -- a skip layer's xyz columns, fc_alpha, the direction columns -- riding along in the same
- * launch; layer1's block and fc_rgb | fc_out stay on the fp32 kernel.  Same status: opt-in experiment. */
-#define NERFHIP_PRECISION_BF16X3_TRAIN 4
-/* F16X3 family (round 4): the same three-MFMA product structure on the fp16 MFMAs, every operand split into two IEEE fp16 pieces:
- * hi = f16(v), lo = f16(v - hi), both round-to-nearest.  A piece carries 11 significant bits and the rounding error of hi is at
- * most half an ulp, so hi + lo reproduces v to 2^-24 relative -- fp32's own rounding -- wherever the low piece is a normal or
- * subnormal fp16 number (the gfx950 matrix pipe multiplies fp16 subnormals exactly; measured: scripts/probe/f16_mfma_probe.hip);
- * the dropped xl.wl term is 2^-24 relative as well.  So a product block carries ~3 x 2^-24 instead of bf16x3's ~2^-16: fp32-grade
- * arithmetic, and the GPU parity suite runs on these plans under the fp32 kernels' assertions.  What fp16's 5-bit exponent costs
- * is handled inside the library, all in exact powers of two: the packed weight pieces (and biases) carry 2^8; every
- * SAMPLE carries the exponent of its current activations / d(pre-activation), chosen by the epilogue that produced them so that its
- * largest value lands in [2^13, 2^14) -- no activation range is out of reach, no cotangent too small --; the stash and every output
- * are plain fp32 values; the weight-gradient kernel splits a region at the power of two its producers recorded for it (one word
- * per region behind the stash / scratch, no host synchronisation) and divides it out exactly in its reduction.  Forward and data
- * gradient run with two waves per SIMD on v_mfma_f32_16x16x32_f16 (csrc/mlp_f16w.hip), the weight gradient on
- * v_mfma_f32_32x32x16_f16.  Same plan kinds as the bf16x3 family: F16X3 inference-only; F16X3_FWD / _FWD_DGRAD / _TRAIN
- * training-capable.  Opt-in, labelled, never selected implicitly. */
 #define NERFHIP_PRECISION_F16X3 5
 #define NERFHIP_PRECISION_F16X3_FWD 6
 #define NERFHIP_PRECISION_F16X3_FWD_DGRAD 7
@@ -227,8 +218,8 @@ int64_t nerfhip_plan_packed_floats(nerfhip_plan_t plan);
 int nerfhip_plan_pack_index(nerfhip_plan_t plan, int32_t* host_table);
 /* packed[i] = table[i] >= 0 ? params[table[i]] : 0   (run once per optimiser step). */
 int nerfhip_pack_weights(const float* params, const int32_t* table, int64_t n, float* packed, nerfhip_stream_t stream);
-/* The same for any plan: fp32 plans gather as above; BF16X3 plans write, per table entry, the bias word or the two bf16
- * pieces hi = bf16(w), lo = bf16(w - hi) of the weight into the high / low blocks of the image.  table: dev
+/* The same for any plan: fp32 plans gather as above; F16X3* plans write, per table entry, the bias word (times 2^8) or the two fp16
+ * pieces hi = f16(2^8 w), lo = f16(2^8 w - hi) of the weight into the high / low blocks of the image.  table: dev
  * int32[packed_floats] (nerfhip_plan_pack_index), packed: dev, packed_floats 32-bit words. */
 int nerfhip_pack_weights_plan(nerfhip_plan_t plan, const float* params, const int32_t* table, float* packed,
                               nerfhip_stream_t stream);

@@ -43,7 +43,7 @@ class RenderCotangents(C.Structure):
                                    "g_depth_fine")]
 
 
-PRECISION_FP32, PRECISION_BF16X3, PRECISION_BF16X3_FWD, PRECISION_BF16X3_FWD_DGRAD, PRECISION_BF16X3_TRAIN = 0, 1, 2, 3, 4  # NERFHIP_PRECISION_*
+PRECISION_FP32 = 0  # NERFHIP_PRECISION_* (1 .. 4: round 3's bf16-piece plans, removed)
 PRECISION_F16X3, PRECISION_F16X3_FWD, PRECISION_F16X3_FWD_DGRAD, PRECISION_F16X3_TRAIN = 5, 6, 7, 8
 PART_COARSE, PART_FINE, PART_SHARED_BWD = 1, 2, 4
 
@@ -206,6 +206,10 @@ class launch_on:
 
 
 _LIB = None
+# `make variant` builds (A/B schedules, wrong-result cost-attribution switches: csrc/nh_diag.h) report nerfhip_version() + DIAG_FLAG.
+# The package refuses them; a diagnostic script under scripts/ that loads one on purpose sets ALLOW_DIAG (and LIB_PATH) first.
+DIAG_FLAG = 1000000
+ALLOW_DIAG = False
 
 
 def get_lib():
@@ -217,4 +221,7 @@ def get_lib():
         _LIB = NerfHipLib(LIB_PATH)
         if _LIB.is_emulated():
             raise NerfHipError("libnerfhip.so reports an emulator build; refusing to use it as the product path")
+        if _LIB.version() >= DIAG_FLAG and not ALLOW_DIAG:
+            lib, _LIB = _LIB, None
+            raise NerfHipError("%s is a `make variant` build (A/B or diagnostic switches, csrc/nh_diag.h): not the product library" % lib.path)
     return _LIB

@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include "nh_diag.h"
 #include "nh_host.h"
 #include "nh_rays.h"
 
@@ -16,7 +17,13 @@ void nh_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* nerfhip_last_error(void) { return g_err; }
-extern "C" int nerfhip_version(void) { return 100; }
+extern "C" int nerfhip_version(void) {
+#ifdef NH_DIAG  // (make variant: an A/B or diagnostic build -- nh_diag.h; the Python package refuses it)
+    return 101 + NH_DIAG_VERSION_FLAG;
+#else
+    return 101;
+#endif
+}
 extern "C" int nerfhip_is_emulated(void) {
 #ifdef NERFHIP_EMU
     return 1;

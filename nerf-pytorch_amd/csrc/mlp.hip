@@ -76,9 +76,8 @@ int nh_mlp_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, i
     }
     if (p->precision != NERFHIP_PRECISION_FP32) {
         NH_REQUIRE(!stash || nh_prec_level(p->precision) != 1,
-                   "mlp_fwd: a bf16x3 / f16x3 plan is inference-only (no activation stash, no backward; the _FWD / _FWD_DGRAD / _TRAIN plans train)");
-        if (!nh_prec_f16(p->precision)) return nh_mlp_forward_bf16(p, packed, in, M, out, stash, stream);
-        return p->w2 ? nh_mlp_forward_f16w(p, packed, in, M, out, stash, stream) : nh_mlp_forward_f16(p, packed, in, M, out, stash, stream);
+                   "mlp_fwd: an f16x3 plan is inference-only (no activation stash, no backward; the _FWD / _FWD_DGRAD / _TRAIN plans train)");
+        return nh_mlp_forward_f16w(p, packed, in, M, out, stash, stream);
     }
     return nh_mlp16_forward(p, packed, in, M, out, stash, stream);
 }
@@ -86,26 +85,24 @@ int nh_mlp_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, i
 int nh_mlp_backward(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash,
                     float* scratch, int64_t scratch_bytes, float* g_params, nerfhip_stream_t stream) {
     NH_REQUIRE(p && packed && g_out && stash && scratch && g_params && M > 0, "mlp_bwd: bad arguments");
-    NH_REQUIRE(nh_prec_level(p->precision) != 1, "mlp_bwd: a bf16x3 / f16x3 plan is inference-only");
+    NH_REQUIRE(nh_prec_level(p->precision) != 1, "mlp_bwd: an f16x3 plan is inference-only");
     NH_REQUIRE(scratch_bytes >= nh_mlp_bwd_scratch_bytes(p, M), "mlp_bwd: scratch too small (%lld < %lld)",
                (long long)scratch_bytes, (long long)nh_mlp_bwd_scratch_bytes(p, M));
     const int64_t nt = nh_ceil_div(M, 128) * 4;
-    const bool bdg = nh_prec_level(p->precision) >= 3, f16 = nh_prec_f16(p->precision);
+    const bool bdg = nh_prec_level(p->precision) >= 3;
     int rc = NERFHIP_OK;
     // fp16 plans whose large weight-gradient blocks run on the fp16 MFMAs: the producers record per-region maxima (behind the
     // stash: the forward's; behind this scratch: the data-gradient launch's), from which k_wgrad_f16x3 takes its scales
     unsigned* amax = nullptr;
     const unsigned* bmax = nullptr;
-    if (f16 && !p->bjobs.empty()) {
+    if (!p->bjobs.empty()) {
         amax = (unsigned*)(scratch + gscale_word_offset(p, nt));
         bmax = (const unsigned*)(stash + nh_stash_floats(p, nt));
         rc = nh_zero_words(amax, NH_RMAX_WORDS, stream);
         if (rc) return rc;
     }
     if (bdg)
-        rc = f16 ? (p->w2 ? nh_mlp_dgrad_f16w(p, packed, g_out, M, stash, scratch, amax, stream)
-                          : nh_mlp_dgrad_f16(p, packed, g_out, M, stash, scratch, amax, stream))
-                 : nh_mlp_dgrad_bf16(p, packed, g_out, M, stash, scratch, nullptr, stream);
+        rc = nh_mlp_dgrad_f16w(p, packed, g_out, M, stash, scratch, amax, stream);
     else
         rc = nh_mlp16_dgrad(p, packed, g_out, M, stash, scratch, stream);
     if (rc) return rc;
@@ -114,8 +111,7 @@ int nh_mlp_backward(nerfhip_plan* p, const float* packed, const float* g_out, in
     if (rc) return rc;
     // (level 4: the large blocks, behind the fp32 kernel's partials)
     float* const partial_b = partial + nh_wgrad_partial_floats(p, nt);
-    return f16 ? nh_wgrad_f16(p, nt, stash, scratch, partial_b, g_params, amax, bmax, stream)
-               : nh_wgrad_bf16(p, nt, stash, scratch, partial_b, g_params, nullptr, nullptr, stream);
+    return nh_wgrad_f16(p, nt, stash, scratch, partial_b, g_params, amax, bmax, stream);
 }
 
 int nh_zero_words(unsigned* dev, int n, nerfhip_stream_t stream) {

@@ -16,6 +16,7 @@
 // the first half of a chunk, stash stores in its second half (mlp16.hip: a weight copy queued behind stash stores is what the
 // store stream really costs).
 #include "nh_device.h"
+#include "nh_diag.h"
 #include "nh_mlp.h"
 
 namespace {
@@ -26,7 +27,15 @@ static_assert(WS == (float)(1 << WS_LOG2), "weight scale");
 constexpr int TARGET_LOG2 = 13;  // a sample's largest operand value lands in [2^13, 2^14)
 constexpr int NO_CAP = 100;
 constexpr int ZERO_EXP = 60;     // exponent of a sample whose values are all zero (mlp_bf16.hip NHB_ZERO_EXP)
-NH_DEVICE int exp_for(unsigned mb, int base_e) { return ((mb >> 23) & 255u) == 0u ? ZERO_EXP : base_e + nh_shift_to(mb, TARGET_LOG2); }
+// Every per-sample exponent stays inside [-S_LIM, S_LIM]: the scales applied with it -- 2^s, 2^-s, 2^(-8 - s) -- are then exactly the
+// powers of two nh_pow2i can represent (it clamps at 2^-126 / 2^127), so what a sample's exponent SAYS and what its values were multiplied
+// by never part (nh_shift_to alone reaches 139 for magnitudes near 2^-126).  A sample whose largest value sits below
+// 2^(13 - S_LIM) = 2^-97 keeps fewer piece bits instead -- it is zero to fp32's neighbours anyway.
+constexpr int S_LIM = 110;
+NH_DEVICE int clamp_exp(int s) { return s < -S_LIM ? -S_LIM : (s > S_LIM ? S_LIM : s); }
+NH_DEVICE int exp_for(unsigned mb, int base_e) { return ((mb >> 23) & 255u) == 0u ? ZERO_EXP : clamp_exp(base_e + nh_shift_to(mb, TARGET_LOG2)); }
+// ... and a renormalisation moves a sample by at most 2^120 in one step (the multiplier is a normal float), within the same limits
+NH_DEVICE int step_exp(int so, int base_e) { return clamp_exp(so > base_e + 120 ? base_e + 120 : (so < base_e - 120 ? base_e - 120 : so)); }
 // a raw network output from an accumulator that holds WS * 2^s * value
 NH_DEVICE float raw_of(float acc, int s) { return acc * nh_pow2i(-WS_LOG2 - s); }
 
@@ -91,7 +100,7 @@ struct MaskW {
 // mul; BITS: the ReLU bits of the values as the next layer consumes them (hi > 0), shift-accumulated in register order
 template <bool RELU, bool BITS>
 NH_DEVICE void convert_pair(const f32x4& a0, const f32x4& a1, nh_f16x8& oh, nh_f16x8& ol, float mul, MaskW& bits, int r0) {
-#ifdef NHW_EXP_NO_EPI  // (diagnostic builds only, wrong results: what the kernel costs without the conversions)
+#ifdef NHW_EXP_NO_EPI  // (NH_DIAG builds only, wrong results: what the kernel costs without the conversions)
     oh[0] = nh_to_f16(a0[0] * mul);
     ol[4] = nh_to_f16(a1[0]);
     return;
@@ -129,14 +138,14 @@ NH_DEVICE unsigned tile_max_bits(const f32x4* acc) {
 template <int NT>
 NH_DEVICE int renorm_convert(const f32x4* acc, nh_f16x8* oh, nh_f16x8* ol, int s_in, int cap) {
     const int base_e = WS_LOG2 + s_in;
-#ifdef NHW_EXP_NO_MAX  // (diagnostic builds only, wrong results)
+#ifdef NHW_EXP_NO_MAX  // (NH_DIAG builds only, wrong results)
     int so = base_e;
 #else
     const unsigned mb = tile_max_bits<NT, false>(acc);
     int so = exp_for(mb, base_e);
 #endif
     so = so < cap ? so : cap;
-    so = so > base_e + 120 ? base_e + 120 : (so < base_e - 120 ? base_e - 120 : so);
+    so = step_exp(so, base_e);
     const float mul = nh_pow2i(so - base_e);
     MaskW none;
     none.w[0] = none.w[1] = 0u;
@@ -211,7 +220,7 @@ NH_DEVICE void gemm_w(WCtx& cx, const nh_f16x8* ah, const nh_f16x8* al, const nh
         float v2 = nh_from_f16(ah[kb][o + 2]) + nh_from_f16(al[kb][o + 2]);
         float v3 = nh_from_f16(ah[kb][o + 3]) + nh_from_f16(al[kb][o + 3]);
         v0 *= row_scale, v1 *= row_scale, v2 *= row_scale, v3 *= row_scale;
-#ifdef NHW_EXP_NO_STORE  // (diagnostic builds only, wrong results: what the stores themselves cost)
+#ifdef NHW_EXP_NO_STORE  // (NH_DIAG builds only, wrong results: what the stores themselves cost)
         if (v0 != 1.2345e-30f || v1 != 5.4321e-30f) return;
 #endif
         nh_store4(in_rows + 16 * ts + 4 * cx.g, v0, v1, v2, v3);  // units 16 ts + 4 g .. + 3
@@ -225,7 +234,7 @@ NH_DEVICE void gemm_w(WCtx& cx, const nh_f16x8* ah, const nh_f16x8* al, const nh
 #else
         nh_wait_vmem();
 #endif
-#ifndef NHW_EXP_NO_BARRIER  // (diagnostic builds only, wrong results: what the chunk barriers cost)
+#ifndef NHW_EXP_NO_BARRIER  // (NH_DIAG builds only, wrong results: what the chunk barriers cost)
         nh_block_sync();   // ... and everyone's; nobody still reads the other buffer
 #endif
         // the next chunk (or the next layer's first one) goes to the other buffer WHILE this one is multiplied
@@ -237,13 +246,13 @@ NH_DEVICE void gemm_w(WCtx& cx, const nh_f16x8* ah, const nh_f16x8* al, const nh
         } else if (next_first > 0) {
             dsrc = next_base, dpieces = next_first >> 10, ddst = 0;
         }
-#ifdef NHW_EXP_NO_STREAM  // (diagnostic builds only, wrong results: what the kernel costs without the weight stream)
+#ifdef NHW_EXP_NO_STREAM  // (NH_DIAG builds only, wrong results: what the kernel costs without the weight stream)
         dpieces = dpieces < 8 ? dpieces : 8;
 #endif
         int dnext = cx.wave;  // this wave's next piece
         auto dma_step = [&]() {
             if (dnext < dpieces) {
-#ifdef NHW_EXP_SAME_SRC  // (diagnostic builds only, wrong results: every piece re-reads the image's first 8 KiB -- issue and LDS cost without the L2 traffic)
+#ifdef NHW_EXP_SAME_SRC  // (NH_DIAG builds only, wrong results: every piece re-reads the image's first 8 KiB -- issue and LDS cost without the L2 traffic)
                 nh_dma16a(cx.dma, cx.lane * 16, (dnext & 7) * 1024, cx.lds_addr + (unsigned)((cx.buf ^ 1) * BUF + ddst + dnext * 1024));
 #else
                 nh_dma16a(cx.dma, cx.lane * 16, (int)dsrc + dnext * 1024, cx.lds_addr + (unsigned)((cx.buf ^ 1) * BUF + ddst + dnext * 1024));
@@ -280,7 +289,7 @@ NH_DEVICE void gemm_w(WCtx& cx, const nh_f16x8* ah, const nh_f16x8* al, const nh
         nh_f16x8 wph[4], wpl[4];
         auto load = [&](int i) {
             wph[i & 3] = *(const nh_f16x8*)(wb + (2 * i) * 1024);
-#ifdef NHW_EXP_HALF_LDS  // (diagnostic builds only, wrong results: half of the operand reads)
+#ifdef NHW_EXP_HALF_LDS  // (NH_DIAG builds only, wrong results: half of the operand reads)
             wpl[i & 3] = wph[i & 3];
 #else
             wpl[i & 3] = *(const nh_f16x8*)(wb + (2 * i + 1) * 1024);
@@ -343,7 +352,7 @@ NH_DEVICE void gemm_w(WCtx& cx, const nh_f16x8* ah, const nh_f16x8* al, const nh
     if (NTS > 0 && cx.wrm && ridx >= 0) note_region(cx, ridx, s_in);
     if (EPI != 0) {
         float mul = 1.0f / WS;
-#ifdef NHW_EXP_NO_MAX  // (diagnostic builds only, wrong results: what the per-sample exponent search costs)
+#ifdef NHW_EXP_NO_MAX  // (NH_DIAG builds only, wrong results: what the per-sample exponent search costs)
         if (DYN) *s_out = s_in;
         if (false) {
 #else
@@ -357,7 +366,7 @@ NH_DEVICE void gemm_w(WCtx& cx, const nh_f16x8* ah, const nh_f16x8* al, const nh
             const int base_e = WS_LOG2 + s_in;
             int so = exp_for(mb, base_e);
             so = so < cap ? so : cap;
-            so = so > base_e + 120 ? base_e + 120 : (so < base_e - 120 ? base_e - 120 : so);
+            so = step_exp(so, base_e);
             mul = nh_pow2i(so - base_e);
             *s_out = so;  // the pieces made below are those of value * 2^so
         }
@@ -794,7 +803,7 @@ int w_lds_limit(K kern, int bytes) {
 int nh_mlp_forward_f16w(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
                         nerfhip_stream_t stream) {
     NH_REQUIRE(M < ((int64_t)1 << 31), "mlp_fwd: at most 2^31 - 1 sample points per call (got %lld)", (long long)M);
-    NH_REQUIRE(p->w2, "mlp_fwd_f16w: the plan's images are not in this kernel's geometry");
+    NH_REQUIRE(nh_prec_f16(p->precision), "mlp_fwd_f16w: not an fp16-piece plan");
     FwdWArgs a;
     memset(&a, 0, sizeof(a));
     a.packed = packed;
@@ -864,7 +873,7 @@ int nh_mlp_forward_f16w(nerfhip_plan* p, const float* packed, const NhMlpInput& 
 
 int nh_mlp_dgrad_f16w(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
                       unsigned* rmax, nerfhip_stream_t stream) {
-    NH_REQUIRE(p->w2, "mlp_bwd_f16w: the plan's images are not in this kernel's geometry");
+    NH_REQUIRE(nh_prec_f16(p->precision), "mlp_bwd_f16w: not an fp16-piece plan");
     DgradWArgs d;
     memset(&d, 0, sizeof(d));
     d.packed = packed;

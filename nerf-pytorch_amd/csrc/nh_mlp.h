@@ -24,25 +24,15 @@ int nh_mlp16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in,
 int nh_mlp16_dgrad(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
                    nerfhip_stream_t stream);
 
-// mlp_bf16.hip (bf16 pieces) and the same source through mlp_f16.hip (fp16 pieces): forward (with / without stash) and
-// data-gradient chain of the split-precision plans; rmax (fp16, level-4 plans): NH_RMAX_WORDS zeroed device words for the region maxima, or NULL
-int nh_mlp_forward_bf16(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
-                        nerfhip_stream_t stream);
-int nh_mlp_dgrad_bf16(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
-                      unsigned* rmax, nerfhip_stream_t stream);
-int nh_pack_pieces_bf16(nerfhip_plan* plan, const float* params, const int32_t* table, float* packed, nerfhip_stream_t stream);
-int nh_mlp_forward_f16(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
-                       nerfhip_stream_t stream);
-int nh_mlp_dgrad_f16(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
-                     unsigned* rmax, nerfhip_stream_t stream);
-// mlp_f16w.hip: the same arithmetic with two waves per SIMD (16-sample waves on v_mfma_f32_16x16x32_f16), for plans whose images are
-// in that geometry (nerfhip_plan::w2)
+// mlp_f16w.hip: forward (with / without stash) and data-gradient chain of the fp16-piece plans: two waves per SIMD, 16-sample waves on
+// v_mfma_f32_16x16x32_f16; rmax (level-4 plans): NH_RMAX_WORDS zeroed device words for the region maxima, or NULL
 int nh_mlp_forward_f16w(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
                         nerfhip_stream_t stream);
 int nh_mlp_dgrad_f16w(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
                       unsigned* rmax, nerfhip_stream_t stream);
 // mlp.hip: n words of device memory to zero, on the stream
 int nh_zero_words(unsigned* dev, int n, nerfhip_stream_t stream);
+// pack_f16.hip: the fp16-piece layer images of a plan
 int nh_pack_pieces_f16(nerfhip_plan* plan, const float* params, const int32_t* table, float* packed, nerfhip_stream_t stream);
 
 // wgrad.hip: split-K weight-gradient GEMMs over the stash / d(pre-activation) images (nt = 32-sample tiles) + reduction
@@ -52,11 +42,9 @@ int64_t nh_wgrad_partial_floats(nerfhip_plan* p, int64_t nt);
 int nh_wgrad(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad, float* partial, float* g_params,
              const unsigned* gscale, nerfhip_stream_t stream);
 
-// wgrad_bf16.hip / wgrad_f16.hip: the large weight blocks of level-4 plans (plan->bjobs) on the 16-bit MFMAs
-int64_t nh_wgrad_x3_partial_floats(nerfhip_plan* p, int64_t nt);
-// amax / bmax (fp16): the region maxima recorded by the data-gradient / forward launch that wrote `grad` / `stash`, or NULL
-int nh_wgrad_bf16(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad, float* partial, float* g_params,
-                  const unsigned* amax, const unsigned* bmax, nerfhip_stream_t stream);
+// wgrad_f16.hip: the large weight blocks of level-4 plans (plan->bjobs) on the fp16 MFMAs
+int64_t nh_wgrad_x3_partial_floats(nerfhip_plan* p, int64_t nt);  // (-1 with an error message: a block list the schedule refuses)
+// amax / bmax: the region maxima recorded by the data-gradient / forward launch that wrote `grad` / `stash`, or NULL
 int nh_wgrad_f16(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad, float* partial, float* g_params,
                  const unsigned* amax, const unsigned* bmax, nerfhip_stream_t stream);
 

@@ -41,45 +41,30 @@ static inline int64_t nh16_image_floats(int kr, int tiles, int W) { return nh16_
 // 32-bit words of ReLU bits per lane and layer: one bit per activation register (W / 4 of them), at least two words
 constexpr int nh16_mask_words(int W) { return W >= 512 ? 4 : 2; }
 
-// ---- split-bf16 inference images (mlp_bf16.hip; plans created with NERFHIP_PRECISION_BF16X3) -----------------------------
-// A layer image = 512 fp32 bias words (one per output row, 32 per tile) + per (k-block kb, 32-row tile t): a 1-KiB block
-// of bf16 HIGH pieces and a 1-KiB block of bf16 LOW pieces, lane l of a block holding the 8 elements
-// W[32 t + (l & 31)][in(kb, l >> 5, e)], e = 0..7.  Hidden inputs: in = nhb_unit(kb, h, e) -- the unit that accumulator
-// register 8*(kb & 1) + e of output tile kb >> 1 holds for lane half h, so a layer's converted accumulators ARE the next
-// layer's B operands.  Encoding inputs: slot 16 kb + 8 h + e (sin / cos of pair slot >> 1 = 3 f + axis in slots 2p, 2p+1;
-// the raw coordinates in slots NS-4 .. NS-2).  Every weight element gives two bf16 pieces = one 32-bit word of image, so an
-// image has 512 + nk * nt * 512 words -- which is also the length of its gather table (nerfhip_plan_pack_index: one source
-// index per bias word, then one per weight element in (kb, t, lane, e) order).
-static inline int nhb_unit(int kb, int h, int e) { return 32 * (kb >> 1) + 16 * (kb & 1) + 8 * (e >> 2) + 4 * h + (e & 3); }
+// ---- fp16-piece images (mlp_f16w.hip, pack_f16.hip; plans created with NERFHIP_PRECISION_F16X3*) -------------------------------
+// A layer image = 512 fp32 bias words (one per output row) + per (k-block kb, 16-row output tile t): a 1-KiB block of fp16 HIGH
+// pieces and a 1-KiB block of fp16 LOW pieces, lane l of a block holding the 8 elements
+// W[16 t + (l & 15)][in(kb, l >> 4, e)], e = 0..7, a k-block being 32 inputs deep.  Hidden inputs: in = nhw_unit(kb, g, e) -- the
+// unit accumulator register e & 3 of output tile 2 kb + (e >> 2) holds for lane group g, so a layer's converted accumulators ARE
+// the next layer's B operands.  Encoding inputs: slot 32 kb + 8 g + e (sin / cos of pair slot >> 1 = 3 f + axis in slots 2p, 2p+1;
+// the raw coordinates in slots NS-4 .. NS-2).  Every weight element gives two fp16 pieces = one 32-bit word of image, so an image
+// has 512 + nk * nt * 512 words -- which is also the length of its gather table (nerfhip_plan_pack_index: one source index per bias
+// word, then one per weight element in (kb, t, lane, e) order).  Blocks are streamed in linear (kb, t) order, nhw_chunk_blocks of
+// them per LDS chunk buffer.
 static inline int64_t nhb_image_words(int nk, int nt) { return 512 + (int64_t)nk * nt * 512; }
-constexpr int NHB_XBLOCKS = 4, NHB_DBLOCKS = 2;  // k-blocks of the xyz (64 slots) / direction (32 slots) encodings
-constexpr int nhb_chunk_bytes(int W) { return W >= 256 ? 65536 : 32768; }  // weight blocks per LDS chunk buffer
-// bytes of a layer's first chunk: its bias block + as many whole k-blocks as fit
-constexpr int nhb_first_bytes(int nk, int nt, int W) {
-    return 2048 + (nk < nhb_chunk_bytes(W) / (nt * 2048) ? nk : nhb_chunk_bytes(W) / (nt * 2048)) * nt * 2048;
-}
-
-// The same images for the two-waves-per-SIMD fp16 kernels (mlp_f16w.hip, v_mfma_f32_16x16x32_f16; nerfhip_plan::w2): 16-row output
-// tiles and 32-deep k-blocks -- lane l of a (k-block kb, tile t) block holds W[16 t + (l & 15)][in(kb, l >> 4, e)], e = 0..7.
-// Hidden inputs: in = nhw_unit(kb, g, e), the unit accumulator register e & 3 of output tile 2 kb + (e >> 2) holds for lane group
-// g; encoding inputs: slot 32 kb + 8 g + e (the SAME slot numbering: the stash's slot rows and the weight-gradient scatter do not
-// change).  Blocks are streamed in linear (kb, t) order, NHW_CHUNK_BLOCKS of them per LDS chunk buffer.
-#ifndef NHB_W2_DEFAULT  // (A/B builds: 0 keeps the fp16 plans on the one-wave-per-SIMD kernels of mlp_f16.hip)
-#define NHB_W2_DEFAULT 1
-#endif
 static inline int nhw_unit(int kb, int g, int e) { return 32 * kb + 16 * (e >> 2) + 4 * g + (e & 3); }
-constexpr int NHW_XBLOCKS = 2, NHW_DBLOCKS = 1;
+constexpr int NHW_XBLOCKS = 2, NHW_DBLOCKS = 1;  // k-blocks of the xyz (64 slots) / direction (32 slots) encodings
+constexpr int NHW_XSLOTS = 32 * NHW_XBLOCKS, NHW_DSLOTS = 32 * NHW_DBLOCKS;
 constexpr int nhw_chunk_blocks(int W) { return W >= 256 ? 32 : 16; }  // 2-KiB (hi + lo) blocks per chunk buffer
 constexpr int nhw_first_bytes(int nblocks, int W) { return 2048 + (nblocks < nhw_chunk_blocks(W) ? nblocks : nhw_chunk_blocks(W)) * 2048; }
 
-// Split-precision plans (include/nerfhip.h NERFHIP_PRECISION_*): `level` says which kernels run on the 16-bit MFMAs -- 0 none
-// (fp32), 1 the inference forward only (inference-only plan), 2 + the training forward, 3 + the data-gradient chain, 4 + the
-// large weight-gradient blocks -- and `f16` which pieces they multiply: bf16 (8 significant bits each, 8-bit exponent) or IEEE
-// fp16 (11 bits, 5-bit exponent: weights pre-scaled, d(raw output) scaled per launch).
-static inline int nh_prec_level(int precision) { return precision <= NERFHIP_PRECISION_BF16X3_TRAIN ? precision : precision - 4; }
+// fp16-piece plans (include/nerfhip.h NERFHIP_PRECISION_F16X3*): `level` says which kernels run on the fp16 MFMAs -- 0 none (fp32),
+// 1 the inference forward only (inference-only plan), 2 + the training forward, 3 + the data-gradient chain, 4 + the large
+// weight-gradient blocks.  (Precisions 1 .. 4 were the bf16-piece plans of round 3: removed in round 5, the numbers stay reserved.)
+static inline int nh_prec_level(int precision) { return precision >= NERFHIP_PRECISION_F16X3 ? precision - 4 : 0; }
 static inline bool nh_prec_f16(int precision) { return precision >= NERFHIP_PRECISION_F16X3; }
-// fp16 pieces: the packed weights (and biases) carry this exact power of two -- a weight's low piece is then a normal fp16 number
-// down to |w| = 2^-10; what is multiplied with them carries per-SAMPLE exponents the kernels keep themselves (mlp_bf16.hip header)
+// the packed weights (and biases) carry this exact power of two -- a weight's low piece is then a normal fp16 number down to
+// |w| = 2^-10; what is multiplied with them carries per-SAMPLE exponents the kernels keep themselves (mlp_f16w.hip header)
 constexpr float NHB_F16_WSCALE = 256.0f;
 
 struct NhTensor {
@@ -102,7 +87,7 @@ struct NhPackedOffsets {
 };
 
 // Words behind a training stash / a backward scratch in which the fp16 kernels record the largest magnitude stored per region
-// (mlp_bf16.hip `rmax`; indices: H[k] / P[k] -> k, FEAT / PFEAT -> L, DIRH / PDIR -> L + 1): zeroed before the producing launch
+// (mlp_f16w.hip `rmax`; indices: H[k] / P[k] -> k, FEAT / PFEAT -> L, DIRH / PDIR -> L + 1): zeroed before the producing launch
 constexpr int NH_RMAX_WORDS = 64;
 // ... and for the regions that ride as guests on the large weight-gradient blocks: the xyz / direction slot regions of the stash, the
 // d(raw output) region of the scratch
@@ -157,7 +142,7 @@ struct NhJob {
     int64_t s_w_off, s_bias_off;
 };
 
-// A weight block whose gradient the split-bf16 weight-gradient kernel computes (NERFHIP_PRECISION_BF16X3_TRAIN; wgrad_bf16.hip):
+// A weight block whose gradient the fp16-piece weight-gradient kernel computes (NERFHIP_PRECISION_F16X3_TRAIN; wgrad_f16.hip):
 // dW[r][c] = sum_samples A[r][s] B[c][s] for r < r_hi, c < col_count, written to w_off + r * w_ld + c; bias = row sums of A.
 struct NhJobB {
     int a_idx, b_idx;                    // the regions' slots among the recorded maxima (NH_RMAX_WORDS)
@@ -165,7 +150,7 @@ struct NhJobB {
     int64_t a_row_prefix, b_row_prefix;  // region offsets = 32 * n_tiles * prefix floats
     int r_hi, col_count, w_ld;
     int64_t w_off, bias_off;
-    // A thin block riding on this one (wgrad_bf16.hip "SA / SB"), taken out of `jobs`: side_kind 1 = a 32-row region of the gradient
+    // A thin block riding on this one (wgrad_f16.hip "SA / SB"), taken out of `jobs`: side_kind 1 = a 32-row region of the gradient
     // scratch as ONE more A tile against this block's B region (side rows s_r_lo .. s_r_hi - 1 are the guest's parameter rows);
     // 2 = a 32- / 64-row slot region of the stash as more B tiles against this block's A region (columns through the slot map
     // s_col_kind: 1 xyz, 2 dir).  side_idx: the region's slot among the recorded maxima.
@@ -183,11 +168,10 @@ struct nerfhip_plan {
     int t_layer1_w, t_layer1_b, t_xyz_w[NH_MAX_LAYERS], t_xyz_b[NH_MAX_LAYERS];
     int t_dir_w, t_dir_b, t_alpha_w, t_alpha_b, t_rgb_w, t_rgb_b, t_feat_w, t_feat_b, t_out_w, t_out_b;
     int precision;                    // NERFHIP_PRECISION_*: nh_prec_level() / nh_prec_f16() above
-    int w2;                           // split-precision images in the geometry of mlp_f16w.hip (16-row tiles, 32-deep k-blocks): fp16 plans
-    NhPackedOffsets pob;              // bf16x3 plans: word offsets of the split-bf16 layer images inside the packed buffer
-    int64_t packed32_floats;          // words of the fp32 image in front of them (0 for _BF16X3, the whole buffer for _FP32)
-    int xyz_slot_b[16 * NHB_XBLOCKS];  // bf16x3 plans: encoding slot -> reference column, or -1
-    int dir_slot_b[16 * NHB_DBLOCKS];
+    NhPackedOffsets pob;              // f16x3 plans: word offsets of the fp16-piece layer images inside the packed buffer
+    int64_t packed32_floats;          // words of the fp32 image in front of them (0 for _F16X3, the whole buffer for _FP32)
+    int xyz_slot_b[NHW_XSLOTS];       // f16x3 plans: encoding slot -> reference column, or -1
+    int dir_slot_b[NHW_DSLOTS];
     int krx, krd;                     // encoding registers per lane group: NH16_KRX / NH16_KRD or the _EXT pair
     int xyz_col16[4][NH16_KRX_EXT];  // slot (r,g) -> reference column of the xyz encoding, or -1  (rows of krx entries)
     int dir_col16[4][NH16_KRD_EXT];
@@ -200,7 +184,7 @@ struct nerfhip_plan {
     NhStashLayout stash;
     NhGradLayout grad;
     std::vector<NhJob> jobs;
-    std::vector<NhJobB> bjobs;        // (BF16X3_TRAIN: the large blocks, taken out of `jobs`)
+    std::vector<NhJobB> bjobs;        // (F16X3_TRAIN: the large blocks, taken out of `jobs`)
     int wgrad_waves;         // waves per workgroup of the weight-gradient kernel: 8 (256- and 512-wide nets) or 4 (narrower)
     bool is_skip(int i) const { return i % skip == 0 && i > 0; }
 };

@@ -5,6 +5,7 @@
 #include <functional>
 
 #include "nh_host.h"
+#include "nh_mlp.h"
 #include "nh_plan.h"
 
 namespace {
@@ -210,9 +211,9 @@ void layout_packed(nerfhip_plan* p) {
     p->packed_floats = off;
 }
 
-// ---- split-bf16 inference images (nh_plan.h "split-bf16 inference images", mlp_bf16.hip) -------------------------------
+// ---- fp16-piece images (nh_plan.h "fp16-piece images", mlp_f16w.hip / pack_f16.hip) -------------------------------------
 struct GemmSpecB {
-    int nk = 0, nt = 0;                            // k-blocks of 16 inputs, 32-row output tiles
+    int nk = 0, nt = 0;                            // k-blocks of 32 inputs, 16-row output tiles
     std::function<int64_t(int, int, int, int)> w;  // (out_row, kb, h, e) -> flat param index or -1
     std::function<int64_t(int)> b;                 // out_row -> flat param index or -1
 };
@@ -236,14 +237,13 @@ bool build_slot_map_b(int L, int include_input, int nslots, int* col) {
 }
 
 void build_specs_b(const nerfhip_plan* p, SpecsB& S) {
-    // (w2: the geometry of mlp_f16w.hip -- `h` is then the lane group l >> 4 and a k-block is 32 inputs deep: nh_plan.h)
-    const bool w2 = p->w2 != 0;
-    const int W = p->W, H = p->H, H2 = H / 2, KBH = w2 ? W / 32 : W / 16, TH = w2 ? W / 16 : W / 32, Dx = p->Dx, Dd = p->Dd, L = p->L;
-    const int XBLOCKS = w2 ? NHW_XBLOCKS : NHB_XBLOCKS, DBLOCKS = w2 ? NHW_DBLOCKS : NHB_DBLOCKS;
+    // (the geometry of mlp_f16w.hip: `h` is the lane group l >> 4 and a k-block is 32 inputs deep -- nh_plan.h)
+    const int W = p->W, H = p->H, H2 = H / 2, KBH = W / 32, TH = W / 16, Dx = p->Dx, Dd = p->Dd, L = p->L;
+    const int XBLOCKS = NHW_XBLOCKS, DBLOCKS = NHW_DBLOCKS;
     auto T = [p](int idx) { return p->tensors[idx]; };
-    auto xcol = [p, w2](int kb, int h, int e) { return p->xyz_slot_b[(w2 ? 32 : 16) * kb + 8 * h + e]; };
-    auto dcol = [p, w2](int kb, int h, int e) { return p->dir_slot_b[(w2 ? 32 : 16) * kb + 8 * h + e]; };
-    auto nhb_unit = [w2](int kb, int h, int e) { return w2 ? nhw_unit(kb, h, e) : ::nhb_unit(kb, h, e); };
+    auto xcol = [p](int kb, int h, int e) { return p->xyz_slot_b[32 * kb + 8 * h + e]; };
+    auto dcol = [p](int kb, int h, int e) { return p->dir_slot_b[32 * kb + 8 * h + e]; };
+    auto nhb_unit = [](int kb, int h, int e) { return nhw_unit(kb, h, e); };
     {
         GemmSpecB& s = S.f_layer1;
         s.nk = XBLOCKS;
@@ -318,7 +318,7 @@ void build_specs_b(const nerfhip_plan* p, SpecsB& S) {
         };
         s.b = [=](int o) -> int64_t { return o < 4 ? ob.off + o : -1; };
     }
-    // ---- the data-gradient chain (NERFHIP_PRECISION_BF16X3_FWD_DGRAD): d(in)[f] = sum_u W[u][f] dpre[u]; k-block element
+    // ---- the data-gradient chain (NERFHIP_PRECISION_F16X3_FWD_DGRAD and up): d(in)[f] = sum_u W[u][f] dpre[u]; k-block element
     // (kb, h, e) is unit u = nhb_unit(kb, h, e) of the layer's OUTPUT, output row f a unit of its input
     for (int i = 0; i < L - 1; ++i) {
         GemmSpecB& s = S.b_xyz[i];
@@ -390,8 +390,8 @@ void for_each_spec_b(const nerfhip_plan* p, SpecsB& S, NhPackedOffsets& o, Fn fn
     }
 }
 
-void fill_spec_b(const GemmSpecB& s, int64_t off, int32_t* table, bool w2) {
-    const int R = w2 ? 16 : 32;  // rows of an output tile; a lane is (row l & (R - 1), group l / R)
+void fill_spec_b(const GemmSpecB& s, int64_t off, int32_t* table) {
+    const int R = 16;  // rows of an output tile; a lane is (row l & (R - 1), group l / R)
     for (int i = 0; i < 512; ++i) table[off + i] = (i < R * s.nt && s.b) ? (int32_t)s.b(i) : -1;
     int32_t* img = table + off + 512;
     for (int kb = 0; kb < s.nk; ++kb)
@@ -401,7 +401,7 @@ void fill_spec_b(const GemmSpecB& s, int64_t off, int32_t* table, bool w2) {
                     img[(((int64_t)kb * s.nt + t) * 64 + lane) * 8 + e] = (int32_t)s.w(R * t + (lane & (R - 1)), kb, lane / R, e);
 }
 
-// the split-bf16 layer images, behind the first `base` words of the packed buffer
+// the fp16-piece layer images, behind the first `base` words of the packed buffer
 void layout_packed_b(nerfhip_plan* p, int64_t base) {
     int64_t off = base;
     memset(&p->pob, 0, sizeof(p->pob));
@@ -594,19 +594,19 @@ void build_layouts_and_jobs(nerfhip_plan* p) {
 #endif
     // (tiles cover the kernel width W; only the rows / columns of the real H hidden units are unpacked)
     const int TW = W / 32, H = p->H, H2 = H / 2;
-    // BF16X3_TRAIN: the hidden x hidden blocks go to the split-bf16 weight-gradient kernel instead (wgrad_bf16.hip)
+    // F16X3_TRAIN: the hidden x hidden blocks go to the fp16-piece weight-gradient kernel instead (wgrad_f16.hip)
     p->bjobs.clear();
     // (128- and 256-wide nets; 128: the four full blocks only -- the half-height block of layers_dir stays a thin job.  Round 3's
     // kernel lost on the 128 x 128 blocks (4x128 step 4.23 -> 5.04 ms); round 4's, which waits for HBM and nothing else, wins:
     // 4.35 -> 4.04 ms, profiles/r04_wgrad_128_ab.txt.  Other widths: _TRAIN is _FWD_DGRAD)
     const bool big_b = nh_prec_level(p->precision) == 4 && (W == 128 || W == 256);
-    // ... and a thin block whose operands such a block streams anyway rides on it as a guest (wgrad_bf16.hip SA / SB) instead of
+    // ... and a thin block whose operands such a block streams anyway rides on it as a guest (wgrad_f16.hip SA / SB) instead of
     // reading them a second time as an fp32 job of its own: a skip layer's xyz columns, fc_alpha's row, layers_dir's direction columns.
-    // (fp16 pieces: the guest regions need recorded maxima, which the kernels of mlp_f16w.hip write)
+    // (the guest regions need recorded maxima, which the kernels of mlp_f16w.hip write)
 #ifdef NHW_NO_GUESTS  // (A/B builds only)
     const bool guests = false;
 #else
-    const bool guests = big_b && (!nh_prec_f16(p->precision) || p->w2);
+    const bool guests = big_b;
 #endif
     auto add_big = [&](const NhRegion& A, int a_rows, const NhRegion& B, int r_hi, int w_tensor, int bias_tensor, int a_idx, int b_idx) {
         NhJobB j;
@@ -687,6 +687,11 @@ extern "C" nerfhip_plan_t nerfhip_plan_create_ex(const nerfhip_model_cfg* cfg, i
         nh_set_error("plan_create_ex: unknown precision %d", precision);
         return nullptr;
     }
+    if (precision > NERFHIP_PRECISION_FP32 && precision < NERFHIP_PRECISION_F16X3) {
+        nh_set_error("plan_create_ex: precision %d named a bf16-piece plan (round 3's experiment); those kernels were removed in round 5 -- "
+                     "the fp16-piece plans NERFHIP_PRECISION_F16X3* are as fast and hold the fp32 parity bounds", precision);
+        return nullptr;
+    }
     return plan_create_impl(cfg, precision);
 }
 extern "C" int nerfhip_plan_precision(nerfhip_plan_t plan) { return plan ? plan->precision : -1; }
@@ -717,7 +722,6 @@ static nerfhip_plan_t plan_create_impl(const nerfhip_model_cfg* cfg, int precisi
     nerfhip_plan* p = new nerfhip_plan();
     p->cfg = *cfg;
     p->precision = precision;
-    p->w2 = 0;
     p->H = cfg->hidden_size;
     // the kernels exist for four widths; a model rides zero-padded on the next one (build_specs16)
     p->W = p->H <= 64 ? 64 : (p->H <= 128 ? 128 : (p->H <= 256 ? 256 : 512));
@@ -782,26 +786,24 @@ static nerfhip_plan_t plan_create_impl(const nerfhip_model_cfg* cfg, int precisi
         p->freqs_dir[k] = 0.f;
     }
     if (precision != NERFHIP_PRECISION_FP32) {
-        // split-bf16 forward: the split-bf16 forward kernel exists for the 128- and 256-wide nets with the reference's own
-        // encoding sizes; everything else is the fp32 path's business
-        const bool okx = build_slot_map_b(cfg->num_encoding_fn_xyz, cfg->include_input_xyz ? 1 : 0, 16 * NHB_XBLOCKS, p->xyz_slot_b);
+        // the fp16-piece kernels exist for the 128- and 256-wide nets with the reference's own encoding sizes; everything else
+        // is the fp32 path's business
+        const bool okx = build_slot_map_b(cfg->num_encoding_fn_xyz, cfg->include_input_xyz ? 1 : 0, NHW_XSLOTS, p->xyz_slot_b);
         const bool okd = build_slot_map_b(p->view ? cfg->num_encoding_fn_dir : 0, (p->view && cfg->include_input_dir) ? 1 : 0,
-                                          16 * NHB_DBLOCKS, p->dir_slot_b);
+                                          NHW_DSLOTS, p->dir_slot_b);
         if (!(okx && okd) || (p->W != 128 && p->W != 256)) {
-            nh_set_error("plan_create_ex: bf16x3 / f16x3 plans need hidden_size in (64, 256], num_encoding_fn_xyz <= 10 and "
+            nh_set_error("plan_create_ex: f16x3 plans need hidden_size in (64, 256], num_encoding_fn_xyz <= 10 and "
                          "num_encoding_fn_dir <= 4 (got %d, %d, %d)", cfg->hidden_size, cfg->num_encoding_fn_xyz, cfg->num_encoding_fn_dir);
             delete p;
             return nullptr;
         }
-        // fp16 pieces: the two-waves-per-SIMD kernels of mlp_f16w.hip and their image geometry
-        p->w2 = (NHB_W2_DEFAULT && nh_prec_f16(precision)) ? 1 : 0;
         memset(&p->po, 0, sizeof(p->po));
         p->packed_floats = 0;
         if (nh_prec_level(precision) != 1) {
             layout_packed(p);  // the fp32 image: its transposed layers feed the data-gradient kernel
             // the training forward stores the encodings in ITS slot order: that is what the weight-gradient scatter must undo
-            for (int row = 0; row < 4 * NH16_KRX_EXT; ++row) p->xyz_slot_col[row] = row < 16 * NHB_XBLOCKS ? p->xyz_slot_b[row] : -1;
-            for (int row = 0; row < 4 * NH16_KRD_EXT; ++row) p->dir_slot_col[row] = row < 16 * NHB_DBLOCKS ? p->dir_slot_b[row] : -1;
+            for (int row = 0; row < 4 * NH16_KRX_EXT; ++row) p->xyz_slot_col[row] = row < NHW_XSLOTS ? p->xyz_slot_b[row] : -1;
+            for (int row = 0; row < 4 * NH16_KRD_EXT; ++row) p->dir_slot_col[row] = row < NHW_DSLOTS ? p->dir_slot_b[row] : -1;
         }
         layout_packed_b(p, p->packed_floats);
     } else {
@@ -815,6 +817,11 @@ static nerfhip_plan_t plan_create_impl(const nerfhip_model_cfg* cfg, int precisi
     for (const NhJob& j : p->jobs) reduce_records += j.side_kind ? 2 : 1;
     if ((int)p->jobs.size() > NH_MAX_JOBS || reduce_records > NH_MAX_JOBS) {
         nh_set_error("plan_create: too many gradient jobs (%d jobs, %d reduce records; limit %d)", (int)p->jobs.size(), reduce_records, NH_MAX_JOBS);
+        delete p;
+        return nullptr;
+    }
+    // (the fp16-piece weight-gradient kernel's launch tables: refused here, with wgrad_f16.hip's message, not at the first backward)
+    if (nh_wgrad_x3_partial_floats(p, 4) < 0) {
         delete p;
         return nullptr;
     }
@@ -848,7 +855,7 @@ extern "C" int nerfhip_plan_describe(nerfhip_plan_t plan, char* buf, int64_t cap
     };
     put("kernel_width %d hidden_size %d layers %d params %lld packed_floats %lld wgrad_waves %d jobs %d precision %d two_wave_images %d\n",
         plan->W, plan->H, plan->L, (long long)plan->nparams, (long long)plan->packed_floats, plan->wgrad_waves, (int)plan->jobs.size(),
-        plan->precision, plan->w2);
+        plan->precision, plan->precision != NERFHIP_PRECISION_FP32 ? 1 : 0);
     for (size_t q = 0; q < plan->jobs.size(); ++q) {
         const NhJob& j = plan->jobs[q];
         put("job %d tiles %dx%d waves %dx%d patch %dx%d cost %d side %d side_tiles %d\n", (int)q, j.a_tiles, j.b_tiles, j.wo, j.wi, j.po,
@@ -863,7 +870,7 @@ extern "C" int nerfhip_plan_pack_index(nerfhip_plan_t plan, int32_t* host_table)
         SpecsB S;
         build_specs_b(plan, S);
         NhPackedOffsets o = plan->pob;
-        for_each_spec_b(plan, S, o, [&](const GemmSpecB& s, int64_t* dst) { fill_spec_b(s, *dst, host_table, plan->w2 != 0); });
+        for_each_spec_b(plan, S, o, [&](const GemmSpecB& s, int64_t* dst) { fill_spec_b(s, *dst, host_table); });
         if (nh_prec_level(plan->precision) == 1) return NERFHIP_OK;
     }
     Specs16 S16;

@@ -16,12 +16,10 @@ from . import _lib as L
 from .nerf_helpers import frequency_bands_cpu
 
 
-PRECISIONS = {"fp32": L.PRECISION_FP32, "bf16x3": L.PRECISION_BF16X3, "bf16x3_fwd": L.PRECISION_BF16X3_FWD,
-              "bf16x3_fwd_dgrad": L.PRECISION_BF16X3_FWD_DGRAD, "bf16x3_train": L.PRECISION_BF16X3_TRAIN,
-              "f16x3": L.PRECISION_F16X3, "f16x3_fwd": L.PRECISION_F16X3_FWD, "f16x3_fwd_dgrad": L.PRECISION_F16X3_FWD_DGRAD,
-              "f16x3_train": L.PRECISION_F16X3_TRAIN}
-TRAINING_PRECISIONS = ("fp32", "bf16x3_fwd", "bf16x3_fwd_dgrad", "bf16x3_train", "f16x3_fwd", "f16x3_fwd_dgrad", "f16x3_train")
-INFERENCE_PRECISIONS = ("fp32", "bf16x3", "f16x3")
+PRECISIONS = {"fp32": L.PRECISION_FP32, "f16x3": L.PRECISION_F16X3, "f16x3_fwd": L.PRECISION_F16X3_FWD,
+              "f16x3_fwd_dgrad": L.PRECISION_F16X3_FWD_DGRAD, "f16x3_train": L.PRECISION_F16X3_TRAIN}
+TRAINING_PRECISIONS = ("fp32", "f16x3_fwd", "f16x3_fwd_dgrad", "f16x3_train")
+INFERENCE_PRECISIONS = ("fp32", "f16x3")
 
 
 class _PlanHandle:
@@ -177,11 +175,9 @@ class FlexibleNeRFModel(torch.nn.Module):
     def set_training_precision(self, precision):
         """Arithmetic of this model's TRAINING passes (and of its inference passes unless set_inference_precision says
         otherwise): "fp32" (default: the reference's own arithmetic, what the headline benchmark runs) or one of the
-        split-precision plans of include/nerfhip.h -- the same three-MFMA product on two 16-bit pieces per operand:
-          "f16x3_fwd" / "f16x3_fwd_dgrad" / "f16x3_train"   IEEE fp16 pieces: ~3 x 2^-24 per product, fp32-grade (the
-              forward | + the data-gradient chain | + the large weight-gradient blocks on the 16-bit MFMAs);
-          "bf16x3_fwd" / "bf16x3_fwd_dgrad" / "bf16x3_train"  bf16 pieces: ~2^-16 per product (round 3's experiments,
-              accepted by PSNR@iters only: DESIGN.md 7.4-7.6).
+        fp16-piece plans of include/nerfhip.h -- three fp16 MFMAs per product on two IEEE fp16 pieces per operand, ~3 x 2^-24 per
+        product, fp32-grade: "f16x3_fwd" (the forward) / "f16x3_fwd_dgrad" (+ the data-gradient chain) / "f16x3_train" (+ the large
+        weight-gradient blocks).
         Parameters (re-homed into a fresh flat buffer, same Parameter objects), optimizer state and checkpoints are
         unaffected; call it before a TrainEngine is built on the model.  The two nets of a render may use different
         precisions (plans are per net)."""
@@ -194,8 +190,8 @@ class FlexibleNeRFModel(torch.nn.Module):
 
     def set_inference_precision(self, precision):
         """Arithmetic of this model's forward passes that no backward follows (torch.no_grad() / mode="validation"):
-        "fp32" (default), "f16x3" (NERFHIP_PRECISION_F16X3: fp16 pieces, fp32-grade products, > 2x the inference
-        throughput) or "bf16x3" (bf16 pieces: ~2^-16 per product).  Inference-only plans: the training precisions are
+        "fp32" (default) or "f16x3" (NERFHIP_PRECISION_F16X3: fp16 pieces, fp32-grade products, > 2x the inference
+        throughput).  Inference-only plans: the training precisions are
         set with set_training_precision.  Raises for geometries the split-precision kernels do not cover."""
         if precision not in INFERENCE_PRECISIONS:
             raise ValueError("inference precision must be one of %s (got %r)" % (INFERENCE_PRECISIONS, precision))

@@ -88,7 +88,7 @@ class _FusedRender(torch.autograd.Function):
         # `training` (decided by the caller: grad mode is off inside Function.forward, and needs_input_grad ignores
         # torch.no_grad()): keep the activation stash for a backward
         # (inference -- no backward follows -- runs on each model's inference plan: fp32 unless set_inference_precision
-        # chose the split-bf16 kernels)
+        # chose the fp16-piece kernels)
         plan_c = model_c._plan if training else model_c._inference_plan()
         plan_f = (model_f._plan if training else model_f._inference_plan()) if nf > 0 else None
         # (training layout 2: this node's backward runs the two nets one after the other on one stream, so they share one

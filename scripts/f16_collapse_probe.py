@@ -16,7 +16,7 @@ lr0 = float(sys.argv[4]) if len(sys.argv) > 4 else 1e-3
 dev = torch.device("cuda", 0)
 student = dict(num_layers=8, hidden_size=256, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4)
 poses, imgs, train, val = P4.teacher_dataset()
-PREC = {"engine": "fp32", "engine_f16fwd": "f16x3_fwd", "engine_f16fd": "f16x3_fwd_dgrad", "engine_f16tr": "f16x3_train", "engine_bf16tr": "bf16x3_train"}
+PREC = {"engine": "fp32", "engine_f16fwd": "f16x3_fwd", "engine_f16fd": "f16x3_fwd_dgrad", "engine_f16tr": "f16x3_train"}
 for arm in arms:
     torch.manual_seed(seed)
     mc, mf = N.FlexibleNeRFModel(**student).to(dev), N.FlexibleNeRFModel(**student).to(dev)

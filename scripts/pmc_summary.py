@@ -15,8 +15,8 @@ def load(pattern):
 
 
 def short(name):
-    for k in ("k_mlp_fwd16", "k_mlp_dgrad16", "k_mlp_fwd_f16x3", "k_mlp_dgrad_f16x3", "k_mlp_fwd_bf16x3", "k_mlp_dgrad_bf16x3", "k_mlp_fwd", "k_mlp_dgrad",
-              "k_wgrad_reduce", "k_wgrad_f16x3", "k_wgrad_bf16x3", "k_wgrad"):
+    for k in ("k_mlp_fwd16", "k_mlp_dgrad16", "k_mlp_fwd_f16x3", "k_mlp_dgrad_f16x3", "k_mlp_fwd", "k_mlp_dgrad",
+              "k_wgrad_reduce", "k_wgrad_f16x3", "k_wgrad"):
         if k in name:
             return k
     return None

@@ -9,12 +9,10 @@ MANY seeds, everything else identical per seed (initial weights, training views,
     dropin     this package behind the reference API + torch.optim.Adam; torch's draws (the numbers `ref` consumes)
     engine_td  TrainEngine (fused loss, k_adam) FED torch's draws -- differs from `dropin` only in Adam / loss kernels
     engine     TrainEngine with its in-kernel Philox draws -- differs from `engine_td` only in the random numbers
-    engine_bf16fwd  `engine` with NERFHIP_PRECISION_BF16X3_FWD nets: the forward passes on the split-bf16 kernel, the backward
-               kernels unchanged fp32 (same draws as `engine`: differs from it only in the forward's arithmetic)
-    engine_bf16fd   the same with NERFHIP_PRECISION_BF16X3_FWD_DGRAD nets: the data-gradient chain on the split-bf16 kernel too
-    engine_bf16tr   the same with NERFHIP_PRECISION_BF16X3_TRAIN nets: also the hidden x hidden weight-gradient blocks (256-wide nets)
-    engine_f16fd / engine_f16tr   (round 4) `engine` with NERFHIP_PRECISION_F16X3_FWD_DGRAD / _TRAIN nets: the same kernels on fp16
-               pieces (fp32-grade products)
+    engine_f16fd / engine_f16tr   (round 4) `engine` with NERFHIP_PRECISION_F16X3_FWD_DGRAD / _TRAIN nets: the forward + data-gradient
+               chain / every GEMM of the step on fp16 pieces (fp32-grade products; same draws as `engine`: differs from it only in the
+               arithmetic).  (Round 3's bf16-piece arms -- engine_bf16fwd / _bf16fd / _bf16tr, profiles/r03_psnr_*.txt -- went with
+               their kernels in round 5.)
 --lr: the initial learning rate of EVERY arm (default the reference recipe's 5e-3, config/lego.yml; at 8x256 half the seeds collapse
 under it in every arm -- a dead net renders a constant --, so the round-4 study of the metric's own geometry lowers it for all arms).
 
@@ -93,9 +91,8 @@ def run(arm, seed, iters, check, student, poses, imgs, train, views):
         ex, ed = N.get_embedding_function(10, True, True), N.get_embedding_function(4, True, True)
     else:
         mc, mf = mc.to(dev), mf.to(dev)
-        if arm in ("engine_bf16fwd", "engine_bf16fd", "engine_bf16tr", "engine_f16fd", "engine_f16tr"):  # the engine arm on a split precision
-            prec = {"engine_bf16fwd": "bf16x3_fwd", "engine_bf16fd": "bf16x3_fwd_dgrad", "engine_bf16tr": "bf16x3_train",
-                    "engine_f16fd": "f16x3_fwd_dgrad", "engine_f16tr": "f16x3_train"}[arm]
+        if arm in ("engine_f16fd", "engine_f16tr"):  # the engine arm on fp16 pieces
+            prec = {"engine_f16fd": "f16x3_fwd_dgrad", "engine_f16tr": "f16x3_train"}[arm]
             mc.set_training_precision(prec)
             mf.set_training_precision(prec)
         eng = N.TrainEngine(mc, mf, NC, NF, perturb=True, white_background=True, noise_std=0.2, lr=LR0, seed=seed)

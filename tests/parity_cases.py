@@ -18,6 +18,7 @@ import torch
 
 import nerf_oracle as O
 import nerf_pytorch_amd._lib as L
+import tolerances as TL
 from backends import ROOT, model_cfg
 from conftest import gold
 
@@ -326,29 +327,22 @@ def case_mlp_forward(b, names=None, m=70):
         x = torch.randn(m, dx + dd, generator=rng(32))
         want = O.mlp_forward(params, x, cfg).numpy()
         got, _ = b.mlp_fwd(plan, packed, x.numpy())
-        close(got, want, 2e-5, 2e-5, what="mlp fwd " + name)
+        close(got, want, *TL.bound("unit.mlp_fwd"), what="mlp fwd " + name)
         b.lib.plan_destroy(plan)
 
 
-BF16X3, BF16X3_FWD, BF16X3_FWD_DGRAD, BF16X3_TRAIN = 1, 2, 3, 4  # NERFHIP_PRECISION_*
-F16X3, F16X3_FWD, F16X3_FWD_DGRAD, F16X3_TRAIN = 5, 6, 7, 8    # the same plans on fp16 pieces: fp32-grade products
+F16X3, F16X3_FWD, F16X3_FWD_DGRAD, F16X3_TRAIN = 5, 6, 7, 8    # NERFHIP_PRECISION_*: the fp16-piece plans (fp32-grade products)
+ARITH_NAME = {0: "fp32", F16X3: "f16x3", F16X3_FWD: "f16x3_fwd", F16X3_FWD_DGRAD: "f16x3_fwd_dgrad", F16X3_TRAIN: "f16x3_train"}
+F16X3_GEOMETRIES = ("default4x128", "northstar8x256", "fern8x128_skip3_L6", "novw4x128", "two_layer_L4_L2", "one_layer",
+                    "one_layer_novw_256", "skip_every_layer_256", "noinput_linear", "odd5x99_skip2", "wide3x200_skip1",
+                    "novw2x130")
 
 
-def loose(precision):
-    """True for the bf16-piece plans (~2^-16 per product: their own, wider bounds).  The fp16-piece plans (~3 x 2^-24 per
-    product) are held to the bounds of the fp32 kernels, unchanged."""
-    return BF16X3 <= precision <= BF16X3_TRAIN
-BF16X3_GEOMETRIES = ("default4x128", "northstar8x256", "fern8x128_skip3_L6", "novw4x128", "two_layer_L4_L2", "one_layer",
-                     "one_layer_novw_256", "skip_every_layer_256", "noinput_linear", "odd5x99_skip2", "wide3x200_skip1",
-                     "novw2x130")
-
-
-def case_mlp_forward_bf16x3(b, names=None, m=70, precision=BF16X3):
-    """The split-bf16 inference forward (mlp_bf16.hip) against the oracle's fp32 forward.  Its products carry ~2^-16
-    relative error by construction (three of the four piece products, fp32 accumulation), so the bound is relative to the
-    output scale and ~50x the fp32 kernels'; what the case pins is the index algebra -- unit permutation, slot map, chunking,
-    bias rows, skip / head / direction layers -- where any slip is an O(1) error."""
-    for name in names or BF16X3_GEOMETRIES:
+def case_mlp_forward_f16x3(b, names=None, m=70, precision=F16X3):
+    """The fp16-piece inference forward (mlp_f16w.hip) against the oracle's fp32 forward AND its fp64 forward: the fp32 kernels' own
+    bound against the former, an fp32-sized distance from the latter (tests/tolerances.py); what the case pins besides is the index
+    algebra -- unit permutation, slot map, chunking, bias rows, skip / head / direction layers -- where any slip is an O(1) error."""
+    for name in names or F16X3_GEOMETRIES:
         cfg = MLP_GEOMETRIES[name]
         plan, params, flat, packed = mlp_setup(b, cfg, seed=31, precision=precision)
         dx, dd = O.model_dims(cfg)
@@ -358,13 +352,11 @@ def case_mlp_forward_bf16x3(b, names=None, m=70, precision=BF16X3):
         got, _ = b.mlp_fwd(plan, packed, x.numpy())
         scale = float(np.abs(want64).max())
         err = float(np.abs(got - want64).max()) / scale
-        fmt = "bf16x3" if loose(precision) else "f16x3"
-        note("mlp_fwd_%s_%s_%s" % (fmt, name, b.name), max_err_over_scale=err,
+        note("mlp_fwd_f16x3_%s_%s" % (name, b.name), max_err_over_scale=err,
              fp32_oracle_err_over_scale=float(np.abs(want - want64).max()) / scale)
-        # (fp16 pieces: the distance from the fp64 forward must be what an fp32 evaluation's is -- torch's own is 1-4e-7)
-        assert err < (5e-5 if loose(precision) else 1.5e-6), (name, err)
-        if not loose(precision):
-            close(got, want, 2e-5, 2e-5, what="mlp fwd f16x3 " + name)  # (the fp32 kernels' own bound: case_mlp_forward)
+        # (the distance from the fp64 forward must be what an fp32 evaluation's is -- torch's own is 1-4e-7)
+        assert err < TL.bound("unit.mlp_fwd.vs_fp64_over_scale", "f16x3"), (name, err)
+        close(got, want, *TL.bound("unit.mlp_fwd", "f16x3"), what="mlp fwd f16x3 " + name)  # (the fp32 kernels' own bound: case_mlp_forward)
         # a training forward (stash) and a backward are refused
         with pytest.raises(L.NerfHipError, match="inference-only"):
             b.mlp_fwd(plan, packed, x.numpy(), want_stash=True)
@@ -373,6 +365,10 @@ def case_mlp_forward_bf16x3(b, names=None, m=70, precision=BF16X3):
         b.make_plan(MLP_GEOMETRIES["llff4x64_skip3_L6"], precision)
     with pytest.raises(L.NerfHipError, match="plans need"):
         b.make_plan(MLP_GEOMETRIES["L12_4x128"], precision)
+    # (values 1 .. 4 named round 3's bf16-piece plans: removed, refused with a message)
+    for removed in (1, 2, 3, 4):
+        with pytest.raises(L.NerfHipError, match="removed in round 5"):
+            b.make_plan(MLP_GEOMETRIES["default4x128"], removed)
 
 
 def case_mlp_golden(b):
@@ -388,11 +384,11 @@ def case_mlp_golden(b):
 
 
 def case_mlp_backward(b, names=None, m=150, precision=0, g_scale=1.0, w_gain=1.0):
-    """precision = BF16X3_FWD: the training forward on the split-bf16 kernel (its stash: slots in ITS order, fp32 rows as it
-    computed them, ReLU masks in the data-gradient kernel's lane layout), the backward kernels unchanged.  The gradient is
-    then the fp32 gradient at activations carrying ~1e-5 relative error: bounds 20x the fp32 path's, rows whose ReLU
-    decisions are closer than 1e-4 (relative) to zero dropped (a third of them: hundreds of units per row)."""
-    margin, tol = (1e-6, 2e-5) if not loose(precision) else (1e-4, 4e-4)
+    """Teacher-forced MLP backward against the oracle's autograd, every parameter tensor.  precision: 0 (the fp32 kernels) or an
+    fp16-piece training plan (F16X3_FWD: the training forward on fp16 pieces -- its stash: slots in ITS order, fp32 rows as it
+    computed them, ReLU masks in the data-gradient kernel's lane layout --, _FWD_DGRAD, _TRAIN) under the SAME margin and bound."""
+    mb = TL.bound("unit.mlp_bwd", ARITH_NAME[precision])
+    margin, tol = mb["margin"], mb["tol"]
     for name in names or ("default4x128", "deep8x128_skip4", "fern8x128_skip3_L6", "novw4x128"):
         cfg = MLP_GEOMETRIES[name]
         plan, params, flat, packed = mlp_setup(b, cfg, seed=41, precision=precision, w_gain=w_gain)
@@ -405,7 +401,7 @@ def case_mlp_backward(b, names=None, m=150, precision=0, g_scale=1.0, w_gain=1.0
         # (seen on MI355X and on the emulator alike: sample 136 of seed 42 for the 3x512 net, pre-activation 3.7e-9)
         keep = O.mlp_relu_margin(params, x, cfg) > margin
         x, go = x[keep].contiguous(), go[keep].contiguous()
-        assert x.shape[0] >= (0.9 if not loose(precision) else 0.1) * m, (x.shape[0], m)   # (8x256: 2,300 units per row)
+        assert x.shape[0] >= 0.9 * m, (x.shape[0], m)   # (8x256: 2,300 units per row)
         p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
         (O.mlp_forward(p, x, cfg) * go).sum().backward()
         got_y, stash = b.mlp_fwd(plan, packed, x.numpy(), want_stash=True)
@@ -427,16 +423,12 @@ def case_mlp_input_grad(b, names=None, m=150, precision=0):
         gen = rng(44)
         x = torch.randn(m, dx + dd, generator=gen)
         go = torch.randn(m, 4, generator=gen)
-        if loose(precision):  # (split-bf16 kernels: rows whose ReLU decisions hang on less than their ~1e-5 are not comparable)
-            keep = O.mlp_relu_margin(params, x, cfg) > 1e-4
-            x, go = x[keep].contiguous(), go[keep].contiguous()
-            m = x.shape[0]
         x = x.requires_grad_(True)
         (O.mlp_forward(params, x, cfg) * go).sum().backward()
         ref = x.grad.numpy()
         _, stash = b.mlp_fwd(plan, packed, x.detach().numpy(), want_stash=True)
         _, gx = b.mlp_bwd(plan, packed, go.numpy(), stash, flat_for_input_grad=flat)
-        tol = 2e-5 if not loose(precision) else 4e-4
+        tol = TL.bound("unit.mlp_input_grad", ARITH_NAME[precision])
         close(gx, ref, tol * float(np.abs(ref).max()) + 1e-7, 10 * tol, what="mlp input grad " + name)
         b.lib.plan_destroy(plan)
 
@@ -525,7 +517,7 @@ def case_e2e_northstar_golden(b, precision=0):
 def case_render_vs_oracle(b, cfg, n, nc, nf, seed=5, white=False, noise=0.3, with_grads=False, tol=1e-4,
                           grad_tol=(1e-3, 5e-3), tag="", precision=0):
     """Fused render against the oracle on random-init nets of an arbitrary geometry (e.g. the 8x256 north star).
-    precision = BF16X3_FWD: both nets' forwards on the split-bf16 kernel (coarse maps then carry its ~1e-5, not fp32 round-off)."""
+    precision: the plans' arithmetic (0: fp32; an fp16-piece training plan: the same bounds)."""
     gen = rng(seed)
     pc, par_c, _, packed_c = mlp_setup(b, cfg, seed=seed + 1, precision=precision)
     pf, par_f, _, packed_f = mlp_setup(b, cfg, seed=seed + 2, precision=precision)
@@ -547,7 +539,7 @@ def case_render_vs_oracle(b, cfg, n, nc, nf, seed=5, white=False, noise=0.3, wit
     # weights (measured on MI355X, 8x256 random init, 256 rays: HIP-vs-CPU rgb_fine 1.5e-5 / acc_fine 2.9e-5, while
     # PyTorch-ROCm-vs-CPU is 2.7e-5 / 5.3e-5; profiles/r01_error_floor.txt) -- rgb keeps the 1e-4 north-star bar.
     for k in ("rgb_coarse", "acc_coarse", "depth_coarse"):
-        close(out[k], want[k].detach().numpy(), 1e-5 if not loose(precision) else 1e-4, what="render %s" % k)
+        close(out[k], want[k].detach().numpy(), 1e-5, what="render %s" % k)
     close(out["rgb_fine"], want["rgb_fine"].detach().numpy(), tol, what="render rgb_fine")
     close(out["acc_fine"], want["acc_fine"].detach().numpy(), 5 * tol, what="render acc_fine")
     close(out["depth_fine"], want["depth_fine"].detach().numpy(), 20 * tol, what="render depth_fine")
@@ -569,9 +561,9 @@ def case_render_vs_oracle(b, cfg, n, nc, nf, seed=5, white=False, noise=0.3, wit
     b.lib.plan_destroy(pf)
 
 
-def case_render_bf16x3(b, cfg, n, nc, nf, seed=5, white=False, noise=0.0, tag="", precision=BF16X3):
-    """Inference render (training = 0) with both nets on NERFHIP_PRECISION_BF16X3 plans against the oracle, beside the fp32
-    plans' result on the same inputs: what the split-bf16 products cost against the 1e-4 bar (recorded per output)."""
+def case_render_f16x3(b, cfg, n, nc, nf, seed=5, white=False, noise=0.0, tag="", precision=F16X3):
+    """Inference render (training = 0) with both nets on NERFHIP_PRECISION_F16X3 plans against the oracle, beside the fp32 plans'
+    result on the same inputs: the coarse pass at fp32 round-off, the fine pass inside the north-star bar like the fp32 kernels."""
     gen = rng(seed)
     ro = torch.tensor([0.2, -0.1, 4.0]).expand(n, 3) + 0.05 * torch.randn(n, 3, generator=gen)
     rd = torch.randn(n, 3, generator=gen) * 0.3
@@ -582,9 +574,7 @@ def case_render_bf16x3(b, cfg, n, nc, nf, seed=5, white=False, noise=0.0, tag=""
     opt = dict(num_coarse=nc, num_fine=nf, perturb=True, lindisp=False, white_background=white, noise_std=noise)
     rnp = {k: v.numpy() for k, v in rand.items()}
     outs = {}
-    BF = precision
-    fmt = "bf16x3" if loose(BF) else "f16x3"
-    for prec in (0, BF):
+    for prec in (0, precision):
         pc, par_c, _, packed_c = mlp_setup(b, cfg, seed=seed + 1, precision=prec)
         pf, par_f, _, packed_f = mlp_setup(b, cfg, seed=seed + 2, precision=prec)
         outs[prec] = b.render(pc, pf, packed_c, packed_f, rays.numpy(), opt, rnp, training=False)
@@ -597,21 +587,14 @@ def case_render_bf16x3(b, cfg, n, nc, nf, seed=5, white=False, noise=0.0, tag=""
     rec = {}
     for k in ("rgb_coarse", "acc_coarse", "rgb_fine", "acc_fine", "depth_fine"):
         w = want[k].detach().numpy()
-        for prec, nm in ((0, "fp32"), (BF, "bf16x3")):
+        for prec, nm in ((0, "fp32"), (precision, "f16x3")):
             e = np.abs(outs[prec][k] - w).reshape(n, -1).max(axis=1)
             rec["%s_%s_max" % (k, nm)] = float(e.max())
             rec["%s_%s_rays_over_1e-4" % (k, nm)] = int((e > 1e-4).sum())
-    note("render_%s_%s_%s" % (fmt, tag or n, b.name), rays=n, **rec)
-    if not loose(BF):  # fp16 pieces: the coarse pass at fp32 round-off, the fine pass inside the north-star bar like the fp32 kernels
-        assert rec["rgb_coarse_bf16x3_max"] <= 1e-5 and rec["acc_coarse_bf16x3_max"] <= 1e-5, rec
-        assert rec["rgb_fine_bf16x3_max"] <= max(1e-4, 2 * rec["rgb_fine_fp32_max"]), rec
-        assert rec["rgb_fine_bf16x3_rays_over_1e-4"] <= 2 * rec["rgb_fine_fp32_rays_over_1e-4"] + 1, rec
-        return
-    # coarse pass: only the products differ -- well inside the bar; fine pass: the sampler amplifies the coarse weights'
-    # differences for BOTH arithmetic variants, the split-bf16 one starts from ~30x larger ones
-    assert rec["rgb_coarse_bf16x3_max"] <= 1e-4 and rec["acc_coarse_bf16x3_max"] <= 1e-4, rec
-    assert rec["rgb_fine_bf16x3_max"] <= 2e-3, rec
-    assert rec["rgb_fine_bf16x3_rays_over_1e-4"] <= max(2, n // 20), rec
+    note("render_f16x3_%s_%s" % (tag or n, b.name), rays=n, **rec)
+    assert rec["rgb_coarse_f16x3_max"] <= 1e-5 and rec["acc_coarse_f16x3_max"] <= 1e-5, rec
+    assert rec["rgb_fine_f16x3_max"] <= max(1e-4, 2 * rec["rgb_fine_fp32_max"]), rec
+    assert rec["rgb_fine_f16x3_rays_over_1e-4"] <= 2 * rec["rgb_fine_fp32_rays_over_1e-4"] + 1, rec
 
 
 def case_ray_grad(b, cfg, n=24, nc=16, nf=16, seed=61, white=False, noise=0.0):

@@ -84,47 +84,12 @@ def test_mlp_512_wide_instances(emu):
     P.case_mlp_input_grad(emu, names=("wide3x512_skip2", "wide2x320"), m=45)
 
 
-def test_mlp_forward_bf16x3(emu):
-    """NERFHIP_PRECISION_BF16X3 plans: the split-bf16 inference forward, both kernel widths, every layer kind."""
-    P.case_mlp_forward_bf16x3(emu, m=37)
-    # more 128-sample groups than resident workgroups (the emulator reports 3 CUs): the persistent loop, ragged last group
-    P.case_mlp_forward_bf16x3(emu, names=("default4x128",), m=900)
-    P.case_mlp_forward_bf16x3(emu, names=("skip_every_layer_256",), m=600)
-    P.case_render_bf16x3(emu, P.MLP_GEOMETRIES["default4x128"], n=10, nc=8, nf=8, tag="4x128_emu")
-
-
-def test_mlp_bf16x3_forward_training_stash_feeds_the_fp32_backward(emu):
-    """NERFHIP_PRECISION_BF16X3_FWD: forward (with stash) on the split-bf16 kernel, backward on the fp32 kernels."""
-    P.case_mlp_backward(emu, names=("default4x128", "novw4x128", "skip_every_layer_256"), m=120, precision=P.BF16X3_FWD)  # (GPU: six)
-    P.case_render_vs_oracle(emu, P.MLP_GEOMETRIES["default4x128"], n=12, nc=16, nf=16, with_grads=True, tag="bf16x3_fwd_emu",
-                            tol=5e-4, grad_tol=(5e-3, 5e-2), precision=P.BF16X3_FWD)
-
-
-def test_mlp_bf16x3_forward_and_data_gradient(emu):
-    """NERFHIP_PRECISION_BF16X3_FWD_DGRAD: forward and data-gradient chain on the split-bf16 kernels, weight gradient fp32."""
-    P.case_mlp_backward(emu, names=("fern8x128_skip3_L6", "novw4x128", "skip_every_layer_256", "one_layer"), m=120,
-                        precision=P.BF16X3_FWD_DGRAD)  # (GPU: eight geometries)
-    P.case_mlp_input_grad(emu, names=("default4x128", "novw4x128"), m=45, precision=P.BF16X3_FWD_DGRAD)
-    P.case_render_vs_oracle(emu, P.MLP_GEOMETRIES["default4x128"], n=12, nc=16, nf=16, with_grads=True, tag="bf16x3_fd_emu",
-                            tol=5e-4, grad_tol=(5e-3, 5e-2), precision=P.BF16X3_FWD_DGRAD)
-
-
-def test_mlp_bf16x3_whole_training_step(emu):
-    """NERFHIP_PRECISION_BF16X3_TRAIN: forward, data gradient AND the large weight-gradient blocks on the bf16 MFMAs (the thin
-    blocks -- encoding columns, fc_alpha, fc_rgb / fc_out -- stay on the fp32 kernel)."""
-    P.case_mlp_backward(emu, names=("skip_every_layer_256", "one_layer_novw_256", "odd5x99_skip2"), m=120,
-                        precision=P.BF16X3_TRAIN)  # (the 128- and 256-wide ones reach k_wgrad_bf16x3; GPU: eight geometries)
-    P.case_render_vs_oracle(emu, P.MLP_GEOMETRIES["default4x128"], n=12, nc=16, nf=16, with_grads=True, tag="bf16x3_train_emu",
-                            tol=5e-4, grad_tol=(5e-3, 5e-2), precision=P.BF16X3_TRAIN)
-
-
-# ---- the same plans on IEEE fp16 pieces (NERFHIP_PRECISION_F16X3*): held to the fp32 kernels' own bounds -----------------------
 def test_mlp_forward_f16x3(emu):
     """The inference forward on fp16 pieces: ~3 x 2^-24 per product -- the fp32 kernels' 2e-5 bound and an fp32-sized distance
     from the fp64 forward, every layer kind, both widths, the persistent loop."""
-    P.case_mlp_forward_bf16x3(emu, m=37, precision=P.F16X3)
-    P.case_mlp_forward_bf16x3(emu, names=("default4x128",), m=900, precision=P.F16X3)
-    P.case_render_bf16x3(emu, P.MLP_GEOMETRIES["default4x128"], n=10, nc=8, nf=8, tag="4x128_emu", precision=P.F16X3)
+    P.case_mlp_forward_f16x3(emu, m=37, precision=P.F16X3)
+    P.case_mlp_forward_f16x3(emu, names=("default4x128",), m=900, precision=P.F16X3)
+    P.case_render_f16x3(emu, P.MLP_GEOMETRIES["default4x128"], n=10, nc=8, nf=8, tag="4x128_emu", precision=P.F16X3)
 
 
 def test_mlp_f16x3_training_levels_hold_the_fp32_gradient_bounds(emu):

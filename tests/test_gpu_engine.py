@@ -88,13 +88,13 @@ def test_two_stream_step_equals_single_stream_step():
     assert float(out[0][2][-1, 2]) < float(out[0][2][0, 2])
 
 
-@pytest.mark.parametrize("precision", ["bf16x3_fwd", "bf16x3_fwd_dgrad", "bf16x3_train", "f16x3_fwd", "f16x3_fwd_dgrad", "f16x3_train"])
-def test_engine_on_split_bf16_training_precisions_tracks_the_fp32_engine(precision):
-    """set_training_precision (NERFHIP_PRECISION_BF16X3_FWD / _FWD_DGRAD; opt-in): the same engine, the same
-    in-kernel draws, the forward (and the data-gradient chain) on the split-bf16 kernels.  One forward/backward: the loss
-    agrees to 1e-4 relative and the flat gradient points the same way (cosine > 0.999, norm within 1 %) -- ReLU decisions that
-    hang on less than the forward's 1e-5 flip, so no element-wise bound is asserted here (tests/parity_cases.py does that on
-    filtered rows); several optimizer steps: the loss falls as the fp32 engine's does.  A state_dict round trip is unaffected."""
+@pytest.mark.parametrize("precision", ["f16x3_fwd", "f16x3_fwd_dgrad", "f16x3_train"])
+def test_engine_on_fp16_piece_training_precisions_tracks_the_fp32_engine(precision):
+    """set_training_precision (NERFHIP_PRECISION_F16X3_FWD / _FWD_DGRAD / _TRAIN; opt-in): the same engine, the same
+    in-kernel draws, the forward (the data-gradient chain, the large weight-gradient blocks) on fp16 pieces.  One forward/backward:
+    the loss agrees to 1e-4 relative and the flat gradient points the same way (cosine > 0.999, norm within 1 %) -- the element-wise
+    bounds are tests/parity_cases.py's, on filtered rows; several optimizer steps: the loss falls as the fp32 engine's does.  A
+    state_dict round trip is unaffected; round 3's bf16-piece names are refused."""
     import nerf_pytorch_amd as N
     dev = _dev()
     res = {}
@@ -117,8 +117,9 @@ def test_engine_on_split_bf16_training_precisions_tracks_the_fp32_engine(precisi
     cos = float(torch.dot(ga, gb) / (ga.norm() * gb.norm()))
     assert cos > 0.999 and abs(float(gb.norm() / ga.norm()) - 1.0) < 0.01, (cos, float(ga.norm()), float(gb.norm()))
     assert float(sb[-1, 2]) < float(sb[0, 2]) and abs(float(sb[-1, 2]) - float(sa[-1, 2])) < 0.02 * float(sa[0, 2]), (sa[:, 2], sb[:, 2])
-    with pytest.raises(ValueError):
-        mc.set_training_precision("bf16")
+    for gone in ("bf16", "bf16x3_train"):
+        with pytest.raises(ValueError):
+            mc.set_training_precision(gone)
 
 
 def test_engine_fed_external_draws_equals_in_kernel_draws(gpu):

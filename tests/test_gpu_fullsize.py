@@ -22,6 +22,7 @@ import torch
 
 import nerf_oracle as O
 import parity_cases as P
+import tolerances as T
 
 pytestmark = pytest.mark.gpu
 
@@ -159,10 +160,9 @@ class _Case:
 
 
 # The arithmetic of the two nets' plans (include/nerfhip.h NERFHIP_PRECISION_*).  Every full-batch test runs with the SAME
-# assertions for each entry: "fp32" (the reference's arithmetic), "f16x3_train" (every GEMM of the step on fp16 pieces), and --
-# end-to-end lego only -- "fp32+bf16x3" (coarse net fp32, so that the sampler sees fp32 weights, fine net
-# on the bf16-piece forward + data-gradient kernels).
-ARITH = {"fp32": (0, 0), "f16x3_train": (P.F16X3_TRAIN, P.F16X3_TRAIN), "fp32+bf16x3": (0, P.BF16X3_FWD_DGRAD)}
+# assertions and the SAME bounds (tests/tolerances.py: no per-arithmetic entry) for each entry: "fp32" (the reference's
+# arithmetic) and "f16x3_train" (every GEMM of the step on fp16 pieces).
+ARITH = {"fp32": (0, 0), "f16x3_train": (P.F16X3_TRAIN, P.F16X3_TRAIN)}
 INFER = {"fp32": 0, "f16x3": P.F16X3}
 
 
@@ -238,27 +238,30 @@ def lego_padded_nets(gpu):
 
 def _coarse_grads_fp64(c):
     """The coarse net's parameter gradients of the same batch from an fp64 run of the oracle (the coarse pass has no sampler in
-    front of it; the fine loss does not reach the coarse net: nerf/train_utils.py:103 detaches).  The yardstick for
-    arithmetics whose rounding is not the oracle's: two fp32 evaluations that multiply the same fp32 operands (the fp32
-    kernels and torch) share most of their rounding, so their DISTANCE understates what either is away from the exact
-    gradient -- measured on the fern batch: 3.5e-6 of max|g| apart, 2e-5 from fp64 both."""
-    par = {k: v.detach().double().requires_grad_(True) for k, v in c.par_c.items()}
-    opt = dict(c.opt, num_fine=0)
-    out = O.render_rays(c.rays.double(), par, None, c.cfg, c.cfg, opt, {k: v.double() for k, v in c.rand.items()}, chunksize=131072)
-    torch.nn.functional.mse_loss(out["rgb_coarse"], c.tgt.double()).backward()
-    return {k: v.grad.numpy() for k, v in par.items()}
+    front of it; the fine loss does not reach the coarse net: nerf/train_utils.py:103 detaches).  Two fp32 evaluations that
+    multiply the same fp32 operands (the fp32 kernels and torch) share most of their rounding, so their DISTANCE understates what
+    either is away from the exact gradient -- measured on the fern batch: 3.5e-6 of max|g| apart, 2e-5 from fp64 both."""
+    if getattr(c, "_g64c", None) is None:
+        par = {k: v.detach().double().requires_grad_(True) for k, v in c.par_c.items()}
+        opt = dict(c.opt, num_fine=0)
+        out = O.render_rays(c.rays.double(), par, None, c.cfg, c.cfg, opt, {k: v.double() for k, v in c.rand.items()}, chunksize=131072)
+        torch.nn.functional.mse_loss(out["rgb_coarse"], c.tgt.double()).backward()
+        c._g64c = {k: v.grad.numpy() for k, v in par.items()}
+    return c._g64c
 
 
-def _end_to_end(c, coarse_grad_tol, fine_grad_tol, rgb_fine_tol=(1e-4, 1e-4), arith="fp32"):
+def _end_to_end(c, coarse_grad, fine_grad, rgb_fine="e2e.rgb_fine", arith="fp32"):
+    """coarse_grad / fine_grad / rgb_fine: names of tests/tolerances.py entries (the same for every arithmetic)."""
     pl = _Plans(c, arith)
     try:
-        return _end_to_end_on(c, pl, coarse_grad_tol, fine_grad_tol, rgb_fine_tol)
+        return _end_to_end_on(c, pl, coarse_grad, fine_grad, rgb_fine)
     finally:
         pl.close()
 
 
-def _end_to_end_on(c, pl, coarse_grad_tol, fine_grad_tol, rgb_fine_tol):
+def _end_to_end_on(c, pl, coarse_grad, fine_grad, rgb_fine):
     gpu = c.gpu
+    B = lambda name: T.bound(name, pl.arith)  # noqa: E731
     out = gpu.render(pl.plan_c, pl.plan_f, pl.packed_c, pl.packed_f, c.rays.numpy(), c.opt, c.rnp, training=True,
                      want_regions=("z_fine",))
     l3, gc, gf = gpu.mse_loss(out["rgb_coarse"], out["rgb_fine"], c.tgt.numpy())
@@ -286,54 +289,55 @@ def _end_to_end_on(c, pl, coarse_grad_tol, fine_grad_tol, rgb_fine_tol):
     rec["grad_fine_worst_rel"] = gfw
     rec["grad_fine_per_tensor"] = gfp
     rec["arithmetic"] = pl.arith
+    if coarse_grad == "e2e.grad_coarse.fp64_yardstick":
+        # no further from the fp64 gradient than torch's own fp32 gradient is (x 1.5) -- for EVERY arithmetic
+        g64 = _coarse_grads_fp64(c)
+        hip64 = _grad_stats(gpu.unflatten(pl.plan_c, out2["g_params_coarse"]), g64)[0]
+        ref64 = _grad_stats(c.ref_gc, g64)[0]
+        rec["grad_coarse_vs_fp64"] = dict(hip=hip64, torch_fp32=ref64, vs_oracle_fp32=gcw)
     _record(c.name + pl.tag, rec)
     # coarse pass: fp32 round-off only
     for k in ("rgb_coarse", "acc_coarse", "depth_coarse"):
-        assert rec["outputs"][k]["max"] <= 1e-5, (k, rec["outputs"][k])
+        assert rec["outputs"][k]["max"] <= B("e2e.coarse_maps.max"), (k, rec["outputs"][k])
     # the north-star bar on colour; acc / depth of the fine pass carry the sampler's conditioning
-    assert rec["outputs"]["rgb_fine"]["max"] <= rgb_fine_tol[0] and rec["outputs"]["rgb_fine"]["p999"] <= rgb_fine_tol[1], \
-        rec["outputs"]["rgb_fine"]
-    assert rec["outputs"]["acc_fine"]["max"] <= 5e-4 and rec["outputs"]["depth_fine"]["max"] <= 2e-3, rec["outputs"]
+    rf = B(rgb_fine)
+    assert rec["outputs"]["rgb_fine"]["max"] <= rf[0] and rec["outputs"]["rgb_fine"]["p999"] <= rf[1], rec["outputs"]["rgb_fine"]
+    assert rec["outputs"]["acc_fine"]["max"] <= B("e2e.acc_fine.max") and rec["outputs"]["depth_fine"]["max"] <= B("e2e.depth_fine.max"), rec["outputs"]
     # ... and must sit inside the reference's own cross-device spread (torch on this GPU vs torch on the CPU): no more
     # rays beyond the 1e-4 bar than that pair has (x2 + 3: both counts are a handful of chaotic events), bulk no wider
     for k in fine_keys:
         h, y = rec["outputs"][k], rec["torch_cuda_vs_cpu"][k]
-        assert h["rays_over_1e4"] <= 2 * y["rays_over_1e4"] + 3, (k, h, y)
-        assert h["p999"] <= 2.0 * y["p999"] + 2e-6, (k, h, y)
+        assert T.within(h["rays_over_1e4"], y["rays_over_1e4"], B("e2e.yardstick.rays_over_1e4")), (k, h, y)
+        assert T.within(h["p999"], y["p999"], B("e2e.yardstick.p999")), (k, h, y)
     zm = rec["z_fine_vs_oracle"]
-    assert zm["hip"]["rays_moved"] <= 2 * zm["torch_cuda"]["rays_moved"] + 3, zm
-    assert abs(float(l3[2]) - float(c.loss)) < 1e-5
-    if pl.arith == "fp32" or (gcw["max"] <= coarse_grad_tol[0] and gcw["p999"] <= coarse_grad_tol[1]):
-        assert gcw["max"] <= coarse_grad_tol[0] and gcw["p999"] <= coarse_grad_tol[1], gcw
+    assert T.within(zm["hip"]["rays_moved"], zm["torch_cuda"]["rays_moved"], B("e2e.yardstick.rays_moved")), zm
+    assert abs(float(l3[2]) - float(c.loss.detach())) < B("e2e.loss")
+    if coarse_grad == "e2e.grad_coarse.fp64_yardstick":
+        form = B(coarse_grad)
+        y64 = rec["grad_coarse_vs_fp64"]
+        assert T.within(y64["hip"]["max"], y64["torch_fp32"]["max"], form) and T.within(y64["hip"]["p999"], y64["torch_fp32"]["p999"], form), y64
+        assert gcw["max"] <= form["cap"], gcw
     else:
-        # The bound is 5x the distance MEASURED between the fp32 kernels and torch, two evaluations that multiply the same
-        # fp32 operands and differ only in summation order.  An arithmetic with its own rounding (fp16 pieces: ~3 x 2^-24 per
-        # product) cannot be that close to torch without being closer to the exact gradient than torch is: hold it to the
-        # fp64 yardstick instead -- no further from the fp64 gradient than torch's fp32 gradient is (x 1.5), and record both.
-        g64 = _coarse_grads_fp64(c)
-        hip64 = _grad_stats(gpu.unflatten(pl.plan_c, out2["g_params_coarse"]), g64)[0]
-        ref64 = _grad_stats(c.ref_gc, g64)[0]
-        rec["grad_coarse_vs_fp64"] = dict(hip=hip64, torch_fp32=ref64, vs_oracle_fp32=gcw, bound_vs_oracle=list(coarse_grad_tol))
-        _record(c.name + pl.tag, rec)
-        assert hip64["max"] <= 1.5 * ref64["max"] + 1e-6 and hip64["p999"] <= 1.5 * ref64["p999"] + 1e-6, rec["grad_coarse_vs_fp64"]
-        assert gcw["max"] <= 1e-4, gcw  # (and in any case inside the bound of the lego batches)
-    assert gfw["max"] <= fine_grad_tol[0] and gfw["p999"] <= fine_grad_tol[1], gfw
+        ct = B(coarse_grad)
+        assert gcw["max"] <= ct[0] and gcw["p999"] <= ct[1], gcw
+    ft = B(fine_grad)
+    assert gfw["max"] <= ft[0] and gfw["p999"] <= ft[1], gfw
     return rec
 
 
-@pytest.mark.parametrize("arith", ["fp32", "f16x3_train", "fp32+bf16x3"])
+@pytest.mark.parametrize("arith", ["fp32", "f16x3_train"])
 def test_lego_full_batch_every_ray_vs_oracle(lego, arith):
     """BASELINE configs[1]: outputs of all rays and all 2 x 595,844 gradient entries against the oracle.
     Measured on MI355X (profiles/r02_parity_fullsize.json): rgb_fine max 7.9e-5 / p99.9 4.7e-5; coarse-net gradients
     max 1.4e-4 / p99.9 3.6e-5 of max|g| (two fp32 sums of 262,144 terms in different orders); fine-net gradients max
     6.5e-4 / p99.9 3.6e-4 (behind the sampler)."""
-    _end_to_end(lego, coarse_grad_tol=(2e-4, 5e-5), fine_grad_tol=(3e-3, 1e-3), arith=arith)
+    _end_to_end(lego, "e2e.grad_coarse.lego8x256", "e2e.grad_fine.lego8x256", arith=arith)
 
 
 @pytest.mark.parametrize("arith", ["fp32", "f16x3_train"])
 def test_lego_default_4x128_nets_full_batch_vs_oracle(lego_default_nets, arith):
     """Measured (profiles/r02_parity_fullsize.json): coarse-net gradients 2.0e-5 / 1.0e-5, fine-net 2.6e-4 / 1.9e-4."""
-    _end_to_end(lego_default_nets, coarse_grad_tol=(1e-4, 5e-5), fine_grad_tol=(1.3e-3, 9e-4), arith=arith)
+    _end_to_end(lego_default_nets, "e2e.grad_coarse.default4x128", "e2e.grad_fine.default4x128", arith=arith)
 
 
 def test_lego_padded_hidden_size_batch_vs_oracle(lego_padded_nets):
@@ -341,7 +345,7 @@ def test_lego_padded_hidden_size_batch_vs_oracle(lego_padded_nets):
     behind the sampler ONE ray of 2048 exceeds the 1e-4 colour bar of the BASELINE configurations (measured max 1.6e-4,
     p99.9 7.6e-5 -- a fine sample that lands in a neighbouring bin), so this case asserts p99.9 <= 1e-4 and max <= 3e-4;
     the teacher-forced fine pass below pins the kernels themselves."""
-    _end_to_end(lego_padded_nets, coarse_grad_tol=(1.7e-4, 5e-5), fine_grad_tol=(3e-3, 2e-3), rgb_fine_tol=(3e-4, 1e-4))
+    _end_to_end(lego_padded_nets, "e2e.grad_coarse.padded5x99", "e2e.grad_fine.padded5x99", rgb_fine="e2e.rgb_fine.padded5x99")
 
 
 def test_lego_padded_hidden_size_teacher_forced_fine_pass(lego_padded_nets):
@@ -351,33 +355,44 @@ def test_lego_padded_hidden_size_teacher_forced_fine_pass(lego_padded_nets):
 @pytest.mark.parametrize("arith", ["fp32", "f16x3_train"])
 def test_fern_full_batch_every_ray_vs_oracle(fern, arith):
     """BASELINE configs[3] (NDC, Dx = 39, 64 + 64, noise 1.0): with sigma noise of std 1.0 the per-sample cotangents of
-    the early layers nearly cancel (case_render_vs_oracle).  Measured (profiles/r02_parity_fullsize.json): coarse-net
-    gradients max 3.5e-6 / p99.9 3.4e-6 of max|g|, fine-net 3.2e-5 / 1.8e-5: the bounds are 5x those."""
-    _end_to_end(fern, coarse_grad_tol=(1.75e-5, 1.75e-5), fine_grad_tol=(1.6e-4, 9e-5), arith=arith)
+    the early layers nearly cancel (case_render_vs_oracle), and two fp32 evaluations that share their rounding sit 3.5e-6 of max|g|
+    apart while both are 2e-5 from the fp64 gradient: the coarse-net gradients are held to the fp64 yardstick (tolerances.py)."""
+    _end_to_end(fern, "e2e.grad_coarse.fp64_yardstick", "e2e.grad_fine.fern8x128", arith=arith)
 
 
 def test_fern_declared_4x64_full_batch_every_ray_vs_oracle(fern_declared):
     """The same full-batch comparison on the geometry config/fern.yml declares.  Bounds: 5x the values
     measured on MI355X (profiles/r04_parity_fullsize.json: coarse-net gradients 3.3e-6 / 3.3e-6 of max|g|, fine-net 5.1e-5 / 4.0e-5;
     rgb_fine max 7.0e-5, 0 rays beyond 1e-4)."""
-    _end_to_end(fern_declared, coarse_grad_tol=(1.7e-5, 1.7e-5), fine_grad_tol=(2.5e-4, 2.0e-4))
+    _end_to_end(fern_declared, "e2e.grad_coarse.fern4x64", "e2e.grad_fine.fern4x64")
 
 
 def test_fern_declared_4x64_teacher_forced_fine_pass(fern_declared):
     _teacher_forced(fern_declared)
 
 
-def _fine_pass_units(c, sel, z, tgt, pl=None):
-    """The fine pass of rays `sel` with given depths through the unit entry points of the C ABI: MLP forward on
-    host-encoded points (writes the stash) -> compositing -> compositing backward -> MLP backward."""
-    gpu, cfg = c.gpu, c.cfg
+def _fine_inputs(c, sel, z):
+    """The fine pass's encoded sample points of rays `sel` at depths z: what run_network (nerf/train_utils.py:8-25) feeds the net."""
+    cfg = c.cfg
     rays = c.rays[sel]
     n, s = z.shape
     ro, rd = rays[..., :3], rays[..., 3:6]
     pts = (ro[..., None, :] + rd[..., None, :] * z[..., :, None]).reshape(-1, 3)
     emb = O.positional_encoding(pts, cfg["num_encoding_fn_xyz"], True, True)
     dirs = rays[..., None, -3:].expand(n, s, 3).reshape(-1, 3)
-    x = torch.cat((emb, O.positional_encoding(dirs, cfg["num_encoding_fn_dir"], True, True)), dim=-1).numpy()
+    return torch.cat((emb, O.positional_encoding(dirs, cfg["num_encoding_fn_dir"], True, True)), dim=-1)
+
+
+def _fine_pass_units(c, sel, z, tgt, pl=None, keep=None):
+    """The fine pass of rays `sel` with given depths through the unit entry points of the C ABI: MLP forward on
+    host-encoded points (writes the stash) -> compositing -> compositing backward -> MLP backward.
+    keep (bool per sample point, or None): the cotangents d(loss)/d(raw) of the other samples are zeroed before the MLP backward --
+    the ReLU-margin filter of tests/tolerances.py; returns additionally the gradients of that filtered pass (None without keep)."""
+    gpu = c.gpu
+    rays = c.rays[sel]
+    n, s = z.shape
+    rd = rays[..., 3:6]
+    x = _fine_inputs(c, sel, z).numpy()
     plan_f, packed_f = (pl.plan_f, pl.packed_f) if pl is not None else (c.plan_f, c.packed_f)
     raw, stash = gpu.mlp_fwd(plan_f, packed_f, x, want_stash=True)
     noise = c.rnp["noise_fine"][sel]
@@ -386,18 +401,44 @@ def _fine_pass_units(c, sel, z, tgt, pl=None):
     g_raw = gpu.volume_render_bwd(raw.reshape(n, s, 4), z.numpy(), rd.numpy(), g_rgb=g_rgb, noise_std=c.opt["noise_std"],
                                   noise=noise)
     gflat = gpu.mlp_bwd(plan_f, packed_f, g_raw.reshape(-1, 4), stash)
-    return raw, rgb, acc, gpu.unflatten(plan_f, gflat), dep, disp
+    kept = None
+    if keep is not None:
+        gk = np.ascontiguousarray(g_raw.reshape(-1, 4) * np.asarray(keep, np.float32)[:, None])
+        kept = gpu.unflatten(plan_f, gpu.mlp_bwd(plan_f, packed_f, gk, stash))
+    return raw, rgb, acc, gpu.unflatten(plan_f, gflat), dep, disp, kept
 
 
-def _oracle_fine_grads(c, sel, z, tgt, dtype):
-    """The same pass on the oracle in `dtype` (fp64 = the yardstick both fp32 implementations are measured against)."""
+def _relu_filter(c):
+    """Per sample point of the case's teacher-forced fine pass: True iff no ReLU input of the fine net is within
+    tolerances.py's `relu_margin` (relative) of zero -- computed once per case on the oracle (fp32, CPU).  A sample outside the
+    filter has a unit whose branch fp32 round-off decides; two fp32-grade evaluations may take different branches there, and
+    that unit's whole row of the layer's weight gradient then moves by the sample's contribution (measured in round 4: row 54 of
+    layers_xyz.1 by 4.0e-5, row 95 of layers_xyz.0 by 1.12e-4 of max|g|).  Such samples are compared on everything BUT gradients."""
+    if getattr(c, "_keep", None) is None:
+        z = c.want["z_fine"].detach()
+        x = _fine_inputs(c, slice(0, c.n), z)
+        par = {k: v.detach() for k, v in c.par_f.items()}
+        with torch.no_grad():
+            m = torch.cat([O.mlp_relu_margin(par, x[i:i + 131072], c.cfg) for i in range(0, x.shape[0], 131072)])
+        c._keep = (m > T.bound("relu_margin")).numpy()
+    return c._keep
+
+
+def _oracle_fine_grads(c, sel, z, tgt, dtype, keep=None):
+    """The same pass on the oracle in `dtype` (fp64 = the yardstick both fp32 implementations are measured against); keep: as in
+    _fine_pass_units (the cotangents of the run's own compositing backward, the filtered samples' rows zeroed)."""
     par = {k: v.detach().to(dtype).requires_grad_(True) for k, v in c.par_f.items()}
     rays = c.rays[sel].to(dtype)
     ro, rd = rays[..., :3], rays[..., 3:6]
     pts = ro[..., None, :] + rd[..., None, :] * z.to(dtype)[..., :, None]
     raw = O.run_network(par, pts, rays, c.cfg)
     rgb = O.volume_render(raw, z.to(dtype), rd, c.opt["noise_std"], c.rand["noise_fine"][sel].to(dtype))[0]
-    torch.nn.functional.mse_loss(rgb, tgt.to(dtype)).backward()
+    loss = torch.nn.functional.mse_loss(rgb, tgt.to(dtype))
+    if keep is None:
+        loss.backward()
+    else:
+        g_raw, = torch.autograd.grad(loss, raw, retain_graph=True)
+        raw.backward(g_raw * torch.from_numpy(np.asarray(keep)).to(dtype).reshape(raw.shape[:-1] + (1,)))
     return {k: v.grad.numpy() for k, v in par.items()}
 
 
@@ -410,81 +451,61 @@ def _teacher_forced(c, arith="fp32"):
 
 
 def _teacher_forced_on(c, pl):
-    """The fine pass with the ORACLE's depths (no sampler between the two sides).  Full batch against the oracle's fp32
-    gradients, then a 256-ray slice against an fp64 run of the oracle: the kernels must sit at the fp32 floor, i.e. no
-    further from fp64 than torch's own fp32 path is.  (What remains between two fp32 implementations is not only the
-    order of the 786,432-term sums: a pre-activation within an ulp of zero takes the other branch of a ReLU, and with
-    ~1e9 pre-activations per batch a handful do.  On the small slice one such sample is visible -- measured: both fp32
-    paths are 2.6e-3 of max|g| away from fp64 in the SAME entry -- hence quantiles, not maxima, on the slice.)"""
+    """The fine pass with the ORACLE's depths (no sampler between the two sides).  Outputs of every sample; parameter gradients
+    (i) of the whole batch against the oracle's -- p99.9 only: a pre-activation within round-off of zero takes the other branch
+    of a ReLU in one of the two evaluations, and with ~1e9 pre-activations per batch a handful do --, (ii) of the samples that
+    pass the ReLU-margin filter (_relu_filter) -- max and p99.9, the bound of round 3, the same for every arithmetic --,
+    (iii) of 256 filtered rays against an fp64 run of the oracle: no further from fp64 than torch's own fp32 run is."""
     n = c.n
+    B = lambda name: T.bound(name, pl.arith)  # noqa: E731
     z = c.want["z_fine"].detach()
-    raw, rgb, acc, grads, dep, disp = _fine_pass_units(c, slice(0, n), z, c.tgt, pl)
+    keep = _relu_filter(c)
+    s = c.nc + c.nf
+    raw, rgb, acc, grads, dep, disp, gkept = _fine_pass_units(c, slice(0, n), z, c.tgt, pl, keep=keep)
+    if getattr(c, "_ref_kept", None) is None:  # (the oracle's filtered gradients: once per case)
+        c._ref_kept = _oracle_fine_grads(c, slice(0, n), z, c.tgt, torch.float32, keep=keep)
     far = float(c.rays[:, 7].max())
     wd = c.want["disp_fine"].detach().numpy()
     assert np.array_equal(np.isnan(disp), np.isnan(wd)), "disparity NaN masks differ (volume_rendering_utils.py:48)"
     drel = np.abs(np.nan_to_num(disp) - np.nan_to_num(wd)) / (1e-30 + np.abs(np.nan_to_num(wd)))
-    rec = dict(rays=n, samples_per_ray=c.nc + c.nf, raw=_stats(raw, c.want["raw_fine"].detach().numpy().reshape(-1, 4)),
+    rec = dict(rays=n, samples_per_ray=s, raw=_stats(raw, c.want["raw_fine"].detach().numpy().reshape(-1, 4)),
                rgb_fine=_stats(rgb, c.want["rgb_fine"].detach().numpy()),
                acc_fine=_stats(acc, c.want["acc_fine"].detach().numpy()),
                depth_fine=_stats(dep, c.want["depth_fine"].detach().numpy()), far=far,
-               disp_fine_rel=dict(max=float(drel.max()), p999=float(np.quantile(drel, 0.999))))
+               disp_fine_rel=dict(max=float(drel.max()), p999=float(np.quantile(drel, 0.999))),
+               relu_filter=dict(margin=T.bound("relu_margin"), samples=int(keep.size), dropped=int((~keep).sum()),
+                                kept_fraction=float(keep.mean())))
     worst, per = _grad_stats(grads, c.ref_gf)
-    rec["grad_fine_worst_rel"] = worst
-    rec["grad_fine_per_tensor"] = per
+    rec["grad_fine_worst_rel"] = worst             # (unfiltered: on record, p99.9 asserted)
+    kworst, kper = _grad_stats(gkept, c._ref_kept)
+    rec["grad_fine_filtered_worst_rel"] = kworst
+    rec["grad_fine_filtered_per_tensor"] = kper
     m = 256
     rec["slice_rays"] = m
     sel = slice(0, m)
-    g_hip = _fine_pass_units(c, sel, z[sel], c.tgt[sel], pl)[3]
-    g32 = _oracle_fine_grads(c, sel, z[sel], c.tgt[sel], torch.float32)
-    g64 = _oracle_fine_grads(c, sel, z[sel], c.tgt[sel], torch.float64)
+    ks = keep[:m * s]
+    g_hip = _fine_pass_units(c, sel, z[sel], c.tgt[sel], pl, keep=ks)[6]
+    if getattr(c, "_slice64", None) is None:
+        c._slice64 = (_oracle_fine_grads(c, sel, z[sel], c.tgt[sel], torch.float32, keep=ks),
+                      _oracle_fine_grads(c, sel, z[sel], c.tgt[sel], torch.float64, keep=ks))
+    g32, g64 = c._slice64
     rec["slice_hip_vs_fp64"] = _grad_stats(g_hip, g64)[0]
     rec["slice_torch_fp32_vs_fp64"] = _grad_stats(g32, g64)[0]
     rec["slice_hip_vs_torch_fp32"] = _grad_stats(g_hip, g32)[0]
-    if pl.arith != "fp32":
-        # An arithmetic with its own rounding is held to the yardstick the fp32 implementations (these kernels, torch) set on
-        # the same slices, over THREE slices: on 256 rays one ReLU branch that round-off decides the other way is visible in a
-        # p99.9, and every implementation has such slices of its own (measured on the fern batch, p99.9: fp16 pieces 8.2e-5 /
-        # 6.0e-5 / 3.7e-7, fp32 kernels 8.2e-5 / 5.3e-7 / 8.9e-6, torch 8.3e-5 / 3.5e-6 / 1.6e-6 -- each flips somewhere, none
-        # twice in the same place; on the 8x256 lego batch every slice carries flips).  Asserted, all values on record:
-        # (i) on EVERY slice the median over all gradient entries -- what the arithmetic itself does, blind to a flipped
-        # branch -- within 1.5x of the fp32 implementations'; (ii) the worst slice -- how large a flip gets -- within 1.5x of theirs.
-        slices = []
-        for s0 in (0, m, 2 * m):
-            sl = slice(s0, s0 + m)
-            g64s = g64 if s0 == 0 else _oracle_fine_grads(c, sl, z[sl], c.tgt[sl], torch.float64)
-            g32s = g32 if s0 == 0 else _oracle_fine_grads(c, sl, z[sl], c.tgt[sl], torch.float32)
-            ga = g_hip if s0 == 0 else _fine_pass_units(c, sl, z[sl], c.tgt[sl], pl)[3]
-            gk = _fine_pass_units(c, sl, z[sl], c.tgt[sl], None)[3]   # (the fp32 kernels)
-            slices.append(dict(first_ray=s0, arith_vs_fp64=_grad_stats(ga, g64s)[0], fp32_kernels_vs_fp64=_grad_stats(gk, g64s)[0],
-                               torch_fp32_vs_fp64=_grad_stats(g32s, g64s)[0]))
-        rec["slices"] = slices
-        pick = lambda fn, key, q: float(fn([sl_[key][q] for sl_ in slices]))  # noqa: E731
-        rec["slices_best"] = {k: dict(p999=pick(min, k, "p999"), max=pick(min, k, "max")) for k in ("arith_vs_fp64", "fp32_kernels_vs_fp64", "torch_fp32_vs_fp64")}
-        rec["slices_worst"] = {k: dict(p999=pick(max, k, "p999"), max=pick(max, k, "max")) for k in ("arith_vs_fp64", "fp32_kernels_vs_fp64", "torch_fp32_vs_fp64")}
     rec["arithmetic"] = pl.arith
     _record(c.name + "_teacher_forced" + pl.tag, rec)
-    assert rec["raw"]["max"] <= 1e-6, rec["raw"]
-    assert rec["rgb_fine"]["max"] <= 2e-6 and rec["acc_fine"]["max"] <= 2e-6, rec
+    assert rec["relu_filter"]["kept_fraction"] >= B("relu_margin.min_kept"), rec["relu_filter"]
+    assert rec["raw"]["max"] <= B("tf.raw.max"), rec["raw"]
+    assert rec["rgb_fine"]["max"] <= B("tf.maps.max") and rec["acc_fine"]["max"] <= B("tf.maps.max"), rec
     # depth = sum w z (volume_rendering_utils.py:44) and disparity (:46-48) on the SAME depths: fp32 round-off only
-    assert rec["depth_fine"]["max"] <= 2e-6 * far, rec["depth_fine"]
-    assert rec["disp_fine_rel"]["max"] <= 1e-5, rec["disp_fine_rel"]
-    # a gradient entry is a sum over 786,432 (lego) samples: the two fp32 summation orders differ by ~sqrt(N) eps.  What may stand
-    # out of that is ONE flipped ReLU branch (docstring): the unit's whole row of the layer's weight gradient moves by that sample's
-    # contribution -- measured: fp32 kernels row 54 of layers_xyz.1 by 4.0e-5, fp16 pieces on 32-sample waves the same row by 4.0e-5,
-    # on 16-sample waves row 95 of layers_xyz.0 by 1.12e-4 (six largest entries of the tensor all in that row, `largest` in the
-    # record).  So: 1e-4 for every entry outside the worst entry's row and column, 3e-4 for that row, p99.9 as before.
-    assert worst["max_outside_worst_row_and_column"] <= 1e-4 and worst["max"] <= 3e-4 and worst["p999"] <= 5e-5, worst
-    if pl.arith == "fp32":
-        assert rec["slice_hip_vs_fp64"]["p999"] <= 1.5 * rec["slice_torch_fp32_vs_fp64"]["p999"] + 1e-6, rec
-        assert rec["slice_hip_vs_fp64"]["max"] <= 1.5 * rec["slice_torch_fp32_vs_fp64"]["max"] + 1e-4, rec
-    else:
-        for sl_ in rec["slices"]:
-            yard50 = max(sl_["fp32_kernels_vs_fp64"]["p50_all"], sl_["torch_fp32_vs_fp64"]["p50_all"])
-            assert sl_["arith_vs_fp64"]["p50_all"] <= 1.5 * yard50 + 1e-9, sl_
-        sm = rec["slices_worst"]
-        yard = max(sm["fp32_kernels_vs_fp64"]["p999"], sm["torch_fp32_vs_fp64"]["p999"])
-        assert sm["arith_vs_fp64"]["p999"] <= 1.5 * yard + 1e-6, (sm, rec["slices"])
-        assert sm["arith_vs_fp64"]["max"] <= 1.5 * max(sm["fp32_kernels_vs_fp64"]["max"], sm["torch_fp32_vs_fp64"]["max"]) + 1e-6, (sm, rec["slices"])
+    assert rec["depth_fine"]["max"] <= B("tf.depth.max_over_far") * far, rec["depth_fine"]
+    assert rec["disp_fine_rel"]["max"] <= B("tf.disp.rel"), rec["disp_fine_rel"]
+    # a gradient entry is a sum over 786,432 (lego) samples: two fp32-grade summation orders differ by ~sqrt(N) eps
+    gt = B("tf.grad.filtered")
+    assert kworst["max"] <= gt[0] and kworst["p999"] <= gt[1], kworst
+    assert worst["p999"] <= gt[1], worst
+    assert T.within(rec["slice_hip_vs_fp64"]["p999"], rec["slice_torch_fp32_vs_fp64"]["p999"], B("tf.slice.vs_fp64.p999")), rec
+    assert T.within(rec["slice_hip_vs_fp64"]["max"], rec["slice_torch_fp32_vs_fp64"]["max"], B("tf.slice.vs_fp64.max")), rec
 
 
 @pytest.mark.parametrize("arith", ["fp32", "f16x3_train"])
@@ -557,12 +578,13 @@ def test_tiny_nerf_geometry_through_the_helpers_vs_oracle():
     loss_c.backward()
     loss_g.backward()
     # the user's network runs on torch's own GEMMs on both sides (rocBLAS vs MKL): fp32 round-off of a 3-layer MLP
-    P.close(rgb_g.detach().cpu().numpy(), rgb_c.detach().numpy(), 2e-5, what="tiny_nerf rgb")
-    assert abs(float(loss_g) - float(loss_c)) < 1e-6
+    P.close(rgb_g.detach().cpu().numpy(), rgb_c.detach().numpy(), T.bound("tiny.rgb"), what="tiny_nerf rgb")
+    assert abs(float(loss_g) - float(loss_c)) < T.bound("tiny.loss")
+    gt = T.bound("tiny.grad")
     for a, b in zip(pg, pc):
         ref = b.grad.numpy()
         scale = float(np.abs(ref).max()) + 1e-12
-        P.close(a.grad.cpu().numpy(), ref, 2e-4 * scale + 1e-9, 1e-3, what="tiny_nerf grad")
+        P.close(a.grad.cpu().numpy(), ref, gt[0] * scale, gt[1], what="tiny_nerf grad")
 
 
 # ---- inverse-CDF indices at full size -----------------------------------------------------------------------------------
@@ -586,7 +608,7 @@ def test_lego_full_batch_sampler_index_flips(lego):
                cdf_entries_differing_from_torch=float((cdf != wc.numpy()).mean()),
                samples_vs_torch=dict(max=float(d.max()), p999=float(np.quantile(d, 0.999)), mean=float(d.mean())))
     _record(c.name + "_sampler_indices", rec)
-    assert flips <= 5, rec   # <= 1e-5 of the indices (3.8e-6 per ulp of CDF perturbation)
+    assert flips <= T.bound("sampler.index_flips"), rec   # <= 1e-5 of the indices (3.8e-6 per ulp of CDF perturbation)
 
 
 # ---- BASELINE configs[4]: eval_nerf.py at 800x800, inference instantiation ----------------------------------------------
@@ -630,32 +652,6 @@ class _EvalCase:
         self.gpu.lib.plan_destroy(self.plan_f)
 
 
-def _bf16x3_arm(c, w, keys, rec, span):
-    """The split-bf16 inference kernels (NERFHIP_PRECISION_BF16X3; never the default) on the same inputs: what ~2^-16
-    relative error per product costs against the same oracle, recorded next to the fp32 kernels and the torch-on-cuda
-    yardstick.  Measured on MI355X (profiles/r03_parity_fullsize.json): in front of the sampler 1e-5 (coarse maps: inside the
-    1e-4 bar); behind it the inverse CDF amplifies the 30x larger differences of the coarse weights -- smooth 8x256 scene:
-    1 % of the rays beyond 1e-4, p99.9 8e-4, max 5e-3 (1.3 of 255 grey levels); rough scene: a third of the rays.  So this
-    arithmetic does NOT hold the north star's 1e-4 bar on the fine maps, which is why it is opt-in and labelled."""
-    gpu = c.gpu
-    if c.cfg["hidden_size"] <= 64:
-        return
-    pb = [gpu.make_plan(c.cfg, 1) for _ in range(2)]
-    kb = [gpu.pack(pl, gpu.flatten_params(pl, {k: v.numpy() for k, v in par.items()})) for pl, par in zip(pb, (c.par_c, c.par_f))]
-    ob = gpu.render(pb[0], pb[1], kb[0], kb[1], c.rays.numpy(), c.opt, None, training=False, want_regions=("z_fine",))
-    for pl in pb:
-        gpu.lib.plan_destroy(pl)
-    rec["bf16x3_vs_cpu"] = {k: dict(_stats(ob[k], w[k]), rays_over_1e4=_over(ob[k], w[k])) for k in keys}
-    rec["z_fine_vs_oracle"]["bf16x3"] = _moved(ob["z_fine"], w["z_fine"], span)
-    b3 = rec["bf16x3_vs_cpu"]
-    # no sampler in front of the coarse maps: the products' ~1e-5 -- times what compositing makes of it: synthetic scenes stay
-    # at 1e-5; the TRAINED lego nets (large sigma at surfaces: alpha = 1 - exp(-sigma delta) amplifies) reach 5.7e-4 on
-    # acc_coarse, 43 of 16,384 rays beyond 1e-4 (measured on MI355X)
-    for k in ("rgb_coarse", "acc_coarse"):
-        assert b3[k]["p999"] <= 5e-4 and b3[k]["max"] <= 5e-3, (k, b3[k])
-    assert b3["rgb_fine"]["mean"] <= 1e-3 and b3["rgb_fine"]["max"] <= 0.1, b3["rgb_fine"]   # (sanity: an image, not noise)
-
-
 def _eval_parity(c):
     gpu = c.gpu
     keys = ("rgb_coarse", "acc_coarse", "depth_coarse", "rgb_fine", "acc_fine", "depth_fine")
@@ -669,8 +665,6 @@ def _eval_parity(c):
                torch_cuda_vs_cpu={k: dict(_stats(yard[k], w[k]), rays_over_1e4=_over(yard[k], w[k])) for k in keys},
                z_fine_vs_oracle=dict(hip=_moved(out["z_fine"], w["z_fine"], span), torch_cuda=_moved(yard["z_fine"], w["z_fine"], span)),
                arithmetic=c.infer)
-    if c.infer == "fp32":
-        _bf16x3_arm(c, w, keys, rec, span)
     for k in ("disp_coarse", "disp_fine"):  # NaN where acc == 0 (volume_rendering_utils.py:48): same pixels
         assert np.array_equal(np.isnan(out[k]), np.isnan(w[k])), k
     rec["nan_disparity_pixels"] = int(np.isnan(w["disp_fine"]).sum())
@@ -679,14 +673,15 @@ def _eval_parity(c):
     assert 0.05 < rec["scene"]["acc_fine_quantiles"][1] < 0.95, "degenerate scene: nothing is being tested"
     _record(c.name, rec)
     h, y = rec["hip_vs_cpu"], rec["torch_cuda_vs_cpu"]
+    B = lambda name: T.bound(name, c.infer)  # noqa: E731
     for k in ("rgb_coarse", "acc_coarse", "depth_coarse"):      # no sampler in front: fp32 round-off
-        assert h[k]["max"] <= 1e-5, (k, h[k])
+        assert h[k]["max"] <= B("eval.coarse_maps.max"), (k, h[k])
     # the north-star bar on colour for the bulk -- unless the reference's own CPU-vs-GPU pair is wider than that on this
     # scene; whatever exceeds the bar must be inside that spread
-    assert h["rgb_fine"]["p999"] <= max(1e-4, 2.0 * y["rgb_fine"]["p999"]), (h["rgb_fine"], y["rgb_fine"])
+    assert T.within(h["rgb_fine"]["p999"], y["rgb_fine"]["p999"], B("eval.rgb_fine.p999")), (h["rgb_fine"], y["rgb_fine"])
     for k in ("rgb_fine", "acc_fine", "depth_fine"):
-        assert h[k]["rays_over_1e4"] <= 2 * y[k]["rays_over_1e4"] + 3, (k, h[k], y[k])
-        assert h[k]["p999"] <= 2.0 * y[k]["p999"] + 2e-6, (k, h[k], y[k])
+        assert T.within(h[k]["rays_over_1e4"], y[k]["rays_over_1e4"], B("eval.yardstick.rays_over_1e4")), (k, h[k], y[k])
+        assert T.within(h[k]["p999"], y[k]["p999"], B("eval.yardstick.p999")), (k, h[k], y[k])
     return rec
 
 
@@ -740,7 +735,8 @@ def test_eval_800x800_northstar_nets_inference_vs_oracle(gpu, smooth, infer):
         # evaluations of this algorithm on different devices agree to 1e-4 on 99.85 % of the rays, not on all: the bar holds
         # for the bulk (p99 below), and the tail must sit inside the reference's own spread (asserted by _eval_parity).
         err = rec["hip_vs_cpu"]["rgb_fine"]
-        assert err["p999"] <= 1.5e-4 and err["rays_over_1e4"] <= 0.0025 * c.n, err
+        assert err["p999"] <= T.bound("eval.smooth.rgb_fine.p999", infer), err
+        assert err["rays_over_1e4"] <= T.bound("eval.smooth.rays_over_1e4.fraction", infer) * c.n, err
 
 
 @pytest.mark.parametrize("infer", ["fp32", "f16x3"])
@@ -757,34 +753,41 @@ def test_eval_800x800_pretrained_lego_nets_inference_vs_oracle(gpu, infer):
         rec = _eval_parity_trained(c)
     finally:
         c.close()
-    assert rec["hip_vs_cpu"]["rgb_fine"]["p999"] <= 2e-4
+    assert rec["hip_vs_cpu"]["rgb_fine"]["p999"] <= T.bound("eval.trained.rgb_fine.p999", infer)
 
 
 def _eval_parity_trained(c):
     """Trained nets: the reference itself moves by 6e-4 between fp32 and fp64 on this checkpoint, so only the
-    yardstick-relative statements are asserted (plus p99.9 <= 2e-4 by the caller)."""
+    yardstick-relative statements are asserted (plus p99.9 <= 2e-4 by the caller).  Two yardsticks, for the coarse maps too: the
+    reference's own torch-on-cuda vs torch-on-CPU pair, and the distance of the oracle's fp32 run from an fp64 run of itself."""
     gpu = c.gpu
+    B = lambda name: T.bound(name, c.infer)  # noqa: E731
     keys = ("rgb_coarse", "acc_coarse", "depth_coarse", "rgb_fine", "acc_fine", "depth_fine")
+    ckeys = ("rgb_coarse", "acc_coarse")
     out = gpu.render(c.plan_c, c.plan_f, c.packed_c, c.packed_f, c.rays.numpy(), c.opt, None, training=False,
                      want_regions=("z_fine",))
     w = {k: v.numpy() for k, v in c.want.items() if v is not None}
     yard = _torch_cuda_yardstick(c, keys + ("z_fine",))
+    with torch.no_grad():  # the coarse pass in fp64 (no sampler in front of it)
+        w64 = O.render_rays(c.rays.double(), {k: v.double() for k, v in c.par_c.items()}, None, c.cfg, c.cfg, dict(c.opt, num_fine=0),
+                            None, chunksize=131072)
+    w64 = {k: w64[k].numpy() for k in ckeys}
     rec = dict(rays=c.n, image="800x800", samples="%d+%d" % (c.nc, c.nf), oracle_seconds=round(c.oracle_seconds, 1),
                hip_vs_cpu={k: dict(_stats(out[k], w[k]), rays_over_1e4=_over(out[k], w[k])) for k in keys},
                torch_cuda_vs_cpu={k: dict(_stats(yard[k], w[k]), rays_over_1e4=_over(yard[k], w[k])) for k in keys},
+               coarse_vs_fp64=dict(hip={k: _stats(out[k], w64[k]) for k in ckeys}, torch_cpu_fp32={k: _stats(w[k], w64[k]) for k in ckeys},
+                                   torch_cuda={k: _stats(yard[k], w64[k]) for k in ckeys}),
                z_fine_vs_oracle=dict(hip=_moved(out["z_fine"], w["z_fine"], 4.0), torch_cuda=_moved(yard["z_fine"], w["z_fine"], 4.0)),
                rays_hitting_the_object=int((w["acc_fine"] > 0.5).sum()), arithmetic=c.infer)
-    if c.infer == "fp32":
-        _bf16x3_arm(c, w, keys, rec, 4.0)
     _record(c.name, rec)
     h, y = rec["hip_vs_cpu"], rec["torch_cuda_vs_cpu"]
-    # (no sampler in front: fp32 round-off on a saturated scene.  acc_coarse max, measured: torch-on-cuda 1.73e-5, fp32 kernels 1.63e-5,
-    # fp16 pieces 1.67e-5 on 32-sample waves and 2.24e-5 on 16-sample waves -- whose forward is as close to fp64 as theirs, 1.4-4.7e-7
-    # of the output scale over twelve geometries (r04_parity_small_cases.json) -- so the bound is the yardstick's own maximum with
-    # the margin the fine maps get below, not the 2e-5 it first was)
-    for k in ("rgb_coarse", "acc_coarse"):
-        assert h[k]["max"] <= max(2e-5, 1.5 * y[k]["max"]), (k, h[k], y[k])
+    # no sampler in front of the coarse maps, but a saturated scene (raw outputs up to 1e4, sigma 4e3): what separates two fp32-grade
+    # evaluations here is the device's sin / cos and summation order times that gain -- the reference's own pair shows how much
+    for k in ckeys:
+        assert T.within(h[k]["max"], y[k]["max"], B("eval.trained.coarse_maps.yardstick")), (k, h[k], y[k])
+        f = rec["coarse_vs_fp64"]
+        assert T.within(f["hip"][k]["max"], f["torch_cpu_fp32"][k]["max"], B("eval.trained.coarse_maps.fp64_yardstick")), (k, f)
     for k in ("rgb_fine", "acc_fine", "depth_fine"):
-        assert h[k]["rays_over_1e4"] <= 2 * y[k]["rays_over_1e4"] + 8, (k, h[k], y[k])
-        assert h[k]["p999"] <= 2.0 * y[k]["p999"] + 5e-6, (k, h[k], y[k])
+        assert T.within(h[k]["rays_over_1e4"], y[k]["rays_over_1e4"], B("eval.trained.yardstick.rays_over_1e4")), (k, h[k], y[k])
+        assert T.within(h[k]["p999"], y[k]["p999"], B("eval.trained.yardstick.p999")), (k, h[k], y[k])
     return rec

@@ -8,6 +8,7 @@ import torch
 
 import nerf_oracle as O
 import parity_cases as P
+import tolerances as T
 from backends import model_cfg
 from conftest import gold
 
@@ -85,45 +86,13 @@ def test_render_512_wide_vs_oracle(gpu):
                             grad_tol=(3.4e-3, 2e-2))
 
 
-def test_mlp_forward_bf16x3(gpu):
-    P.case_mlp_forward_bf16x3(gpu, m=3000)
-    P.case_render_bf16x3(gpu, P.MLP_GEOMETRIES["default4x128"], n=300, nc=64, nf=64, tag="4x128_300")
-    P.case_render_bf16x3(gpu, P.MLP_GEOMETRIES["northstar8x256"], n=128, nc=64, nf=128, tag="8x256_128")
-
-
-def test_mlp_bf16x3_forward_training_stash_feeds_the_fp32_backward(gpu):
-    P.case_mlp_backward(gpu, names=("default4x128", "fern8x128_skip3_L6", "novw4x128", "skip_every_layer_256", "odd5x99_skip2",
-                                    "northstar8x256"), m=1500, precision=P.BF16X3_FWD)
-    P.case_render_vs_oracle(gpu, P.MLP_GEOMETRIES["default4x128"], n=200, nc=64, nf=64, with_grads=True, tag="bf16x3_fwd_4x128_200",
-                            tol=5e-4, grad_tol=(5e-3, 5e-2), precision=P.BF16X3_FWD)
-    P.case_render_vs_oracle(gpu, P.MLP_GEOMETRIES["northstar8x256"], n=48, nc=64, nf=128, with_grads=True, tag="bf16x3_fwd_8x256_48",
-                            tol=5e-4, grad_tol=(5e-3, 5e-2), precision=P.BF16X3_FWD)
-
-
-def test_mlp_bf16x3_forward_and_data_gradient(gpu):
-    P.case_mlp_backward(gpu, names=("default4x128", "fern8x128_skip3_L6", "novw4x128", "skip_every_layer_256", "odd5x99_skip2",
-                                    "one_layer", "two_layer_L4_L2", "northstar8x256"), m=1500, precision=P.BF16X3_FWD_DGRAD)
-    P.case_mlp_input_grad(gpu, names=("default4x128", "novw4x128", "northstar8x256"), m=1500, precision=P.BF16X3_FWD_DGRAD)
-    P.case_render_vs_oracle(gpu, P.MLP_GEOMETRIES["northstar8x256"], n=48, nc=64, nf=128, with_grads=True, tag="bf16x3_fd_8x256_48",
-                            tol=5e-4, grad_tol=(5e-3, 5e-2), precision=P.BF16X3_FWD_DGRAD)
-
-
-def test_mlp_bf16x3_whole_training_step(gpu):
-    P.case_mlp_backward(gpu, names=("default4x128", "fern8x128_skip3_L6", "novw4x128", "skip_every_layer_256", "odd5x99_skip2",
-                                    "one_layer", "two_layer_L4_L2", "northstar8x256"), m=1500, precision=P.BF16X3_TRAIN)
-    P.case_render_vs_oracle(gpu, P.MLP_GEOMETRIES["northstar8x256"], n=48, nc=64, nf=128, with_grads=True, tag="bf16x3_train_8x256_48",
-                            tol=5e-4, grad_tol=(5e-3, 5e-2), precision=P.BF16X3_TRAIN)
-    P.case_render_vs_oracle(gpu, P.MLP_GEOMETRIES["default4x128"], n=200, nc=64, nf=64, with_grads=True, tag="bf16x3_train_4x128_200",
-                            tol=5e-4, grad_tol=(5e-3, 5e-2), precision=P.BF16X3_TRAIN)
-
-
-# ---- the same plans on IEEE fp16 pieces (NERFHIP_PRECISION_F16X3*): the fp32 kernels' own bounds, unchanged -------------------
+# ---- the fp16-piece plans (NERFHIP_PRECISION_F16X3*): the fp32 kernels' own bounds (tests/tolerances.py: one entry per quantity) ----
 def test_mlp_forward_f16x3(gpu):
     """Twelve geometries: within the fp32 kernels' 2e-5 of the oracle and at an fp32-sized distance from the fp64 forward; the
     fused inference render: coarse maps at 1e-5, the fine pass no further from the oracle than the fp32 kernels' own."""
-    P.case_mlp_forward_bf16x3(gpu, m=3000, precision=P.F16X3)
-    P.case_render_bf16x3(gpu, P.MLP_GEOMETRIES["default4x128"], n=300, nc=64, nf=64, tag="4x128_300", precision=P.F16X3)
-    P.case_render_bf16x3(gpu, P.MLP_GEOMETRIES["northstar8x256"], n=128, nc=64, nf=128, tag="8x256_128", precision=P.F16X3)
+    P.case_mlp_forward_f16x3(gpu, m=3000, precision=P.F16X3)
+    P.case_render_f16x3(gpu, P.MLP_GEOMETRIES["default4x128"], n=300, nc=64, nf=64, tag="4x128_300", precision=P.F16X3)
+    P.case_render_f16x3(gpu, P.MLP_GEOMETRIES["northstar8x256"], n=128, nc=64, nf=128, tag="8x256_128", precision=P.F16X3)
 
 
 @pytest.mark.parametrize("level", ["fwd", "fwd_dgrad", "train"])
@@ -140,9 +109,9 @@ def test_mlp_f16x3_training_levels_hold_the_fp32_gradient_bounds(gpu, level):
         P.case_mlp_backward(gpu, names=("northstar8x256",), m=1500, precision=prec, w_gain=0.3)
         P.case_mlp_input_grad(gpu, names=("default4x128", "novw4x128", "northstar8x256"), m=1500, precision=prec)
     P.case_render_vs_oracle(gpu, P.MLP_GEOMETRIES["northstar8x256"], n=48, nc=64, nf=128, with_grads=True, tag="f16x3_%s_8x256_48" % level,
-                            grad_tol=(3.4e-3, 5.6e-3), precision=prec)  # (test_northstar_render_and_gradients_vs_oracle's bounds)
+                            grad_tol=T.bound("unit.render_grad.northstar48", P.ARITH_NAME[prec]), precision=prec)  # (test_northstar_render_and_gradients_vs_oracle's bounds)
     P.case_render_vs_oracle(gpu, P.MLP_GEOMETRIES["default4x128"], n=200, nc=64, nf=64, white=True, noise=1.0, with_grads=True,
-                            tag="f16x3_%s_default200_white_noise1" % level, grad_tol=(1e-5, 5.5e-3), precision=prec)  # (test_default_model_render_white_background's)
+                            tag="f16x3_%s_default200_white_noise1" % level, grad_tol=T.bound("unit.render_grad.default200_white_noise1", P.ARITH_NAME[prec]), precision=prec)  # (test_default_model_render_white_background's)
 
 
 @pytest.mark.parametrize("name", ["e2e_a.npz", "e2e_b.npz", "e2e_c.npz", "e2e_d.npz", "e2e_northstar.npz"])
@@ -191,13 +160,13 @@ def test_e2e_reference_goldens(gpu, name):
 
 def test_northstar_render_and_gradients_vs_oracle(gpu):
     P.case_render_vs_oracle(gpu, P.MLP_GEOMETRIES["northstar8x256"], n=48, nc=64, nf=128, with_grads=True, tag="northstar48",
-                            grad_tol=(3.4e-3, 5.6e-3))  # measured 6.8e-4 / 1.1e-3 (profiles/r03_parity_small_cases.json)
+                            grad_tol=T.bound("unit.render_grad.northstar48"))  # measured 6.8e-4 / 1.1e-3 (profiles/r03_parity_small_cases.json)
 
 
 def test_default_model_render_white_background(gpu):
     P.case_render_vs_oracle(gpu, P.MLP_GEOMETRIES["default4x128"], n=200, nc=64, nf=64, white=True, noise=1.0,
                             with_grads=True, tag="default200_white_noise1",
-                            grad_tol=(1e-5, 5.5e-3))    # measured 2.1e-6 / 1.1e-3
+                            grad_tol=T.bound("unit.render_grad.default200_white_noise1"))    # measured 2.1e-6 / 1.1e-3
 
 
 def test_ray_gradients_c_abi(gpu):

@@ -74,7 +74,11 @@ void nh_prof_events(const char* name, void** start, void** stop) {
     r.name = name;
     r.a = prof_event();
     r.b = prof_event();
-    if (!r.a || !r.b) return;
+    if (!r.a || !r.b) {  // (one of the pair could not be created: the other goes back to the pool, the launch stays untimed)
+        if (r.a) g_prof_pool.push_back(r.a);
+        if (r.b) g_prof_pool.push_back(r.b);
+        return;
+    }
     *start = (void*)r.a;
     *stop = (void*)r.b;
     g_prof.push_back(std::move(r));

@@ -220,13 +220,17 @@ class TrainEngine:
         buffers, the same process group, nothing else on the device -- as HIP events on the current stream around a
         synchronous collective (mean of `reps` after `warmup`).  In the step the fine net's all-reduce overlaps the coarse
         backward, so these are upper bounds of what the exchange adds.  Returns {"fine": ms, "coarse": ms} (None entries
-        when there is no process group); the gradient buffers are restored."""
+        when there is no process group).  The step's pending collectives are waited for first and the live gradient is not
+        touched (the transfers run on a zero-filled buffer of the same size)."""
         if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
             return dict(fine=None, coarse=None)
+        self.wait_gradients()  # (never next to the step's own collectives: they would reduce the same process group concurrently)
         out = {}
-        keep = self.grad.clone()
+        # a zero-filled scratch of the gradient's size, NOT the live gradient: `warmup + reps` in-place SUM all-reduces multiply a
+        # buffer by world^23 (inf / NaN on larger worlds); zeros stay zeros, and the transfer does not depend on the values
+        scratch = torch.zeros_like(self.grad)
         with torch.cuda.device(self.dev):
-            for name, sl in (("fine", self.grad[self.nc_params:]), ("coarse", self.grad[:self.nc_params])):
+            for name, sl in (("fine", scratch[self.nc_params:]), ("coarse", scratch[:self.nc_params])):
                 if sl.numel() == 0:
                     out[name] = None
                     continue
@@ -240,7 +244,6 @@ class TrainEngine:
                 b.record()
                 torch.cuda.synchronize(self.dev)
                 out[name] = round(a.elapsed_time(b) / reps, 4)
-            self.grad.copy_(keep)
         return out
 
     def optimizer_step(self, lr=None):

@@ -1,0 +1,58 @@
+#!/bin/bash
+# gpurun --timeout T -- "bash scripts/gpu_r5.sh PART [PART ...]"      (round 5: ONE parameterised script instead of a script per call)
+#   tests   the GPU suite (pytest -m gpu) and smoke() on the library in the tree            -> gpurun_out/pytest_gpu.log, smoke.log
+#   mocks   the loop mocks (scripts/f16w_loop_mock, scripts/ws_loop_mock: built in the container, they travel)  -> mocks.txt
+#   bench   the driver's default line, then the labelled lines (f16x3_train, 4x128 fp32 / f16x3_train, fern, eval fp32 / f16x3)
+#   prof    rocprofv3 --kernel-trace --stats of the default line and of the f16x3_train line, then the PMC passes of both
+#   psnr8   8 seeds x 2000 iterations of the f16x3_train arm at 8x256 (scripts/psnr_arms.py; the fp32 arms: profiles/r04_psnr_8x256_runs)
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out
+R=$GRAFT_REPO_ROOT/gpurun_out
+show() {
+  for f in "$@"; do
+    echo "== $f"; tail -1 $R/$f.log | python -c "
+import sys, json
+try:
+    d = json.loads(sys.stdin.read())
+    print(d['value'], d['ms_per_step'], d.get('precision'), {k: (v['ms_per_step'], v['frac'], v['hbm_frac']) for k, v in (d['roofline'] or {}).get('mlp_kernels', {}).items()})
+    if 'labelled_lines' in d: print('   labelled', {k: (v.get('value'), v.get('ms_per_step'), v.get('speedup_vs_pytorch_rocm_fwd_bwd')) for k, v in d['labelled_lines'].items()}, 'x torch', d.get('speedup_vs_pytorch_rocm_fwd_bwd'))
+except Exception as e:
+    print('unparsed', repr(e)[:200])
+"
+  done
+}
+for part in "$@"; do
+case $part in
+tests)
+  timeout 900 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider > $R/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $R/pytest_gpu.log
+  timeout 120 python __graft_entry__.py smoke > $R/smoke.log 2>&1; echo "smoke rc=$?" >> $R/smoke.log
+  grep -E "passed|failed|rc=" $R/pytest_gpu.log | tail -3; grep -E "^FAILED|^ERROR" $R/pytest_gpu.log | head -20; tail -2 $R/smoke.log ;;
+mocks)
+  { echo "# scripts/f16w_loop_mock (the product's loop structure), then scripts/ws_loop_mock (weight-stationary), same box, back to back"
+    timeout 120 scripts/f16w_loop_mock; timeout 120 scripts/ws_loop_mock; timeout 120 scripts/ws_loop_mock; } > $R/mocks.txt 2>&1
+  cat $R/mocks.txt ;;
+bench)
+  timeout 400 python bench.py > $R/bench.log 2>&1
+  timeout 100 python bench.py --no-cpu-baseline --precision f16x3_train > $R/bench_f16x3_train.log 2>&1
+  timeout 100 python bench.py --no-cpu-baseline --hidden 128 --layers 4 > $R/bench_4x128.log 2>&1
+  timeout 100 python bench.py --no-cpu-baseline --hidden 128 --layers 4 --precision f16x3_train > $R/bench_f16x3_train_4x128.log 2>&1
+  timeout 100 python bench.py --no-cpu-baseline --workload fern > $R/bench_fern_4x64.log 2>&1
+  timeout 100 python bench.py --mode eval --no-cpu-baseline > $R/bench_eval.log 2>&1
+  timeout 100 python bench.py --mode eval --no-cpu-baseline --precision f16x3 > $R/bench_eval_f16x3.log 2>&1
+  show bench bench_f16x3_train bench_4x128 bench_f16x3_train_4x128 bench_fern_4x64 bench_eval bench_eval_f16x3 ;;
+prof)
+  cd /tmp
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $R/bench_prof.log 2>&1
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/prof_f16 -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --precision f16x3_train > $R/bench_prof_f16.log 2>&1
+  cd $GRAFT_REPO_ROOT
+  bash scripts/gpu_pmc.sh > $R/pmc.log 2>&1; cp $R/pmc_summary.json $R/pmc_summary_8x256_4096.json; cp $R/pmc_summary.txt $R/pmc_summary_8x256_4096.txt
+  PMC_BENCH_ARGS="--precision f16x3_train" bash scripts/gpu_pmc.sh > $R/pmc_f16.log 2>&1; cp $R/pmc_summary.json $R/pmc_summary_f16x3_train.json; cp $R/pmc_summary.txt $R/pmc_summary_f16x3_train.txt
+  tail -6 $R/pmc_summary_8x256_4096.txt; tail -12 $R/pmc_summary_f16x3_train.txt; find $R/prof $R/prof_f16 -name "*kernel_stats.csv" | head -2 ;;
+psnr8)
+  mkdir -p $R/psnr8
+  for s in 1 2 3 4 5 6 7 8; do
+    timeout 120 python scripts/psnr_arms.py $s 2000 $R/psnr8/seed$s.json --arms engine_f16tr --hidden 256 --layers 8 --lr 1e-3 > $R/psnr8/seed$s.log 2>&1
+    echo "seed $s rc=$? $(grep 'engine_f16tr' $R/psnr8/seed$s.log | tail -1 | cut -c1-160)"
+  done ;;
+*) echo "unknown part $part" ;;
+esac
+done

@@ -469,9 +469,9 @@ def main():
     infer_only = prec_f == "f16x3"
     if (args.mode == "train" and infer_only) or (args.mode == "eval" and not infer_only and prec_f != "fp32"):
         raise SystemExit("--precision f16x3 goes with --mode eval, f16x3_fwd / _fwd_dgrad / _train with --mode train")
-    if (prec_c != "fp32" or prec_f != "fp32") and not 64 < cfg["hidden_size"] <= 256:
-        # (nerfhip_plan_create_ex refuses such plans: the split-precision kernels exist for the 128- and 256-wide kernel widths)
-        raise SystemExit("--precision %s needs hidden_size in (64, 256] (this workload: %d); the 64- and 512-wide nets run fp32"
+    if (prec_c != "fp32" or prec_f != "fp32") and cfg["hidden_size"] > 256:
+        # (nerfhip_plan_create_ex refuses such plans: the fp16-piece kernels exist for the 64-, 128- and 256-wide kernel widths)
+        raise SystemExit("--precision %s needs hidden_size <= 256 (this workload: %d); the 512-wide nets run fp32"
                          % (args.precision, cfg["hidden_size"]))
     if args.mode == "train":
         if prec_c != "fp32":

@@ -189,7 +189,9 @@ nerfhip_plan_t nerfhip_plan_create(const nerfhip_model_cfg* cfg);
  *   F16X3_TRAIN      ... and the large weight-gradient GEMMs (hidden x hidden blocks: ~94 % of those FLOPs) on the fp16 MFMAs, with
  *                    the thin blocks that share a region with one of them -- a skip layer's xyz columns, fc_alpha, the direction
  *                    columns -- riding along in the same launch; layer1's block and fc_rgb | fc_out stay on the fp32 kernel.
- * Supported for kernel widths 128 and 256, num_encoding_fn_xyz <= 10, num_encoding_fn_dir <= 4.  Opt-in, labelled.
+ * Supported for kernel widths 64, 128 and 256 (hidden_size <= 256; 64-wide nets: new in round 5 -- config/fern.yml's declared 4 x 64 --,
+ * their weight-gradient GEMMs all stay on the fp32 kernel: _TRAIN is _FWD_DGRAD there), num_encoding_fn_xyz <= 10,
+ * num_encoding_fn_dir <= 4.  Opt-in, labelled.
  * Values 1 .. 4 named round 3's bf16-piece plans (~2^-16 per product: they did not hold the parity bounds); removed in round 5,
  * nerfhip_plan_create_ex refuses them with a message, the numbers stay reserved. */
 #define NERFHIP_PRECISION_FP32 0

@@ -862,6 +862,8 @@ int nh_mlp_forward_f16w(nerfhip_plan* p, const float* packed, const NhMlpInput& 
     else if (p->W == 256) NH_FWDW(256, false)
     else if (p->W == 128 && p->view) NH_FWDW(128, true)
     else if (p->W == 128) NH_FWDW(128, false)
+    else if (p->W == 64 && p->view) NH_FWDW(64, true)
+    else if (p->W == 64) NH_FWDW(64, false)
     else {
         nh_set_error("mlp_fwd: no f16x3 kernel for kernel width %d", p->W);
         return NERFHIP_ERR_UNSUPPORTED;
@@ -903,6 +905,8 @@ int nh_mlp_dgrad_f16w(nerfhip_plan* p, const float* packed, const float* g_out, 
     else if (p->W == 256) NH_BWDW(256, false)
     else if (p->W == 128 && p->view) NH_BWDW(128, true)
     else if (p->W == 128) NH_BWDW(128, false)
+    else if (p->W == 64 && p->view) NH_BWDW(64, true)
+    else if (p->W == 64) NH_BWDW(64, false)
     else {
         nh_set_error("mlp_bwd: no f16x3 data-gradient kernel for kernel width %d", p->W);
         return NERFHIP_ERR_UNSUPPORTED;

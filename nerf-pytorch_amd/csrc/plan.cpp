@@ -791,8 +791,8 @@ static nerfhip_plan_t plan_create_impl(const nerfhip_model_cfg* cfg, int precisi
         const bool okx = build_slot_map_b(cfg->num_encoding_fn_xyz, cfg->include_input_xyz ? 1 : 0, NHW_XSLOTS, p->xyz_slot_b);
         const bool okd = build_slot_map_b(p->view ? cfg->num_encoding_fn_dir : 0, (p->view && cfg->include_input_dir) ? 1 : 0,
                                           NHW_DSLOTS, p->dir_slot_b);
-        if (!(okx && okd) || (p->W != 128 && p->W != 256)) {
-            nh_set_error("plan_create_ex: f16x3 plans need hidden_size in (64, 256], num_encoding_fn_xyz <= 10 and "
+        if (!(okx && okd) || (p->W != 64 && p->W != 128 && p->W != 256)) {
+            nh_set_error("plan_create_ex: f16x3 plans need hidden_size <= 256, num_encoding_fn_xyz <= 10 and "
                          "num_encoding_fn_dir <= 4 (got %d, %d, %d)", cfg->hidden_size, cfg->num_encoding_fn_xyz, cfg->num_encoding_fn_dir);
             delete p;
             return nullptr;

@@ -4,6 +4,7 @@
 #   mocks   the loop mocks (scripts/f16w_loop_mock, scripts/ws_loop_mock: built in the container, they travel)  -> mocks.txt
 #   bench   the driver's default line, then the labelled lines (f16x3_train, 4x128 fp32 / f16x3_train, fern, eval fp32 / f16x3)
 #   prof    rocprofv3 --kernel-trace --stats of the default line and of the f16x3_train line, then the PMC passes of both
+#   soakshort  3000 iterations of the f16x3_train arm with the FILTERED gradient comparison every 250 (scripts/psnr_soak.py)
 #   psnr8   8 seeds x 2000 iterations of the f16x3_train arm at 8x256 (scripts/psnr_arms.py; the fp32 arms: profiles/r04_psnr_8x256_runs)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT/gpurun_out
@@ -36,9 +37,10 @@ bench)
   timeout 100 python bench.py --no-cpu-baseline --hidden 128 --layers 4 > $R/bench_4x128.log 2>&1
   timeout 100 python bench.py --no-cpu-baseline --hidden 128 --layers 4 --precision f16x3_train > $R/bench_f16x3_train_4x128.log 2>&1
   timeout 100 python bench.py --no-cpu-baseline --workload fern > $R/bench_fern_4x64.log 2>&1
+  timeout 100 python bench.py --no-cpu-baseline --workload fern --precision f16x3_train > $R/bench_fern_4x64_f16x3_train.log 2>&1
   timeout 100 python bench.py --mode eval --no-cpu-baseline > $R/bench_eval.log 2>&1
   timeout 100 python bench.py --mode eval --no-cpu-baseline --precision f16x3 > $R/bench_eval_f16x3.log 2>&1
-  show bench bench_f16x3_train bench_4x128 bench_f16x3_train_4x128 bench_fern_4x64 bench_eval bench_eval_f16x3 ;;
+  show bench bench_f16x3_train bench_4x128 bench_f16x3_train_4x128 bench_fern_4x64 bench_fern_4x64_f16x3_train bench_eval bench_eval_f16x3 ;;
 prof)
   cd /tmp
   timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $R/bench_prof.log 2>&1
@@ -53,6 +55,10 @@ psnr8)
     timeout 120 python scripts/psnr_arms.py $s 2000 $R/psnr8/seed$s.json --arms engine_f16tr --hidden 256 --layers 8 --lr 1e-3 > $R/psnr8/seed$s.log 2>&1
     echo "seed $s rc=$? $(grep 'engine_f16tr' $R/psnr8/seed$s.log | tail -1 | cut -c1-160)"
   done ;;
+soakshort)
+  mkdir -p $R/soak
+  timeout 200 python scripts/psnr_soak.py 1 3000 $R/soak/soak_short_filtered_seed1.json --arms engine_f16tr --check 3000 --diag 250 > $R/soak/soak_short_filtered_seed1.log 2>&1
+  echo "soakshort rc=$?"; grep diag $R/soak/soak_short_filtered_seed1.log | cut -c1-260 ;;
 *) echo "unknown part $part" ;;
 esac
 done

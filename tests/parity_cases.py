@@ -335,7 +335,7 @@ F16X3, F16X3_FWD, F16X3_FWD_DGRAD, F16X3_TRAIN = 5, 6, 7, 8    # NERFHIP_PRECISI
 ARITH_NAME = {0: "fp32", F16X3: "f16x3", F16X3_FWD: "f16x3_fwd", F16X3_FWD_DGRAD: "f16x3_fwd_dgrad", F16X3_TRAIN: "f16x3_train"}
 F16X3_GEOMETRIES = ("default4x128", "northstar8x256", "fern8x128_skip3_L6", "novw4x128", "two_layer_L4_L2", "one_layer",
                     "one_layer_novw_256", "skip_every_layer_256", "noinput_linear", "odd5x99_skip2", "wide3x200_skip1",
-                    "novw2x130")
+                    "novw2x130", "llff4x64_skip3_L6", "deep8x64_skip4", "novw3x64_skip1", "one_layer_64", "narrow3x40")
 
 
 def case_mlp_forward_f16x3(b, names=None, m=70, precision=F16X3):
@@ -362,9 +362,9 @@ def case_mlp_forward_f16x3(b, names=None, m=70, precision=F16X3):
             b.mlp_fwd(plan, packed, x.numpy(), want_stash=True)
         b.lib.plan_destroy(plan)
     with pytest.raises(L.NerfHipError, match="plans need"):
-        b.make_plan(MLP_GEOMETRIES["llff4x64_skip3_L6"], precision)
+        b.make_plan(MLP_GEOMETRIES["wide3x512_skip2"], precision)     # (512-wide nets run fp32)
     with pytest.raises(L.NerfHipError, match="plans need"):
-        b.make_plan(MLP_GEOMETRIES["L12_4x128"], precision)
+        b.make_plan(MLP_GEOMETRIES["L12_4x128"], precision)           # (more than 10 xyz frequencies: the fp32 kernels' extended slots)
     # (values 1 .. 4 named round 3's bf16-piece plans: removed, refused with a message)
     for removed in (1, 2, 3, 4):
         with pytest.raises(L.NerfHipError, match="removed in round 5"):

@@ -109,6 +109,16 @@ def test_mlp_f16x3_training_levels_hold_the_fp32_gradient_bounds(emu):
                             precision=P.F16X3_TRAIN)  # (128-wide nets: the four full blocks reach k_wgrad_f16x3<128, 128>)
 
 
+def test_mlp_f16x3_64_wide_instances(emu):
+    """k_mlp_fwd_f16x3w<64> / k_mlp_dgrad_f16x3w<64>: four output tiles, two 32-deep k-blocks, whole layers inside one chunk."""
+    names = ("llff4x64_skip3_L6", "novw3x64_skip1", "one_layer_64")
+    P.case_mlp_forward_f16x3(emu, names=names + ("narrow3x40",), m=37, precision=P.F16X3)
+    P.case_mlp_backward(emu, names=names, m=100, precision=P.F16X3_TRAIN)
+    P.case_mlp_backward(emu, names=("deep8x64_skip4",), m=100, precision=P.F16X3_FWD)
+    P.case_render_vs_oracle(emu, P.MLP_GEOMETRIES["llff4x64_skip3_L6"], n=12, nc=16, nf=16, noise=1.0, with_grads=True,
+                            tag="f16x3_llff64_emu", grad_tol=(1e-3, 2e-2), precision=P.F16X3_TRAIN)
+
+
 def test_ndc_rays_backward(emu):
     P.case_ndc_rays_bwd(emu, n=200)
 

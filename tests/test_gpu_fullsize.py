@@ -360,15 +360,17 @@ def test_fern_full_batch_every_ray_vs_oracle(fern, arith):
     _end_to_end(fern, "e2e.grad_coarse.fp64_yardstick", "e2e.grad_fine.fern8x128", arith=arith)
 
 
-def test_fern_declared_4x64_full_batch_every_ray_vs_oracle(fern_declared):
-    """The same full-batch comparison on the geometry config/fern.yml declares.  Bounds: 5x the values
-    measured on MI355X (profiles/r04_parity_fullsize.json: coarse-net gradients 3.3e-6 / 3.3e-6 of max|g|, fine-net 5.1e-5 / 4.0e-5;
-    rgb_fine max 7.0e-5, 0 rays beyond 1e-4)."""
-    _end_to_end(fern_declared, "e2e.grad_coarse.fern4x64", "e2e.grad_fine.fern4x64")
+@pytest.mark.parametrize("arith", ["fp32", "f16x3_train"])
+def test_fern_declared_4x64_full_batch_every_ray_vs_oracle(fern_declared, arith):
+    """The same full-batch comparison on the geometry config/fern.yml declares, on the fp32 kernels and -- the
+    64-wide instances of mlp_f16w.hip, round 5 -- on fp16 pieces.  Fine-net bounds: 5x the values measured on MI355X
+    (profiles/r04_parity_fullsize.json: 5.1e-5 / 4.0e-5; rgb_fine max 7.0e-5, 0 rays beyond 1e-4); coarse net: the fp64 yardstick."""
+    _end_to_end(fern_declared, "e2e.grad_coarse.fp64_yardstick", "e2e.grad_fine.fern4x64", arith=arith)
 
 
-def test_fern_declared_4x64_teacher_forced_fine_pass(fern_declared):
-    _teacher_forced(fern_declared)
+@pytest.mark.parametrize("arith", ["fp32", "f16x3_train"])
+def test_fern_declared_4x64_teacher_forced_fine_pass(fern_declared, arith):
+    _teacher_forced(fern_declared, arith)
 
 
 def _fine_inputs(c, sel, z):

@@ -114,6 +114,18 @@ def test_mlp_f16x3_training_levels_hold_the_fp32_gradient_bounds(gpu, level):
                             tag="f16x3_%s_default200_white_noise1" % level, grad_tol=T.bound("unit.render_grad.default200_white_noise1", P.ARITH_NAME[prec]), precision=prec)  # (test_default_model_render_white_background's)
 
 
+def test_mlp_f16x3_64_wide_instances(gpu):
+    """The 64-wide instances of the fp16-piece kernels (config/fern.yml's declared 4 x 64, config/llff.yml; round 5): what
+    test_mlp_64_wide_instances / test_render_64_wide_llff_config_vs_oracle assert of the fp32 kernels, every training level (the
+    weight-gradient GEMMs of 64-wide nets all stay on the fp32 kernel: _TRAIN is _FWD_DGRAD there)."""
+    names = ("llff4x64_skip3_L6", "deep8x64_skip4", "novw3x64_skip1", "one_layer_64")
+    for prec in (P.F16X3_FWD, P.F16X3_FWD_DGRAD, P.F16X3_TRAIN):
+        P.case_mlp_backward(gpu, names=names, m=1500, precision=prec)
+    P.case_mlp_input_grad(gpu, names=("llff4x64_skip3_L6",), m=1500, precision=P.F16X3_FWD_DGRAD)
+    P.case_render_vs_oracle(gpu, P.MLP_GEOMETRIES["llff4x64_skip3_L6"], n=300, nc=64, nf=64, noise=1.0, with_grads=True,
+                            tag="f16x3_llff64_300", grad_tol=(1e-3, 2e-2), precision=P.F16X3_TRAIN)
+
+
 @pytest.mark.parametrize("name", ["e2e_a.npz", "e2e_b.npz", "e2e_c.npz", "e2e_d.npz", "e2e_northstar.npz"])
 def test_e2e_reference_goldens_f16x3_train(gpu, name):
     """The goldens recorded from the REAL reference (outputs, loss, every gradient tensor), every kernel of the step on fp16 pieces:

@@ -38,6 +38,7 @@ def bench_lines():
     for src, dst in (("bench.log", "bench_line.json"), ("bench_f16x3_train.log", "bench_line_f16x3_train.json"),
                      ("bench_4x128.log", "bench_line_4x128.json"), ("bench_f16x3_train_4x128.log", "bench_line_f16x3_train_4x128.json"),
                      ("bench_fern_4x64.log", "bench_line_fern_4x64.json"), ("bench_fern_4x64_f16x3_train.log", "bench_line_fern_4x64_f16x3_train.json"),
+                     ("bench_fern_4x64_f16x3_fwd.log", "bench_line_fern_4x64_f16x3_fwd.json"),
                      ("bench_eval.log", "bench_line_eval_800x800.json"), ("bench_eval_f16x3.log", "bench_line_eval_800x800_f16x3.json"),
                      ("bench_800_1024_fp32.log", "bench_line_800x800_1024rays.json"), ("bench_800_8192_fp32.log", "bench_line_800x800_8192rays.json"),
                      ("bench_800_1024_f16x3_train.log", "bench_line_800x800_1024rays_f16x3_train.json"),

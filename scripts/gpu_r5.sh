@@ -4,6 +4,7 @@
 #   mocks   the loop mocks (scripts/f16w_loop_mock, scripts/ws_loop_mock: built in the container, they travel)  -> mocks.txt
 #   bench   the driver's default line, then the labelled lines (f16x3_train, 4x128 fp32 / f16x3_train, fern, eval fp32 / f16x3)
 #   prof    rocprofv3 --kernel-trace --stats of the default line and of the f16x3_train line, then the PMC passes of both
+#   proxy   the one-GPU proxy lines of the 8-GPU strong-scaling shape;  fernfwd  fern on f16x3_fwd plans
 #   soakshort  3000 iterations of the f16x3_train arm with the FILTERED gradient comparison every 250 (scripts/psnr_soak.py)
 #   psnr8   8 seeds x 2000 iterations of the f16x3_train arm at 8x256 (scripts/psnr_arms.py; the fp32 arms: profiles/r04_psnr_8x256_runs)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out
@@ -52,9 +53,18 @@ prof)
 psnr8)
   mkdir -p $R/psnr8
   for s in 1 2 3 4 5 6 7 8; do
-    timeout 120 python scripts/psnr_arms.py $s 2000 $R/psnr8/seed$s.json --arms engine_f16tr --hidden 256 --layers 8 --lr 1e-3 > $R/psnr8/seed$s.log 2>&1
+    timeout 170 python scripts/psnr_arms.py $s 2000 $R/psnr8/seed$s.json --arms engine_f16tr --hidden 256 --layers 8 --lr 1e-3 > $R/psnr8/seed$s.log 2>&1
     echo "seed $s rc=$? $(grep 'engine_f16tr' $R/psnr8/seed$s.log | tail -1 | cut -c1-160)"
   done ;;
+proxy)   # the per-GPU shape of BASELINE configs[2] (800x800, 8192 rays over 8 GPUs = 1024 per GPU) and the whole step, on one GPU
+  for spec in "1024 fp32" "8192 fp32" "1024 f16x3_train" "8192 f16x3_train"; do
+    set -- $spec
+    timeout 120 python bench.py --no-cpu-baseline --image 800 --rays $1 --precision $2 > $R/bench_800_$1_$2.log 2>&1
+  done
+  show bench_800_1024_fp32 bench_800_8192_fp32 bench_800_1024_f16x3_train bench_800_8192_f16x3_train ;;
+fernfwd)
+  timeout 100 python bench.py --no-cpu-baseline --workload fern --precision f16x3_fwd > $R/bench_fern_4x64_f16x3_fwd.log 2>&1
+  show bench_fern_4x64_f16x3_fwd ;;
 soakshort)
   mkdir -p $R/soak
   timeout 200 python scripts/psnr_soak.py 1 3000 $R/soak/soak_short_filtered_seed1.json --arms engine_f16tr --check 3000 --diag 250 > $R/soak/soak_short_filtered_seed1.log 2>&1

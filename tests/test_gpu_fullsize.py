@@ -581,7 +581,7 @@ def test_tiny_nerf_geometry_through_the_helpers_vs_oracle():
     loss_g.backward()
     # the user's network runs on torch's own GEMMs on both sides (rocBLAS vs MKL): fp32 round-off of a 3-layer MLP
     P.close(rgb_g.detach().cpu().numpy(), rgb_c.detach().numpy(), T.bound("tiny.rgb"), what="tiny_nerf rgb")
-    assert abs(float(loss_g) - float(loss_c)) < T.bound("tiny.loss")
+    assert abs(float(loss_g.detach()) - float(loss_c.detach())) < T.bound("tiny.loss")
     gt = T.bound("tiny.grad")
     for a, b in zip(pg, pc):
         ref = b.grad.numpy()

@@ -65,6 +65,12 @@ proxy)   # the per-GPU shape of BASELINE configs[2] (800x800,
 fernfwd)
   timeout 100 python bench.py --no-cpu-baseline --workload fern --precision f16x3_fwd > $R/bench_fern_4x64_f16x3_fwd.log 2>&1
   show bench_fern_4x64_f16x3_fwd ;;
+soak)    # more seeds of the 20 000-iteration soak (scripts/gpu_r5_soak.sh ran seeds 1, 2): SOAK_SEEDS="3 4" bash scripts/gpu_r5.sh soak
+  mkdir -p $R/soak
+  for seed in ${SOAK_SEEDS:-3}; do
+    timeout 1150 python scripts/psnr_soak.py $seed ${SOAK_ITERS:-20000} $R/soak/soak_seed$seed.json --arms engine_f16tr,engine > $R/soak/soak_seed$seed.log 2>&1
+    echo "soak seed $seed rc=$?"; grep "val_psnr" $R/soak/soak_seed$seed.log | tail -2 | cut -c1-200
+  done ;;
 soakshort)
   mkdir -p $R/soak
   timeout 200 python scripts/psnr_soak.py 1 3000 $R/soak/soak_short_filtered_seed1.json --arms engine_f16tr --check 3000 --diag 250 > $R/soak/soak_short_filtered_seed1.log 2>&1

@@ -26,16 +26,31 @@ constexpr int WS_LOG2 = 8;
 static_assert(WS == (float)(1 << WS_LOG2), "weight scale");
 constexpr int TARGET_LOG2 = 13;  // a sample's largest operand value lands in [2^13, 2^14)
 constexpr int NO_CAP = 100;
-constexpr int ZERO_EXP = 60;     // exponent of a sample whose values are all zero (mlp_bf16.hip NHB_ZERO_EXP)
+// Exponent of a sample whose values are all zero (a dead layer, a zero cotangent behind an opaque surface or in front of a white
+// background, a padding sample of the last group): low enough that a bias times 2^60 stays a float.  The value is RESERVED for such
+// samples -- a non-zero sample whose exponent comes out at exactly 60 takes 59 (one bit less headroom) -- because note_region must tell
+// them apart: a zero sample sets no region bound at all.  (Round 4 let it set 2^(14 - 60) = 2^-46, "never a region's scale": true for
+// every region training produces -- the soak's d(pre-activation) bounds are 2^-24 ... 2^-12 -- and wrong for a region whose largest
+// value is below 2^-46: its values were then split 2^-46 too low and the weight gradient of cotangents below ~1e-20 lost bits, below
+// ~1e-25 everything.  Found by tests/parity_cases.py case_f16x3_range_extremes on the emulator.)
+constexpr int ZERO_EXP = 60;
 // Every per-sample exponent stays inside [-S_LIM, S_LIM]: the scales applied with it -- 2^s, 2^-s, 2^(-8 - s) -- are then exactly the
 // powers of two nh_pow2i can represent (it clamps at 2^-126 / 2^127), so what a sample's exponent SAYS and what its values were multiplied
 // by never part (nh_shift_to alone reaches 139 for magnitudes near 2^-126).  A sample whose largest value sits below
 // 2^(13 - S_LIM) = 2^-97 keeps fewer piece bits instead -- it is zero to fp32's neighbours anyway.
 constexpr int S_LIM = 110;
 NH_DEVICE int clamp_exp(int s) { return s < -S_LIM ? -S_LIM : (s > S_LIM ? S_LIM : s); }
-NH_DEVICE int exp_for(unsigned mb, int base_e) { return ((mb >> 23) & 255u) == 0u ? ZERO_EXP : clamp_exp(base_e + nh_shift_to(mb, TARGET_LOG2)); }
-// ... and a renormalisation moves a sample by at most 2^120 in one step (the multiplier is a normal float), within the same limits
-NH_DEVICE int step_exp(int so, int base_e) { return clamp_exp(so > base_e + 120 ? base_e + 120 : (so < base_e - 120 ? base_e - 120 : so)); }
+NH_DEVICE int not_zero_exp(int s) { return s == ZERO_EXP ? ZERO_EXP - 1 : s; }
+NH_DEVICE int exp_for(unsigned mb, int base_e) {
+    return ((mb >> 23) & 255u) == 0u ? ZERO_EXP : not_zero_exp(clamp_exp(base_e + nh_shift_to(mb, TARGET_LOG2)));
+}
+// ... a layer that also reads encodings caps the hidden exponent at theirs, and a renormalisation moves a sample by at most 2^120 in one
+// step (the multiplier is a normal float), within the same limits; an all-zero sample keeps its reserved exponent
+NH_DEVICE int step_exp(int so, int base_e, int cap) {
+    if (so == ZERO_EXP) return so;
+    so = so < cap ? so : cap;
+    return not_zero_exp(clamp_exp(so > base_e + 120 ? base_e + 120 : (so < base_e - 120 ? base_e - 120 : so)));
+}
 // a raw network output from an accumulator that holds WS * 2^s * value
 NH_DEVICE float raw_of(float acc, int s) { return acc * nh_pow2i(-WS_LOG2 - s); }
 
@@ -60,7 +75,7 @@ struct WCtx {
 };
 // the rows a gemm stored for region `ridx` came from pieces below 2^(TARGET + 1) at per-sample exponent s: note the bound
 NH_DEVICE void note_region(const WCtx& cx, int ridx, int s) {
-    const int e = 256 + 14 - s;
+    const int e = s == ZERO_EXP ? 1 : 256 + 14 - s;  // (an all-zero sample bounds nothing: the smallest word)
     const unsigned wm = nh_wave_max_u32((unsigned)(e < 1 ? 1 : (e > 511 ? 511 : e)));
     if (cx.lane == 0 && wm > cx.wrm[ridx]) cx.wrm[ridx] = wm;
 }
@@ -144,8 +159,7 @@ NH_DEVICE int renorm_convert(const f32x4* acc, nh_f16x8* oh, nh_f16x8* ol, int s
     const unsigned mb = tile_max_bits<NT, false>(acc);
     int so = exp_for(mb, base_e);
 #endif
-    so = so < cap ? so : cap;
-    so = step_exp(so, base_e);
+    so = step_exp(so, base_e, cap);
     const float mul = nh_pow2i(so - base_e);
     MaskW none;
     none.w[0] = none.w[1] = 0u;
@@ -365,8 +379,7 @@ NH_DEVICE void gemm_w(WCtx& cx, const nh_f16x8* ah, const nh_f16x8* al, const nh
             const unsigned mb = tile_max_bits<NTE, EPI == 1>(acc);
             const int base_e = WS_LOG2 + s_in;
             int so = exp_for(mb, base_e);
-            so = so < cap ? so : cap;
-            so = step_exp(so, base_e);
+            so = step_exp(so, base_e, cap);
             mul = nh_pow2i(so - base_e);
             *s_out = so;  // the pieces made below are those of value * 2^so
         }

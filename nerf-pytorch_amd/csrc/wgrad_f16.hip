@@ -67,7 +67,11 @@ struct WgBArgs {
 };
 
 // a region's recorded word (256 + log2 of the bound on its magnitudes; 0: nothing recorded) -> the shift that brings the bound to 2^14
-NH_DEVICE int region_shift(unsigned word) { return word == 0u ? 0 : 14 - ((int)word - 256); }
+// (0: nothing recorded, 1: only all-zero samples -- nothing to scale)
+NH_DEVICE int region_shift(unsigned word) { return word <= 1u ? 0 : 14 - ((int)word - 256); }
+// a sum of products of values split at 2^sa and 2^sb, brought back: two exact multiplies (one factor 2^(-sa - sb) would leave the range
+// of a normal float for tiny cotangents: sa reaches 110 + 14)
+NH_DEVICE float unscale2(float v, int sa, int sb) { return (v * nh_pow2i(-sa)) * nh_pow2i(-sb); }
 
 // SA / SB: rows of a thin block's region that rides on the launch's blocks -- SA (32): ONE more A tile against the block's B tiles
 // (fc_alpha's row of POUT against H_{L-1}, next to fc_feat); SB (32 | 64): one or two more B tiles against the block's A tiles (the
@@ -343,8 +347,8 @@ NH_KERNEL void k_wgrad_reduce_f16x3(WgBArgs a) {
         const int row = 32 * (tile / TB) + (c & 3) + 8 * (c >> 2) + 4 * (l >> 5), col = 32 * (tile % TB) + (l & 31);
         if (row < jb.r_hi && col < jb.col_count) {
             // (the powers of two the kernel split this block's regions at: exact to divide out)
-            const float unscale = scaled ? nh_pow2i(-region_shift(a.amax[jb.a_idx]) - region_shift(a.bmax[jb.b_idx])) : 1.0f;
-            a.g_params[jb.w_off + (int64_t)row * jb.w_ld + col] = sum_partials(e) * unscale;
+            const float v = sum_partials(e);
+            a.g_params[jb.w_off + (int64_t)row * jb.w_ld + col] = scaled ? unscale2(v, region_shift(a.amax[jb.a_idx]), region_shift(a.bmax[jb.b_idx])) : v;
         }
     } else if (e < E + AR) {  // bias: thread t of every workgroup summed row t mod AR
         const int row = e - E;
@@ -371,14 +375,16 @@ NH_KERNEL void k_wgrad_reduce_f16x3(WgBArgs a) {
             const int row = 32 * (tile / (SB / 32)) + r32, slot = 32 * (tile % (SB / 32)) + (l & 31);
             const int col = (int)a.scol[slot];
             if (row < jb.r_hi && col >= 0 && col < a.s_col_count) {
-                const float unscale = scaled ? nh_pow2i(-region_shift(a.amax[jb.a_idx]) - region_shift(a.bmax[a.s_idx])) : 1.0f;
-                a.g_params[jb.s_w_off + (int64_t)row * jb.s_w_ld + a.s_col_base + col] = sum_partials(E + se) * unscale;
+                const float v = sum_partials(E + se);
+                a.g_params[jb.s_w_off + (int64_t)row * jb.s_w_ld + a.s_col_base + col] =
+                    scaled ? unscale2(v, region_shift(a.amax[jb.a_idx]), region_shift(a.bmax[a.s_idx])) : v;
             }
         } else {  // tile (0, tb): side row r32, column of the host block
             const int col = 32 * tile + (l & 31);
             if (r32 >= a.s_r_lo && r32 < a.s_r_hi && col < jb.col_count) {
-                const float unscale = scaled ? nh_pow2i(-region_shift(a.amax[a.s_idx]) - region_shift(a.bmax[jb.b_idx])) : 1.0f;
-                a.g_params[jb.s_w_off + (int64_t)(r32 - a.s_r_lo) * jb.s_w_ld + col] = sum_partials(E + se) * unscale;
+                const float v = sum_partials(E + se);
+                a.g_params[jb.s_w_off + (int64_t)(r32 - a.s_r_lo) * jb.s_w_ld + col] =
+                    scaled ? unscale2(v, region_shift(a.amax[a.s_idx]), region_shift(a.bmax[jb.b_idx])) : v;
             }
         }
     } else if (SA && e < NALL) {  // the side block's bias: threads t and t + SA of every workgroup summed side row t

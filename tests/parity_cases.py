@@ -414,6 +414,53 @@ def case_mlp_backward(b, names=None, m=150, precision=0, g_scale=1.0, w_gain=1.0
         b.lib.plan_destroy(plan)
 
 
+def case_f16x3_range_extremes(b, m=120):
+    """The edges of the fp16-piece bookkeeping (round 5).  (i) Cotangents of 1e-30, 1e-33 and of fp32-SUBNORMAL size (1e-39):
+    the per-sample exponent would be 113 / 123 / undefined -- it is clamped at 110 / the sample counts as all-zero (mlp_f16w.hip
+    exp_for): every gradient stays finite; at 1e-30 it is no further from the fp64 gradient than torch's own fp32 backward (x 3), at 1e-33 within 2e-2 of
+    max|g| (fewer piece bits below 2^-97).  This case found round 4's zero-sample region bound (mlp_f16w.hip ZERO_EXP): with cotangents below
+    ~1e-20 the fp16-piece weight gradient lost bits, below ~1e-25 everything.  (ii) Weights
+    beyond fp16's range once scaled by 2^8 (|w| up to ~440): k_pack_f16x3 saturates the pieces instead of writing Inf -- outputs finite
+    (and meaningless: the limit |w| < 255.9 is in include/nerfhip.h); the fp32 kernels on the same weights agree with the oracle."""
+    cfg = MLP_GEOMETRIES["default4x128"]
+    dx, dd = O.model_dims(cfg)
+    plan, params, flat, packed = mlp_setup(b, cfg, seed=41, precision=F16X3_TRAIN)
+    gen = rng(42)
+    x = torch.randn(m, dx + dd, generator=gen)
+    keep = O.mlp_relu_margin(params, x, cfg) > 1e-5
+    x = x[keep].contiguous()
+    go1 = torch.randn(x.shape[0], 4, generator=gen)
+    _, stash = b.mlp_fwd(plan, packed, x.numpy(), want_stash=True)
+    for g_scale, compare in ((1e-30, True), (1e-33, True), (1e-39, False)):
+        go = go1 * g_scale
+        grads = b.unflatten(plan, b.mlp_bwd(plan, packed, go.numpy(), stash))
+        assert all(np.isfinite(v).all() for v in grads.values()), g_scale
+        if compare:
+            # the yardstick: torch's OWN fp32 backward against fp64 on the same cotangents -- down here the d(pre-activation) values of the
+            # deep layers reach fp32's subnormal range (2^-110 times what the transposed layers damp), whatever multiplies them
+            p64 = {k: v.double().requires_grad_(True) for k, v in params.items()}
+            (O.mlp_forward(p64, x.double(), cfg) * go.double()).sum().backward()
+            p32 = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+            (O.mlp_forward(p32, x, cfg) * go).sum().backward()
+            for k, v in p64.items():
+                ref = v.grad.numpy()
+                scale = float(np.abs(ref).max())
+                e_hip = float(np.abs(grads[k] - ref).max()) / scale
+                e_t32 = float(np.abs(p32[k].grad.numpy() - ref).max()) / scale
+                note("f16x3_tiny_cotangents_%g_%s_%s" % (g_scale, k, b.name), hip_vs_fp64=e_hip, torch_fp32_vs_fp64=e_t32)
+                # (1e-30: inside the clamp's full-precision range give or take 3 bits; 1e-33: 13 bits below it -- the pieces of the deep
+                # layers' d(pre-activation) keep ~12 bits: documented in mlp_f16w.hip / DESIGN 8.8, bounded here)
+                assert e_hip <= (3.0 * e_t32 + 1e-4 if g_scale >= 1e-30 else 2e-2), (k, g_scale, e_hip, e_t32)
+        else:  # (cotangents below fp32's normal range: whatever survives is that small)
+            assert max(float(np.abs(v).max()) for v in grads.values()) < 1e-30
+    b.lib.plan_destroy(plan)
+    plan, params, flat, packed = mlp_setup(b, cfg, seed=41, precision=F16X3, w_gain=5000.0)
+    assert max(float(v.abs().max()) for k, v in params.items() if k.endswith("weight")) > 256.0
+    got, _ = b.mlp_fwd(plan, packed, x.numpy())
+    assert np.isfinite(got).all()
+    b.lib.plan_destroy(plan)
+
+
 def case_mlp_input_grad(b, names=None, m=150, precision=0):
     """d(loss)/d(x) of FlexibleNeRFModel.forward vs the oracle's autograd (x enters layer1, the skip layers, layers_dir)."""
     for name in names or ("default4x128", "fern8x128_skip3_L6", "novw4x128", "odd5x99_skip2"):

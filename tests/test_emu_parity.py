@@ -109,6 +109,10 @@ def test_mlp_f16x3_training_levels_hold_the_fp32_gradient_bounds(emu):
                             precision=P.F16X3_TRAIN)  # (128-wide nets: the four full blocks reach k_wgrad_f16x3<128, 128>)
 
 
+def test_f16x3_range_extremes(emu):
+    P.case_f16x3_range_extremes(emu, m=60)
+
+
 def test_mlp_f16x3_64_wide_instances(emu):
     """k_mlp_fwd_f16x3w<64> / k_mlp_dgrad_f16x3w<64>: four output tiles, two 32-deep k-blocks, whole layers inside one chunk."""
     names = ("llff4x64_skip3_L6", "novw3x64_skip1", "one_layer_64")

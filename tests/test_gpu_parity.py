@@ -114,6 +114,10 @@ def test_mlp_f16x3_training_levels_hold_the_fp32_gradient_bounds(gpu, level):
                             tag="f16x3_%s_default200_white_noise1" % level, grad_tol=T.bound("unit.render_grad.default200_white_noise1", P.ARITH_NAME[prec]), precision=prec)  # (test_default_model_render_white_background's)
 
 
+def test_f16x3_range_extremes(gpu):
+    P.case_f16x3_range_extremes(gpu, m=1500)
+
+
 def test_mlp_f16x3_64_wide_instances(gpu):
     """The 64-wide instances of the fp16-piece kernels (config/fern.yml's declared 4 x 64, config/llff.yml; round 5): what
     test_mlp_64_wide_instances / test_render_64_wide_llff_config_vs_oracle assert of the fp32 kernels, every training level (the

@@ -64,7 +64,13 @@ def main():
     image, pose = scene(dev)
     _, _, eng = make_engine(dev, world, rank, overlap)
     grad0, pc, pf, loss = run(eng, image, pose, steps, n, dev)
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), grad0=grad0, pc=pc, pf=pf, loss=loss)
+    # the self-diagnosis of bench.py's N-GPU line (TrainEngine.collective_times_ms): times the exchange on a zero scratch, after the
+    # step's own collectives -- the live gradient must come back untouched and finite (it used to be summed world^23 times)
+    before = eng.grad.clone()
+    coll = eng.collective_times_ms(reps=2, warmup=1)
+    assert torch.equal(eng.grad, before) and bool(torch.isfinite(eng.grad).all()), "collective_times_ms touched the gradient"
+    assert coll["fine"] is not None and coll["coarse"] is not None and coll["fine"] >= 0.0 and coll["coarse"] >= 0.0, coll
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), grad0=grad0, pc=pc, pf=pf, loss=loss, coll=np.array([coll["fine"], coll["coarse"]]))
     torch.distributed.destroy_process_group()
 
 

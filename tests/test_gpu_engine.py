@@ -173,6 +173,7 @@ def test_two_rank_engine_stays_in_lockstep_and_matches_one_process(tmp_path, ove
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     for k in ("grad0", "pc", "pf"):
         assert np.array_equal(r0[k], r1[k]), "ranks diverged: " + k
+    assert r0["coll"].shape == (2,) and np.isfinite(r0["coll"]).all()   # (collective_times_ms ran on both ranks and left the gradient alone)
     image, pose = D.scene(dev)
     _, _, eng = D.make_engine(dev, 1, 0, bool(overlap))
     grad0, pc, pf, _ = D.run(eng, image, pose, steps, 2 * n, dev)

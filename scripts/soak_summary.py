@@ -31,11 +31,11 @@ n = len(last)
 mean = sum(last) / n
 if n > 1:
     sd = math.sqrt(sum((d - mean) ** 2 for d in last) / (n - 1))
-    t = {2: 12.706, 3: 4.303, 4: 3.182, 5: 2.776, 6: 2.571, 7: 2.447, 8: 2.365}.get(n, 2.0)
-    P("\nf16x3 - fp32 at iteration %s: mean %+.3f dB, 95 %% interval [%+.2f, %+.2f] (Student t, n = %d pairs: with two pairs the interval says little beyond" %
+    t = {2: 12.706, 3: 4.303, 4: 3.182, 5: 2.776, 6: 2.571, 7: 2.447, 8: 2.365}.get(n, 2.0)  # (two-sided 95 %, n - 1 degrees of freedom)
+    P("\nf16x3 - fp32 at iteration %s: mean %+.3f dB, 95 %% interval [%+.2f, %+.2f] (Student t, n = %d pairs);" %
       (its[-1], mean, mean - t * sd / math.sqrt(n), mean + t * sd / math.sqrt(n), n))
     alld = [r["arms"]["engine_f16tr"]["checkpoints"][i]["val_psnr"] - r["arms"]["engine"]["checkpoints"][i]["val_psnr"] for r in runs for i in its]
-    P("containing 0); over all %d checkpoint pairs of both seeds: mean %+.3f dB, largest |delta| %.3f dB, sign + %d / - %d" %
+    P("over all %d checkpoint pairs: mean %+.3f dB, largest |delta| %.3f dB, sign + %d / - %d" %
       (len(alld), sum(alld) / len(alld), max(abs(d) for d in alld), sum(d > 0 for d in alld), sum(d < 0 for d in alld)))
 P("training wall time for %s iterations (validation and diagnostics excluded): fp32 %s s, f16x3 %s s" %
   (its[-1], [r["arms"]["engine"]["checkpoints"][its[-1]]["train_wall_s"] for r in runs], [r["arms"]["engine_f16tr"]["checkpoints"][its[-1]]["train_wall_s"] for r in runs]))
@@ -60,8 +60,12 @@ for r in runs:
     P("  region bounds recorded by the kernels (log2): stash regions %d .. %d, d(pre-activation) regions %d .. %d" % (min(sb), max(sb), min(gb), max(gb)))
     P("  forward on fp16 pieces vs torch fp32, max over the sub-batch, of max|raw|: %.1e .. %.1e" % (min(dg[k]["kernel_raw_vs_torch"] for k in ks), max(dg[k]["kernel_raw_vs_torch"] for k in ks)))
     d = [dg[k]["kernel_grad_vs_torch_worst_rel"] for k in ks]
-    P("  fp16-piece gradient vs torch's fp32 gradient on that sub-batch, worst tensor, of max|g|, UNFILTERED: median %.1e; per diagnostic: %s" %
-      (sorted(d)[len(d) // 2], " ".join("%.0e" % v for v in d)))
+    filt = "relu_filter_kept_fraction" in dg[ks[0]]
+    P("  fp16-piece gradient vs torch's fp32 gradient on that sub-batch, worst tensor, of max|g|, %s: median %.1e, max %.1e; per diagnostic: %s" %
+      ("on the samples that pass the ReLU-margin filter (kept %.2f .. %.2f)" % (min(dg[k]["relu_filter_kept_fraction"] for k in ks),
+                                                                               max(dg[k]["relu_filter_kept_fraction"] for k in ks)) if filt
+       else "UNFILTERED (the first two seeds ran before the diagnostic filtered: 2-9e-6, or one flipped ReLU branch)",
+       sorted(d)[len(d) // 2], max(d), " ".join("%.0e" % v for v in d)))
 if short:
     s = json.load(open(short))
     dg = s["arms"]["engine_f16tr"]["diagnostics"]

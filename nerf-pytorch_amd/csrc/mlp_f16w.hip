@@ -215,6 +215,11 @@ NH_DEVICE void gemm_w(WCtx& cx, const nh_f16x8* ah, const nh_f16x8* al, const nh
                       int s_in = 0, int s_x = 0, int cap = NO_CAP, int* s_out = nullptr, MaskW* bits_out = nullptr, int ridx = -1,
                       float bias_mul = 0.0f, bool use_bias_mul = false) {
     constexpr int NK = NKA + NKB, NBLK = NK * NT, CB = WShape<W>::CB, BUF = WShape<W>::BUF, NCH = (NBLK + CB - 1) / CB;
+    // A sample whose hidden inputs are ALL ZERO (a dead layer: ZERO_EXP, which no cap touches -- step_exp) carries any exponent equally
+    // well: in a gemm that also reads encodings it takes theirs, so that the encoding pieces are not rescaled by 2^(60 - s_x) out of
+    // fp16's range.  What the stored input rows say about their region is still "nothing" (s_note).
+    const int s_note = s_in;
+    if (DYN && NKA > 0 && NKB > 0 && s_in == ZERO_EXP) s_in = s_x;
     constexpr int NTS = STORE ? 2 * NKA : 0;  // input row tiles a training launch stores (STORE: in_rows is not NULL)
     // encoding pieces made at 2^s_x, wanted at the hidden inputs' 2^s_in (<= s_x): rescaled once (v_pk_mul_f16 by a power of two)
     constexpr bool RESCALE = DYN && NKA > 0 && NKB > 0;
@@ -363,7 +368,7 @@ NH_DEVICE void gemm_w(WCtx& cx, const nh_f16x8* ah, const nh_f16x8* al, const nh
         while (dnext < dpieces) dma_step();  // (whatever the pairs did not cover: short chunks in front of long ones)
         cx.buf ^= 1;
     }
-    if (NTS > 0 && cx.wrm && ridx >= 0) note_region(cx, ridx, s_in);
+    if (NTS > 0 && cx.wrm && ridx >= 0) note_region(cx, ridx, s_note);
     if (EPI != 0) {
         float mul = 1.0f / WS;
 #ifdef NHW_EXP_NO_MAX  // (NH_DIAG builds only, wrong results: what the per-sample exponent search costs)

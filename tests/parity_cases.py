@@ -461,6 +461,44 @@ def case_f16x3_range_extremes(b, m=120):
     b.lib.plan_destroy(plan)
 
 
+def case_f16x3_dead_layers(b, m=120):
+    """Samples whose hidden activations are ALL ZERO in front of a gemm that also reads encodings (the direction layer behind a dead
+    fc_feat; a skip layer behind a dead layers_xyz): the reserved zero exponent must not reach the encoding rescale (2^(60 - s_x) is out
+    of fp16's range: the eval test on the trained lego nets met it as wrong colours on 78 rays, round 5).  Forward and every gradient
+    against the oracle, inference and training plans."""
+    for name, dead in (("default4x128", "fc_feat.bias"), ("deep8x128_skip4", "layers_xyz.3.bias"), ("northstar8x256", "layers_xyz.3.bias")):
+        cfg = MLP_GEOMETRIES[name]
+        dx, dd = O.model_dims(cfg)
+        for precision in (F16X3, F16X3_TRAIN):
+            plan = b.make_plan(cfg, precision)
+            params = O.init_params(cfg, seed=51)
+            params[dead] = params[dead] - 30.0            # every unit of that layer dead for every sample (pre-activations are O(1))
+            flat = b.flatten_params(plan, {k: v.numpy() for k, v in params.items()})
+            packed = b.pack(plan, flat)
+            gen = rng(52)
+            x = torch.randn(m, dx + dd, generator=gen)
+            go = torch.randn(m, 4, generator=gen)
+            want = O.mlp_forward(params, x, cfg).numpy()
+            if precision == F16X3:
+                got, _ = b.mlp_fwd(plan, packed, x.numpy())
+                close(got, want, *TL.bound("unit.mlp_fwd", "f16x3"), what="dead layer fwd " + name)
+            else:
+                keep = O.mlp_relu_margin(params, x, cfg) > 1e-6
+                x, go = x[keep].contiguous(), go[keep].contiguous()
+                assert x.shape[0] >= m // 4, (name, x.shape[0])
+                p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+                (O.mlp_forward(p, x, cfg) * go).sum().backward()
+                got, stash = b.mlp_fwd(plan, packed, x.numpy(), want_stash=True)
+                close(got, O.mlp_forward(params, x, cfg).numpy(), *TL.bound("unit.mlp_fwd", "f16x3_train"), what="dead layer fwd (train) " + name)
+                grads = b.unflatten(plan, b.mlp_bwd(plan, packed, go.numpy(), stash))
+                tol = TL.bound("unit.mlp_bwd", "f16x3_train")["tol"]
+                for k, v in p.items():
+                    ref = v.grad.numpy()
+                    scale = float(np.abs(ref).max()) + 1e-12
+                    close(grads[k], ref, tol * scale + 1e-7, 10 * tol, what="dead layer bwd %s %s" % (name, k))
+            b.lib.plan_destroy(plan)
+
+
 def case_mlp_input_grad(b, names=None, m=150, precision=0):
     """d(loss)/d(x) of FlexibleNeRFModel.forward vs the oracle's autograd (x enters layer1, the skip layers, layers_dir)."""
     for name in names or ("default4x128", "fern8x128_skip3_L6", "novw4x128", "odd5x99_skip2"):

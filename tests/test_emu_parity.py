@@ -109,6 +109,10 @@ def test_mlp_f16x3_training_levels_hold_the_fp32_gradient_bounds(emu):
                             precision=P.F16X3_TRAIN)  # (128-wide nets: the four full blocks reach k_wgrad_f16x3<128, 128>)
 
 
+def test_f16x3_dead_layers(emu):
+    P.case_f16x3_dead_layers(emu, m=60)
+
+
 def test_f16x3_range_extremes(emu):
     P.case_f16x3_range_extremes(emu, m=60)
 

@@ -112,7 +112,7 @@ struct MaskW {
 };
 
 // two accumulator tiles (2 kb, 2 kb + 1) -> k-block kb of the next layer's operand pieces: hi = f16(v), lo = f16(v - hi), v = acc *
-// mul; BITS: the ReLU bits of the values as the next layer consumes them (hi > 0), shift-accumulated in register order
+// mul; BITS: the ReLU bits of the VALUES (v > 0: the fp32 kernels' definition), shift-accumulated in register order
 template <bool RELU, bool BITS>
 NH_DEVICE void convert_pair(const f32x4& a0, const f32x4& a1, nh_f16x8& oh, nh_f16x8& ol, float mul, MaskW& bits, int r0) {
 #ifdef NHW_EXP_NO_EPI  // (NH_DIAG builds only, wrong results: what the kernel costs without the conversions)
@@ -128,8 +128,12 @@ NH_DEVICE void convert_pair(const f32x4& a0, const f32x4& a1, nh_f16x8& oh, nh_f
         oh[e] = hi;
         ol[e] = nh_to_f16(v - nh_from_f16(hi));
         if (BITS) {
+            // the ReLU bit of the VALUE (v > 0; v is already >= 0 here), as the fp32 kernels record it -- not of its high piece: where a
+            // cap holds a sample's exponent down to its encodings' (skip layers, layers_dir), activations below 2^-24 of the encodings
+            // flush to zero pieces, and a bit taken from the piece would gate their unit's gradient off although the unit is active
+            // (found by a scale fuzz on the emulator: weights x 1e-3 with zero biases lost fc_feat's / layer1's whole gradient)
             const int r = r0 + e;
-            bits.w[r >> 5] = (bits.w[r >> 5] << 1) | (nh_from_f16(hi) > 0.0f ? 1u : 0u);
+            bits.w[r >> 5] = (bits.w[r >> 5] << 1) | nh_pos_bit(v);
         }
     }
 }

@@ -461,6 +461,50 @@ def case_f16x3_range_extremes(b, m=120):
     b.lib.plan_destroy(plan)
 
 
+def case_f16x3_scale_fuzz(b, m=40, names=("default4x128", "deep8x128_skip4", "novw4x128", "llff4x64_skip3_L6"), grid=None):
+    """Inputs x 1e-6 ... 1e3, weights x 1e-3 ... 30, biases x 0 ... 100 (and one all-zero input row): the fp16-piece training plans
+    against the oracle in fp64, with torch's own fp32 forward / backward on the same numbers as the yardstick -- forward within 10x of
+    torch's distance (+ 2e-6 of the output scale), every gradient tensor within 30x (+ 1e-4 of max|g|), everything finite.  The corner
+    weights x 1e-3 / zero biases found round 5's ReLU-bit bug: activations far below their sample's capped exponent flushed to zero PIECES
+    and the bit was taken from the piece, so fc_feat's (layers_dir behind it) and layer1's (a skip layer behind it) whole gradient was gated off."""
+    import itertools
+    grid = grid or list(itertools.product((1e-6, 1.0, 1e3), (1e-3, 1.0, 30.0), (0.0, 1.0, 100.0)))
+    for name in names:
+        cfg = MLP_GEOMETRIES[name]
+        dx, dd = O.model_dims(cfg)
+        for x_scale, w_gain, b_gain in grid:
+            plan = b.make_plan(cfg, F16X3_TRAIN)
+            params = {k: (v * w_gain if k.endswith("weight") else v * b_gain) for k, v in O.init_params(cfg, seed=61).items()}
+            packed = b.pack(plan, b.flatten_params(plan, {k: v.numpy() for k, v in params.items()}))
+            gen = rng(62)
+            x = torch.randn(m, dx + dd, generator=gen) * x_scale
+            x[3] = 0.0
+            go = torch.randn(m, 4, generator=gen)
+            p64 = {k: v.double().requires_grad_(True) for k, v in params.items()}
+            y64 = O.mlp_forward(p64, x.double(), cfg)
+            (y64 * go.double()).sum().backward()
+            p32 = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+            y32 = O.mlp_forward(p32, x, cfg)
+            (y32 * go).sum().backward()
+            got, stash = b.mlp_fwd(plan, packed, x.numpy(), want_stash=True)
+            grads = b.unflatten(plan, b.mlp_bwd(plan, packed, go.numpy(), stash))
+            what = (name, x_scale, w_gain, b_gain)
+            assert np.isfinite(got).all() and all(np.isfinite(v).all() for v in grads.values()), what
+            ys = float(y64.detach().abs().max()) + 1e-300
+            e_f = float(np.abs(got - y64.detach().numpy()).max()) / ys
+            e_f32 = float((y32.detach().double() - y64.detach()).abs().max()) / ys
+            assert e_f <= 10.0 * e_f32 + 2e-6, what + (e_f, e_f32)
+            for k, v in p64.items():
+                ref = v.grad.numpy()
+                sc = float(np.abs(ref).max())
+                if sc == 0.0:
+                    continue
+                e = float(np.abs(grads[k] - ref).max()) / sc
+                e32 = float(np.abs(p32[k].grad.numpy() - ref).max()) / sc
+                assert e <= max(30.0 * e32, 1e-4), what + (k, e, e32)
+            b.lib.plan_destroy(plan)
+
+
 def case_f16x3_dead_layers(b, m=120):
     """Samples whose hidden activations are ALL ZERO in front of a gemm that also reads encodings (the direction layer behind a dead
     fc_feat; a skip layer behind a dead layers_xyz): the reserved zero exponent must not reach the encoding rescale (2^(60 - s_x) is out

@@ -109,6 +109,12 @@ def test_mlp_f16x3_training_levels_hold_the_fp32_gradient_bounds(emu):
                             precision=P.F16X3_TRAIN)  # (128-wide nets: the four full blocks reach k_wgrad_f16x3<128, 128>)
 
 
+def test_f16x3_scale_fuzz(emu):
+    """(the corners on the emulator; the GPU suite walks the whole 3 x 3 x 3 grid on four geometries)"""
+    P.case_f16x3_scale_fuzz(emu, m=24, names=("default4x128", "deep8x128_skip4"),
+                            grid=[(1.0, 1e-3, 0.0), (1e-6, 1e-3, 0.0), (1e3, 30.0, 100.0), (1e-6, 30.0, 1.0), (1.0, 1.0, 1.0)])
+
+
 def test_f16x3_dead_layers(emu):
     P.case_f16x3_dead_layers(emu, m=60)
 

@@ -114,6 +114,10 @@ def test_mlp_f16x3_training_levels_hold_the_fp32_gradient_bounds(gpu, level):
                             tag="f16x3_%s_default200_white_noise1" % level, grad_tol=T.bound("unit.render_grad.default200_white_noise1", P.ARITH_NAME[prec]), precision=prec)  # (test_default_model_render_white_background's)
 
 
+def test_f16x3_scale_fuzz(gpu):
+    P.case_f16x3_scale_fuzz(gpu, m=700)
+
+
 def test_f16x3_dead_layers(gpu):
     P.case_f16x3_dead_layers(gpu, m=1500)
 

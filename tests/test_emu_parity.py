@@ -112,7 +112,7 @@ def test_mlp_f16x3_training_levels_hold_the_fp32_gradient_bounds(emu):
 def test_f16x3_scale_fuzz(emu):
     """(the corners on the emulator; the GPU suite walks the whole 3 x 3 x 3 grid on four geometries)"""
     P.case_f16x3_scale_fuzz(emu, m=24, names=("default4x128", "deep8x128_skip4"),
-                            grid=[(1.0, 1e-3, 0.0), (1e-6, 1e-3, 0.0), (1e3, 30.0, 100.0), (1e-6, 30.0, 1.0), (1.0, 1.0, 1.0)])
+                            grid=[(1.0, 1e-3, 0.0), (1e-6, 1e-3, 0.0), (1e3, 30.0, 100.0), (1e-6, 30.0, 1.0), (1.0, 3e-2, 0.0), (1.0, 1.0, 1.0)])
 
 
 def test_f16x3_dead_layers(emu):

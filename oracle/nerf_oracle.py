@@ -240,7 +240,7 @@ def mlp_forward(params, x, cfg):
     return F.linear(h, params["fc_out.weight"], params["fc_out.bias"])
 
 
-def mlp_relu_margin(params, x, cfg):
+def mlp_relu_margin(params, x, cfg, per_layer=False):
     """Per input row: the smallest |pre-activation| among everything FlexibleNeRFModel.forward (nerf/models.py:233-256)
     passes through a ReLU, relative to the largest one of the row.  A row whose margin is ~1e-7 has a unit whose ReLU
     branch is decided by fp32 round-off: two fp32 implementations with different summation orders may take different
@@ -262,6 +262,8 @@ def mlp_relu_margin(params, x, cfg):
         pres.append(F.linear(torch.cat((F.relu(pre), x[..., dx:]), dim=-1), params["layers_dir.0.weight"], params["layers_dir.0.bias"]))
     if not pres:
         return torch.ones(x.shape[0])
+    if per_layer:  # each layer's smallest |pre-activation| relative to THAT layer's largest (nets whose layers differ by orders of magnitude)
+        return torch.stack([p.abs().min(dim=-1).values / (p.abs().max(dim=-1).values + 1e-300) for p in pres], dim=0).min(dim=0).values
     allp = torch.cat(pres, dim=-1)
     return allp.abs().min(dim=-1).values / (allp.abs().max(dim=-1).values + 1e-30)
 

@@ -485,6 +485,14 @@ def case_f16x3_scale_fuzz(b, m=40, names=("default4x128", "deep8x128_skip4", "no
             x = torch.randn(m, dx + dd, generator=gen) * x_scale
             x[3] = 0.0
             go = torch.randn(m, 4, generator=gen)
+            # (rows with a ReLU input within 1e-5, relative, of zero are dropped as in case_mlp_backward: with zero biases and m = 700 one
+            # such unit moves a gradient tensor by 1e-2 of max|g| for the fp32 kernels and the fp16 pieces alike -- met on the emulator)
+            keep = O.mlp_relu_margin(params, x, cfg, per_layer=True) > 1e-5
+            x, go = x[keep].contiguous(), go[keep].contiguous()
+            if x.shape[0] < m // 4:
+                failures.append((name, x_scale, w_gain, b_gain, "filter left %d of %d rows" % (x.shape[0], m)))
+                b.lib.plan_destroy(plan)
+                continue
             p64 = {k: v.double().requires_grad_(True) for k, v in params.items()}
             y64 = O.mlp_forward(p64, x.double(), cfg)
             (y64 * go.double()).sum().backward()

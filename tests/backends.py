@@ -299,7 +299,7 @@ class Backend:
     def render(self, plan_c, plan_f, packed_c, packed_f, rays, opt, rand=None, seed=0, ray_offset=0, training=False,
                g_rgb=None, want_regions=(), ray_grad_params=None):
         """opt: dict(num_coarse, num_fine, perturb, lindisp, white_background, noise_std).  Returns dict of outputs
-        (+ flat grads 'g_params_coarse/fine' when g_rgb = (g_c, g_f) is given)."""
+        (+ flat grads 'g_params_coarse/fine' when g_rgb = (g_c, g_f), or a callable that makes them from the outputs, is given)."""
         rand = rand or {}
         n, stride = rays.shape
         nc, nf = opt["num_coarse"], opt["num_fine"]
@@ -329,6 +329,8 @@ class Backend:
         if nf == 0:
             for k in names[4:]:
                 out[k] = None
+        if callable(g_rgb):  # g_rgb(outputs) -> (g_coarse, g_fine): the loss between this forward and its backward
+            g_rgb = g_rgb(out)
         if g_rgb is not None:
             gc, gf = self.dev(np.ascontiguousarray(g_rgb[0], np.float32)), self.devopt(g_rgb[1])
             gpc = self.empty((self.lib.plan_num_params(plan_c),))

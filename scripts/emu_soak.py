@@ -52,6 +52,7 @@ def pose_spherical(theta_deg, phi_deg, radius):
 
 
 def teacher_views(n_train=12, n_val=2):
+    CFG = B.model_cfg()  # (the teacher's own geometry, whatever the students')
     w = np.load(WEIGHTS)
     par_c = {k[2:]: torch.from_numpy(w[k]) for k in w.files if k.startswith("c_")}
     par_f = {k[2:]: torch.from_numpy(w[k]) for k in w.files if k.startswith("f_")}
@@ -158,8 +159,13 @@ def main():
     ap.add_argument("--init", choices=("random", "pretrained"), default="random",
                     help="pretrained: start from the teacher's own weights -- the late-training regime (saturated densities, "
                          "tiny cotangents) from the first iteration on")
+    ap.add_argument("--layers", type=int, default=4, help="students' num_layers (skip 4; --init random only): 8 makes the skip "
+                    "layer's xyz columns guests of a hidden x hidden block in k_wgrad_f16x3")
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
+    if args.layers != 4:
+        assert args.init == "random", "the pretrained weights are 4 x 128"
+        CFG.update(B.model_cfg(num_layers=args.layers))
     torch.set_num_threads(1)
     b = B.EmuBackend()
     rays_all, imgs, train, val = teacher_views()
@@ -167,8 +173,8 @@ def main():
     arm = Arm(b, prec, args.seed, args.nc, args.nf, args.noise, args.init)
     ref32 = Arm(b, L.PRECISION_FP32, args.seed, args.nc, args.nf, args.noise) if prec else None  # (its plans only: diagnostics)
     g = torch.Generator().manual_seed(1000 + args.seed)  # the data stream: identical in every arm of a seed
-    rec = dict(args=vars(args), cfg="4x128 skip 4, %d + %d samples, %d rays / iteration, %dx%d views of the lego-lowres teacher, white "
-               "background" % (args.nc, args.nf, args.rays, SIDE, SIDE), lib_sources_sha16=None, checkpoints=[], nonfinite=[], losses=[])
+    rec = dict(args=vars(args), cfg="%dx128 skip 4, %d + %d samples, %d rays / iteration, %dx%d views of the lego-lowres teacher, white "
+               "background" % (args.layers, args.nc, args.nf, args.rays, SIDE, SIDE), lib_sources_sha16=None, checkpoints=[], nonfinite=[], losses=[])
     try:
         import bench
         rec["lib_sources_sha16"] = bench.lib_sources_sha16()

@@ -161,11 +161,14 @@ def main():
                          "tiny cotangents) from the first iteration on")
     ap.add_argument("--layers", type=int, default=4, help="students' num_layers (skip 4; --init random only): 8 makes the skip "
                     "layer's xyz columns guests of a hidden x hidden block in k_wgrad_f16x3")
+    ap.add_argument("--hidden", type=int, default=128, help="students' hidden_size (--init random only): 64 = the 64-wide kernel instances")
+    ap.add_argument("--skip", type=int, default=4)
+    ap.add_argument("--fx", type=int, default=10, help="students' num_encoding_fn_xyz (config/fern.yml: 6)")
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
-    if args.layers != 4:
-        assert args.init == "random", "the pretrained weights are 4 x 128"
-        CFG.update(B.model_cfg(num_layers=args.layers))
+    if (args.layers, args.hidden, args.skip, args.fx) != (4, 128, 4, 10):
+        assert args.init == "random", "the pretrained weights are 4 x 128, skip 4, 10 frequencies"
+        CFG.update(B.model_cfg(num_layers=args.layers, hidden_size=args.hidden, skip_connect_every=args.skip, num_encoding_fn_xyz=args.fx))
     torch.set_num_threads(1)
     b = B.EmuBackend()
     rays_all, imgs, train, val = teacher_views()
@@ -173,8 +176,8 @@ def main():
     arm = Arm(b, prec, args.seed, args.nc, args.nf, args.noise, args.init)
     ref32 = Arm(b, L.PRECISION_FP32, args.seed, args.nc, args.nf, args.noise) if prec else None  # (its plans only: diagnostics)
     g = torch.Generator().manual_seed(1000 + args.seed)  # the data stream: identical in every arm of a seed
-    rec = dict(args=vars(args), cfg="%dx128 skip 4, %d + %d samples, %d rays / iteration, %dx%d views of the lego-lowres teacher, white "
-               "background" % (args.layers, args.nc, args.nf, args.rays, SIDE, SIDE), lib_sources_sha16=None, checkpoints=[], nonfinite=[], losses=[])
+    rec = dict(args=vars(args), cfg="%dx%d skip %d, %d xyz frequencies, %d + %d samples, %d rays / iteration, %dx%d views of the lego-lowres teacher, white "
+               "background" % (args.layers, args.hidden, args.skip, args.fx, args.nc, args.nf, args.rays, SIDE, SIDE), lib_sources_sha16=None, checkpoints=[], nonfinite=[], losses=[])
     try:
         import bench
         rec["lib_sources_sha16"] = bench.lib_sources_sha16()

@@ -15,7 +15,8 @@ for path in sorted(glob.glob(os.path.join(d, "*.json"))):
             runs.setdefault(name[:-len(arm) - 1], {})[arm] = json.load(open(path))
 
 print("# scripts/emu_soak.py: the SHIPPED kernel sources (tests/emu: every kernel of the step executed by the CPU wave emulator) trained for")
-print("# real: 4x128 nets, 32 + 32 samples per ray, 32 rays per iteration, Adam, the lego-lowres teacher at 48x48 on a white background;")
+print("# real: 4x128 nets (one pair 8x128; three pairs 4x64 skip 3 with 6 frequencies = config/fern.yml's declared geometry, on the 64-wide")
+print("# kernel instances), 32 + 32 samples per ray, 32 rays per iteration, Adam, the lego-lowres teacher at 48x48 on a white background;")
 print("# arms fp32 plans / NERFHIP_PRECISION_F16X3_TRAIN plans: same initial weights, views, pixels, draws.  `random`: torch's default init,")
 print("# lr 5e-3 (early training); `pretrained`: started from the reference's own 200 000-iteration lego-lowres weights at that iteration's")
 print("# lr 7.9e-4 (late training: saturated densities, background rays with exactly zero cotangents).  Gradient columns: worst tensor's")

@@ -276,7 +276,7 @@ def kernel_kind(name):
         return "dgrad"
     if "k_wgrad_f16x3" in name:
         return "wgrad_big"    # (--precision f16x3_train: the hidden x hidden blocks on the fp16 MFMAs)
-    if "k_wgrad<MD>[thin" in name:
+    if "k_wgrad<" in name and "[thin" in name:
         return "wgrad_thin"   # (... and what is left to the fp32 kernel then)
     if "k_wgrad<" in name:
         return "wgrad"
@@ -393,6 +393,10 @@ def main():
                          "forward; --mode train --precision f16x3_fwd the training forward, f16x3_fwd_dgrad + the data-gradient chain, "
                          "f16x3_train + the large weight-gradient blocks.  A+B: coarse net A, fine net B.  Separate, labelled lines: "
                          "the driver's default stays fp32")
+    ap.add_argument("--compact", action="store_true",
+                    help="train: compacted backward (FlexibleNeRFModel.set_backward_compaction): data and weight gradient over the sample "
+                         "points whose d(loss)/d(raw) row is not all zero.  A labelled line: it states the zero fraction of the step it "
+                         "timed and prices the backward kernels on the FLOPs they executed; the driver's default stays dense")
     ap.add_argument("--gather", action="store_true", help="eval: rank 0 also receives every pose's rows (output plumbing)")
     ap.add_argument("--no-kernel-profile", action="store_true", help="do not bracket the launches of the timed region with HIP events (no "
                     "per-kernel times, no roofline object): what the events cost a short step")
@@ -478,6 +482,9 @@ def main():
             mc.set_training_precision(prec_c)
         if prec_f != "fp32":
             mf.set_training_precision(prec_f)
+        if args.compact:
+            mc.set_backward_compaction(True)
+            mf.set_backward_compaction(True)
         strong = args.global_rays > 0
         if strong:
             lo, hi = N.parallel.shard_bounds(args.global_rays, rank, world)
@@ -552,6 +559,8 @@ def main():
             allreduce_ms = eng.collective_times_ms()
     dt = max(per_rank)
     loss_host = [float(v) for v in last.cpu()] if args.mode == "train" else None
+    # compacted backward: the sample points the LAST timed step's backward kept, per net (two words per net of its workspace)
+    kept = eng.backward_sample_counts() if (args.mode == "train" and args.compact) else None
     # What the per-launch HIP events of the timed region cost: the same K steps once more WITHOUT them (N = 1 only).  Nothing at
     # 27 ms per step; 0.28 ms of a 2.0-ms fern step (a step is ~40 launches, each with two event records on the host's path).
     unprofiled = None
@@ -597,17 +606,23 @@ def main():
             w[0] += flops
             w[1] += nbytes
             w[2] += launches
-        for m, prec in ((m_c, prec_c), (m_f, prec_f)):
+        # compacted backward (--compact): the backward kernels are priced on the sample points they EXECUTED -- those the last timed
+        # step's backward kept -- so that a fraction of a roofline can never exceed 1 by skipping work
+        kept_c, kept_f = m_c, m_f
+        if kept is not None:
+            kept_c = kept["coarse"][0] if kept["coarse"] else m_c
+            kept_f = kept["fine"][0] if kept["fine"] else m_f
+        for m, mb, prec in ((m_c, kept_c, prec_c), (m_f, kept_f, prec_f)):
             fmt, level = precision_level(prec)
             add("fwd", fmt if level >= 1 else "fp32", 2.0 * fwd_macs * m, stash_b * m)
             if args.mode != "train":
                 continue
-            add("dgrad", fmt if level >= 3 else "fp32", 2.0 * dgrad_macs * m, dgrad_b * m)
+            add("dgrad", fmt if level >= 3 else "fp32", 2.0 * dgrad_macs * mb, dgrad_b * mb)
             if level == 4 and 64 < Wd <= 256:
-                add("wgrad_big", fmt, 2.0 * big_macs * m, big_b * m, big_launches)
-                add("wgrad_thin", "fp32", 2.0 * (fwd_macs - big_macs) * m, thin_b * m)
+                add("wgrad_big", fmt, 2.0 * big_macs * mb, big_b * mb, big_launches)
+                add("wgrad_thin", "fp32", 2.0 * (fwd_macs - big_macs) * mb, thin_b * mb)
             else:
-                add("wgrad", "fp32", 2.0 * fwd_macs * m, wgrad_b * m)
+                add("wgrad", "fp32", 2.0 * fwd_macs * mb, wgrad_b * mb)
         # template instances of one kernel (k_wgrad_f16x3<full> / <half>) count as one
         merged = {}
         for name, (cnt, ms) in kern.items():
@@ -663,8 +678,8 @@ def main():
                         mlp_kernels=kernels,
                         kernel_ms_per_step={nm: round(m / args.steps, 4) for nm, (_, m) in sorted(kern.items(), key=lambda kv: -kv[1][1])})
         if args.mode == "train":
-            total_flops = (2.0 * (2 * fwd_macs + dgrad_macs)) * (m_c + m_f)
-            step_bytes = (stash_b + dgrad_b + wgrad_b) * (m_c + m_f)
+            total_flops = 2.0 * fwd_macs * (m_c + m_f) + 2.0 * (fwd_macs + dgrad_macs) * (kept_c + kept_f)   # (executed: == algorithmic when dense)
+            step_bytes = stash_b * (m_c + m_f) + (dgrad_b + wgrad_b) * (kept_c + kept_f)
             if args.workload == "lego":
                 workload = ("lego %dx%d synthetic views (BASELINE configs[%d]): %d rays/GPU/iter (%d over all GPUs), %d coarse + %d "
                             "fine samples, %dx%d coarse+fine nets, perturb, noise 0.2, Adam, full iteration"
@@ -711,6 +726,18 @@ def main():
                    step_algorithmic_hbm_tb_s=round(step_bytes / sec / 1e12, 3),
                    step_hbm_frac_of_8tb_s=round(step_bytes / sec / 1e12 / HBM_PEAK_TBS, 4),
                    final_loss=loss_host, roofline=roof)
+        if args.mode == "train":
+            res["backward"] = "compacted" if args.compact else "dense"
+        if kept is not None:
+            frac = lambda kv, m: None if kv is None else round(1.0 - kv[0] / float(m), 4)  # noqa: E731
+            res["zero_cotangent_fraction"] = dict(
+                coarse=frac(kept["coarse"], m_c), fine=frac(kept["fine"], m_f),
+                backward_sample_points=round(1.0 - (kept_c + kept_f) / float(m_c + m_f), 4),
+                kept_sample_points=dict(coarse=kept_c, fine=kept_f), sample_points=dict(coarse=m_c, fine=m_f),
+                what="sample points whose d(loss)/d(raw) row is exactly zero in the last timed step (relu(sigma + noise) off, or behind the "
+                     "sample where the ray's transmittance reaches 0: nerf/volume_rendering_utils.py:38-42) and which the compacted backward "
+                     "therefore dropped; the backward kernels' FLOPs, bytes and roofline fractions in this line count the KEPT sample points "
+                     "only (executed work), step_tflops likewise")
         if world > 1:
             # self-diagnosis of the first real N-GPU run: the exchange next to the compute, per net
             res["multi_gpu"] = dict(nranks=world, rccl=rccl, ms_per_step_per_rank=res["ms_per_step_per_rank"],

@@ -229,6 +229,21 @@ int nerfhip_pack_weights_plan(nerfhip_plan_t plan, const float* params, const in
 int64_t nerfhip_plan_stash_bytes(nerfhip_plan_t plan, int64_t m);
 /* Bytes of scratch nerfhip_mlp_bwd needs for m sample points. */
 int64_t nerfhip_plan_bwd_scratch_bytes(nerfhip_plan_t plan, int64_t m);
+/* Compacted backward (round 6; off by default).  sigma_a = relu(raw[..., 3] + noise) (nerf/volume_rendering_utils.py:38): wherever
+ * that ReLU is off, and behind the sample at which a ray's transmittance reaches 0, a sample's weight is exactly 0, so its
+ * d(loss)/d(raw) is exactly zero in all four channels -- and with it every d(pre-activation) row of that sample in every layer, a zero
+ * term of every weight-gradient sum the reference's autograd (train_nerf.py:259) computes densely.  With the option on,
+ * nerfhip_mlp_bwd (and the render backward entry points, which end in it) first lists the samples whose g_out row is not all zero
+ * (ascending sample index; two small launches, no atomics, no host synchronisation), the data-gradient kernels walk that list and
+ * the weight-gradient kernels sum over it: the same sums in a fixed order with their zero terms dropped -- equal to the dense
+ * gradient up to the rounding of a different split of the sample range over the workgroups.  The forward and the stash are
+ * unchanged.  A launch whose regions exceed 4 GiB (m >= 2^22 sample points) runs dense regardless. */
+int nerfhip_plan_set_bwd_compaction(nerfhip_plan_t plan, int on);
+int nerfhip_plan_bwd_compaction(nerfhip_plan_t plan);
+/* Byte offset, inside a backward scratch for m sample points, of int32[2] = {samples the last compacted backward kept, samples of
+ * that launch} (written on the launch stream; meaningful after a compacted nerfhip_mlp_bwd only).  Inside a render workspace the
+ * scratch of a net is the region "bwd_scratch_coarse" / "bwd_scratch_fine" (nerfhip_render_workspace_region), m = n_rays * samples. */
+int64_t nerfhip_plan_bwd_stats_offset(nerfhip_plan_t plan, int64_t m);
 /* Frequency bands (host float[16] each) exactly as the reference builds them are supplied by the caller. */
 int nerfhip_plan_set_freqs(nerfhip_plan_t plan, const float* freqs_xyz, const float* freqs_dir);
 
@@ -289,7 +304,8 @@ int64_t nerfhip_render_workspace_bytes(nerfhip_plan_t plan_coarse, nerfhip_plan_
 /* Where a forward leaves its per-sample intermediates inside the workspace (byte offset and size), for inspection:
  * name = "z_coarse" [n,nc] (nerf/train_utils.py:58-65), "raw_coarse" [n,nc,4] (run_network's output, :70-77),
  * "weights_coarse" [n,nc] (:86), "z_fine" [n,nc+nf] (:103-105), "raw_fine" [n,nc+nf,4] (:108-115).  The reference
- * function returns none of them; the parity tests read the sample depths to count inverse-CDF index flips. */
+ * function returns none of them; the parity tests read the sample depths to count inverse-CDF index flips.
+ * Training layouts also name "bwd_scratch_coarse" / "bwd_scratch_fine": the scratch each net's backward runs in. */
 int nerfhip_render_workspace_region(nerfhip_plan_t plan_coarse, nerfhip_plan_t plan_fine, const nerfhip_render_cfg* cfg,
                                     int64_t n_rays, int training, const char* name, int64_t* offset, int64_t* bytes);
 

@@ -100,6 +100,9 @@ _PROTOS = {
     "nerfhip_plan_stash_bytes": (c_i64, [C.c_void_p, c_i64]),
     "nerfhip_plan_bwd_scratch_bytes": (c_i64, [C.c_void_p, c_i64]),
     "nerfhip_plan_set_freqs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nerfhip_plan_set_bwd_compaction": (C.c_int, [C.c_void_p, C.c_int]),
+    "nerfhip_plan_bwd_compaction": (C.c_int, [C.c_void_p]),
+    "nerfhip_plan_bwd_stats_offset": (c_i64, [C.c_void_p, c_i64]),
     "nerfhip_mlp_fwd": (C.c_int, [C.c_void_p, c_f, c_f, c_i64, c_f, c_f, c_f]),
     "nerfhip_mlp_bwd": (C.c_int, [C.c_void_p, c_f, c_f, c_i64, c_f, c_f, c_i64, c_f, c_f]),
     "nerfhip_mlp_bwd_input": (C.c_int, [C.c_void_p, c_f, c_i64, c_f, c_f, c_f]),
@@ -154,7 +157,8 @@ class NerfHipLib:
             fn.restype = res
             fn.argtypes = args
             if res is C.c_int and name not in ("nerfhip_version", "nerfhip_is_emulated", "nerfhip_plan_dim_xyz",
-                                              "nerfhip_plan_dim_dir", "nerfhip_plan_num_tensors", "nerfhip_plan_precision"):
+                                              "nerfhip_plan_dim_dir", "nerfhip_plan_num_tensors", "nerfhip_plan_precision",
+                                              "nerfhip_plan_bwd_compaction"):
                 setattr(self, name[len("nerfhip_"):], self._checked(fn, name))
             else:
                 setattr(self, name[len("nerfhip_"):], fn)

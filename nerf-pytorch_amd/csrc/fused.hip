@@ -92,10 +92,14 @@ extern "C" int nerfhip_render_workspace_region(nerfhip_plan_t plan_coarse, nerfh
         bool fine;
     } regions[] = {{"z_coarse", w.z_c, n_rays * nc * 4, false},      {"raw_coarse", w.raw_c, n_rays * nc * 16, false},
                    {"weights_coarse", w.w_c, n_rays * nc * 4, false}, {"z_fine", w.z_f, n_rays * sf * 4, true},
-                   {"raw_fine", w.raw_f, n_rays * sf * 16, true}};
+                   {"raw_fine", w.raw_f, n_rays * sf * 16, true},
+                   // (training layouts: each net's backward scratch -- nerfhip_plan_bwd_stats_offset points into it)
+                   {"bwd_scratch_coarse", w.scratch_c, w.scratch_c_bytes, false},
+                   {"bwd_scratch_fine", w.scratch_f, w.scratch_f_bytes, true}};
     for (const auto& r : regions)
         if (strcmp(name, r.name) == 0) {
             NH_REQUIRE(!r.fine || cfg->num_fine > 0, "render_workspace_region: %s needs num_fine > 0", name);
+            NH_REQUIRE(training || strncmp(name, "bwd_", 4) != 0, "render_workspace_region: %s exists in a training layout only", name);
             *offset = r.off;
             *bytes = r.bytes;
             return NERFHIP_OK;

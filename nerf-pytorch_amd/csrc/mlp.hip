@@ -29,22 +29,36 @@ struct InGradArgs {
     int D;
     float* g_x;
     const unsigned* gscale;  // fp16 data-gradient chains: the images carry nh_gscale_of(*gscale); else NULL
+    // compacted backward: image row r belongs to sample cidx[r], r < cstats[NH_CSTAT_ACTIVE]; the other samples' rows of g_x are
+    // zero (k_zero_floats runs first)
+    const int* cidx;
+    const int* cstats;
 };
 
 NH_KERNEL void k_mlp_input_grad(InGradArgs a) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= a.M * a.D) return;
-    const int64_t m = idx / a.D;
-    const int c = (int)(idx - m * a.D);
+    const int64_t r = idx / a.D;  // row of the d(pre-activation) images
+    const int c = (int)(idx - r * a.D);
+    int64_t m = r;                // the sample it belongs to
+    if (a.cidx) {
+        if (r >= (int64_t)a.cstats[NH_CSTAT_ACTIVE]) return;
+        m = a.cidx[r];
+    }
     float s = 0.0f;
     for (int k = 0; k < a.nterms; ++k) {
         const InGradTerm& t = a.t[k];
         if (c < t.out0 || c >= t.out0 + t.ncols) continue;
-        const float* dp = a.scratch + (size_t)32 * (size_t)a.nt * (size_t)t.a_prefix + (size_t)m * (size_t)t.a_rows;
+        const float* dp = a.scratch + (size_t)32 * (size_t)a.nt * (size_t)t.a_prefix + (size_t)r * (size_t)t.a_rows;
         const float* w = a.params + t.w_off + t.col0 + (c - t.out0);
         for (int u = 0; u < t.nu; ++u) s = fmaf(dp[u], w[(size_t)u * t.w_ld], s);
     }
-    a.g_x[idx] = a.gscale ? s * nh_gscale_inv(*a.gscale) : s;
+    a.g_x[m * a.D + c] = a.gscale ? s * nh_gscale_inv(*a.gscale) : s;
+}
+
+NH_KERNEL void k_zero_floats(float* out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = 0.0f;
 }
 
 NH_KERNEL void k_zero_words(unsigned* out, int n) {
@@ -59,10 +73,15 @@ NH_KERNEL void k_zero_words(unsigned* out, int n) {
 static int64_t gscale_word_offset(nerfhip_plan* p, int64_t nt) {
     return nt * p->grad.total_rows * 32 + nh_wgrad_partial_floats(p, nt) + nh_wgrad_x3_partial_floats(p, nt);
 }
+// (... then the sample list of a compacted backward, compact.hip: reserved whether or not the plan's option is on)
+static int64_t compact_word_offset(nerfhip_plan* p, int64_t nt) { return gscale_word_offset(p, nt) + NH_RMAX_WORDS; }
 int64_t nh_mlp_bwd_scratch_bytes(nerfhip_plan* p, int64_t M) {
     const int64_t nt = nh_ceil_div(M, 128) * 4;
-    return (gscale_word_offset(p, nt) + NH_RMAX_WORDS) * (int64_t)sizeof(float);
+    return (compact_word_offset(p, nt) + nh_compact_ints(nt * 32)) * (int64_t)sizeof(float);
 }
+// A backward over M sample points runs compacted when the plan asks for it and a gathered row's byte offset inside a region (at most
+// 256 rows of 4 bytes per sample) fits the 32-bit offset of a buffer instruction; otherwise it runs dense.
+static bool compacts(const nerfhip_plan* p, int64_t M) { return p->bwd_compact && nh_ceil_div(M, 128) * 128 * 1024 < ((int64_t)1 << 32); }
 
 int nh_mlp_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
                    nerfhip_stream_t stream) {
@@ -101,17 +120,37 @@ int nh_mlp_backward(nerfhip_plan* p, const float* packed, const float* g_out, in
         rc = nh_zero_words(amax, NH_RMAX_WORDS, stream);
         if (rc) return rc;
     }
+    // compacted backward: list the samples whose d(raw output) row is not all zero; every kernel below then walks that list
+    NhCompact cview;
+    const NhCompact* cx = nullptr;
+    if (compacts(p, M)) {
+        cview = nh_compact_view((int*)(scratch + compact_word_offset(p, nt)), nt * 32);
+        rc = nh_compact_build(g_out, M, cview, stream);
+        if (rc) return rc;
+        cx = &cview;
+    }
     if (bdg)
-        rc = nh_mlp_dgrad_f16w(p, packed, g_out, M, stash, scratch, amax, stream);
+        rc = nh_mlp_dgrad_f16w(p, packed, g_out, M, stash, scratch, amax, cx, stream);
     else
-        rc = nh_mlp16_dgrad(p, packed, g_out, M, stash, scratch, stream);
+        rc = nh_mlp16_dgrad(p, packed, g_out, M, stash, scratch, cx, stream);
     if (rc) return rc;
     float* const partial = scratch + (size_t)nt * (size_t)p->grad.total_rows * 32;
-    rc = nh_wgrad(p, nt, stash, scratch, partial, g_params, nullptr, stream);
+    rc = nh_wgrad(p, nt, stash, scratch, partial, g_params, nullptr, cx, stream);
     if (rc) return rc;
     // (level 4: the large blocks, behind the fp32 kernel's partials)
     float* const partial_b = partial + nh_wgrad_partial_floats(p, nt);
-    return nh_wgrad_f16(p, nt, stash, scratch, partial_b, g_params, amax, bmax, stream);
+    return nh_wgrad_f16(p, nt, stash, scratch, partial_b, g_params, amax, bmax, cx, stream);
+}
+
+extern "C" int nerfhip_plan_set_bwd_compaction(nerfhip_plan_t plan, int on) {
+    NH_REQUIRE(plan, "plan_set_bwd_compaction: plan is NULL");
+    plan->bwd_compact = on != 0;
+    return NERFHIP_OK;
+}
+extern "C" int nerfhip_plan_bwd_compaction(nerfhip_plan_t plan) { return plan && plan->bwd_compact ? 1 : 0; }
+extern "C" int64_t nerfhip_plan_bwd_stats_offset(nerfhip_plan_t plan, int64_t m) {
+    if (!plan || m < 0) return -1;
+    return compact_word_offset(plan, nh_ceil_div(m, 128) * 4) * (int64_t)sizeof(float);
 }
 
 int nh_zero_words(unsigned* dev, int n, nerfhip_stream_t stream) {
@@ -170,6 +209,14 @@ extern "C" int nerfhip_mlp_bwd_input(nerfhip_plan_t p, const float* params, int6
     a.D = p->Dx + p->Dd;
     a.g_x = g_x;
     a.gscale = nullptr;  // (the d(pre-activation) images are plain values in every precision)
+    if (compacts(p, m)) {  // (the backward that filled `scratch` ran compacted: its images are in list order)
+        const NhCompact c = nh_compact_view((int*)const_cast<void*>(scratch) + compact_word_offset(p, a.nt), a.nt * 32);
+        a.cidx = c.idx;
+        a.cstats = c.stats;
+        NH_LAUNCH(k_zero_floats, nh_ceil_div(m * a.D, 256), 256, 0, stream, g_x, m * a.D);
+        const int rc = nh_launch_status("zero_floats");
+        if (rc) return rc;
+    }
     NH_LAUNCH(k_mlp_input_grad, nh_ceil_div(m * a.D, 256), 256, 0, stream, a);
     return nh_launch_status("mlp_input_grad");
 }

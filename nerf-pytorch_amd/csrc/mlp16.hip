@@ -591,11 +591,18 @@ struct Dgrad16Args {
     float* grad;
     NhGradLayout gl;
     unsigned long long* clk;  // shader-clock probe counters, or NULL
+    // compacted backward (compact.hip), or NULLs: slot c of the launch is sample cidx[c] -- d(raw output) and the ReLU masks are
+    // gathered by it, the d(pre-activation) images are written in slot order; cstats[NH_CSTAT_ACTIVE] slots carry a sample
+    const int* cidx;
+    const int* cstats;
 };
 
 template <int W, bool VIEW>
 NH_KERNEL void NH_LB(64 * Shape<W>::NW, Shape<W>::WAVES_PER_SIMD) k_mlp_dgrad16(Dgrad16Args a) {
     constexpr int KH = W / 4, TW = W / 16, NW = Shape<W>::NW, MW = Shape<W>::MW;
+    // compacted: a workgroup whose slots are all behind the list has nothing to write (wgrad reads the first ceil(active / 32) tiles)
+    const int n_slots = a.cidx ? nh_uload_i32(a.cstats, NH_CSTAT_ACTIVE) : 0;
+    if (a.cidx && (int64_t)blockIdx.x * (NW * 16) >= (int64_t)n_slots) return;
     NH_DYN_LDS(lds_raw);
     nh_clk_begin(a.clk, (unsigned long long*)(lds_raw + Lds<W>::BYTES));
     Ctx cx;
@@ -616,8 +623,12 @@ NH_KERNEL void NH_LB(64 * Shape<W>::NW, Shape<W>::WAVES_PER_SIMD) k_mlp_dgrad16(
     const int lane = cx.lane, g = cx.g, j = lane & 15, wave = cx.wave;
     const int64_t tile = (int64_t)blockIdx.x * (NW / 2) + (wave >> 1);
     const int js = 16 * (wave & 1) + j;
-    const int64_t m = tile * 32 + js;
-    const bool valid = m < a.M;
+    int64_t m = tile * 32 + js;  // this lane's slot, then its sample
+    bool valid = m < a.M;
+    if (a.cidx) {
+        valid = m < (int64_t)n_slots;
+        m = valid ? (int64_t)a.cidx[m] : 0;
+    }
     const NhPackedOffsets& po = a.off;
     const int L = a.L;
     // the transposed images carry no bias: their 512-float bias block is all zero weights (index -1 -> 0.0f)
@@ -643,13 +654,16 @@ NH_KERNEL void NH_LB(64 * Shape<W>::NW, Shape<W>::WAVES_PER_SIMD) k_mlp_dgrad16(
     // POUT (32 rows): rows 0..2 d(rgb raw), row 3 d(sigma raw), rows 4..31 zero; group g writes rows 8g..8g+7
     const bool g0 = g == 0;
     const PoutPost store_pout{gref(a.gl.POUT, 32, 8 * g), g0 ? go0 : 0.f, g0 ? go1 : 0.f, g0 ? go2 : 0.f, g0 ? go3 : 0.f};
+    // the forward wrote the mask words of wave tile (sample >> 4), lane 16 g + (sample & 15): this very lane's in the dense backward
+    const int64_t wave_tile = a.cidx ? (m >> 4) : ((int64_t)blockIdx.x * NW + wave);
+    const int mask_lane = a.cidx ? 16 * g + (int)(m & 15) : lane;
     const char* const mask_base = (const char*)((const unsigned*)(a.stash + (size_t)32 * (size_t)a.nt * (size_t)a.sl.total_rows) +
-                                                (size_t)((int64_t)blockIdx.x * NW + wave) * a.sl.n_masks * (64 * MW));
+                                                (size_t)wave_tile * a.sl.n_masks * (64 * MW));
     // ReLU masks: `mb` gates the d(pre-activation) currently held in registers -- applied by the NEXT gemm, group by
     // group, just before it consumes / stores them (GatePre) -- while `mn` is fetched for the one being accumulated
     MaskBits<MW> mb, mn;
     auto get_mask = [&](int idx) {
-        const unsigned* p = (const unsigned*)(mask_base + (size_t)idx * (256 * MW) + (size_t)((unsigned)lane * (4u * MW)));
+        const unsigned* p = (const unsigned*)(mask_base + (size_t)idx * (256 * MW) + (size_t)((unsigned)mask_lane * (4u * MW)));
 #pragma unroll
         for (int w = 0; w < MW; ++w) mn.w[w] = p[w];
     };
@@ -795,7 +809,7 @@ void fill_fwd_args(nerfhip_plan* p, const float* packed, const NhMlpInput& in, i
 }
 
 void fill_dgrad_args(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
-                     Dgrad16Args& d) {
+                     const NhCompact* cx, Dgrad16Args& d) {
     memset(&d, 0, sizeof(d));
     d.packed = packed;
     d.packed_bytes = (unsigned)(p->packed_floats * 4);
@@ -809,6 +823,8 @@ void fill_dgrad_args(nerfhip_plan* p, const float* packed, const float* g_out, i
     d.grad = scratch;
     d.gl = p->grad;
     d.clk = nh_prof_clock_slot(NH_CLK_DGRAD);
+    d.cidx = cx ? cx->idx : nullptr;
+    d.cstats = cx ? cx->stats : nullptr;
 }
 
 // whole 128-sample groups are launched: every stash tile is written
@@ -838,7 +854,7 @@ void fill_dgrad_args(nerfhip_plan* p, const float* packed, const float* g_out, i
 int nh_mlp16_forward_w512(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
                           nerfhip_stream_t stream);
 int nh_mlp16_dgrad_w512(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
-                        nerfhip_stream_t stream);
+                        const NhCompact* cx, nerfhip_stream_t stream);
 int nh_mlp16_forward_ext(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
                          nerfhip_stream_t stream);
 
@@ -873,9 +889,9 @@ int nh_mlp16_forward_w512(nerfhip_plan* p, const float* packed, const NhMlpInput
 }
 
 int nh_mlp16_dgrad_w512(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
-                        nerfhip_stream_t stream) {
+                        const NhCompact* cx, nerfhip_stream_t stream) {
     Dgrad16Args d;
-    fill_dgrad_args(p, packed, g_out, M, stash, scratch, d);
+    fill_dgrad_args(p, packed, g_out, M, stash, scratch, cx, d);
     const int64_t groups = nh_ceil_div(M, 128);
     int rc = NERFHIP_OK;
     if (p->view) NH_BWD16(512, true)
@@ -902,10 +918,10 @@ int nh_mlp16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in,
 }
 
 int nh_mlp16_dgrad(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
-                   nerfhip_stream_t stream) {
-    if (p->W == 512) return nh_mlp16_dgrad_w512(p, packed, g_out, M, stash, scratch, stream);
+                   const NhCompact* cx, nerfhip_stream_t stream) {
+    if (p->W == 512) return nh_mlp16_dgrad_w512(p, packed, g_out, M, stash, scratch, cx, stream);
     Dgrad16Args d;
-    fill_dgrad_args(p, packed, g_out, M, stash, scratch, d);
+    fill_dgrad_args(p, packed, g_out, M, stash, scratch, cx, d);
     const int64_t groups = nh_ceil_div(M, 128);
     int rc = NERFHIP_OK;
     if (p->W == 256 && p->view) NH_BWD16(256, true)

@@ -661,11 +661,19 @@ struct DgradWArgs {
     float* grad;
     NhGradLayout gl;
     unsigned* rmax;  // level-4 plans: per-region maxima of the images written (P[k] -> k, PFEAT -> L, PDIR -> L + 1), else NULL
+    // compacted backward (compact.hip), or NULLs: slot c of the launch is sample cidx[c] -- d(raw output) and the ReLU masks are
+    // gathered by it, the d(pre-activation) images are written in slot order; cstats[NH_CSTAT_ACTIVE] slots carry a sample
+    const int* cidx;
+    const int* cstats;
 };
 
 template <int W, bool VIEW>
 NH_KERNEL void NH_LB(512, 2) k_mlp_dgrad_f16x3w(DgradWArgs a) {
     constexpr int TW = WShape<W>::TW, KB = WShape<W>::KB, BUF = WShape<W>::BUF;
+    // compacted: the launch's groups are those of the sample list; a workgroup without one has nothing to stream
+    const int n_slots = a.cidx ? nh_uload_i32(a.cstats, NH_CSTAT_ACTIVE) : 0;
+    const int64_t groups = a.cidx ? (int64_t)((n_slots + 127) >> 7) : a.groups;
+    if ((int64_t)blockIdx.x >= groups) return;
     NH_DYN_LDS(lds_raw);
     WCtx cx;
     cx.lds = lds_raw;
@@ -684,13 +692,18 @@ NH_KERNEL void NH_LB(512, 2) k_mlp_dgrad_f16x3w(DgradWArgs a) {
     const int first_bytes = VIEW ? first(1, TW / 2) : first(1, TW);
     w_issue<BUF>(cx, first_img, first_bytes, 0, 0);
 
-    for (int64_t grp = blockIdx.x; grp < a.groups; grp += gridDim.x) {
-        const bool again = grp + gridDim.x < a.groups;
-        const int64_t m = grp * 128 + cx.wave * 16 + j;
+    for (int64_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const bool again = grp + gridDim.x < groups;
+        int64_t m = grp * 128 + cx.wave * 16 + j;  // this lane's slot, then its sample
+        bool valid = m < a.M;
+        if (a.cidx) {
+            valid = m < (int64_t)n_slots;
+            m = valid ? (int64_t)a.cidx[m] : 0;
+        }
         const int64_t tile32 = grp * 4 + (cx.wave >> 1);
         const int s32 = 16 * (cx.wave & 1) + j;
-        float go[4] = {0.f, 0.f, 0.f, 0.f};  // d(raw output) of this lane's sample (zero beyond M: nothing flows)
-        if (m < a.M) {
+        float go[4] = {0.f, 0.f, 0.f, 0.f};  // d(raw output) of this lane's sample (zero beyond M / the list: nothing flows)
+        if (valid) {
             const float4 t4 = *(const float4*)(a.g_out + (size_t)m * 4);
             go[0] = t4.x, go[1] = t4.y, go[2] = t4.z, go[3] = t4.w;
         }
@@ -698,10 +711,13 @@ NH_KERNEL void NH_LB(512, 2) k_mlp_dgrad_f16x3w(DgradWArgs a) {
         auto grow = [&](const NhRegion& R, int rows) -> float* {
             return a.grad + (size_t)32 * (size_t)a.nt * (size_t)R.row_prefix + ((size_t)tile32 * 32 + (size_t)s32) * (size_t)rows;
         };
-        // ReLU mask `idx` of this lane's units (the forward wrote the words of this very lane)
+        // ReLU mask `idx` of this lane's units: the forward wrote the words of wave tile (sample >> 4), lane 16 g + (sample & 15) --
+        // this very lane's in the dense backward
+        const int64_t wave_tile = a.cidx ? (m >> 4) : grp * 8 + cx.wave;
+        const int mask_lane = a.cidx ? 16 * g + (int)(m & 15) : cx.lane;
         auto get_mask = [&](int idx) -> MaskW {
             const unsigned* p = (const unsigned*)(a.stash + (size_t)32 * (size_t)a.nt * (size_t)a.sl.total_rows) +
-                                ((size_t)(grp * 8 + cx.wave) * (size_t)a.sl.n_masks + (size_t)idx) * 128 + (size_t)cx.lane * 2;
+                                ((size_t)wave_tile * (size_t)a.sl.n_masks + (size_t)idx) * 128 + (size_t)mask_lane * 2;
             MaskW mw;
             mw.w[0] = p[0];
             mw.w[1] = p[1];
@@ -896,7 +912,7 @@ int nh_mlp_forward_f16w(nerfhip_plan* p, const float* packed, const NhMlpInput& 
 }
 
 int nh_mlp_dgrad_f16w(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
-                      unsigned* rmax, nerfhip_stream_t stream) {
+                      unsigned* rmax, const NhCompact* cpt, nerfhip_stream_t stream) {
     NH_REQUIRE(nh_prec_f16(p->precision), "mlp_bwd_f16w: not an fp16-piece plan");
     DgradWArgs d;
     memset(&d, 0, sizeof(d));
@@ -913,6 +929,8 @@ int nh_mlp_dgrad_f16w(nerfhip_plan* p, const float* packed, const float* g_out, 
     d.grad = scratch;
     d.gl = p->grad;
     d.rmax = rmax;
+    d.cidx = cpt ? cpt->idx : nullptr;
+    d.cstats = cpt ? cpt->stats : nullptr;
     const int64_t resident = (int64_t)w_compute_units();
     const int64_t grid = d.groups < resident ? d.groups : resident;
     int rc = NERFHIP_OK;

@@ -52,21 +52,10 @@ NH_DEVICE f32x16 nh_mfma32(float a, float b, f32x16 c) {
 // D[4*(l>>4) + c][l&15].  32 cycles per instruction, 40 cycles dependent latency.
 NH_DEVICE f32x4 nh_mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-// bf16 pieces of the split-precision inference kernel (mlp_bf16.hip).  nh_to_bf16: round-to-nearest-even
-// (v_cvt_pk_bf16_f32).  nh_mfma_bf16: D = A(32x16) * B(16x32) + C on v_mfma_f32_32x32x16_bf16, fp32 accumulation; lane l
-// supplies A[l&31][8*(l>>5) + e] and B[8*(l>>5) + e][l&31], e = 0..7; D registers as for nh_mfma32.
-typedef __bf16 nh_bf16;
-typedef __bf16 nh_bf16x8 __attribute__((ext_vector_type(8)));
-NH_DEVICE nh_bf16 nh_to_bf16(float v) { return (nh_bf16)v; }
-NH_DEVICE float nh_from_bf16(nh_bf16 h) { return (float)h; }
-NH_DEVICE f32x16 nh_mfma_bf16(nh_bf16x8 a, nh_bf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-
-// IEEE fp16 pieces of the f16x3 plans (the same kernels, compiled a second time: mlp_f16.hip, wgrad_f16.hip).  nh_to_f16:
-// round-to-nearest-even incl. subnormal results (v_cvt_f16_f32; the kernels run with fp16 denormals on, HIP's default);
-// nh_mfma_f16: v_mfma_f32_32x32x16_f16, operand / result layout as nh_mfma_bf16 -- the matrix pipe takes fp16 subnormal inputs
-// at face value (measured on MI355X: scripts/probe/f16_mfma_probe.hip).
+// IEEE fp16 pieces of the f16x3 plans (mlp_f16w.hip, wgrad_f16.hip).  nh_to_f16: round-to-nearest-even incl. subnormal results
+// (v_cvt_f16_f32; the kernels run with fp16 denormals on, HIP's default); nh_mfma_f16: D = A(32x16) * B(16x32) + C on
+// v_mfma_f32_32x32x16_f16, fp32 accumulation; lane l supplies A[l&31][8*(l>>5) + e] and B[8*(l>>5) + e][l&31], e = 0..7; D registers
+// as for nh_mfma32 -- the matrix pipe takes fp16 subnormal inputs at face value (measured on MI355X: scripts/probe/f16_mfma_probe.hip).
 typedef _Float16 nh_f16;
 typedef _Float16 nh_f16x8 __attribute__((ext_vector_type(8)));
 NH_DEVICE nh_f16 nh_to_f16(float v) { return (nh_f16)v; }
@@ -93,18 +82,12 @@ NH_DEVICE unsigned long long nh_lds_tr16(const char* lds_ptr) {
     __builtin_memcpy(&u, &v, 8);
     return u;
 }
-// sum of the two 16-bit floats packed in `pair` (+ c), in fp32: v_dot2c_f32_f16 / v_dot2c_f32_bf16 against (1, 1)
+// sum of the two fp16 values packed in `pair` (+ c), in fp32: v_dot2c_f32_f16 against (1, 1)
 NH_DEVICE float nh_pair_sum_f16(unsigned pair, float c) {
     typedef _Float16 nh_h2 __attribute__((ext_vector_type(2)));
     nh_h2 a, one = {(_Float16)1.0f, (_Float16)1.0f};
     __builtin_memcpy(&a, &pair, 4);
     return __builtin_amdgcn_fdot2(a, one, c, false);
-}
-NH_DEVICE float nh_pair_sum_bf16(unsigned pair, float c) {
-    typedef __bf16 nh_b2 __attribute__((ext_vector_type(2)));
-    nh_b2 a, one = {(__bf16)1.0f, (__bf16)1.0f};
-    __builtin_memcpy(&a, &pair, 4);
-    return __builtin_amdgcn_fdot2_f32_bf16(a, one, c, false);
 }
 // maximum of v over the wave, as a wave-uniform value: six v_max_u32 with DPP operands (row_shr 1 2 4 8, row_bcast 15 31) and a
 // v_readlane -- no LDS traffic
@@ -171,6 +154,14 @@ NH_DEVICE void nh_dma16a(const NhDmaSrc& s, int voff, int soff, unsigned lds_wav
         :
         : "s"(__builtin_amdgcn_readfirstlane((int)lds_wave_addr)), "v"(voff), "s"(s.r), "s"(__builtin_amdgcn_readfirstlane(soff))
         : "memory");
+}
+// p[i] for a wave-uniform address in memory that no launch on the device writes while this kernel runs (a sample list built by the
+// launch before): read through the constant address space, i.e. s_load_dword -- a scalar register, counted by lgkmcnt, NOT by vmcnt:
+// the kernels that call it keep LDS-DMA copies in flight whose completion they count themselves (nh_wait_vmem_keep), and a vector
+// load the compiler tracks would make it wait for all of them at the load's first use.
+NH_DEVICE int nh_uload_i32(const int* p, int i) {
+    typedef const __attribute__((address_space(4))) int* nh_cptr;
+    return ((nh_cptr)(unsigned long long)p)[i];
 }
 NH_DEVICE void nh_wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // ... until at most N of this wave's vector-memory operations are outstanding (the N newest: they complete in order)

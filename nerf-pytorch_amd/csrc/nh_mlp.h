@@ -12,6 +12,20 @@ struct NhMlpInput {
     int S;
 };
 
+// The sample list of a compacted backward (compact.hip; nerfhip_plan_set_bwd_compaction): behind a backward scratch's region maxima.
+// stats[NH_CSTAT_ACTIVE] = samples whose d(raw output) row is not all zero, stats[NH_CSTAT_TOTAL] = samples of the launch;
+// idx[0 .. active): their sample indices, ascending, padded with sample 0 up to the next multiple of 128.
+// idx == NULL in a kernel's arguments: the dense backward.
+constexpr int NH_CSTAT_WORDS = 16, NH_CSTAT_ACTIVE = 0, NH_CSTAT_TOTAL = 1;
+struct NhCompact {
+    int* stats;
+    int* counts;  // per 2048-sample block (k_compact_count)
+    int* idx;
+};
+int64_t nh_compact_ints(int64_t M);                  // 32-bit words of the area for M sample points
+NhCompact nh_compact_view(int* area, int64_t M);
+int nh_compact_build(const float* g_out, int64_t M, const NhCompact& c, nerfhip_stream_t stream);
+
 int nh_mlp_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
                    nerfhip_stream_t stream);
 int nh_mlp_backward(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash,
@@ -21,15 +35,16 @@ int64_t nh_mlp_bwd_scratch_bytes(nerfhip_plan* p, int64_t M);
 // mlp16.hip: the forward / data-gradient chain on v_mfma_f32_16x16x4_f32, two waves per SIMD
 int nh_mlp16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
                      nerfhip_stream_t stream);
+// (cx: the compacted backward's sample list, or NULL -- here and in every backward kernel below)
 int nh_mlp16_dgrad(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
-                   nerfhip_stream_t stream);
+                   const NhCompact* cx, nerfhip_stream_t stream);
 
 // mlp_f16w.hip: forward (with / without stash) and data-gradient chain of the fp16-piece plans: two waves per SIMD, 16-sample waves on
 // v_mfma_f32_16x16x32_f16; rmax (level-4 plans): NH_RMAX_WORDS zeroed device words for the region maxima, or NULL
 int nh_mlp_forward_f16w(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
                         nerfhip_stream_t stream);
 int nh_mlp_dgrad_f16w(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
-                      unsigned* rmax, nerfhip_stream_t stream);
+                      unsigned* rmax, const NhCompact* cx, nerfhip_stream_t stream);
 // mlp.hip: n words of device memory to zero, on the stream
 int nh_zero_words(unsigned* dev, int n, nerfhip_stream_t stream);
 // pack_f16.hip: the fp16-piece layer images of a plan
@@ -40,13 +55,13 @@ int64_t nh_wgrad_partial_floats(nerfhip_plan* p, int64_t nt);
 // gscale: a device word with the bits of a maximum the images were scaled by (nh_gscale_of; the reduction multiplies by
 // nh_gscale_inv), or NULL (every precision stores plain values today)
 int nh_wgrad(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad, float* partial, float* g_params,
-             const unsigned* gscale, nerfhip_stream_t stream);
+             const unsigned* gscale, const NhCompact* cx, nerfhip_stream_t stream);
 
 // wgrad_f16.hip: the large weight blocks of level-4 plans (plan->bjobs) on the fp16 MFMAs
 int64_t nh_wgrad_x3_partial_floats(nerfhip_plan* p, int64_t nt);  // (-1 with an error message: a block list the schedule refuses)
 // amax / bmax: the region maxima recorded by the data-gradient / forward launch that wrote `grad` / `stash`, or NULL
 int nh_wgrad_f16(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad, float* partial, float* g_params,
-                 const unsigned* amax, const unsigned* bmax, nerfhip_stream_t stream);
+                 const unsigned* amax, const unsigned* bmax, const NhCompact* cx, nerfhip_stream_t stream);
 
 // render.hip: compositing backward with the optional dL/d||rd|| output, and the gradient w.r.t. the packed rays
 int nh_volume_render_bwd(const float* raw, const float* z, const float* rd, int rd_stride, int64_t n, int s, float noise_std,

@@ -56,20 +56,26 @@ struct JobRed {  // k_wgrad_reduce
     int tile0;     // first accumulator tile of this block inside a workgroup's partial (0, or behind the host job's tiles)
 };
 constexpr int NH_JOBS_DEV = NH_MAX_JOBS;
-static_assert(sizeof(JobDev) * NH_JOBS_DEV + 64 <= 4096 && sizeof(JobRed) * NH_JOBS_DEV + 248 <= 4096,
+static_assert(sizeof(JobDev) * NH_JOBS_DEV + 80 <= 4096 && sizeof(JobRed) * NH_JOBS_DEV + 248 <= 4096,
               "the job tables must fit the 4 KB kernel-argument limit");
 // Workgroup shapes.  256-wide nets: 8 waves per workgroup (two per SIMD), two LDS stages of 16384 floats (+ slack for
 // the operand prefetch that runs one k-step past the end of a stage): one workgroup per CU.  128-wide nets (jobs of at
 // most 4 x 4 tiles): 4 waves per workgroup with 2 x 2 patches -- 1.0 instead of 1.5 operand dwords per MFMA -- and
 // stages of 8192 floats, so that TWO workgroups share a CU: the two waves of a SIMD then belong to different
 // workgroups and do not meet at the same barriers.
-template <int NWV_, int STAGE_>
+// CX: the compacted backward (compact.hip) -- the A operands are the first ceil(active / 32) tiles of the compacted d(pre-activation)
+// images, the B operands the activation rows of the listed samples, gathered row by row.  Its own instantiation of the kernel: the
+// dense kernel's registers (256 VGPRs, no scratch) are not touched by the gather's address arithmetic.
+template <int NWV_, int STAGE_, bool CX_ = false>
 struct WMode {
     static constexpr int NWV = NWV_, STAGE = STAGE_, LDS_DATA = 2 * STAGE_ * 4 + 4096, LDS_BYTES = LDS_DATA + NH_CLK_LDS_BYTES;
+    static constexpr bool CX = CX_;
 };
 // (stage = one 32-sample tile of a 256 + 256 (128 + 128) row job plus a 64-row side region)
 using WModeWide = WMode<8, 18432>;
 using WModeNarrow = WMode<4, 9216>;
+using WModeWideCx = WMode<8, 18432, true>;
+using WModeNarrowCx = WMode<4, 9216, true>;
 // split-K partial of one workgroup: [accumulator tiles of the largest job][16 regs][64 lanes], then 512 bias partials
 // (then 128 floats of per-wave timeline records in the instrumented build); WgradArgs::part_bias / part_stride
 #ifdef NH_WGRAD_TIMELINE
@@ -86,6 +92,8 @@ struct WgradArgs {
     int njobs, total_wgs;
     int part_bias, part_stride;  // floats: offset of the bias partials inside a workgroup's partial, size of a partial
     unsigned long long* clk;     // shader-clock probe counters, or NULL (nh_prof_clock_slot)
+    const int* cidx;             // compacted backward (MD::CX launches): the sample list and its statistics
+    const int* cstats;
     JobDev jobs[NH_JOBS_DEV];
 };
 struct ReduceArgs {
@@ -181,6 +189,22 @@ struct WStageDma {
     NhDmaSrc sa, sb, sc;
     unsigned dst;  // LDS byte address of the stage
     int pa, pab, ptot, boff, coff, q, lane16;
+    // gathered blocks (compacted backward): sample slot0 + k of the stage is row cidx[slot0 + k] of the WHOLE region the descriptor
+    // then spans; b_sh / s_sh = log2 of a row's bytes; s_gather: the side block lives in the stash (B-side) and is gathered too
+    const int* cidx;
+    int slot0, b_sh, s_sh;
+    bool s_gather;
+    // the row of this wave's NEXT gathered B piece, fetched one piece ahead: its scalar load is long complete at the piece's turn
+    // (fetched at the piece itself, the wave would wait for the scalar cache once per piece, ~10 % of a stage)
+    unsigned nxt_row;
+    int nxt_pq;
+    NH_MEMBER void prefetch_b(int pq) {
+        nxt_pq = -1;
+        if (b_sh >= 10 && pq >= 0 && pq < pab - pa) {
+            nxt_pq = pq;
+            nxt_row = (unsigned)nh_uload_i32(cidx, slot0 + (int)(((unsigned)pq << 10) >> b_sh));
+        }
+    }
     // blocks A, B and (s_fl > 0) the side block: ntile * {a,b,s}_fl floats each, landing at stage + 0, g*a_fl, g*(a_fl+b_fl)
     NH_MEMBER void init(const float* ga, const float* gb, const float* gs, int a_fl, int b_fl, int s_fl, int ntile, int g,
                         unsigned stage_addr, int wave, int lane) {
@@ -200,34 +224,77 @@ struct WStageDma {
         q = wave;
         lane16 = lane * 16;
     }
-    template <int NWV, bool SIDE>
+    // the same for a compacted stage: block A is contiguous (the compacted image); B0 (and S0 for a B-side block) name the whole
+    // region, `slot` the stage's first sample slot
+    template <int NWV>
+    NH_MEMBER void init_cx(const float* ga, const float* B0, const float* gs, unsigned b_bytes, unsigned s_bytes, int a_fl, int b_fl,
+                           int s_fl, int ntile, int g, unsigned stage_addr, int wave, int lane, int slot) {
+        init(ga, B0, gs, a_fl, b_fl, s_fl, ntile, g, stage_addr, wave, lane);
+        sb = nh_dma_src(B0, b_bytes);
+        if (s_fl > 0 && s_gather) sc = nh_dma_src(gs, s_bytes);
+        slot0 = slot;
+        prefetch_b((wave < pa ? wave + (pa - wave + NWV - 1) / NWV * NWV : wave) - pa);  // this wave's first B piece
+    }
+    // 1-KiB piece `pq` of a gathered block whose rows are (1 << sh) bytes; row_known: `row0` is the piece's row (prefetch_b)
+    NH_MEMBER void gather_piece(const NhDmaSrc& src, int pq, int sh, unsigned lds_dst, bool row_known = false, unsigned row0 = 0u) const {
+        if (sh >= 10) {  // a quarter / half / whole row of ONE sample: the source offset is wave-uniform
+            const unsigned byte0 = (unsigned)pq << 10;
+            const unsigned row = row_known ? row0 : (unsigned)nh_uload_i32(cidx, slot0 + (int)(byte0 >> sh));
+            nh_dma16a(src, lane16, (int)((row << sh) + (byte0 & ((1u << sh) - 1u))), lds_dst);
+        } else {         // 2 / 4 / 8 whole rows: each lane picks its sample's
+            const int n = 1 << (10 - sh), s0 = slot0 + pq * n, e = lane16 >> sh;
+            unsigned row = (unsigned)nh_uload_i32(cidx, s0);
+            for (int k = 1; k < n; ++k) {
+                const unsigned rk = (unsigned)nh_uload_i32(cidx, s0 + k);
+                row = e == k ? rk : row;  // (a rolled loop over scalar loads: one v_cndmask per row)
+            }
+            nh_dma16a(src, (int)((row << sh) + ((unsigned)lane16 & ((1u << sh) - 1u))), 0, lds_dst);
+        }
+    }
+    template <int NWV, bool SIDE, bool CX>
     NH_MEMBER void issue(int n) {
         for (int c = 0; c < n && q < ptot; ++c, q += NWV) {
-#ifdef NH_WGRAD_TIMELINE
-            // (instrumented build only: with the stamp bookkeeping ROCm 7.2's clang hands VGPRs to the "s" descriptor operand
-            // of the copy instruction and the build fails; the descriptors are re-uniformised per piece.  This costs the
-            // instrumented kernel ~10 % -- more on small jobs: its timeline shows the order of events and the wait / barrier
-            // shares, not the product kernel's absolute times.)
-            NhDmaSrc ta = sa, tb = sb, tc = sc;
-            for (int e = 0; e < 4; ++e) {
-                ta.r[e] = __builtin_amdgcn_readfirstlane(ta.r[e]);
-                tb.r[e] = __builtin_amdgcn_readfirstlane(tb.r[e]);
-                if (SIDE) tc.r[e] = __builtin_amdgcn_readfirstlane(tc.r[e]);
+            // (the instrumented build, and the compacted kernel: with more scalar state live -- the stamp bookkeeping; the list
+            // pointer and row shifts -- ROCm 7.2's clang hands VGPRs to the "s" descriptor operand of the copy instruction and the
+            // build fails; the descriptors are re-uniformised per piece.  This costs the instrumented kernel ~10 % -- more on small
+            // jobs: its timeline shows the order of events and the wait / barrier shares, not the product kernel's absolute times.)
+#if defined(NH_WGRAD_TIMELINE) && !defined(NERFHIP_EMU)
+            constexpr bool reuniform = true;
+#elif !defined(NERFHIP_EMU) && !defined(NH_CX_NO_REUNIFORM)
+            constexpr bool reuniform = CX;
+#else
+            constexpr bool reuniform = false;
+#endif
+            if constexpr (reuniform) {
+#ifndef NERFHIP_EMU
+                NhDmaSrc ta = sa, tb = sb, tc = sc;
+                for (int e = 0; e < 4; ++e) {
+                    ta.r[e] = __builtin_amdgcn_readfirstlane(ta.r[e]);
+                    tb.r[e] = __builtin_amdgcn_readfirstlane(tb.r[e]);
+                    if (SIDE) tc.r[e] = __builtin_amdgcn_readfirstlane(tc.r[e]);
+                }
+                piece<NWV, SIDE, CX>(ta, tb, tc);
+#endif
+            } else {
+                piece<NWV, SIDE, CX>(sa, sb, sc);
             }
-            if (q < pa)
-                nh_dma16a(ta, lane16, q * 1024, dst + q * 1024);
-            else if (!SIDE || q < pab)
+        }
+    }
+    template <int NWV, bool SIDE, bool CX>
+    NH_MEMBER void piece(const NhDmaSrc& ta, const NhDmaSrc& tb, const NhDmaSrc& tc) {
+        if (q < pa)
+            nh_dma16a(ta, lane16, q * 1024, dst + q * 1024);
+        else if (!SIDE || q < pab) {
+            if constexpr (CX) {
+                gather_piece(tb, q - pa, b_sh, dst + boff + q * 1024, nxt_pq == q - pa, nxt_row);
+                prefetch_b(q - pa + NWV);
+            } else
                 nh_dma16a(tb, lane16, (q - pa) * 1024, dst + boff + q * 1024);
+        } else {
+            if (CX && s_gather)
+                gather_piece(tc, q - pab, s_sh, dst + coff + q * 1024);
             else
                 nh_dma16a(tc, lane16, (q - pab) * 1024, dst + coff + q * 1024);
-#else
-            if (q < pa)
-                nh_dma16a(sa, lane16, q * 1024, dst + q * 1024);
-            else if (!SIDE || q < pab)
-                nh_dma16a(sb, lane16, (q - pa) * 1024, dst + boff + q * 1024);
-            else
-                nh_dma16a(sc, lane16, (q - pab) * 1024, dst + coff + q * 1024);
-#endif
         }
     }
 };
@@ -293,12 +360,29 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
     const float* gs = SIDE ? S0 + (size_t)t0 * s_fl : nullptr;
     int left = (int)(t1 - t0);                 // tiles not yet requested
     const unsigned lds_addr = nh_lds_addr(lds);
+    constexpr bool CX = MD::CX;
+    // compacted backward: tile t of the job is slots 32 t .. 32 t + 31 of the sample list -- the A block (and an A-side block) are
+    // tile t of the compacted images, the B block (and a B-side block) the listed samples' rows of the whole stash region
+    constexpr bool SGATHER = CX && SD::SK == 2;
+    int slot = (int)t0 * 32;
+    const unsigned b_bytes = (unsigned)((size_t)a.nt * 32 * (size_t)br * 4), s_bytes = (unsigned)((size_t)a.nt * 32 * (size_t)(srows ? srows : 1) * 4);
     WStageDma dma;
     dma.ptot = 0;
+    if constexpr (CX) {
+        dma.cidx = a.cidx;
+        dma.b_sh = 31 - __builtin_clz((unsigned)(br * 4));
+        dma.s_sh = 31 - __builtin_clz((unsigned)((srows ? srows : 1) * 4));
+        dma.s_gather = SGATHER;
+    }
     if (nstage > 0) {
         const int nt0 = left < g ? left : g;
-        dma.init(ga, gb, gs, a_fl, b_fl, s_fl, nt0, g, lds_addr, wave, lane);
-        dma.template issue<MD::NWV, SIDE>(1 << 20);
+        if constexpr (CX) {
+            dma.template init_cx<MD::NWV>(ga, B0, SGATHER ? S0 : gs, b_bytes, s_bytes, a_fl, b_fl, s_fl, nt0, g, lds_addr, wave, lane, slot);
+            slot += 32 * nt0;
+        } else {
+            dma.init(ga, gb, gs, a_fl, b_fl, s_fl, nt0, g, lds_addr, wave, lane);
+        }
+        dma.template issue<MD::NWV, SIDE, CX>(1 << 20);
         ga += (size_t)nt0 * a_fl, gb += (size_t)nt0 * b_fl, left -= nt0;
         if (SIDE) gs += (size_t)nt0 * s_fl;
     }
@@ -332,8 +416,15 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
         nh_sched_fence();  // first operand reads leave before the scalar set-up of the next copy
         const int ntn = left < g ? left : g;
         dma.ptot = 0;
-        if (ntn > 0)
-            dma.init(ga, gb, gs, a_fl, b_fl, s_fl, ntn, g, lds_addr + (unsigned)(((n + 1) & 1) * NH_WG_STAGE_FLOATS * 4), wave, lane);
+        if (ntn > 0) {
+            if constexpr (CX) {
+                dma.template init_cx<MD::NWV>(ga, B0, SGATHER ? S0 : gs, b_bytes, s_bytes, a_fl, b_fl, s_fl, ntn, g,
+                            lds_addr + (unsigned)(((n + 1) & 1) * NH_WG_STAGE_FLOATS * 4), wave, lane, slot);
+                slot += 32 * ntn;
+            } else {
+                dma.init(ga, gb, gs, a_fl, b_fl, s_fl, ntn, g, lds_addr + (unsigned)(((n + 1) & 1) * NH_WG_STAGE_FLOATS * 4), wave, lane);
+            }
+        }
         ga += (size_t)ntn * a_fl, gb += (size_t)ntn * b_fl, left -= ntn;
         if (SIDE) gs += (size_t)ntn * s_fl;
         if (active) {
@@ -342,7 +433,7 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
 #pragma unroll
                 for (int s = 0; s < 16; s += 2) {
                     wstep_load(c1, pa + (s + 1) * 2 * AR, pb + (s + 1) * 2 * BR, ps + (s + 1) * 2 * srows);
-                    dma.template issue<MD::NWV, SIDE>(1);
+                    dma.template issue<MD::NWV, SIDE, CX>(1);
                     nh_sched_fence();
                     wstep_mfma<PO, PI, BX, SD>(c0, acc, bsum, sacc, sbsum, srow, ss);
                     // (last: one k-step past the stage, unused)
@@ -355,7 +446,7 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
                 for (int s = 0; s < steps; s += 2) {
                     pa += 2 * ar, pb += 2 * br, ps += 2 * srows;
                     wstep_load(c1, pa, pb, ps);
-                    dma.template issue<MD::NWV, SIDE>(1);  // the next stage streams in underneath the MFMAs (at most 9 pieces per wave and stage)
+                    dma.template issue<MD::NWV, SIDE, CX>(1);  // the next stage streams in underneath the MFMAs (at most 9 pieces per wave and stage)
                     nh_sched_fence();
                     wstep_mfma<PO, PI, BX, SD>(c0, acc, bsum, sacc, sbsum, srow, ss);
                     pa += 2 * ar, pb += 2 * br, ps += 2 * srows;
@@ -365,7 +456,7 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
                 }
             }
         }
-        dma.template issue<MD::NWV, SIDE>(1 << 20);  // idle waves, and whatever a short stage left over
+        dma.template issue<MD::NWV, SIDE, CX>(1 << 20);  // idle waves, and whatever a short stage left over
         ntile = ntn;
     }
 #ifdef NH_WGRAD_TIMELINE
@@ -504,7 +595,9 @@ NH_KERNEL void NH_LB(64 * MD::NWV, 2) k_wgrad(WgradArgs a) {
     const JobDev jb = a.jobs[ji];
     const int nks = (ji + 1 < a.njobs ? a.jobs[ji + 1].wg_start : a.total_wgs) - jb.wg_start;
     const int ks = (int)wg - jb.wg_start;
-    const int64_t t0 = a.nt * ks / nks, t1 = a.nt * (ks + 1) / nks;
+    // (compacted: the job's tiles are those of the sample list, however many the launch's cotangents left)
+    const int64_t ntl = MD::CX ? (int64_t)((nh_uload_i32(a.cstats, NH_CSTAT_ACTIVE) + 31) >> 5) : a.nt;
+    const int64_t t0 = ntl * ks / nks, t1 = ntl * (ks + 1) / nks;
     const int lane = nh_lane(), wave = nh_wave_in_block();
     const bool active = wave < jb.wo * jb.wi;  // idle waves still copy and synchronise
     // wave -> patch (ow, iw); the column index is rotated by the row so that the waves of one column (which carry the
@@ -763,7 +856,7 @@ int64_t nh_wgrad_partial_floats(nerfhip_plan* p, int64_t nt) {
 }
 
 int nh_wgrad(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad, float* partial, float* g_params,
-             const unsigned* gscale, nerfhip_stream_t stream) {
+             const unsigned* gscale, const NhCompact* cx, nerfhip_stream_t stream) {
     WgradArgs w;
     ReduceArgs red;
     memset(&w, 0, sizeof(w));
@@ -780,6 +873,8 @@ int nh_wgrad(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad,
     NH_REQUIRE(red.njobs <= NH_JOBS_DEV, "wgrad: %d reduce records exceed the table of %d", red.njobs, NH_JOBS_DEV);
     w.nt = nt;
     w.clk = nh_prof_clock_slot(NH_CLK_WGRAD);
+    w.cidx = cx ? cx->idx : nullptr;
+    w.cstats = cx ? cx->stats : nullptr;
     for (int q = 0; q < w.njobs; ++q) {
         const NhJob& j = p->jobs[q];
         NH_REQUIRE(j.b_row0 == 0 && 32 * j.a_tiles == j.a_region_rows && 32 * j.b_tiles == j.b_region_rows &&
@@ -793,7 +888,11 @@ int nh_wgrad(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad,
     int rc = NERFHIP_OK;
     // (profile name: a level-4 plan leaves this kernel the thin blocks only -- a different amount of work under the same symbol)
     const char* const name = p->bjobs.empty() ? "k_wgrad<MD>" : "k_wgrad<MD>[thin blocks]";
-    if (p->wgrad_waves == 4)
+    if (cx) {
+        // (a gathered row's byte offset is a 32-bit buffer offset: nh_mlp_backward compacts only launches whose regions fit)
+        const char* const name_cx = p->bjobs.empty() ? "k_wgrad<MD, compacted>" : "k_wgrad<MD, compacted>[thin blocks]";
+        rc = p->wgrad_waves == 4 ? launch_wgrad<WModeNarrowCx>(w, name_cx, stream) : launch_wgrad<WModeWideCx>(w, name_cx, stream);
+    } else if (p->wgrad_waves == 4)
         rc = launch_wgrad<WModeNarrow>(w, name, stream);
     else
         rc = launch_wgrad<WModeWide>(w, name, stream);

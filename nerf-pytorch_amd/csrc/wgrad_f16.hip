@@ -63,6 +63,11 @@ struct WgBArgs {
     int64_t s_off, s_bias_off;
     int s_idx, s_r_lo, s_r_hi, s_col_base, s_col_count;
     signed char scol[64];    // SB launches: encoding slot -> reference column of the side block, or -1
+    // compacted backward (CX launches; compact.hip): the sample list and its statistics.  The A regions (and an SA guest's) are then the
+    // compacted d(pre-activation) images -- sample slot s is row s --, the B regions (and an SB guest's) are gathered: slot s is row
+    // cidx[s] of the stash region
+    const int* cidx;
+    const int* cstats;
     WgBJob jobs[NHW_MAX_JOBS];
 };
 
@@ -144,7 +149,42 @@ NH_DEVICE float rows_store(const RowItems<ROWS>& r, char* hi_blocks, char* lo_bl
     return sum;
 }
 
-template <int AR, int BR, int SA = 0, int SB = 0>
+// 1-KiB piece p of one 16-sample step of a gathered region (ROWS rows per sample): a piece holds N = 1024 / (4 ROWS) whole rows (or a
+// part of one); rows[e]: the list entries of the samples it covers (gather_rows), each lane copies 16 bytes of its sample's row
+template <int ROWS>
+struct GatherN {
+    static constexpr int RB = ROWS * 4, N = RB >= 1024 ? 1 : 1024 / RB;
+};
+template <int ROWS>
+NH_DEVICE void gather_rows(unsigned* rows, const int* cidx, int s0, int p) {
+    constexpr int RB = GatherN<ROWS>::RB, N = GatherN<ROWS>::N;
+    const int first = RB >= 1024 ? s0 + (p * 1024) / RB : s0 + p * N;
+#pragma unroll
+    for (int e = 0; e < N; ++e) rows[e] = (unsigned)nh_uload_i32(cidx, first + e);
+}
+template <int ROWS>
+NH_DEVICE void gather_piece_f16(const NhDmaSrc& src, const unsigned* rows, int p, int lane, unsigned lds_dst) {
+    constexpr int RB = GatherN<ROWS>::RB, N = GatherN<ROWS>::N;
+    if constexpr (RB >= 1024) {
+        nh_dma16a(src, lane * 16, (int)(rows[0] * (unsigned)RB + ((unsigned)p * 1024u) % RB), lds_dst);
+    } else {
+        const int e = (lane * 16) / RB;
+        unsigned row = rows[0];
+#pragma unroll
+        for (int k = 1; k < N; ++k) {
+            row = e == k ? rows[k] : row;
+#ifndef NERFHIP_EMU
+            // (one v_cndmask per row: left alone, the compiler turns the chain into a dynamically indexed read of a private array,
+            // i.e. 4 N bytes of scratch memory per lane and a scratch load per piece)
+            asm volatile("" : "+v"(row));
+#endif
+        }
+        nh_dma16a(src, (int)(row * (unsigned)RB + (unsigned)(lane * 16) % RB), 0, lds_dst);
+    }
+}
+
+// CX: the compacted backward -- its own instantiations, the dense kernels' registers are not touched
+template <int AR, int BR, int SA = 0, int SB = 0, bool CX = false>
 NH_KERNEL void NH_LB(NHW_THREADS, NHW_WAVES / 4) k_wgrad_f16x3(WgBArgs a) {
     using S = WShape<AR, BR, SA, SB>;
     constexpr int PO = S::PO, PI = S::PI, SR = S::SR;
@@ -161,7 +201,9 @@ NH_KERNEL void NH_LB(NHW_THREADS, NHW_WAVES / 4) k_wgrad_f16x3(WgBArgs a) {
     while (jq + 1 < a.njobs && (int)blockIdx.x >= a.jobs[jq + 1].wg0) ++jq;
     const WgBJob& jb = a.jobs[jq];
     const int64_t k = (int64_t)blockIdx.x - jb.wg0;
-    const int64_t u0 = 2 * (a.nt * k / jb.nwg), u1 = 2 * (a.nt * (k + 1) / jb.nwg);
+    // (compacted: the block's tiles are those of the sample list, however many the launch's cotangents left)
+    const int64_t ntl = CX ? (int64_t)((nh_uload_i32(a.cstats, NH_CSTAT_ACTIVE) + 31) >> 5) : a.nt;
+    const int64_t u0 = 2 * (ntl * k / jb.nwg), u1 = 2 * (ntl * (k + 1) / jb.nwg);
     const float* const a_reg = a.grad + jb.a_off;
     const float* const b_reg = a.stash + jb.b_off;
     const float* const s_reg = SR ? (SA ? a.grad : a.stash) + a.s_off : nullptr;
@@ -173,15 +215,41 @@ NH_KERNEL void NH_LB(NHW_THREADS, NHW_WAVES / 4) k_wgrad_f16x3(WgBArgs a) {
     constexpr int SPIECES = S::STAGE_S / 1024;                               // ... and one more for the first SPIECES waves
     static_assert(S::STAGE_A % (1024 * NHW_WAVES) == 0 && S::STAGE_B % (1024 * NHW_WAVES) == 0, "every wave issues the same number of pieces");
     static_assert(SPIECES <= NHW_WAVES, "at most one side piece per wave");
+    // (CX) the list entries of the samples this wave's gathered pieces of a step cover -- scalar registers, fetched by preload(u) well
+    // before issue(u) needs them: at the top of the iteration that ends in it (fetched at the pieces themselves, the wave waited for
+    // the scalar cache two or three times per step: + 16 % on this HBM-bound kernel)
+    constexpr int NPB = S::STAGE_B / 1024 / NHW_WAVES;  // gathered B pieces per wave and step
+    static_assert(!CX || NPB * NHW_WAVES * 1024 == S::STAGE_B, "every wave gathers the same number of B pieces");
+    unsigned rb[NPB * GatherN<BR>::N > 0 ? NPB * GatherN<BR>::N : 1], rs[GatherN<(SB ? SB : 32)>::N];
+    auto preload = [&](int64_t u) {
+        if (CX) {
+#pragma unroll
+            for (int j = 0; j < NPB; ++j) gather_rows<BR>(rb + j * GatherN<BR>::N, a.cidx, (int)u * 16, wave + j * NHW_WAVES);
+            // (every wave: a conditional fill would park the array in scratch memory)
+            if (SB) gather_rows<(SB ? SB : 32)>(rs, a.cidx, (int)u * 16, wave < SPIECES ? wave : 0);
+        }
+    };
     auto issue = [&](int64_t u) {  // one step of the regions -> stage u % NHW_STAGES: 1-KiB pieces dealt to the waves
         const NhDmaSrc da = nh_dma_src(a_reg + (size_t)u * 16 * AR, (unsigned)S::STAGE_A);
-        const NhDmaSrc db = nh_dma_src(b_reg + (size_t)u * 16 * BR, (unsigned)S::STAGE_B);
         const unsigned st = lds0 + (unsigned)((int)(u % NHW_STAGES) * S::STAGE);
         for (int p = wave; p < S::STAGE_A / 1024; p += NHW_WAVES) nh_dma16a(da, lane * 16, p * 1024, st + (unsigned)(p * 1024));
-        for (int p = wave; p < S::STAGE_B / 1024; p += NHW_WAVES) nh_dma16a(db, lane * 16, p * 1024, st + (unsigned)(S::STAGE_A + p * 1024));
+        if (CX) {  // the B rows of the step's 16 listed samples, out of the whole region (their list entries: preload(u))
+            const NhDmaSrc db = nh_dma_src(b_reg, (unsigned)((size_t)a.nt * 32 * BR * 4));
+#pragma unroll
+            for (int j = 0; j < NPB; ++j)
+                gather_piece_f16<BR>(db, rb + j * GatherN<BR>::N, wave + j * NHW_WAVES, lane, st + (unsigned)(S::STAGE_A + (wave + j * NHW_WAVES) * 1024));
+        } else {
+            const NhDmaSrc db = nh_dma_src(b_reg + (size_t)u * 16 * BR, (unsigned)S::STAGE_B);
+            for (int p = wave; p < S::STAGE_B / 1024; p += NHW_WAVES) nh_dma16a(db, lane * 16, p * 1024, st + (unsigned)(S::STAGE_A + p * 1024));
+        }
         if (SR) {
-            const NhDmaSrc ds = nh_dma_src(s_reg + (size_t)u * 16 * SR, (unsigned)S::STAGE_S);
-            if (wave < SPIECES) nh_dma16a(ds, lane * 16, wave * 1024, st + (unsigned)(S::STAGE_A + S::STAGE_B + wave * 1024));
+            if (CX && SB) {  // (an SB guest lives in the stash: gathered; an SA guest in the compacted gradient scratch: contiguous)
+                const NhDmaSrc ds = nh_dma_src(s_reg, (unsigned)((size_t)a.nt * 32 * (SR ? SR : 1) * 4));
+                if (wave < SPIECES) gather_piece_f16<(SB ? SB : 32)>(ds, rs, wave, lane, st + (unsigned)(S::STAGE_A + S::STAGE_B + wave * 1024));
+            } else {
+                const NhDmaSrc ds = nh_dma_src(s_reg + (size_t)u * 16 * SR, (unsigned)S::STAGE_S);
+                if (wave < SPIECES) nh_dma16a(ds, lane * 16, wave * 1024, st + (unsigned)(S::STAGE_A + S::STAGE_B + wave * 1024));
+            }
         }
     };
     f32x16 acc[PO][PI];
@@ -206,8 +274,12 @@ NH_KERNEL void NH_LB(NHW_THREADS, NHW_WAVES / 4) k_wgrad_f16x3(WgBArgs a) {
     const int ta0 = wo * PO, tb0 = wi * PI;
 #pragma unroll
     for (int d = 0; d < NHW_STAGES; ++d)
-        if (u0 + d < u1) issue(u0 + d);
+        if (u0 + d < u1) {
+            preload(u0 + d);
+            issue(u0 + d);
+        }
     for (int64_t u = u0; u < u1; ++u) {
+        if (u + NHW_STAGES < u1) preload(u + NHW_STAGES);  // (consumed by the issue() at the end of this iteration)
         // the copy of step u is this wave's OLDEST outstanding one: wait for it alone while the later steps' copies stay in flight
 #ifndef NHW_EXP_NO_WAIT  // (NH_DIAG builds only, wrong results)
         const int64_t behind = u1 - 1 - u < NHW_STAGES - 1 ? u1 - 1 - u : NHW_STAGES - 1;  // steps in flight behind step u
@@ -512,12 +584,21 @@ int launch(WgBArgs& w, nerfhip_stream_t stream) {
     if (w.njobs == 0) return NERFHIP_OK;
     using S = WShape<AR, BR, SA, SB>;
     static_assert(S::PART == AR * BR + S::SIDE_TILES * 1024 + NHW_THREADS + (SA ? 64 : 0), "schedule() sizes the partials");
-    int rc = w_lds_limit(k_wgrad_f16x3<AR, BR, SA, SB>, S::LDS_BYTES);
-    if (rc) return rc;
     const int wgs = w.jobs[w.njobs - 1].wg0 + w.jobs[w.njobs - 1].nwg;
-    NH_LAUNCH_NAMED(AR == BR ? (SA || SB ? "k_wgrad_f16x3<full+side>" : "k_wgrad_f16x3<full>")
-                             : (SA || SB ? "k_wgrad_f16x3<half+side>" : "k_wgrad_f16x3<half>"),
-                    (k_wgrad_f16x3<AR, BR, SA, SB>), wgs, NHW_THREADS, (S::LDS_BYTES), stream, w);
+    int rc = NERFHIP_OK;
+    if (w.cidx) {
+        rc = w_lds_limit(k_wgrad_f16x3<AR, BR, SA, SB, true>, S::LDS_BYTES);
+        if (rc) return rc;
+        NH_LAUNCH_NAMED(AR == BR ? (SA || SB ? "k_wgrad_f16x3<full+side, compacted>" : "k_wgrad_f16x3<full, compacted>")
+                                 : (SA || SB ? "k_wgrad_f16x3<half+side, compacted>" : "k_wgrad_f16x3<half, compacted>"),
+                        (k_wgrad_f16x3<AR, BR, SA, SB, true>), wgs, NHW_THREADS, (S::LDS_BYTES), stream, w);
+    } else {
+        rc = w_lds_limit(k_wgrad_f16x3<AR, BR, SA, SB>, S::LDS_BYTES);
+        if (rc) return rc;
+        NH_LAUNCH_NAMED(AR == BR ? (SA || SB ? "k_wgrad_f16x3<full+side>" : "k_wgrad_f16x3<full>")
+                                 : (SA || SB ? "k_wgrad_f16x3<half+side>" : "k_wgrad_f16x3<half>"),
+                        (k_wgrad_f16x3<AR, BR, SA, SB>), wgs, NHW_THREADS, (S::LDS_BYTES), stream, w);
+    }
     rc = nh_launch_status("wgrad_f16x3");
     if (rc) return rc;
     constexpr int NALL = AR * BR + AR + S::SIDE_TILES * 1024 + SA;
@@ -533,7 +614,7 @@ int64_t nh_wgrad_x3_partial_floats(nerfhip_plan* p, int64_t nt) {
 }
 
 int nh_wgrad_f16(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad, float* partial, float* g_params,
-                     const unsigned* amax, const unsigned* bmax, nerfhip_stream_t stream) {
+                 const unsigned* amax, const unsigned* bmax, const NhCompact* cx, nerfhip_stream_t stream) {
     if (p->bjobs.empty()) return NERFHIP_OK;
     NH_REQUIRE((int)p->bjobs.size() <= NHW_MAX_JOBS, "wgrad_f16: too many blocks");
     std::vector<LaunchB> L;
@@ -547,6 +628,8 @@ int nh_wgrad_f16(nerfhip_plan* p, int64_t nt, const float* stash, const float* g
         w.g_params = g_params;
         w.amax = amax;
         w.bmax = bmax;
+        w.cidx = cx ? cx->idx : nullptr;
+        w.cstats = cx ? cx->stats : nullptr;
         w.partial = partial + off;
         off += (int64_t)(w.jobs[w.njobs - 1].wg0 + w.jobs[w.njobs - 1].nwg) * w.part_stride;
         const int W = p->W;

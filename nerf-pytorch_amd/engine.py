@@ -197,6 +197,27 @@ class TrainEngine:
             else:
                 self.loss.copy_(self._loss_c)
 
+    def backward_sample_counts(self):
+        """{"coarse": (kept, total), "fine": (kept, total)}: the sample points the last step's COMPACTED backward of each net kept
+        (those whose d(loss)/d(raw) row is not all zero) and the sample points of that launch; None for a net whose
+        set_backward_compaction is off.  Reads two words per net from the step's workspace: synchronises the device."""
+        out = {"coarse": None, "fine": None}
+        if self._ws is None:
+            return out
+        lib, n = self.lib, self._ws_n
+        plan_f = self.mf._plan if self.mf is not None else None
+        torch.cuda.synchronize(self.dev)
+        words = self._ws.view(torch.int32)
+        for name, model, samples in (("coarse", self.mc, self.cfg.num_coarse), ("fine", self.mf, self.cfg.num_coarse + self.cfg.num_fine)):
+            if model is None or not model.backward_compaction:
+                continue
+            off, nb = C.c_int64(), C.c_int64()
+            lib.render_workspace_region(self.mc._plan, plan_f, C.byref(self.cfg), n, 1, ("bwd_scratch_" + name).encode(), C.byref(off), C.byref(nb))
+            so = lib.plan_bwd_stats_offset(model._plan, n * samples)
+            w = words[(off.value + so) // 4:(off.value + so) // 4 + 2].cpu()
+            out[name] = (int(w[0]), int(w[1]))
+        return out
+
     def wait_gradients(self):
         """Orders this device's current stream behind the step's gradient all-reduces (no-op without collectives).
 

@@ -162,6 +162,7 @@ class FlexibleNeRFModel(torch.nn.Module):
         self._inf_packed = None
         if getattr(self, "inference_precision", "fp32") != "fp32":
             self._inf_owner = _PlanHandle(self.cfg, PRECISIONS[self.inference_precision])
+        lib.plan_set_bwd_compaction(self._plan, int(bool(getattr(self, "backward_compaction", False))))
         self._flatten()
 
     @property
@@ -186,6 +187,18 @@ class FlexibleNeRFModel(torch.nn.Module):
         _PlanHandle(self.cfg, PRECISIONS[precision])  # (raises for a geometry the split-precision kernels do not cover, before anything changes)
         self.training_precision = precision
         self._native_init()
+        return self
+
+    backward_compaction = False
+
+    def set_backward_compaction(self, on=True):
+        """Compacted backward (nerfhip_plan_set_bwd_compaction; off by default): this model's backward passes drop the sample points
+        whose d(loss)/d(raw) row is exactly zero -- sigma_a = relu(raw[..., 3] + noise) is off there, or the ray's transmittance has
+        reached 0 (nerf/volume_rendering_utils.py:38-42) -- instead of multiplying zeros through eight layers as autograd does
+        (train_nerf.py:259).  The gradient is the same sum with its zero terms dropped; forward, stash, parameters and optimizer state
+        are unaffected.  Works with every training precision; may be switched at any time."""
+        self.backward_compaction = bool(on)
+        L.get_lib().plan_set_bwd_compaction(self._plan, int(self.backward_compaction))
         return self
 
     def set_inference_precision(self, precision):

@@ -278,8 +278,21 @@ class Backend:
         self.lib.mlp_fwd(plan, self.ptr(packed), self.ptr(dx), m, self.ptr(out), self.p(stash), self.stream())
         return self.host(out), stash
 
-    def mlp_bwd(self, plan, packed, g_out, stash, flat_for_input_grad=None):
-        """Flat parameter gradient; with `flat_for_input_grad` (the flat parameter vector) also d(loss)/d(x)."""
+    def set_compaction(self, plan, on):
+        """nerfhip_plan_set_bwd_compaction: the plan's backward drops the samples whose d(raw output) row is all zero."""
+        self.lib.plan_set_bwd_compaction(plan, int(bool(on)))
+        assert self.lib.plan_bwd_compaction(plan) == int(bool(on))
+
+    def bwd_stats(self, plan, m, scratch):
+        """(samples kept, samples of the launch) of the last compacted backward that ran in `scratch`."""
+        off = self.lib.plan_bwd_stats_offset(plan, m)
+        assert off >= 0 and off % 4 == 0
+        w = self.host(scratch[off // 4:off // 4 + 2])
+        return tuple(int(v) for v in np.ascontiguousarray(w).view(np.int32))
+
+    def mlp_bwd(self, plan, packed, g_out, stash, flat_for_input_grad=None, want_stats=False):
+        """Flat parameter gradient; with `flat_for_input_grad` (the flat parameter vector) also d(loss)/d(x); with want_stats
+        also the compacted backward's (kept, total) sample counts."""
         m = g_out.shape[0]
         dg = self.dev(np.ascontiguousarray(g_out, np.float32))
         sb = self.lib.plan_bwd_scratch_bytes(plan, m)
@@ -287,6 +300,8 @@ class Backend:
         gp = self.empty((self.lib.plan_num_params(plan),))
         self.lib.mlp_bwd(plan, self.ptr(packed), self.ptr(dg), m, self.ptr(stash), self.ptr(scratch), sb, self.ptr(gp),
                          self.stream())
+        if want_stats:
+            return self.host(gp), self.bwd_stats(plan, m, scratch)
         if flat_for_input_grad is None:
             return self.host(gp)
         d = self.lib.plan_dim_xyz(plan) + self.lib.plan_dim_dir(plan)
@@ -351,6 +366,16 @@ class Backend:
                 out["g_rays"] = self.host(g_rays)
             out["g_params_coarse"] = self.host(gpc)
             out["g_params_fine"] = self.host(gpf) if gpf is not None else None
+            # (kept, total) sample points of each net's backward, where its plan runs compacted (nerfhip_plan_set_bwd_compaction)
+            for name, plan, samples in (("coarse", plan_c, nc), ("fine", plan_f, nc + nf)):
+                if plan is None or samples == 0 or not self.lib.plan_bwd_compaction(plan):
+                    continue
+                off, nb = C.c_int64(), C.c_int64()
+                self.lib.render_workspace_region(plan_c, plan_f, C.byref(cfg), n, 2, ("bwd_scratch_" + name).encode(), C.byref(off),
+                                                 C.byref(nb))
+                so = self.lib.plan_bwd_stats_offset(plan, n * samples)
+                w = self.host(ws[(off.value + so) // 4:(off.value + so) // 4 + 2])
+                out["bwd_kept_" + name] = tuple(int(v) for v in np.ascontiguousarray(w).view(np.int32))
         return out
 
     def mse_loss(self, rgb_c, rgb_f, target, grad_scale=1.0):

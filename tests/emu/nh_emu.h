@@ -152,57 +152,9 @@ NH_DEVICE f32x4 nh_mfma16(float a, float b, f32x4 c) {
     return d;
 }
 
-// bf16 pieces (mlp_bf16.hip): software round-to-nearest-even conversion; v_mfma_f32_32x32x16_bf16 semantics -- lane l
-// supplies A[l&31][8*(l>>5)+e] and B[8*(l>>5)+e][l&31]; D registers as for nh_mfma32; exact products, fp32 fmaf chain
-// (the hardware's internal summation order is not part of what the tests pin down: they compare to 1e-5-level bounds).
-struct nh_bf16 {
-    uint16_t bits;
-};
-struct nh_bf16x8 {
-    nh_bf16 v[8];
-    nh_bf16& operator[](int i) { return v[i]; }
-    const nh_bf16& operator[](int i) const { return v[i]; }
-};
-NH_DEVICE nh_bf16 nh_to_bf16(float f) {
-    uint32_t u;
-    memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return nh_bf16{(uint16_t)((u >> 16) | 0x40u)};  // NaN stays NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return nh_bf16{(uint16_t)(u >> 16)};
-}
-NH_DEVICE float nh_from_bf16(nh_bf16 h) {
-    uint32_t u = (uint32_t)h.bits << 16;
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
-}
-NH_DEVICE f32x16 nh_mfma_bf16(nh_bf16x8 a, nh_bf16x8 b, f32x16 c) {
-    emu::WaveState& w = emu::cur_wave();
-    const int lane = emu::cur->lane, j = lane & 31, h = lane >> 5;
-    f32x16 d = c;
-    for (int part = 0; part < 2; ++part) {  // elements 4*part .. 4*part+3 of every lane: 8 bytes per exchange
-        int ph = emu::cur->xphase;
-        emu::cur->xphase ^= 1;
-        memcpy(&w.xa[ph][lane], &a.v[4 * part], 8);
-        memcpy(&w.xb[ph][lane], &b.v[4 * part], 8);
-        emu::wave_barrier();
-        for (int r = 0; r < 16; ++r) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-            float acc = d[r];
-            for (int hh = 0; hh < 2; ++hh)
-                for (int e = 0; e < 4; ++e) {
-                    nh_bf16 av[4], bv[4];
-                    memcpy(av, &w.xa[ph][i + 32 * hh], 8);
-                    memcpy(bv, &w.xb[ph][j + 32 * hh], 8);
-                    acc = fmaf(nh_from_bf16(av[e]), nh_from_bf16(bv[e]), acc);
-                }
-            d[r] = acc;
-        }
-    }
-    return d;
-}
-
-// IEEE fp16 pieces (mlp_f16.hip): software round-to-nearest-even conversion incl. subnormals; the MFMA as nh_mfma_bf16
+// IEEE fp16 pieces (mlp_f16w.hip, wgrad_f16.hip): software round-to-nearest-even conversion incl. subnormals;
+// v_mfma_f32_32x32x16_f16 semantics -- lane l supplies A[l&31][8*(l>>5)+e] and B[8*(l>>5)+e][l&31]; D registers as for nh_mfma32;
+// exact products, fp32 fmaf chain (the hardware's internal summation order is not part of what the tests pin down)
 struct nh_f16 {
     uint16_t bits;
 };
@@ -321,9 +273,6 @@ NH_DEVICE unsigned long long nh_lds_tr16(const char* lds_ptr) {
 NH_DEVICE float nh_pair_sum_f16(unsigned pair, float c) {
     return (c + nh_from_f16(nh_f16{(uint16_t)(pair & 0xffffu)})) + nh_from_f16(nh_f16{(uint16_t)(pair >> 16)});
 }
-NH_DEVICE float nh_pair_sum_bf16(unsigned pair, float c) {
-    return (c + nh_from_bf16(nh_bf16{(uint16_t)(pair & 0xffffu)})) + nh_from_bf16(nh_bf16{(uint16_t)(pair >> 16)});
-}
 NH_DEVICE unsigned nh_wave_max_u32(unsigned v) {
     for (int d = 32; d >= 1; d >>= 1) {
         const unsigned o = (unsigned)nh_shfl_xor_i((int)v, d);
@@ -349,6 +298,7 @@ NH_DEVICE unsigned nh_lds_addr(const float* lds_ptr) { return (unsigned)((const 
 NH_DEVICE void nh_dma16a(const NhDmaSrc& s, int voff, int soff, unsigned lds_wave_addr) {
     nh_dma16(s, voff, soff, (float*)(emu::g_dyn_smem + lds_wave_addr));
 }
+NH_DEVICE int nh_uload_i32(const int* p, int i) { return p[i]; }
 NH_DEVICE void nh_wait_vmem() {}
 template <int N>
 NH_DEVICE void nh_wait_vmem_keep() {}

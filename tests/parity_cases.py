@@ -414,6 +414,67 @@ def case_mlp_backward(b, names=None, m=150, precision=0, g_scale=1.0, w_gain=1.0
         b.lib.plan_destroy(plan)
 
 
+def case_mlp_backward_compacted(b, names=None, m=300, precision=0, fractions=(0.0, 0.45, 0.85, 1.0), g_scale=1.0):
+    """The compacted backward (nerfhip_plan_set_bwd_compaction; csrc/compact.hip) against the dense one of the same plan and against the
+    oracle's autograd.  d(raw output) rows are zeroed at random at the given fractions -- what relu(sigma + noise)
+    (nerf/volume_rendering_utils.py:38) does to the cotangents of a training batch: 0 (nothing to drop), in between (ragged last tile,
+    gathered rows), 1 (every row zero: the gradient is exactly zero) --; also a batch whose ONLY non-zero row is the last sample.
+    Compacted == dense up to the rounding of another split-K partition (`unit.compact_vs_dense`, of max|g| per tensor); the count the
+    library reports is the number of non-zero rows; d(loss)/d(x) comes out the same with zero rows for the dropped samples."""
+    mb = TL.bound("unit.mlp_bwd", ARITH_NAME[precision])
+    margin, tol = mb["margin"], mb["tol"]
+    ctol = TL.bound("unit.compact_vs_dense", ARITH_NAME[precision])
+    for name in names or ("default4x128", "fern8x128_skip3_L6", "novw4x128"):
+        cfg = MLP_GEOMETRIES[name]
+        plan, params, flat, packed = mlp_setup(b, cfg, seed=47, precision=precision)
+        dx, dd = O.model_dims(cfg)
+        gen = rng(48)
+        x = torch.randn(m, dx + dd, generator=gen)
+        keep = O.mlp_relu_margin(params, x, cfg) > margin
+        x = x[keep].contiguous()
+        mm = x.shape[0]
+        assert mm >= 0.9 * m
+        go_full = torch.randn(mm, 4, generator=gen) * g_scale
+        patterns = []
+        for fr in fractions:
+            on = (torch.rand(mm, generator=gen) >= fr) if 0.0 < fr < 1.0 else torch.full((mm,), fr == 0.0)
+            patterns.append(("zero fraction %.2f" % fr, on))
+        last = torch.zeros(mm, dtype=torch.bool)
+        last[-1] = True
+        patterns.append(("only the last sample", last))
+        _, stash = b.mlp_fwd(plan, packed, x.numpy(), want_stash=True)
+        for what, on in patterns:
+            go = go_full * on[:, None].float()
+            p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+            xr = x.clone().requires_grad_(True)
+            (O.mlp_forward(p, xr, cfg) * go).sum().backward()
+            b.set_compaction(plan, False)
+            dense, gx_dense = b.mlp_bwd(plan, packed, go.numpy(), stash, flat_for_input_grad=flat)
+            b.set_compaction(plan, True)
+            comp, stats = b.mlp_bwd(plan, packed, go.numpy(), stash, want_stats=True)
+            _, gx_comp = b.mlp_bwd(plan, packed, go.numpy(), stash, flat_for_input_grad=flat)
+            assert stats == (int(on.sum()), mm), (name, what, stats, int(on.sum()), mm)
+            assert np.isfinite(comp).all(), (name, what)
+            if not bool(on.any()):
+                assert not comp.any() and not gx_comp.any(), (name, what)  # (every term dropped: exactly zero)
+            gd, gc = b.unflatten(plan, dense), b.unflatten(plan, comp)
+            worst = 0.0
+            for k, v in p.items():
+                ref = v.grad.numpy()
+                scale = float(np.abs(ref).max()) + 1e-12
+                close(gc[k], ref, tol * scale + 1e-7 * g_scale, 10 * tol, what="compacted mlp bwd %s %s %s" % (name, what, k))
+                d = float(np.abs(gc[k] - gd[k]).max()) / (float(np.abs(gd[k]).max()) + 1e-30)
+                worst = max(worst, d)
+                assert d <= ctol, ("compacted vs dense", name, what, k, d, ctol)
+            # d(loss)/d(x): per-sample chains, no sum over samples -- identical rows, zero rows where the cotangent is zero
+            sx = float(np.abs(gx_dense).max()) + 1e-30
+            assert float(np.abs(gx_comp - gx_dense).max()) <= 1e-6 * sx, (name, what)
+            assert not gx_comp[~on.numpy()].any(), (name, what)
+            note("compact_vs_dense_%s_%s" % (ARITH_NAME[precision], b.name), **{"%s | %s" % (name, what): worst})
+        b.set_compaction(plan, False)
+        b.lib.plan_destroy(plan)
+
+
 def case_f16x3_range_extremes(b, m=120):
     """The edges of the fp16-piece bookkeeping (round 5).  (i) Cotangents of 1e-30, 1e-33 and of fp32-SUBNORMAL size (1e-39):
     the per-sample exponent would be 113 / 123 / undefined -- it is clamped at 110 / the sample counts as all-zero (mlp_f16w.hip

@@ -177,6 +177,59 @@ def test_mlp_backward(gpu):
                                     "northstar8x256"), m=1500)
 
 
+@pytest.mark.parametrize("arith", ["fp32", "f16x3_fwd_dgrad", "f16x3_train"])
+def test_compacted_backward_equals_dense(gpu, arith):
+    """nerfhip_plan_set_bwd_compaction (round 6): the backward over the samples whose d(raw output) row is not all zero == the dense
+    backward of the same plan (`unit.compact_vs_dense`), and both within the oracle's autograd bound; zero fractions 0 ... 1, a batch
+    whose only non-zero row is its last sample; every kernel width."""
+    prec = {"fp32": 0, "f16x3_fwd_dgrad": P.F16X3_FWD_DGRAD, "f16x3_train": P.F16X3_TRAIN}[arith]
+    P.case_mlp_backward_compacted(gpu, names=("northstar8x256", "default4x128", "fern8x128_skip3_L6", "novw4x128", "llff4x64_skip3_L6"),
+                                  m=1500, precision=prec)
+    if arith == "fp32":
+        P.case_mlp_backward_compacted(gpu, names=("wide3x512_skip2", "odd5x99_skip2", "one_layer"), m=700, fractions=(0.5, 0.97))
+    else:
+        P.case_mlp_backward_compacted(gpu, names=("default4x128",), m=1500, precision=prec, fractions=(0.6,), g_scale=3e-7)
+
+
+@pytest.mark.parametrize("arith", ["fp32", "f16x3_train"])
+def test_full_size_compacted_backward_equals_dense(gpu, arith):
+    """BASELINE configs[1] at full size (4096 rays, 64 + 128, 8x256): the fused render's backward with both plans compacted against the
+    same backward dense -- the cotangents are the renderer's own, so the rows dropped are exactly those relu(sigma + noise) and the
+    transmittance zero (nerf/volume_rendering_utils.py:38-42); the kept / total counts the library reports equal the number of non-zero
+    d(raw) rows a dense torch evaluation of the compositing backward finds."""
+    prec = {"fp32": 0, "f16x3_train": P.F16X3_TRAIN}[arith]
+    cfg = P.MLP_GEOMETRIES["northstar8x256"]
+    pc, _, _, packed_c = P.mlp_setup(gpu, cfg, seed=11, precision=prec)
+    pf, _, _, packed_f = P.mlp_setup(gpu, cfg, seed=12, precision=prec)
+    _, _, _, _, _, rays, opt, tgt = _full_setup(gpu)
+    n = rays.shape[0]
+    fwd = gpu.render(pc, pf, packed_c, packed_f, rays, opt, None, seed=5, training=True)
+    _, gc, gf = gpu.mse_loss(fwd["rgb_coarse"], fwd["rgb_fine"], tgt)
+    dense = gpu.render(pc, pf, packed_c, packed_f, rays, opt, None, seed=5, training=True, g_rgb=(gc, gf))
+    gpu.set_compaction(pc, True)
+    gpu.set_compaction(pf, True)
+    comp = gpu.render(pc, pf, packed_c, packed_f, rays, opt, None, seed=5, training=True, g_rgb=(gc, gf))
+    again = gpu.render(pc, pf, packed_c, packed_f, rays, opt, None, seed=5, training=True, g_rgb=(gc, gf))
+    tol = T.bound("e2e.compact_vs_dense")
+    rec = {}
+    for key, name, total in (("g_params_coarse", "coarse", n * 64), ("g_params_fine", "fine", n * 192)):
+        kept, tot = comp["bwd_kept_" + name]
+        assert tot == total and 0 < kept < total, (name, kept, tot)
+        assert np.array_equal(comp[key], again[key]), key           # fixed order: bit-reproducible
+        assert np.isfinite(comp[key]).all()
+        worst = 0.0
+        for plan in ((pc,) if name == "coarse" else (pf,)):
+            gd, gk = gpu.unflatten(plan, dense[key]), gpu.unflatten(plan, comp[key])
+            for k in gd:
+                d = float(np.abs(gk[k] - gd[k]).max()) / (float(np.abs(gd[k]).max()) + 1e-30)
+                worst = max(worst, d)
+                assert d <= tol, (arith, key, k, d, tol)
+        rec[name] = dict(kept=kept, total=tot, zero_fraction=round(1.0 - kept / tot, 4), worst_vs_dense=worst)
+    P.note("full_size_compact_vs_dense_%s" % arith, **{"%s_%s" % (a, b): v for a, r in rec.items() for b, v in r.items()})
+    for p in (pc, pf):
+        gpu.lib.plan_destroy(p)
+
+
 @pytest.mark.parametrize("name", ["e2e_a.npz", "e2e_b.npz", "e2e_c.npz", "e2e_d.npz"])
 def test_e2e_reference_goldens(gpu, name):
     P.case_e2e_golden(gpu, name)

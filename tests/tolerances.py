@@ -90,6 +90,13 @@ TOL = {
     "unit.mlp_fwd.vs_fp64_over_scale": (1.5e-6, "distance from the fp64 forward over the output scale (torch fp32: 1.2-3.6e-7)"),
     "unit.mlp_bwd": (dict(margin=1e-6, tol=2e-5), "teacher-forced MLP backward, m = 1500: of max|g| per tensor (case_mlp_backward)"),
     "unit.mlp_input_grad": (2e-5, "d(loss)/d(x), of max|g|"),
+    "e2e.compact_vs_dense": (2e-5, "the full lego batch's backward compacted against dense, of max|g| per tensor: two fp32-grade orders of one "
+                                   "sum of up to 786,432 terms whose zero terms were dropped (measured on MI355X: see "
+                                   "profiles/r06_parity_small_cases.json `full_size_compact_vs_dense_*`)"),
+    "unit.compact_vs_dense": (1e-5, "the compacted backward against the dense one of the same plan, of max|g| per tensor: the same terms "
+                                    "(zero terms dropped) summed under another split of the sample range over the workgroups -- two "
+                                    "fp32-grade orders of one sum, ~sqrt(terms) x 2^-24 of a term (case_mlp_backward_compacted; measured "
+                                    "<= 1e-6 on the emulator and on MI355X)"),
     "unit.render_grad.northstar48": ((3.4e-3, 5.6e-3), "48 rays of 8x256 behind the sampler: 5 x measured (6.8e-4 / 1.1e-3)"),
     "unit.render_grad.default200_white_noise1": ((1e-5, 5.5e-3), "5 x measured (2.1e-6 / 1.1e-3)"),
 }

@@ -382,6 +382,7 @@ def main():
     ap.add_argument("--global-rays", type=int, default=0, help="strong scaling: rays per iteration over ALL GPUs")
     ap.add_argument("--image", type=int, default=0, help="image side: default 400 (train) / 800 (eval)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-labelled-lines", action="store_true", help="default run only: skip the child-process lines (other precisions / workloads)")
     ap.add_argument("--hidden", type=int, default=0, help="hidden_size (default: the workload's)")
     ap.add_argument("--layers", type=int, default=0, help="num_layers (default: the workload's)")
     ap.add_argument("--overlap", type=int, default=-1, help="1: two-stream step (coarse backward next to the fine pass); "
@@ -393,9 +394,10 @@ def main():
                          "forward; --mode train --precision f16x3_fwd the training forward, f16x3_fwd_dgrad + the data-gradient chain, "
                          "f16x3_train + the large weight-gradient blocks.  A+B: coarse net A, fine net B.  Separate, labelled lines: "
                          "the driver's default stays fp32")
-    ap.add_argument("--compact", action="store_true",
+    ap.add_argument("--compact", nargs="?", const="gather", default=None, choices=("gather", "recompute"),
                     help="train: compacted backward (FlexibleNeRFModel.set_backward_compaction): data and weight gradient over the sample "
-                         "points whose d(loss)/d(raw) row is not all zero.  A labelled line: it states the zero fraction of the step it "
+                         "points whose d(loss)/d(raw) row is not all zero; `recompute`: additionally a stash-free training forward, the "
+                         "backward re-runs the forward for the kept samples.  A labelled line: it states the zero fraction of the step it "
                          "timed and prices the backward kernels on the FLOPs they executed; the driver's default stays dense")
     ap.add_argument("--gather", action="store_true", help="eval: rank 0 also receives every pose's rows (output plumbing)")
     ap.add_argument("--no-kernel-profile", action="store_true", help="do not bracket the launches of the timed region with HIP events (no "
@@ -483,8 +485,8 @@ def main():
         if prec_f != "fp32":
             mf.set_training_precision(prec_f)
         if args.compact:
-            mc.set_backward_compaction(True)
-            mf.set_backward_compaction(True)
+            mc.set_backward_compaction("recompute" if args.compact == "recompute" else True)
+            mf.set_backward_compaction("recompute" if args.compact == "recompute" else True)
         strong = args.global_rays > 0
         if strong:
             lo, hi = N.parallel.shard_bounds(args.global_rays, rank, world)
@@ -614,7 +616,10 @@ def main():
             kept_f = kept["fine"][0] if kept["fine"] else m_f
         for m, mb, prec in ((m_c, kept_c, prec_c), (m_f, kept_f, prec_f)):
             fmt, level = precision_level(prec)
-            add("fwd", fmt if level >= 1 else "fp32", 2.0 * fwd_macs * m, stash_b * m)
+            if args.mode == "train" and args.compact == "recompute":  # (stash-free pass over all samples + a stash-writing pass over the kept ones)
+                add("fwd", fmt if level >= 1 else "fp32", 2.0 * fwd_macs * (m + mb), 20 * m + stash_b * mb, 2)
+            else:
+                add("fwd", fmt if level >= 1 else "fp32", 2.0 * fwd_macs * m, stash_b * m)
             if args.mode != "train":
                 continue
             add("dgrad", fmt if level >= 3 else "fp32", 2.0 * dgrad_macs * mb, dgrad_b * mb)
@@ -679,6 +684,8 @@ def main():
                         kernel_ms_per_step={nm: round(m / args.steps, 4) for nm, (_, m) in sorted(kern.items(), key=lambda kv: -kv[1][1])})
         if args.mode == "train":
             total_flops = 2.0 * fwd_macs * (m_c + m_f) + 2.0 * (fwd_macs + dgrad_macs) * (kept_c + kept_f)   # (executed: == algorithmic when dense)
+            if args.compact == "recompute":
+                total_flops += 2.0 * fwd_macs * (kept_c + kept_f)
             step_bytes = stash_b * (m_c + m_f) + (dgrad_b + wgrad_b) * (kept_c + kept_f)
             if args.workload == "lego":
                 workload = ("lego %dx%d synthetic views (BASELINE configs[%d]): %d rays/GPU/iter (%d over all GPUs), %d coarse + %d "
@@ -727,7 +734,7 @@ def main():
                    step_hbm_frac_of_8tb_s=round(step_bytes / sec / 1e12 / HBM_PEAK_TBS, 4),
                    final_loss=loss_host, roofline=roof)
         if args.mode == "train":
-            res["backward"] = "compacted" if args.compact else "dense"
+            res["backward"] = {None: "dense", "gather": "compacted", "recompute": "compacted, stash recomputed for the kept samples"}[args.compact]
         if kept is not None:
             frac = lambda kv, m: None if kv is None else round(1.0 - kv[0] / float(m), 4)  # noqa: E731
             res["zero_cotangent_fraction"] = dict(
@@ -759,28 +766,65 @@ def main():
                     res["speedup_vs_pytorch_rocm_fwd_bwd"] = round(res["value"] / res["pytorch_rocm_reference"]["value"], 3)
                 except Exception as e:  # the torch arm needs ~13 GB and must never take the bench line down
                     res["pytorch_rocm_reference"] = dict(error=repr(e)[:200])
-                if args.workload == "lego" and cfg == MODEL and args.precision == "fp32":
-                    # the same workload, same steps, on the fp16-piece kernels (the arithmetic that holds the parity suite at the
-                    # fp32 kernels' bounds: tests/test_gpu_fullsize.py) -- a labelled line of its own, measured by
-                    # this very script in a child process; `value` above stays the fp32 headline
+                if args.workload == "lego" and cfg == MODEL and args.precision == "fp32" and not args.compact and not args.no_labelled_lines:
+                    # Labelled lines, each measured by this very script in a child process (`value` above stays the dense fp32 headline):
+                    # the same workload on the fp16-piece kernels (the arithmetic that holds the parity suite at the fp32 kernels' bounds:
+                    # tests/test_gpu_fullsize.py); both with the compacted backward; BASELINE configs[3] (fern) and [4] (eval,
+                    # one pose); the 4x128 nets the reference's scripts really build (train_nerf.py:117-134); and the trained regime
+                    # (scripts/bench_trained.py: 2000 iterations on the teacher scene first -- where most cotangent rows are zero)
+                    ref = res["pytorch_rocm_reference"].get("value")
                     res["labelled_lines"] = {}
-                    for prec in ("f16x3_train",):
+                    short = ["--no-cpu-baseline", "--no-labelled-lines", "--steps", str(min(args.steps, 10)), "--warmup", "2"]
+                    children = (("f16x3_train", ["--precision", "f16x3_train", "--steps", str(args.steps), "--warmup", str(args.warmup)]),
+                                ("fp32_compact", ["--compact"]),
+                                ("f16x3_train_compact", ["--precision", "f16x3_train", "--compact"]),
+                                ("fern_fp32", ["--workload", "fern"]),
+                                ("fern_f16x3_train", ["--workload", "fern", "--precision", "f16x3_train"]),
+                                ("4x128_fp32", ["--hidden", "128", "--layers", "4"]),
+                                ("4x128_f16x3_train", ["--hidden", "128", "--layers", "4", "--precision", "f16x3_train"]),
+                                ("eval_fp32", ["--mode", "eval", "--steps", "1", "--warmup", "1"]),
+                                ("eval_f16x3", ["--mode", "eval", "--precision", "f16x3", "--steps", "1", "--warmup", "1"]))
+                    for label, extra in children:
                         try:
-                            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--precision", prec, "--no-cpu-baseline", "--steps",
-                                                  str(args.steps), "--warmup", str(args.warmup), "--rays", str(args.rays)],
-                                                 capture_output=True, text=True, timeout=300)
+                            cmd = [sys.executable, os.path.abspath(__file__)] + short + ["--rays", str(args.rays)] + extra
+                            out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
                             j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
-                            res["labelled_lines"][prec] = dict(
-                                value=j["value"], unit=j["unit"], ms_per_step=j["ms_per_step"], dtype=j["dtype"],
-                                vs_fp32_line=round(j["value"] / res["value"], 3),
-                                speedup_vs_pytorch_rocm_fwd_bwd=(round(j["value"] / res["pytorch_rocm_reference"]["value"], 3)
-                                                                 if "value" in res["pytorch_rocm_reference"] else None),
-                                mlp_kernels={k: dict(kernel=v["kernel"], ms_per_step=v["ms_per_step"], frac_of_own_mfma_roofline=v["frac"],
-                                                     hbm_tb_s=v["hbm_tb_s"], hbm_frac=v["hbm_frac"])
-                                             for k, v in j["roofline"]["mlp_kernels"].items()},
-                                command="python bench.py --precision %s" % prec)
+                            line = dict(metric=j["metric"], value=j["value"], unit=j["unit"], ms_per_step=j["ms_per_step"], steps=j["steps"],
+                                        dtype=j["dtype"], workload=j["config"]["workload"], backward=j.get("backward"),
+                                        step_tflops_executed=j["step_tflops"],
+                                        mlp_kernels={k: dict(kernel=v["kernel"], ms_per_step=v["ms_per_step"], frac_of_own_mfma_roofline=v["frac"],
+                                                             hbm_tb_s=v["hbm_tb_s"], hbm_frac=v["hbm_frac"])
+                                                     for k, v in j["roofline"]["mlp_kernels"].items()},
+                                        dominant_kernel=dict(kernel=j["roofline"]["kernel"], bound=j["roofline"]["bound"], frac=j["roofline"]["frac"]),
+                                        command="python bench.py " + " ".join(extra))
+                            if "zero_cotangent_fraction" in j:
+                                z = j["zero_cotangent_fraction"]
+                                line["zero_cotangent_fraction"] = dict(coarse=z["coarse"], fine=z["fine"], backward_sample_points=z["backward_sample_points"])
+                            if label.startswith(("f16x3", "fp32_compact")):
+                                line["vs_fp32_line"] = round(j["value"] / res["value"], 3)
+                                line["speedup_vs_pytorch_rocm_fwd_bwd"] = round(j["value"] / ref, 3) if ref else None
+                            res["labelled_lines"][label] = line
                         except Exception as e:
-                            res["labelled_lines"][prec] = dict(error=repr(e)[:200])
+                            res["labelled_lines"][label] = dict(error=repr(e)[:200])
+                    try:
+                        tmp = os.path.join(ROOT, "gpurun_out", "bench_trained_regime.json")
+                        os.makedirs(os.path.dirname(tmp), exist_ok=True)
+                        subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bench_trained.py"), tmp, "--iters", "2000", "--steps",
+                                        str(min(args.steps, 10)), "--warmup", "2"], capture_output=True, text=True, timeout=600)
+                        t = json.load(open(tmp))
+                        tr = dict(what="%s; students %s, %s samples, %d rays/step; trained %d iterations (%s) before the timed steps; full iterations "
+                                       "(selection from resident views, forward, loss, backward, Adam, re-pack)"
+                                       % (t["scene"], t["student"], t["samples"], t["rays_per_step"], t["pretrain_iters"], t["pretrain"]["arm"]),
+                                  zero_cotangent_fraction_while_training=t["pretrain"]["zero_cotangent_fraction_at_iteration"],
+                                  val_psnr_after_pretraining=t["pretrain"].get("val_psnr"), command="python scripts/bench_trained.py OUT.json")
+                        for arm, v in t["arms"].items():
+                            tr[arm] = dict(value=v["rays_per_s"], unit="rays/s", ms_per_step=v["ms_per_step"],
+                                           zero_cotangent_fraction=v["zero_cotangent_fraction_last_step"],
+                                           speedup_vs_pytorch_rocm_fwd_bwd=round(v["rays_per_s"] / ref, 3) if ref else None,
+                                           grad_vs_dense_of_max=v.get("grad_vs_dense_of_max"), kernel_ms_per_step=v["kernel_ms_per_step"])
+                        res["labelled_lines"]["trained_regime"] = tr
+                    except Exception as e:
+                        res["labelled_lines"]["trained_regime"] = dict(error=repr(e)[:200])
             else:
                 res["cpu_baseline"] = cpu_baseline_eval()
         else:

@@ -237,7 +237,16 @@ int64_t nerfhip_plan_bwd_scratch_bytes(nerfhip_plan_t plan, int64_t m);
  * (ascending sample index; two small launches, no atomics, no host synchronisation), the data-gradient kernels walk that list and
  * the weight-gradient kernels sum over it: the same sums in a fixed order with their zero terms dropped -- equal to the dense
  * gradient up to the rounding of a different split of the sample range over the workgroups.  The forward and the stash are
- * unchanged.  A launch whose regions exceed 4 GiB (m >= 2^22 sample points) runs dense regardless. */
+ * unchanged.  A launch whose regions exceed 4 GiB (m >= 2^22 sample points) runs dense regardless.
+ *   on = 0  dense (default);
+ *   on = 1  compacted: the training forward writes the whole stash as always, the weight-gradient kernels gather the listed samples'
+ *           rows out of it;
+ *   on = 2  compacted AND recomputed, inside the fused render entry points (nerfhip_render_fwd / _bwd and their _parts forms): the
+ *           training forward of this plan writes NO stash (it is the inference instantiation of the same kernel: bit-identical
+ *           outputs), and the backward, once it has the list, re-runs the forward for the listed samples only, which leaves their
+ *           activation rows and ReLU masks in list order -- the weight-gradient kernels then read contiguous blocks.  Pays where most
+ *           rows are dropped and the stash-writing forward is much slower than the plain one (the fp16-piece plans: DESIGN.md).
+ *           nerfhip_mlp_fwd / nerfhip_mlp_bwd, whose caller owns the stash between the two calls, treat 2 as 1. */
 int nerfhip_plan_set_bwd_compaction(nerfhip_plan_t plan, int on);
 int nerfhip_plan_bwd_compaction(nerfhip_plan_t plan);
 /* Byte offset, inside a backward scratch for m sample points, of int32[2] = {samples the last compacted backward kept, samples of

@@ -100,6 +100,7 @@ NhCompact nh_compact_view(int* area, int64_t M) {
     c.stats = area;
     c.counts = area + NH_CSTAT_WORDS;
     c.idx = c.counts + ((nh_ceil_div(M, CB_SAMPLES) + 15) & ~(int64_t)15);
+    c.stash_in_list_order = false;
     return c;
 }
 

@@ -144,7 +144,9 @@ extern "C" int nerfhip_render_fwd_parts(nerfhip_plan_t pc, nerfhip_plan_t pf, co
         if (rc) return rc;
         in.z = z_c;
         in.S = nc;
-        rc = nh_mlp_forward(pc, packed_c, in, n * nc, raw_c, training ? (float*)(ws + w.stash_c) : nullptr, stream);
+        // (a plan whose backward recomputes the stash for the samples it keeps -- nerfhip_plan_set_bwd_compaction(plan, 2) -- runs the
+        // stash-free forward here)
+        rc = nh_mlp_forward(pc, packed_c, in, n * nc, raw_c, (training && !nh_mlp_recomputes(pc, n * nc)) ? (float*)(ws + w.stash_c) : nullptr, stream);
         if (rc) return rc;
         rc = nerfhip_volume_render_fwd(raw_c, z_c, rays + 3, stride, n, nc, cfg->noise_std, r->noise_coarse, seed, 1u,
                                        ray_offset, cfg->white_background, out->rgb_coarse, out->disp_coarse,
@@ -160,7 +162,7 @@ extern "C" int nerfhip_render_fwd_parts(nerfhip_plan_t pc, nerfhip_plan_t pf, co
         if (rc) return rc;
         in.z = z_f;
         in.S = sf;
-        rc = nh_mlp_forward(pf, packed_f, in, n * sf, raw_f, training ? (float*)(ws + w.stash_f) : nullptr, stream);
+        rc = nh_mlp_forward(pf, packed_f, in, n * sf, raw_f, (training && !nh_mlp_recomputes(pf, n * sf)) ? (float*)(ws + w.stash_f) : nullptr, stream);
         if (rc) return rc;
         rc = nerfhip_volume_render_fwd(raw_f, z_f, rays + 3, stride, n, sf, cfg->noise_std, r->noise_fine, seed, 3u,
                                        ray_offset, cfg->white_background, out->rgb_fine, out->disp_fine, out->acc_fine,
@@ -237,8 +239,16 @@ extern "C" int nerfhip_render_bwd_rays(nerfhip_plan_t pc, nerfhip_plan_t pf, con
                                   cfg->noise_std, r->noise_fine, seed, 3u, ray_offset, cfg->white_background, g->g_rgb_fine,
                                   g->g_depth_fine, g->g_acc_fine, nullptr, g_raw, g_rays ? (float*)(ws + w.gnorm_f) : nullptr, stream);
         if (rc) return rc;
-        rc = nh_mlp_backward(pf, packed_f, g_raw, n * sf, (const float*)(ws + w.stash_f), (float*)(ws + w.scratch_f),
-                             w.scratch_f_bytes, g_params_f, stream);
+        if (nh_mlp_recomputes(pf, n * sf)) {
+            NhMlpInput in;
+            memset(&in, 0, sizeof(in));
+            in.mode = 1, in.rays = rays, in.ray_stride = stride, in.z = (const float*)(ws + w.z_f), in.S = sf;
+            rc = nh_mlp_backward_recompute(pf, packed_f, in, g_raw, n * sf, (float*)(ws + w.stash_f), (float*)(ws + w.scratch_f),
+                                           w.scratch_f_bytes, g_params_f, stream);
+        } else {
+            rc = nh_mlp_backward(pf, packed_f, g_raw, n * sf, (const float*)(ws + w.stash_f), (float*)(ws + w.scratch_f),
+                                 w.scratch_f_bytes, g_params_f, stream);
+        }
         if (rc) return rc;
         if (g_rays) {
             rc = ray_grad_of_pass(pf, params_f, rays, stride, n, (const float*)(ws + w.z_f), sf, (const float*)(ws + w.scratch_f),
@@ -256,8 +266,16 @@ extern "C" int nerfhip_render_bwd_rays(nerfhip_plan_t pc, nerfhip_plan_t pf, con
                                   g->g_depth_coarse, g->g_acc_coarse, nullptr, g_raw, g_rays ? (float*)(ws + w.gnorm_c) : nullptr,
                                   stream);
         if (rc) return rc;
-        rc = nh_mlp_backward(pc, packed_c, g_raw, n * nc, (const float*)(ws + w.stash_c), (float*)(ws + w.scratch_c),
-                             w.scratch_c_bytes, g_params_c, stream);
+        if (nh_mlp_recomputes(pc, n * nc)) {
+            NhMlpInput in;
+            memset(&in, 0, sizeof(in));
+            in.mode = 1, in.rays = rays, in.ray_stride = stride, in.z = (const float*)(ws + w.z_c), in.S = nc;
+            rc = nh_mlp_backward_recompute(pc, packed_c, in, g_raw, n * nc, (float*)(ws + w.stash_c), (float*)(ws + w.scratch_c),
+                                           w.scratch_c_bytes, g_params_c, stream);
+        } else {
+            rc = nh_mlp_backward(pc, packed_c, g_raw, n * nc, (const float*)(ws + w.stash_c), (float*)(ws + w.scratch_c),
+                                 w.scratch_c_bytes, g_params_c, stream);
+        }
         if (rc) return rc;
         if (g_rays) {
             rc = ray_grad_of_pass(pc, params_c, rays, stride, n, (const float*)(ws + w.z_c), nc, (const float*)(ws + w.scratch_c),

@@ -81,11 +81,21 @@ int64_t nh_mlp_bwd_scratch_bytes(nerfhip_plan* p, int64_t M) {
 }
 // A backward over M sample points runs compacted when the plan asks for it and a gathered row's byte offset inside a region (at most
 // 256 rows of 4 bytes per sample) fits the 32-bit offset of a buffer instruction; otherwise it runs dense.
-static bool compacts(const nerfhip_plan* p, int64_t M) { return p->bwd_compact && nh_ceil_div(M, 128) * 128 * 1024 < ((int64_t)1 << 32); }
+static bool compacts(const nerfhip_plan* p, int64_t M) { return p->bwd_compact != 0 && nh_ceil_div(M, 128) * 128 * 1024 < ((int64_t)1 << 32); }
+bool nh_mlp_recomputes(const nerfhip_plan* p, int64_t M) { return p->bwd_compact == 2 && compacts(p, M) && nh_prec_level(p->precision) != 1; }
+
+static int mlp_forward_any(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
+                           nerfhip_stream_t stream, const NhCompact* list);
 
 int nh_mlp_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
                    nerfhip_stream_t stream) {
-    NH_REQUIRE(p && packed && out && M >= 0, "mlp_fwd: bad arguments");
+    NH_REQUIRE(out, "mlp_fwd: bad arguments");
+    return mlp_forward_any(p, packed, in, M, out, stash, stream, nullptr);
+}
+
+static int mlp_forward_any(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
+                           nerfhip_stream_t stream, const NhCompact* list) {
+    NH_REQUIRE(p && packed && M >= 0, "mlp_fwd: bad arguments");
     if (M == 0) return NERFHIP_OK;
     if (in.mode == 1) {
         NH_REQUIRE(p->freqs_set, "mlp_fwd: nerfhip_plan_set_freqs has not been called");
@@ -96,13 +106,14 @@ int nh_mlp_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, i
     if (p->precision != NERFHIP_PRECISION_FP32) {
         NH_REQUIRE(!stash || nh_prec_level(p->precision) != 1,
                    "mlp_fwd: an f16x3 plan is inference-only (no activation stash, no backward; the _FWD / _FWD_DGRAD / _TRAIN plans train)");
-        return nh_mlp_forward_f16w(p, packed, in, M, out, stash, stream);
+        return nh_mlp_forward_f16w(p, packed, in, M, out, stash, stream, list);
     }
-    return nh_mlp16_forward(p, packed, in, M, out, stash, stream);
+    return nh_mlp16_forward(p, packed, in, M, out, stash, stream, list);
 }
 
-int nh_mlp_backward(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash,
-                    float* scratch, int64_t scratch_bytes, float* g_params, nerfhip_stream_t stream) {
+// `recompute`: the forward of this launch wrote no stash (nh_mlp_recomputes); `in` names its input again
+static int mlp_backward_any(nerfhip_plan* p, const float* packed, const NhMlpInput* recompute, const float* g_out, int64_t M, float* stash,
+                            float* scratch, int64_t scratch_bytes, float* g_params, nerfhip_stream_t stream) {
     NH_REQUIRE(p && packed && g_out && stash && scratch && g_params && M > 0, "mlp_bwd: bad arguments");
     NH_REQUIRE(nh_prec_level(p->precision) != 1, "mlp_bwd: an f16x3 plan is inference-only");
     NH_REQUIRE(scratch_bytes >= nh_mlp_bwd_scratch_bytes(p, M), "mlp_bwd: scratch too small (%lld < %lld)",
@@ -110,6 +121,23 @@ int nh_mlp_backward(nerfhip_plan* p, const float* packed, const float* g_out, in
     const int64_t nt = nh_ceil_div(M, 128) * 4;
     const bool bdg = nh_prec_level(p->precision) >= 3;
     int rc = NERFHIP_OK;
+    // compacted backward: list the samples whose d(raw output) row is not all zero; every kernel below then walks that list
+    NhCompact cview;
+    const NhCompact* cx = nullptr;
+    if (compacts(p, M)) {
+        cview = nh_compact_view((int*)(scratch + compact_word_offset(p, nt)), nt * 32);
+        rc = nh_compact_build(g_out, M, cview, stream);
+        if (rc) return rc;
+        cx = &cview;
+    }
+    if (recompute) {
+        // ... and the forward is run again for the listed samples only: their activation rows and ReLU masks, in list order (the
+        // fp16-piece forward also records the stash's region maxima again, behind the stash as every training forward does)
+        NH_REQUIRE(cx, "mlp_bwd: a recomputing backward needs the compacted list");
+        rc = mlp_forward_any(p, packed, *recompute, M, nullptr, stash, stream, cx);
+        if (rc) return rc;
+        cview.stash_in_list_order = true;
+    }
     // fp16 plans whose large weight-gradient blocks run on the fp16 MFMAs: the producers record per-region maxima (behind the
     // stash: the forward's; behind this scratch: the data-gradient launch's), from which k_wgrad_f16x3 takes its scales
     unsigned* amax = nullptr;
@@ -119,15 +147,6 @@ int nh_mlp_backward(nerfhip_plan* p, const float* packed, const float* g_out, in
         bmax = (const unsigned*)(stash + nh_stash_floats(p, nt));
         rc = nh_zero_words(amax, NH_RMAX_WORDS, stream);
         if (rc) return rc;
-    }
-    // compacted backward: list the samples whose d(raw output) row is not all zero; every kernel below then walks that list
-    NhCompact cview;
-    const NhCompact* cx = nullptr;
-    if (compacts(p, M)) {
-        cview = nh_compact_view((int*)(scratch + compact_word_offset(p, nt)), nt * 32);
-        rc = nh_compact_build(g_out, M, cview, stream);
-        if (rc) return rc;
-        cx = &cview;
     }
     if (bdg)
         rc = nh_mlp_dgrad_f16w(p, packed, g_out, M, stash, scratch, amax, cx, stream);
@@ -142,12 +161,23 @@ int nh_mlp_backward(nerfhip_plan* p, const float* packed, const float* g_out, in
     return nh_wgrad_f16(p, nt, stash, scratch, partial_b, g_params, amax, bmax, cx, stream);
 }
 
+int nh_mlp_backward(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash,
+                    float* scratch, int64_t scratch_bytes, float* g_params, nerfhip_stream_t stream) {
+    return mlp_backward_any(p, packed, nullptr, g_out, M, (float*)stash, scratch, scratch_bytes, g_params, stream);
+}
+
+int nh_mlp_backward_recompute(nerfhip_plan* p, const float* packed, const NhMlpInput& in, const float* g_out, int64_t M, float* stash,
+                              float* scratch, int64_t scratch_bytes, float* g_params, nerfhip_stream_t stream) {
+    return mlp_backward_any(p, packed, &in, g_out, M, stash, scratch, scratch_bytes, g_params, stream);
+}
+
 extern "C" int nerfhip_plan_set_bwd_compaction(nerfhip_plan_t plan, int on) {
     NH_REQUIRE(plan, "plan_set_bwd_compaction: plan is NULL");
-    plan->bwd_compact = on != 0;
+    NH_REQUIRE(on >= 0 && on <= 2, "plan_set_bwd_compaction: 0 (dense), 1 (compacted) or 2 (compacted, the render path recomputes the stash)");
+    plan->bwd_compact = on;
     return NERFHIP_OK;
 }
-extern "C" int nerfhip_plan_bwd_compaction(nerfhip_plan_t plan) { return plan && plan->bwd_compact ? 1 : 0; }
+extern "C" int nerfhip_plan_bwd_compaction(nerfhip_plan_t plan) { return plan ? plan->bwd_compact : 0; }
 extern "C" int64_t nerfhip_plan_bwd_stats_offset(nerfhip_plan_t plan, int64_t m) {
     if (!plan || m < 0) return -1;
     return compact_word_offset(plan, nh_ceil_div(m, 128) * 4) * (int64_t)sizeof(float);

@@ -415,6 +415,11 @@ struct Fwd16Args {
     float* stash;
     NhStashLayout sl;
     unsigned long long* clk;  // shader-clock probe counters, or NULL (nh_prof_clock_slot)
+    // a forward over a compaction list (the recomputing backward, mlp.hip nh_mlp_backward_recompute), or NULLs: slot c of the launch
+    // computes sample cidx[c] and writes that sample's stash rows and ReLU masks AT SLOT c; cstats[NH_CSTAT_ACTIVE] slots carry a
+    // sample; `out` may be NULL
+    const int* cidx;
+    const int* cstats;
 };
 
 // TRAIN: the launch writes the activation stash (rows, encoding slots, ReLU masks) for the backward kernels
@@ -423,6 +428,9 @@ template <int W, bool VIEW, bool TRAIN, bool EXT = false>
 NH_KERNEL void NH_LB(64 * Shape<W>::NW, Shape<W>::WAVES_PER_SIMD) k_mlp_fwd16(Fwd16Args a) {
     constexpr int KH = W / 4, TW = W / 16, KX = EXT ? NH16_KRX_EXT : NH16_KRX, KD = EXT ? NH16_KRD_EXT : NH16_KRD;
     constexpr int NW = Shape<W>::NW, MW = Shape<W>::MW;
+    // (a launch over a list: a workgroup whose slots are all behind it has nothing to do)
+    const int n_slots = (TRAIN && a.cidx) ? nh_uload_i32(a.cstats, NH_CSTAT_ACTIVE) : 0;
+    if (TRAIN && a.cidx && (int64_t)blockIdx.x * (NW * 16) >= (int64_t)n_slots) return;
     NH_DYN_LDS(lds_raw);
     nh_clk_begin(a.clk, (unsigned long long*)(lds_raw + Lds<W>::BYTES));
     Ctx cx;
@@ -444,8 +452,12 @@ NH_KERNEL void NH_LB(64 * Shape<W>::NW, Shape<W>::WAVES_PER_SIMD) k_mlp_fwd16(Fw
     const int64_t tile = (int64_t)blockIdx.x * (NW / 2) + (wave >> 1);  // 32-sample stash tile
     const int js = 16 * (wave & 1) + j;                         // this lane's sample inside it
     const int64_t m = tile * 32 + js;
-    const bool valid = m < a.M;
-    const int64_t mc = valid ? m : a.M - 1;
+    bool valid = m < a.M;
+    int64_t mc = valid ? m : a.M - 1;  // the sample this lane computes
+    if (TRAIN && a.cidx) {              // (slot m of a list: its sample; padding slots compute sample cidx[m] = 0 and are never read)
+        valid = m < (int64_t)n_slots;
+        mc = (int64_t)a.cidx[m];
+    }
     const int m_i = (int)m;  // (the host checks M < 2^31)
     const NhPackedOffsets& po = a.off;
 
@@ -551,7 +563,7 @@ NH_KERNEL void NH_LB(64 * Shape<W>::NW, Shape<W>::WAVES_PER_SIMD) k_mlp_fwd16(Fw
         finish<TW / 2, true, TRAIN, false>(acc, dh, bits.w, bits.w);
         gemm16<W, KH / 2, 0, 1>(cx, dh, nullptr, po.f_rgb, 0, 0, acc,
                                 RowsPost<TW / 2, MW>{sref(a.sl.DIRH, W / 2, 4 * g), dh, mref(a.L), bits, hi});
-        if (valid && g == 0) {
+        if (valid && g == 0 && a.out) {
             float4 r4;
             r4.x = acc[0][0];
             r4.y = acc[0][1];
@@ -561,7 +573,7 @@ NH_KERNEL void NH_LB(64 * Shape<W>::NW, Shape<W>::WAVES_PER_SIMD) k_mlp_fwd16(Fw
         }
     } else {
         gemm16<W, KH, 0, 1>(cx, act, nullptr, po.f_head, 0, 0, acc, post_last_hidden);
-        if (valid && g == 0) {
+        if (valid && g == 0 && a.out) {
             float4 r4;
             r4.x = acc[0][0];
             r4.y = acc[0][1];
@@ -595,6 +607,7 @@ struct Dgrad16Args {
     // gathered by it, the d(pre-activation) images are written in slot order; cstats[NH_CSTAT_ACTIVE] slots carry a sample
     const int* cidx;
     const int* cstats;
+    int cstash_listed;  // the stash is in list order too (a recomputed one): the ReLU masks of slot c are at slot c
 };
 
 template <int W, bool VIEW>
@@ -655,8 +668,9 @@ NH_KERNEL void NH_LB(64 * Shape<W>::NW, Shape<W>::WAVES_PER_SIMD) k_mlp_dgrad16(
     const bool g0 = g == 0;
     const PoutPost store_pout{gref(a.gl.POUT, 32, 8 * g), g0 ? go0 : 0.f, g0 ? go1 : 0.f, g0 ? go2 : 0.f, g0 ? go3 : 0.f};
     // the forward wrote the mask words of wave tile (sample >> 4), lane 16 g + (sample & 15): this very lane's in the dense backward
-    const int64_t wave_tile = a.cidx ? (m >> 4) : ((int64_t)blockIdx.x * NW + wave);
-    const int mask_lane = a.cidx ? 16 * g + (int)(m & 15) : lane;
+    const bool mask_gather = a.cidx && !a.cstash_listed;
+    const int64_t wave_tile = mask_gather ? (m >> 4) : ((int64_t)blockIdx.x * NW + wave);
+    const int mask_lane = mask_gather ? 16 * g + (int)(m & 15) : lane;
     const char* const mask_base = (const char*)((const unsigned*)(a.stash + (size_t)32 * (size_t)a.nt * (size_t)a.sl.total_rows) +
                                                 (size_t)wave_tile * a.sl.n_masks * (64 * MW));
     // ReLU masks: `mb` gates the d(pre-activation) currently held in registers -- applied by the NEXT gemm, group by
@@ -775,7 +789,8 @@ extern "C" int nerfhip_debug_phases16(unsigned long long* host16, int reset) {
 // mlp16_ext.hip (NH16_EXT_TU) likewise holds the forward kernels with the extended encoding registers, every width.
 namespace {
 
-void fill_fwd_args(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash, Fwd16Args& a) {
+void fill_fwd_args(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash, Fwd16Args& a,
+                   const NhCompact* list = nullptr) {
     memset(&a, 0, sizeof(a));
     a.packed = packed;
     a.packed_bytes = (unsigned)(p->packed_floats * 4);
@@ -806,6 +821,8 @@ void fill_fwd_args(nerfhip_plan* p, const float* packed, const NhMlpInput& in, i
     a.stash = stash;
     a.sl = p->stash;
     a.clk = nh_prof_clock_slot(NH_CLK_FWD);
+    a.cidx = (list && stash) ? list->idx : nullptr;
+    a.cstats = (list && stash) ? list->stats : nullptr;
 }
 
 void fill_dgrad_args(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
@@ -825,6 +842,7 @@ void fill_dgrad_args(nerfhip_plan* p, const float* packed, const float* g_out, i
     d.clk = nh_prof_clock_slot(NH_CLK_DGRAD);
     d.cidx = cx ? cx->idx : nullptr;
     d.cstats = cx ? cx->stats : nullptr;
+    d.cstash_listed = (cx && cx->stash_in_list_order) ? 1 : 0;
 }
 
 // whole 128-sample groups are launched: every stash tile is written
@@ -852,18 +870,18 @@ void fill_dgrad_args(nerfhip_plan* p, const float* packed, const float* g_out, i
 }  // namespace
 
 int nh_mlp16_forward_w512(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
-                          nerfhip_stream_t stream);
+                          nerfhip_stream_t stream, const NhCompact* list);
 int nh_mlp16_dgrad_w512(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
                         const NhCompact* cx, nerfhip_stream_t stream);
 int nh_mlp16_forward_ext(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
-                         nerfhip_stream_t stream);
+                         nerfhip_stream_t stream, const NhCompact* list);
 
 #if defined(NH16_EXT_TU)
 // every width with the extended encoding registers (mlp16_ext.hip)
 int nh_mlp16_forward_ext(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
-                         nerfhip_stream_t stream) {
+                         nerfhip_stream_t stream, const NhCompact* list) {
     Fwd16Args a;
-    fill_fwd_args(p, packed, in, M, out, stash, a);
+    fill_fwd_args(p, packed, in, M, out, stash, a, list);
     const int64_t groups = nh_ceil_div(M, 128);
     int rc = NERFHIP_OK;
     if (p->W == 512 && p->view) NH_FWD16_E(512, true, true)
@@ -878,9 +896,9 @@ int nh_mlp16_forward_ext(nerfhip_plan* p, const float* packed, const NhMlpInput&
 }
 #elif defined(NH16_W512_TU)
 int nh_mlp16_forward_w512(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
-                          nerfhip_stream_t stream) {
+                          nerfhip_stream_t stream, const NhCompact* list) {
     Fwd16Args a;
-    fill_fwd_args(p, packed, in, M, out, stash, a);
+    fill_fwd_args(p, packed, in, M, out, stash, a, list);
     const int64_t groups = nh_ceil_div(M, 128);
     int rc = NERFHIP_OK;
     if (p->view) NH_FWD16(512, true)
@@ -900,12 +918,13 @@ int nh_mlp16_dgrad_w512(nerfhip_plan* p, const float* packed, const float* g_out
 }
 #else
 int nh_mlp16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
-                     nerfhip_stream_t stream) {
+                     nerfhip_stream_t stream, const NhCompact* list) {
     NH_REQUIRE(M < ((int64_t)1 << 31), "mlp_fwd: at most 2^31 - 1 sample points per call (got %lld)", (long long)M);
-    if (p->krx != NH16_KRX) return nh_mlp16_forward_ext(p, packed, in, M, out, stash, stream);
-    if (p->W == 512) return nh_mlp16_forward_w512(p, packed, in, M, out, stash, stream);
+    NH_REQUIRE(out || (list && stash), "mlp_fwd: out is NULL");
+    if (p->krx != NH16_KRX) return nh_mlp16_forward_ext(p, packed, in, M, out, stash, stream, list);
+    if (p->W == 512) return nh_mlp16_forward_w512(p, packed, in, M, out, stash, stream, list);
     Fwd16Args a;
-    fill_fwd_args(p, packed, in, M, out, stash, a);
+    fill_fwd_args(p, packed, in, M, out, stash, a, list);
     const int64_t groups = nh_ceil_div(M, 128);
     int rc = NERFHIP_OK;
     if (p->W == 256 && p->view) NH_FWD16(256, true)

@@ -34,12 +34,15 @@ constexpr int NO_CAP = 100;
 // value is below 2^-46: its values were then split 2^-46 too low and the weight gradient of cotangents below ~1e-20 lost bits, below
 // ~1e-25 everything.  Found by tests/parity_cases.py case_f16x3_range_extremes on the emulator.)
 constexpr int ZERO_EXP = 60;
-// Every per-sample exponent stays inside [-S_LIM, S_LIM]: the scales applied with it -- 2^s, 2^-s, 2^(-8 - s) -- are then exactly the
+// Every per-sample exponent stays inside [S_MIN, S_LIM]: the scales applied with it -- 2^s, 2^-s, 2^(-8 - s) -- are then exactly the
 // powers of two nh_pow2i can represent (it clamps at 2^-126 / 2^127), so what a sample's exponent SAYS and what its values were multiplied
 // by never part (nh_shift_to alone reaches 139 for magnitudes near 2^-126).  A sample whose largest value sits below
 // 2^(13 - S_LIM) = 2^-97 keeps fewer piece bits instead -- it is zero to fp32's neighbours anyway.
-constexpr int S_LIM = 110;
-NH_DEVICE int clamp_exp(int s) { return s < -S_LIM ? -S_LIM : (s > S_LIM ? S_LIM : s); }
+// The lower end never binds: a float's magnitude is below 2^128, so its exponent to [2^13, 2^14) is at least 13 - 127 = S_MIN, and at
+// S_MIN all three scales are still normal floats (2^-114, 2^114, 2^106).  (Round 5 clamped at -S_LIM: a sample whose largest value
+// reached 2^124 was then scaled to 2^14 ... 2^17 -- above fp16's 65504, Inf pieces, NaN outputs)
+constexpr int S_LIM = 110, S_MIN = TARGET_LOG2 - 127;
+NH_DEVICE int clamp_exp(int s) { return s < S_MIN ? S_MIN : (s > S_LIM ? S_LIM : s); }
 NH_DEVICE int not_zero_exp(int s) { return s == ZERO_EXP ? ZERO_EXP - 1 : s; }
 NH_DEVICE int exp_for(unsigned mb, int base_e) {
     return ((mb >> 23) & 255u) == 0u ? ZERO_EXP : not_zero_exp(clamp_exp(base_e + nh_shift_to(mb, TARGET_LOG2)));
@@ -496,6 +499,10 @@ struct FwdWArgs {
     unsigned* rmax;    // level-4 plans: per-region maxima of what the stash holds (H[k] -> k, FEAT -> L), else NULL
     NhStashLayout sl;
     int64_t nt;        // 32-sample tiles of the launch (4 per 128-sample group)
+    // a forward over a compaction list (the recomputing backward), or NULLs: slot c computes sample cidx[c] and writes that sample's
+    // stash rows and ReLU masks AT SLOT c; cstats[NH_CSTAT_ACTIVE] slots carry a sample; `out` may be NULL
+    const int* cidx;
+    const int* cstats;
 };
 
 // TRAIN: the launch also writes the activation stash -- encoding slots, every layer's fp32 output rows (plain values), ReLU masks -- in
@@ -503,6 +510,11 @@ struct FwdWArgs {
 template <int W, bool VIEW, bool TRAIN>
 NH_KERNEL void NH_LB(512, 2) k_mlp_fwd_f16x3w(FwdWArgs a) {
     constexpr int TW = WShape<W>::TW, KB = WShape<W>::KB, BUF = WShape<W>::BUF, CB = WShape<W>::CB;
+    // (a launch over a list: its groups are the list's; a workgroup without one has nothing to stream)
+    const bool listed = TRAIN && a.cidx;
+    const int n_slots = listed ? nh_uload_i32(a.cstats, NH_CSTAT_ACTIVE) : 0;
+    const int64_t groups = listed ? (int64_t)((n_slots + 127) >> 7) : a.groups;
+    if ((int64_t)blockIdx.x >= groups) return;
     NH_DYN_LDS(lds_raw);
     WCtx cx;
     cx.lds = lds_raw;
@@ -524,11 +536,15 @@ NH_KERNEL void NH_LB(512, 2) k_mlp_fwd_f16x3w(FwdWArgs a) {
 
     // persistent workgroups (one per CU): each walks over its 128-sample groups; the last layer of a group already streams layer1 of
     // the next
-    for (int64_t grp = blockIdx.x; grp < a.groups; grp += gridDim.x) {
-        const bool again = grp + gridDim.x < a.groups;
+    for (int64_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const bool again = grp + gridDim.x < groups;
         const int64_t m = grp * 128 + cx.wave * 16 + j;
-        const bool valid = m < a.M;
-        const int64_t mc = valid ? m : a.M - 1;
+        bool valid = m < a.M;
+        int64_t mc = valid ? m : a.M - 1;  // the sample this lane computes
+        if (listed) {                      // (slot m of a list: its sample; padding slots compute sample cidx[m] = 0 and are never read)
+            valid = m < (int64_t)n_slots;
+            mc = (int64_t)a.cidx[m];
+        }
         // training: this sample's row of a stash region ([32-sample tile][sample][rows]; whole groups are written, clamped samples
         // included), and this lane's mask words ([16-sample wave tile][mask][64 lanes][2 words])
         const int64_t tile32 = grp * 4 + (cx.wave >> 1);
@@ -617,7 +633,7 @@ NH_KERNEL void NH_LB(512, 2) k_mlp_fwd_f16x3w(FwdWArgs a) {
             gemm_w<W, 1, KB / 2, 0, 0, 0, true, false, TRAIN>(cx, hh, hl, nullptr, nullptr, po.f_rgb * 4, po.f_layer1 * 4, again ? first(XB, TW) : 0, acc,
                                                        nullptr, nullptr, TRAIN ? srow(a.sl.DIRH, W / 2) : nullptr, TRAIN ? smask(a.L) : nullptr,
                                                        &in_bits, TRAIN ? nh_pow2i(-s) : 1.0f, s, s);
-            if (valid && g == 0) {
+            if (valid && g == 0 && a.out) {
                 float4 r4;
                 r4.x = raw_of(acc[0][0], s);
                 r4.y = raw_of(acc[0][1], s);
@@ -631,7 +647,7 @@ NH_KERNEL void NH_LB(512, 2) k_mlp_fwd_f16x3w(FwdWArgs a) {
                                                    nullptr, TRAIN ? srow(a.sl.H[a.L - 1], W) : nullptr,
                                                    (TRAIN && a.L > 1) ? smask(a.L - 2) : nullptr, &in_bits, TRAIN ? nh_pow2i(-s) : 1.0f, s, s, NO_CAP,
                                                    nullptr, nullptr, TRAIN ? a.L - 1 : -1);  // fc_out (models.py:256)
-            if (valid && g == 0) {
+            if (valid && g == 0 && a.out) {
                 float4 r4;
                 r4.x = raw_of(acc[0][0], s);
                 r4.y = raw_of(acc[0][1], s);
@@ -665,6 +681,7 @@ struct DgradWArgs {
     // gathered by it, the d(pre-activation) images are written in slot order; cstats[NH_CSTAT_ACTIVE] slots carry a sample
     const int* cidx;
     const int* cstats;
+    int cstash_listed;  // the stash is in list order too (a recomputed one): the ReLU masks of slot c are at slot c
 };
 
 template <int W, bool VIEW>
@@ -713,8 +730,9 @@ NH_KERNEL void NH_LB(512, 2) k_mlp_dgrad_f16x3w(DgradWArgs a) {
         };
         // ReLU mask `idx` of this lane's units: the forward wrote the words of wave tile (sample >> 4), lane 16 g + (sample & 15) --
         // this very lane's in the dense backward
-        const int64_t wave_tile = a.cidx ? (m >> 4) : grp * 8 + cx.wave;
-        const int mask_lane = a.cidx ? 16 * g + (int)(m & 15) : cx.lane;
+        const bool mask_gather = a.cidx && !a.cstash_listed;
+        const int64_t wave_tile = mask_gather ? (m >> 4) : grp * 8 + cx.wave;
+        const int mask_lane = mask_gather ? 16 * g + (int)(m & 15) : cx.lane;
         auto get_mask = [&](int idx) -> MaskW {
             const unsigned* p = (const unsigned*)(a.stash + (size_t)32 * (size_t)a.nt * (size_t)a.sl.total_rows) +
                                 ((size_t)wave_tile * (size_t)a.sl.n_masks + (size_t)idx) * 128 + (size_t)mask_lane * 2;
@@ -839,8 +857,9 @@ int w_lds_limit(K kern, int bytes) {
 }  // namespace
 
 int nh_mlp_forward_f16w(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
-                        nerfhip_stream_t stream) {
+                        nerfhip_stream_t stream, const NhCompact* list) {
     NH_REQUIRE(M < ((int64_t)1 << 31), "mlp_fwd: at most 2^31 - 1 sample points per call (got %lld)", (long long)M);
+    NH_REQUIRE(out || (list && stash), "mlp_fwd: out is NULL");
     NH_REQUIRE(nh_prec_f16(p->precision), "mlp_fwd_f16w: not an fp16-piece plan");
     FwdWArgs a;
     memset(&a, 0, sizeof(a));
@@ -876,6 +895,8 @@ int nh_mlp_forward_f16w(nerfhip_plan* p, const float* packed, const NhMlpInput& 
     a.Lx = p->cfg.num_encoding_fn_xyz;
     a.Ld = p->view ? p->cfg.num_encoding_fn_dir : 0;
     a.out = out;
+    a.cidx = (list && stash) ? list->idx : nullptr;
+    a.cstats = (list && stash) ? list->stats : nullptr;
     const int64_t groups = nh_ceil_div(M, 128);
     a.groups = groups;
     // as many workgroups as are resident at once: one 8-wave workgroup per CU (256-wide nets: its LDS; 128-wide: its 173-202 VGPRs)
@@ -931,6 +952,7 @@ int nh_mlp_dgrad_f16w(nerfhip_plan* p, const float* packed, const float* g_out, 
     d.rmax = rmax;
     d.cidx = cpt ? cpt->idx : nullptr;
     d.cstats = cpt ? cpt->stats : nullptr;
+    d.cstash_listed = (cpt && cpt->stash_in_list_order) ? 1 : 0;
     const int64_t resident = (int64_t)w_compute_units();
     const int64_t grid = d.groups < resident ? d.groups : resident;
     int rc = NERFHIP_OK;

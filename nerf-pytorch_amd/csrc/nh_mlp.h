@@ -21,6 +21,9 @@ struct NhCompact {
     int* stats;
     int* counts;  // per 2048-sample block (k_compact_count)
     int* idx;
+    // the stash the backward kernels read is ITSELF in list order (written by a forward over the list: nh_mlp_backward_recompute):
+    // ReLU masks and activation rows of slot c sit at slot c -- nothing is gathered but d(raw output)
+    bool stash_in_list_order;
 };
 int64_t nh_compact_ints(int64_t M);                  // 32-bit words of the area for M sample points
 NhCompact nh_compact_view(int* area, int64_t M);
@@ -30,11 +33,19 @@ int nh_mlp_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, i
                    nerfhip_stream_t stream);
 int nh_mlp_backward(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash,
                     float* scratch, int64_t scratch_bytes, float* g_params, nerfhip_stream_t stream);
+// plans with bwd_compact == 2 inside the fused render: the forward over `in` wrote no stash; lists the samples with a non-zero
+// d(raw output) row, re-runs the forward for them (writing `stash` in list order) and differentiates those
+int nh_mlp_backward_recompute(nerfhip_plan* p, const float* packed, const NhMlpInput& in, const float* g_out, int64_t M, float* stash,
+                              float* scratch, int64_t scratch_bytes, float* g_params, nerfhip_stream_t stream);
 int64_t nh_mlp_bwd_scratch_bytes(nerfhip_plan* p, int64_t M);
+// a backward over M sample points of this plan re-runs its forward (bwd_compact == 2 and the launch compacts at all)
+bool nh_mlp_recomputes(const nerfhip_plan* p, int64_t M);
 
 // mlp16.hip: the forward / data-gradient chain on v_mfma_f32_16x16x4_f32, two waves per SIMD
+// (list: a forward over the samples of a compaction list only -- slot c computes sample idx[c] and writes ITS stash rows / masks at
+// slot c; `out` may then be NULL; else NULL)
 int nh_mlp16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
-                     nerfhip_stream_t stream);
+                     nerfhip_stream_t stream, const NhCompact* list = nullptr);
 // (cx: the compacted backward's sample list, or NULL -- here and in every backward kernel below)
 int nh_mlp16_dgrad(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
                    const NhCompact* cx, nerfhip_stream_t stream);
@@ -42,7 +53,7 @@ int nh_mlp16_dgrad(nerfhip_plan* p, const float* packed, const float* g_out, int
 // mlp_f16w.hip: forward (with / without stash) and data-gradient chain of the fp16-piece plans: two waves per SIMD, 16-sample waves on
 // v_mfma_f32_16x16x32_f16; rmax (level-4 plans): NH_RMAX_WORDS zeroed device words for the region maxima, or NULL
 int nh_mlp_forward_f16w(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
-                        nerfhip_stream_t stream);
+                        nerfhip_stream_t stream, const NhCompact* list = nullptr);
 int nh_mlp_dgrad_f16w(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
                       unsigned* rmax, const NhCompact* cx, nerfhip_stream_t stream);
 // mlp.hip: n words of device memory to zero, on the stream

@@ -186,7 +186,10 @@ struct nerfhip_plan {
     std::vector<NhJob> jobs;
     std::vector<NhJobB> bjobs;        // (F16X3_TRAIN: the large blocks, taken out of `jobs`)
     int wgrad_waves;         // waves per workgroup of the weight-gradient kernel: 8 (256- and 512-wide nets) or 4 (narrower)
-    bool bwd_compact = false;  // nerfhip_plan_set_bwd_compaction: the backward drops the samples whose d(raw output) row is zero
+    // nerfhip_plan_set_bwd_compaction: 0 dense; 1 the backward drops the samples whose d(raw output) row is zero (list + gathered stash
+    // rows); 2 the same, and inside the fused render the training forward writes NO stash -- the backward re-runs the forward for the
+    // listed samples only and leaves a compacted stash (no gather in the weight-gradient kernels)
+    int bwd_compact = 0;
     bool is_skip(int i) const { return i % skip == 0 && i > 0; }
 };
 // floats of a training stash of `tiles` 32-sample tiles: the row regions, then the ReLU masks (the region maxima follow)

@@ -260,7 +260,7 @@ struct WStageDma {
             // jobs: its timeline shows the order of events and the wait / barrier shares, not the product kernel's absolute times.)
 #if defined(NH_WGRAD_TIMELINE) && !defined(NERFHIP_EMU)
             constexpr bool reuniform = true;
-#elif !defined(NERFHIP_EMU) && !defined(NH_CX_NO_REUNIFORM)
+#elif !defined(NERFHIP_EMU)
             constexpr bool reuniform = CX;
 #else
             constexpr bool reuniform = false;
@@ -285,13 +285,13 @@ struct WStageDma {
         if (q < pa)
             nh_dma16a(ta, lane16, q * 1024, dst + q * 1024);
         else if (!SIDE || q < pab) {
-            if constexpr (CX) {
+            if (CX && cidx) {
                 gather_piece(tb, q - pa, b_sh, dst + boff + q * 1024, nxt_pq == q - pa, nxt_row);
                 prefetch_b(q - pa + NWV);
             } else
                 nh_dma16a(tb, lane16, (q - pa) * 1024, dst + boff + q * 1024);
         } else {
-            if (CX && s_gather)
+            if (CX && cidx && s_gather)
                 gather_piece(tc, q - pab, s_sh, dst + coff + q * 1024);
             else
                 nh_dma16a(tc, lane16, (q - pab) * 1024, dst + coff + q * 1024);
@@ -376,7 +376,7 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
     }
     if (nstage > 0) {
         const int nt0 = left < g ? left : g;
-        if constexpr (CX) {
+        if (CX && a.cidx) {  // (a.cidx == NULL in a CX launch: the stash is in list order itself -- contiguous blocks, the list's count)
             dma.template init_cx<MD::NWV>(ga, B0, SGATHER ? S0 : gs, b_bytes, s_bytes, a_fl, b_fl, s_fl, nt0, g, lds_addr, wave, lane, slot);
             slot += 32 * nt0;
         } else {
@@ -417,7 +417,7 @@ NH_DEVICE void wgrad_body(const WgradArgs& a, const JobDev& jb, int64_t t0, int6
         const int ntn = left < g ? left : g;
         dma.ptot = 0;
         if (ntn > 0) {
-            if constexpr (CX) {
+            if (CX && a.cidx) {
                 dma.template init_cx<MD::NWV>(ga, B0, SGATHER ? S0 : gs, b_bytes, s_bytes, a_fl, b_fl, s_fl, ntn, g,
                             lds_addr + (unsigned)(((n + 1) & 1) * NH_WG_STAGE_FLOATS * 4), wave, lane, slot);
                 slot += 32 * ntn;
@@ -873,7 +873,7 @@ int nh_wgrad(nerfhip_plan* p, int64_t nt, const float* stash, const float* grad,
     NH_REQUIRE(red.njobs <= NH_JOBS_DEV, "wgrad: %d reduce records exceed the table of %d", red.njobs, NH_JOBS_DEV);
     w.nt = nt;
     w.clk = nh_prof_clock_slot(NH_CLK_WGRAD);
-    w.cidx = cx ? cx->idx : nullptr;
+    w.cidx = (cx && !cx->stash_in_list_order) ? cx->idx : nullptr;
     w.cstats = cx ? cx->stats : nullptr;
     for (int q = 0; q < w.njobs; ++q) {
         const NhJob& j = p->jobs[q];

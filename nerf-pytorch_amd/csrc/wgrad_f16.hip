@@ -222,7 +222,7 @@ NH_KERNEL void NH_LB(NHW_THREADS, NHW_WAVES / 4) k_wgrad_f16x3(WgBArgs a) {
     static_assert(!CX || NPB * NHW_WAVES * 1024 == S::STAGE_B, "every wave gathers the same number of B pieces");
     unsigned rb[NPB * GatherN<BR>::N > 0 ? NPB * GatherN<BR>::N : 1], rs[GatherN<(SB ? SB : 32)>::N];
     auto preload = [&](int64_t u) {
-        if (CX) {
+        if (CX && a.cidx) {  // (a.cidx == NULL in a CX launch: the stash is in list order itself -- contiguous steps, the list's count)
 #pragma unroll
             for (int j = 0; j < NPB; ++j) gather_rows<BR>(rb + j * GatherN<BR>::N, a.cidx, (int)u * 16, wave + j * NHW_WAVES);
             // (every wave: a conditional fill would park the array in scratch memory)
@@ -233,7 +233,7 @@ NH_KERNEL void NH_LB(NHW_THREADS, NHW_WAVES / 4) k_wgrad_f16x3(WgBArgs a) {
         const NhDmaSrc da = nh_dma_src(a_reg + (size_t)u * 16 * AR, (unsigned)S::STAGE_A);
         const unsigned st = lds0 + (unsigned)((int)(u % NHW_STAGES) * S::STAGE);
         for (int p = wave; p < S::STAGE_A / 1024; p += NHW_WAVES) nh_dma16a(da, lane * 16, p * 1024, st + (unsigned)(p * 1024));
-        if (CX) {  // the B rows of the step's 16 listed samples, out of the whole region (their list entries: preload(u))
+        if (CX && a.cidx) {  // the B rows of the step's 16 listed samples, out of the whole region (their list entries: preload(u))
             const NhDmaSrc db = nh_dma_src(b_reg, (unsigned)((size_t)a.nt * 32 * BR * 4));
 #pragma unroll
             for (int j = 0; j < NPB; ++j)
@@ -243,7 +243,7 @@ NH_KERNEL void NH_LB(NHW_THREADS, NHW_WAVES / 4) k_wgrad_f16x3(WgBArgs a) {
             for (int p = wave; p < S::STAGE_B / 1024; p += NHW_WAVES) nh_dma16a(db, lane * 16, p * 1024, st + (unsigned)(S::STAGE_A + p * 1024));
         }
         if (SR) {
-            if (CX && SB) {  // (an SB guest lives in the stash: gathered; an SA guest in the compacted gradient scratch: contiguous)
+            if (CX && SB && a.cidx) {  // (an SB guest lives in the stash: gathered; an SA guest in the compacted gradient scratch: contiguous)
                 const NhDmaSrc ds = nh_dma_src(s_reg, (unsigned)((size_t)a.nt * 32 * (SR ? SR : 1) * 4));
                 if (wave < SPIECES) gather_piece_f16<(SB ? SB : 32)>(ds, rs, wave, lane, st + (unsigned)(S::STAGE_A + S::STAGE_B + wave * 1024));
             } else {
@@ -586,7 +586,7 @@ int launch(WgBArgs& w, nerfhip_stream_t stream) {
     static_assert(S::PART == AR * BR + S::SIDE_TILES * 1024 + NHW_THREADS + (SA ? 64 : 0), "schedule() sizes the partials");
     const int wgs = w.jobs[w.njobs - 1].wg0 + w.jobs[w.njobs - 1].nwg;
     int rc = NERFHIP_OK;
-    if (w.cidx) {
+    if (w.cstats) {
         rc = w_lds_limit(k_wgrad_f16x3<AR, BR, SA, SB, true>, S::LDS_BYTES);
         if (rc) return rc;
         NH_LAUNCH_NAMED(AR == BR ? (SA || SB ? "k_wgrad_f16x3<full+side, compacted>" : "k_wgrad_f16x3<full, compacted>")
@@ -628,7 +628,7 @@ int nh_wgrad_f16(nerfhip_plan* p, int64_t nt, const float* stash, const float* g
         w.g_params = g_params;
         w.amax = amax;
         w.bmax = bmax;
-        w.cidx = cx ? cx->idx : nullptr;
+        w.cidx = (cx && !cx->stash_in_list_order) ? cx->idx : nullptr;
         w.cstats = cx ? cx->stats : nullptr;
         w.partial = partial + off;
         off += (int64_t)(w.jobs[w.njobs - 1].wg0 + w.jobs[w.njobs - 1].nwg) * w.part_stride;

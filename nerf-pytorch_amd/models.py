@@ -162,7 +162,7 @@ class FlexibleNeRFModel(torch.nn.Module):
         self._inf_packed = None
         if getattr(self, "inference_precision", "fp32") != "fp32":
             self._inf_owner = _PlanHandle(self.cfg, PRECISIONS[self.inference_precision])
-        lib.plan_set_bwd_compaction(self._plan, int(bool(getattr(self, "backward_compaction", False))))
+        lib.plan_set_bwd_compaction(self._plan, int(getattr(self, "backward_compaction", 0)))
         self._flatten()
 
     @property
@@ -189,16 +189,19 @@ class FlexibleNeRFModel(torch.nn.Module):
         self._native_init()
         return self
 
-    backward_compaction = False
+    backward_compaction = 0
 
     def set_backward_compaction(self, on=True):
         """Compacted backward (nerfhip_plan_set_bwd_compaction; off by default): this model's backward passes drop the sample points
         whose d(loss)/d(raw) row is exactly zero -- sigma_a = relu(raw[..., 3] + noise) is off there, or the ray's transmittance has
         reached 0 (nerf/volume_rendering_utils.py:38-42) -- instead of multiplying zeros through eight layers as autograd does
         (train_nerf.py:259).  The gradient is the same sum with its zero terms dropped; forward, stash, parameters and optimizer state
-        are unaffected.  Works with every training precision; may be switched at any time."""
-        self.backward_compaction = bool(on)
-        L.get_lib().plan_set_bwd_compaction(self._plan, int(self.backward_compaction))
+        are unaffected.  Works with every training precision; may be switched between steps.
+        on = "recompute" (nerfhip_plan_set_bwd_compaction(plan, 2)): inside the fused render (run_one_iter_of_nerf / TrainEngine) the
+        training forward additionally writes no activation stash; the backward re-runs the forward for the samples it keeps.  Pays
+        where most rows are dropped and the stash-writing forward is much slower than the plain one (the fp16-piece plans)."""
+        self.backward_compaction = 2 if on == "recompute" else int(bool(on))
+        L.get_lib().plan_set_bwd_compaction(self._plan, self.backward_compaction)
         return self
 
     def set_inference_precision(self, precision):

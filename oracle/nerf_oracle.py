@@ -263,7 +263,12 @@ def mlp_relu_margin(params, x, cfg, per_layer=False):
     if not pres:
         return torch.ones(x.shape[0])
     if per_layer:  # each layer's smallest |pre-activation| relative to THAT layer's largest (nets whose layers differ by orders of magnitude)
-        return torch.stack([p.abs().min(dim=-1).values / (p.abs().max(dim=-1).values + 1e-300) for p in pres], dim=0).min(dim=0).values
+        def one(p):
+            mx = p.abs().max(dim=-1).values
+            # (a layer whose pre-activations are ALL zero -- a zero input row under zero biases -- has no branch round-off could flip:
+            # margin 1, the row is compared; 0 / 0 would be NaN, `NaN > margin` False, and the row silently dropped)
+            return torch.where(mx > 0, p.abs().min(dim=-1).values / torch.where(mx > 0, mx, torch.ones_like(mx)), torch.ones_like(mx))
+        return torch.stack([one(p) for p in pres], dim=0).min(dim=0).values
     allp = torch.cat(pres, dim=-1)
     return allp.abs().min(dim=-1).values / (allp.abs().max(dim=-1).values + 1e-30)
 

@@ -9,7 +9,7 @@ recorded 75-87 % on this scene).  This script
   1. trains 8x256 coarse + fine students for --iters iterations on the teacher scene of scripts/psnr400.py (lego views rendered from the
      reference's lego-lowres weights, white background, 4096 rays of a 400x400 view per step, 64 + 128 samples) with the engine that
      ships (f16x3_train plans, compacted backward: the fastest arm; the weights it leaves are what every arm below starts from),
-  2. then times, for each arm in {fp32, f16x3_train} x {dense, compacted}: --steps full training iterations (ray selection from a
+  2. then times, for each arm in {fp32, f16x3_train} x {dense, compacted, recomputed (stash-free forward + forward again for the kept samples)}: --steps full training iterations (ray selection from a
      resident view, forward, loss, backward, Adam, re-pack) after --warmup, HIP-event bracketed per kernel, on the same data stream,
   3. and records per arm: rays/s, ms/step, the zero-cotangent fraction of the last timed step per net (compacted arms: read from the
      library; dense arms: the same step's d(raw) rows counted with torch), per-kernel ms/step, and -- compacted vs dense, same weights,
@@ -86,6 +86,9 @@ if __name__ == "__main__":
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--save-weights", default=None, help="keep the trained weights (a torch file) for later calls")
+    ap.add_argument("--load-weights", default=None, help="skip the training: start from a file written by --save-weights (profiler runs)")
+    ap.add_argument("--arms", default=None, help="comma-separated subset of the arms, e.g. f16x3_train_compacted (default: all six)")
     a = ap.parse_args()
     lib = L.get_lib()
     poses, imgs, train, val = P4.teacher_dataset()
@@ -93,33 +96,42 @@ if __name__ == "__main__":
     res = dict(scene="teacher scene of scripts/psnr400.py: 400x400 lego views rendered from the reference's lego-lowres weights, white background",
                student="8x256 coarse + fine", rays_per_step=RAYS, samples="64 + 128", pretrain_iters=a.iters, lr0=a.lr, steps=a.steps,
                warmup=a.warmup, lib_version=lib.version(), arms={})
-    # 1. the trained regime
-    torch.manual_seed(a.seed)
-    mc, mf, eng = make_engine(None, None, "f16x3_train", True, a.lr, a.seed)
-    stream = data_stream(poses, imgs, train, a.seed)
-    t0 = time.perf_counter()
-    fracs = {}
-    for i in range(1, a.iters + 1):
-        ro, rd, tgt = next(stream)
-        eng.step(N.pack_rays(ro, rd, opts), tgt, lr=N.TrainEngine.lr_at(i - 1, lr0=a.lr))
-        if i in (1, 10, 100, 500, 1000, 2000, 5000, 10000, 20000) or i == a.iters:
-            k = eng.backward_sample_counts()
-            fracs[i] = {n: round(1.0 - v[0] / v[1], 4) for n, v in k.items()}
-            print("pretrain", i, fracs[i], flush=True)
-    torch.cuda.synchronize()
-    res["pretrain"] = dict(arm="f16x3_train, compacted backward", wall_s=round(time.perf_counter() - t0, 2), zero_cotangent_fraction_at_iteration=fracs,
-                           train_psnr_last=float(N.TrainEngine.psnr(float(eng.loss[2]))))
-    vals = P4.validate_hip(mc, mf, poses, imgs, val[:2])
-    res["pretrain"]["val_psnr"] = P4.psnr(sum(c for c, _ in vals) / len(vals) + sum(f for _, f in vals) / len(vals))
-    state_c, state_f = copy.deepcopy(mc.state_dict()), copy.deepcopy(mf.state_dict())
-    del eng, mc, mf
-    torch.cuda.empty_cache()
+    if a.load_weights:
+        saved = torch.load(a.load_weights)
+        state_c, state_f = saved["coarse"], saved["fine"]
+        res["pretrain"] = saved["pretrain"]
+    else:
+        # 1. the trained regime
+        torch.manual_seed(a.seed)
+        mc, mf, eng = make_engine(None, None, "f16x3_train", True, a.lr, a.seed)
+        stream = data_stream(poses, imgs, train, a.seed)
+        t0 = time.perf_counter()
+        fracs = {}
+        for i in range(1, a.iters + 1):
+            ro, rd, tgt = next(stream)
+            eng.step(N.pack_rays(ro, rd, opts), tgt, lr=N.TrainEngine.lr_at(i - 1, lr0=a.lr))
+            if i in (1, 10, 100, 500, 1000, 2000, 5000, 10000, 20000) or i == a.iters:
+                k = eng.backward_sample_counts()
+                fracs[i] = {n: round(1.0 - v[0] / v[1], 4) for n, v in k.items()}
+                print("pretrain", i, fracs[i], flush=True)
+        torch.cuda.synchronize()
+        res["pretrain"] = dict(arm="f16x3_train, compacted backward", wall_s=round(time.perf_counter() - t0, 2), zero_cotangent_fraction_at_iteration=fracs,
+                               train_psnr_last=float(N.TrainEngine.psnr(float(eng.loss[2]))))
+        vals = P4.validate_hip(mc, mf, poses, imgs, val[:2])
+        res["pretrain"]["val_psnr"] = P4.psnr(sum(c for c, _ in vals) / len(vals) + sum(f for _, f in vals) / len(vals))
+        state_c, state_f = copy.deepcopy(mc.state_dict()), copy.deepcopy(mf.state_dict())
+        del eng, mc, mf
+        torch.cuda.empty_cache()
+        if a.save_weights:
+            torch.save(dict(coarse=state_c, fine=state_f, pretrain=res["pretrain"]), a.save_weights)
     # 2. the arms, all from the same weights on the same stream
     lr = N.TrainEngine.lr_at(a.iters, lr0=a.lr)
     grads = {}
     for prec in ("fp32", "f16x3_train"):
-        for compact in (False, True):
-            arm = "%s_%s" % (prec, "compacted" if compact else "dense")
+        for compact in (False, True, "recompute"):
+            arm = "%s_%s" % (prec, {False: "dense", True: "compacted", "recompute": "recomputed"}[compact])
+            if a.arms and arm not in a.arms.split(","):
+                continue
             mc, mf, eng = make_engine(state_c, state_f, prec, compact, a.lr, a.seed + 7)
             # one step on a fixed batch first: the gradient this arm computes from the common weights (compacted vs dense below)
             s0 = data_stream(poses, imgs, train, 999)
@@ -138,10 +150,13 @@ if __name__ == "__main__":
             json.dump(res, open(a.out, "w"), indent=1)
     n0 = None
     for prec in ("fp32", "f16x3_train"):
-        d, c = grads[prec + "_dense"], grads[prec + "_compacted"]
-        n0 = d.numel() // 2
-        res["arms"][prec + "_compacted"]["grad_vs_dense_of_max"] = dict(
-            coarse=float((c[:n0] - d[:n0]).abs().max() / d[:n0].abs().max()), fine=float((c[n0:] - d[n0:]).abs().max() / d[n0:].abs().max()))
-        res["arms"][prec + "_compacted"]["speedup_vs_dense"] = round(res["arms"][prec + "_dense"]["ms_per_step"] / res["arms"][prec + "_compacted"]["ms_per_step"], 3)
+        for kind in ("_compacted", "_recomputed"):
+            if prec + "_dense" not in grads or prec + kind not in grads:
+                continue
+            d, c = grads[prec + "_dense"], grads[prec + kind]
+            n0 = d.numel() // 2
+            res["arms"][prec + kind]["grad_vs_dense_of_max"] = dict(
+                coarse=float((c[:n0] - d[:n0]).abs().max() / d[:n0].abs().max()), fine=float((c[n0:] - d[n0:]).abs().max() / d[n0:].abs().max()))
+            res["arms"][prec + kind]["speedup_vs_dense"] = round(res["arms"][prec + "_dense"]["ms_per_step"] / res["arms"][prec + kind]["ms_per_step"], 3)
     json.dump(res, open(a.out, "w"), indent=1)
     print(json.dumps({k: (v["rays_per_s"], v["ms_per_step"], v["zero_cotangent_fraction_last_step"]) for k, v in res["arms"].items()}))

@@ -44,6 +44,7 @@ import nerf_pytorch_amd as N  # noqa: E402
 import nerf_pytorch_amd._lib as L  # noqa: E402
 import psnr400 as P4  # noqa: E402  (teacher dataset, validation renders)
 from psnr_arms import data_stream  # noqa: E402
+from bench import lib_sources_sha16  # noqa: E402  (the fingerprint of the kernel sources the loaded library was built from)
 
 dev = torch.device("cuda", 0)
 H = W = 400
@@ -153,7 +154,7 @@ def diagnose(eng, mf, rays, tgt, student, f16):
     return out
 
 
-def run(arm, seed, iters, check, diag_every, student, lr0, poses, imgs, train, views):
+def run(arm, seed, iters, check, diag_every, student, lr0, poses, imgs, train, views, compact=False):
     P4.STUDENT.clear()
     P4.STUDENT.update(student)
     torch.manual_seed(seed)
@@ -163,6 +164,9 @@ def run(arm, seed, iters, check, diag_every, student, lr0, poses, imgs, train, v
     if f16:
         mc.set_training_precision("f16x3_train")
         mf.set_training_precision("f16x3_train")
+    # (round 6: the compacted backward changes the summation order of every weight gradient -- its own long run)
+    mc.set_backward_compaction(compact)
+    mf.set_backward_compaction(compact)
     eng = N.TrainEngine(mc, mf, NC, NF, perturb=True, white_background=True, noise_std=0.2, lr=lr0, seed=seed)
     opts = N.make_options(NC, NF, white_background=True)
     stream = data_stream(poses, imgs, train, seed)
@@ -177,8 +181,11 @@ def run(arm, seed, iters, check, diag_every, student, lr0, poses, imgs, train, v
             torch.cuda.synchronize()
             t_train += time.perf_counter() - t_mark
             if i % diag_every == 0:
+                kept = eng.backward_sample_counts() if compact else None
                 diags[i] = diagnose(eng, mf, rays, tgt, student, f16)
                 d = diags[i]
+                if kept is not None:
+                    d["zero_cotangent_fraction"] = {k: round(1.0 - v[0] / v[1], 4) for k, v in kept.items() if v}
                 print(arm, seed, i, "diag", dict(finite=(d["grad_finite"], d["loss_finite"]), absmax=d["grad_absmax"],
                                                  H=d["activation_exponents"]["H%d" % (student["num_layers"] - 1)], P1=d["dpre_exponents"]["P1"],
                                                  k=d.get("kernel_grad_vs_torch_worst_rel")), flush=True)
@@ -205,13 +212,15 @@ if __name__ == "__main__":
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--check", type=int, default=2000)
     ap.add_argument("--diag", type=int, default=1000)
+    ap.add_argument("--compact", action="store_true", help="both arms with the compacted backward (set_backward_compaction)")
     a = ap.parse_args()
     student = dict(num_layers=a.layers, hidden_size=a.hidden, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4)
     check = list(range(a.check, a.iters + 1, a.check)) or [a.iters]
     poses, imgs, train, val = P4.teacher_dataset()
     views = val[:P4.VAL_PER_CHECK]
     res = dict(seed=a.seed, iters=a.iters, lr0=a.lr, student="%dx%d" % (a.layers, a.hidden), rays_per_iter=RAYS, image="%dx%d" % (H, W),
-               diag_rays=DIAG_RAYS, arms={})
+               diag_rays=DIAG_RAYS, backward="compacted" if a.compact else "dense", lib_sources_sha16=lib_sources_sha16(),
+               lib_version=L.get_lib().version(), arms={})
     for arm in a.arms.split(","):
-        res["arms"][arm] = run(arm, a.seed, a.iters, check, a.diag, student, a.lr, poses, imgs, train, views)
+        res["arms"][arm] = run(arm, a.seed, a.iters, check, a.diag, student, a.lr, poses, imgs, train, views, compact=a.compact)
         json.dump(res, open(a.out, "w"), indent=1)

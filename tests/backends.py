@@ -280,8 +280,9 @@ class Backend:
 
     def set_compaction(self, plan, on):
         """nerfhip_plan_set_bwd_compaction: the plan's backward drops the samples whose d(raw output) row is all zero."""
-        self.lib.plan_set_bwd_compaction(plan, int(bool(on)))
-        assert self.lib.plan_bwd_compaction(plan) == int(bool(on))
+        mode = 2 if on == "recompute" else int(bool(on))
+        self.lib.plan_set_bwd_compaction(plan, mode)
+        assert self.lib.plan_bwd_compaction(plan) == mode
 
     def bwd_stats(self, plan, m, scratch):
         """(samples kept, samples of the launch) of the last compacted backward that ran in `scratch`."""
@@ -350,7 +351,15 @@ class Backend:
             gc, gf = self.dev(np.ascontiguousarray(g_rgb[0], np.float32)), self.devopt(g_rgb[1])
             gpc = self.empty((self.lib.plan_num_params(plan_c),))
             gpf = self.empty((self.lib.plan_num_params(plan_f),)) if nf > 0 else None
-            if ray_grad_params is None:
+            compacted = bool(self.lib.plan_bwd_compaction(plan_c)) or bool(plan_f and self.lib.plan_bwd_compaction(plan_f))
+            if ray_grad_params is None and compacted and int(training) == 1:
+                # (one set of backward buffers per net -- the layout the workspace was sized for --, so that each net's kept / total
+                # counts survive the other net's backward: nerfhip_render_bwd shares ONE scratch between the two)
+                cot = L.RenderCotangents(self.ptr(gc), None, None, self.p(gf), None, None)
+                self.lib.render_bwd_parts(plan_c, plan_f, C.byref(cfg), self.ptr(dr), n, self.ptr(packed_c), self.p(packed_f),
+                                          C.byref(rr), seed, ray_offset, C.byref(cot), self.ptr(ws), wsb, self.ptr(gpc), self.p(gpf),
+                                          L.PART_COARSE | (L.PART_FINE if nf > 0 else 0), self.stream())
+            elif ray_grad_params is None:
                 self.lib.render_bwd(plan_c, plan_f, C.byref(cfg), self.ptr(dr), n, self.ptr(packed_c), self.p(packed_f),
                                     C.byref(rr), seed, ray_offset, self.ptr(gc), self.p(gf), self.ptr(ws), wsb, self.ptr(gpc),
                                     self.p(gpf), self.stream())
@@ -371,7 +380,9 @@ class Backend:
                 if plan is None or samples == 0 or not self.lib.plan_bwd_compaction(plan):
                     continue
                 off, nb = C.c_int64(), C.c_int64()
-                self.lib.render_workspace_region(plan_c, plan_f, C.byref(cfg), n, 2, ("bwd_scratch_" + name).encode(), C.byref(off),
+                if not (ray_grad_params is None and int(training) == 1):
+                    continue  # (shared backward buffers: the second net's backward has overwritten the first one's counts)
+                self.lib.render_workspace_region(plan_c, plan_f, C.byref(cfg), n, 1, ("bwd_scratch_" + name).encode(), C.byref(off),
                                                  C.byref(nb))
                 so = self.lib.plan_bwd_stats_offset(plan, n * samples)
                 w = self.host(ws[(off.value + so) // 4:(off.value + so) // 4 + 2])

@@ -475,6 +475,54 @@ def case_mlp_backward_compacted(b, names=None, m=300, precision=0, fractions=(0.
         b.lib.plan_destroy(plan)
 
 
+def case_render_compacted(b, cfg, n, nc, nf, precision=0, seed=9, white=False, noise=0.3, tag=""):
+    """The fused render's backward in its three modes on one batch -- dense, compacted (stash rows gathered), compacted + recomputed
+    (nerfhip_plan_set_bwd_compaction(plan, 2): stash-free training forward, the backward re-runs the forward for the listed samples) --
+    with the renderer's OWN cotangents: the rows dropped are those relu(sigma + noise) and the transmittance zero
+    (nerf/volume_rendering_utils.py:38-42).  Outputs bit-identical in all modes (the stash-free forward is the same kernel without its
+    stores); gradients of both nets within `unit.compact_vs_dense` of the dense ones; kept + dropped = all samples, and some of each."""
+    gen = rng(seed)
+    pc, par_c, _, packed_c = mlp_setup(b, cfg, seed=seed + 1, precision=precision)
+    pf, par_f, _, packed_f = mlp_setup(b, cfg, seed=seed + 2, precision=precision)
+    ro = torch.tensor([0.2, -0.1, 4.0]).expand(n, 3) + 0.05 * torch.randn(n, 3, generator=gen)
+    rd = torch.randn(n, 3, generator=gen) * 0.3
+    rd[:, 2] = -1.0
+    rays = O.pack_rays(ro, rd, 2.0, 6.0, rd if cfg["use_viewdirs"] else None).numpy()
+    rnp = dict(t_rand=torch.rand(n, nc, generator=gen).numpy(), noise_coarse=torch.randn(n, nc, generator=gen).numpy(),
+               u=torch.rand(n, nf, generator=gen).numpy(), noise_fine=torch.randn(n, nc + nf, generator=gen).numpy())
+    opt = dict(num_coarse=nc, num_fine=nf, perturb=True, lindisp=False, white_background=white, noise_std=noise)
+    tgt = torch.rand(n, 3, generator=gen).numpy()
+    ctol = TL.bound("unit.compact_vs_dense", ARITH_NAME[precision])
+    res = {}
+    for mode in (False, True, "recompute"):
+        b.set_compaction(pc, mode)
+        b.set_compaction(pf, mode)
+        fwd = b.render(pc, pf, packed_c, packed_f, rays, opt, rnp, training=True)
+        if mode is False:
+            _, gc, gf = b.mse_loss(fwd["rgb_coarse"], fwd["rgb_fine"], tgt)
+        res[mode] = b.render(pc, pf, packed_c, packed_f, rays, opt, rnp, training=True, g_rgb=(gc, gf))
+    dense = res[False]
+    for mode in (True, "recompute"):
+        r = res[mode]
+        for k in ("rgb_coarse", "acc_coarse", "depth_coarse", "disp_coarse", "rgb_fine", "acc_fine", "depth_fine", "disp_fine"):
+            assert np.array_equal(r[k], dense[k], equal_nan=True), (mode, k)
+        for key, name, plan, total in (("g_params_coarse", "coarse", pc, n * nc), ("g_params_fine", "fine", pf, n * (nc + nf))):
+            kept, tot = r["bwd_kept_" + name]
+            assert tot == total and 0 < kept < total, (mode, name, kept, tot)
+            assert r["bwd_kept_" + name] == res[True]["bwd_kept_" + name]
+            gd, gk = b.unflatten(plan, dense[key]), b.unflatten(plan, r[key])
+            worst = 0.0
+            for k in gd:
+                assert np.isfinite(gk[k]).all(), (mode, key, k)
+                d = float(np.abs(gk[k] - gd[k]).max()) / (float(np.abs(gd[k]).max()) + 1e-30)
+                worst = max(worst, d)
+                assert d <= ctol, ("compacted render vs dense", mode, key, k, d, ctol)
+            note("render_compacted_%s_%s_%s" % (tag or n, ARITH_NAME[precision], b.name),
+                 **{"%s %s" % (mode, name): worst, "zero fraction " + name: 1.0 - kept / float(tot)})
+    for p in (pc, pf):
+        b.lib.plan_destroy(p)
+
+
 def case_f16x3_range_extremes(b, m=120):
     """The edges of the fp16-piece bookkeeping (round 5).  (i) Cotangents of 1e-30, 1e-33 and of fp32-SUBNORMAL size (1e-39):
     the per-sample exponent would be 113 / 123 / undefined -- it is clamped at 110 / the sample counts as all-zero (mlp_f16w.hip
@@ -519,6 +567,26 @@ def case_f16x3_range_extremes(b, m=120):
     assert max(float(v.abs().max()) for k, v in params.items() if k.endswith("weight")) > 256.0
     got, _ = b.mlp_fwd(plan, packed, x.numpy())
     assert np.isfinite(got).all()
+    b.lib.plan_destroy(plan)
+    # (iii) fp32's TOP edge: input rows of 1e30 ... 1e37 -- activations up to 2^124.  A sample's exponent goes down to 13 - 127
+    # (mlp_f16w.hip S_MIN); round 5 clamped it at -110 and such a sample's pieces overflowed fp16 (NaN outputs).  Wherever the oracle's
+    # fp32 forward is finite the kernel's is, and agrees to 1e-4 of the row's largest output; the other rows of the batch are untouched.
+    plan, params, flat, packed = mlp_setup(b, cfg, seed=41, precision=F16X3)
+    xb = x.clone()
+    scales = (1e30, 1e33, 1e35, 1e36, 1e37)
+    for r, sc in enumerate(scales):
+        xb[r] = x[r] * sc
+    want = O.mlp_forward(params, xb, cfg).numpy()
+    got, _ = b.mlp_fwd(plan, packed, xb.numpy())
+    base, _ = b.mlp_fwd(plan, packed, x.numpy())
+    assert np.array_equal(got[len(scales):], base[len(scales):])
+    checked = 0
+    for r in range(len(scales)):
+        if np.isfinite(want[r]).all():
+            assert np.isfinite(got[r]).all(), (r, scales[r], got[r], want[r])
+            assert float(np.abs(got[r] - want[r]).max()) <= 1e-4 * float(np.abs(want[r]).max()), (r, scales[r], got[r], want[r])
+            checked += 1
+    assert checked >= 2, checked
     b.lib.plan_destroy(plan)
 
 
@@ -763,10 +831,26 @@ def case_render_vs_oracle(b, cfg, n, nc, nf, seed=5, white=False, noise=0.3, wit
         # a fine sample moves): any two fp32 implementations differ by ~1e-3 there (see DESIGN.md "parity tolerances").
         # (1e-3 for the coarse net: with noise_std up to 1.0 and a white background the per-sample cotangents nearly
         # cancel in the early layers; the teacher-forced case_mlp_backward keeps the tight 2e-5 bound on the kernels.)
+        case = "render_vs_oracle_%s_%s" % (tag or n, b.name)
         for plan, par, key, gt in ((pc, par_c, "g_params_coarse", grad_tol[0]), (pf, par_f, "g_params_fine", grad_tol[1])):
             grads = b.unflatten(plan, out[key])
+            if isinstance(gt, dict):
+                # coarse net (no sampler in front): held to the fp64 yardstick -- no further from an fp64 run of the oracle than the oracle's
+                # own fp32 run is (x mul + add), per tensor, of max|g|
+                assert key == "g_params_coarse"
+                p64 = {k: v.detach().double().requires_grad_(True) for k, v in par_c.items()}
+                o64 = O.render_rays(rays.double(), p64, None, cfg, cfg, dict(opt, num_fine=0), {k: v.double() for k, v in rand.items()})
+                torch.nn.functional.mse_loss(o64["rgb_coarse"], tgt.double()).backward()
+                for k, v in grads.items():
+                    ref = p64[k].grad.numpy()
+                    scale = float(np.abs(ref).max()) + 1e-30
+                    e_hip = float(np.abs(np.asarray(v, np.float64) - ref).max()) / scale
+                    e_t32 = float(np.abs(par[k].grad.numpy().astype(np.float64) - ref).max()) / scale
+                    note(case, **{"coarse_vs_fp64 " + k: e_hip, "torch_fp32_vs_fp64 " + k: e_t32})
+                    assert TL.within(e_hip, e_t32, gt), (case, k, e_hip, e_t32, gt)
+                continue
             for k, v in grads.items():
-                grad_close(v, par[k].grad.numpy(), gt, "grad %s %s" % (key, k), "render_vs_oracle_%s_%s" % (tag or n, b.name), key)
+                grad_close(v, par[k].grad.numpy(), gt, "grad %s %s" % (key, k), case, key)
     b.lib.plan_destroy(pc)
     b.lib.plan_destroy(pf)
 

@@ -120,6 +120,15 @@ def test_compacted_backward_equals_dense(emu):
     P.case_mlp_backward_compacted(emu, names=("default4x128",), m=200, precision=P.F16X3_TRAIN, fractions=(0.6,), g_scale=3e-7)
 
 
+def test_render_backward_modes_dense_compacted_recomputed(emu):
+    """The fused render with both plans dense / compacted / compacted + recomputed: identical outputs, equal gradients (fp32 and fp16
+    pieces; 128- and 64-wide kernels on the emulator, 256-wide on the GPU)."""
+    P.case_render_compacted(emu, P.MLP_GEOMETRIES["default4x128"], n=10, nc=16, nf=16, tag="4x128_emu")
+    P.case_render_compacted(emu, P.MLP_GEOMETRIES["llff4x64_skip3_L6"], n=9, nc=16, nf=16, tag="llff64_emu", white=True)
+    P.case_render_compacted(emu, P.MLP_GEOMETRIES["default4x128"], n=10, nc=16, nf=16, precision=P.F16X3_TRAIN, tag="4x128_emu")
+    P.case_render_compacted(emu, P.MLP_GEOMETRIES["novw4x128"], n=9, nc=16, nf=8, precision=P.F16X3_FWD_DGRAD, tag="novw_emu")
+
+
 def test_f16x3_scale_fuzz(emu):
     """(the corners on the emulator; the GPU suite walks the whole 3 x 3 x 3 grid on four geometries)"""
     P.case_f16x3_scale_fuzz(emu, m=24, names=("default4x128", "deep8x128_skip4"),

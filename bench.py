@@ -394,10 +394,11 @@ def main():
                          "forward; --mode train --precision f16x3_fwd the training forward, f16x3_fwd_dgrad + the data-gradient chain, "
                          "f16x3_train + the large weight-gradient blocks.  A+B: coarse net A, fine net B.  Separate, labelled lines: "
                          "the driver's default stays fp32")
-    ap.add_argument("--compact", nargs="?", const="gather", default=None, choices=("gather", "recompute"),
+    ap.add_argument("--compact", nargs="?", const="gather", default=None, choices=("gather", "recompute", "auto"),
                     help="train: compacted backward (FlexibleNeRFModel.set_backward_compaction): data and weight gradient over the sample "
                          "points whose d(loss)/d(raw) row is not all zero; `recompute`: additionally a stash-free training forward, the "
-                         "backward re-runs the forward for the kept samples.  A labelled line: it states the zero fraction of the step it "
+                         "backward re-runs the forward for the kept samples; `auto`: TrainEngine(backward='auto') picks dense / compacted / recomputed per net "
+                         "and step from the zero fraction the previous steps reported.  A labelled line: it states the zero fraction of the step it "
                          "timed and prices the backward kernels on the FLOPs they executed; the driver's default stays dense")
     ap.add_argument("--gather", action="store_true", help="eval: rank 0 also receives every pose's rows (output plumbing)")
     ap.add_argument("--no-kernel-profile", action="store_true", help="do not bracket the launches of the timed region with HIP events (no "
@@ -484,7 +485,7 @@ def main():
             mc.set_training_precision(prec_c)
         if prec_f != "fp32":
             mf.set_training_precision(prec_f)
-        if args.compact:
+        if args.compact in ("gather", "recompute"):
             mc.set_backward_compaction("recompute" if args.compact == "recompute" else True)
             mf.set_backward_compaction("recompute" if args.compact == "recompute" else True)
         strong = args.global_rays > 0
@@ -496,7 +497,8 @@ def main():
             n = args.rays
             total_rays = n * world
         eng = N.TrainEngine(mc, mf, nc, nf, perturb=True, lindisp=False, white_background=False, noise_std=wl["noise"], lr=5e-3,
-                            seed=1234, world_size=world, rank=rank, overlap=None if args.overlap < 0 else bool(args.overlap))
+                            seed=1234, world_size=world, rank=rank, overlap=None if args.overlap < 0 else bool(args.overlap),
+                            backward="auto" if args.compact == "auto" else None)
         opts = N.make_options(nc, nf, num_random_rays=n, radiance_field_noise_std=wl["noise"], no_ndc=wl["no_ndc"], near=wl["near"],
                               far=wl["far"])
         g = torch.Generator(device=dev).manual_seed(1000 + rank)
@@ -563,6 +565,12 @@ def main():
     loss_host = [float(v) for v in last.cpu()] if args.mode == "train" else None
     # compacted backward: the sample points the LAST timed step's backward kept, per net (two words per net of its workspace)
     kept = eng.backward_sample_counts() if (args.mode == "train" and args.compact) else None
+    # (the mode the accounting below assumes: `auto` -> what the last timed step's nets ran in; per-net / per-step mixes make the auto
+    # line's per-kernel fractions approximate -- its rays/s is what it is)
+    eff_compact = args.compact
+    if args.mode == "train" and args.compact == "auto":
+        modes = [m.backward_compaction for m in (mc, mf)]
+        eff_compact = "recompute" if 2 in modes else ("gather" if 1 in modes else None)
     # What the per-launch HIP events of the timed region cost: the same K steps once more WITHOUT them (N = 1 only).  Nothing at
     # 27 ms per step; 0.28 ms of a 2.0-ms fern step (a step is ~40 launches, each with two event records on the host's path).
     unprofiled = None
@@ -616,7 +624,7 @@ def main():
             kept_f = kept["fine"][0] if kept["fine"] else m_f
         for m, mb, prec in ((m_c, kept_c, prec_c), (m_f, kept_f, prec_f)):
             fmt, level = precision_level(prec)
-            if args.mode == "train" and args.compact == "recompute":  # (stash-free pass over all samples + a stash-writing pass over the kept ones)
+            if args.mode == "train" and eff_compact == "recompute":  # (stash-free pass over all samples + a stash-writing pass over the kept ones)
                 add("fwd", fmt if level >= 1 else "fp32", 2.0 * fwd_macs * (m + mb), 20 * m + stash_b * mb, 2)
             else:
                 add("fwd", fmt if level >= 1 else "fp32", 2.0 * fwd_macs * m, stash_b * m)
@@ -684,7 +692,7 @@ def main():
                         kernel_ms_per_step={nm: round(m / args.steps, 4) for nm, (_, m) in sorted(kern.items(), key=lambda kv: -kv[1][1])})
         if args.mode == "train":
             total_flops = 2.0 * fwd_macs * (m_c + m_f) + 2.0 * (fwd_macs + dgrad_macs) * (kept_c + kept_f)   # (executed: == algorithmic when dense)
-            if args.compact == "recompute":
+            if eff_compact == "recompute":
                 total_flops += 2.0 * fwd_macs * (kept_c + kept_f)
             step_bytes = stash_b * (m_c + m_f) + (dgrad_b + wgrad_b) * (kept_c + kept_f)
             if args.workload == "lego":
@@ -734,7 +742,10 @@ def main():
                    step_hbm_frac_of_8tb_s=round(step_bytes / sec / 1e12 / HBM_PEAK_TBS, 4),
                    final_loss=loss_host, roofline=roof)
         if args.mode == "train":
-            res["backward"] = {None: "dense", "gather": "compacted", "recompute": "compacted, stash recomputed for the kept samples"}[args.compact]
+            res["backward"] = {None: "dense", "gather": "compacted", "recompute": "compacted, stash recomputed for the kept samples",
+                               "auto": "auto (per net and step: dense / compacted / recomputed by the zero fraction of earlier steps)"}[args.compact]
+            if args.compact == "auto":
+                res["backward_modes_used"] = dict(steps_dense_compacted_recomputed=eng.backward_modes_used, last_known_zero_fraction=eng._zero_frac)
         if kept is not None:
             frac = lambda kv, m: None if kv is None else round(1.0 - kv[0] / float(m), 4)  # noqa: E731
             res["zero_cotangent_fraction"] = dict(

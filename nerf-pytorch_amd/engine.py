@@ -30,7 +30,7 @@ from .parallel import allreduce_gradients
 class TrainEngine:
     def __init__(self, model_coarse, model_fine, num_coarse, num_fine, perturb=True, lindisp=False, white_background=False,
                  noise_std=0.0, lr=5e-3, betas=(0.9, 0.999), eps=1e-8, seed=0, process_group=None, world_size=None,
-                 rank=None, overlap=None, always_reduce=False):
+                 rank=None, overlap=None, always_reduce=False, backward=None):
         self.lib = L.get_lib()
         self.mc, self.mf = model_coarse, model_fine if num_fine > 0 else None
         self.dev = model_coarse.flat_params.device
@@ -71,6 +71,22 @@ class TrainEngine:
         self._ws = None
         self._ws_n = -1
         self._bufs = None
+        # backward mode of the step: None -- whatever each model's set_backward_compaction says (default: dense); "dense" / "compact" /
+        # "recompute" -- set on both models; "auto" -- chosen per net and per step from the zero-cotangent fraction the previous
+        # compacted steps reported (read back asynchronously: no host synchronisation), see _choose_backward_modes
+        if backward not in (None, "dense", "compact", "recompute", "auto"):
+            raise ValueError("backward must be None, 'dense', 'compact', 'recompute' or 'auto' (got %r)" % (backward,))
+        self.backward = backward
+        self._zero_frac = {"coarse": None, "fine": None}   # last known fraction of all-zero d(loss)/d(raw) rows per net
+        self._stats_host = None
+        self._stats_event = None
+        self._stats_pending = None
+        self._probe_every = 50
+        self.backward_modes_used = {"coarse": [0, 0, 0], "fine": [0, 0, 0]}   # steps run dense / compacted / recomputed per net ("auto")
+        if backward in ("dense", "compact", "recompute"):
+            for m in (self.mc, self.mf):
+                if m is not None:
+                    m.set_backward_compaction({"dense": False, "compact": True, "recompute": "recompute"}[backward])
         self.t_vals = linspace01(num_coarse, self.dev)
         self.u_det = linspace01(num_fine, self.dev) if num_fine > 0 else None
         self.repack()
@@ -133,6 +149,8 @@ class TrainEngine:
         self._check_inputs(rays, target)
         lib, n = self.lib, rays.shape[0]
         gscale = 1.0 if global_rays is None else float(n) * self.world / float(global_rays)
+        if self.backward == "auto":
+            self._choose_backward_modes()
         self._prepare(n)
         b = self._bufs
         nf = self.cfg.num_fine
@@ -196,6 +214,65 @@ class TrainEngine:
                 torch.stack((self._loss_c[0], self._loss_f[0], self._loss_c[0] + self._loss_f[0]), out=self.loss)
             else:
                 self.loss.copy_(self._loss_c)
+            if self.backward == "auto":
+                self._request_backward_stats(n)
+
+    # ---- backward="auto" ---------------------------------------------------------------------------------------------------------
+    # A compacted step costs what its gather costs when nothing is dropped (fp32: k_wgrad + 19 %, fp16 pieces + 1 %) and saves the
+    # dropped fraction of the data and weight gradient; the recomputing mode additionally trades the stash stream of the forward for a
+    # second forward over the kept samples (pays above ~2/3 dropped rows for the fp16-piece plans, never for fp32): DESIGN.md 3.3-3.4.
+    @staticmethod
+    def _mode_for(frac, f16):
+        if frac is None:
+            return 0
+        if f16:
+            return 2 if frac >= 0.72 else (1 if frac >= 0.05 else 0)
+        return 1 if frac >= 0.15 else 0
+
+    def _choose_backward_modes(self):
+        """Sets each net's plan option for the step about to run.  The fractions come from the last compacted step whose two statistics
+        words per net have arrived on the host (an asynchronous copy behind that step's backward; polled, never waited for); a net that
+        runs dense produces none, so every `_probe_every`-th step runs compacted to look again."""
+        if self._stats_event is not None and self._stats_event.query():
+            h = self._stats_host.tolist()
+            for k, name in enumerate(self._stats_pending):
+                kept, total = h[2 * k], h[2 * k + 1]
+                if total > 0:
+                    self._zero_frac[name] = 1.0 - kept / float(total)
+            self._stats_event = None
+        probe = self.step_count % self._probe_every == 0
+        for name, m in (("coarse", self.mc), ("fine", self.mf)):
+            if m is None:
+                continue
+            mode = self._mode_for(self._zero_frac[name], m.training_precision != "fp32")
+            if probe and mode == 0:
+                mode = 1
+            if m.backward_compaction != mode:
+                m.set_backward_compaction({0: False, 1: True, 2: "recompute"}[mode])
+            self.backward_modes_used[name][mode] += 1
+
+    def _request_backward_stats(self, n):
+        """Enqueues the copy of {kept, total} of every net that ran compacted in the step just issued (current stream)."""
+        if self._stats_event is not None:
+            return  # (the previous request is still in flight)
+        names = [nm for nm, m in (("coarse", self.mc), ("fine", self.mf)) if m is not None and m.backward_compaction]
+        if not names:
+            return
+        if self._stats_host is None:
+            self._stats_host = torch.zeros(4, dtype=torch.int32).pin_memory()
+        lib = self.lib
+        plan_f = self.mf._plan if self.mf is not None else None
+        words = self._ws.view(torch.int32)
+        for k, name in enumerate(names):
+            model = self.mc if name == "coarse" else self.mf
+            samples = self.cfg.num_coarse if name == "coarse" else self.cfg.num_coarse + self.cfg.num_fine
+            off, nb = C.c_int64(), C.c_int64()
+            lib.render_workspace_region(self.mc._plan, plan_f, C.byref(self.cfg), n, 1, ("bwd_scratch_" + name).encode(), C.byref(off), C.byref(nb))
+            so = (off.value + lib.plan_bwd_stats_offset(model._plan, n * samples)) // 4
+            self._stats_host[2 * k:2 * k + 2].copy_(words[so:so + 2], non_blocking=True)
+        self._stats_pending = names
+        self._stats_event = torch.cuda.Event()
+        self._stats_event.record(torch.cuda.current_stream(self.dev))
 
     def backward_sample_counts(self):
         """{"coarse": (kept, total), "fine": (kept, total)}: the sample points the last step's COMPACTED backward of each net kept

@@ -41,6 +41,7 @@ STUDENT = dict(num_layers=8, hidden_size=256, skip_connect_every=4, num_encoding
 
 
 def make_engine(state_c, state_f, precision, compact, lr, seed):
+    """compact: False / True / "recompute" (set on both models) or "auto" (TrainEngine(backward="auto"))."""
     mc, mf = N.FlexibleNeRFModel(**STUDENT), N.FlexibleNeRFModel(**STUDENT)
     if state_c is not None:
         mc.load_state_dict(state_c)
@@ -49,9 +50,11 @@ def make_engine(state_c, state_f, precision, compact, lr, seed):
     if precision != "fp32":
         mc.set_training_precision(precision)
         mf.set_training_precision(precision)
-    mc.set_backward_compaction(compact)
-    mf.set_backward_compaction(compact)
-    eng = N.TrainEngine(mc, mf, NC, NF, perturb=True, white_background=True, noise_std=0.2, lr=lr, seed=seed)
+    if compact != "auto":
+        mc.set_backward_compaction(compact)
+        mf.set_backward_compaction(compact)
+    eng = N.TrainEngine(mc, mf, NC, NF, perturb=True, white_background=True, noise_std=0.2, lr=lr, seed=seed,
+                        backward="auto" if compact == "auto" else None)
     return mc, mf, eng
 
 
@@ -128,8 +131,8 @@ if __name__ == "__main__":
     lr = N.TrainEngine.lr_at(a.iters, lr0=a.lr)
     grads = {}
     for prec in ("fp32", "f16x3_train"):
-        for compact in (False, True, "recompute"):
-            arm = "%s_%s" % (prec, {False: "dense", True: "compacted", "recompute": "recomputed"}[compact])
+        for compact in (False, True, "recompute", "auto"):
+            arm = "%s_%s" % (prec, {False: "dense", True: "compacted", "recompute": "recomputed", "auto": "auto"}[compact])
             if a.arms and arm not in a.arms.split(","):
                 continue
             mc, mf, eng = make_engine(state_c, state_f, prec, compact, a.lr, a.seed + 7)
@@ -142,6 +145,8 @@ if __name__ == "__main__":
             ms, kern = timed(eng, data_stream(poses, imgs, train, 4242), opts, a.steps, a.warmup, lr)
             kept = eng.backward_sample_counts()
             zf = {n: (None if v is None else round(1.0 - v[0] / v[1], 4)) for n, v in kept.items()}
+            if compact == "auto":
+                zf["steps_dense_compacted_recomputed"] = eng.backward_modes_used
             res["arms"][arm] = dict(rays_per_s=round(RAYS / ms, 1), ms_per_step=round(ms * 1e3, 3), zero_cotangent_fraction_last_step=zf,
                                     kernel_ms_per_step=kern, final_loss=[float(v) for v in eng.loss.cpu()])
             print(arm, res["arms"][arm]["rays_per_s"], res["arms"][arm]["ms_per_step"], zf, flush=True)
@@ -150,7 +155,7 @@ if __name__ == "__main__":
             json.dump(res, open(a.out, "w"), indent=1)
     n0 = None
     for prec in ("fp32", "f16x3_train"):
-        for kind in ("_compacted", "_recomputed"):
+        for kind in ("_compacted", "_recomputed", "_auto"):
             if prec + "_dense" not in grads or prec + kind not in grads:
                 continue
             d, c = grads[prec + "_dense"], grads[prec + kind]

@@ -122,6 +122,56 @@ def test_engine_on_fp16_piece_training_precisions_tracks_the_fp32_engine(precisi
             mc.set_training_precision(gone)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "f16x3_train"])
+def test_engine_backward_modes_compacted_recomputed_auto_track_the_dense_engine(precision):
+    """TrainEngine(backward=...) (round 6): the compacted backward, the recomputing one and "auto" against the dense engine -- same
+    weights, rays, in-kernel draws.  One forward/backward: the SAME loss bit for bit (the forward is the same kernel with or without
+    its stash stores) and the flat gradient within 1e-5 of max|g| (another association of the same fp32 sums, zero terms dropped);
+    the library's kept counts are below the sample counts (torch's init at sigma noise 0.2: ~40 % of the rows are zero).  120 steps on
+    an empty white scene (every target pixel white under white_background: the nets learn sigma -> off, the rows die out): "auto"
+    probes with its first step, follows the fraction to the compacted (fp16 pieces: then the recomputing) backward, and every mode's loss curve ends where
+    the dense engine's does."""
+    import nerf_pytorch_amd as N
+    dev = _dev()
+    rays, rgba = _rays(1024, dev)
+    white = torch.ones(1024, 3, device=dev)
+    res = {}
+    for mode in ("dense", "compact", "recompute", "auto"):
+        mc, mf = _models(dev)
+        if precision != "fp32":
+            mc.set_training_precision(precision)
+            mf.set_training_precision(precision)
+        eng = N.TrainEngine(mc, mf, 32, 32, noise_std=0.2, white_background=True, lr=1e-3, seed=11, world_size=1, rank=0, backward=mode)
+        if mode != "auto":
+            eng.forward_backward(rays, rgba[:, :3], ray_offset=0)
+            torch.cuda.synchronize()
+            g0, l0 = eng.grad.clone(), eng.loss.clone()
+            kept = eng.backward_sample_counts()
+        else:
+            g0 = l0 = kept = None
+        losses = torch.stack([eng.step(rays, white, ray_offset=0).clone() for _ in range(120)])
+        torch.cuda.synchronize()
+        res[mode] = (g0, l0, kept, losses, eng)
+    gd, ld, _, sd, _ = res["dense"]
+    for mode in ("compact", "recompute"):
+        g, l, kept, s, _ = res[mode]
+        assert torch.equal(l, ld), (mode, l, ld)
+        assert float((g - gd).abs().max()) <= 1e-5 * float(gd.abs().max()), (mode, float((g - gd).abs().max()), float(gd.abs().max()))
+        for name, total in (("coarse", 1024 * 32), ("fine", 1024 * 64)):
+            assert kept[name][1] == total and 0 < kept[name][0] < total, (mode, name, kept)
+    tail = lambda s: float(s[-20:, 2].mean())  # noqa: E731
+    assert tail(sd) < 0.25 * float(sd[0, 2])           # (the scene is learned)
+    for mode in ("compact", "recompute", "auto"):
+        assert torch.isfinite(res[mode][3]).all()
+        assert abs(tail(res[mode][3]) - tail(sd)) <= 0.05 * tail(sd) + 1e-4, (mode, tail(res[mode][3]), tail(sd))
+    used = res["auto"][4].backward_modes_used
+    assert sum(used["fine"]) == 120 and used["fine"][1] + used["fine"][2] > 20, used  # (the first step probes; then by the fraction)
+    if precision != "fp32":
+        assert used["fine"][2] + used["coarse"][2] > 0, used                           # (fp16 pieces: the recomputing mode was reached)
+    else:
+        assert used["fine"][2] == 0 and used["coarse"][2] == 0, used                   # (fp32: it never pays)
+
+
 def test_engine_fed_external_draws_equals_in_kernel_draws(gpu):
     """TrainEngine.step(draws=...) (the PSNR experiment's "engine on torch's draws" arm): feeding the engine the numbers
     nerfhip_rng_fill reports for (seed, stream, element) reproduces the in-kernel Philox step bit for bit."""

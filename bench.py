@@ -322,7 +322,7 @@ def pmc_traffic(cfg, n, kind):
     kname = "k_wgrad" if kind == "wgrad" else "k_mlp_%s16" % kind
     mine = lib_sources_sha16()
     stale = None
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         for fn in ("%s_pmc_summary_%s.json" % (rnd, tag), "%s_pmc_summary.json" % rnd):
             path = os.path.join(ROOT, "profiles", fn)
             if not os.path.exists(path) or (fn.endswith("summary.json") and (cfg != MODEL or n != RAYS_PER_GPU)):

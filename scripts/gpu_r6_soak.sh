@@ -1,7 +1,8 @@
 #!/bin/bash
 # gpurun --timeout 3300 -- "bash scripts/gpu_r6_soak.sh"
 # Round 6: (a) the GPU suite + smoke on the build, (b) the 20 000-iteration soak of VERDICT r5 item 2 on it (scripts/psnr_soak.py):
-# two seeds x {f16x3_train, fp32} with the compacted backward, and the f16x3_train arm with the dense backward.
+# two seeds x {f16x3_train, fp32} with the compacted backward (the f16x3_train arm in its stash-recomputing form, SOAK_F16_MODE), and the
+# f16x3_train arm with the dense backward.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out/r06_soak
 R=$GRAFT_REPO_ROOT/gpurun_out/r06_soak
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
@@ -14,8 +15,10 @@ timeout 300 python scripts/psnr_soak.py 9 40 $R/preflight.json --arms engine_f16
 rc=$?; echo "preflight rc=$rc"; tail -3 $R/preflight.log
 if [ $rc -ne 0 ]; then tail -30 $R/preflight.log; exit 1; fi
 for seed in 1 2; do
-  timeout 700 python scripts/psnr_soak.py $seed $ITERS $R/soak_compact_seed$seed.json --arms engine_f16tr,engine --compact > $R/soak_compact_seed$seed.log 2>&1
-  echo "compact soak seed $seed rc=$?"; grep "val_psnr" $R/soak_compact_seed$seed.log | tail -2
+  timeout 400 python scripts/psnr_soak.py $seed $ITERS $R/soak_compact_seed$seed.json --arms engine --compact > $R/soak_compact_seed$seed.log 2>&1
+  echo "compact fp32 soak seed $seed rc=$?"; grep "val_psnr" $R/soak_compact_seed$seed.log | tail -1
+  timeout 300 python scripts/psnr_soak.py $seed $ITERS $R/soak_${SOAK_F16_MODE:-recompute}_seed$seed.json --arms engine_f16tr --compact ${SOAK_F16_MODE:-recompute} > $R/soak_${SOAK_F16_MODE:-recompute}_seed$seed.log 2>&1
+  echo "${SOAK_F16_MODE:-recompute} f16x3 soak seed $seed rc=$?"; grep "val_psnr" $R/soak_${SOAK_F16_MODE:-recompute}_seed$seed.log | tail -1
   timeout 500 python scripts/psnr_soak.py $seed $ITERS $R/soak_dense_seed$seed.json --arms engine_f16tr > $R/soak_dense_seed$seed.log 2>&1
   echo "dense f16x3 soak seed $seed rc=$?"; grep "val_psnr" $R/soak_dense_seed$seed.log | tail -1
 done

@@ -510,6 +510,9 @@ def case_render_compacted(b, cfg, n, nc, nf, precision=0, seed=9, white=False, n
             kept, tot = r["bwd_kept_" + name]
             assert tot == total and 0 < kept < total, (mode, name, kept, tot)
             assert r["bwd_kept_" + name] == res[True]["bwd_kept_" + name]
+            # (mode 2 differs from mode 1 only in WHERE the kept samples' stash rows sit: same list, same rows, same tile ranges --
+            # the same gradient bit for bit)
+            assert np.array_equal(r[key], res[True][key]), ("recomputed vs compacted", key)
             gd, gk = b.unflatten(plan, dense[key]), b.unflatten(plan, r[key])
             worst = 0.0
             for k in gd:
@@ -891,12 +894,16 @@ def case_render_f16x3(b, cfg, n, nc, nf, seed=5, white=False, noise=0.0, tag="",
     assert rec["rgb_fine_f16x3_rays_over_1e-4"] <= 2 * rec["rgb_fine_fp32_rays_over_1e-4"] + 1, rec
 
 
-def case_ray_grad(b, cfg, n=24, nc=16, nf=16, seed=61, white=False, noise=0.0):
+def case_ray_grad(b, cfg, n=24, nc=16, nf=16, seed=61, white=False, noise=0.0, compact=False):
     """nerfhip_render_bwd_rays: d(loss)/d(rays) -- origin, direction and viewdirs columns -- against the oracle's autograd
-    (nerf/train_utils.py:67,107: pts = ro + rd * z;  nerf/volume_rendering_utils.py:24: dists * ||rd||)."""
+    (nerf/train_utils.py:67,107: pts = ro + rd * z;  nerf/volume_rendering_utils.py:24: dists * ||rd||).
+    compact (True / "recompute"): the same with both plans' backward compacted -- the d(pre-activation) images the input gradient
+    is formed from are then in list order, and the samples the list dropped contribute exactly nothing."""
     gen = rng(seed)
     pc, par_c, flat_c, packed_c = mlp_setup(b, cfg, seed=seed + 1)
     pf, par_f, flat_f, packed_f = mlp_setup(b, cfg, seed=seed + 2)
+    b.set_compaction(pc, compact)
+    b.set_compaction(pf, compact)
     ro = torch.tensor([0.2, -0.1, 4.0]).expand(n, 3) + 0.05 * torch.randn(n, 3, generator=gen)
     rd = torch.randn(n, 3, generator=gen) * 0.3
     rd[:, 2] = -1.0
@@ -935,7 +942,7 @@ def case_ray_grad(b, cfg, n=24, nc=16, nf=16, seed=61, white=False, noise=0.0):
                          yard_over=int((e_yard > 2e-3).sum()), hip_max=float(e_hip.max()), yard_max=float(e_yard.max()))
         assert np.median(e_hip) <= 3.0 * np.median(e_yard) + 2e-6, (what, rec[what])
         assert (e_hip > 2e-3).sum() <= 2 * (e_yard > 2e-3).sum() + 3, (what, rec[what])
-    note("ray_grad_%dx%d_n%d_%s" % (cfg["num_layers"], cfg["hidden_size"], n, b.name), **{"%s_%s" % (w_, k): v for w_, d in rec.items()
+    note("ray_grad_%dx%d_n%d%s_%s" % (cfg["num_layers"], cfg["hidden_size"], n, "_%s" % compact if compact else "", b.name), **{"%s_%s" % (w_, k): v for w_, d in rec.items()
                                                                                             for k, v in d.items()})
     assert np.all(got[:, 6:8] == 0.0)
     b.lib.plan_destroy(pc)

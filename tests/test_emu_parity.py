@@ -127,6 +127,9 @@ def test_render_backward_modes_dense_compacted_recomputed(emu):
     P.case_render_compacted(emu, P.MLP_GEOMETRIES["llff4x64_skip3_L6"], n=9, nc=16, nf=16, tag="llff64_emu", white=True)
     P.case_render_compacted(emu, P.MLP_GEOMETRIES["default4x128"], n=10, nc=16, nf=16, precision=P.F16X3_TRAIN, tag="4x128_emu")
     P.case_render_compacted(emu, P.MLP_GEOMETRIES["novw4x128"], n=9, nc=16, nf=8, precision=P.F16X3_FWD_DGRAD, tag="novw_emu")
+    # ... and d(loss)/d(rays) through the compacted images (nerfhip_render_bwd_rays), both modes
+    P.case_ray_grad(emu, P.MLP_GEOMETRIES["default4x128"], n=12, nc=8, nf=8, compact=True)
+    P.case_ray_grad(emu, P.MLP_GEOMETRIES["default4x128"], n=12, nc=8, nf=8, compact="recompute")
 
 
 def test_f16x3_scale_fuzz(emu):

@@ -262,6 +262,9 @@ def test_ray_gradients_c_abi(gpu):
     P.case_ray_grad(gpu, P.MLP_GEOMETRIES["northstar8x256"], n=64, nc=32, nf=32, noise=0.2)
     P.case_ray_grad(gpu, P.MLP_GEOMETRIES["novw3x64_skip1"], n=100, white=True, noise=0.5)
     P.case_ray_grad(gpu, P.MLP_GEOMETRIES["wide2x320"], n=40)
+    # (round 6: through the compacted d(pre-activation) images, both modes)
+    P.case_ray_grad(gpu, P.MLP_GEOMETRIES["default4x128"], n=300, nc=64, nf=64, compact=True)
+    P.case_ray_grad(gpu, P.MLP_GEOMETRIES["northstar8x256"], n=64, nc=32, nf=32, noise=0.2, compact="recompute")
 
 
 def test_internal_rng_equals_external_draws(gpu):

@@ -40,6 +40,9 @@ NC, NF, RAYS = 64, 128, 4096
 STUDENT = dict(num_layers=8, hidden_size=256, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4)
 
 
+OVERLAP = None  # (--overlap: the engine's two-stream step; None = its default for the net width)
+
+
 def make_engine(state_c, state_f, precision, compact, lr, seed):
     """compact: False / True / "recompute" (set on both models) or "auto" (TrainEngine(backward="auto"))."""
     mc, mf = N.FlexibleNeRFModel(**STUDENT), N.FlexibleNeRFModel(**STUDENT)
@@ -54,7 +57,7 @@ def make_engine(state_c, state_f, precision, compact, lr, seed):
         mc.set_backward_compaction(compact)
         mf.set_backward_compaction(compact)
     eng = N.TrainEngine(mc, mf, NC, NF, perturb=True, white_background=True, noise_std=0.2, lr=lr, seed=seed,
-                        backward="auto" if compact == "auto" else None)
+                        backward="auto" if compact == "auto" else None, overlap=OVERLAP)
     return mc, mf, eng
 
 
@@ -91,14 +94,19 @@ if __name__ == "__main__":
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--save-weights", default=None, help="keep the trained weights (a torch file) for later calls")
     ap.add_argument("--load-weights", default=None, help="skip the training: start from a file written by --save-weights (profiler runs)")
+    ap.add_argument("--hidden", type=int, default=256, help="hidden_size of the students (128 with --layers 4: the nets train_nerf.py:117-134 really builds)")
+    ap.add_argument("--layers", type=int, default=8)
+    ap.add_argument("--overlap", type=int, default=-1, help="1: two-stream step (coarse backward next to the fine pass), 0: one stream, -1: the engine's default")
     ap.add_argument("--arms", default=None, help="comma-separated subset of the arms, e.g. f16x3_train_compacted (default: all six)")
     a = ap.parse_args()
+    OVERLAP = None if a.overlap < 0 else bool(a.overlap)
+    STUDENT.update(num_layers=a.layers, hidden_size=a.hidden)
     lib = L.get_lib()
     poses, imgs, train, val = P4.teacher_dataset()
     opts = N.make_options(NC, NF, white_background=True)
     res = dict(scene="teacher scene of scripts/psnr400.py: 400x400 lego views rendered from the reference's lego-lowres weights, white background",
-               student="8x256 coarse + fine", rays_per_step=RAYS, samples="64 + 128", pretrain_iters=a.iters, lr0=a.lr, steps=a.steps,
-               warmup=a.warmup, lib_version=lib.version(), arms={})
+               student="%dx%d coarse + fine" % (a.layers, a.hidden), rays_per_step=RAYS, samples="64 + 128", pretrain_iters=a.iters, lr0=a.lr, steps=a.steps,
+               warmup=a.warmup, lib_version=lib.version(), two_stream_step=OVERLAP, arms={})
     if a.load_weights:
         saved = torch.load(a.load_weights)
         state_c, state_f = saved["coarse"], saved["fine"]

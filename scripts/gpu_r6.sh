@@ -6,6 +6,7 @@
 #   prof     rocprofv3 --kernel-trace --stats: the default line; the trained-regime arms dense / compacted / recomputed (weights of `trained`)
 #   pmc      PMC passes (SQ / FETCH_SIZE / WRITE_SIZE, each its own run) of the default line and of the trained-regime arms
 #   ab       dense vs compacted on the default workload (0 % zero rows: what the gather costs)
+#   trained_more  bench_trained.py with the two-stream step, and on the 4x128 nets
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out/r06
 R=$GRAFT_REPO_ROOT/gpurun_out/r06
 W=$R/trained_weights.pt
@@ -39,6 +40,9 @@ bench)
   timeout 900 python bench.py > $R/bench.log 2>&1; echo "bench rc=$?"; line $R/bench.log ;;
 trained)
   timeout 500 python scripts/bench_trained.py $R/bench_trained.json --iters 2000 --save-weights $W > $R/bench_trained.log 2>&1; echo "trained rc=$?"; tail -8 $R/bench_trained.log ;;
+trained_more)   # the two-stream step in the compacted modes; the 4x128 nets train_nerf.py really builds
+  timeout 400 python scripts/bench_trained.py $R/bench_trained_overlap1.json --iters 2000 --overlap 1 --arms fp32_compacted,f16x3_train_compacted,f16x3_train_recomputed,f16x3_train_dense > $R/bench_trained_overlap1.log 2>&1; tail -5 $R/bench_trained_overlap1.log
+  timeout 400 python scripts/bench_trained.py $R/bench_trained_4x128.json --iters 2000 --hidden 128 --layers 4 > $R/bench_trained_4x128.log 2>&1; tail -9 $R/bench_trained_4x128.log ;;
 ab)
   for a in "" "--compact" "--compact recompute" "--precision f16x3_train" "--precision f16x3_train --compact" "--precision f16x3_train --compact recompute"; do
     t=$(echo $a | tr -d " -"); timeout 150 python bench.py --no-cpu-baseline --no-labelled-lines $a > $R/ab_$t.log 2>&1; line $R/ab_$t.log

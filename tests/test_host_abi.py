@@ -222,6 +222,29 @@ def test_product_reads_no_environment_and_ships_one_kernel_set():
         "pack_f16.hip", "render.hip", "sample.hip", "wgrad.hip", "wgrad_f16.hip"]
 
 
+def test_backward_mode_thresholds_and_option_plumbing():
+    """TrainEngine(backward="auto") (round 6): the mode a net's next step runs in, from the zero-cotangent fraction its last compacted
+    step reported -- dense while nothing is known or too little is dropped to pay for the gather; fp32 plans never the recomputing
+    mode (a second fp32 forward over the kept samples costs more than the stash stream it saves); fp16-piece plans recompute from
+    72 % dropped rows.  And the C-ABI option round-trips through the plan (no GPU needed: plans are host objects)."""
+    from nerf_pytorch_amd.engine import TrainEngine as E
+    assert [E._mode_for(f, False) for f in (None, 0.0, 0.10, 0.15, 0.5, 0.99)] == [0, 0, 0, 1, 1, 1]
+    assert [E._mode_for(f, True) for f in (None, 0.0, 0.04, 0.05, 0.5, 0.71, 0.72, 0.99)] == [0, 0, 0, 1, 1, 1, 2, 2]
+    lib = L.bind(L.LIB_PATH)
+    cfg = L.ModelCfg(4, 128, 4, 10, 4, 1, 1, 1, 1, 1)
+    plan = lib.plan_create(C.byref(cfg))
+    assert plan and lib.plan_bwd_compaction(plan) == 0
+    for mode in (1, 2, 0):
+        lib.plan_set_bwd_compaction(plan, mode)
+        assert lib.plan_bwd_compaction(plan) == mode
+    with pytest.raises(L.NerfHipError, match="0 \\(dense\\), 1 \\(compacted\\) or 2"):
+        lib.plan_set_bwd_compaction(plan, 3)
+    # the statistics words sit inside the backward scratch, behind everything the dense backward uses
+    off, total = lib.plan_bwd_stats_offset(plan, 4096), lib.plan_bwd_scratch_bytes(plan, 4096)
+    assert 0 < off < total and off % 4 == 0 and total - off >= 4 * (16 + 4096)
+    lib.plan_destroy(plan)
+
+
 def test_tolerance_table_holds_every_arithmetic_to_the_same_bounds():
     """the fp16-piece plans are held to the fp32 kernels' bounds -- the table has no per-arithmetic entry for an
     fp32-grade arithmetic, and the full-batch GPU tests select no bound (and no assertion) by arithmetic."""

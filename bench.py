@@ -270,6 +270,10 @@ def self_launch(n, argv):
 
 
 def kernel_kind(name):
+    if "k_bwd64r_reduce" in name:
+        return None
+    if "k_bwd64r" in name:
+        return "bwd64r"       # (--compact fused / fused_compact: forward recomputed + data gradient + weight gradient, one kernel)
     if "k_mlp_fwd" in name:
         return "fwd"
     if "k_mlp_dgrad" in name:
@@ -394,7 +398,7 @@ def main():
                          "forward; --mode train --precision f16x3_fwd the training forward, f16x3_fwd_dgrad + the data-gradient chain, "
                          "f16x3_train + the large weight-gradient blocks.  A+B: coarse net A, fine net B.  Separate, labelled lines: "
                          "the driver's default stays fp32")
-    ap.add_argument("--compact", nargs="?", const="gather", default=None, choices=("gather", "recompute", "auto"),
+    ap.add_argument("--compact", nargs="?", const="gather", default=None, choices=("gather", "recompute", "fused", "fused_compact", "auto"),
                     help="train: compacted backward (FlexibleNeRFModel.set_backward_compaction): data and weight gradient over the sample "
                          "points whose d(loss)/d(raw) row is not all zero; `recompute`: additionally a stash-free training forward, the "
                          "backward re-runs the forward for the kept samples; `auto`: TrainEngine(backward='auto') picks dense / compacted / recomputed per net "
@@ -485,9 +489,10 @@ def main():
             mc.set_training_precision(prec_c)
         if prec_f != "fp32":
             mf.set_training_precision(prec_f)
-        if args.compact in ("gather", "recompute"):
-            mc.set_backward_compaction("recompute" if args.compact == "recompute" else True)
-            mf.set_backward_compaction("recompute" if args.compact == "recompute" else True)
+        if args.compact in ("gather", "recompute", "fused", "fused_compact"):
+            # (fused / fused_compact: the one-kernel backward of 64-wide fp32 nets, csrc/mlp64r.hip -- raises for other geometries)
+            mc.set_backward_compaction(True if args.compact == "gather" else args.compact)
+            mf.set_backward_compaction(True if args.compact == "gather" else args.compact)
         strong = args.global_rays > 0
         if strong:
             lo, hi = N.parallel.shard_bounds(args.global_rays, rank, world)
@@ -570,7 +575,7 @@ def main():
     eff_compact = args.compact
     if args.mode == "train" and args.compact == "auto":
         modes = [m.backward_compaction for m in (mc, mf)]
-        eff_compact = "recompute" if 2 in modes else ("gather" if 1 in modes else None)
+        eff_compact = ("fused_compact" if 4 in modes else "fused" if 3 in modes else "recompute" if 2 in modes else ("gather" if 1 in modes else None))
     # What the per-launch HIP events of the timed region cost: the same K steps once more WITHOUT them (N = 1 only).  Nothing at
     # 27 ms per step; 0.28 ms of a 2.0-ms fern step (a step is ~40 launches, each with two event records on the host's path).
     unprofiled = None
@@ -624,11 +629,18 @@ def main():
             kept_f = kept["fine"][0] if kept["fine"] else m_f
         for m, mb, prec in ((m_c, kept_c, prec_c), (m_f, kept_f, prec_f)):
             fmt, level = precision_level(prec)
-            if args.mode == "train" and eff_compact == "recompute":  # (stash-free pass over all samples + a stash-writing pass over the kept ones)
+            if args.mode == "train" and eff_compact in ("fused", "fused_compact"):
+                add("fwd", "fp32", 2.0 * fwd_macs * m, 20 * m)   # (stash-free)
+            elif args.mode == "train" and eff_compact == "recompute":  # (stash-free pass over all samples + a stash-writing pass over the kept ones)
                 add("fwd", fmt if level >= 1 else "fp32", 2.0 * fwd_macs * (m + mb), 20 * m + stash_b * mb, 2)
             else:
                 add("fwd", fmt if level >= 1 else "fp32", 2.0 * fwd_macs * m, stash_b * m)
             if args.mode != "train":
+                continue
+            if eff_compact in ("fused", "fused_compact"):
+                # the stash-free forward above; then ONE kernel: the forward again, the data gradient, the weight gradient -- executed
+                # FLOPs; it reads a sample's depth, ray and d(raw) row and writes one partial per workgroup
+                add("bwd64r", "fp32", 2.0 * (2 * fwd_macs + dgrad_macs) * mb, 40 * mb)
                 continue
             add("dgrad", fmt if level >= 3 else "fp32", 2.0 * dgrad_macs * mb, dgrad_b * mb)
             if level == 4 and 64 < Wd <= 256:
@@ -656,8 +668,8 @@ def main():
             tf = fl / (ms_step * 1e-3) / 1e12
             gb = by / 1e9
             ghz = None
-            if fam == "fp32" and kind in ("fwd", "dgrad", "wgrad", "wgrad_thin"):
-                cyc, ticks = (int(clk[3 * {"fwd": 0, "dgrad": 1}.get(kind, 2) + c]) for c in range(2))
+            if fam == "fp32" and kind in ("fwd", "dgrad", "wgrad", "wgrad_thin", "bwd64r"):
+                cyc, ticks = (int(clk[3 * {"fwd": 0, "dgrad": 1, "bwd64r": 1}.get(kind, 2) + c]) for c in range(2))
                 ghz = 0.1 * cyc / ticks if ticks else None
             counter_gb, source = (pmc_traffic(cfg, n, kind) if (args.mode == "train" and args.precision == "fp32" and args.workload == "lego"
                                                                and kind in ("fwd", "dgrad", "wgrad")) else (None, None))
@@ -692,9 +704,11 @@ def main():
                         kernel_ms_per_step={nm: round(m / args.steps, 4) for nm, (_, m) in sorted(kern.items(), key=lambda kv: -kv[1][1])})
         if args.mode == "train":
             total_flops = 2.0 * fwd_macs * (m_c + m_f) + 2.0 * (fwd_macs + dgrad_macs) * (kept_c + kept_f)   # (executed: == algorithmic when dense)
-            if eff_compact == "recompute":
+            if eff_compact in ("recompute", "fused", "fused_compact"):
                 total_flops += 2.0 * fwd_macs * (kept_c + kept_f)
             step_bytes = stash_b * (m_c + m_f) + (dgrad_b + wgrad_b) * (kept_c + kept_f)
+            if eff_compact in ("fused", "fused_compact"):
+                step_bytes = 20 * (m_c + m_f) + 40 * (kept_c + kept_f)
             if args.workload == "lego":
                 workload = ("lego %dx%d synthetic views (BASELINE configs[%d]): %d rays/GPU/iter (%d over all GPUs), %d coarse + %d "
                             "fine samples, %dx%d coarse+fine nets, perturb, noise 0.2, Adam, full iteration"
@@ -743,6 +757,8 @@ def main():
                    final_loss=loss_host, roofline=roof)
         if args.mode == "train":
             res["backward"] = {None: "dense", "gather": "compacted", "recompute": "compacted, stash recomputed for the kept samples",
+                               "fused": "fused (one persistent kernel per net: forward recomputed, data gradient, weight gradient; no stash, no d(pre-activation) images)",
+                               "fused_compact": "fused, over the samples whose d(loss)/d(raw) row is non-zero",
                                "auto": "auto (per net and step: dense / compacted / recomputed by the zero fraction of earlier steps)"}[args.compact]
             if args.compact == "auto":
                 res["backward_modes_used"] = dict(steps_dense_compacted_recomputed=eng.backward_modes_used, last_known_zero_fraction=eng._zero_frac)

@@ -246,7 +246,16 @@ int64_t nerfhip_plan_bwd_scratch_bytes(nerfhip_plan_t plan, int64_t m);
  *           outputs), and the backward, once it has the list, re-runs the forward for the listed samples only, which leaves their
  *           activation rows and ReLU masks in list order -- the weight-gradient kernels then read contiguous blocks.  Pays where most
  *           rows are dropped and the stash-writing forward is much slower than the plain one (the fp16-piece plans: DESIGN.md).
- *           nerfhip_mlp_fwd / nerfhip_mlp_bwd, whose caller owns the stash between the two calls, treat 2 as 1. */
+ *           nerfhip_mlp_fwd / nerfhip_mlp_bwd, whose caller owns the stash between the two calls, treat 2 as 1.
+ *   on = 3  fused (plans with an LDS-resident image only: fp32, hidden_size <= 64, view directions, at most 4 layers none of which is a
+ *           skip layer, num_encoding_fn_xyz <= 10, num_encoding_fn_dir <= 4 -- config/fern.yml, config/llff.yml; other plans:
+ *           NERFHIP_ERR_ARG), inside the fused render entry points: the training forward writes no stash, and ONE persistent kernel per
+ *           net keeps all its weights in LDS, recomputes the forward of 128 sample points at a time, runs the data-gradient chain and
+ *           sums the weight gradients in registers -- no stash, no d(pre-activation) images, no separate weight-gradient kernel; a
+ *           fixed-order reduction of one partial per workgroup follows (no atomics: bit-reproducible).  Every sample is differentiated.
+ *   on = 4  fused over the list: the same kernel walks the samples whose d(raw) row is not all zero (the list of mode 1).
+ *           A render backward that must leave the d(pre-activation) images (nerfhip_render_bwd_rays with g_rays) runs 3 / 4 as 2;
+ *           nerfhip_mlp_fwd / nerfhip_mlp_bwd treat them as 1. */
 int nerfhip_plan_set_bwd_compaction(nerfhip_plan_t plan, int on);
 int nerfhip_plan_bwd_compaction(nerfhip_plan_t plan);
 /* Byte offset, inside a backward scratch for m sample points, of int32[2] = {samples the last compacted backward kept, samples of

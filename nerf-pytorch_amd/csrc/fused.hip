@@ -244,7 +244,7 @@ extern "C" int nerfhip_render_bwd_rays(nerfhip_plan_t pc, nerfhip_plan_t pf, con
             memset(&in, 0, sizeof(in));
             in.mode = 1, in.rays = rays, in.ray_stride = stride, in.z = (const float*)(ws + w.z_f), in.S = sf;
             rc = nh_mlp_backward_recompute(pf, packed_f, in, g_raw, n * sf, (float*)(ws + w.stash_f), (float*)(ws + w.scratch_f),
-                                           w.scratch_f_bytes, g_params_f, stream);
+                                           w.scratch_f_bytes, g_params_f, g_rays != nullptr, stream);
         } else {
             rc = nh_mlp_backward(pf, packed_f, g_raw, n * sf, (const float*)(ws + w.stash_f), (float*)(ws + w.scratch_f),
                                  w.scratch_f_bytes, g_params_f, stream);
@@ -271,7 +271,7 @@ extern "C" int nerfhip_render_bwd_rays(nerfhip_plan_t pc, nerfhip_plan_t pf, con
             memset(&in, 0, sizeof(in));
             in.mode = 1, in.rays = rays, in.ray_stride = stride, in.z = (const float*)(ws + w.z_c), in.S = nc;
             rc = nh_mlp_backward_recompute(pc, packed_c, in, g_raw, n * nc, (float*)(ws + w.stash_c), (float*)(ws + w.scratch_c),
-                                           w.scratch_c_bytes, g_params_c, stream);
+                                           w.scratch_c_bytes, g_params_c, g_rays != nullptr, stream);
         } else {
             rc = nh_mlp_backward(pc, packed_c, g_raw, n * nc, (const float*)(ws + w.stash_c), (float*)(ws + w.scratch_c),
                                  w.scratch_c_bytes, g_params_c, stream);

@@ -5,6 +5,7 @@
 #include <stdlib.h>
 
 #include "nh_mlp.h"
+#include "nh_r64.h"
 
 namespace {
 
@@ -75,14 +76,19 @@ static int64_t gscale_word_offset(nerfhip_plan* p, int64_t nt) {
 }
 // (... then the sample list of a compacted backward, compact.hip: reserved whether or not the plan's option is on)
 static int64_t compact_word_offset(nerfhip_plan* p, int64_t nt) { return gscale_word_offset(p, nt) + NH_RMAX_WORDS; }
+// (... then, plans with a resident image: one partial gradient per workgroup of the fused backward, mlp64r.hip)
+static int64_t fused_partial_offset(nerfhip_plan* p, int64_t nt) { return compact_word_offset(p, nt) + nh_compact_ints(nt * 32); }
 int64_t nh_mlp_bwd_scratch_bytes(nerfhip_plan* p, int64_t M) {
     const int64_t nt = nh_ceil_div(M, 128) * 4;
-    return (compact_word_offset(p, nt) + nh_compact_ints(nt * 32)) * (int64_t)sizeof(float);
+    return (fused_partial_offset(p, nt) + nh_mlp64r_partial_floats(p, M)) * (int64_t)sizeof(float);
 }
 // A backward over M sample points runs compacted when the plan asks for it and a gathered row's byte offset inside a region (at most
 // 256 rows of 4 bytes per sample) fits the 32-bit offset of a buffer instruction; otherwise it runs dense.
-static bool compacts(const nerfhip_plan* p, int64_t M) { return p->bwd_compact != 0 && nh_ceil_div(M, 128) * 128 * 1024 < ((int64_t)1 << 32); }
-bool nh_mlp_recomputes(const nerfhip_plan* p, int64_t M) { return p->bwd_compact == 2 && compacts(p, M) && nh_prec_level(p->precision) != 1; }
+// (the fused modes 3 / 4 leave no d(pre-activation) images: whoever needs them -- the ray gradient, nerfhip_mlp_bwd with a stash of its
+// caller -- gets mode 2's data flow)
+static int image_mode(const nerfhip_plan* p) { return p->bwd_compact >= 3 ? 2 : p->bwd_compact; }
+static bool compacts(const nerfhip_plan* p, int64_t M) { return image_mode(p) != 0 && nh_ceil_div(M, 128) * 128 * 1024 < ((int64_t)1 << 32); }
+bool nh_mlp_recomputes(const nerfhip_plan* p, int64_t M) { return image_mode(p) == 2 && compacts(p, M) && nh_prec_level(p->precision) != 1; }
 
 static int mlp_forward_any(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
                            nerfhip_stream_t stream, const NhCompact* list);
@@ -113,7 +119,7 @@ static int mlp_forward_any(nerfhip_plan* p, const float* packed, const NhMlpInpu
 
 // `recompute`: the forward of this launch wrote no stash (nh_mlp_recomputes); `in` names its input again
 static int mlp_backward_any(nerfhip_plan* p, const float* packed, const NhMlpInput* recompute, const float* g_out, int64_t M, float* stash,
-                            float* scratch, int64_t scratch_bytes, float* g_params, nerfhip_stream_t stream) {
+                            float* scratch, int64_t scratch_bytes, float* g_params, bool need_images, nerfhip_stream_t stream) {
     NH_REQUIRE(p && packed && g_out && stash && scratch && g_params && M > 0, "mlp_bwd: bad arguments");
     NH_REQUIRE(nh_prec_level(p->precision) != 1, "mlp_bwd: an f16x3 plan is inference-only");
     NH_REQUIRE(scratch_bytes >= nh_mlp_bwd_scratch_bytes(p, M), "mlp_bwd: scratch too small (%lld < %lld)",
@@ -121,6 +127,18 @@ static int mlp_backward_any(nerfhip_plan* p, const float* packed, const NhMlpInp
     const int64_t nt = nh_ceil_div(M, 128) * 4;
     const bool bdg = nh_prec_level(p->precision) >= 3;
     int rc = NERFHIP_OK;
+    if (recompute && p->bwd_compact >= 3 && p->r64_off >= 0 && !need_images) {
+        // the fused backward (mlp64r.hip): forward recomputed, data gradient and weight gradient in one kernel; mode 4 walks the list
+        NhCompact lview;
+        const NhCompact* lx = nullptr;
+        if (p->bwd_compact == 4) {
+            lview = nh_compact_view((int*)(scratch + compact_word_offset(p, nt)), nt * 32);
+            rc = nh_compact_build(g_out, M, lview, stream);
+            if (rc) return rc;
+            lx = &lview;
+        }
+        return nh_mlp64r_backward(p, packed, *recompute, g_out, M, scratch + fused_partial_offset(p, nt), g_params, lx, stream);
+    }
     // compacted backward: list the samples whose d(raw output) row is not all zero; every kernel below then walks that list
     NhCompact cview;
     const NhCompact* cx = nullptr;
@@ -163,17 +181,20 @@ static int mlp_backward_any(nerfhip_plan* p, const float* packed, const NhMlpInp
 
 int nh_mlp_backward(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash,
                     float* scratch, int64_t scratch_bytes, float* g_params, nerfhip_stream_t stream) {
-    return mlp_backward_any(p, packed, nullptr, g_out, M, (float*)stash, scratch, scratch_bytes, g_params, stream);
+    return mlp_backward_any(p, packed, nullptr, g_out, M, (float*)stash, scratch, scratch_bytes, g_params, true, stream);
 }
 
 int nh_mlp_backward_recompute(nerfhip_plan* p, const float* packed, const NhMlpInput& in, const float* g_out, int64_t M, float* stash,
-                              float* scratch, int64_t scratch_bytes, float* g_params, nerfhip_stream_t stream) {
-    return mlp_backward_any(p, packed, &in, g_out, M, stash, scratch, scratch_bytes, g_params, stream);
+                              float* scratch, int64_t scratch_bytes, float* g_params, bool need_images, nerfhip_stream_t stream) {
+    return mlp_backward_any(p, packed, &in, g_out, M, stash, scratch, scratch_bytes, g_params, need_images, stream);
 }
 
 extern "C" int nerfhip_plan_set_bwd_compaction(nerfhip_plan_t plan, int on) {
     NH_REQUIRE(plan, "plan_set_bwd_compaction: plan is NULL");
-    NH_REQUIRE(on >= 0 && on <= 2, "plan_set_bwd_compaction: 0 (dense), 1 (compacted) or 2 (compacted, the render path recomputes the stash)");
+    NH_REQUIRE(on >= 0 && on <= 4, "plan_set_bwd_compaction: 0 (dense), 1 (compacted), 2 (compacted, the render path recomputes the stash), "
+               "3 (the fused backward of 64-wide nets) or 4 (the fused backward over the compacted list)");
+    NH_REQUIRE(on < 3 || plan->r64_off >= 0, "plan_set_bwd_compaction: the fused backward (3, 4) exists for fp32 plans of hidden_size <= 64 with view "
+               "directions, at most 4 layers, no skip layer and num_encoding_fn_xyz <= 10 / num_encoding_fn_dir <= 4");
     plan->bwd_compact = on;
     return NERFHIP_OK;
 }

@@ -35,8 +35,10 @@ int nh_mlp_backward(nerfhip_plan* p, const float* packed, const float* g_out, in
                     float* scratch, int64_t scratch_bytes, float* g_params, nerfhip_stream_t stream);
 // plans with bwd_compact == 2 inside the fused render: the forward over `in` wrote no stash; lists the samples with a non-zero
 // d(raw output) row, re-runs the forward for them (writing `stash` in list order) and differentiates those
+// need_images: the caller reads the d(pre-activation) images afterwards (the ray gradient): a plan in a fused mode (3 / 4: mlp64r.hip
+// leaves none) then runs as mode 2
 int nh_mlp_backward_recompute(nerfhip_plan* p, const float* packed, const NhMlpInput& in, const float* g_out, int64_t M, float* stash,
-                              float* scratch, int64_t scratch_bytes, float* g_params, nerfhip_stream_t stream);
+                              float* scratch, int64_t scratch_bytes, float* g_params, bool need_images, nerfhip_stream_t stream);
 int64_t nh_mlp_bwd_scratch_bytes(nerfhip_plan* p, int64_t M);
 // a backward over M sample points of this plan re-runs its forward (bwd_compact == 2 and the launch compacts at all)
 bool nh_mlp_recomputes(const nerfhip_plan* p, int64_t M);
@@ -49,6 +51,12 @@ int nh_mlp16_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in,
 // (cx: the compacted backward's sample list, or NULL -- here and in every backward kernel below)
 int nh_mlp16_dgrad(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash, float* scratch,
                    const NhCompact* cx, nerfhip_stream_t stream);
+
+// mlp64r.hip: the fused, stash-free backward of 64-wide nets with an LDS-resident image (nh_r64.h): forward recomputed, data
+// gradient and weight gradient in one persistent kernel + a fixed-order reduction of one partial per workgroup
+int64_t nh_mlp64r_partial_floats(const nerfhip_plan* p, int64_t M);
+int nh_mlp64r_backward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, const float* g_out, int64_t M, float* partial,
+                       float* g_params, const NhCompact* cx, nerfhip_stream_t stream);
 
 // mlp_f16w.hip: forward (with / without stash) and data-gradient chain of the fp16-piece plans: two waves per SIMD, 16-sample waves on
 // v_mfma_f32_16x16x32_f16; rmax (level-4 plans): NH_RMAX_WORDS zeroed device words for the region maxima, or NULL

@@ -188,8 +188,11 @@ struct nerfhip_plan {
     int wgrad_waves;         // waves per workgroup of the weight-gradient kernel: 8 (256- and 512-wide nets) or 4 (narrower)
     // nerfhip_plan_set_bwd_compaction: 0 dense; 1 the backward drops the samples whose d(raw output) row is zero (list + gathered stash
     // rows); 2 the same, and inside the fused render the training forward writes NO stash -- the backward re-runs the forward for the
-    // listed samples only and leaves a compacted stash (no gather in the weight-gradient kernels)
+    // listed samples only and leaves a compacted stash (no gather in the weight-gradient kernels); 3 / 4 (plans with a resident image,
+    // nh_r64.h, inside the fused render): the stash-free forward and ONE fused backward kernel over every sample (3) / over the list (4)
     int bwd_compact = 0;
+    // float offset, inside the packed buffer, of the LDS-resident image of the fused backward for 64-wide nets (nh_r64.h), or -1
+    int64_t r64_off = -1;
     bool is_skip(int i) const { return i % skip == 0 && i > 0; }
 };
 // floats of a training stash of `tiles` 32-sample tiles: the row regions, then the ReLU masks (the region maxima follow)

@@ -7,6 +7,7 @@
 #include "nh_host.h"
 #include "nh_mlp.h"
 #include "nh_plan.h"
+#include "nh_r64.h"
 
 namespace {
 
@@ -415,6 +416,46 @@ void layout_packed_b(nerfhip_plan* p, int64_t base) {
     p->packed_floats = off;
 }
 
+// the resident image of the fused 64-wide backward (nh_r64.h): row-major matrices, k column = nh_feat16(r, g) of the input register,
+// 16-byte chunks swizzled with the row (r64_pos)
+void fill_r64(const nerfhip_plan* p, int32_t* table) {
+    const R64Layout Y = r64_layout(p->L);
+    int32_t* img = table + p->r64_off;
+    for (int i = 0; i < Y.image_floats; ++i) img[i] = -1;
+    const int H = p->H, H2 = H / 2, Dx = p->Dx, Dd = p->Dd;
+    auto T = [p](int idx) { return p->tensors[idx]; };
+    // slot register (r, g) of k column kc
+    auto slot_r = [](int kc) { return 4 * (kc >> 4) + (kc & 3); };
+    auto slot_g = [](int kc) { return (kc >> 2) & 3; };
+    for (int o = 0; o < H; ++o) {
+        for (int kc = 0; kc < 64; ++kc) {
+            const int c = p->xyz_col16[slot_g(kc)][slot_r(kc)];
+            if (c >= 0) img[Y.l1 + o * R64_S + r64_pos(o, kc)] = (int32_t)(T(p->t_layer1_w).off + (int64_t)o * Dx + c);
+        }
+        img[Y.b_l1 + o] = (int32_t)(T(p->t_layer1_b).off + o);
+        for (int i = 0; i < p->L - 1; ++i) {
+            for (int k = 0; k < H; ++k) img[Y.xyz[i] + o * R64_S + r64_pos(o, k)] = (int32_t)(T(p->t_xyz_w[i]).off + (int64_t)o * H + k);
+            img[Y.b_xyz[i] + o] = (int32_t)(T(p->t_xyz_b[i]).off + o);
+        }
+        for (int k = 0; k < H; ++k) img[Y.head + o * R64_S + r64_pos(o, k)] = (int32_t)(T(p->t_feat_w).off + (int64_t)o * H + k);
+        img[Y.b_feat + o] = (int32_t)(T(p->t_feat_b).off + o);
+    }
+    for (int k = 0; k < H; ++k) img[Y.head + 64 * R64_S + r64_pos(64, k)] = (int32_t)(T(p->t_alpha_w).off + k);
+    img[Y.b_alpha] = (int32_t)T(p->t_alpha_b).off;
+    for (int o = 0; o < H2; ++o) {
+        for (int k = 0; k < H; ++k) img[Y.dir + o * R64_SD + r64_pos(o, k)] = (int32_t)(T(p->t_dir_w).off + (int64_t)o * (H + Dd) + k);
+        for (int kc = 0; kc < 32; ++kc) {
+            const int c = p->dir_col16[slot_g(kc)][slot_r(kc)];
+            if (c >= 0) img[Y.dir + o * R64_SD + 64 + r64_pos(o, kc)] = (int32_t)(T(p->t_dir_w).off + (int64_t)o * (H + Dd) + H + c);
+        }
+        img[Y.b_dir + o] = (int32_t)(T(p->t_dir_b).off + o);
+    }
+    for (int o = 0; o < 3; ++o) {
+        for (int k = 0; k < H2; ++k) img[Y.rgb + o * R64_SR + k] = (int32_t)(T(p->t_rgb_w).off + (int64_t)o * H2 + k);
+        img[Y.b_rgb + o] = (int32_t)(T(p->t_rgb_b).off + o);
+    }
+}
+
 NhRegion add_region(int64_t* total, int rows) {
     NhRegion r;
     r.rows = rows > 256 ? 256 : rows;  // a 512-row activation: two consecutive 256-row regions, named by the first
@@ -808,6 +849,10 @@ static nerfhip_plan_t plan_create_impl(const nerfhip_model_cfg* cfg, int precisi
         layout_packed_b(p, p->packed_floats);
     } else {
         layout_packed(p);
+        if (nh_r64_eligible(p)) {  // the LDS-resident image of the fused backward (mlp64r.hip), behind the layer images
+            p->r64_off = p->packed_floats;
+            p->packed_floats += r64_layout(p->L).image_floats;
+        }
         p->packed32_floats = p->packed_floats;
         memset(&p->pob, 0, sizeof(p->pob));
     }
@@ -877,6 +922,7 @@ extern "C" int nerfhip_plan_pack_index(nerfhip_plan_t plan, int32_t* host_table)
     build_specs16(plan, S16);
     NhPackedOffsets o = plan->po;
     for_each_spec(plan, S16, o, [&](const GemmSpec16& s, int64_t* dst) { fill_spec16(s, *dst, host_table, plan->W); });
+    if (plan->r64_off >= 0) fill_r64(plan, host_table);
     return NERFHIP_OK;
 }
 

@@ -74,19 +74,20 @@ class TrainEngine:
         # backward mode of the step: None -- whatever each model's set_backward_compaction says (default: dense); "dense" / "compact" /
         # "recompute" -- set on both models; "auto" -- chosen per net and per step from the zero-cotangent fraction the previous
         # compacted steps reported (read back asynchronously: no host synchronisation), see _choose_backward_modes
-        if backward not in (None, "dense", "compact", "recompute", "auto"):
-            raise ValueError("backward must be None, 'dense', 'compact', 'recompute' or 'auto' (got %r)" % (backward,))
+        if backward not in (None, "dense", "compact", "recompute", "fused", "fused_compact", "auto"):
+            raise ValueError("backward must be None, 'dense', 'compact', 'recompute', 'fused', 'fused_compact' or 'auto' (got %r)" % (backward,))
         self.backward = backward
         self._zero_frac = {"coarse": None, "fine": None}   # last known fraction of all-zero d(loss)/d(raw) rows per net
         self._stats_host = None
         self._stats_event = None
         self._stats_pending = None
         self._probe_every = 50
-        self.backward_modes_used = {"coarse": [0, 0, 0], "fine": [0, 0, 0]}   # steps run dense / compacted / recomputed per net ("auto")
-        if backward in ("dense", "compact", "recompute"):
+        # steps run dense / compacted / recomputed / fused / fused over the list, per net ("auto")
+        self.backward_modes_used = {"coarse": [0, 0, 0, 0, 0], "fine": [0, 0, 0, 0, 0]}
+        if backward in ("dense", "compact", "recompute", "fused", "fused_compact"):
             for m in (self.mc, self.mf):
                 if m is not None:
-                    m.set_backward_compaction({"dense": False, "compact": True, "recompute": "recompute"}[backward])
+                    m.set_backward_compaction({"dense": False, "compact": True}.get(backward, backward))
         self.t_vals = linspace01(num_coarse, self.dev)
         self.u_det = linspace01(num_fine, self.dev) if num_fine > 0 else None
         self.repack()
@@ -221,8 +222,12 @@ class TrainEngine:
     # A compacted step costs what its gather costs when nothing is dropped (fp32: k_wgrad + 19 %, fp16 pieces + 1 %) and saves the
     # dropped fraction of the data and weight gradient; the recomputing mode additionally trades the stash stream of the forward for a
     # second forward over the kept samples (pays above ~2/3 dropped rows for the fp16-piece plans, never for fp32): DESIGN.md 3.3-3.4.
+    # Nets with a fused backward (fp32, 64 wide: csrc/mlp64r.hip) always run it -- over every sample until the list is known to drop
+    # at least 5 % of them (the list costs two small launches), over the list from there on.
     @staticmethod
-    def _mode_for(frac, f16):
+    def _mode_for(frac, f16, fused=False):
+        if fused:
+            return 4 if (frac is not None and frac >= 0.05) else 3
         if frac is None:
             return 0
         if f16:
@@ -244,18 +249,20 @@ class TrainEngine:
         for name, m in (("coarse", self.mc), ("fine", self.mf)):
             if m is None:
                 continue
-            mode = self._mode_for(self._zero_frac[name], m.training_precision != "fp32")
+            mode = self._mode_for(self._zero_frac[name], m.training_precision != "fp32", m.fused_backward_available())
             if probe and mode == 0:
                 mode = 1
+            if probe and mode == 3:
+                mode = 4
             if m.backward_compaction != mode:
-                m.set_backward_compaction({0: False, 1: True, 2: "recompute"}[mode])
+                m.set_backward_compaction({0: False, 1: True, 2: "recompute", 3: "fused", 4: "fused_compact"}[mode])
             self.backward_modes_used[name][mode] += 1
 
     def _request_backward_stats(self, n):
         """Enqueues the copy of {kept, total} of every net that ran compacted in the step just issued (current stream)."""
         if self._stats_event is not None:
             return  # (the previous request is still in flight)
-        names = [nm for nm, m in (("coarse", self.mc), ("fine", self.mf)) if m is not None and m.backward_compaction]
+        names = [nm for nm, m in (("coarse", self.mc), ("fine", self.mf)) if m is not None and m.backward_compaction in (1, 2, 4)]
         if not names:
             return
         if self._stats_host is None:
@@ -286,7 +293,7 @@ class TrainEngine:
         torch.cuda.synchronize(self.dev)
         words = self._ws.view(torch.int32)
         for name, model, samples in (("coarse", self.mc, self.cfg.num_coarse), ("fine", self.mf, self.cfg.num_coarse + self.cfg.num_fine)):
-            if model is None or not model.backward_compaction:
+            if model is None or model.backward_compaction not in (1, 2, 4):  # (3: the fused backward over every sample builds no list)
                 continue
             off, nb = C.c_int64(), C.c_int64()
             lib.render_workspace_region(self.mc._plan, plan_f, C.byref(self.cfg), n, 1, ("bwd_scratch_" + name).encode(), C.byref(off), C.byref(nb))

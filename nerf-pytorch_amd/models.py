@@ -199,10 +199,30 @@ class FlexibleNeRFModel(torch.nn.Module):
         are unaffected.  Works with every training precision; may be switched between steps.
         on = "recompute" (nerfhip_plan_set_bwd_compaction(plan, 2)): inside the fused render (run_one_iter_of_nerf / TrainEngine) the
         training forward additionally writes no activation stash; the backward re-runs the forward for the samples it keeps.  Pays
-        where most rows are dropped and the stash-writing forward is much slower than the plain one (the fp16-piece plans)."""
-        self.backward_compaction = 2 if on == "recompute" else int(bool(on))
+        where most rows are dropped and the stash-writing forward is much slower than the plain one (the fp16-piece plans).
+        on = "fused" / "fused_compact" (3 / 4; fp32 nets of hidden_size <= 64 with view directions, <= 4 layers, no skip layer --
+        config/fern.yml, config/llff.yml; raises for other geometries): inside the fused render the forward writes no stash and ONE
+        persistent kernel with the whole net resident in LDS recomputes the forward, runs the data-gradient chain and sums the weight
+        gradients (csrc/mlp64r.hip) -- over every sample, or over the samples with a non-zero d(loss)/d(raw) row."""
+        self.backward_compaction = {"recompute": 2, "fused": 3, "fused_compact": 4}.get(on, int(bool(on)))
         L.get_lib().plan_set_bwd_compaction(self._plan, self.backward_compaction)
         return self
+
+    def fused_backward_available(self):
+        """True where set_backward_compaction("fused") works: the plan has an LDS-resident image (csrc/nh_r64.h nh_r64_eligible)."""
+        cached = getattr(self, "_fused_ok", None)
+        if cached is not None and cached[0] is self._plan:
+            return cached[1]
+        lib = L.get_lib()
+        cur = lib.plan_bwd_compaction(self._plan)
+        try:
+            lib.plan_set_bwd_compaction(self._plan, 3)
+            ok = True
+        except L.NerfHipError:
+            ok = False
+        lib.plan_set_bwd_compaction(self._plan, cur)
+        self._fused_ok = (self._plan, ok)
+        return ok
 
     def set_inference_precision(self, precision):
         """Arithmetic of this model's forward passes that no backward follows (torch.no_grad() / mode="validation"):

@@ -475,12 +475,14 @@ def case_mlp_backward_compacted(b, names=None, m=300, precision=0, fractions=(0.
         b.lib.plan_destroy(plan)
 
 
-def case_render_compacted(b, cfg, n, nc, nf, precision=0, seed=9, white=False, noise=0.3, tag=""):
+def case_render_compacted(b, cfg, n, nc, nf, precision=0, seed=9, white=False, noise=0.3, tag="", fused=False):
     """The fused render's backward in its three modes on one batch -- dense, compacted (stash rows gathered), compacted + recomputed
     (nerfhip_plan_set_bwd_compaction(plan, 2): stash-free training forward, the backward re-runs the forward for the listed samples) --
     with the renderer's OWN cotangents: the rows dropped are those relu(sigma + noise) and the transmittance zero
     (nerf/volume_rendering_utils.py:38-42).  Outputs bit-identical in all modes (the stash-free forward is the same kernel without its
-    stores); gradients of both nets within `unit.compact_vs_dense` of the dense ones; kept + dropped = all samples, and some of each."""
+    stores); gradients of both nets within `unit.compact_vs_dense` of the dense ones; kept + dropped = all samples, and some of each.
+    fused: also the two modes of the fused backward of 64-wide nets (3 / 4, csrc/mlp64r.hip: one persistent kernel, no stash, no
+    d(pre-activation) images) -- over every sample, and over the same list."""
     gen = rng(seed)
     pc, par_c, _, packed_c = mlp_setup(b, cfg, seed=seed + 1, precision=precision)
     pf, par_f, _, packed_f = mlp_setup(b, cfg, seed=seed + 2, precision=precision)
@@ -494,7 +496,8 @@ def case_render_compacted(b, cfg, n, nc, nf, precision=0, seed=9, white=False, n
     tgt = torch.rand(n, 3, generator=gen).numpy()
     ctol = TL.bound("unit.compact_vs_dense", ARITH_NAME[precision])
     res = {}
-    for mode in (False, True, "recompute"):
+    modes = (False, True, "recompute") + (("fused", "fused_compact") if fused else ())
+    for mode in modes:
         b.set_compaction(pc, mode)
         b.set_compaction(pf, mode)
         fwd = b.render(pc, pf, packed_c, packed_f, rays, opt, rnp, training=True)
@@ -502,17 +505,19 @@ def case_render_compacted(b, cfg, n, nc, nf, precision=0, seed=9, white=False, n
             _, gc, gf = b.mse_loss(fwd["rgb_coarse"], fwd["rgb_fine"], tgt)
         res[mode] = b.render(pc, pf, packed_c, packed_f, rays, opt, rnp, training=True, g_rgb=(gc, gf))
     dense = res[False]
-    for mode in (True, "recompute"):
+    for mode in modes[1:]:
         r = res[mode]
         for k in ("rgb_coarse", "acc_coarse", "depth_coarse", "disp_coarse", "rgb_fine", "acc_fine", "depth_fine", "disp_fine"):
             assert np.array_equal(r[k], dense[k], equal_nan=True), (mode, k)
         for key, name, plan, total in (("g_params_coarse", "coarse", pc, n * nc), ("g_params_fine", "fine", pf, n * (nc + nf))):
-            kept, tot = r["bwd_kept_" + name]
-            assert tot == total and 0 < kept < total, (mode, name, kept, tot)
-            assert r["bwd_kept_" + name] == res[True]["bwd_kept_" + name]
+            kept, tot = r["bwd_kept_" + name] if mode != "fused" else res[True]["bwd_kept_" + name]
+            if mode != "fused":
+                assert tot == total and 0 < kept < total, (mode, name, kept, tot)
+                assert r["bwd_kept_" + name] == res[True]["bwd_kept_" + name]
             # (mode 2 differs from mode 1 only in WHERE the kept samples' stash rows sit: same list, same rows, same tile ranges --
             # the same gradient bit for bit)
-            assert np.array_equal(r[key], res[True][key]), ("recomputed vs compacted", key)
+            if mode == "recompute":
+                assert np.array_equal(r[key], res[True][key]), ("recomputed vs compacted", key)
             gd, gk = b.unflatten(plan, dense[key]), b.unflatten(plan, r[key])
             worst = 0.0
             for k in gd:

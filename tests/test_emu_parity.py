@@ -132,6 +132,26 @@ def test_render_backward_modes_dense_compacted_recomputed(emu):
     P.case_ray_grad(emu, P.MLP_GEOMETRIES["default4x128"], n=12, nc=8, nf=8, compact="recompute")
 
 
+def test_fused_backward_of_64_wide_nets(emu):
+    """nerfhip_plan_set_bwd_compaction(plan, 3 / 4), csrc/mlp64r.hip: persistent workgroups with the whole net in LDS -- forward
+    recomputed, data gradient, weight gradient and bias sums in one kernel, a fixed-order reduction of one partial per workgroup --
+    against the dense three-kernel backward on the same batch: 4 layers (config/fern.yml's 4 x 64), one layer, a padded hidden size
+    (40 of 64 units); several rounds per workgroup (the emulator has 3 "compute units"), a ragged last round; over every sample and
+    over the compaction list.  Plans without a resident image refuse the modes."""
+    import pytest
+    P.case_render_compacted(emu, P.MLP_GEOMETRIES["llff4x64_skip3_L6"], n=9, nc=16, nf=16, tag="llff64_fused_emu", white=True, fused=True)
+    P.case_render_compacted(emu, P.MLP_GEOMETRIES["llff4x64_skip3_L6"], n=37, nc=24, nf=8, tag="llff64_fused_rounds_emu", noise=1.0, fused=True)
+    P.case_render_compacted(emu, P.MLP_GEOMETRIES["one_layer_64"], n=20, nc=16, nf=16, tag="one64_fused_emu", noise=0.0, fused=True)
+    P.case_render_compacted(emu, P.MLP_GEOMETRIES["narrow3x40"], n=17, nc=24, nf=16, tag="narrow40_fused_emu", fused=True)
+    # ... and d(loss)/d(rays) with the fused modes set: the ray gradient needs the d(pre-activation) images -> mode 2's data flow
+    P.case_ray_grad(emu, P.MLP_GEOMETRIES["llff4x64_skip3_L6"], n=12, nc=8, nf=8, compact="fused_compact")
+    for name in ("default4x128", "novw3x64_skip1", "deep8x64_skip4"):   # 128 wide / no view directions / 8 layers with a skip layer
+        plan = emu.make_plan(P.MLP_GEOMETRIES[name], 0)
+        with pytest.raises(Exception, match="fused backward"):
+            emu.set_compaction(plan, "fused")
+        emu.lib.plan_destroy(plan)
+
+
 def test_f16x3_scale_fuzz(emu):
     """(the corners on the emulator; the GPU suite walks the whole 3 x 3 x 3 grid on four geometries)"""
     P.case_f16x3_scale_fuzz(emu, m=24, names=("default4x128", "deep8x128_skip4"),

@@ -186,8 +186,11 @@ class _Plans:
     """Plans + packed images of a case's two nets in one arithmetic (the case's own fp32 plans are reused for "fp32")."""
 
     def __init__(self, c, arith):
-        self.c, self.arith = c, arith
-        pc_, pf_ = ARITH[arith]
+        # "fp32_fused": the fp32 plans with the fused backward of 64-wide nets (nerfhip_plan_set_bwd_compaction(plan, 3), csrc/mlp64r.hip):
+        # another data flow, the SAME arithmetic -- held to the fp32 rows of the tolerance table
+        self.fused = arith == "fp32_fused"
+        self.c, self.arith = c, ("fp32" if self.fused else arith)
+        pc_, pf_ = ARITH[self.arith]
         gpu = c.gpu
         self.own = []
         if pc_ == 0:
@@ -203,8 +206,14 @@ class _Plans:
             self.packed_f = gpu.pack(self.plan_f, gpu.flatten_params(self.plan_f, {k: v.detach().numpy() for k, v in c.par_f.items()}))
             self.own.append(self.plan_f)
         self.tag = "" if arith == "fp32" else "_" + arith
+        if self.fused:
+            gpu.set_compaction(self.plan_c, "fused")
+            gpu.set_compaction(self.plan_f, "fused")
 
     def close(self):
+        if self.fused:
+            self.c.gpu.set_compaction(self.plan_c, False)
+            self.c.gpu.set_compaction(self.plan_f, False)
         for pl in self.own:
             self.c.gpu.lib.plan_destroy(pl)
 
@@ -383,7 +392,7 @@ def test_fern_full_batch_every_ray_vs_oracle(fern, arith):
     _end_to_end(fern, "e2e.grad_coarse.fp64_yardstick", "e2e.grad_fine.yardstick", arith=arith)
 
 
-@pytest.mark.parametrize("arith", ["fp32", "f16x3_train"])
+@pytest.mark.parametrize("arith", ["fp32", "f16x3_train", "fp32_fused"])
 def test_fern_declared_4x64_full_batch_every_ray_vs_oracle(fern_declared, arith):
     """The same full-batch comparison on the geometry config/fern.yml declares, on the fp32 kernels and -- the
     64-wide instances of mlp_f16w.hip, round 5 -- on fp16 pieces.  Fine-net bounds: 5x the values measured on MI355X

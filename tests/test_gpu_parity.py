@@ -199,6 +199,16 @@ def test_render_backward_modes_dense_compacted_recomputed(gpu, arith):
     P.case_render_compacted(gpu, P.MLP_GEOMETRIES["llff4x64_skip3_L6"], n=200, nc=64, nf=64, precision=prec, tag="llff200")
 
 
+def test_fused_backward_of_64_wide_nets(gpu):
+    """csrc/mlp64r.hip on MI355X (tests/test_emu_parity.py has the same cases on the emulator): 256 persistent workgroups, several
+    rounds each, a ragged last round; 4 x 64 (config/fern.yml), one layer, 40 of 64 units; every sample and the compaction list."""
+    P.case_render_compacted(gpu, P.MLP_GEOMETRIES["llff4x64_skip3_L6"], n=4096, nc=64, nf=64, tag="llff4096_fused", noise=1.0, fused=True)
+    P.case_render_compacted(gpu, P.MLP_GEOMETRIES["llff4x64_skip3_L6"], n=777, nc=24, nf=9, tag="llff777_fused", white=True, fused=True)
+    P.case_render_compacted(gpu, P.MLP_GEOMETRIES["one_layer_64"], n=300, nc=16, nf=16, tag="one64_fused", noise=0.0, fused=True)
+    P.case_render_compacted(gpu, P.MLP_GEOMETRIES["narrow3x40"], n=500, nc=24, nf=16, tag="narrow40_fused", fused=True)
+    P.case_ray_grad(gpu, P.MLP_GEOMETRIES["llff4x64_skip3_L6"], n=12, nc=8, nf=8, compact="fused_compact")
+
+
 @pytest.mark.parametrize("arith", ["fp32", "f16x3_train"])
 def test_full_size_compacted_backward_equals_dense(gpu, arith):
     """BASELINE configs[1] at full size (4096 rays, 64 + 128, 8x256): the fused render's backward with both plans compacted against the

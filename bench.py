@@ -274,7 +274,7 @@ def kernel_kind(name):
         return None
     if "k_bwd64r" in name:
         return "bwd64r"       # (--compact fused / fused_compact: forward recomputed + data gradient + weight gradient, one kernel)
-    if "k_mlp_fwd" in name:
+    if "k_mlp_fwd" in name or "k_fwd64r" in name:
         return "fwd"
     if "k_mlp_dgrad" in name:
         return "dgrad"
@@ -398,7 +398,7 @@ def main():
                          "forward; --mode train --precision f16x3_fwd the training forward, f16x3_fwd_dgrad + the data-gradient chain, "
                          "f16x3_train + the large weight-gradient blocks.  A+B: coarse net A, fine net B.  Separate, labelled lines: "
                          "the driver's default stays fp32")
-    ap.add_argument("--compact", nargs="?", const="gather", default=None, choices=("gather", "recompute", "fused", "fused_compact", "auto"),
+    ap.add_argument("--compact", nargs="?", const="gather", default=None, choices=("dense", "gather", "recompute", "fused", "fused_compact", "auto"),
                     help="train: compacted backward (FlexibleNeRFModel.set_backward_compaction): data and weight gradient over the sample "
                          "points whose d(loss)/d(raw) row is not all zero; `recompute`: additionally a stash-free training forward, the "
                          "backward re-runs the forward for the kept samples; `auto`: TrainEngine(backward='auto') picks dense / compacted / recomputed per net "
@@ -489,10 +489,11 @@ def main():
             mc.set_training_precision(prec_c)
         if prec_f != "fp32":
             mf.set_training_precision(prec_f)
-        if args.compact in ("gather", "recompute", "fused", "fused_compact"):
-            # (fused / fused_compact: the one-kernel backward of 64-wide fp32 nets, csrc/mlp64r.hip -- raises for other geometries)
-            mc.set_backward_compaction(True if args.compact == "gather" else args.compact)
-            mf.set_backward_compaction(True if args.compact == "gather" else args.compact)
+        if args.compact in ("dense", "gather", "recompute", "fused", "fused_compact"):
+            # (fused / fused_compact: the one-kernel backward of 64-wide fp32 nets, csrc/mlp64r.hip -- raises for other geometries; it
+            # is those nets' default: `dense` asks for the three-kernel backward)
+            mc.set_backward_compaction({"dense": False, "gather": True}.get(args.compact, args.compact))
+            mf.set_backward_compaction({"dense": False, "gather": True}.get(args.compact, args.compact))
         strong = args.global_rays > 0
         if strong:
             lo, hi = N.parallel.shard_bounds(args.global_rays, rank, world)
@@ -569,11 +570,11 @@ def main():
     dt = max(per_rank)
     loss_host = [float(v) for v in last.cpu()] if args.mode == "train" else None
     # compacted backward: the sample points the LAST timed step's backward kept, per net (two words per net of its workspace)
-    kept = eng.backward_sample_counts() if (args.mode == "train" and args.compact) else None
+    kept = eng.backward_sample_counts() if (args.mode == "train" and args.compact not in (None, "dense")) else None
     # (the mode the accounting below assumes: `auto` -> what the last timed step's nets ran in; per-net / per-step mixes make the auto
     # line's per-kernel fractions approximate -- its rays/s is what it is)
-    eff_compact = args.compact
-    if args.mode == "train" and args.compact == "auto":
+    eff_compact = None if args.compact == "dense" else args.compact
+    if args.mode == "train" and args.compact in (None, "auto"):   # (None: the models' defaults -- fused where a plan has it)
         modes = [m.backward_compaction for m in (mc, mf)]
         eff_compact = ("fused_compact" if 4 in modes else "fused" if 3 in modes else "recompute" if 2 in modes else ("gather" if 1 in modes else None))
     # What the per-launch HIP events of the timed region cost: the same K steps once more WITHOUT them (N = 1 only).  Nothing at
@@ -756,10 +757,10 @@ def main():
                    step_hbm_frac_of_8tb_s=round(step_bytes / sec / 1e12 / HBM_PEAK_TBS, 4),
                    final_loss=loss_host, roofline=roof)
         if args.mode == "train":
-            res["backward"] = {None: "dense", "gather": "compacted", "recompute": "compacted, stash recomputed for the kept samples",
+            res["backward"] = {None: "dense", "dense": "dense", "gather": "compacted", "recompute": "compacted, stash recomputed for the kept samples",
                                "fused": "fused (one persistent kernel per net: forward recomputed, data gradient, weight gradient; no stash, no d(pre-activation) images)",
                                "fused_compact": "fused, over the samples whose d(loss)/d(raw) row is non-zero",
-                               "auto": "auto (per net and step: dense / compacted / recomputed by the zero fraction of earlier steps)"}[args.compact]
+                               "auto": "auto (per net and step: dense / compacted / recomputed by the zero fraction of earlier steps)"}[args.compact if args.compact else eff_compact]
             if args.compact == "auto":
                 res["backward_modes_used"] = dict(steps_dense_compacted_recomputed=eng.backward_modes_used, last_known_zero_fraction=eng._zero_frac)
         if kept is not None:
@@ -805,7 +806,8 @@ def main():
                     children = (("f16x3_train", ["--precision", "f16x3_train", "--steps", str(args.steps), "--warmup", str(args.warmup)]),
                                 ("fp32_compact", ["--compact"]),
                                 ("f16x3_train_compact", ["--precision", "f16x3_train", "--compact"]),
-                                ("fern_fp32", ["--workload", "fern"]),
+                                ("fern_fp32", ["--workload", "fern"]),   # (4 x 64 fp32 nets: the fused one-kernel backward is their default)
+                                ("fern_fp32_dense", ["--workload", "fern", "--compact", "dense"]),
                                 ("fern_f16x3_train", ["--workload", "fern", "--precision", "f16x3_train"]),
                                 ("4x128_fp32", ["--hidden", "128", "--layers", "4"]),
                                 ("4x128_f16x3_train", ["--hidden", "128", "--layers", "4", "--precision", "f16x3_train"]),
@@ -824,6 +826,8 @@ def main():
                                                      for k, v in j["roofline"]["mlp_kernels"].items()},
                                         dominant_kernel=dict(kernel=j["roofline"]["kernel"], bound=j["roofline"]["bound"], frac=j["roofline"]["frac"]),
                                         command="python bench.py " + " ".join(extra))
+                            if j.get("unprofiled_rerun"):   # (the same steps without the per-launch HIP events: what a 2-ms step pays for them)
+                                line["ms_per_step_without_launch_events"] = j["unprofiled_rerun"]["ms_per_step"]
                             if "zero_cotangent_fraction" in j:
                                 z = j["zero_cotangent_fraction"]
                                 line["zero_cotangent_fraction"] = dict(coarse=z["coarse"], fine=z["fine"], backward_sample_points=z["backward_sample_points"])

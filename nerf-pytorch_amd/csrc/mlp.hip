@@ -114,6 +114,8 @@ static int mlp_forward_any(nerfhip_plan* p, const float* packed, const NhMlpInpu
                    "mlp_fwd: an f16x3 plan is inference-only (no activation stash, no backward; the _FWD / _FWD_DGRAD / _TRAIN plans train)");
         return nh_mlp_forward_f16w(p, packed, in, M, out, stash, stream, list);
     }
+    // 64-wide nets with an LDS-resident image (nh_r64.h): the persistent forward whenever no stash is asked for
+    if (p->r64_off >= 0 && !stash && !list) return nh_mlp64r_forward(p, packed, in, M, out, stream);
     return nh_mlp16_forward(p, packed, in, M, out, stash, stream, list);
 }
 

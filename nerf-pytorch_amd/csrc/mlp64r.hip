@@ -1,5 +1,5 @@
 // mlp64r.hip -- the fused, stash-free backward of 64-wide nets (config/fern.yml, config/llff.yml: 4 x 64): persistent workgroups
-// that keep the WHOLE net in LDS and, per 128 sample points, recompute the forward (nerf/models.py:233-256), run the data-gradient
+// that keep the WHOLE net in LDS and, per 64 sample points, recompute the forward (nerf/models.py:233-256), run the data-gradient
 // chain and sum the weight gradients (what autograd does behind train_nerf.py:259) -- no activation stash, no d(pre-activation)
 // images, no separate weight-gradient kernel.  What reaches HBM is one partial gradient per workgroup (fixed-order reduction, no
 // atomics: k_bwd64r_reduce).
@@ -12,22 +12,31 @@
 // Layout vocabulary (nh_plan.h): a wave owns 16 sample points, lane l = (sample j = l & 15, k-group g = l >> 4), an activation of
 // 64 units lives in 16 registers (register r: unit nh_feat16(r, g)) -- the C/D layout of v_mfma_f32_16x16x4_f32, so the forward and
 // the transposed chain run register to register exactly as in mlp16.hip, with the A operands read from the resident image
-// (nh_r64.h: one row-major copy serves both orientations).
+// (nh_r64.h: one row-major, chunk-swizzled copy serves both orientations without bank conflicts).
 //
 // The weight gradient dW[out][in] = sum_samples dP[out][s] H[in][s] contracts over SAMPLES: both MFMA operands must have the unit on
-// the lane's low bits and the sample on k -- the transpose of what the chain holds.  Every wave therefore writes its tile's
-// operand blocks (16 units x 16 samples, 1 KiB) into the exchange area, sample-major with an XOR swizzle (conflict-free 16-byte
-// writes, conflict-free 4-byte reads in operand order), and after a barrier every wave accumulates ITS share of the layer's
-// 16 x 16 gradient tiles over all 8 tiles of the round (k = 128 samples): the 88 KB of gradient accumulators are spread over the
-// 8 waves' registers (13 tiles = 52 registers each for a 4-layer net) instead of needing 344 registers in one wave.
+// the lane's low bits and the sample on k -- the transpose of what the chain holds -- and its 88 KB of accumulators are 344 registers
+// per lane: more than a wave that also carries the activations of every layer can hold.  So the workgroup's eight waves take TWO
+// ROLES, one wave of each per SIMD:
+//   chain waves (0..3): one 16-sample tile each per round -- encode, forward (registers only: X, H_0 .. H_{L-1}, FEAT, DIRH stay
+//       live), then layer by layer the d(pre-activation) P; per step they write the step's operand blocks (16 units x 16 samples,
+//       1 KiB each) into the exchange area, sample-major with an XOR swizzle (conflict-free 16-byte stores and 4-byte operand reads);
+//   weight-gradient waves (4..7): wave v owns a quarter of every layer's 16 x 16 gradient tiles (25 tiles = 100 accumulator
+//       registers for a 4-layer net, + 7 row sums for the biases) and accumulates them over the round's four tiles (k = 64 samples
+//       per step), operands double buffered in registers it has to spare.
+// The roles overlap: while the weight-gradient waves multiply step k, the chain waves compute the transposed layer of step k + 1 --
+// the matrix pipe of a SIMD always has one wave of each kind to draw from, neither kind spills, and the first design's second
+// barrier per step guards nothing but the hand-over.  (First design, all eight waves in both roles on 8 tiles per round: 256
+// registers + 70..200 spilled, operands read just in time for want of registers, 0.54 of the fp32 MFMA peak at best.)
 //
-// One round (128 sample points; L layers; two barriers per step):
-//   copy layer1's weights into the exchange area | encode | layer1 .. layers_dir (forward, registers only)
-//   step a: POUT PDIR DIRH D      units: fc_rgb, layers_dir's direction columns        then dFEAT
-//   step b: FEAT                  units: layers_dir's hidden columns                   then dH_{L-1}
-//   step c: PFEAT H_{L-1}         units: fc_feat, fc_alpha                             then dH_{L-2}
-//   step d_k: P_{i+1} H_i         units: layers_xyz[i], i = L-2 .. 0                   then dH_{i-1}
-//   step e: P_0 X                 units: layer1
+// One round (64 sample points; L layers).  Per step the chain waves do [free barrier | write operands | publish barrier], the
+// weight-gradient waves [free barrier | publish barrier | multiply]:
+//   encode | layer1 .. layers_dir (forward)
+//   step a: POUT PDIR DIRH D      tiles: fc_rgb, layers_dir's direction columns        chain meanwhile: dFEAT
+//   step b: FEAT                  tiles: layers_dir's hidden columns                   chain meanwhile: dH_{L-1}
+//   step c: PFEAT H_{L-1}         tiles: fc_feat, fc_alpha                             chain meanwhile: dH_{L-2}
+//   step d_k: P_{i+1} H_i         tiles: layers_xyz[i], i = L-2 .. 0                   chain meanwhile: dH_{i-1}
+//   step e: P_0 X                 tiles: layer1                                        chain meanwhile: the next round's forward
 // The samples may be a compaction list (compact.hip): slot c computes sample idx[c] -- a gather that costs nothing here, since the
 // forward is recomputed from the rays anyway.
 #include <stdlib.h>
@@ -55,6 +64,26 @@ struct Bwd64rArgs {
     const int* cstats;
     unsigned long long* clk;
 };
+
+#ifdef NH_PHASE_TIMING  // (`make dbg` builds only: shader cycles per phase, summed over the waves of a role; scripts/r64_phases.py)
+__device__ unsigned long long g_ph64[16];
+#define PH_DECL unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_last_ = clock64()
+#define PH(i)                                   \
+    do {                                        \
+        const unsigned long long t_ = clock64(); \
+        ph_[i] += t_ - ph_last_;                \
+        ph_last_ = t_;                          \
+    } while (0)
+#define PH_FLUSH(base)                                                   \
+    do {                                                                 \
+        if (lane == 0)                                                   \
+            for (int q_ = 0; q_ < 8; ++q_) atomicAdd(&g_ph64[(base) + q_], ph_[q_]); \
+    } while (0)
+#else
+#define PH_DECL
+#define PH(i)
+#define PH_FLUSH(base)
+#endif
 
 NH_DEVICE float sel3(int a, float x, float y, float z) { return a == 0 ? x : (a == 1 ? y : z); }
 
@@ -91,7 +120,7 @@ NH_DEVICE int opaque(int v) {
     return v;
 }
 
-#ifdef R64_PAD_LAYOUT
+#ifdef NH64_PAD_LAYOUT
 #define FOFF(R, fx) (16 * (R) + (fx))
 #else
 #define FOFF(R, fx) ((16 * (R)) ^ (fx))
@@ -121,27 +150,6 @@ NH_DEVICE void zero_acc(f32x4* acc) {
 template <int KR, int T, int STRIDE>
 NH_DEVICE void gemm_f(const float* w, int fx, const float* in, f32x4* acc) {
     static_assert(KR % 4 == 0 && T % 2 == 0, "four k-steps per 16-byte read, two tiles per step");
-#ifdef R64_GEMMF_FULL
-    {
-        asm volatile("" : "+v"(fx));
-        float4 a[2][T];
-#pragma unroll
-        for (int t = 0; t < T; ++t) a[0][t] = *(const float4*)(w + 16 * t * STRIDE + FOFF(0, fx));
-#pragma unroll
-        for (int R = 0; R < KR / 4; ++R) {
-            if (R + 1 < KR / 4) {
-#pragma unroll
-                for (int t = 0; t < T; ++t) a[(R + 1) & 1][t] = *(const float4*)(w + 16 * t * STRIDE + FOFF(R + 1, fx));
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-#pragma unroll
-                for (int t = 0; t < T; ++t) acc[t] = nh_mfma16(pick4(a[R & 1][t], c), in[4 * R + c], acc[t]);
-            }
-        }
-        return;
-    }
-#endif
     constexpr int NS = (KR / 4) * (T / 2);  // steps: (R, tile pair), R-major
 #ifndef NERFHIP_EMU
     asm volatile("" : "+v"(fx));  // (opaque: the four offsets (16 R) ^ fx are formed per call, not kept live across the round)
@@ -175,7 +183,7 @@ NH_DEVICE void gemm_t(const float* wt, int g16, int i4, const float* dp, f32x4* 
     // sixteen more live registers of a kernel that has none to spare)
     asm volatile("" : "+v"(g16), "+v"(i4));
 #endif
-#ifdef R64_PAD_LAYOUT
+#ifdef NH64_PAD_LAYOUT
     {
         float a[2][T];
 #pragma unroll
@@ -211,31 +219,41 @@ NH_DEVICE void gemm_t(const float* wt, int g16, int i4, const float* dp, f32x4* 
     }
 }
 
-// One gradient tile over the round: acc (16 out rows x 16 in units) += sum over the 8 tiles' 16 samples of A[row][s] B[unit][s];
-// pa / pb = the blocks' slots in tile 0 of the exchange area; this lane's element of k-step q inside a block is 64 q + rq[q & 1].
-// rs += the A operands this lane saw (row sums = bias gradients; lane group g' holds the samples = g' mod 4)
-NH_DEVICE void unit1(const float* pa, const float* pb, const int* rq, f32x4& acc, float& rs) {
+// NB gradient tiles that share their A block, over the round: acc[n] (16 out rows x 16 in units) += sum over the tiles' 16 samples
+// of A[row][s] B_n[unit][s].  rq[q & 1] + 64 q = this lane's element of k-step q inside a block of the exchange area `ex`; aoff / boff = the A block's / the first B block's slot (floats; B blocks in
+// consecutive slots).  Every read is (one of four pointers formed here) + a constant: formed from separate lane and block offsets,
+// the compiler kept one address register per (tile, k-step, block) -- ~100 more live registers, all spilled.  The operands of the next
+// tile are read while this one is multiplied.  rs += the A operands this lane saw (row sums = bias gradients; lane group g' holds the
+// samples = g' mod 4)
+template <int NB>
+NH_DEVICE void unitN(const float* ex, const int* rq, int aoff, int boff, f32x4* acc, float& rs) {
+    // (the four offsets are opaque INTEGERS, the base stays the LDS array: as opaque pointers the reads became flat loads)
+    int oa[2] = {rq[0] + aoff, rq[1] + aoff}, ob[2] = {rq[0] + boff, rq[1] + boff};
+#ifndef NERFHIP_EMU
+    asm volatile("" : "+v"(oa[0]), "+v"(oa[1]), "+v"(ob[0]), "+v"(ob[1]));
+#endif
+    float av[2][4], bv[2][NB][4];
 #pragma unroll
-    for (int t = 0; t < NWV; ++t) {
+    for (int q = 0; q < 4; ++q) {
+        av[0][q] = ex[oa[q & 1] + 64 * q];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float a = pa[t * R64_TILE_F + 64 * q + rq[q & 1]], b = pb[t * R64_TILE_F + 64 * q + rq[q & 1]];
-            acc = nh_mfma16(a, b, acc);
-            rs += a;
-        }
+        for (int n = 0; n < NB; ++n) bv[0][n][q] = ex[ob[q & 1] + 256 * n + 64 * q];
     }
-}
-// two tiles that share their A block (B blocks pb and pb + 256)
-NH_DEVICE void unit2(const float* pa, const float* pb, const int* rq, f32x4& acc0, f32x4& acc1, float& rs) {
 #pragma unroll
-    for (int t = 0; t < NWV; ++t) {
+    for (int t = 0; t < R64_TILES; ++t) {
+        if (t + 1 < R64_TILES) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                av[(t + 1) & 1][q] = ex[oa[q & 1] + (t + 1) * R64_TILE_F + 64 * q];
+#pragma unroll
+                for (int n = 0; n < NB; ++n) bv[(t + 1) & 1][n][q] = ex[ob[q & 1] + (t + 1) * R64_TILE_F + 256 * n + 64 * q];
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int e = t * R64_TILE_F + 64 * q + rq[q & 1];
-            const float a = pa[e], b0 = pb[e], b1 = pb[e + 256];
-            acc0 = nh_mfma16(a, b0, acc0);
-            acc1 = nh_mfma16(a, b1, acc1);
-            rs += a;
+#pragma unroll
+            for (int n = 0; n < NB; ++n) acc[n] = nh_mfma16(av[t & 1][q], bv[t & 1][n][q], acc[n]);
+            rs += av[t & 1][q];
         }
     }
 }
@@ -265,208 +283,406 @@ NH_DEVICE float gate_pos(float v, float h) {
 template <int L>
 NH_KERNEL void NH_LB(64 * NWV, 2) k_bwd64r(Bwd64rArgs a) {
     constexpr R64Layout Y = r64_layout(L);
-    constexpr int NU = r64_units(L), NB = r64_bias_regs(L);
+    constexpr int NU = r64_units(L), NB = r64_bias_regs(L), TL = R64_TILES;
     NH_DYN_LDS(lds_raw);
     float* const lds = (float*)lds_raw;
-    float* const ex = lds + Y.res_floats;
+    float* const ex = lds + Y.image_floats;
     float* const lfreq = lds + r64_lds_floats(L);  // 16 xyz + 16 direction frequency bands
     nh_clk_begin(a.clk, (unsigned long long*)(lds_raw + (r64_lds_floats(L) + 32) * 4));
-    if (threadIdx.x < 32) lfreq[threadIdx.x] = threadIdx.x < 16 ? a.fx[threadIdx.x & 15] : a.fd[threadIdx.x & 15];
-    nh_block_sync();
     const int lane = nh_lane(), g = lane >> 4, j = lane & 15, wave = nh_wave_in_block();
-    const unsigned lds_addr = nh_lds_addr(lds);
-    const NhDmaSrc dma = nh_dma_src(a.image, a.image_bytes);
-
-    // the resident segment: 1-KiB pieces, wave w takes pieces w, w + 8, ...
-    for (int q = wave; q < Y.res_floats / 256; q += NWV) nh_dma16a(dma, lane * 16, q * 1024, lds_addr + (unsigned)q * 1024u);
-
+    {
+        // the whole image: 1-KiB pieces, wave w takes pieces w, w + 8, ...
+        const unsigned lds_addr = nh_lds_addr(lds);
+        const NhDmaSrc dma = nh_dma_src(a.image, a.image_bytes);
+        for (int q = wave; q < Y.image_floats / 256; q += NWV) nh_dma16a(dma, lane * 16, q * 1024, lds_addr + (unsigned)q * 1024u);
+        if (threadIdx.x < 32) lfreq[threadIdx.x] = threadIdx.x < 16 ? a.fx[threadIdx.x & 15] : a.fd[threadIdx.x & 15];
+        nh_wait_vmem();
+        nh_block_sync();
+    }
     const int n_slots = a.cidx ? nh_uload_i32(a.cstats, NH_CSTAT_ACTIVE) : (int)a.M;
-    const int rounds = (n_slots + 16 * NWV - 1) / (16 * NWV);
-
-    // lane offsets into the image (floats; nh_r64.h): forward rows / transposed rows of the 64-column matrices and of layers_dir
-#ifdef R64_PAD_LAYOUT
-    const int lf = j * R64_S, lt = 4 * g * R64_S + j, lfd = j * R64_SD, ltd = 4 * g * R64_SD + j;
-    const int fx = 4 * g, g16 = 0, i4 = 0;
-#else
-    const int lf = j * R64_S, lt = 4 * g * R64_S + (j & 3), lfd = j * R64_SD, ltd = 4 * g * R64_SD + (j & 3);
-    const int fx = 16 * (j >> 2) + 4 * (g ^ (j & 3)), g16 = 16 * g, i4 = 4 * (j >> 2);
-#endif
-    // exchange area: where this lane writes a block of its wave's tile, and its element of k-step q when it reads one (sample
-    // s = 4 q + g: float s * 16 + 4 ((j >> 2) ^ ((s >> 1) & 3)) + (j & 3) = 64 q + rq[q & 1])
-    float* const pw = ex + wave * R64_TILE_F + j * 16 + 4 * (g ^ ((j >> 1) & 3));
+    const int rounds = (n_slots + 16 * TL - 1) / (16 * TL);
+    // this lane's element of k-step q when it reads a block of the exchange area (sample s = 4 q + g: float
+    // s * 16 + 4 ((j >> 2) ^ ((s >> 1) & 3)) + (j & 3) = 64 q + rq[q & 1])
     int rq[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) rq[q] = 16 * g + 4 * ((j >> 2) ^ ((2 * q + (g >> 1)) & 3)) + (j & 3);
-    f32x4 U[NU];
-    float rsum[NB];
-#pragma unroll
-    for (int u = 0; u < NU; ++u) U[u][0] = U[u][1] = U[u][2] = U[u][3] = 0.0f;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) rsum[b] = 0.0f;
 
-    // The sample of this lane's slot in round `rd` (a list entry: fetched one round ahead, during step e of the round before).
-    // (a list is padded with sample 0 up to a multiple of 128; a dense tail computes the last sample: finite values times a zero
-    // cotangent)
-    int m_next = 0;
-    auto fetch_sample = [&](int rd) {
-        const int slot = rd * (16 * NWV) + wave * 16 + j;
-        m_next = a.cidx ? a.cidx[slot] : (slot < n_slots ? slot : (int)a.M - 1);
-    };
-    if ((int)blockIdx.x < rounds) fetch_sample((int)blockIdx.x);
-    for (int round = (int)blockIdx.x; round < rounds; round += (int)gridDim.x) {
-        // ---- layer1's weights travel into the exchange area (everybody is done reading it: the barrier that closed step e) while
-        // the encodings are computed
-        for (int q = wave; q < r64_up(64 * R64_S, 256) / 256; q += NWV)
-            nh_dma16a(dma, lane * 16, (Y.l1 + q * 256) * 4, lds_addr + (unsigned)(Y.res_floats + q * 256) * 4u);
-        const bool valid = round * (16 * NWV) + wave * 16 + j < n_slots;
-        const int m = m_next;
-        const float* const rr = a.rays + (size_t)(m / a.S) * a.ray_stride;
+    if (wave >= TL) {
+        // ================================ weight-gradient wave v: a quarter of every layer's gradient tiles ================================
+        const int v = wave - TL;
+        f32x4 U[NU];
+        float rsum[NB];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) U[u][0] = U[u][1] = U[u][2] = U[u][3] = 0.0f;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) rsum[b] = 0.0f;
+        // While the chain waves run their forward this wave has nothing to multiply: it prepares the inputs of ITS tile of the NEXT
+        // round -- sample, depth, ray, both encodings (twelve sincosf per lane: 10 % of a round when the chain waves did it) -- and hands
+        // them over through LDS.
+        float* const pass = ex + R64_EX_F + v * R64_PASS_TILE_F + lane * 4;
+        float Xn[NH16_KRX], Dn[NH16_KRD];
+        auto prep = [&](int rd) {
+            const int slot = rd * (16 * TL) + v * 16 + j;
+            // (a list is padded with sample 0 up to a multiple of 128; a dense tail computes the last sample)
+            const int m = a.cidx ? a.cidx[slot] : (slot < n_slots ? slot : (int)a.M - 1);
+            const float* const rr = a.rays + (size_t)(m / a.S) * a.ray_stride;
+            const float zz = a.z[m];
+            // pts = ro + rd * z   (nerf/train_utils.py:67,107)
+            const float px = rr[0] + rr[3] * zz, py = rr[1] + rr[4] * zz, pz = rr[2] + rr[5] * zz;
+            encode_slots<NH16_KRX>(Xn, px, py, pz, opaque(g), lfreq, a.Lx);
+            encode_slots<NH16_KRD>(Dn, rr[8], rr[9], rr[10], opaque(g), lfreq + 16, a.Ld);
+        };
+        auto hand_over = [&]() {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) nh_store4(pass + q * 256, Xn[4 * q], Xn[4 * q + 1], Xn[4 * q + 2], Xn[4 * q + 3]);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) nh_store4(pass + (4 + q) * 256, Dn[4 * q], Dn[4 * q + 1], Dn[4 * q + 2], Dn[4 * q + 3]);
+        };
+        if ((int)blockIdx.x < rounds) {
+            prep((int)blockIdx.x);
+            hand_over();
+        }
+        nh_block_sync();  // (the first round's hand-over is in LDS)
+        PH_DECL;
+        for (int round = (int)blockIdx.x; round < rounds; round += (int)gridDim.x) {
+            const bool more = round + (int)gridDim.x < rounds;
+            if (more) prep(round + (int)gridDim.x);
+            PH(3);  // [11] preparing the next round
+            // step a: slot 0 POUT, 1..2 PDIR, 3..4 DIRH, 5..6 D -- fc_rgb (waves 0, 1: POUT x DIRH block v),
+            // layers_dir's direction columns (PDIR block v >> 1 x D block v & 1).  The chain waves read the hand-over area at the top
+            // of their round, i.e. before they reach this barrier: the next round's may be written behind it.
+            nh_block_sync();
+            if (more) hand_over();
+            nh_block_sync();
+            PH(0);  // [8] waiting for step a (the chain waves' forward)
+            if (v < 2) unitN<1>(ex, rq, 0, (3 + v) * 256, &U[0], rsum[0]);
+            unitN<1>(ex, rq, (1 + (v >> 1)) * 256, (5 + (v & 1)) * 256, &U[1], rsum[1]);
+            PH(1);  // [9] multiplying
+            // step b: slots 3..6 FEAT -- layers_dir's hidden columns (PDIR block v >> 1 x FEAT blocks 2 (v & 1), + 1)
+            nh_block_sync();
+            nh_block_sync();
+            PH(2);  // [10] waiting for the steps b ..
+            {
+                float unused = 0.0f;
+                unitN<2>(ex, rq, (1 + (v >> 1)) * 256, (3 + 2 * (v & 1)) * 256, &U[2], unused);
+            }
+            PH(1);
+            // step c: slots 1..4 PFEAT, 5..8 H_{L-1} (POUT still in 0) -- fc_feat rows 16 v .., fc_alpha's units 16 v ..
+            nh_block_sync();
+            nh_block_sync();
+            PH(2);
+            unitN<4>(ex, rq, (1 + v) * 256, 5 * 256, &U[4], rsum[2]);
+            {
+                float unused = 0.0f;
+                unitN<1>(ex, rq, 0, (5 + v) * 256, &U[8], unused);
+            }
+            PH(1);
+            // steps d_k: slots 1..4 P_{i+1}, 5..8 H_i -- layers_xyz[i] rows 16 v .., i = L-2-k; step e: P_0 and X -- layer1
+#pragma unroll
+            for (int k = 0; k < L; ++k) {
+                nh_block_sync();
+                nh_block_sync();
+                PH(2);
+                unitN<4>(ex, rq, (1 + v) * 256, 5 * 256, &U[9 + 4 * k], rsum[3 + k]);
+                PH(1);
+            }
+        }
+        PH_FLUSH(8);
+        // this workgroup's partial: [weight-gradient wave][register][lane]
+        float* const part = a.partial + (size_t)blockIdx.x * r64_partial_floats(L) + (size_t)v * r64_regs(L) * 64 + lane;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) part[(4 * u + c) * 64] = U[u][c];
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) part[(4 * NU + b) * 64] = rsum[b];
+    } else {
+        // ================================ chain wave: tile `wave` of every round ================================
+        // lane offsets into the image (floats; nh_r64.h): forward rows / transposed rows of the 64-column matrices and of layers_dir
+#ifdef NH64_PAD_LAYOUT
+        const int lf = j * R64_S, lt = 4 * g * R64_S + j, lfd = j * R64_SD, ltd = 4 * g * R64_SD + j;
+        const int fx = 4 * g, g16 = 0, i4 = 0;
+#else
+        const int lf = j * R64_S, lt = 4 * g * R64_S + (j & 3), lfd = j * R64_SD, ltd = 4 * g * R64_SD + (j & 3);
+        const int fx = 16 * (j >> 2) + 4 * (g ^ (j & 3)), g16 = 16 * g, i4 = 4 * (j >> 2);
+#endif
+        // where this lane writes a block of its tile
+        float* const pw = ex + wave * R64_TILE_F + j * 16 + 4 * (g ^ ((j >> 1) & 3));
+        const float* const pass = ex + R64_EX_F + wave * R64_PASS_TILE_F + lane * 4;
+        // The sample of this lane's slot in round `rd` (a list entry: fetched one round ahead).  A list is padded with sample 0 up to a
+        // multiple of 128; a dense tail computes the last sample: finite values times a zero cotangent
+        int m_next = 0;
+        auto fetch_sample = [&](int rd) {
+            const int slot = rd * (16 * TL) + wave * 16 + j;
+            m_next = a.cidx ? a.cidx[slot] : (slot < n_slots ? slot : (int)a.M - 1);
+        };
+        if ((int)blockIdx.x < rounds) fetch_sample((int)blockIdx.x);
+        nh_block_sync();  // (the first round's hand-over is in LDS)
+        PH_DECL;
+        for (int round = (int)blockIdx.x; round < rounds; round += (int)gridDim.x) {
+            const bool valid = round * (16 * TL) + wave * 16 + j < n_slots;
+            const int m = m_next;
+            // the encodings of this tile: prepared by the weight-gradient wave of this SIMD during the round before
+            float X[NH16_KRX], Dd[NH16_KRD];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 t4 = *(const float4*)(pass + q * 256);
+                X[4 * q] = t4.x, X[4 * q + 1] = t4.y, X[4 * q + 2] = t4.z, X[4 * q + 3] = t4.w;
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float4 t4 = *(const float4*)(pass + (4 + q) * 256);
+                Dd[4 * q] = t4.x, Dd[4 * q + 1] = t4.y, Dd[4 * q + 2] = t4.z, Dd[4 * q + 3] = t4.w;
+            }
+            if (round + (int)gridDim.x < rounds) fetch_sample(round + (int)gridDim.x);
+            // d(loss)/d(raw output) of this lane's sample: asked for here, needed when the backward starts
+            float go0 = 0.f, go1 = 0.f, go2 = 0.f, go3 = 0.f;
+            if (valid) {
+                const float4 t4 = *(const float4*)(a.g_out + (size_t)m * 4);
+                go0 = t4.x, go1 = t4.y, go2 = t4.z, go3 = t4.w;
+            }
+            PH(0);  // [0] hand-over read
+            // ---- forward, registers only (nerf/models.py:233-256); H[0] = layer1(x) has no activation (:238)
+            f32x4 acc[4];
+            float H[L][16];
+            bias_init<4>(acc, lds + Y.b_l1 + 4 * g);
+            gemm_f<NH16_KRX, 4, R64_S>(lds + Y.l1 + lf, fx, X, acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) H[0][r] = acc[r >> 2][r & 3];
+#pragma unroll
+            for (int i = 0; i < L - 1; ++i) {
+                bias_init<4>(acc, lds + Y.b_xyz[i] + 4 * g);
+                gemm_f<16, 4, R64_S>(lds + Y.xyz[i] + lf, fx, H[i], acc);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) H[i + 1][r] = nh_relu(acc[r >> 2][r & 3]);
+            }
+            float FEAT[16], DIRH[8];
+            bias_init<4>(acc, lds + Y.b_feat + 4 * g);
+            gemm_f<16, 4, R64_S>(lds + Y.head + lf, fx, H[L - 1], acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) FEAT[r] = nh_relu(acc[r >> 2][r & 3]);
+            bias_init<2>(acc, lds + Y.b_dir + 4 * g);
+            gemm_f<16, 2, R64_SD>(lds + Y.dir + lfd, fx, FEAT, acc);
+            gemm_f<NH16_KRD, 2, R64_SD>(lds + Y.dir + 64 + lfd, fx, Dd, acc);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) DIRH[r] = nh_relu(acc[r >> 2][r & 3]);
+
+            PH(1);  // [1] forward
+            // ---- backward.  d(DIRH pre-activation) = relu'(DIRH) * fc_rgb^T d(rgb raw): ONE k-step, group g carries d(rgb raw)[g]
+            float PDIR[8];
+            {
+                zero_acc<2>(acc);
+                const float b = g == 0 ? go0 : (g == 1 ? go1 : (g == 2 ? go2 : 0.0f));
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[t] = nh_mfma16(lds[Y.rgb + g * R64_SR + 16 * t + j], b, acc[t]);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) PDIR[r] = gate_pos(acc[r >> 2][r & 3], DIRH[r]);
+            }
+            // step a: slot 0 POUT (rows 0..2 d(rgb raw), row 3 d(sigma raw)), 1..2 PDIR, 3..4 DIRH, 5..6 D
+            PH(2);  // [2] transposed layers, gates
+            nh_block_sync();  // (free: the weight-gradient waves are done with the step before)
+            PH(3);  // [3] waiting for the weight-gradient waves
+            ex_put(pw, 0, g == 0 ? go0 : 0.f, g == 0 ? go1 : 0.f, g == 0 ? go2 : 0.f, g == 0 ? go3 : 0.f);
+            ex_put_blocks<2>(pw, 1, PDIR);
+            ex_put_blocks<2>(pw, 3, DIRH);
+            ex_put_blocks<2>(pw, 5, Dd);
+            nh_block_sync();  // (publish)
+            PH(4);  // [4] operand stores + publish barrier
+            // d(FEAT pre-activation) = relu'(FEAT) * layers_dir[:, :64]^T PDIR
+            float PFEAT[16];
+            zero_acc<4>(acc);
+            gemm_t<8, 4, R64_SD>(lds + Y.dir + ltd, g16, i4, PDIR, acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) PFEAT[r] = gate_pos(acc[r >> 2][r & 3], FEAT[r]);
+            // step b: slots 3..6 FEAT (PDIR stays in 1..2)
+            PH(2);
+            nh_block_sync();
+            PH(3);
+            ex_put_blocks<4>(pw, 3, FEAT);
+            nh_block_sync();
+            PH(4);
+            // dH_{L-1} = fc_feat^T PFEAT + fc_alpha^T d(sigma raw) (one more k-step: group 0 carries d(sigma raw))
+            float P[2][16];
+            {
+                zero_acc<4>(acc);
+                gemm_t<16, 4, R64_S>(lds + Y.head + lt, g16, i4, PFEAT, acc);
+                const float b = g == 0 ? go3 : 0.0f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = nh_mfma16(lds[Y.head + 64 * R64_S + 16 * t + j], b, acc[t]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) P[0][r] = L > 1 ? gate_pos(acc[r >> 2][r & 3], H[L - 1][r]) : acc[r >> 2][r & 3];
+            }
+            // step c: slots 1..4 PFEAT, 5..8 H_{L-1} (POUT stays in 0)
+            PH(2);
+            nh_block_sync();
+            PH(3);
+            ex_put_blocks<4>(pw, 1, PFEAT);
+            ex_put_blocks<4>(pw, 5, H[L - 1]);
+            nh_block_sync();
+            PH(4);
+            // steps d_k: layers_xyz[i], i = L-2-k: first dH_i = layers_xyz[i]^T P_{i+1} (P_{i+1} = P[k & 1]), then slots 1..4 P_{i+1},
+            // 5..8 H_i
+#pragma unroll
+            for (int k = 0; k < L - 1; ++k) {
+                const int i = L - 2 - k;
+                zero_acc<4>(acc);
+                gemm_t<16, 4, R64_S>(lds + Y.xyz[i] + lt, g16, i4, P[k & 1], acc);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) P[(k + 1) & 1][r] = i >= 1 ? gate_pos(acc[r >> 2][r & 3], H[i][r]) : acc[r >> 2][r & 3];
+                PH(2);
+                nh_block_sync();
+                PH(3);
+                ex_put_blocks<4>(pw, 1, P[k & 1]);
+                ex_put_blocks<4>(pw, 5, H[i]);
+                nh_block_sync();
+                PH(4);
+            }
+            // step e: layer1: slots 1..4 P_0, 5..8 X
+            PH(2);
+            nh_block_sync();
+            PH(3);
+            ex_put_blocks<4>(pw, 1, P[(L - 1) & 1]);
+            ex_put_blocks<4>(pw, 5, X);
+            nh_block_sync();
+            PH(4);
+        }
+        PH_FLUSH(0);
+    }
+    nh_clk_end((const unsigned long long*)(lds_raw + (r64_lds_floats(L) + 32) * 4));
+}
+
+// ---- the persistent forward with the resident image: what the stash-free training forward and inference of these nets run ----------
+// Sixteen waves per workgroup (four per SIMD: a wave needs ~100 registers without a backward to serve), one workgroup per CU, the image
+// copied once; a wave walks over 16-sample tiles: encode, layer1 .. fc_rgb register to register, one 16-byte store per sample.  No
+// barrier after the image has landed.  Same k order per output as k_mlp_fwd16 (bias first, k-steps in register order, four lane
+// groups per MFMA): bit-identical results.
+constexpr int NWF = 16;
+struct Fwd64rArgs {
+    const float* image;
+    unsigned image_bytes;
+    int64_t M;
+    int mode;  // 0: encoded rows x [M, dx + dd]; 1: rays + depths
+    const float* x;
+    int dx, dd;
+    signed char xcol[4][NH16_KRX], dcol[4][NH16_KRD];  // slot (g, r) -> column of x (mode 0), or -1
+    const float* rays;
+    int ray_stride;
+    const float* z;
+    int S;
+    float fx[16], fd[16];
+    int Lx, Ld;
+    float* out;
+    unsigned long long* clk;
+};
+
+// one output tile: acc += W[i][k cols] * in (16 dependent MFMAs per 4 k-registers are spread over ... one accumulator: short layers only)
+template <int KR, int STRIDE>
+NH_DEVICE void gemm_f1(const float* w, int fx, const float* in, f32x4& acc) {
+#pragma unroll
+    for (int R = 0; R < KR / 4; ++R) {
+        const float4 a4 = *(const float4*)(w + FOFF(R, fx));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc = nh_mfma16(pick4(a4, c), in[4 * R + c], acc);
+    }
+}
+
+template <int L>
+NH_KERNEL void NH_LB(64 * NWF, 4) k_fwd64r(Fwd64rArgs a) {
+    constexpr R64Layout Y = r64_layout(L);
+    NH_DYN_LDS(lds_raw);
+    float* const lds = (float*)lds_raw;
+    float* const lfreq = lds + Y.image_floats;
+    nh_clk_begin(a.clk, (unsigned long long*)(lds_raw + (Y.image_floats + 32) * 4));
+    const int lane = nh_lane(), g = lane >> 4, j = lane & 15, wave = nh_wave_in_block();
+    {
+        const unsigned lds_addr = nh_lds_addr(lds);
+        const NhDmaSrc dma = nh_dma_src(a.image, a.image_bytes);
+        for (int q = wave; q < Y.image_floats / 256; q += NWF) nh_dma16a(dma, lane * 16, q * 1024, lds_addr + (unsigned)q * 1024u);
+        if (threadIdx.x < 32) lfreq[threadIdx.x] = threadIdx.x < 16 ? a.fx[threadIdx.x & 15] : a.fd[threadIdx.x & 15];
+        nh_wait_vmem();
+        nh_block_sync();
+    }
+#ifdef NH64_PAD_LAYOUT
+    const int lf = j * R64_S, lfd = j * R64_SD, fx = 4 * g;
+#else
+    const int lf = j * R64_S, lfd = j * R64_SD, fx = 16 * (j >> 2) + 4 * (g ^ (j & 3));
+#endif
+    const int64_t tiles = (a.M + 15) / 16;
+    for (int64_t tile = (int64_t)blockIdx.x * NWF + wave; tile < tiles; tile += (int64_t)gridDim.x * NWF) {
+        const int64_t slot = tile * 16 + j;
+        const bool valid = slot < a.M;
+        const int m = (int)(valid ? slot : a.M - 1);
         float X[NH16_KRX];
-        {
+        const float* const xr = a.mode == 0 ? a.x + (size_t)m * (size_t)(a.dx + a.dd) : nullptr;
+        const float* const rr = a.mode == 0 ? nullptr : a.rays + (size_t)(m / a.S) * a.ray_stride;
+        if (a.mode == 0) {
+#pragma unroll
+            for (int r = 0; r < NH16_KRX; ++r) {
+                const int c = a.xcol[g][r];
+                X[r] = c >= 0 ? xr[c] : 0.0f;
+            }
+        } else {
             const float zz = a.z[m];
             // pts = ro + rd * z   (nerf/train_utils.py:67,107)
             const float px = rr[0] + rr[3] * zz, py = rr[1] + rr[4] * zz, pz = rr[2] + rr[5] * zz;
             encode_slots<NH16_KRX>(X, px, py, pz, opaque(g), lfreq, a.Lx);
         }
-        nh_wait_vmem();
-        nh_block_sync();
-
-        // ---- forward, registers only (nerf/models.py:233-256); H[0] = layer1(x) has no activation (:238)
         f32x4 acc[4];
-        float H[L][16];
+        float Hc[16];
         bias_init<4>(acc, lds + Y.b_l1 + 4 * g);
-        gemm_f<NH16_KRX, 4, R64_S>(ex + lf, fx, X, acc);
+        gemm_f<NH16_KRX, 4, R64_S>(lds + Y.l1 + lf, fx, X, acc);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) H[0][r] = acc[r >> 2][r & 3];
-        // d(loss)/d(raw output) of this lane's sample: asked for here, needed when the backward starts (behind the other layers)
-        float go0 = 0.f, go1 = 0.f, go2 = 0.f, go3 = 0.f;
-        if (valid) {
-            const float4 t4 = *(const float4*)(a.g_out + (size_t)m * 4);
-            go0 = t4.x, go1 = t4.y, go2 = t4.z, go3 = t4.w;
-        }
+        for (int r = 0; r < 16; ++r) Hc[r] = acc[r >> 2][r & 3];  // no activation after layer1 (models.py:238)
 #pragma unroll
         for (int i = 0; i < L - 1; ++i) {
             bias_init<4>(acc, lds + Y.b_xyz[i] + 4 * g);
-            gemm_f<16, 4, R64_S>(lds + Y.xyz[i] + lf, fx, H[i], acc);
+            gemm_f<16, 4, R64_S>(lds + Y.xyz[i] + lf, fx, Hc, acc);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) H[i + 1][r] = nh_relu(acc[r >> 2][r & 3]);
+            for (int r = 0; r < 16; ++r) Hc[r] = nh_relu(acc[r >> 2][r & 3]);
         }
-        float FEAT[16], DIRH[8], Dd[NH16_KRD];
+        // fc_alpha (row 64 of the head matrix: row 0 of a fifth tile; the other rows of that tile are whatever follows the matrix and
+        // are never read back), then fc_feat
+        f32x4 aa;
+        bias_init<1>(&aa, lds + Y.b_alpha + 4 * g);
+        gemm_f1<16, R64_S>(lds + Y.head + 64 * R64_S + lf, fx, Hc, aa);
+        const float alpha = aa[0];
         bias_init<4>(acc, lds + Y.b_feat + 4 * g);
-        gemm_f<16, 4, R64_S>(lds + Y.head + lf, fx, H[L - 1], acc);
+        gemm_f<16, 4, R64_S>(lds + Y.head + lf, fx, Hc, acc);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) FEAT[r] = nh_relu(acc[r >> 2][r & 3]);
-        encode_slots<NH16_KRD>(Dd, rr[8], rr[9], rr[10], opaque(g), lfreq + 16, a.Ld);
+        for (int r = 0; r < 16; ++r) Hc[r] = nh_relu(acc[r >> 2][r & 3]);
+        float Dd[NH16_KRD];
+        if (a.mode == 0) {
+#pragma unroll
+            for (int r = 0; r < NH16_KRD; ++r) {
+                const int c = (int)a.dcol[g][r];
+                Dd[r] = c >= 0 ? xr[a.dx + c] : 0.0f;
+            }
+        } else {
+            encode_slots<NH16_KRD>(Dd, rr[8], rr[9], rr[10], opaque(g), lfreq + 16, a.Ld);
+        }
         bias_init<2>(acc, lds + Y.b_dir + 4 * g);
-        gemm_f<16, 2, R64_SD>(lds + Y.dir + lfd, fx, FEAT, acc);
+        gemm_f<16, 2, R64_SD>(lds + Y.dir + lfd, fx, Hc, acc);
         gemm_f<NH16_KRD, 2, R64_SD>(lds + Y.dir + 64 + lfd, fx, Dd, acc);
+        float dh[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) DIRH[r] = nh_relu(acc[r >> 2][r & 3]);
-
-        // ---- backward.  d(DIRH pre-activation) = relu'(DIRH) * fc_rgb^T d(rgb raw): ONE k-step, group g carries d(rgb raw)[g]
-        float PDIR[8];
-        {
-            zero_acc<2>(acc);
-            const float b = g == 0 ? go0 : (g == 1 ? go1 : (g == 2 ? go2 : 0.0f));
+        for (int r = 0; r < 8; ++r) dh[r] = nh_relu(acc[r >> 2][r & 3]);
+        // fc_rgb: 16 rows x 36 floats, not swizzled
+        f32x4 ar;
+        bias_init<1>(&ar, lds + Y.b_rgb + 4 * g);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) acc[t] = nh_mfma16(lds[Y.rgb + g * R64_SR + 16 * t + j], b, acc[t]);
+        for (int R = 0; R < 2; ++R) {
+            const float4 a4 = *(const float4*)(lds + Y.rgb + j * R64_SR + 16 * R + 4 * g);
 #pragma unroll
-            for (int r = 0; r < 8; ++r) PDIR[r] = gate_pos(acc[r >> 2][r & 3], DIRH[r]);
+            for (int c = 0; c < 4; ++c) ar = nh_mfma16(pick4(a4, c), dh[4 * R + c], ar);
         }
-        nh_block_sync();  // every wave is done with layer1's weights: the exchange area may be written
-        // step a: slot 0 POUT (rows 0..2 d(rgb raw), row 3 d(sigma raw)), 1..2 PDIR, 3..4 DIRH, 5..6 D
-        ex_put(pw, 0, g == 0 ? go0 : 0.f, g == 0 ? go1 : 0.f, g == 0 ? go2 : 0.f, g == 0 ? go3 : 0.f);
-        ex_put_blocks<2>(pw, 1, PDIR);
-        ex_put_blocks<2>(pw, 3, DIRH);
-        ex_put_blocks<2>(pw, 5, Dd);
-        nh_block_sync();
-        float PFEAT[16];
-        {
-            // fc_rgb: waves 0, 1 (POUT x DIRH block w); layers_dir direction columns: waves 2..5 (PDIR block x D block)
-            if (wave < 2)
-                unit1(ex, ex + (3 + wave) * 256, rq, U[0], rsum[0]);
-            else if (wave < 6)
-                unit1(ex + (1 + ((wave - 2) >> 1)) * 256, ex + (5 + ((wave - 2) & 1)) * 256, rq, U[0], rsum[0]);
-            // d(FEAT pre-activation) = relu'(FEAT) * layers_dir[:, :64]^T PDIR
-            zero_acc<4>(acc);
-            gemm_t<8, 4, R64_SD>(lds + Y.dir + ltd, g16, i4, PDIR, acc);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) PFEAT[r] = gate_pos(acc[r >> 2][r & 3], FEAT[r]);
+        if (valid && g == 0) {
+            float4 r4;
+            r4.x = ar[0], r4.y = ar[1], r4.z = ar[2], r4.w = alpha;
+            *(float4*)(a.out + (size_t)m * 4) = r4;
         }
-        nh_block_sync();
-        // step b: slots 3..6 FEAT (PDIR stays in 1..2)
-        ex_put_blocks<4>(pw, 3, FEAT);
-        nh_block_sync();
-        float P[2][16];
-        {
-            float unused = 0.0f;  // (layers_dir's bias was summed in step a)
-            unit1(ex + (1 + (wave >> 2)) * 256, ex + (3 + (wave & 3)) * 256, rq, U[1], unused);
-            // dH_{L-1} = fc_feat^T PFEAT + fc_alpha^T d(sigma raw) (one more k-step: group 0 carries d(sigma raw))
-            zero_acc<4>(acc);
-            gemm_t<16, 4, R64_S>(lds + Y.head + lt, g16, i4, PFEAT, acc);
-            const float b = g == 0 ? go3 : 0.0f;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = nh_mfma16(lds[Y.head + 64 * R64_S + 16 * t + j], b, acc[t]);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) P[0][r] = L > 1 ? gate_pos(acc[r >> 2][r & 3], H[L - 1][r]) : acc[r >> 2][r & 3];
-        }
-        nh_block_sync();
-        // step c: slots 1..4 PFEAT, 5..8 H_{L-1} (POUT stays in 0)
-        ex_put_blocks<4>(pw, 1, PFEAT);
-        ex_put_blocks<4>(pw, 5, H[L - 1]);
-        nh_block_sync();
-        {
-            // fc_feat: wave w takes out rows 16 (w >> 1), in units 32 (w & 1) .. + 31; fc_alpha: waves 0..3 (one per SIMD), in units 16 w ..
-            unit2(ex + (1 + (wave >> 1)) * 256, ex + (5 + 2 * (wave & 1)) * 256, rq, U[2], U[3], rsum[1]);
-            if (wave < 4) {
-                float unused = 0.0f;
-                unit1(ex, ex + (5 + wave) * 256, rq, U[4], unused);
-            }
-            if (L > 1) {
-                zero_acc<4>(acc);
-                gemm_t<16, 4, R64_S>(lds + Y.xyz[L > 1 ? L - 2 : 0] + lt, g16, i4, P[0], acc);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) P[1][r] = L > 2 ? gate_pos(acc[r >> 2][r & 3], H[L > 2 ? L - 2 : 0][r]) : acc[r >> 2][r & 3];
-            }
-        }
-        nh_block_sync();
-        // steps d_k: layers_xyz[i], i = L-2-k: slots 1..4 P_{i+1}, 5..8 H_i
-#pragma unroll
-        for (int k = 0; k < L - 1; ++k) {
-            const int i = L - 2 - k;
-            ex_put_blocks<4>(pw, 1, P[k & 1]);
-            ex_put_blocks<4>(pw, 5, H[i]);
-            nh_block_sync();
-            unit2(ex + (1 + (wave >> 1)) * 256, ex + (5 + 2 * (wave & 1)) * 256, rq, U[5 + 2 * k], U[6 + 2 * k], rsum[2 + k]);
-            if (i >= 1) {  // dH_{i-1} = layers_xyz[i-1]^T P_i (P_i = the register set this step did not write)
-                zero_acc<4>(acc);
-                gemm_t<16, 4, R64_S>(lds + Y.xyz[i >= 1 ? i - 1 : 0] + lt, g16, i4, P[(k + 1) & 1], acc);
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    P[k & 1][r] = i >= 2 ? gate_pos(acc[r >> 2][r & 3], H[i >= 2 ? i - 1 : 0][r]) : acc[r >> 2][r & 3];
-            }
-            nh_block_sync();
-        }
-        // step e: layer1: slots 1..4 P_0, 5..8 X
-        ex_put_blocks<4>(pw, 1, P[(L - 1) & 1]);
-        ex_put_blocks<4>(pw, 5, X);
-        nh_block_sync();
-        const bool more = round + (int)gridDim.x < rounds;
-        if (more) fetch_sample(round + (int)gridDim.x);
-        unit2(ex + (1 + (wave >> 1)) * 256, ex + (5 + 2 * (wave & 1)) * 256, rq, U[5 + 2 * (L - 1)], U[6 + 2 * (L - 1)], rsum[L + 1]);
-        nh_block_sync();
     }
-    nh_wait_vmem();
-    // ---- this workgroup's partial: [wave][register][lane]
-    float* const part = a.partial + (size_t)blockIdx.x * r64_partial_floats(L) + (size_t)wave * r64_regs(L) * 64 + lane;
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) part[(4 * u + c) * 64] = U[u][c];
-    }
-#pragma unroll
-    for (int b = 0; b < NB; ++b) part[(4 * NU + b) * 64] = rsum[b];
-    nh_clk_end((const unsigned long long*)(lds_raw + (r64_lds_floats(L) + 32) * 4));
+    nh_clk_end((const unsigned long long*)(lds_raw + (Y.image_floats + 32) * 4));
 }
 
 // ---- reduction: g_params[e] = sum over the workgroups' partials, in workgroup order ------------------------------------------------------
@@ -479,12 +695,12 @@ struct Red64rArgs {
     signed char xcol[4][NH16_KRX], dcol[4][NH16_KRD];  // slot (g, r) -> reference column, or -1
 };
 
-// One block per (wave, register) row of the partials: 64 elements x 4 slices of the workgroup range; slice s adds the partials of
+// One block per (weight-gradient wave, register) row of the partials: 64 elements x 4 slices of the workgroup range; slice s adds the partials of
 // workgroups s, s + 4, ... in four interleaved running sums, the slices are combined through LDS in slice order -- a fixed order:
 // bit-reproducible, no atomics.  Each element then decodes which parameter it is (none: padding, a wave that idles in that step).
 NH_KERNEL void k_bwd64r_reduce(Red64rArgs a) {
     NH_SHARED float part[4][64];
-    const int L = a.L, NU = r64_units(L), NR = r64_regs(L), H = a.H, H2 = H / 2, stride = R64_WAVES * NR * 64;
+    const int L = a.L, NU = r64_units(L), NR = r64_regs(L), H = a.H, H2 = H / 2, stride = R64_TILES * NR * 64;
     const int row = (int)blockIdx.x, lane = (int)threadIdx.x & 63, slice = (int)threadIdx.x >> 6;
     const int reg = row % NR, w = row / NR;
     {
@@ -504,28 +720,26 @@ NH_KERNEL void k_bwd64r_reduce(Red64rArgs a) {
     int64_t dst = -1;
     if (reg < 4 * NU) {
         const int u = reg >> 2, row16 = 4 * gq + (reg & 3);  // out row inside the A block, in unit inside the B block = fl
-        if (u == 0) {
-            if (w < 2) {  // fc_rgb
-                const int col = 16 * w + fl;
-                if (row16 < 3 && col < H2) dst = a.o_rgb_w + (int64_t)row16 * H2 + col;
-            } else if (w < 6) {  // layers_dir, direction columns: D block (w-2)&1 = slot registers 4 b .. 4 b + 3 of group fl >> 2
-                const int orow = 16 * ((w - 2) >> 1) + row16, c = (int)a.dcol[fl >> 2][4 * ((w - 2) & 1) + (fl & 3)];
-                if (orow < H2 && c >= 0) dst = a.o_dir_w + (int64_t)orow * (H + a.Dd) + H + c;
-            }
-        } else if (u == 1) {  // layers_dir, hidden columns
-            const int orow = 16 * (w >> 2) + row16, col = 16 * (w & 3) + fl;
-            if (orow < H2 && col < H) dst = a.o_dir_w + (int64_t)orow * (H + a.Dd) + col;
-        } else if (u == 2 || u == 3) {  // fc_feat
-            const int orow = 16 * (w >> 1) + row16, col = 16 * (2 * (w & 1) + (u - 2)) + fl;
-            if (orow < H && col < H) dst = a.o_feat_w + (int64_t)orow * H + col;
-        } else if (u == 4) {  // fc_alpha: row 3 of POUT (waves 0..3: in units 16 w ..)
+        if (u == 0) {  // fc_rgb (waves 0, 1)
             const int col = 16 * w + fl;
-            if (w < 4 && row16 == 3 && col < H) dst = a.o_alpha_w + col;
-        } else if (u < 5 + 2 * (L - 1)) {  // layers_xyz[i]
-            const int k = (u - 5) >> 1, i = L - 2 - k, orow = 16 * (w >> 1) + row16, col = 16 * (2 * (w & 1) + ((u - 5) & 1)) + fl;
+            if (w < 2 && row16 < 3 && col < H2) dst = a.o_rgb_w + (int64_t)row16 * H2 + col;
+        } else if (u == 1) {  // layers_dir, direction columns: D block w & 1 = slot registers 4 b .. 4 b + 3 of group fl >> 2
+            const int orow = 16 * (w >> 1) + row16, c = (int)a.dcol[fl >> 2][4 * (w & 1) + (fl & 3)];
+            if (orow < H2 && c >= 0) dst = a.o_dir_w + (int64_t)orow * (H + a.Dd) + H + c;
+        } else if (u < 4) {  // layers_dir, hidden columns
+            const int orow = 16 * (w >> 1) + row16, col = 16 * (2 * (w & 1) + (u - 2)) + fl;
+            if (orow < H2 && col < H) dst = a.o_dir_w + (int64_t)orow * (H + a.Dd) + col;
+        } else if (u < 8) {  // fc_feat
+            const int orow = 16 * w + row16, col = 16 * (u - 4) + fl;
+            if (orow < H && col < H) dst = a.o_feat_w + (int64_t)orow * H + col;
+        } else if (u == 8) {  // fc_alpha: row 3 of POUT
+            const int col = 16 * w + fl;
+            if (row16 == 3 && col < H) dst = a.o_alpha_w + col;
+        } else if (u < 9 + 4 * (L - 1)) {  // layers_xyz[i]
+            const int k = (u - 9) >> 2, i = L - 2 - k, orow = 16 * w + row16, col = 16 * ((u - 9) & 3) + fl;
             if (orow < H && col < H) dst = a.o_xyz_w[i] + (int64_t)orow * H + col;
         } else {  // layer1: X block b = slot registers 4 b .. 4 b + 3 of group fl >> 2
-            const int b = 2 * (w & 1) + ((u - 5) & 1), orow = 16 * (w >> 1) + row16, c = (int)a.xcol[fl >> 2][4 * b + (fl & 3)];
+            const int b = (u - 9) & 3, orow = 16 * w + row16, c = (int)a.xcol[fl >> 2][4 * b + (fl & 3)];
             if (orow < H && c >= 0) dst = a.o_l1_w + (int64_t)orow * a.Dx + c;
         }
         if (dst >= 0 && slice == 0) a.g_params[dst] = total;
@@ -538,18 +752,17 @@ NH_KERNEL void k_bwd64r_reduce(Red64rArgs a) {
     nh_block_sync();
     if (gq != 0 || slice != 0) return;
     const int b = reg - 4 * NU;
-    if (b == 0) {
-        if (w == 0)
-            dst = fl < 3 ? a.o_rgb_b + fl : (fl == 3 ? a.o_alpha_b : -1);
-        else if (w == 2 || w == 4)
-            dst = 16 * ((w - 2) >> 1) + fl < H2 ? a.o_dir_b + 16 * ((w - 2) >> 1) + fl : -1;
-    } else if ((w & 1) == 0) {
-        const int orow = 16 * (w >> 1) + fl;
+    if (b == 0) {  // POUT: rows 0..2 fc_rgb's bias, row 3 fc_alpha's (wave 0's sums)
+        if (w == 0) dst = fl < 3 ? a.o_rgb_b + fl : (fl == 3 ? a.o_alpha_b : -1);
+    } else if (b == 1) {  // PDIR block w >> 1 (waves 0 and 2)
+        if ((w & 1) == 0 && 16 * (w >> 1) + fl < H2) dst = a.o_dir_b + 16 * (w >> 1) + fl;
+    } else {
+        const int orow = 16 * w + fl;
         if (orow < H) {
-            if (b == 1)
+            if (b == 2)
                 dst = a.o_feat_b + orow;
-            else if (b < L + 1)
-                dst = a.o_xyz_b[L - 2 - (b - 2)] + orow;
+            else if (b < L + 2)
+                dst = a.o_xyz_b[L - 2 - (b - 3)] + orow;
             else
                 dst = a.o_l1_b + orow;
         }
@@ -599,9 +812,70 @@ int launch_bwd(const Bwd64rArgs& a, int grid, nerfhip_stream_t stream) {
 
 }  // namespace
 
+#ifdef NH_PHASE_TIMING
+extern "C" int nerfhip_debug_phases64(unsigned long long* host16, int reset) {
+    (void)hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_ph64), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ph64), z, sizeof(z));
+    }
+    return 0;
+}
+#endif
+
+template <int L>
+static int launch_fwd(const Fwd64rArgs& a, int grid, nerfhip_stream_t stream) {
+    const int bytes = (r64_layout(L).image_floats + 32) * 4 + NH_CLK_LDS_BYTES;
+    const int rc = lds_limit(k_fwd64r<L>, bytes);
+    if (rc) return rc;
+    NH_LAUNCH((k_fwd64r<L>), grid, 64 * NWF, bytes, stream, a);
+    return nh_launch_status("fwd64r");
+}
+
+// The forward of an eligible plan without a stash (inference, the stash-free training forward of the fused modes): raw[M, 4]
+int nh_mlp64r_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, nerfhip_stream_t stream) {
+    NH_REQUIRE(nh_r64_eligible(p) && p->r64_off >= 0, "fwd64r: the plan has no resident image");
+    NH_REQUIRE(packed && out && M > 0 && M < ((int64_t)1 << 31), "fwd64r: bad arguments");
+    Fwd64rArgs a;
+    memset(&a, 0, sizeof(a));
+    const R64Layout Y = r64_layout(p->L);
+    a.image = packed + p->r64_off;
+    a.image_bytes = (unsigned)(Y.image_floats * 4);
+    a.M = M;
+    a.mode = in.mode;
+    a.x = in.x;
+    a.dx = p->Dx;
+    a.dd = p->Dd;
+    for (int g = 0; g < 4; ++g) {
+        for (int r = 0; r < NH16_KRX; ++r) a.xcol[g][r] = (signed char)p->xyz_col16[g][r];
+        for (int r = 0; r < NH16_KRD; ++r) a.dcol[g][r] = (signed char)p->dir_col16[g][r];
+    }
+    a.rays = in.rays;
+    a.ray_stride = in.ray_stride;
+    a.z = in.z;
+    a.S = in.S;
+    for (int k = 0; k < 16; ++k) {
+        a.fx[k] = p->freqs_xyz[k];
+        a.fd[k] = p->freqs_dir[k];
+    }
+    a.Lx = p->cfg.num_encoding_fn_xyz;
+    a.Ld = p->cfg.num_encoding_fn_dir;
+    a.out = out;
+    a.clk = nh_prof_clock_slot(NH_CLK_FWD);
+    const int64_t wgs = nh_ceil_div(nh_ceil_div(M, 16), NWF);
+    const int cus = compute_units();
+    const int grid = (int)(wgs < cus ? wgs : cus);
+    switch (p->L) {
+        case 1: return launch_fwd<1>(a, grid, stream);
+        case 2: return launch_fwd<2>(a, grid, stream);
+        case 3: return launch_fwd<3>(a, grid, stream);
+        default: return launch_fwd<4>(a, grid, stream);
+    }
+}
+
 // workgroups of a fused backward over M sample points: one per compute unit, at most one per round
 static int r64_grid(int64_t M) {
-    const int64_t rounds = nh_ceil_div(M, 16 * NWV);
+    const int64_t rounds = nh_ceil_div(M, 16 * R64_TILES);
     const int cus = compute_units();
     return (int)(rounds < cus ? (rounds < 1 ? 1 : rounds) : cus);
 }
@@ -666,6 +940,6 @@ int nh_mlp64r_backward(nerfhip_plan* p, const float* packed, const NhMlpInput& i
         for (int k = 0; k < NH16_KRX; ++k) r.xcol[g][k] = (signed char)p->xyz_col16[g][k];
         for (int k = 0; k < NH16_KRD; ++k) r.dcol[g][k] = (signed char)p->dir_col16[g][k];
     }
-    NH_LAUNCH(k_bwd64r_reduce, R64_WAVES * r64_regs(p->L), 256, 0, stream, r);
+    NH_LAUNCH(k_bwd64r_reduce, R64_TILES * r64_regs(p->L), 256, 0, stream, r);
     return nh_launch_status("bwd64r_reduce");
 }

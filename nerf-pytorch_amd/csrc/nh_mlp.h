@@ -55,6 +55,8 @@ int nh_mlp16_dgrad(nerfhip_plan* p, const float* packed, const float* g_out, int
 // mlp64r.hip: the fused, stash-free backward of 64-wide nets with an LDS-resident image (nh_r64.h): forward recomputed, data
 // gradient and weight gradient in one persistent kernel + a fixed-order reduction of one partial per workgroup
 int64_t nh_mlp64r_partial_floats(const nerfhip_plan* p, int64_t M);
+// ... and the persistent forward with the same image: raw[M, 4] without a stash (inference, the stash-free training forward)
+int nh_mlp64r_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, nerfhip_stream_t stream);
 int nh_mlp64r_backward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, const float* g_out, int64_t M, float* partial,
                        float* g_params, const NhCompact* cx, nerfhip_stream_t stream);
 

@@ -14,14 +14,13 @@
 //             to 68 floats, measured SQ_LDS_BANK_CONFLICT = 22 % of the LDS cycles: that rule assumed contiguous quarter waves);
 //   transposed A'[i = in unit][k = out row]: lane (g, i) reads W[nh_feat16(r, g)][16 t + i] -- one ds_read_b32 per k-step -- at
 //             dword 16 (t ^ g) + 4 ((i >> 2) ^ c) + (i & 3) of its row: 32 lanes, 32 banks.
-// Segments: RES (resident from the first round on: layers_xyz, fc_feat + fc_alpha, layers_dir, fc_rgb, every bias) and L1
-// (layer1's weights: only the forward needs them -- they are copied into the operand-exchange area at the start of every round and
-// overwritten by it afterwards; 160 KB of LDS hold RES + the exchange area, not both plus layer1).
+// Segments: RES (layers_xyz, fc_feat + fc_alpha, layers_dir, fc_rgb, every bias), then L1 (layer1's weights: only the forward reads
+// them); one copy of the whole image at kernel start.  Behind it in LDS: the operand-exchange area (R64_TILES tiles).
 #pragma once
 #include "nh_plan.h"
 
 constexpr int R64_MAX_LAYERS = 4;
-#ifdef R64_PAD_LAYOUT  // (A/B builds only: the first build's padded rows, measured 22 % bank-conflict cycles)
+#ifdef NH64_PAD_LAYOUT  // (A/B builds only: the first build's padded rows, measured 22 % bank-conflict cycles)
 constexpr int R64_S = 68, R64_SD = 100, R64_SR = 36;
 constexpr int r64_pos(int, int kc) { return kc; }
 #else
@@ -31,16 +30,17 @@ constexpr int R64_SR = 36;   // fc_rgb: 32 hidden (+ 4), not swizzled (read once
 // float offset of k column kc (< 64) inside (the 64-float half of) row `row`
 constexpr int r64_pos(int row, int kc) { return 4 * ((kc >> 2) ^ (row & 15)) + (kc & 3); }
 #endif
-constexpr int R64_WAVES = 8;                    // waves per workgroup = 16-sample tiles per round
+constexpr int R64_WAVES = 8;                    // waves per workgroup: R64_TILES chain waves + R64_TILES weight-gradient waves
+constexpr int R64_TILES = 4;                    // 16-sample tiles per round (one per chain wave)
 constexpr int R64_TILE_BLOCKS = 9;              // 16-feature x 16-sample blocks one tile may hold in the exchange area
 constexpr int R64_TILE_F = R64_TILE_BLOCKS * 256;
-constexpr int R64_EX_F = R64_WAVES * R64_TILE_F;  // floats of the exchange area (72 KiB)
+constexpr int R64_EX_F = R64_TILES * R64_TILE_F;  // floats of the exchange area (36 KiB)
 
 struct R64Layout {
     int xyz[R64_MAX_LAYERS];  // layers_xyz[i]: 64 rows x R64_S
     int head;                 // fc_feat rows 0..63, fc_alpha row 64: 65 rows x R64_S
     int dir;                  // layers_dir[0]: 32 rows x R64_SD
-    int rgb;                  // fc_rgb: 16 rows x R64_SR (rows 3..15 zero)
+    int rgb;                  // fc_rgb: 4 rows x R64_SR (row 3 zero)
     int b_l1, b_xyz[R64_MAX_LAYERS], b_feat, b_alpha, b_dir, b_rgb;
     int res_floats;           // RES segment, a multiple of 256 floats (1-KiB copy pieces)
     int l1;                   // layer1: 64 rows x R64_S, at res_floats in the image (R64_L1_F floats: whole 1-KiB pieces)
@@ -60,7 +60,7 @@ constexpr R64Layout r64_layout(int L) {
     y.dir = off;
     off += 32 * R64_SD;
     y.rgb = off;
-    off += 16 * R64_SR;
+    off += 4 * R64_SR;
     y.b_l1 = off;
     off += 64;
     for (int i = 0; i < L - 1; ++i) {
@@ -80,15 +80,19 @@ constexpr R64Layout r64_layout(int L) {
     y.image_floats = y.res_floats + r64_up(64 * R64_S, 256);  // (64 * 64 floats = 16 copy pieces)
     return y;
 }
-constexpr int r64_lds_floats(int L) { return r64_layout(L).res_floats + R64_EX_F; }
-static_assert((r64_lds_floats(R64_MAX_LAYERS) + 32) * 4 + 32 <= 160 * 1024, "RES + the exchange area must fit the 160 KB of LDS");
+// ... and the hand-over area: per tile the 16 registers of the xyz encoding and the 8 of the direction encoding,
+// [register quad][lane][4] (the weight-gradient waves encode the next round while the chain waves are in their forward: mlp64r.hip)
+constexpr int R64_PASS_TILE_F = 24 * 64;
+constexpr int R64_PASS_F = R64_TILES * R64_PASS_TILE_F;
+constexpr int r64_lds_floats(int L) { return r64_layout(L).image_floats + R64_EX_F + R64_PASS_F; }
+static_assert((r64_lds_floats(R64_MAX_LAYERS) + 32) * 4 + 32 <= 160 * 1024, "the image + the exchange area must fit the 160 KB of LDS");
 
-// Accumulators of one wave (mlp64r.hip "units"): NU accumulator tiles (4 registers each) + NB row-sum registers (biases)
-constexpr int r64_units(int L) { return 5 + 2 * L; }
-constexpr int r64_bias_regs(int L) { return 2 + L; }
+// Accumulators of one weight-gradient wave (mlp64r.hip "units"): NU accumulator tiles (4 registers each) + NB row-sum registers (biases)
+constexpr int r64_units(int L) { return 9 + 4 * L; }
+constexpr int r64_bias_regs(int L) { return 3 + L; }
 constexpr int r64_regs(int L) { return 4 * r64_units(L) + r64_bias_regs(L); }
-// floats of one workgroup's partial: [wave][register][lane]
-constexpr int r64_partial_floats(int L) { return R64_WAVES * r64_regs(L) * 64; }
+// floats of one workgroup's partial: [weight-gradient wave][register][lane]
+constexpr int r64_partial_floats(int L) { return R64_TILES * r64_regs(L) * 64; }
 
 static inline bool nh_r64_eligible(const nerfhip_plan* p) {
     if (p->precision != NERFHIP_PRECISION_FP32 || p->W != 64 || !p->view || p->L < 1 || p->L > R64_MAX_LAYERS || p->krx != NH16_KRX ||

@@ -162,7 +162,12 @@ class FlexibleNeRFModel(torch.nn.Module):
         self._inf_packed = None
         if getattr(self, "inference_precision", "fp32") != "fp32":
             self._inf_owner = _PlanHandle(self.cfg, PRECISIONS[self.inference_precision])
-        lib.plan_set_bwd_compaction(self._plan, int(getattr(self, "backward_compaction", 0)))
+        # the backward's data flow: what set_backward_compaction last asked for; by default the fused one-kernel backward where the plan
+        # has it (fp32 nets of hidden_size <= 64 with view directions, <= 4 layers, no skip layer: csrc/mlp64r.hip), else dense
+        if getattr(self, "_backward_choice", None) is None:
+            self._fused_ok = None
+            self.backward_compaction = 3 if self.fused_backward_available() else 0
+        lib.plan_set_bwd_compaction(self._plan, int(self.backward_compaction))
         self._flatten()
 
     @property
@@ -201,9 +206,11 @@ class FlexibleNeRFModel(torch.nn.Module):
         training forward additionally writes no activation stash; the backward re-runs the forward for the samples it keeps.  Pays
         where most rows are dropped and the stash-writing forward is much slower than the plain one (the fp16-piece plans).
         on = "fused" / "fused_compact" (3 / 4; fp32 nets of hidden_size <= 64 with view directions, <= 4 layers, no skip layer --
-        config/fern.yml, config/llff.yml; raises for other geometries): inside the fused render the forward writes no stash and ONE
+        config/fern.yml, config/llff.yml; raises for other geometries; "fused" is those nets' DEFAULT, on = False gives them the
+        three-kernel dense backward): inside the fused render the forward writes no stash and ONE
         persistent kernel with the whole net resident in LDS recomputes the forward, runs the data-gradient chain and sums the weight
         gradients (csrc/mlp64r.hip) -- over every sample, or over the samples with a non-zero d(loss)/d(raw) row."""
+        self._backward_choice = on
         self.backward_compaction = {"recompute": 2, "fused": 3, "fused_compact": 4}.get(on, int(bool(on)))
         L.get_lib().plan_set_bwd_compaction(self._plan, self.backward_compaction)
         return self

@@ -188,8 +188,9 @@ class _Plans:
     def __init__(self, c, arith):
         # "fp32_fused": the fp32 plans with the fused backward of 64-wide nets (nerfhip_plan_set_bwd_compaction(plan, 3), csrc/mlp64r.hip):
         # another data flow, the SAME arithmetic -- held to the fp32 rows of the tolerance table
-        self.fused = arith == "fp32_fused"
-        self.c, self.arith = c, ("fp32" if self.fused else arith)
+        self.tag = "" if arith == "fp32" else "_" + arith
+        self.fused = self.tag.endswith("_fused")
+        self.c, self.arith = c, (arith[:-len("_fused")] if self.fused else arith)
         pc_, pf_ = ARITH[self.arith]
         gpu = c.gpu
         self.own = []
@@ -205,7 +206,6 @@ class _Plans:
             self.plan_f = gpu.make_plan(c.cfg, pf_)
             self.packed_f = gpu.pack(self.plan_f, gpu.flatten_params(self.plan_f, {k: v.detach().numpy() for k, v in c.par_f.items()}))
             self.own.append(self.plan_f)
-        self.tag = "" if arith == "fp32" else "_" + arith
         if self.fused:
             gpu.set_compaction(self.plan_c, "fused")
             gpu.set_compaction(self.plan_f, "fused")

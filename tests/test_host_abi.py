@@ -218,7 +218,7 @@ def test_product_reads_no_environment_and_ships_one_kernel_set():
     wg = open(os.path.join(csrc, "wgrad.hip")).read()
     assert wg.count("#ifdef NH_WGRAD_TIMELINE") >= 3 and "nh_wall_clock()" in wg  # instrumentation is debug-build only
     assert sorted(f for f in os.listdir(csrc) if f.endswith(".hip")) == [
-        "compact.hip", "dataio.hip", "elementwise.hip", "fused.hip", "mlp.hip", "mlp16.hip", "mlp16_ext.hip", "mlp16_w512.hip", "mlp_f16w.hip",
+        "compact.hip", "dataio.hip", "elementwise.hip", "fused.hip", "mlp.hip", "mlp16.hip", "mlp16_ext.hip", "mlp16_w512.hip", "mlp64r.hip", "mlp_f16w.hip",
         "pack_f16.hip", "render.hip", "sample.hip", "wgrad.hip", "wgrad_f16.hip"]
 
 
@@ -237,8 +237,21 @@ def test_backward_mode_thresholds_and_option_plumbing():
     for mode in (1, 2, 0):
         lib.plan_set_bwd_compaction(plan, mode)
         assert lib.plan_bwd_compaction(plan) == mode
-    with pytest.raises(L.NerfHipError, match="0 \\(dense\\), 1 \\(compacted\\) or 2"):
+    with pytest.raises(L.NerfHipError, match="0 \\(dense\\), 1 \\(compacted\\), 2"):
+        lib.plan_set_bwd_compaction(plan, 5)
+    # the fused one-kernel backward (3, 4; csrc/mlp64r.hip) exists for plans with an LDS-resident image only: a 4 x 128 net has none
+    with pytest.raises(L.NerfHipError, match="fused backward"):
         lib.plan_set_bwd_compaction(plan, 3)
+    fern = L.ModelCfg(4, 64, 3, 6, 4, 1, 1, 1, 1, 1)   # config/fern.yml's nets
+    pf = lib.plan_create(C.byref(fern))
+    for mode in (3, 4, 0):
+        lib.plan_set_bwd_compaction(pf, mode)
+        assert lib.plan_bwd_compaction(pf) == mode
+    # (its packed buffer carries the resident image behind the layer images; its scratch one partial per workgroup behind the list)
+    assert lib.plan_packed_floats(pf) > 0 and lib.plan_bwd_scratch_bytes(pf, 4096) > lib.plan_bwd_stats_offset(pf, 4096)
+    lib.plan_destroy(pf)
+    # ... and TrainEngine(backward="auto") always runs it where it exists: over every sample until the list is known to drop 5 %
+    assert [E._mode_for(f, False, True) for f in (None, 0.0, 0.04, 0.05, 0.9)] == [3, 3, 3, 4, 4]
     # the statistics words sit inside the backward scratch, behind everything the dense backward uses
     off, total = lib.plan_bwd_stats_offset(plan, 4096), lib.plan_bwd_scratch_bytes(plan, 4096)
     assert 0 < off < total and off % 4 == 0 and total - off >= 4 * (16 + 4096)

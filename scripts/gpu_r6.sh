@@ -49,26 +49,28 @@ trained_more)   # the two-stream step in the compacted modes; the 4x128 nets tra
 fused)
   timeout 900 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider -k "fused or fern_declared_4x64_full" > $R/pytest_fused.log 2>&1; echo "pytest rc=$?"
   grep -E "passed|failed" $R/pytest_fused.log | tail -2; grep -E "^FAILED|^ERROR|Error|assert" $R/pytest_fused.log | head -20
-  for a in "" "--compact fused" "--compact fused_compact" "--compact fused --overlap 0" "--overlap 0"; do
+  for a in "" "--compact dense" "--compact fused_compact" "--overlap 0" "--compact dense --overlap 0"; do   # ("": fused, the default of these nets)
     t=$(echo $a | tr -d " -"); timeout 150 python bench.py --workload fern --no-cpu-baseline --no-labelled-lines $a > $R/fern_$t.log 2>&1; line $R/fern_$t.log
   done
   cd /tmp
-  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/prof_fern_fused -o bench -- python $GRAFT_REPO_ROOT/bench.py --workload fern --compact fused --no-cpu-baseline --no-labelled-lines > $R/prof_fern_fused.log 2>&1
+  rm -rf $R/prof_fern_fused
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/prof_fern_fused -o bench -- python $GRAFT_REPO_ROOT/bench.py --workload fern --overlap 0 --no-cpu-baseline --no-labelled-lines > $R/prof_fern_fused.log 2>&1
   cd $GRAFT_REPO_ROOT
   f=$(find $R/prof_fern_fused -name "*kernel_stats.csv" | head -1); echo "== $f"; [ -n "$f" ] && head -14 $f | cut -c1-200 ;;
 fused_pmc)   # counters of the fused kernel: matrix-pipe busy, wait buckets, LDS bank conflicts (each group its own pass)
   cd /tmp; P=/tmp/pmcf && rm -rf $P && mkdir -p $P
-  CMD="python $GRAFT_REPO_ROOT/bench.py --workload fern --compact fused --overlap 0 --steps 3 --warmup 1 --no-cpu-baseline --no-labelled-lines"
+  CMD="python $GRAFT_REPO_ROOT/bench.py --workload fern --overlap 0 --steps 3 --warmup 1 --no-cpu-baseline --no-labelled-lines"
   timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $P/sq -- $CMD > $P/sq.log 2>&1
   timeout 200 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -d $P/lds -- $CMD > $P/lds.log 2>&1
-  timeout 200 rocprofv3 --kernel-trace --pmc SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_INSTS_SALU SQ_BUSY_CYCLES --output-format csv -d $P/lds2 -- $CMD > $P/lds2.log 2>&1
+  timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/fetch -- $CMD > $P/fetch.log 2>&1
+  timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/write -- $CMD > $P/write.log 2>&1
   cd $GRAFT_REPO_ROOT
   python - $P <<'PY' | tee $R/pmc_fused.txt
 import csv, glob, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = "bwd64r" if "k_bwd64r<" in r["Kernel_Name"] else ("fwd16" if "k_mlp_fwd16" in r["Kernel_Name"] else None)
+        k = "bwd64r" if "k_bwd64r<" in r["Kernel_Name"] else ("fwd64r" if "k_fwd64r" in r["Kernel_Name"] else None)
         if k:
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
 for k in acc:
@@ -79,8 +81,10 @@ for k in acc:
         print("   mfma_util %.3f wait_any %.3f wait_inst %.3f active %.3f" % (a["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 256 * 4), a["SQ_WAIT_ANY"] / wc, a["SQ_WAIT_INST_ANY"] / wc, a["SQ_ACTIVE_INST_ANY"] / wc))
     if a.get("SQ_LDS_IDX_ACTIVE"):
         print("   lds bank conflict cycles / lds active cycles %.3f" % (a["SQ_LDS_BANK_CONFLICT"] / a["SQ_LDS_IDX_ACTIVE"]))
+    if "FETCH_SIZE" in a:   # KiB; FETCH_SIZE counts 64 B per 128-B request for wide reads on gfx950: x2 (MI355X_MICROARCH.md)
+        print("   HBM per launch: FETCH %.3f GB (x2 corr %.3f), WRITE %.3f GB" % (a["FETCH_SIZE"] * 1024 / 1e9, 2 * a["FETCH_SIZE"] * 1024 / 1e9, a["WRITE_SIZE"] * 1024 / 1e9))
 PY
-  tail -3 $P/sq.log $P/lds.log $P/lds2.log | cut -c1-200 ;;
+  ;;
 ab)
   for a in "" "--compact" "--compact recompute" "--precision f16x3_train" "--precision f16x3_train --compact" "--precision f16x3_train --compact recompute"; do
     t=$(echo $a | tr -d " -"); timeout 150 python bench.py --no-cpu-baseline --no-labelled-lines $a > $R/ab_$t.log 2>&1; line $R/ab_$t.log

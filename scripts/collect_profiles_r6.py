@@ -44,10 +44,26 @@ def bench_lines():
 
 
 def trained():
-    j = json.load(open(os.path.join(G, "bench_trained.json")))
-    j["lib_sources_sha16"] = j.get("lib_sources_sha16") or SHA  # (the script loads the library of the tree it runs in)
-    j["_builder_run"] = "scripts/bench_trained.py through gpurun (scripts/gpu_r6.sh trained)"
-    json.dump(j, open(os.path.join(P, TAG + "_bench_trained.json"), "w"), indent=1)
+    for name in ("bench_trained", "bench_trained_overlap1", "bench_trained_4x128", "bench_trained_4x64"):
+        path = os.path.join(G, name + ".json")
+        if not os.path.exists(path):
+            continue
+        j = json.load(open(path))
+        j["lib_sources_sha16"] = j.get("lib_sources_sha16") or SHA  # (the script loads the library of the tree it runs in)
+        j["_builder_run"] = "scripts/bench_trained.py through gpurun (scripts/gpu_r6.sh trained / trained_more)"
+        json.dump(j, open(os.path.join(P, "%s_%s.json" % (TAG, name)), "w"), indent=1)
+
+
+def fern_lines():
+    """scripts/gpu_r6.sh fused: BASELINE configs[3] with the fused one-kernel backward (the default of these nets), dense, over the list."""
+    for path in sorted(glob.glob(os.path.join(G, "fern_*.log"))):
+        name = os.path.basename(path)[5:-4] or "default"
+        json.dump(stamp(last_json_line(path)), open(os.path.join(P, "%s_bench_line_fern_%s.json" % (TAG, name)), "w"), indent=1)
+    if os.path.exists(os.path.join(G, "pmc_fused.txt")):
+        with open(os.path.join(P, TAG + "_pmc_fused.txt"), "w") as f:
+            f.write("# rocprofv3 --pmc passes (each counter group its own run) of python bench.py --workload fern --overlap 0 --steps 3 --warmup 1: the fused\n"
+                    "# backward k_bwd64r and the resident forward k_fwd64r of the 4 x 64 nets, averages per launch (kernel sources %s)\n" % SHA)
+            f.write(open(os.path.join(G, "pmc_fused.txt")).read())
 
 
 def kernel_stats():
@@ -55,7 +71,8 @@ def kernel_stats():
                    ("prof_f16x3_train_dense", "python scripts/bench_trained.py --load-weights W --arms f16x3_train_dense"),
                    ("prof_f16x3_train_compacted", "python scripts/bench_trained.py --load-weights W --arms f16x3_train_compacted"),
                    ("prof_f16x3_train_recomputed", "python scripts/bench_trained.py --load-weights W --arms f16x3_train_recomputed"),
-                   ("prof_fp32_compacted", "python scripts/bench_trained.py --load-weights W --arms fp32_compacted")):
+                   ("prof_fp32_compacted", "python scripts/bench_trained.py --load-weights W --arms fp32_compacted"),
+                   ("prof_fern_fused", "python bench.py --workload fern --overlap 0 --no-cpu-baseline --no-labelled-lines")):
         files = glob.glob(os.path.join(G, d, "**", "*kernel_stats.csv"), recursive=True)
         if not files:
             continue
@@ -148,6 +165,6 @@ def soak():
         W("(round 5, dense, same seeds / data stream / protocol, profiles/r05_psnr_soak.txt: fp32 26.95 / 26.83 dB, f16x3 26.98 / 26.72 dB at 20 000; 543 s / 260 s)\n")
 
 
-for fn in (bench_lines, trained, kernel_stats, parity_records, gpu_tests, pmc, soak):
+for fn in (bench_lines, trained, fern_lines, kernel_stats, parity_records, gpu_tests, pmc, soak):
     maybe(fn)
 print("\n".join(sorted(f for f in os.listdir(P) if f.startswith(TAG))))

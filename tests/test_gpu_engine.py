@@ -172,6 +172,54 @@ def test_engine_backward_modes_compacted_recomputed_auto_track_the_dense_engine(
         assert used["fine"][2] == 0 and used["coarse"][2] == 0, used                   # (fp32: it never pays)
 
 
+def test_engine_on_64_wide_nets_runs_the_fused_backward_by_default():
+    """config/fern.yml's 4 x 64 nets (round 6, csrc/mlp64r.hip): a model whose plan has the LDS-resident image takes the fused one-kernel
+    backward by default; TrainEngine(backward="dense" / "fused" / "fused_compact" / "auto") on the same weights, rays and in-kernel
+    draws: the SAME loss bit for bit (the stash-free resident forward computes what the stash-writing one does), flat gradients within
+    1e-5 of max|g| of the dense engine's (another association of the same fp32 sums); 120 steps on an empty white scene end where the
+    dense engine's do; "auto" runs fused over every sample until the list is known to drop rows, then fused over the list."""
+    import nerf_pytorch_amd as N
+    dev = _dev()
+    cfg = dict(num_layers=4, hidden_size=64, skip_connect_every=3, num_encoding_fn_xyz=6, num_encoding_fn_dir=4)
+    rays, rgba = _rays(1024, dev)
+    white = torch.ones(1024, 3, device=dev)
+    mc, mf = _models(dev, cfg=cfg)
+    assert mc.fused_backward_available() and mc.backward_compaction == 3 and mf.backward_compaction == 3
+    wide = _models(dev)[0]
+    assert not wide.fused_backward_available() and wide.backward_compaction == 0
+    with pytest.raises(Exception, match="fused backward"):
+        wide.set_backward_compaction("fused")
+    res = {}
+    for mode in ("dense", None, "fused", "fused_compact", "auto"):
+        mc, mf = _models(dev, cfg=cfg)
+        eng = N.TrainEngine(mc, mf, 32, 32, noise_std=0.2, white_background=True, lr=1e-3, seed=11, world_size=1, rank=0, backward=mode)
+        if mode != "auto":
+            eng.forward_backward(rays, rgba[:, :3], ray_offset=0)
+            torch.cuda.synchronize()
+            g0, l0 = eng.grad.clone(), eng.loss.clone()
+        else:
+            g0 = l0 = None
+        losses = torch.stack([eng.step(rays, white, ray_offset=0).clone() for _ in range(120)])
+        torch.cuda.synchronize()
+        res[mode] = (g0, l0, losses, eng)
+    gd, ld, sd, _ = res["dense"]
+    assert res[None][3].mc.backward_compaction == 3                       # (backward=None: the models' default)
+    assert torch.equal(res[None][0], res["fused"][0])
+    for mode in ("fused", "fused_compact"):
+        g, l, s, eng = res[mode]
+        assert torch.equal(l, ld), (mode, l, ld)
+        assert float((g - gd).abs().max()) <= 1e-5 * float(gd.abs().max()), (mode, float((g - gd).abs().max()), float(gd.abs().max()))
+    kept = res["fused_compact"][3].backward_sample_counts()
+    assert kept["coarse"][1] == 1024 * 32 and kept["fine"][1] == 1024 * 64 and res["fused"][3].backward_sample_counts()["fine"] is None
+    tail = lambda s: float(s[-20:, 2].mean())  # noqa: E731
+    assert tail(sd) < 0.25 * float(sd[0, 2])
+    for mode in (None, "fused", "fused_compact", "auto"):
+        assert torch.isfinite(res[mode][2]).all()
+        assert abs(tail(res[mode][2]) - tail(sd)) <= 0.05 * tail(sd) + 1e-4, (mode, tail(res[mode][2]), tail(sd))
+    used = res["auto"][3].backward_modes_used
+    assert sum(used["fine"]) == 120 and used["fine"][0] + used["fine"][1] + used["fine"][2] == 0 and used["fine"][4] > 20, used
+
+
 def test_engine_fed_external_draws_equals_in_kernel_draws(gpu):
     """TrainEngine.step(draws=...) (the PSNR experiment's "engine on torch's draws" arm): feeding the engine the numbers
     nerfhip_rng_fill reports for (seed, stream, element) reproduces the in-kernel Philox step bit for bit."""

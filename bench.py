@@ -641,7 +641,8 @@ def main():
             if eff_compact in ("fused", "fused_compact"):
                 # the stash-free forward above; then ONE kernel: the forward again, the data gradient, the weight gradient -- executed
                 # FLOPs; it reads a sample's depth, ray and d(raw) row and writes one partial per workgroup
-                add("bwd64r", "fp32", 2.0 * (2 * fwd_macs + dgrad_macs) * mb, 40 * mb)
+                # (the recomputed forward stops at the activations: fc_alpha's and fc_rgb's rows are not multiplied again)
+                add("bwd64r", "fp32", 2.0 * (2 * fwd_macs + dgrad_macs - (Wd + 3 * (Wd // 2))) * mb, 40 * mb)
                 continue
             add("dgrad", fmt if level >= 3 else "fp32", 2.0 * dgrad_macs * mb, dgrad_b * mb)
             if level == 4 and 64 < Wd <= 256:

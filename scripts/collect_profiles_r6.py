@@ -109,22 +109,23 @@ def pmc():
             shutil.copyfile(path, os.path.join(P, "%s_%s" % (TAG, os.path.basename(path))))
 
 
-def soak():
-    runs = sorted(glob.glob(os.path.join(S, "soak_*_seed*.json")))
+def soak(pattern="soak_*_seed*.json", out="_psnr_soak.txt"):
+    runs = sorted(glob.glob(os.path.join(S, pattern)))
     if not runs:
         raise OSError("no soak runs")
     os.makedirs(os.path.join(P, TAG + "_psnr_soak_runs"), exist_ok=True)
     for r in runs:
         shutil.copyfile(r, os.path.join(P, TAG + "_psnr_soak_runs", os.path.basename(r)))
     docs = [json.load(open(r)) for r in runs]
-    with open(os.path.join(P, TAG + "_psnr_soak.txt"), "w") as f:
+    with open(os.path.join(P, TAG + out), "w") as f:
         W = f.write
         d0 = docs[0]
         W("# scripts/psnr_soak.py (scripts/gpu_r6_soak.sh): %s students, %s, %d rays/iter, lr %g x 0.1^(i/250000), %d iterations on the teacher scene\n"
           % (d0["student"], d0["image"], d0["rays_per_iter"], d0["lr0"], d0["iters"]))
         W("# arms: engine = TrainEngine on fp32 plans; engine_f16tr = the same engine on NERFHIP_PRECISION_F16X3_TRAIN plans; backward: compacted\n"
           "# (set_backward_compaction(True): data and weight gradient over the samples whose d(loss)/d(raw) row is non-zero), recomputed (its\n"
-          "# stash-recomputing form, set_backward_compaction('recompute'): the same gradient bit for bit, another data flow) or dense.\n"
+          "# stash-recomputing form, set_backward_compaction('recompute'): the same gradient bit for bit, another data flow), dense, or -- 64-wide\n"
+          "# fp32 nets -- fused / fused_compact (csrc/mlp64r.hip: one persistent kernel per net, over every sample / over the list).\n"
           "# validation PSNR = -10 log10(coarse_mse + fine_mse) on 3 whole held-out 400x400 views (train_nerf.py:258-260, :339-347)\n")
         W("# kernel sources of the runs: %s   (the tree: %s%s)\n\n" % (sorted({d.get("lib_sources_sha16") for d in docs}), SHA,
                                                                        "" if all(d.get("lib_sources_sha16") == SHA for d in docs) else "  <-- STALE: re-run on the final build"))
@@ -133,9 +134,9 @@ def soak():
         for d in docs:
             for arm in d["arms"]:
                 cols.append((d["seed"], d["backward"], arm, d["arms"][arm]))
-        W("%-7s" % "iter" + "".join("  s%d %-9s %-6s" % (s, b, "fp32" if a == "engine" else "f16x3") for s, b, a, _ in cols) + "\n")
+        W("%-7s" % "iter" + "".join("  s%d %-13s %-6s" % (s, b, "fp32" if a == "engine" else "f16x3") for s, b, a, _ in cols) + "\n")
         for i in its:
-            W("%-7s" % i + "".join("  %22.3f" % c["checkpoints"][i]["val_psnr"] for _, _, _, c in cols) + "\n")
+            W("%-7s" % i + "".join("  %26.3f" % c["checkpoints"][i]["val_psnr"] for _, _, _, c in cols) + "\n")
         W("\n")
         for s, b, a, c in cols:
             dg = c["diagnostics"]
@@ -143,7 +144,7 @@ def soak():
             finite = all(dg[k]["grad_finite"] and dg[k]["loss_finite"] and dg[k].get("kernel_grad_finite", True) for k in ks)
             zf = [dg[k].get("zero_cotangent_fraction") for k in ks if dg[k].get("zero_cotangent_fraction")]
             kg = [dg[k]["kernel_grad_vs_torch_worst_rel"] for k in ks if dg[k].get("kernel_grad_vs_torch_worst_rel") is not None]
-            W("seed %d %-9s %-6s: every gradient / loss finite at %d diagnostics: %s; wall %6.1f s for %s iterations" %
+            W("seed %d %-13s %-6s: every gradient / loss finite at %d diagnostics: %s; wall %6.1f s for %s iterations" %
               (s, b, "fp32" if a == "engine" else "f16x3", len(ks), finite, c["checkpoints"][its[-1]]["train_wall_s"], its[-1]))
             if zf:
                 W("; zero-cotangent fraction coarse %.2f-%.2f, fine %.2f-%.2f" % (min(z["coarse"] for z in zf), max(z["coarse"] for z in zf),
@@ -162,9 +163,19 @@ def soak():
             if (s, "dense", "engine_f16tr") in by and f16:
                 W(";  f16x3 %s - f16x3 dense %+.3f dB" % (f16[0], f16[1] - by[(s, "dense", "engine_f16tr")]))
             W("\n")
-        W("(round 5, dense, same seeds / data stream / protocol, profiles/r05_psnr_soak.txt: fp32 26.95 / 26.83 dB, f16x3 26.98 / 26.72 dB at 20 000; 543 s / 260 s)\n")
+        if d0["student"] == "8x256":
+            W("(round 5, dense, same seeds / data stream / protocol, profiles/r05_psnr_soak.txt: fp32 26.95 / 26.83 dB, f16x3 26.98 / 26.72 dB at 20 000; 543 s / 260 s)\n")
+        else:   # fused / fused over the list against dense, per seed, at the last checkpoint
+            for s in sorted({s for s, _, _, _ in cols}):
+                if (s, "dense", "engine") in by:
+                    W("seed %d at %s: " % (s, last) + ";  ".join("%s - dense %+.3f dB" % (b, v - by[(s, "dense", "engine")])
+                                                                 for (ss, b, a), v in sorted(by.items()) if ss == s and b != "dense") + "\n")
 
 
-for fn in (bench_lines, trained, fern_lines, kernel_stats, parity_records, gpu_tests, pmc, soak):
+def soak64():
+    soak("soak64_*_seed*.json", "_psnr_soak_4x64.txt")
+
+
+for fn in (bench_lines, trained, fern_lines, kernel_stats, parity_records, gpu_tests, pmc, soak, soak64):
     maybe(fn)
 print("\n".join(sorted(f for f in os.listdir(P) if f.startswith(TAG))))

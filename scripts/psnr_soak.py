@@ -165,8 +165,9 @@ def run(arm, seed, iters, check, diag_every, student, lr0, poses, imgs, train, v
         mc.set_training_precision("f16x3_train")
         mf.set_training_precision("f16x3_train")
     # (round 6: the compacted backward changes the summation order of every weight gradient -- its own long run)
-    mc.set_backward_compaction("recompute" if compact == "recompute" else bool(compact))
-    mf.set_backward_compaction("recompute" if compact == "recompute" else bool(compact))
+    mode = {"compact": True, None: False, False: False}.get(compact, compact)   # ("recompute" / "fused" / "fused_compact": by name)
+    mc.set_backward_compaction(mode)
+    mf.set_backward_compaction(mode)
     eng = N.TrainEngine(mc, mf, NC, NF, perturb=True, white_background=True, noise_std=0.2, lr=lr0, seed=seed)
     opts = N.make_options(NC, NF, white_background=True)
     stream = data_stream(poses, imgs, train, seed)
@@ -212,7 +213,7 @@ if __name__ == "__main__":
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--check", type=int, default=2000)
     ap.add_argument("--diag", type=int, default=1000)
-    ap.add_argument("--compact", nargs="?", const="compact", default=None, choices=("compact", "recompute"),
+    ap.add_argument("--compact", nargs="?", const="compact", default=None, choices=("compact", "recompute", "fused", "fused_compact"),
                     help="both arms with the compacted backward (set_backward_compaction(True)); `recompute`: its stash-recomputing form")
     a = ap.parse_args()
     student = dict(num_layers=a.layers, hidden_size=a.hidden, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4)
@@ -220,7 +221,7 @@ if __name__ == "__main__":
     poses, imgs, train, val = P4.teacher_dataset()
     views = val[:P4.VAL_PER_CHECK]
     res = dict(seed=a.seed, iters=a.iters, lr0=a.lr, student="%dx%d" % (a.layers, a.hidden), rays_per_iter=RAYS, image="%dx%d" % (H, W),
-               diag_rays=DIAG_RAYS, backward={None: "dense", "compact": "compacted", "recompute": "recomputed"}[a.compact], lib_sources_sha16=lib_sources_sha16(),
+               diag_rays=DIAG_RAYS, backward={None: "dense", "compact": "compacted", "recompute": "recomputed"}.get(a.compact, a.compact), lib_sources_sha16=lib_sources_sha16(),
                lib_version=L.get_lib().version(), arms={})
     for arm in a.arms.split(","):
         res["arms"][arm] = run(arm, a.seed, a.iters, check, a.diag, student, a.lr, poses, imgs, train, views, compact=a.compact)

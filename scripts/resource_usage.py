@@ -13,7 +13,7 @@ print("%-78s %5s %5s %5s %7s %4s %6s %6s %6s" % ("kernel", "SGPR", "VGPR", "AGPR
                                                  "LDS"))
 import sys
 FILES = sys.argv[1:] or (
-    "mlp16.hip", "mlp16_w512.hip", "mlp16_ext.hip", "mlp_f16w.hip", "wgrad_f16.hip", "pack_f16.hip", "wgrad.hip", "mlp.hip", "render.hip", "sample.hip", "compact.hip", "elementwise.hip", "dataio.hip")
+    "mlp16.hip", "mlp16_w512.hip", "mlp16_ext.hip", "mlp64r.hip", "mlp_f16w.hip", "wgrad_f16.hip", "pack_f16.hip", "wgrad.hip", "mlp.hip", "render.hip", "sample.hip", "compact.hip", "elementwise.hip", "dataio.hip")
 for f in FILES:
     extra = ["-fno-slp-vectorize", "-mllvm", "-instcombine-max-copied-from-constant-users=4000"] if f == "wgrad.hip" else []  # (as the Makefile does)
     err = subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + extra + ["-c", f, "-o", "/dev/null"], cwd=HERE, capture_output=True,

@@ -299,6 +299,9 @@ MLP_GEOMETRIES = {
     "deep8x64_skip4": model_cfg(8, 64, 4, 10, 4),
     "novw3x64_skip1": model_cfg(3, 64, 1, 10, 0, use_viewdirs=False),
     "one_layer_64": model_cfg(1, 64, 4, 4, 2),
+    # ... and the other instantiations of the fused backward of 64-wide nets (csrc/mlp64r.hip: one kernel per layer count 1..4)
+    "two_layer_64": model_cfg(2, 64, 4, 10, 4),
+    "three_layer_48": model_cfg(3, 48, 4, 6, 2),
     # hidden_size in (256, 512]: the 512-wide instances (one wave per SIMD, accumulators in AGPRs), split weight-gradient jobs
     "wide3x512_skip2": model_cfg(3, 512, 2, 10, 4),
     "wide2x320": model_cfg(2, 320, 4, 6, 2),
@@ -527,6 +530,44 @@ def case_render_compacted(b, cfg, n, nc, nf, precision=0, seed=9, white=False, n
                 assert d <= ctol, ("compacted render vs dense", mode, key, k, d, ctol)
             note("render_compacted_%s_%s_%s" % (tag or n, ARITH_NAME[precision], b.name),
                  **{"%s %s" % (mode, name): worst, "zero fraction " + name: 1.0 - kept / float(tot)})
+    for p in (pc, pf):
+        b.lib.plan_destroy(p)
+
+
+def case_render_fused_edges(b, cfg, seed=17):
+    """Edges of the fused backward (nerfhip_plan_set_bwd_compaction 3 / 4, csrc/mlp64r.hip): (i) all-zero cotangents -- mode 3 multiplies
+    zeros (every d(pre-activation) is an exact zero), mode 4's list is empty (no round runs; the partials are written all the same) --
+    both gradients are EXACTLY zero; (ii) a batch smaller than one 64-sample round (one ray, 8 + 8 samples) against the dense backward."""
+    gen = rng(seed)
+    pc, _, _, packed_c = mlp_setup(b, cfg, seed=seed + 1)
+    pf, _, _, packed_f = mlp_setup(b, cfg, seed=seed + 2)
+    ctol = TL.bound("unit.compact_vs_dense", "fp32")
+    for n, nc, nf in ((1, 8, 8), (5, 16, 8)):
+        ro = torch.tensor([0.2, -0.1, 4.0]).expand(n, 3) + 0.05 * torch.randn(n, 3, generator=gen)
+        rd = torch.randn(n, 3, generator=gen) * 0.3
+        rd[:, 2] = -1.0
+        rays = O.pack_rays(ro, rd, 2.0, 6.0, rd).numpy()
+        rnp = dict(t_rand=torch.rand(n, nc, generator=gen).numpy(), noise_coarse=torch.randn(n, nc, generator=gen).numpy(),
+                   u=torch.rand(n, nf, generator=gen).numpy(), noise_fine=torch.randn(n, nc + nf, generator=gen).numpy())
+        opt = dict(num_coarse=nc, num_fine=nf, perturb=True, lindisp=False, white_background=False, noise_std=0.0)
+        tgt = torch.rand(n, 3, generator=gen).numpy()
+        res = {}
+        for mode in (False, "fused", "fused_compact"):
+            b.set_compaction(pc, mode)
+            b.set_compaction(pf, mode)
+            fwd = b.render(pc, pf, packed_c, packed_f, rays, opt, rnp, training=True)
+            if mode is False:
+                _, gc, gf = b.mse_loss(fwd["rgb_coarse"], fwd["rgb_fine"], tgt)
+            res[mode] = b.render(pc, pf, packed_c, packed_f, rays, opt, rnp, training=True, g_rgb=(gc, gf))
+            zero = b.render(pc, pf, packed_c, packed_f, rays, opt, rnp, training=True, g_rgb=(np.zeros_like(gc), np.zeros_like(gf)))
+            for key in ("g_params_coarse", "g_params_fine"):
+                assert not zero[key].any(), ("zero cotangents", mode, key, float(np.abs(zero[key]).max()))
+        for mode in ("fused", "fused_compact"):
+            for key, plan in (("g_params_coarse", pc), ("g_params_fine", pf)):
+                gd, gk = b.unflatten(plan, res[False][key]), b.unflatten(plan, res[mode][key])
+                for k in gd:
+                    d = float(np.abs(gk[k] - gd[k]).max()) / (float(np.abs(gd[k]).max()) + 1e-30)
+                    assert d <= ctol, ("fused vs dense, small batch", n, mode, key, k, d)
     for p in (pc, pf):
         b.lib.plan_destroy(p)
 

@@ -143,6 +143,9 @@ def test_fused_backward_of_64_wide_nets(emu):
     P.case_render_compacted(emu, P.MLP_GEOMETRIES["llff4x64_skip3_L6"], n=37, nc=24, nf=8, tag="llff64_fused_rounds_emu", noise=1.0, fused=True)
     P.case_render_compacted(emu, P.MLP_GEOMETRIES["one_layer_64"], n=20, nc=16, nf=16, tag="one64_fused_emu", noise=0.0, fused=True)
     P.case_render_compacted(emu, P.MLP_GEOMETRIES["narrow3x40"], n=17, nc=24, nf=16, tag="narrow40_fused_emu", fused=True)
+    P.case_render_compacted(emu, P.MLP_GEOMETRIES["two_layer_64"], n=11, nc=16, nf=16, tag="two64_fused_emu", fused=True)
+    P.case_render_compacted(emu, P.MLP_GEOMETRIES["three_layer_48"], n=11, nc=16, nf=8, tag="three48_fused_emu", white=True, fused=True)
+    P.case_render_fused_edges(emu, P.MLP_GEOMETRIES["llff4x64_skip3_L6"])
     # ... and d(loss)/d(rays) with the fused modes set: the ray gradient needs the d(pre-activation) images -> mode 2's data flow
     P.case_ray_grad(emu, P.MLP_GEOMETRIES["llff4x64_skip3_L6"], n=12, nc=8, nf=8, compact="fused_compact")
     for name in ("default4x128", "novw3x64_skip1", "deep8x64_skip4"):   # 128 wide / no view directions / 8 layers with a skip layer

@@ -206,6 +206,9 @@ def test_fused_backward_of_64_wide_nets(gpu):
     P.case_render_compacted(gpu, P.MLP_GEOMETRIES["llff4x64_skip3_L6"], n=777, nc=24, nf=9, tag="llff777_fused", white=True, fused=True)
     P.case_render_compacted(gpu, P.MLP_GEOMETRIES["one_layer_64"], n=300, nc=16, nf=16, tag="one64_fused", noise=0.0, fused=True)
     P.case_render_compacted(gpu, P.MLP_GEOMETRIES["narrow3x40"], n=500, nc=24, nf=16, tag="narrow40_fused", fused=True)
+    P.case_render_compacted(gpu, P.MLP_GEOMETRIES["two_layer_64"], n=400, nc=32, nf=16, tag="two64_fused", fused=True)
+    P.case_render_compacted(gpu, P.MLP_GEOMETRIES["three_layer_48"], n=400, nc=16, nf=24, tag="three48_fused", white=True, fused=True)
+    P.case_render_fused_edges(gpu, P.MLP_GEOMETRIES["llff4x64_skip3_L6"])
     P.case_ray_grad(gpu, P.MLP_GEOMETRIES["llff4x64_skip3_L6"], n=12, nc=8, nf=8, compact="fused_compact")
 
 

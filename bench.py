@@ -398,7 +398,7 @@ def main():
                          "forward; --mode train --precision f16x3_fwd the training forward, f16x3_fwd_dgrad + the data-gradient chain, "
                          "f16x3_train + the large weight-gradient blocks.  A+B: coarse net A, fine net B.  Separate, labelled lines: "
                          "the driver's default stays fp32")
-    ap.add_argument("--compact", nargs="?", const="gather", default=None, choices=("dense", "gather", "recompute", "fused", "fused_compact", "auto"),
+    ap.add_argument("--compact", nargs="?", const="gather", default=None, choices=("dense", "gather", "recompute", "fused", "fused_compact", "fused_stash", "auto"),
                     help="train: compacted backward (FlexibleNeRFModel.set_backward_compaction): data and weight gradient over the sample "
                          "points whose d(loss)/d(raw) row is not all zero; `recompute`: additionally a stash-free training forward, the "
                          "backward re-runs the forward for the kept samples; `auto`: TrainEngine(backward='auto') picks dense / compacted / recomputed per net "
@@ -489,7 +489,7 @@ def main():
             mc.set_training_precision(prec_c)
         if prec_f != "fp32":
             mf.set_training_precision(prec_f)
-        if args.compact in ("dense", "gather", "recompute", "fused", "fused_compact"):
+        if args.compact in ("dense", "gather", "recompute", "fused", "fused_compact", "fused_stash"):
             # (fused / fused_compact: the one-kernel backward of 64-wide fp32 nets, csrc/mlp64r.hip -- raises for other geometries; it
             # is those nets' default: `dense` asks for the three-kernel backward)
             mc.set_backward_compaction({"dense": False, "gather": True}.get(args.compact, args.compact))
@@ -576,7 +576,8 @@ def main():
     eff_compact = None if args.compact == "dense" else args.compact
     if args.mode == "train" and args.compact in (None, "auto"):   # (None: the models' defaults -- fused where a plan has it)
         modes = [m.backward_compaction for m in (mc, mf)]
-        eff_compact = ("fused_compact" if 4 in modes else "fused" if 3 in modes else "recompute" if 2 in modes else ("gather" if 1 in modes else None))
+        eff_compact = ("fused_compact" if 4 in modes else "fused_stash" if 5 in modes else "fused" if 3 in modes else "recompute" if 2 in modes
+                       else ("gather" if 1 in modes else None))
     # What the per-launch HIP events of the timed region cost: the same K steps once more WITHOUT them (N = 1 only).  Nothing at
     # 27 ms per step; 0.28 ms of a 2.0-ms fern step (a step is ~40 launches, each with two event records on the host's path).
     unprofiled = None
@@ -630,8 +631,11 @@ def main():
             kept_f = kept["fine"][0] if kept["fine"] else m_f
         for m, mb, prec in ((m_c, kept_c, prec_c), (m_f, kept_f, prec_f)):
             fmt, level = precision_level(prec)
+            r64_stash_b = 4 * (64 * Ln + 192)   # (the register-image stash of mode 5, csrc/nh_r64.h: bytes per sample point)
             if args.mode == "train" and eff_compact in ("fused", "fused_compact"):
                 add("fwd", "fp32", 2.0 * fwd_macs * m, 20 * m)   # (stash-free)
+            elif args.mode == "train" and eff_compact == "fused_stash":
+                add("fwd", "fp32", 2.0 * fwd_macs * m, (20 + r64_stash_b) * m)
             elif args.mode == "train" and eff_compact == "recompute":  # (stash-free pass over all samples + a stash-writing pass over the kept ones)
                 add("fwd", fmt if level >= 1 else "fp32", 2.0 * fwd_macs * (m + mb), 20 * m + stash_b * mb, 2)
             else:
@@ -643,6 +647,10 @@ def main():
                 # FLOPs; it reads a sample's depth, ray and d(raw) row and writes one partial per workgroup
                 # (the recomputed forward stops at the activations: fc_alpha's and fc_rgb's rows are not multiplied again)
                 add("bwd64r", "fp32", 2.0 * (2 * fwd_macs + dgrad_macs - (Wd + 3 * (Wd // 2))) * mb, 40 * mb)
+                continue
+            if eff_compact == "fused_stash":
+                # ONE kernel: the data gradient and the weight gradient over the register-image stash the forward left (nothing recomputed)
+                add("bwd64r", "fp32", 2.0 * (fwd_macs + dgrad_macs) * mb, (16 + r64_stash_b) * mb)
                 continue
             add("dgrad", fmt if level >= 3 else "fp32", 2.0 * dgrad_macs * mb, dgrad_b * mb)
             if level == 4 and 64 < Wd <= 256:
@@ -711,6 +719,8 @@ def main():
             step_bytes = stash_b * (m_c + m_f) + (dgrad_b + wgrad_b) * (kept_c + kept_f)
             if eff_compact in ("fused", "fused_compact"):
                 step_bytes = 20 * (m_c + m_f) + 40 * (kept_c + kept_f)
+            if eff_compact == "fused_stash":
+                step_bytes = (36 + 8 * (64 * Ln + 192)) * (m_c + m_f)
             if args.workload == "lego":
                 workload = ("lego %dx%d synthetic views (BASELINE configs[%d]): %d rays/GPU/iter (%d over all GPUs), %d coarse + %d "
                             "fine samples, %dx%d coarse+fine nets, perturb, noise 0.2, Adam, full iteration"
@@ -761,6 +771,8 @@ def main():
             res["backward"] = {None: "dense", "dense": "dense", "gather": "compacted", "recompute": "compacted, stash recomputed for the kept samples",
                                "fused": "fused (one persistent kernel per net: forward recomputed, data gradient, weight gradient; no stash, no d(pre-activation) images)",
                                "fused_compact": "fused, over the samples whose d(loss)/d(raw) row is non-zero",
+                               "fused_stash": "fused over a register-image stash (one persistent kernel per net: data gradient + weight gradient; the forward leaves the chain's "
+                                              "registers in HBM, 1.8 KB per sample point, instead of being recomputed)",
                                "auto": "auto (per net and step: dense / compacted / recomputed by the zero fraction of earlier steps)"}[args.compact if args.compact else eff_compact]
             if args.compact == "auto":
                 res["backward_modes_used"] = dict(steps_dense_compacted_recomputed=eng.backward_modes_used, last_known_zero_fraction=eng._zero_frac)

@@ -254,7 +254,13 @@ int64_t nerfhip_plan_bwd_scratch_bytes(nerfhip_plan_t plan, int64_t m);
  *           sums the weight gradients in registers -- no stash, no d(pre-activation) images, no separate weight-gradient kernel; a
  *           fixed-order reduction of one partial per workgroup follows (no atomics: bit-reproducible).  Every sample is differentiated.
  *   on = 4  fused over the list: the same kernel walks the samples whose d(raw) row is not all zero (the list of mode 1).
- *           A render backward that must leave the d(pre-activation) images (nerfhip_render_bwd_rays with g_rays) runs 3 / 4 as 2;
+ *   on = 5  fused over a register-image stash (same plans as 3): the training forward -- the persistent LDS-resident kernel -- also
+ *           stores the registers the backward's chain works on (both encodings, every layer's activations: 64 L + 192 floats per
+ *           sample point, whole-KiB stores, inside the plan's stash region of the render workspace), and the fused kernel reads them
+ *           back (each array re-loaded for the next 64 samples right behind its last use) instead of recomputing the forward.  Same
+ *           arithmetic on the same values in the same order as 3: the gradient is bit-identical; a third fewer multiplies in the
+ *           backward for 2 x 1.8 KB of HBM traffic per sample point.  Every sample is differentiated.
+ *           A render backward that must leave the d(pre-activation) images (nerfhip_render_bwd_rays with g_rays) runs 3 / 4 / 5 as 2;
  *           nerfhip_mlp_fwd / nerfhip_mlp_bwd treat them as 1. */
 int nerfhip_plan_set_bwd_compaction(nerfhip_plan_t plan, int on);
 int nerfhip_plan_bwd_compaction(nerfhip_plan_t plan);

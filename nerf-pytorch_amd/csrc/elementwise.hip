@@ -19,9 +19,9 @@ void nh_set_error(const char* fmt, ...) {
 extern "C" const char* nerfhip_last_error(void) { return g_err; }
 extern "C" int nerfhip_version(void) {
 #ifdef NH_DIAG  // (make variant: an A/B or diagnostic build -- nh_diag.h; the Python package refuses it)
-    return 103 + NH_DIAG_VERSION_FLAG;
+    return 104 + NH_DIAG_VERSION_FLAG;
 #else
-    return 103;  // (102: round 6 -- the compacted backward's three entry points; 103: + the fused backward modes 3 / 4 of 64-wide nets)
+    return 104;  // (102: round 6 -- the compacted backward's three entry points; 103: + the fused backward modes 3 / 4 of 64-wide nets; 104: + mode 5)
 #endif
 }
 extern "C" int nerfhip_is_emulated(void) {

@@ -146,7 +146,8 @@ extern "C" int nerfhip_render_fwd_parts(nerfhip_plan_t pc, nerfhip_plan_t pf, co
         in.S = nc;
         // (a plan whose backward recomputes the stash for the samples it keeps -- nerfhip_plan_set_bwd_compaction(plan, 2) -- runs the
         // stash-free forward here)
-        rc = nh_mlp_forward(pc, packed_c, in, n * nc, raw_c, (training && !nh_mlp_recomputes(pc, n * nc)) ? (float*)(ws + w.stash_c) : nullptr, stream);
+        rc = training ? nh_mlp_forward_training(pc, packed_c, in, n * nc, raw_c, (float*)(ws + w.stash_c), stream)
+                      : nh_mlp_forward(pc, packed_c, in, n * nc, raw_c, nullptr, stream);
         if (rc) return rc;
         rc = nerfhip_volume_render_fwd(raw_c, z_c, rays + 3, stride, n, nc, cfg->noise_std, r->noise_coarse, seed, 1u,
                                        ray_offset, cfg->white_background, out->rgb_coarse, out->disp_coarse,
@@ -162,7 +163,8 @@ extern "C" int nerfhip_render_fwd_parts(nerfhip_plan_t pc, nerfhip_plan_t pf, co
         if (rc) return rc;
         in.z = z_f;
         in.S = sf;
-        rc = nh_mlp_forward(pf, packed_f, in, n * sf, raw_f, (training && !nh_mlp_recomputes(pf, n * sf)) ? (float*)(ws + w.stash_f) : nullptr, stream);
+        rc = training ? nh_mlp_forward_training(pf, packed_f, in, n * sf, raw_f, (float*)(ws + w.stash_f), stream)
+                      : nh_mlp_forward(pf, packed_f, in, n * sf, raw_f, nullptr, stream);
         if (rc) return rc;
         rc = nerfhip_volume_render_fwd(raw_f, z_f, rays + 3, stride, n, sf, cfg->noise_std, r->noise_fine, seed, 3u,
                                        ray_offset, cfg->white_background, out->rgb_fine, out->disp_fine, out->acc_fine,

@@ -115,8 +115,20 @@ static int mlp_forward_any(nerfhip_plan* p, const float* packed, const NhMlpInpu
         return nh_mlp_forward_f16w(p, packed, in, M, out, stash, stream, list);
     }
     // 64-wide nets with an LDS-resident image (nh_r64.h): the persistent forward whenever no stash is asked for
-    if (p->r64_off >= 0 && !stash && !list) return nh_mlp64r_forward(p, packed, in, M, out, stream);
+    if (p->r64_off >= 0 && !stash && !list) return nh_mlp64r_forward(p, packed, in, M, out, nullptr, stream);
     return nh_mlp16_forward(p, packed, in, M, out, stash, stream, list);
+}
+
+// mode 5 inside the fused render: fp32 plan with a resident image whose register-image stash fits the plan's stash region
+static bool fused_stashed(const nerfhip_plan* p, int64_t M) {
+    return p->bwd_compact == 5 && p->r64_off >= 0 && nh_r64_stash_fits(p) && nh_mlp_recomputes(p, M);
+}
+
+int nh_mlp_forward_training(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
+                            nerfhip_stream_t stream) {
+    NH_REQUIRE(p && out && stash, "mlp_fwd: bad arguments");
+    if (M > 0 && fused_stashed(p, M)) return nh_mlp64r_forward(p, packed, in, M, out, stash, stream);
+    return mlp_forward_any(p, packed, in, M, out, nh_mlp_recomputes(p, M) ? nullptr : stash, stream, nullptr);
 }
 
 // `recompute`: the forward of this launch wrote no stash (nh_mlp_recomputes); `in` names its input again
@@ -131,6 +143,8 @@ static int mlp_backward_any(nerfhip_plan* p, const float* packed, const NhMlpInp
     int rc = NERFHIP_OK;
     if (recompute && p->bwd_compact >= 3 && p->r64_off >= 0 && !need_images) {
         // the fused backward (mlp64r.hip): forward recomputed, data gradient and weight gradient in one kernel; mode 4 walks the list
+        if (fused_stashed(p, M))  // mode 5: the forward left the register-image stash; nothing is recomputed, every sample is walked
+            return nh_mlp64r_backward(p, packed, *recompute, g_out, M, scratch + fused_partial_offset(p, nt), g_params, nullptr, stash, stream);
         NhCompact lview;
         const NhCompact* lx = nullptr;
         if (p->bwd_compact == 4) {
@@ -139,7 +153,7 @@ static int mlp_backward_any(nerfhip_plan* p, const float* packed, const NhMlpInp
             if (rc) return rc;
             lx = &lview;
         }
-        return nh_mlp64r_backward(p, packed, *recompute, g_out, M, scratch + fused_partial_offset(p, nt), g_params, lx, stream);
+        return nh_mlp64r_backward(p, packed, *recompute, g_out, M, scratch + fused_partial_offset(p, nt), g_params, lx, nullptr, stream);
     }
     // compacted backward: list the samples whose d(raw output) row is not all zero; every kernel below then walks that list
     NhCompact cview;
@@ -193,10 +207,12 @@ int nh_mlp_backward_recompute(nerfhip_plan* p, const float* packed, const NhMlpI
 
 extern "C" int nerfhip_plan_set_bwd_compaction(nerfhip_plan_t plan, int on) {
     NH_REQUIRE(plan, "plan_set_bwd_compaction: plan is NULL");
-    NH_REQUIRE(on >= 0 && on <= 4, "plan_set_bwd_compaction: 0 (dense), 1 (compacted), 2 (compacted, the render path recomputes the stash), "
-               "3 (the fused backward of 64-wide nets) or 4 (the fused backward over the compacted list)");
-    NH_REQUIRE(on < 3 || plan->r64_off >= 0, "plan_set_bwd_compaction: the fused backward (3, 4) exists for fp32 plans of hidden_size <= 64 with view "
+    NH_REQUIRE(on >= 0 && on <= 5, "plan_set_bwd_compaction: 0 (dense), 1 (compacted), 2 (compacted, the render path recomputes the stash), "
+               "3 (the fused backward of 64-wide nets), 4 (the fused backward over the compacted list) or 5 (the fused backward over a "
+               "register-image stash)");
+    NH_REQUIRE(on < 3 || plan->r64_off >= 0, "plan_set_bwd_compaction: the fused backward (3, 4, 5) exists for fp32 plans of hidden_size <= 64 with view "
                "directions, at most 4 layers, no skip layer and num_encoding_fn_xyz <= 10 / num_encoding_fn_dir <= 4");
+    NH_REQUIRE(on != 5 || nh_r64_stash_fits(plan), "plan_set_bwd_compaction: the register-image stash of mode 5 does not fit this plan's stash region");
     plan->bwd_compact = on;
     return NERFHIP_OK;
 }

@@ -62,8 +62,24 @@ struct Bwd64rArgs {
     float* partial;      // [gridDim.x][r64_partial_floats(L)]
     const int* cidx;     // compaction list or NULL (dense: slot c is sample c)
     const int* cstats;
+    const float* stash;  // k_bwd64r<L, true>: the register-image stash k_fwd64r<L, true> wrote (nh_r64.h), dense launches only
     unsigned long long* clk;
 };
+
+// NQ quads (four registers each) of this lane from / to a register-image tile (p = tile + quad * 256 + lane * 4)
+template <int NQ>
+NH_DEVICE void quads_load(float* dst, const float* p) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const float4 t4 = *(const float4*)(p + q * 256);
+        dst[4 * q] = t4.x, dst[4 * q + 1] = t4.y, dst[4 * q + 2] = t4.z, dst[4 * q + 3] = t4.w;
+    }
+}
+template <int NQ>
+NH_DEVICE void quads_store(float* p, const float* src) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) nh_store4(p + q * 256, src[4 * q], src[4 * q + 1], src[4 * q + 2], src[4 * q + 3]);
+}
 
 #ifdef NH_PHASE_TIMING  // (`make dbg` builds only: shader cycles per phase, summed over the waves of a role; scripts/r64_phases.py)
 __device__ unsigned long long g_ph64[16];
@@ -280,7 +296,12 @@ NH_DEVICE float gate_pos(float v, float h) {
     return u != 0u ? v : 0.0f;
 }
 
-template <int L>
+// ST: the stashed variant (mode 5).  The chain waves do not recompute the forward: X, D, H_0 .. H_{L-1}, FEAT, DIRH of their tile come from
+// the register-image stash the training forward (k_fwd64r<L, true>) left, each array re-loaded for the NEXT round right behind its last
+// use in this one -- the registers are the same, the loads have a whole round to land, and they arrive in the order the next round
+// needs them (DIRH, D, d(raw) first, X last).  The weight-gradient waves prepare nothing.  Same arithmetic on the same values in the
+// same order as the recomputing variant: the gradient is bit-identical.
+template <int L, bool ST>
 NH_KERNEL void NH_LB(64 * NWV, 2) k_bwd64r(Bwd64rArgs a) {
     constexpr R64Layout Y = r64_layout(L);
     constexpr int NU = r64_units(L), NB = r64_bias_regs(L), TL = R64_TILES;
@@ -338,14 +359,14 @@ NH_KERNEL void NH_LB(64 * NWV, 2) k_bwd64r(Bwd64rArgs a) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) nh_store4(pass + (4 + q) * 256, Dn[4 * q], Dn[4 * q + 1], Dn[4 * q + 2], Dn[4 * q + 3]);
         };
-        if ((int)blockIdx.x < rounds) {
+        if (!ST && (int)blockIdx.x < rounds) {
             prep((int)blockIdx.x);
             hand_over();
         }
         nh_block_sync();  // (the first round's hand-over is in LDS)
         PH_DECL;
         for (int round = (int)blockIdx.x; round < rounds; round += (int)gridDim.x) {
-            const bool more = round + (int)gridDim.x < rounds;
+            const bool more = !ST && round + (int)gridDim.x < rounds;
             if (more) prep(round + (int)gridDim.x);
             PH(3);  // [11] preparing the next round
             // step a: slot 0 POUT, 1..2 PDIR, 3..4 DIRH, 5..6 D -- fc_rgb (waves 0, 1: POUT x DIRH block v),
@@ -418,13 +439,48 @@ NH_KERNEL void NH_LB(64 * NWV, 2) k_bwd64r(Bwd64rArgs a) {
             m_next = a.cidx ? a.cidx[slot] : (slot < n_slots ? slot : (int)a.M - 1);
         };
         if ((int)blockIdx.x < rounds) fetch_sample((int)blockIdx.x);
+        // ST: the tile of this wave in round `rd` inside the register-image stash (a tile behind the last one: the last one -- finite
+        // values under zero cotangents), and the d(raw) row of this lane's sample there (slot = sample: ST launches are dense)
+        constexpr int TS = r64_stash_tile_floats(L);
+        const int64_t tiles_total = (a.M + 15) / 16;
+        auto stash_tile = [&](int rd) {
+            const int64_t t = (int64_t)rd * TL + wave;
+            return a.stash + (size_t)(t < tiles_total ? t : tiles_total - 1) * TS + lane * 4;
+        };
+        float X[NH16_KRX], Dd[NH16_KRD], H[L][16], FEAT[16], DIRH[8];
+        float gn0 = 0.f, gn1 = 0.f, gn2 = 0.f, gn3 = 0.f;  // (ST) d(raw) of the round to come
+        auto fetch_go = [&](int rd) {
+            const int slot = rd * (16 * TL) + wave * 16 + j;
+            gn0 = gn1 = gn2 = gn3 = 0.f;
+            if (slot < n_slots) {
+                const float4 t4 = *(const float4*)(a.g_out + (size_t)slot * 4);
+                gn0 = t4.x, gn1 = t4.y, gn2 = t4.z, gn3 = t4.w;
+            }
+        };
+        if (ST && (int)blockIdx.x < rounds) {
+            const float* const t0 = stash_tile((int)blockIdx.x);
+            quads_load<2>(DIRH, t0 + r64_sq_dirh(L) * 256);
+            quads_load<2>(Dd, t0 + R64_SQ_D * 256);
+            fetch_go((int)blockIdx.x);
+            quads_load<4>(FEAT, t0 + r64_sq_feat(L) * 256);
+#pragma unroll
+            for (int i = L - 1; i >= 0; --i) quads_load<4>(H[i], t0 + (R64_SQ_H + 4 * i) * 256);
+            quads_load<4>(X, t0 + R64_SQ_X * 256);
+        }
         nh_block_sync();  // (the first round's hand-over is in LDS)
         PH_DECL;
         for (int round = (int)blockIdx.x; round < rounds; round += (int)gridDim.x) {
             const bool valid = round * (16 * TL) + wave * 16 + j < n_slots;
             const int m = m_next;
+            const bool st_more = ST && round + (int)gridDim.x < rounds;
+            const float* const tn = st_more ? stash_tile(round + (int)gridDim.x) : nullptr;
+            float go0 = 0.f, go1 = 0.f, go2 = 0.f, go3 = 0.f;
+            f32x4 acc[4];
+            if (ST) {
+                go0 = gn0, go1 = gn1, go2 = gn2, go3 = gn3;
+                PH(0);
+            } else {
             // the encodings of this tile: prepared by the weight-gradient wave of this SIMD during the round before
-            float X[NH16_KRX], Dd[NH16_KRD];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 t4 = *(const float4*)(pass + q * 256);
@@ -437,15 +493,12 @@ NH_KERNEL void NH_LB(64 * NWV, 2) k_bwd64r(Bwd64rArgs a) {
             }
             if (round + (int)gridDim.x < rounds) fetch_sample(round + (int)gridDim.x);
             // d(loss)/d(raw output) of this lane's sample: asked for here, needed when the backward starts
-            float go0 = 0.f, go1 = 0.f, go2 = 0.f, go3 = 0.f;
             if (valid) {
                 const float4 t4 = *(const float4*)(a.g_out + (size_t)m * 4);
                 go0 = t4.x, go1 = t4.y, go2 = t4.z, go3 = t4.w;
             }
             PH(0);  // [0] hand-over read
             // ---- forward, registers only (nerf/models.py:233-256); H[0] = layer1(x) has no activation (:238)
-            f32x4 acc[4];
-            float H[L][16];
             bias_init<4>(acc, lds + Y.b_l1 + 4 * g);
             gemm_f<NH16_KRX, 4, R64_S>(lds + Y.l1 + lf, fx, X, acc);
 #pragma unroll
@@ -457,7 +510,6 @@ NH_KERNEL void NH_LB(64 * NWV, 2) k_bwd64r(Bwd64rArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) H[i + 1][r] = nh_relu(acc[r >> 2][r & 3]);
             }
-            float FEAT[16], DIRH[8];
             bias_init<4>(acc, lds + Y.b_feat + 4 * g);
             gemm_f<16, 4, R64_S>(lds + Y.head + lf, fx, H[L - 1], acc);
 #pragma unroll
@@ -467,6 +519,7 @@ NH_KERNEL void NH_LB(64 * NWV, 2) k_bwd64r(Bwd64rArgs a) {
             gemm_f<NH16_KRD, 2, R64_SD>(lds + Y.dir + 64 + lfd, fx, Dd, acc);
 #pragma unroll
             for (int r = 0; r < 8; ++r) DIRH[r] = nh_relu(acc[r >> 2][r & 3]);
+            }
 
             PH(1);  // [1] forward
             // ---- backward.  d(DIRH pre-activation) = relu'(DIRH) * fc_rgb^T d(rgb raw): ONE k-step, group g carries d(rgb raw)[g]
@@ -488,6 +541,11 @@ NH_KERNEL void NH_LB(64 * NWV, 2) k_bwd64r(Bwd64rArgs a) {
             ex_put_blocks<2>(pw, 3, DIRH);
             ex_put_blocks<2>(pw, 5, Dd);
             nh_block_sync();  // (publish)
+            if (st_more) {  // (their last use is behind them: the next round's, into the same registers)
+                quads_load<2>(DIRH, tn + r64_sq_dirh(L) * 256);
+                quads_load<2>(Dd, tn + R64_SQ_D * 256);
+                fetch_go(round + (int)gridDim.x);
+            }
             PH(4);  // [4] operand stores + publish barrier
             // d(FEAT pre-activation) = relu'(FEAT) * layers_dir[:, :64]^T PDIR
             float PFEAT[16];
@@ -501,6 +559,7 @@ NH_KERNEL void NH_LB(64 * NWV, 2) k_bwd64r(Bwd64rArgs a) {
             PH(3);
             ex_put_blocks<4>(pw, 3, FEAT);
             nh_block_sync();
+            if (st_more) quads_load<4>(FEAT, tn + r64_sq_feat(L) * 256);
             PH(4);
             // dH_{L-1} = fc_feat^T PFEAT + fc_alpha^T d(sigma raw) (one more k-step: group 0 carries d(sigma raw))
             float P[2][16];
@@ -520,6 +579,7 @@ NH_KERNEL void NH_LB(64 * NWV, 2) k_bwd64r(Bwd64rArgs a) {
             ex_put_blocks<4>(pw, 1, PFEAT);
             ex_put_blocks<4>(pw, 5, H[L - 1]);
             nh_block_sync();
+            if (st_more) quads_load<4>(H[L - 1], tn + (R64_SQ_H + 4 * (L - 1)) * 256);
             PH(4);
             // steps d_k: layers_xyz[i], i = L-2-k: first dH_i = layers_xyz[i]^T P_{i+1} (P_{i+1} = P[k & 1]), then slots 1..4 P_{i+1},
             // 5..8 H_i
@@ -536,6 +596,7 @@ NH_KERNEL void NH_LB(64 * NWV, 2) k_bwd64r(Bwd64rArgs a) {
                 ex_put_blocks<4>(pw, 1, P[k & 1]);
                 ex_put_blocks<4>(pw, 5, H[i]);
                 nh_block_sync();
+                if (st_more) quads_load<4>(H[i], tn + (R64_SQ_H + 4 * i) * 256);
                 PH(4);
             }
             // step e: layer1: slots 1..4 P_0, 5..8 X
@@ -545,6 +606,7 @@ NH_KERNEL void NH_LB(64 * NWV, 2) k_bwd64r(Bwd64rArgs a) {
             ex_put_blocks<4>(pw, 1, P[(L - 1) & 1]);
             ex_put_blocks<4>(pw, 5, X);
             nh_block_sync();
+            if (st_more) quads_load<4>(X, tn + R64_SQ_X * 256);
             PH(4);
         }
         PH_FLUSH(0);
@@ -573,6 +635,7 @@ struct Fwd64rArgs {
     float fx[16], fd[16];
     int Lx, Ld;
     float* out;
+    float* stash;  // k_fwd64r<L, true>: the register-image stash of the stashed fused backward (nh_r64.h), ceil(M / 16) tiles
     unsigned long long* clk;
 };
 
@@ -587,7 +650,9 @@ NH_DEVICE void gemm_f1(const float* w, int fx, const float* in, f32x4& acc) {
     }
 }
 
-template <int L>
+// ST (the training forward of mode 5): every activation the backward's chain reads also goes to the register-image stash, one 1-KiB
+// store per four registers, as it is produced.
+template <int L, bool ST>
 NH_KERNEL void NH_LB(64 * NWF, 4) k_fwd64r(Fwd64rArgs a) {
     constexpr R64Layout Y = r64_layout(L);
     NH_DYN_LDS(lds_raw);
@@ -628,18 +693,22 @@ NH_KERNEL void NH_LB(64 * NWF, 4) k_fwd64r(Fwd64rArgs a) {
             const float px = rr[0] + rr[3] * zz, py = rr[1] + rr[4] * zz, pz = rr[2] + rr[5] * zz;
             encode_slots<NH16_KRX>(X, px, py, pz, opaque(g), lfreq, a.Lx);
         }
+        float* const st = ST ? a.stash + (size_t)tile * r64_stash_tile_floats(L) + lane * 4 : nullptr;
+        if (ST) quads_store<4>(st + R64_SQ_X * 256, X);
         f32x4 acc[4];
         float Hc[16];
         bias_init<4>(acc, lds + Y.b_l1 + 4 * g);
         gemm_f<NH16_KRX, 4, R64_S>(lds + Y.l1 + lf, fx, X, acc);
 #pragma unroll
         for (int r = 0; r < 16; ++r) Hc[r] = acc[r >> 2][r & 3];  // no activation after layer1 (models.py:238)
+        if (ST) quads_store<4>(st + R64_SQ_H * 256, Hc);
 #pragma unroll
         for (int i = 0; i < L - 1; ++i) {
             bias_init<4>(acc, lds + Y.b_xyz[i] + 4 * g);
             gemm_f<16, 4, R64_S>(lds + Y.xyz[i] + lf, fx, Hc, acc);
 #pragma unroll
             for (int r = 0; r < 16; ++r) Hc[r] = nh_relu(acc[r >> 2][r & 3]);
+            if (ST) quads_store<4>(st + (R64_SQ_H + 4 * (i + 1)) * 256, Hc);
         }
         // fc_alpha (row 64 of the head matrix: row 0 of a fifth tile; the other rows of that tile are whatever follows the matrix and
         // are never read back), then fc_feat
@@ -651,6 +720,7 @@ NH_KERNEL void NH_LB(64 * NWF, 4) k_fwd64r(Fwd64rArgs a) {
         gemm_f<16, 4, R64_S>(lds + Y.head + lf, fx, Hc, acc);
 #pragma unroll
         for (int r = 0; r < 16; ++r) Hc[r] = nh_relu(acc[r >> 2][r & 3]);
+        if (ST) quads_store<4>(st + r64_sq_feat(L) * 256, Hc);
         float Dd[NH16_KRD];
         if (a.mode == 0) {
 #pragma unroll
@@ -661,12 +731,14 @@ NH_KERNEL void NH_LB(64 * NWF, 4) k_fwd64r(Fwd64rArgs a) {
         } else {
             encode_slots<NH16_KRD>(Dd, rr[8], rr[9], rr[10], opaque(g), lfreq + 16, a.Ld);
         }
+        if (ST) quads_store<2>(st + R64_SQ_D * 256, Dd);
         bias_init<2>(acc, lds + Y.b_dir + 4 * g);
         gemm_f<16, 2, R64_SD>(lds + Y.dir + lfd, fx, Hc, acc);
         gemm_f<NH16_KRD, 2, R64_SD>(lds + Y.dir + 64 + lfd, fx, Dd, acc);
         float dh[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) dh[r] = nh_relu(acc[r >> 2][r & 3]);
+        if (ST) quads_store<2>(st + r64_sq_dirh(L) * 256, dh);
         // fc_rgb: 16 rows x 36 floats, not swizzled
         f32x4 ar;
         bias_init<1>(&ar, lds + Y.b_rgb + 4 * g);
@@ -804,9 +876,15 @@ int lds_limit(K kern, int bytes) {
 template <int L>
 int launch_bwd(const Bwd64rArgs& a, int grid, nerfhip_stream_t stream) {
     const int bytes = (r64_lds_floats(L) + 32) * 4 + NH_CLK_LDS_BYTES;
-    const int rc = lds_limit(k_bwd64r<L>, bytes);
+    if (a.stash) {
+        const int rc = lds_limit(k_bwd64r<L, true>, bytes);
+        if (rc) return rc;
+        NH_LAUNCH((k_bwd64r<L, true>), grid, 64 * NWV, bytes, stream, a);
+        return nh_launch_status("bwd64r (stashed)");
+    }
+    const int rc = lds_limit(k_bwd64r<L, false>, bytes);
     if (rc) return rc;
-    NH_LAUNCH((k_bwd64r<L>), grid, 64 * NWV, bytes, stream, a);
+    NH_LAUNCH((k_bwd64r<L, false>), grid, 64 * NWV, bytes, stream, a);
     return nh_launch_status("bwd64r");
 }
 
@@ -826,15 +904,24 @@ extern "C" int nerfhip_debug_phases64(unsigned long long* host16, int reset) {
 template <int L>
 static int launch_fwd(const Fwd64rArgs& a, int grid, nerfhip_stream_t stream) {
     const int bytes = (r64_layout(L).image_floats + 32) * 4 + NH_CLK_LDS_BYTES;
-    const int rc = lds_limit(k_fwd64r<L>, bytes);
+    if (a.stash) {
+        const int rc = lds_limit(k_fwd64r<L, true>, bytes);
+        if (rc) return rc;
+        NH_LAUNCH((k_fwd64r<L, true>), grid, 64 * NWF, bytes, stream, a);
+        return nh_launch_status("fwd64r (stashing)");
+    }
+    const int rc = lds_limit(k_fwd64r<L, false>, bytes);
     if (rc) return rc;
-    NH_LAUNCH((k_fwd64r<L>), grid, 64 * NWF, bytes, stream, a);
+    NH_LAUNCH((k_fwd64r<L, false>), grid, 64 * NWF, bytes, stream, a);
     return nh_launch_status("fwd64r");
 }
 
 // The forward of an eligible plan without a stash (inference, the stash-free training forward of the fused modes): raw[M, 4]
-int nh_mlp64r_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, nerfhip_stream_t stream) {
+// ... or, stash != NULL (the training forward of mode 5), with the register-image stash of nh_r64.h: ceil(M / 16) tiles
+int nh_mlp64r_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
+                      nerfhip_stream_t stream) {
     NH_REQUIRE(nh_r64_eligible(p) && p->r64_off >= 0, "fwd64r: the plan has no resident image");
+    NH_REQUIRE(!stash || nh_r64_stash_fits(p), "fwd64r: the register-image stash does not fit this plan's stash region");
     NH_REQUIRE(packed && out && M > 0 && M < ((int64_t)1 << 31), "fwd64r: bad arguments");
     Fwd64rArgs a;
     memset(&a, 0, sizeof(a));
@@ -861,6 +948,7 @@ int nh_mlp64r_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in
     a.Lx = p->cfg.num_encoding_fn_xyz;
     a.Ld = p->cfg.num_encoding_fn_dir;
     a.out = out;
+    a.stash = stash;
     a.clk = nh_prof_clock_slot(NH_CLK_FWD);
     const int64_t wgs = nh_ceil_div(nh_ceil_div(M, 16), NWF);
     const int cus = compute_units();
@@ -887,9 +975,12 @@ int64_t nh_mlp64r_partial_floats(const nerfhip_plan* p, int64_t M) {
 
 // The fused backward of an eligible plan (nh_r64_eligible) over the fused render's input: g_params = d(loss)/d(parameters) for
 // d(loss)/d(raw output) = g_out.  cx: a compaction list built from g_out, or NULL (every sample).  partial: nh_mlp64r_partial_floats.
+// stash: the register-image stash nh_mlp64r_forward left for these M sample points (then cx must be NULL: the stashed variant runs
+// over every sample and recomputes nothing), or NULL (the forward is recomputed from `in`).
 int nh_mlp64r_backward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, const float* g_out, int64_t M, float* partial,
-                       float* g_params, const NhCompact* cx, nerfhip_stream_t stream) {
+                       float* g_params, const NhCompact* cx, const float* stash, nerfhip_stream_t stream) {
     NH_REQUIRE(nh_r64_eligible(p) && p->r64_off >= 0, "bwd64r: the plan has no resident image");
+    NH_REQUIRE(!stash || (!cx && nh_r64_stash_fits(p)), "bwd64r: the stashed variant runs dense, over a stash that fits the plan's region");
     NH_REQUIRE(in.mode == 1 && in.rays && in.z && in.S > 0 && in.ray_stride >= 11 && p->freqs_set, "bwd64r: bad fused input");
     NH_REQUIRE(packed && g_out && partial && g_params && M > 0 && M < ((int64_t)1 << 31), "bwd64r: bad arguments");
     Bwd64rArgs a;
@@ -912,6 +1003,7 @@ int nh_mlp64r_backward(nerfhip_plan* p, const float* packed, const NhMlpInput& i
     a.partial = partial;
     a.cidx = cx ? cx->idx : nullptr;
     a.cstats = cx ? cx->stats : nullptr;
+    a.stash = stash;
     a.clk = nh_prof_clock_slot(NH_CLK_DGRAD);
     const int grid = r64_grid(M);
     int rc = NERFHIP_OK;

@@ -31,6 +31,10 @@ int nh_compact_build(const float* g_out, int64_t M, const NhCompact& c, nerfhip_
 
 int nh_mlp_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
                    nerfhip_stream_t stream);
+// the training forward of the fused render: writes into `stash` what THIS plan's backward mode will read there -- the general stash
+// (modes 0, 1), nothing (the recomputing modes 2, 3, 4), the register-image stash of the stashed fused backward (mode 5)
+int nh_mlp_forward_training(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
+                            nerfhip_stream_t stream);
 int nh_mlp_backward(nerfhip_plan* p, const float* packed, const float* g_out, int64_t M, const float* stash,
                     float* scratch, int64_t scratch_bytes, float* g_params, nerfhip_stream_t stream);
 // plans with bwd_compact == 2 inside the fused render: the forward over `in` wrote no stash; lists the samples with a non-zero
@@ -56,9 +60,12 @@ int nh_mlp16_dgrad(nerfhip_plan* p, const float* packed, const float* g_out, int
 // gradient and weight gradient in one persistent kernel + a fixed-order reduction of one partial per workgroup
 int64_t nh_mlp64r_partial_floats(const nerfhip_plan* p, int64_t M);
 // ... and the persistent forward with the same image: raw[M, 4] without a stash (inference, the stash-free training forward)
-int nh_mlp64r_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, nerfhip_stream_t stream);
+// (stash: NULL, or -- mode 5 -- the register-image stash of nh_r64.h: written by the forward, read by the backward instead of
+// recomputing; the backward then runs over every sample, cx == NULL)
+int nh_mlp64r_forward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, int64_t M, float* out, float* stash,
+                      nerfhip_stream_t stream);
 int nh_mlp64r_backward(nerfhip_plan* p, const float* packed, const NhMlpInput& in, const float* g_out, int64_t M, float* partial,
-                       float* g_params, const NhCompact* cx, nerfhip_stream_t stream);
+                       float* g_params, const NhCompact* cx, const float* stash, nerfhip_stream_t stream);
 
 // mlp_f16w.hip: forward (with / without stash) and data-gradient chain of the fp16-piece plans: two waves per SIMD, 16-sample waves on
 // v_mfma_f32_16x16x32_f16; rmax (level-4 plans): NH_RMAX_WORDS zeroed device words for the region maxima, or NULL

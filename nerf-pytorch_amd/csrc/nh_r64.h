@@ -87,6 +87,17 @@ constexpr int R64_PASS_F = R64_TILES * R64_PASS_TILE_F;
 constexpr int r64_lds_floats(int L) { return r64_layout(L).image_floats + R64_EX_F + R64_PASS_F; }
 static_assert((r64_lds_floats(R64_MAX_LAYERS) + 32) * 4 + 32 <= 160 * 1024, "the image + the exchange area must fit the 160 KB of LDS");
 
+// The register-image stash of the fused backward's stashed variant (mode 5, mlp64r.hip k_fwd64r<L, true> -> k_bwd64r<L, true>): per
+// 16-sample tile the registers the chain waves would otherwise recompute, exactly as a wave holds them -- [quad][lane][4], quad = four
+// consecutive registers of an activation: X (4 quads), D (2), H_0 .. H_{L-1} (4 each), FEAT (4), DIRH (2).  Every store / load
+// instruction moves one whole KiB; 64 L + 192 floats per sample point (4 x 64: 1792 B -- what the general stash takes: the region
+// of the render workspace is the same one).
+constexpr int R64_SQ_X = 0, R64_SQ_D = 4, R64_SQ_H = 6;
+constexpr int r64_sq_feat(int L) { return R64_SQ_H + 4 * L; }
+constexpr int r64_sq_dirh(int L) { return R64_SQ_H + 4 * L + 4; }
+constexpr int r64_stash_quads(int L) { return 4 * L + 12; }
+constexpr int r64_stash_tile_floats(int L) { return r64_stash_quads(L) * 256; }
+
 // Accumulators of one weight-gradient wave (mlp64r.hip "units"): NU accumulator tiles (4 registers each) + NB row-sum registers (biases)
 constexpr int r64_units(int L) { return 9 + 4 * L; }
 constexpr int r64_bias_regs(int L) { return 3 + L; }
@@ -101,4 +112,8 @@ static inline bool nh_r64_eligible(const nerfhip_plan* p) {
     for (int i = 0; i < p->L - 1; ++i)
         if (p->is_skip(i)) return false;
     return true;
+}
+// ... and its stashed variant fits the stash region the render workspace reserves for the plan (nh_stash_floats per 32-sample tile)
+static inline bool nh_r64_stash_fits(const nerfhip_plan* p) {
+    return nh_r64_eligible(p) && nh_stash_floats(p, 1) >= 2 * (int64_t)r64_stash_tile_floats(p->L);
 }

@@ -74,17 +74,17 @@ class TrainEngine:
         # backward mode of the step: None -- whatever each model's set_backward_compaction says (default: dense); "dense" / "compact" /
         # "recompute" -- set on both models; "auto" -- chosen per net and per step from the zero-cotangent fraction the previous
         # compacted steps reported (read back asynchronously: no host synchronisation), see _choose_backward_modes
-        if backward not in (None, "dense", "compact", "recompute", "fused", "fused_compact", "auto"):
-            raise ValueError("backward must be None, 'dense', 'compact', 'recompute', 'fused', 'fused_compact' or 'auto' (got %r)" % (backward,))
+        if backward not in (None, "dense", "compact", "recompute", "fused", "fused_compact", "fused_stash", "auto"):
+            raise ValueError("backward must be None, 'dense', 'compact', 'recompute', 'fused', 'fused_compact', 'fused_stash' or 'auto' (got %r)" % (backward,))
         self.backward = backward
         self._zero_frac = {"coarse": None, "fine": None}   # last known fraction of all-zero d(loss)/d(raw) rows per net
         self._stats_host = None
         self._stats_event = None
         self._stats_pending = None
         self._probe_every = 50
-        # steps run dense / compacted / recomputed / fused / fused over the list, per net ("auto")
-        self.backward_modes_used = {"coarse": [0, 0, 0, 0, 0], "fine": [0, 0, 0, 0, 0]}
-        if backward in ("dense", "compact", "recompute", "fused", "fused_compact"):
+        # steps run dense / compacted / recomputed / fused / fused over the list / fused over the stash, per net ("auto")
+        self.backward_modes_used = {"coarse": [0, 0, 0, 0, 0, 0], "fine": [0, 0, 0, 0, 0, 0]}
+        if backward in ("dense", "compact", "recompute", "fused", "fused_compact", "fused_stash"):
             for m in (self.mc, self.mf):
                 if m is not None:
                     m.set_backward_compaction({"dense": False, "compact": True}.get(backward, backward))
@@ -222,12 +222,15 @@ class TrainEngine:
     # A compacted step costs what its gather costs when nothing is dropped (fp32: k_wgrad + 19 %, fp16 pieces + 1 %) and saves the
     # dropped fraction of the data and weight gradient; the recomputing mode additionally trades the stash stream of the forward for a
     # second forward over the kept samples (pays above ~2/3 dropped rows for the fp16-piece plans, never for fp32): DESIGN.md 3.3-3.4.
-    # Nets with a fused backward (fp32, 64 wide: csrc/mlp64r.hip) always run it -- over every sample until the list is known to drop
-    # at least 5 % of them (the list costs two small launches), over the list from there on.
+    # Nets with a fused backward (fp32, 64 wide: csrc/mlp64r.hip) always run it -- over every sample (from the register-image stash,
+    # mode 5, where the plan has it: 0.70 of the recomputing kernel's time) until the list is known to drop enough of them: 5 % against
+    # the recomputing mode 3 (the list costs two small launches), 30 % against mode 5 (the list walk recomputes its forward) --, over
+    # the list from there on.
     @staticmethod
-    def _mode_for(frac, f16, fused=False):
+    def _mode_for(frac, f16, fused=0):
         if fused:
-            return 4 if (frac is not None and frac >= 0.05) else 3
+            dense_mode = 5 if fused == 5 else 3
+            return 4 if (frac is not None and frac >= (0.30 if dense_mode == 5 else 0.05)) else dense_mode
         if frac is None:
             return 0
         if f16:
@@ -252,10 +255,10 @@ class TrainEngine:
             mode = self._mode_for(self._zero_frac[name], m.training_precision != "fp32", m.fused_backward_available())
             if probe and mode == 0:
                 mode = 1
-            if probe and mode == 3:
+            if probe and mode in (3, 5):
                 mode = 4
             if m.backward_compaction != mode:
-                m.set_backward_compaction({0: False, 1: True, 2: "recompute", 3: "fused", 4: "fused_compact"}[mode])
+                m.set_backward_compaction({0: False, 1: True, 2: "recompute", 3: "fused", 4: "fused_compact", 5: "fused_stash"}[mode])
             self.backward_modes_used[name][mode] += 1
 
     def _request_backward_stats(self, n):

@@ -140,11 +140,11 @@ if __name__ == "__main__":
     grads = {}
     fused_ok = N.FlexibleNeRFModel(**STUDENT).to(dev).fused_backward_available()   # (fp32 students of hidden_size <= 64: csrc/mlp64r.hip)
     for prec in ("fp32", "f16x3_train"):
-        for compact in (False, True, "recompute", "fused", "fused_compact", "auto"):
+        for compact in (False, True, "recompute", "fused", "fused_compact", "fused_stash", "auto"):
             arm = "%s_%s" % (prec, {False: "dense", True: "compacted", "recompute": "recomputed", "auto": "auto"}.get(compact, compact))
             if a.arms and arm not in a.arms.split(","):
                 continue
-            if compact in ("fused", "fused_compact") and not (fused_ok and prec == "fp32"):
+            if compact in ("fused", "fused_compact", "fused_stash") and not (fused_ok and prec == "fp32"):
                 continue
             mc, mf, eng = make_engine(state_c, state_f, prec, compact, a.lr, a.seed + 7)
             # one step on a fixed batch first: the gradient this arm computes from the common weights (compacted vs dense below)
@@ -157,7 +157,7 @@ if __name__ == "__main__":
             kept = eng.backward_sample_counts()
             zf = {n: (None if v is None else round(1.0 - v[0] / v[1], 4)) for n, v in kept.items()}
             if compact == "auto":
-                zf["steps_dense_compacted_recomputed_fused_fusedcompact"] = eng.backward_modes_used
+                zf["steps_dense_compacted_recomputed_fused_fusedcompact_fusedstash"] = eng.backward_modes_used
             res["arms"][arm] = dict(rays_per_s=round(RAYS / ms, 1), ms_per_step=round(ms * 1e3, 3), zero_cotangent_fraction_last_step=zf,
                                     kernel_ms_per_step=kern, final_loss=[float(v) for v in eng.loss.cpu()])
             print(arm, res["arms"][arm]["rays_per_s"], res["arms"][arm]["ms_per_step"], zf, flush=True)
@@ -166,7 +166,7 @@ if __name__ == "__main__":
             json.dump(res, open(a.out, "w"), indent=1)
     n0 = None
     for prec in ("fp32", "f16x3_train"):
-        for kind in ("_compacted", "_recomputed", "_fused", "_fused_compact", "_auto"):
+        for kind in ("_compacted", "_recomputed", "_fused", "_fused_compact", "_fused_stash", "_auto"):
             if prec + "_dense" not in grads or prec + kind not in grads:
                 continue
             d, c = grads[prec + "_dense"], grads[prec + kind]

@@ -3,5 +3,5 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 cp nerf-pytorch_amd/libnerfhip.so /tmp/libnerfhip_product.so
 cp nerf-pytorch_amd/libnerfhip_ph.so nerf-pytorch_amd/libnerfhip.so
-python scripts/r64_phases.py 2>&1 | tail -14
+for m in ${@:-fused}; do echo "== $m"; python scripts/r64_phases.py $m 2>&1 | tail -14; done
 cp /tmp/libnerfhip_product.so nerf-pytorch_amd/libnerfhip.so

@@ -15,7 +15,7 @@ lib = ctypes.CDLL(L.LIB_PATH)
 wl = bench.WORKLOADS["fern"] if hasattr(bench, "WORKLOADS") else None
 cfg = dict(num_layers=4, hidden_size=64, skip_connect_every=3, num_encoding_fn_xyz=6, num_encoding_fn_dir=4)
 mc, mf = N.FlexibleNeRFModel(**cfg).cuda(), N.FlexibleNeRFModel(**cfg).cuda()
-eng = N.TrainEngine(mc, mf, 64, 64, perturb=True, white_background=False, noise_std=1.0, lr=5e-3, seed=1, backward="fused", overlap=False)
+eng = N.TrainEngine(mc, mf, 64, 64, perturb=True, white_background=False, noise_std=1.0, lr=5e-3, seed=1, backward=(sys.argv[1] if len(sys.argv) > 1 else "fused"), overlap=False)
 n = 4096
 g = torch.Generator(device="cuda").manual_seed(1)
 ro = torch.rand(n, 3, generator=g, device="cuda") - 0.5

@@ -280,7 +280,7 @@ class Backend:
 
     def set_compaction(self, plan, on):
         """nerfhip_plan_set_bwd_compaction: the plan's backward drops the samples whose d(raw output) row is all zero."""
-        mode = {"recompute": 2, "fused": 3, "fused_compact": 4}.get(on, int(bool(on)))
+        mode = {"recompute": 2, "fused": 3, "fused_compact": 4, "fused_stash": 5}.get(on, int(bool(on)))
         self.lib.plan_set_bwd_compaction(plan, mode)
         assert self.lib.plan_bwd_compaction(plan) == mode
 

@@ -484,8 +484,10 @@ def case_render_compacted(b, cfg, n, nc, nf, precision=0, seed=9, white=False, n
     with the renderer's OWN cotangents: the rows dropped are those relu(sigma + noise) and the transmittance zero
     (nerf/volume_rendering_utils.py:38-42).  Outputs bit-identical in all modes (the stash-free forward is the same kernel without its
     stores); gradients of both nets within `unit.compact_vs_dense` of the dense ones; kept + dropped = all samples, and some of each.
-    fused: also the two modes of the fused backward of 64-wide nets (3 / 4, csrc/mlp64r.hip: one persistent kernel, no stash, no
-    d(pre-activation) images) -- over every sample, and over the same list."""
+    fused: also the modes of the fused backward of 64-wide nets (3 / 4 / 5, csrc/mlp64r.hip: one persistent kernel, no
+    d(pre-activation) images) -- over every sample with the forward recomputed, over the same list, and over every sample with the
+    chain's registers read back from the register-image stash the training forward left (5: the SAME arithmetic as 3 on the same
+    values -- its gradient equals mode 3's bit for bit)."""
     gen = rng(seed)
     pc, par_c, _, packed_c = mlp_setup(b, cfg, seed=seed + 1, precision=precision)
     pf, par_f, _, packed_f = mlp_setup(b, cfg, seed=seed + 2, precision=precision)
@@ -499,7 +501,7 @@ def case_render_compacted(b, cfg, n, nc, nf, precision=0, seed=9, white=False, n
     tgt = torch.rand(n, 3, generator=gen).numpy()
     ctol = TL.bound("unit.compact_vs_dense", ARITH_NAME[precision])
     res = {}
-    modes = (False, True, "recompute") + (("fused", "fused_compact") if fused else ())
+    modes = (False, True, "recompute") + (("fused", "fused_compact", "fused_stash") if fused else ())
     for mode in modes:
         b.set_compaction(pc, mode)
         b.set_compaction(pf, mode)
@@ -513,8 +515,11 @@ def case_render_compacted(b, cfg, n, nc, nf, precision=0, seed=9, white=False, n
         for k in ("rgb_coarse", "acc_coarse", "depth_coarse", "disp_coarse", "rgb_fine", "acc_fine", "depth_fine", "disp_fine"):
             assert np.array_equal(r[k], dense[k], equal_nan=True), (mode, k)
         for key, name, plan, total in (("g_params_coarse", "coarse", pc, n * nc), ("g_params_fine", "fine", pf, n * (nc + nf))):
-            kept, tot = r["bwd_kept_" + name] if mode != "fused" else res[True]["bwd_kept_" + name]
-            if mode != "fused":
+            dense_walk = mode in ("fused", "fused_stash")  # (no list)
+            kept, tot = r["bwd_kept_" + name] if not dense_walk else res[True]["bwd_kept_" + name]
+            if mode == "fused_stash":
+                assert np.array_equal(r[key], res["fused"][key]), ("stashed vs recomputing fused backward", key)
+            if not dense_walk:
                 assert tot == total and 0 < kept < total, (mode, name, kept, tot)
                 assert r["bwd_kept_" + name] == res[True]["bwd_kept_" + name]
             # (mode 2 differs from mode 1 only in WHERE the kept samples' stash rows sit: same list, same rows, same tile ranges --
@@ -552,7 +557,7 @@ def case_render_fused_edges(b, cfg, seed=17):
         opt = dict(num_coarse=nc, num_fine=nf, perturb=True, lindisp=False, white_background=False, noise_std=0.0)
         tgt = torch.rand(n, 3, generator=gen).numpy()
         res = {}
-        for mode in (False, "fused", "fused_compact"):
+        for mode in (False, "fused", "fused_compact", "fused_stash"):
             b.set_compaction(pc, mode)
             b.set_compaction(pf, mode)
             fwd = b.render(pc, pf, packed_c, packed_f, rays, opt, rnp, training=True)
@@ -562,7 +567,7 @@ def case_render_fused_edges(b, cfg, seed=17):
             zero = b.render(pc, pf, packed_c, packed_f, rays, opt, rnp, training=True, g_rgb=(np.zeros_like(gc), np.zeros_like(gf)))
             for key in ("g_params_coarse", "g_params_fine"):
                 assert not zero[key].any(), ("zero cotangents", mode, key, float(np.abs(zero[key]).max()))
-        for mode in ("fused", "fused_compact"):
+        for mode in ("fused", "fused_compact", "fused_stash"):
             for key, plan in (("g_params_coarse", pc), ("g_params_fine", pf)):
                 gd, gk = b.unflatten(plan, res[False][key]), b.unflatten(plan, res[mode][key])
                 for k in gd:

@@ -174,7 +174,7 @@ def test_engine_backward_modes_compacted_recomputed_auto_track_the_dense_engine(
 
 def test_engine_on_64_wide_nets_runs_the_fused_backward_by_default():
     """config/fern.yml's 4 x 64 nets (round 6, csrc/mlp64r.hip): a model whose plan has the LDS-resident image takes the fused one-kernel
-    backward by default; TrainEngine(backward="dense" / "fused" / "fused_compact" / "auto") on the same weights, rays and in-kernel
+    backward by default (over the register-image stash, mode 5); TrainEngine(backward="dense" / "fused" / "fused_compact" / "fused_stash" / "auto") on the same weights, rays and in-kernel
     draws: the SAME loss bit for bit (the stash-free resident forward computes what the stash-writing one does), flat gradients within
     1e-5 of max|g| of the dense engine's (another association of the same fp32 sums); 120 steps on an empty white scene end where the
     dense engine's do; "auto" runs fused over every sample until the list is known to drop rows, then fused over the list."""
@@ -184,13 +184,13 @@ def test_engine_on_64_wide_nets_runs_the_fused_backward_by_default():
     rays, rgba = _rays(1024, dev)
     white = torch.ones(1024, 3, device=dev)
     mc, mf = _models(dev, cfg=cfg)
-    assert mc.fused_backward_available() and mc.backward_compaction == 3 and mf.backward_compaction == 3
+    assert mc.fused_backward_available() == 5 and mc.backward_compaction == 5 and mf.backward_compaction == 5
     wide = _models(dev)[0]
     assert not wide.fused_backward_available() and wide.backward_compaction == 0
     with pytest.raises(Exception, match="fused backward"):
         wide.set_backward_compaction("fused")
     res = {}
-    for mode in ("dense", None, "fused", "fused_compact", "auto"):
+    for mode in ("dense", None, "fused", "fused_compact", "fused_stash", "auto"):
         mc, mf = _models(dev, cfg=cfg)
         eng = N.TrainEngine(mc, mf, 32, 32, noise_std=0.2, white_background=True, lr=1e-3, seed=11, world_size=1, rank=0, backward=mode)
         if mode != "auto":
@@ -203,9 +203,10 @@ def test_engine_on_64_wide_nets_runs_the_fused_backward_by_default():
         torch.cuda.synchronize()
         res[mode] = (g0, l0, losses, eng)
     gd, ld, sd, _ = res["dense"]
-    assert res[None][3].mc.backward_compaction == 3                       # (backward=None: the models' default)
-    assert torch.equal(res[None][0], res["fused"][0])
-    for mode in ("fused", "fused_compact"):
+    assert res[None][3].mc.backward_compaction == 5                       # (backward=None: the models' default)
+    assert torch.equal(res[None][0], res["fused_stash"][0])
+    assert torch.equal(res["fused"][0], res["fused_stash"][0])            # (the same arithmetic on the same values: bit-identical)
+    for mode in ("fused", "fused_compact", "fused_stash"):
         g, l, s, eng = res[mode]
         assert torch.equal(l, ld), (mode, l, ld)
         assert float((g - gd).abs().max()) <= 1e-5 * float(gd.abs().max()), (mode, float((g - gd).abs().max()), float(gd.abs().max()))
@@ -213,7 +214,7 @@ def test_engine_on_64_wide_nets_runs_the_fused_backward_by_default():
     assert kept["coarse"][1] == 1024 * 32 and kept["fine"][1] == 1024 * 64 and res["fused"][3].backward_sample_counts()["fine"] is None
     tail = lambda s: float(s[-20:, 2].mean())  # noqa: E731
     assert tail(sd) < 0.25 * float(sd[0, 2])
-    for mode in (None, "fused", "fused_compact", "auto"):
+    for mode in (None, "fused", "fused_compact", "fused_stash", "auto"):
         assert torch.isfinite(res[mode][2]).all()
         assert abs(tail(res[mode][2]) - tail(sd)) <= 0.05 * tail(sd) + 1e-4, (mode, tail(res[mode][2]), tail(sd))
     used = res["auto"][3].backward_modes_used

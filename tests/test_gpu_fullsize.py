@@ -187,10 +187,11 @@ class _Plans:
 
     def __init__(self, c, arith):
         # "fp32_fused": the fp32 plans with the fused backward of 64-wide nets (nerfhip_plan_set_bwd_compaction(plan, 3), csrc/mlp64r.hip):
-        # another data flow, the SAME arithmetic -- held to the fp32 rows of the tolerance table
+        # another data flow, the SAME arithmetic -- held to the fp32 rows of the tolerance table; "fp32_fused_stash": the same kernel over
+        # the register-image stash its training forward leaves (mode 5: what these nets run by default)
         self.tag = "" if arith == "fp32" else "_" + arith
-        self.fused = self.tag.endswith("_fused")
-        self.c, self.arith = c, (arith[:-len("_fused")] if self.fused else arith)
+        self.fused = "fused_stash" if self.tag.endswith("_fused_stash") else ("fused" if self.tag.endswith("_fused") else None)
+        self.c, self.arith = c, (arith[:-len("_" + self.fused)] if self.fused else arith)
         pc_, pf_ = ARITH[self.arith]
         gpu = c.gpu
         self.own = []
@@ -207,8 +208,8 @@ class _Plans:
             self.packed_f = gpu.pack(self.plan_f, gpu.flatten_params(self.plan_f, {k: v.detach().numpy() for k, v in c.par_f.items()}))
             self.own.append(self.plan_f)
         if self.fused:
-            gpu.set_compaction(self.plan_c, "fused")
-            gpu.set_compaction(self.plan_f, "fused")
+            gpu.set_compaction(self.plan_c, self.fused)
+            gpu.set_compaction(self.plan_f, self.fused)
 
     def close(self):
         if self.fused:
@@ -392,7 +393,7 @@ def test_fern_full_batch_every_ray_vs_oracle(fern, arith):
     _end_to_end(fern, "e2e.grad_coarse.fp64_yardstick", "e2e.grad_fine.yardstick", arith=arith)
 
 
-@pytest.mark.parametrize("arith", ["fp32", "f16x3_train", "fp32_fused"])
+@pytest.mark.parametrize("arith", ["fp32", "f16x3_train", "fp32_fused", "fp32_fused_stash"])
 def test_fern_declared_4x64_full_batch_every_ray_vs_oracle(fern_declared, arith):
     """The same full-batch comparison on the geometry config/fern.yml declares, on the fp32 kernels and -- the
     64-wide instances of mlp_f16w.hip, round 5 -- on fp16 pieces.  Fine-net bounds: 5x the values measured on MI355X

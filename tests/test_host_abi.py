@@ -238,20 +238,25 @@ def test_backward_mode_thresholds_and_option_plumbing():
         lib.plan_set_bwd_compaction(plan, mode)
         assert lib.plan_bwd_compaction(plan) == mode
     with pytest.raises(L.NerfHipError, match="0 \\(dense\\), 1 \\(compacted\\), 2"):
-        lib.plan_set_bwd_compaction(plan, 5)
-    # the fused one-kernel backward (3, 4; csrc/mlp64r.hip) exists for plans with an LDS-resident image only: a 4 x 128 net has none
-    with pytest.raises(L.NerfHipError, match="fused backward"):
-        lib.plan_set_bwd_compaction(plan, 3)
+        lib.plan_set_bwd_compaction(plan, 6)
+    # the fused one-kernel backward (3, 4, 5; csrc/mlp64r.hip) exists for plans with an LDS-resident image only: a 4 x 128 net has none
+    for mode in (3, 5):
+        with pytest.raises(L.NerfHipError, match="fused backward"):
+            lib.plan_set_bwd_compaction(plan, mode)
     fern = L.ModelCfg(4, 64, 3, 6, 4, 1, 1, 1, 1, 1)   # config/fern.yml's nets
     pf = lib.plan_create(C.byref(fern))
-    for mode in (3, 4, 0):
+    for mode in (3, 4, 5, 0):
         lib.plan_set_bwd_compaction(pf, mode)
         assert lib.plan_bwd_compaction(pf) == mode
+    # (mode 5's register-image stash -- 64 L + 192 floats per sample point -- lives in the plan's own stash region)
+    assert lib.plan_stash_bytes(pf, 4096) >= 4096 * 4 * (64 * 4 + 192)
     # (its packed buffer carries the resident image behind the layer images; its scratch one partial per workgroup behind the list)
     assert lib.plan_packed_floats(pf) > 0 and lib.plan_bwd_scratch_bytes(pf, 4096) > lib.plan_bwd_stats_offset(pf, 4096)
     lib.plan_destroy(pf)
-    # ... and TrainEngine(backward="auto") always runs it where it exists: over every sample until the list is known to drop 5 %
-    assert [E._mode_for(f, False, True) for f in (None, 0.0, 0.04, 0.05, 0.9)] == [3, 3, 3, 4, 4]
+    # ... and TrainEngine(backward="auto") always runs it where it exists: over every sample (from the register-image stash where the
+    # plan has it) until the list is known to drop 30 % (5 % against the recomputing mode 3)
+    assert [E._mode_for(f, False, 3) for f in (None, 0.0, 0.04, 0.05, 0.9)] == [3, 3, 3, 4, 4]
+    assert [E._mode_for(f, False, 5) for f in (None, 0.0, 0.05, 0.29, 0.30, 0.9)] == [5, 5, 5, 5, 4, 4]
     # the statistics words sit inside the backward scratch, behind everything the dense backward uses
     off, total = lib.plan_bwd_stats_offset(plan, 4096), lib.plan_bwd_scratch_bytes(plan, 4096)
     assert 0 < off < total and off % 4 == 0 and total - off >= 4 * (16 + 4096)

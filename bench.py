@@ -273,7 +273,7 @@ def kernel_kind(name):
     if "k_bwd64r_reduce" in name:
         return None
     if "k_bwd64r" in name:
-        return "bwd64r"       # (--compact fused / fused_compact: forward recomputed + data gradient + weight gradient, one kernel)
+        return "bwd64r"       # (--compact fused / fused_compact / fused_stash: [forward recomputed +] data gradient + weight gradient, one kernel)
     if "k_mlp_fwd" in name or "k_fwd64r" in name:
         return "fwd"
     if "k_mlp_dgrad" in name:
@@ -819,7 +819,8 @@ def main():
                     children = (("f16x3_train", ["--precision", "f16x3_train", "--steps", str(args.steps), "--warmup", str(args.warmup)]),
                                 ("fp32_compact", ["--compact"]),
                                 ("f16x3_train_compact", ["--precision", "f16x3_train", "--compact"]),
-                                ("fern_fp32", ["--workload", "fern"]),   # (4 x 64 fp32 nets: the fused one-kernel backward is their default)
+                                ("fern_fp32", ["--workload", "fern"]),   # (4 x 64 fp32 nets: the fused one-kernel backward over the register-image stash is their default)
+                                ("fern_fp32_recompute", ["--workload", "fern", "--compact", "fused"]),   # (... the same kernel recomputing its forward: no stash at all)
                                 ("fern_fp32_dense", ["--workload", "fern", "--compact", "dense"]),
                                 ("fern_f16x3_train", ["--workload", "fern", "--precision", "f16x3_train"]),
                                 ("4x128_fp32", ["--hidden", "128", "--layers", "4"]),

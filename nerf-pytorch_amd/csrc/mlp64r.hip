@@ -307,7 +307,15 @@ NH_KERNEL void NH_LB(64 * NWV, 2) k_bwd64r(Bwd64rArgs a) {
     constexpr int NU = r64_units(L), NB = r64_bias_regs(L), TL = R64_TILES;
     NH_DYN_LDS(lds_raw);
     float* const lds = (float*)lds_raw;
-    float* const ex = lds + Y.image_floats;
+    // ST: layer1's weights (the image's last segment: only the forward reads them) and the hand-over area are not needed -- their room
+    // holds a SECOND exchange buffer: the chain waves write step k + 1 into one while the weight-gradient waves multiply step k out of
+    // the other, and a step has ONE barrier (publish) instead of two (free, publish): the chain never waits for its stores' turn.
+    // `bo` = the float offset of the buffer of the current step (both roles toggle it after every step).  Operands that outlive their
+    // step: POUT (slot 0 of step a's buffer) is read again in step c -- two steps later: the same buffer, whose slot 0 nobody writes in
+    // between --, PDIR (step a) again in step b: the chain puts it into step b's buffer as well.
+    constexpr int IMG_F = ST ? Y.res_floats : Y.image_floats;
+    static_assert(!ST || Y.res_floats + 2 * R64_EX_F <= r64_lds_floats(L), "the second exchange buffer fits where layer1 and the hand-over area were");
+    float* const ex = lds + IMG_F;
     float* const lfreq = lds + r64_lds_floats(L);  // 16 xyz + 16 direction frequency bands
     nh_clk_begin(a.clk, (unsigned long long*)(lds_raw + (r64_lds_floats(L) + 32) * 4));
     const int lane = nh_lane(), g = lane >> 4, j = lane & 15, wave = nh_wave_in_block();
@@ -315,7 +323,7 @@ NH_KERNEL void NH_LB(64 * NWV, 2) k_bwd64r(Bwd64rArgs a) {
         // the whole image: 1-KiB pieces, wave w takes pieces w, w + 8, ...
         const unsigned lds_addr = nh_lds_addr(lds);
         const NhDmaSrc dma = nh_dma_src(a.image, a.image_bytes);
-        for (int q = wave; q < Y.image_floats / 256; q += NWV) nh_dma16a(dma, lane * 16, q * 1024, lds_addr + (unsigned)q * 1024u);
+        for (int q = wave; q < IMG_F / 256; q += NWV) nh_dma16a(dma, lane * 16, q * 1024, lds_addr + (unsigned)q * 1024u);
         if (threadIdx.x < 32) lfreq[threadIdx.x] = threadIdx.x < 16 ? a.fx[threadIdx.x & 15] : a.fd[threadIdx.x & 15];
         nh_wait_vmem();
         nh_block_sync();
@@ -327,6 +335,7 @@ NH_KERNEL void NH_LB(64 * NWV, 2) k_bwd64r(Bwd64rArgs a) {
     int rq[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) rq[q] = 16 * g + 4 * ((j >> 2) ^ ((2 * q + (g >> 1)) & 3)) + (j & 3);
+    int bo = 0;  // (ST: the exchange buffer of the step at hand, 0 / R64_EX_F)
 
     if (wave >= TL) {
         // ================================ weight-gradient wave v: a quarter of every layer's gradient tiles ================================
@@ -372,39 +381,43 @@ NH_KERNEL void NH_LB(64 * NWV, 2) k_bwd64r(Bwd64rArgs a) {
             // step a: slot 0 POUT, 1..2 PDIR, 3..4 DIRH, 5..6 D -- fc_rgb (waves 0, 1: POUT x DIRH block v),
             // layers_dir's direction columns (PDIR block v >> 1 x D block v & 1).  The chain waves read the hand-over area at the top
             // of their round, i.e. before they reach this barrier: the next round's may be written behind it.
-            nh_block_sync();
+            if (!ST) nh_block_sync();
             if (more) hand_over();
             nh_block_sync();
             PH(0);  // [8] waiting for step a (the chain waves' forward)
-            if (v < 2) unitN<1>(ex, rq, 0, (3 + v) * 256, &U[0], rsum[0]);
-            unitN<1>(ex, rq, (1 + (v >> 1)) * 256, (5 + (v & 1)) * 256, &U[1], rsum[1]);
+            if (v < 2) unitN<1>(ex, rq, bo, bo + (3 + v) * 256, &U[0], rsum[0]);
+            unitN<1>(ex, rq, bo + (1 + (v >> 1)) * 256, bo + (5 + (v & 1)) * 256, &U[1], rsum[1]);
+            if (ST) bo ^= R64_EX_F;
             PH(1);  // [9] multiplying
             // step b: slots 3..6 FEAT -- layers_dir's hidden columns (PDIR block v >> 1 x FEAT blocks 2 (v & 1), + 1)
-            nh_block_sync();
+            if (!ST) nh_block_sync();
             nh_block_sync();
             PH(2);  // [10] waiting for the steps b ..
             {
                 float unused = 0.0f;
-                unitN<2>(ex, rq, (1 + (v >> 1)) * 256, (3 + 2 * (v & 1)) * 256, &U[2], unused);
+                unitN<2>(ex, rq, bo + (1 + (v >> 1)) * 256, bo + (3 + 2 * (v & 1)) * 256, &U[2], unused);
             }
+            if (ST) bo ^= R64_EX_F;
             PH(1);
             // step c: slots 1..4 PFEAT, 5..8 H_{L-1} (POUT still in 0) -- fc_feat rows 16 v .., fc_alpha's units 16 v ..
-            nh_block_sync();
+            if (!ST) nh_block_sync();
             nh_block_sync();
             PH(2);
-            unitN<4>(ex, rq, (1 + v) * 256, 5 * 256, &U[4], rsum[2]);
+            unitN<4>(ex, rq, bo + (1 + v) * 256, bo + 5 * 256, &U[4], rsum[2]);
             {
                 float unused = 0.0f;
-                unitN<1>(ex, rq, 0, (5 + v) * 256, &U[8], unused);
+                unitN<1>(ex, rq, bo, bo + (5 + v) * 256, &U[8], unused);
             }
+            if (ST) bo ^= R64_EX_F;
             PH(1);
             // steps d_k: slots 1..4 P_{i+1}, 5..8 H_i -- layers_xyz[i] rows 16 v .., i = L-2-k; step e: P_0 and X -- layer1
 #pragma unroll
             for (int k = 0; k < L; ++k) {
-                nh_block_sync();
+                if (!ST) nh_block_sync();
                 nh_block_sync();
                 PH(2);
-                unitN<4>(ex, rq, (1 + v) * 256, 5 * 256, &U[9 + 4 * k], rsum[3 + k]);
+                unitN<4>(ex, rq, bo + (1 + v) * 256, bo + 5 * 256, &U[9 + 4 * k], rsum[3 + k]);
+                if (ST) bo ^= R64_EX_F;
                 PH(1);
             }
         }
@@ -534,13 +547,13 @@ NH_KERNEL void NH_LB(64 * NWV, 2) k_bwd64r(Bwd64rArgs a) {
             }
             // step a: slot 0 POUT (rows 0..2 d(rgb raw), row 3 d(sigma raw)), 1..2 PDIR, 3..4 DIRH, 5..6 D
             PH(2);  // [2] transposed layers, gates
-            nh_block_sync();  // (free: the weight-gradient waves are done with the step before)
+            if (!ST) nh_block_sync();  // (free: the weight-gradient waves are done with the step before)
             PH(3);  // [3] waiting for the weight-gradient waves
-            ex_put(pw, 0, g == 0 ? go0 : 0.f, g == 0 ? go1 : 0.f, g == 0 ? go2 : 0.f, g == 0 ? go3 : 0.f);
-            ex_put_blocks<2>(pw, 1, PDIR);
-            ex_put_blocks<2>(pw, 3, DIRH);
-            ex_put_blocks<2>(pw, 5, Dd);
-            nh_block_sync();  // (publish)
+            ex_put(pw + bo, 0, g == 0 ? go0 : 0.f, g == 0 ? go1 : 0.f, g == 0 ? go2 : 0.f, g == 0 ? go3 : 0.f);
+            ex_put_blocks<2>(pw + bo, 1, PDIR);
+            ex_put_blocks<2>(pw + bo, 3, DIRH);
+            ex_put_blocks<2>(pw + bo, 5, Dd);
+            nh_block_sync(); if (ST) bo ^= R64_EX_F;  // (publish)
             if (st_more) {  // (their last use is behind them: the next round's, into the same registers)
                 quads_load<2>(DIRH, tn + r64_sq_dirh(L) * 256);
                 quads_load<2>(Dd, tn + R64_SQ_D * 256);
@@ -555,10 +568,11 @@ NH_KERNEL void NH_LB(64 * NWV, 2) k_bwd64r(Bwd64rArgs a) {
             for (int r = 0; r < 16; ++r) PFEAT[r] = gate_pos(acc[r >> 2][r & 3], FEAT[r]);
             // step b: slots 3..6 FEAT (PDIR stays in 1..2)
             PH(2);
-            nh_block_sync();
+            if (!ST) nh_block_sync();
             PH(3);
-            ex_put_blocks<4>(pw, 3, FEAT);
-            nh_block_sync();
+            if (ST) ex_put_blocks<2>(pw + bo, 1, PDIR);  // (this step's buffer is not step a's)
+            ex_put_blocks<4>(pw + bo, 3, FEAT);
+            nh_block_sync(); if (ST) bo ^= R64_EX_F;
             if (st_more) quads_load<4>(FEAT, tn + r64_sq_feat(L) * 256);
             PH(4);
             // dH_{L-1} = fc_feat^T PFEAT + fc_alpha^T d(sigma raw) (one more k-step: group 0 carries d(sigma raw))
@@ -574,11 +588,11 @@ NH_KERNEL void NH_LB(64 * NWV, 2) k_bwd64r(Bwd64rArgs a) {
             }
             // step c: slots 1..4 PFEAT, 5..8 H_{L-1} (POUT stays in 0)
             PH(2);
-            nh_block_sync();
+            if (!ST) nh_block_sync();
             PH(3);
-            ex_put_blocks<4>(pw, 1, PFEAT);
-            ex_put_blocks<4>(pw, 5, H[L - 1]);
-            nh_block_sync();
+            ex_put_blocks<4>(pw + bo, 1, PFEAT);
+            ex_put_blocks<4>(pw + bo, 5, H[L - 1]);
+            nh_block_sync(); if (ST) bo ^= R64_EX_F;
             if (st_more) quads_load<4>(H[L - 1], tn + (R64_SQ_H + 4 * (L - 1)) * 256);
             PH(4);
             // steps d_k: layers_xyz[i], i = L-2-k: first dH_i = layers_xyz[i]^T P_{i+1} (P_{i+1} = P[k & 1]), then slots 1..4 P_{i+1},
@@ -591,21 +605,21 @@ NH_KERNEL void NH_LB(64 * NWV, 2) k_bwd64r(Bwd64rArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) P[(k + 1) & 1][r] = i >= 1 ? gate_pos(acc[r >> 2][r & 3], H[i][r]) : acc[r >> 2][r & 3];
                 PH(2);
-                nh_block_sync();
+                if (!ST) nh_block_sync();
                 PH(3);
-                ex_put_blocks<4>(pw, 1, P[k & 1]);
-                ex_put_blocks<4>(pw, 5, H[i]);
-                nh_block_sync();
+                ex_put_blocks<4>(pw + bo, 1, P[k & 1]);
+                ex_put_blocks<4>(pw + bo, 5, H[i]);
+                nh_block_sync(); if (ST) bo ^= R64_EX_F;
                 if (st_more) quads_load<4>(H[i], tn + (R64_SQ_H + 4 * i) * 256);
                 PH(4);
             }
             // step e: layer1: slots 1..4 P_0, 5..8 X
             PH(2);
-            nh_block_sync();
+            if (!ST) nh_block_sync();
             PH(3);
-            ex_put_blocks<4>(pw, 1, P[(L - 1) & 1]);
-            ex_put_blocks<4>(pw, 5, X);
-            nh_block_sync();
+            ex_put_blocks<4>(pw + bo, 1, P[(L - 1) & 1]);
+            ex_put_blocks<4>(pw + bo, 5, X);
+            nh_block_sync(); if (ST) bo ^= R64_EX_F;
             if (st_more) quads_load<4>(X, tn + R64_SQ_X * 256);
             PH(4);
         }

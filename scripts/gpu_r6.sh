@@ -45,11 +45,11 @@ trained_more)   # the two-stream step in the compacted modes; the 4x128 nets tra
   timeout 400 python scripts/bench_trained.py $R/bench_trained_overlap1.json --iters 2000 --overlap 1 --arms fp32_compacted,f16x3_train_compacted,f16x3_train_recomputed,f16x3_train_dense > $R/bench_trained_overlap1.log 2>&1; tail -5 $R/bench_trained_overlap1.log
   timeout 400 python scripts/bench_trained.py $R/bench_trained_4x128.json --iters 2000 --hidden 128 --layers 4 > $R/bench_trained_4x128.log 2>&1; tail -9 $R/bench_trained_4x128.log
   # ... and 4 x 64 students (config/fern.yml's geometry on the teacher scene): dense / compacted / fused / fused over the list
-  timeout 400 python scripts/bench_trained.py $R/bench_trained_4x64.json --iters 2000 --hidden 64 --layers 4 --arms fp32_dense,fp32_compacted,fp32_fused,fp32_fused_compact,fp32_auto,f16x3_train_dense,f16x3_train_recomputed > $R/bench_trained_4x64.log 2>&1; tail -9 $R/bench_trained_4x64.log ;;
+  timeout 400 python scripts/bench_trained.py $R/bench_trained_4x64.json --iters 2000 --hidden 64 --layers 4 --arms fp32_dense,fp32_compacted,fp32_fused,fp32_fused_compact,fp32_fused_stash,fp32_auto,f16x3_train_dense,f16x3_train_recomputed > $R/bench_trained_4x64.log 2>&1; tail -9 $R/bench_trained_4x64.log ;;
 fused)
   timeout 900 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider -k "fused or fern_declared_4x64_full" > $R/pytest_fused.log 2>&1; echo "pytest rc=$?"
   grep -E "passed|failed" $R/pytest_fused.log | tail -2; grep -E "^FAILED|^ERROR|Error|assert" $R/pytest_fused.log | head -20
-  for a in "" "--compact dense" "--compact fused_compact" "--overlap 0" "--compact dense --overlap 0"; do   # ("": fused, the default of these nets)
+  for a in "" "--compact fused" "--compact dense" "--compact fused_compact" "--overlap 0" "--compact fused --overlap 0" "--compact dense --overlap 0"; do   # ("": fused over the stash, the default of these nets; "fused": the recomputing variant)
     t=$(echo $a | tr -d " -"); timeout 150 python bench.py --workload fern --no-cpu-baseline --no-labelled-lines $a > $R/fern_$t.log 2>&1; line $R/fern_$t.log
   done
   cd /tmp

@@ -165,7 +165,7 @@ def run(arm, seed, iters, check, diag_every, student, lr0, poses, imgs, train, v
         mc.set_training_precision("f16x3_train")
         mf.set_training_precision("f16x3_train")
     # (round 6: the compacted backward changes the summation order of every weight gradient -- its own long run)
-    mode = {"compact": True, None: False, False: False}.get(compact, compact)   # ("recompute" / "fused" / "fused_compact": by name)
+    mode = {"compact": True, None: False, False: False}.get(compact, compact)   # ("recompute" / "fused" / "fused_compact" / "fused_stash": by name)
     mc.set_backward_compaction(mode)
     mf.set_backward_compaction(mode)
     eng = N.TrainEngine(mc, mf, NC, NF, perturb=True, white_background=True, noise_std=0.2, lr=lr0, seed=seed)
@@ -213,7 +213,7 @@ if __name__ == "__main__":
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--check", type=int, default=2000)
     ap.add_argument("--diag", type=int, default=1000)
-    ap.add_argument("--compact", nargs="?", const="compact", default=None, choices=("compact", "recompute", "fused", "fused_compact"),
+    ap.add_argument("--compact", nargs="?", const="compact", default=None, choices=("compact", "recompute", "fused", "fused_compact", "fused_stash"),
                     help="both arms with the compacted backward (set_backward_compaction(True)); `recompute`: its stash-recomputing form")
     a = ap.parse_args()
     student = dict(num_layers=a.layers, hidden_size=a.hidden, skip_connect_every=4, num_encoding_fn_xyz=10, num_encoding_fn_dir=4)

@@ -113,6 +113,10 @@ class _FusedRender(torch.autograd.Function):
         # (the ray gradient multiplies by the weights of THIS forward: keep copies only if it will be asked for)
         flats = (model_c._flat.clone(), model_f._flat.clone() if nf > 0 else None) if (training and rays_grad) else None
         ctx.keep = (rays, model_c, model_f, cfg, rand, ws, wsb, packed_c, packed_f, training, flats)
+        # (the backward data flow is an option of the PLAN, and what this forward left in the workspace -- the general stash, nothing, the
+        # register-image stash -- depends on it: the node's backward runs in the mode its forward ran in, whatever
+        # set_backward_compaction was called with in between)
+        ctx.bwd_modes = (lib.plan_bwd_compaction(plan_c), lib.plan_bwd_compaction(plan_f) if plan_f is not None else 0) if training else None
         ctx.mark_non_differentiable(bufs["disp_coarse"], bufs["disp_fine"])
         return tuple(bufs[k] for k in names)
 
@@ -143,15 +147,24 @@ class _FusedRender(torch.autograd.Function):
             if g_rays is not None:
                 tmpb = lib.render_bwd_rays_tmp_bytes(model_c._plan, plan_f, C.byref(cfg), n)
                 tmp = torch.empty(tmpb // 4 + 1, dtype=torch.float32, device=dev)
-            with L.launch_on(rays, ws, gpc, gpf, tmp, *[k for k in keep if k is not None]) as st:
-                lib.render_bwd_rays(model_c._plan, plan_f, C.byref(cfg), rays.data_ptr(), n,
-                                    packed_c.data_ptr(), packed_f.data_ptr() if nf > 0 else None, C.byref(rr), 0, 0,
-                                    C.byref(cot), ws.data_ptr(), wsb, gpc.data_ptr(),
-                                    gpf.data_ptr() if gpf is not None else None, parts | L.PART_SHARED_BWD,
-                                    flats[0].data_ptr() if flats is not None else None,
-                                    flats[1].data_ptr() if (flats is not None and flats[1] is not None) else None,
-                                    tmp.data_ptr() if tmp is not None else None, tmpb,
-                                    g_rays.data_ptr() if g_rays is not None else None, st)
+            now = (lib.plan_bwd_compaction(model_c._plan), lib.plan_bwd_compaction(plan_f) if plan_f is not None else 0)
+            for plan, was, cur in ((model_c._plan, ctx.bwd_modes[0], now[0]), (plan_f, ctx.bwd_modes[1], now[1])):
+                if plan is not None and was != cur:
+                    lib.plan_set_bwd_compaction(plan, was)
+            try:
+                with L.launch_on(rays, ws, gpc, gpf, tmp, *[k for k in keep if k is not None]) as st:
+                    lib.render_bwd_rays(model_c._plan, plan_f, C.byref(cfg), rays.data_ptr(), n,
+                                        packed_c.data_ptr(), packed_f.data_ptr() if nf > 0 else None, C.byref(rr), 0, 0,
+                                        C.byref(cot), ws.data_ptr(), wsb, gpc.data_ptr(),
+                                        gpf.data_ptr() if gpf is not None else None, parts | L.PART_SHARED_BWD,
+                                        flats[0].data_ptr() if flats is not None else None,
+                                        flats[1].data_ptr() if (flats is not None and flats[1] is not None) else None,
+                                        tmp.data_ptr() if tmp is not None else None, tmpb,
+                                        g_rays.data_ptr() if g_rays is not None else None, st)
+            finally:
+                for plan, was, cur in ((model_c._plan, ctx.bwd_modes[0], now[0]), (plan_f, ctx.bwd_modes[1], now[1])):
+                    if plan is not None and was != cur:
+                        lib.plan_set_bwd_compaction(plan, cur)
         grads = model_c._split_flat(gpc) + (model_f._split_flat(gpf) if nf > 0 else ())
         return (g_rays,) + (None,) * 6 + grads
 

@@ -148,6 +148,8 @@ def test_fused_backward_of_64_wide_nets(emu):
     P.case_render_fused_edges(emu, P.MLP_GEOMETRIES["llff4x64_skip3_L6"])
     # ... and d(loss)/d(rays) with the fused modes set: the ray gradient needs the d(pre-activation) images -> mode 2's data flow
     P.case_ray_grad(emu, P.MLP_GEOMETRIES["llff4x64_skip3_L6"], n=12, nc=8, nf=8, compact="fused_compact")
+    # (mode 5: the forward left the register-image stash; the recomputing flow overwrites it with the general one for the list)
+    P.case_ray_grad(emu, P.MLP_GEOMETRIES["llff4x64_skip3_L6"], n=12, nc=8, nf=8, compact="fused_stash")
     for name in ("default4x128", "novw3x64_skip1", "deep8x64_skip4"):   # 128 wide / no view directions / 8 layers with a skip layer
         plan = emu.make_plan(P.MLP_GEOMETRIES[name], 0)
         with pytest.raises(Exception, match="fused backward"):

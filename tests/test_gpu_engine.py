@@ -385,3 +385,39 @@ def test_fused_path_propagates_accumulation_and_depth_losses():
     scale = float(np.abs(grads[1]).max())
     assert scale > 0
     P.close(grads[0], grads[1], 2e-5 * scale, what="acc/depth/disp loss gradient, fused vs generic")
+
+
+def test_autograd_node_runs_its_backward_in_the_mode_of_its_forward():
+    """The backward data flow is an option of the plan, and what a training forward leaves in its workspace depends on it (the general
+    stash, nothing, the register-image stash of 64-wide nets: nerfhip_plan_set_bwd_compaction).  The autograd node of the fused render
+    (run_one_iter_of_nerf -> loss.backward(), the reference's own loop: train_nerf.py:226-259) pins the modes its forward ran in: calling
+    set_backward_compaction between the forward and the backward changes later forwards, not this node's gradient -- bit for bit --
+    and the models keep what was asked for."""
+    import nerf_pytorch_amd as N
+    dev = _dev()
+    cfg = dict(num_layers=4, hidden_size=64, skip_connect_every=3, num_encoding_fn_xyz=6, num_encoding_fn_dir=4)
+    ex, ed = N.get_embedding_function(6, True, True), N.get_embedding_function(4, True, True)
+    opts = N.make_options(24, 24, perturb=False, radiance_field_noise_std=0.0)
+    g = torch.Generator().manual_seed(31)
+    ro = torch.tensor([0.0, 0.0, 4.0]).expand(300, 3).contiguous().to(dev)
+    rd = torch.randn(300, 3, generator=g) * 0.3
+    rd[:, 2] = -1.0
+    rd = rd.to(dev)
+    tgt = torch.rand(300, 3, generator=g).to(dev)
+    for first, then in ((None, False), (None, "fused"), (False, "fused_stash"), ("recompute", False), (True, "recompute")):
+        grads = []
+        for switch in (False, True):
+            mc, mf = _models(dev, cfg=cfg, seeds=(5, 6))
+            if first is not None:
+                mc.set_backward_compaction(first), mf.set_backward_compaction(first)
+            out = N.run_one_iter_of_nerf(300, 1, 30.0, mc, mf, ro, rd, opts, encode_position_fn=ex, encode_direction_fn=ed)
+            loss = ((out[0] - tgt) ** 2).mean() + ((out[3] - tgt) ** 2).mean()
+            if switch:
+                mc.set_backward_compaction(then), mf.set_backward_compaction(then)
+                want = mc.backward_compaction
+            loss.backward()
+            if switch:
+                assert mc.backward_compaction == want and N._lib.get_lib().plan_bwd_compaction(mc._plan) == want
+            grads.append(torch.cat([p.grad.reshape(-1) for p in list(mc.parameters()) + list(mf.parameters())]))
+        assert torch.isfinite(grads[1]).all() and float(grads[0].abs().max()) > 0
+        assert torch.equal(grads[0], grads[1]), (first, then, float((grads[0] - grads[1]).abs().max()))

@@ -210,6 +210,7 @@ def test_fused_backward_of_64_wide_nets(gpu):
     P.case_render_compacted(gpu, P.MLP_GEOMETRIES["three_layer_48"], n=400, nc=16, nf=24, tag="three48_fused", white=True, fused=True)
     P.case_render_fused_edges(gpu, P.MLP_GEOMETRIES["llff4x64_skip3_L6"])
     P.case_ray_grad(gpu, P.MLP_GEOMETRIES["llff4x64_skip3_L6"], n=12, nc=8, nf=8, compact="fused_compact")
+    P.case_ray_grad(gpu, P.MLP_GEOMETRIES["llff4x64_skip3_L6"], n=333, nc=24, nf=16, compact="fused_stash")
 
 
 @pytest.mark.parametrize("arith", ["fp32", "f16x3_train"])

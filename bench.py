@@ -821,9 +821,14 @@ def main():
                                 ("f16x3_train_compact", ["--precision", "f16x3_train", "--compact"]),
                                 ("fern_fp32", ["--workload", "fern"]),   # (4 x 64 fp32 nets: the fused one-kernel backward over the register-image stash is their default)
                                 ("fern_fp32_recompute", ["--workload", "fern", "--compact", "fused"]),   # (... the same kernel recomputing its forward: no stash at all)
+                                # (nets of hidden_size <= 128 run the two-stream step by default: the coarse backward shares the GPU with the fine pass,
+                                # and a kernel's event-to-event time -- hence its fraction of a roofline -- is then that of HALF a GPU at times.  The
+                                # same lines on ONE stream: what the kernels do when they have the chip to themselves)
+                                ("fern_fp32_one_stream", ["--workload", "fern", "--overlap", "0"]),
                                 ("fern_fp32_dense", ["--workload", "fern", "--compact", "dense"]),
                                 ("fern_f16x3_train", ["--workload", "fern", "--precision", "f16x3_train"]),
                                 ("4x128_fp32", ["--hidden", "128", "--layers", "4"]),
+                                ("4x128_fp32_one_stream", ["--hidden", "128", "--layers", "4", "--overlap", "0"]),
                                 ("4x128_f16x3_train", ["--hidden", "128", "--layers", "4", "--precision", "f16x3_train"]),
                                 ("eval_fp32", ["--mode", "eval", "--steps", "1", "--warmup", "1"]),
                                 ("eval_f16x3", ["--mode", "eval", "--precision", "f16x3", "--steps", "1", "--warmup", "1"]))
@@ -839,6 +844,7 @@ def main():
                                                              hbm_tb_s=v["hbm_tb_s"], hbm_frac=v["hbm_frac"])
                                                      for k, v in j["roofline"]["mlp_kernels"].items()},
                                         dominant_kernel=dict(kernel=j["roofline"]["kernel"], bound=j["roofline"]["bound"], frac=j["roofline"]["frac"]),
+                                        two_stream_step=j["config"].get("two_stream_step"),
                                         command="python bench.py " + " ".join(extra))
                             if j.get("unprofiled_rerun"):   # (the same steps without the per-launch HIP events: what a 2-ms step pays for them)
                                 line["ms_per_step_without_launch_events"] = j["unprofiled_rerun"]["ms_per_step"]

@@ -323,7 +323,9 @@ def pmc_traffic(cfg, n, kind):
     the fingerprint of the kernel sources this library was built from (`lib_sources_sha16`): a stale file is refused and the
     line says so."""
     tag = "%dx%d_%d" % (cfg["num_layers"], cfg["hidden_size"], n)
-    kname = "k_wgrad" if kind == "wgrad" else "k_mlp_%s16" % kind
+    # (r64: the 64-wide nets' stashed fused backward, csrc/mlp64r.hip mode 5 -- k_fwd64r writes the register-image stash, k_bwd64r reads it)
+    r64 = kind in ("fwd64r", "bwd64r")
+    kname = "k_wgrad" if kind == "wgrad" else ("k_" + kind if r64 else "k_mlp_%s16" % kind)
     mine = lib_sources_sha16()
     stale = None
     for rnd in ("r06", "r05", "r04", "r03", "r02"):
@@ -341,9 +343,10 @@ def pmc_traffic(cfg, n, kind):
                 continue
             # like with like: the algorithmic figure of k_wgrad is its operand READ stream, that of the forward / data-gradient
             # kernels their stash / d(pre-activation) WRITE stream (weights and masks are the small remainder)
-            per = [r["fetch_gb_x2"] if kind == "wgrad" else r["write_gb"] for r in rows]
+            reads = kind in ("wgrad", "bwd64r")
+            per = [r["fetch_gb_x2"] if reads else r["write_gb"] for r in rows]
             return round(sum(per) / len(per), 3), "profiles/%s (rocprofv3 --pmc passes of this command on kernel sources %s: %s, mean over " \
-                "the launch sizes recorded)" % (fn, mine, "FETCH_SIZE x2" if kind == "wgrad" else "WRITE_SIZE")
+                "the launch sizes recorded)" % (fn, mine, "FETCH_SIZE x2" if reads else "WRITE_SIZE")
     return None, stale
 
 
@@ -683,6 +686,8 @@ def main():
                 ghz = 0.1 * cyc / ticks if ticks else None
             counter_gb, source = (pmc_traffic(cfg, n, kind) if (args.mode == "train" and args.precision == "fp32" and args.workload == "lego"
                                                                and kind in ("fwd", "dgrad", "wgrad")) else (None, None))
+            if args.mode == "train" and args.workload == "fern" and eff_compact == "fused_stash" and kind in ("fwd", "bwd64r"):
+                counter_gb, source = pmc_traffic(cfg, n, "fwd64r" if kind == "fwd" else kind)
             # a kernel is priced against ITS OWN matrix pipe: fp32 MFMA, or the 16-bit MFMA at three instructions per product block
             peak = FP32_MFMA_PEAK_TFLOPS if fam == "fp32" else F16X3_PEAK_TFLOPS
             key = kind if kinds_seen.count(kind) == 1 else "%s[%s]" % (kind, fam)
@@ -843,7 +848,8 @@ def main():
                                         mlp_kernels={k: dict(kernel=v["kernel"], ms_per_step=v["ms_per_step"], frac_of_own_mfma_roofline=v["frac"],
                                                              hbm_tb_s=v["hbm_tb_s"], hbm_frac=v["hbm_frac"])
                                                      for k, v in j["roofline"]["mlp_kernels"].items()},
-                                        dominant_kernel=dict(kernel=j["roofline"]["kernel"], bound=j["roofline"]["bound"], frac=j["roofline"]["frac"]),
+                                        dominant_kernel=dict(kernel=j["roofline"]["kernel"], bound=j["roofline"]["bound"], frac=j["roofline"]["frac"],
+                                                             traffic=j["roofline"].get("traffic")),
                                         two_stream_step=j["config"].get("two_stream_step"),
                                         command="python bench.py " + " ".join(extra))
                             if j.get("unprofiled_rerun"):   # (the same steps without the per-launch HIP events: what a 2-ms step pays for them)

@@ -30,6 +30,16 @@ PY
 need_weights() {
   [ -f $W ] || timeout 400 python scripts/bench_trained.py $R/bench_trained.json --iters 2000 --save-weights $W > $R/bench_trained.log 2>&1
 }
+P=/tmp/pmc6
+run_pmc() {  # name, command...
+  n=$1; shift
+  mkdir -p $P/$n
+  timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $P/$n/sq -- "$@" > $P/$n/sq.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/$n/fetch -- "$@" > $P/$n/fetch.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/$n/write -- "$@" > $P/$n/write.log 2>&1
+  python $GRAFT_REPO_ROOT/scripts/pmc_summary.py $P/$n $R/pmc_summary_$n.json > $R/pmc_summary_$n.txt 2>&1
+  echo "== pmc $n"; cat $R/pmc_summary_$n.txt | cut -c1-220
+}
 for part in "$@"; do
 case $part in
 tests)
@@ -104,20 +114,17 @@ pmc)
   need_weights
   cd /tmp
   P=/tmp/pmc6 && rm -rf $P && mkdir -p $P
-  run_pmc() {  # name, command...
-    n=$1; shift
-    mkdir -p $P/$n
-    timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $P/$n/sq -- "$@" > $P/$n/sq.log 2>&1
-    timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/$n/fetch -- "$@" > $P/$n/fetch.log 2>&1
-    timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/$n/write -- "$@" > $P/$n/write.log 2>&1
-    python $GRAFT_REPO_ROOT/scripts/pmc_summary.py $P/$n $R/pmc_summary_$n.json > $R/pmc_summary_$n.txt 2>&1
-    echo "== pmc $n"; cat $R/pmc_summary_$n.txt | cut -c1-220
-  }
   run_pmc 8x256_4096 python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-labelled-lines --overlap 0
+  # BASELINE configs[3] (fern, 4 x 64 nets on the stashed fused backward): k_fwd64r writes the register-image stash, k_bwd64r reads it
+  run_pmc 4x64_4096 python $GRAFT_REPO_ROOT/bench.py --workload fern --steps 3 --warmup 1 --no-cpu-baseline --no-labelled-lines --overlap 0
   for arm in f16x3_train_dense f16x3_train_compacted fp32_dense fp32_compacted; do
     run_pmc trained_$arm python $GRAFT_REPO_ROOT/scripts/bench_trained.py /tmp/pmc6/$arm.json --load-weights $W --arms $arm --steps 2 --warmup 1
   done
   cp $R/pmc_summary_8x256_4096.json $R/pmc_summary.json; cd $GRAFT_REPO_ROOT ;;
+pmc_fern)   # only the fern passes of `pmc`
+  cd /tmp; rm -rf $P/4x64_4096; mkdir -p $P
+  run_pmc 4x64_4096 python $GRAFT_REPO_ROOT/bench.py --workload fern --steps 3 --warmup 1 --no-cpu-baseline --no-labelled-lines --overlap 0
+  cd $GRAFT_REPO_ROOT ;;
 *) echo "unknown part $part" ;;
 esac
 done

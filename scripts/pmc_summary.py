@@ -16,7 +16,7 @@ def load(pattern):
 
 def short(name):
     for k in ("k_mlp_fwd16", "k_mlp_dgrad16", "k_mlp_fwd_f16x3", "k_mlp_dgrad_f16x3", "k_mlp_fwd", "k_mlp_dgrad",
-              "k_wgrad_reduce", "k_wgrad_f16x3", "k_wgrad"):
+              "k_wgrad_reduce", "k_wgrad_f16x3", "k_wgrad", "k_bwd64r_reduce", "k_bwd64r", "k_fwd64r"):
         if k in name:
             return k
     return None

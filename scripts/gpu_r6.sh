@@ -117,6 +117,7 @@ pmc)
   run_pmc 8x256_4096 python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-labelled-lines --overlap 0
   # BASELINE configs[3] (fern, 4 x 64 nets on the stashed fused backward): k_fwd64r writes the register-image stash, k_bwd64r reads it
   run_pmc 4x64_4096 python $GRAFT_REPO_ROOT/bench.py --workload fern --steps 3 --warmup 1 --no-cpu-baseline --no-labelled-lines --overlap 0
+  run_pmc 4x128_4096 python $GRAFT_REPO_ROOT/bench.py --hidden 128 --layers 4 --steps 3 --warmup 1 --no-cpu-baseline --no-labelled-lines --overlap 0
   for arm in f16x3_train_dense f16x3_train_compacted fp32_dense fp32_compacted; do
     run_pmc trained_$arm python $GRAFT_REPO_ROOT/scripts/bench_trained.py /tmp/pmc6/$arm.json --load-weights $W --arms $arm --steps 2 --warmup 1
   done
@@ -124,6 +125,10 @@ pmc)
 pmc_fern)   # only the fern passes of `pmc`
   cd /tmp; rm -rf $P/4x64_4096; mkdir -p $P
   run_pmc 4x64_4096 python $GRAFT_REPO_ROOT/bench.py --workload fern --steps 3 --warmup 1 --no-cpu-baseline --no-labelled-lines --overlap 0
+  cd $GRAFT_REPO_ROOT ;;
+pmc_4x128)  # the 4 x 128 nets train_nerf.py:117-134 builds (the labelled lines 4x128_fp32*)
+  cd /tmp; rm -rf $P/4x128_4096; mkdir -p $P
+  run_pmc 4x128_4096 python $GRAFT_REPO_ROOT/bench.py --hidden 128 --layers 4 --steps 3 --warmup 1 --no-cpu-baseline --no-labelled-lines --overlap 0
   cd $GRAFT_REPO_ROOT ;;
 *) echo "unknown part $part" ;;
 esac

@@ -213,11 +213,52 @@ class FlexibleNeRFModel(torch.nn.Module):
         gradients (csrc/mlp64r.hip) -- over every sample, or over the samples with a non-zero d(loss)/d(raw) row.
         on = "fused_stash" (5; same nets): the training forward leaves the chain's registers (encodings, every layer's activations)
         in a register-image stash -- whole-KiB stores, 1.8 KB per sample point -- and the same kernel reads them back instead of
-        recomputing the forward: bit-identical gradient, a third fewer MFMAs in the backward, 2 x 1.8 KB of HBM traffic per sample."""
+        recomputing the forward: bit-identical gradient, a third fewer MFMAs in the backward, 2 x 1.8 KB of HBM traffic per sample.
+        on = "auto": inside the fused render of the reference's own loop (run_one_iter_of_nerf -> loss.backward(), train_nerf.py:226-259)
+        the mode of every training forward is chosen from the zero-row fraction this model's last compacted backward reported -- what
+        TrainEngine(backward="auto") does for the engine's step: dense (64-wide nets: fused over the stash) while too little is dropped
+        to pay for the list, compacted / recomputed / fused over the list from there on; a dense net is probed with one compacted
+        pass every 50 forwards.  The two statistics words come back by an asynchronous copy that is polled, never waited for."""
         self._backward_choice = on
-        self.backward_compaction = {"recompute": 2, "fused": 3, "fused_compact": 4, "fused_stash": 5}.get(on, int(bool(on)))
+        if on == "auto":
+            self._auto_frac, self._auto_calls, self._auto_event, self._auto_host = None, 0, None, None
+            self.backward_compaction = self.fused_backward_available() or 0
+        else:
+            self.backward_compaction = {"recompute": 2, "fused": 3, "fused_compact": 4, "fused_stash": 5}.get(on, int(bool(on)))
         L.get_lib().plan_set_bwd_compaction(self._plan, self.backward_compaction)
         return self
+
+    def _auto_choose_backward(self):
+        """set_backward_compaction("auto"): sets the plan's mode for the training forward about to run (train_utils._FusedRender)."""
+        if getattr(self, "_backward_choice", None) != "auto":
+            return
+        from .engine import TrainEngine
+        if self._auto_event is not None and self._auto_event.query():
+            kept, total = self._auto_host.tolist()
+            if total > 0:
+                self._auto_frac = 1.0 - kept / float(total)
+            self._auto_event = None
+        mode = TrainEngine._mode_for(self._auto_frac, self.training_precision != "fp32", self.fused_backward_available())
+        probe = self._auto_calls % 50 == 0
+        self._auto_calls += 1
+        if probe and mode == 0:
+            mode = 1
+        if probe and mode in (3, 5):
+            mode = 4
+        if mode != self.backward_compaction:
+            self.backward_compaction = mode
+            L.get_lib().plan_set_bwd_compaction(self._plan, mode)
+
+    def _auto_note_stats(self, words):
+        """... and, behind a backward that ran over the list, asks for its {kept, total} (words: two int32 on the device; the copy is
+        ordered behind the backward on the current stream and lands in pinned memory)."""
+        if getattr(self, "_backward_choice", None) != "auto" or self._auto_event is not None:
+            return
+        if self._auto_host is None:
+            self._auto_host = torch.zeros(2, dtype=torch.int32).pin_memory()
+        self._auto_host.copy_(words, non_blocking=True)
+        self._auto_event = torch.cuda.Event()
+        self._auto_event.record(torch.cuda.current_stream(words.device))
 
     def fused_backward_available(self):
         """Truthy where set_backward_compaction("fused") works -- the plan has an LDS-resident image (csrc/nh_r64.h nh_r64_eligible):
@@ -281,6 +322,9 @@ class FlexibleNeRFModel(torch.nn.Module):
         state = self.__dict__.copy()
         for k in ("_plan_owner", "_flat", "_flat_grad", "_pack_table", "_packed_buf", "_inf_owner", "_inf_table", "_inf_packed"):
             state[k] = None
+        for k in ("_auto_event", "_auto_host"):   # (set_backward_compaction("auto"): the copy in flight stays behind)
+            if k in state:
+                state[k] = None
         return state
 
     def __setstate__(self, state):

@@ -89,6 +89,10 @@ class _FusedRender(torch.autograd.Function):
         # torch.no_grad()): keep the activation stash for a backward
         # (inference -- no backward follows -- runs on each model's inference plan: fp32 unless set_inference_precision
         # chose the fp16-piece kernels)
+        if training:  # (models with set_backward_compaction("auto") pick the mode of this pass from their last compacted backward)
+            model_c._auto_choose_backward()
+            if nf > 0:
+                model_f._auto_choose_backward()
         plan_c = model_c._plan if training else model_c._inference_plan()
         plan_f = (model_f._plan if training else model_f._inference_plan()) if nf > 0 else None
         # (training layout 2: this node's backward runs the two nets one after the other on one stream, so they share one
@@ -151,16 +155,36 @@ class _FusedRender(torch.autograd.Function):
             for plan, was, cur in ((model_c._plan, ctx.bwd_modes[0], now[0]), (plan_f, ctx.bwd_modes[1], now[1])):
                 if plan is not None and was != cur:
                     lib.plan_set_bwd_compaction(plan, was)
+            # "auto" models read the {kept, total} words of their compacted backward; the two nets share one set of backward buffers
+            # here (the fine pass runs first), so the passes are issued one by one with the copy in between -- the same launches in
+            # the same order as the single call (not with a ray gradient: its second pass accumulates into the first one's)
+            auto = [m for m in (model_c, model_f) if m is not None and getattr(m, "_backward_choice", None) == "auto"]
+            passes = [parts]
+            if auto and g_rays is None and parts == (L.PART_COARSE | L.PART_FINE):
+                passes = [L.PART_FINE, L.PART_COARSE]
+
+            def note(model, name, samples):
+                if model in auto and lib.plan_bwd_compaction(model._plan) in (1, 2, 4):
+                    off, nb = C.c_int64(), C.c_int64()
+                    lib.render_workspace_region(model_c._plan, plan_f, C.byref(cfg), n, 2, name, C.byref(off), C.byref(nb))
+                    so = (off.value + lib.plan_bwd_stats_offset(model._plan, n * samples)) // 4
+                    model._auto_note_stats(ws.view(torch.int32)[so:so + 2])
+
             try:
                 with L.launch_on(rays, ws, gpc, gpf, tmp, *[k for k in keep if k is not None]) as st:
-                    lib.render_bwd_rays(model_c._plan, plan_f, C.byref(cfg), rays.data_ptr(), n,
-                                        packed_c.data_ptr(), packed_f.data_ptr() if nf > 0 else None, C.byref(rr), 0, 0,
-                                        C.byref(cot), ws.data_ptr(), wsb, gpc.data_ptr(),
-                                        gpf.data_ptr() if gpf is not None else None, parts | L.PART_SHARED_BWD,
-                                        flats[0].data_ptr() if flats is not None else None,
-                                        flats[1].data_ptr() if (flats is not None and flats[1] is not None) else None,
-                                        tmp.data_ptr() if tmp is not None else None, tmpb,
-                                        g_rays.data_ptr() if g_rays is not None else None, st)
+                    for part in passes:
+                        lib.render_bwd_rays(model_c._plan, plan_f, C.byref(cfg), rays.data_ptr(), n,
+                                            packed_c.data_ptr(), packed_f.data_ptr() if nf > 0 else None, C.byref(rr), 0, 0,
+                                            C.byref(cot), ws.data_ptr(), wsb, gpc.data_ptr(),
+                                            gpf.data_ptr() if gpf is not None else None, part | L.PART_SHARED_BWD,
+                                            flats[0].data_ptr() if flats is not None else None,
+                                            flats[1].data_ptr() if (flats is not None and flats[1] is not None) else None,
+                                            tmp.data_ptr() if tmp is not None else None, tmpb,
+                                            g_rays.data_ptr() if g_rays is not None else None, st)
+                        if part & L.PART_FINE and len(passes) == 2:
+                            note(model_f, b"bwd_scratch_fine", cfg.num_coarse + nf)
+                    if parts & L.PART_COARSE:   # (the coarse pass ran last: its words are the ones in the shared buffers)
+                        note(model_c, b"bwd_scratch_coarse", cfg.num_coarse)
             finally:
                 for plan, was, cur in ((model_c._plan, ctx.bwd_modes[0], now[0]), (plan_f, ctx.bwd_modes[1], now[1])):
                     if plan is not None and was != cur:

@@ -421,3 +421,58 @@ def test_autograd_node_runs_its_backward_in_the_mode_of_its_forward():
             grads.append(torch.cat([p.grad.reshape(-1) for p in list(mc.parameters()) + list(mf.parameters())]))
         assert torch.isfinite(grads[1]).all() and float(grads[0].abs().max()) > 0
         assert torch.equal(grads[0], grads[1]), (first, then, float((grads[0] - grads[1]).abs().max()))
+
+
+@pytest.mark.parametrize("hidden", [64, 128])
+def test_models_in_auto_mode_pick_their_backward_through_the_reference_loop(hidden):
+    """set_backward_compaction("auto") on the models (no TrainEngine): the reference's own loop -- run_one_iter_of_nerf, loss.backward(),
+    torch.optim.Adam (train_nerf.py:226-261) -- on a scene that empties out: the autograd node's backward reports {kept, total} per net
+    (the two nets share one set of backward buffers there: the passes are issued one by one with the copy in between), the models
+    move from their dense mode (0; 64-wide nets: fused over the stash, 5) to the list (1 / 4) once it is known to drop enough rows, and
+    the gradient of the mode they end in equals the dense one on the same weights and rays."""
+    import copy
+    import nerf_pytorch_amd as N
+    dev = _dev()
+    cfg = dict(num_layers=4, hidden_size=hidden, skip_connect_every=3 if hidden == 64 else 4, num_encoding_fn_xyz=6, num_encoding_fn_dir=4)
+    ex, ed = N.get_embedding_function(6, True, True), N.get_embedding_function(4, True, True)
+    opts = N.make_options(32, 32, perturb=False, radiance_field_noise_std=0.0, white_background=True)
+    g = torch.Generator().manual_seed(7)
+    n = 512
+    ro = torch.tensor([0.0, 0.0, 4.0]).expand(n, 3).contiguous().to(dev)
+    rd = torch.randn(n, 3, generator=g) * 0.3
+    rd[:, 2] = -1.0
+    rd = rd.to(dev)
+    white = torch.ones(n, 3, device=dev)
+    mc, mf = _models(dev, cfg=cfg, seeds=(5, 6))
+    dense_mode = 5 if hidden == 64 else 0
+    assert mc.backward_compaction == dense_mode
+    mc.set_backward_compaction("auto"), mf.set_backward_compaction("auto")
+    assert mc.backward_compaction == dense_mode and mf.backward_compaction == dense_mode
+    opt = torch.optim.Adam(list(mc.parameters()) + list(mf.parameters()), lr=1e-3)
+    seen = set()
+    for it in range(150):
+        out = N.run_one_iter_of_nerf(n, 1, 30.0, mc, mf, ro, rd, opts, encode_position_fn=ex, encode_direction_fn=ed)
+        seen.add((mc.backward_compaction, mf.backward_compaction))
+        loss = ((out[0] - white) ** 2).mean() + ((out[3] - white) ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        if it % 10 == 9:
+            torch.cuda.synchronize()   # (lets the asynchronous statistics land: a real loop's logging does the same)
+    assert torch.isfinite(loss).all() and float(loss.detach()) < 0.05, float(loss.detach())
+    list_mode = 4 if hidden == 64 else 1
+    assert mc._auto_frac is not None and mf._auto_frac is not None and mf._auto_frac > 0.5, (mc._auto_frac, mf._auto_frac)
+    assert any(m[1] == list_mode for m in seen) and mf.backward_compaction == list_mode, (seen, mf.backward_compaction)
+    # the gradient in the mode the loop ended in, against the dense backward of the same weights
+    grads = []
+    for dense in (False, True):
+        a, b = copy.deepcopy(mc), copy.deepcopy(mf)
+        if dense:
+            a.set_backward_compaction(False), b.set_backward_compaction(False)
+        else:
+            a.set_backward_compaction({1: True, 4: "fused_compact"}.get(mc.backward_compaction, False))
+            b.set_backward_compaction({1: True, 4: "fused_compact"}[mf.backward_compaction])
+        out = N.run_one_iter_of_nerf(n, 1, 30.0, a, b, ro, rd, opts, encode_position_fn=ex, encode_direction_fn=ed)
+        (((out[0] - 0.5) ** 2).mean() + ((out[3] - 0.5) ** 2).mean()).backward()
+        grads.append(torch.cat([p.grad.reshape(-1) for p in list(a.parameters()) + list(b.parameters())]))
+    assert float((grads[0] - grads[1]).abs().max()) <= 1e-5 * float(grads[1].abs().max()) + 1e-12

@@ -878,7 +878,9 @@ def main():
                             tr[arm] = dict(value=v["rays_per_s"], unit="rays/s", ms_per_step=v["ms_per_step"],
                                            zero_cotangent_fraction=v["zero_cotangent_fraction_last_step"],
                                            speedup_vs_pytorch_rocm_fwd_bwd=round(v["rays_per_s"] / ref, 3) if ref else None,
-                                           grad_vs_dense_of_max=v.get("grad_vs_dense_of_max"), kernel_ms_per_step=v["kernel_ms_per_step"])
+                                           grad_vs_dense_of_max=v.get("grad_vs_dense_of_max"), kernel_ms_per_step=v.get("kernel_ms_per_step"))
+                            if arm.startswith("dropin_"):   # (the reference's own loop on the drop-in API: scripts/bench_trained.py part 3)
+                                tr[arm].update(what=v.get("what"), backward_modes_at_the_end=v.get("backward_modes_at_the_end"))
                         res["labelled_lines"]["trained_regime"] = tr
                     except Exception as e:
                         res["labelled_lines"]["trained_regime"] = dict(error=repr(e)[:200])

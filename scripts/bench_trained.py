@@ -11,7 +11,9 @@ recorded 75-87 % on this scene).  This script
      ships (f16x3_train plans, compacted backward: the fastest arm; the weights it leaves are what every arm below starts from),
   2. then times, for each arm in {fp32, f16x3_train} x {dense, compacted, recomputed (stash-free forward + forward again for the kept samples)}: --steps full training iterations (ray selection from a
      resident view, forward, loss, backward, Adam, re-pack) after --warmup, HIP-event bracketed per kernel, on the same data stream,
-  3. and records per arm: rays/s, ms/step, the zero-cotangent fraction of the last timed step per net (compacted arms: read from the
+  3. (and the same regime through the reference's own loop on the drop-in API -- run_one_iter_of_nerf, loss.backward(), torch.optim.Adam --
+     dense and with set_backward_compaction("auto") on the models: the arms dropin_*),
+  4. and records per arm: rays/s, ms/step, the zero-cotangent fraction of the last timed step per net (compacted arms: read from the
      library; dense arms: the same step's d(raw) rows counted with torch), per-kernel ms/step, and -- compacted vs dense, same weights,
      same rays, same draws -- the largest gradient difference of max|g| per net.
 
@@ -174,5 +176,47 @@ if __name__ == "__main__":
             res["arms"][prec + kind]["grad_vs_dense_of_max"] = dict(
                 coarse=float((c[:n0] - d[:n0]).abs().max() / d[:n0].abs().max()), fine=float((c[n0:] - d[n0:]).abs().max() / d[n0:].abs().max()))
             res["arms"][prec + kind]["speedup_vs_dense"] = round(res["arms"][prec + "_dense"]["ms_per_step"] / res["arms"][prec + kind]["ms_per_step"], 3)
+    # 3. the same regime through the REFERENCE'S OWN LOOP on the drop-in API (import swap; no TrainEngine):
+    # run_one_iter_of_nerf, img2mse, loss.backward(), torch.optim.Adam.step() (train_nerf.py:226-261) -- dense, and with
+    # set_backward_compaction("auto") on the two models (the policy of the engine's backward="auto", per net and forward pass)
+    ex = N.get_embedding_function(STUDENT["num_encoding_fn_xyz"], True, True)
+    ed = N.get_embedding_function(STUDENT["num_encoding_fn_dir"], True, True)
+    for prec in ("fp32", "f16x3_train"):
+        for mode in ("dense", "auto"):
+            arm = "dropin_%s_%s" % (prec, mode)
+            if a.arms and arm not in a.arms.split(","):
+                continue
+            mc, mf, _eng = make_engine(state_c, state_f, prec, False, a.lr, a.seed + 7)
+            del _eng
+            if mode == "auto":
+                mc.set_backward_compaction("auto"), mf.set_backward_compaction("auto")
+            optim = torch.optim.Adam(list(mc.parameters()) + list(mf.parameters()), lr=lr)
+            stream = data_stream(poses, imgs, train, 4242)
+            warm = 60 if mode == "auto" else a.warmup    # (the first statistics must have come back, and the probe cadence settled)
+            batches = [next(stream) for _ in range(a.steps)]
+
+            def loop_step(ro, rd, tgt):
+                out = N.run_one_iter_of_nerf(400, 400, 1.0, mc, mf, ro, rd, opts, mode="train", encode_position_fn=ex, encode_direction_fn=ed)
+                loss = N.img2mse(out[0], tgt[..., :3]) + N.img2mse(out[3], tgt[..., :3])
+                loss.backward()
+                optim.step()
+                optim.zero_grad()
+
+            for _ in range(warm):
+                loop_step(*next(stream))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for ro, rd, tgt in batches:
+                loop_step(ro, rd, tgt)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / a.steps
+            res["arms"][arm] = dict(rays_per_s=round(RAYS / ms, 1), ms_per_step=round(ms * 1e3, 3),
+                                    zero_cotangent_fraction_last_step=dict(coarse=getattr(mc, "_auto_frac", None), fine=getattr(mf, "_auto_frac", None)),
+                                    backward_modes_at_the_end=[mc.backward_compaction, mf.backward_compaction],
+                                    what="run_one_iter_of_nerf + img2mse + loss.backward() + torch.optim.Adam.step(): the reference's loop body on the drop-in API")
+            print(arm, res["arms"][arm]["rays_per_s"], res["arms"][arm]["ms_per_step"], res["arms"][arm]["backward_modes_at_the_end"], flush=True)
+            del mc, mf, optim
+            torch.cuda.empty_cache()
+            json.dump(res, open(a.out, "w"), indent=1)
     json.dump(res, open(a.out, "w"), indent=1)
     print(json.dumps({k: (v["rays_per_s"], v["ms_per_step"], v["zero_cotangent_fraction_last_step"]) for k, v in res["arms"].items()}))

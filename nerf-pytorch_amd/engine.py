@@ -63,8 +63,12 @@ class TrainEngine:
         self._loss_c = torch.zeros(3, dtype=torch.float32, device=self.dev)
         self._loss_f = torch.zeros(3, dtype=torch.float32, device=self.dev)
         # two-stream graph: measured on MI355X (profiles/r02_overlap_ab.txt) +3.5 % for 128-wide nets (the short kernels'
-        # tails fill), -0.4 % for 256-wide nets (every launch already fills the chip for milliseconds) -> default by width
-        self.overlap = (model_coarse.cfg["hidden_size"] <= 128) if overlap is None else bool(overlap)  # (128-wide kernels)
+        # tails fill), -0.4 % for 256-wide fp32 nets (every launch already fills the chip for milliseconds); the fp16-piece
+        # plans at 256 wide (HBM- and latency-bound kernels that leave the matrix pipe idle half the time: room for a second
+        # stream): +1.4 % dense, +6 % compacted, +7 % recomputed (profiles/r06_bench_trained_overlap1.json against
+        # r06_bench_trained.json of round 6's first passes) -> default by width and arithmetic
+        self.overlap = ((model_coarse.cfg["hidden_size"] <= 128 or getattr(model_coarse, "training_precision", "fp32") != "fp32")
+                        if overlap is None else bool(overlap))
         self._side = None       # second HIP stream of this device (created on first use)
         self._ev = None
         self._pending = []      # in-flight gradient all-reduces of the current step

@@ -71,15 +71,21 @@ def test_engine_validates_rays_and_target():
     assert float(eng.loss[2]) > 0 and abs(float(eng.loss[0] + eng.loss[1]) - float(eng.loss[2])) < 1e-7
 
 
-def test_two_stream_step_equals_single_stream_step():
+@pytest.mark.parametrize("precision,mode", [("fp32", None), ("f16x3_train", None), ("f16x3_train", "recompute"), ("fp32", "compact")])
+def test_two_stream_step_equals_single_stream_step(precision, mode):
     """The overlapped graph (coarse backward on a side stream next to the fine pass) runs the same kernels on the same
-    data: parameters after several steps are bit-identical to the single-stream order."""
+    data: parameters after several steps are bit-identical to the single-stream order -- on the fp32 plans (two-stream by default up
+    to 128 wide) and on the fp16-piece plans (two-stream by default at every width), dense and with the compacted / recomputing backward."""
     import nerf_pytorch_amd as N
     dev = _dev()
     out = []
-    for overlap in (True, False):
-        mc, mf = _models(dev)
-        eng = N.TrainEngine(mc, mf, 32, 32, noise_std=0.2, seed=11, world_size=1, rank=0, overlap=overlap)
+    wide = dict(CFG, hidden_size=256)   # (the default depends on the arithmetic only above 128 wide)
+    for overlap in (True, False, None):
+        mc, mf = _models(dev, cfg=wide)
+        if precision != "fp32":
+            mc.set_training_precision(precision), mf.set_training_precision(precision)
+        eng = N.TrainEngine(mc, mf, 32, 32, noise_std=0.2, seed=11, world_size=1, rank=0, overlap=overlap, backward=mode)
+        assert eng.overlap == (overlap if overlap is not None else precision != "fp32")   # (the 8 x 256 default: by arithmetic)
         rays, rgba = _rays(640, dev)
         losses = [eng.step(rays, rgba[:, :3], ray_offset=0).clone() for _ in range(4)]
         torch.cuda.synchronize()
